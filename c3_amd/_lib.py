@@ -1,0 +1,93 @@
+"""ctypes binding of libc3prop.so (the C ABI declared in include/c3prop.h).
+
+The library is the product: there is no CPU fallback.  If the shared object is
+missing or a call is made without a visible GPU, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libc3prop.so")
+
+# flags (mirror include/c3prop.h)
+HOST_PTRS = 0x1
+PER_SLICE_H = 0x2
+ORDER_RIGHT = 0x4
+FORCE_GENERIC = 0x8
+
+KERNEL_NAMES = {0: "none", 1: "generic_lds", 2: "generic_global", 3: "smalld", 4: "mfma"}
+
+SOLVERS = {"rk4": 0, "rk38": 1, "rk5": 2, "tsit5": 3}
+STEPS = {"schrodinger": 0, "von_neumann": 1, "lindblad": 2}
+
+_vp = C.c_void_p
+_i = C.c_int
+_i64 = C.c_int64
+_d = C.c_double
+
+# name -> (restype, argtypes); every symbol include/c3prop.h declares
+SIGNATURES = {
+    "c3p_version": (_i, []),
+    "c3p_device_count": (_i, []),
+    "c3p_last_error": (C.c_char_p, []),
+    "c3p_last_kernel": (_i, []),
+    "c3p_set_profiling": (_i, [_i]),
+    "c3p_last_kernel_ms": (_d, []),
+    "c3p_shutdown": (None, []),
+    "c3p_pwc_unitary": (_i, [_vp, _i64, _vp, _i64, _vp, _d, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "c3p_pwc_lindblad": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _d, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "c3p_expm": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "c3p_matmul_chain": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "c3p_superop": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "c3p_kron": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "c3p_ode_solve": (_i, [_vp, _vp, _vp, _vp, _i, _d, _i, _i, _i, _i, _i, _i, _vp, _i64, _i, _i, _vp, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class C3PropError(Exception):
+    """Raised with the reference's `C3:Error` prefix (c3/experiment.py:465-468)."""
+
+
+def load() -> C.CDLL:
+    """Load libc3prop.so and bind every declared symbol.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise C3PropError(
+            f"C3:Error: {LIB_PATH} is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the propagator path."
+        )
+    # PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Import torch
+    # first so that the process holds ONE HIP runtime and torch device pointers / streams
+    # are valid inside libc3prop.so.
+    import torch  # noqa: F401
+
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().c3p_last_error().decode("utf-8", "replace")
+        raise C3PropError(f"C3:Error: {msg}")
+
+
+def require_gpu() -> None:
+    lib = load()
+    if lib.c3p_device_count() <= 0:
+        raise C3PropError("C3:Error: no HIP device visible; the propagator path has no CPU fallback.")
+
+
+def last_kernel() -> str:
+    return KERNEL_NAMES.get(load().c3p_last_kernel(), "?")

@@ -1,0 +1,640 @@
+// C ABI of libc3prop.so (see include/c3prop.h for the contract and the reference
+// functions each entry point stands in for).
+#include <mutex>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+
+#include "../../include/c3prop.h"
+#include "c3p_kernels.h"
+#include "c3p_ode.h"
+#include "c3p_smalld.h"
+
+namespace {
+
+thread_local std::string g_err;
+thread_local int g_last_kernel = C3P_KERNEL_NONE;
+int g_profiling = 0;
+
+int fail(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return -1;
+}
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t e__ = (expr);                                                           \
+    if (e__ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e__)); \
+  } while (0)
+
+// Per-device workspace slots, grown lazily, freed by c3p_shutdown().
+enum Slot { SL_SEG_A = 0, SL_SEG_B, SL_SCRATCH, SL_CLP, SL_TABLES, SL_IN0, SL_IN1, SL_IN2, SL_IN3, SL_IN4, SL_OUT0, SL_OUT1, SL_COUNT };
+
+struct DeviceWs {
+  void* ptr[SL_COUNT] = {};
+  size_t cap[SL_COUNT] = {};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ev_valid = false;
+};
+
+std::mutex g_mu;
+std::vector<DeviceWs> g_ws;
+
+DeviceWs* ws_for_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if ((int)g_ws.size() <= dev) g_ws.resize(dev + 1);
+  return &g_ws[dev];
+}
+
+int ws_get(DeviceWs* w, Slot s, size_t bytes, void** out) {
+  if (bytes == 0) bytes = 16;
+  if (w->cap[s] < bytes) {
+    if (w->ptr[s]) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(w->ptr[s]));
+      w->ptr[s] = nullptr;
+      w->cap[s] = 0;
+    }
+    size_t want = bytes + bytes / 8;
+    HIP_TRY(hipMalloc(&w->ptr[s], want));
+    w->cap[s] = want;
+  }
+  *out = w->ptr[s];
+  return 0;
+}
+
+struct ChainPlan {
+  int S, seg_len;
+  bool global_scratch;
+};
+
+const int kMaxGenericDm = 256;
+
+ChainPlan plan_generic(int B, int N, int Dm) {
+  ChainPlan p;
+  const size_t lds = c3p_generic_lds_bytes(Dm);
+  p.global_scratch = lds > (size_t)(156 * 1024);
+  int wg_per_cu = 2;
+  if (!p.global_scratch) {
+    wg_per_cu = (int)((160 * 1024) / (lds + 3072));
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    if (wg_per_cu > 8) wg_per_cu = 8;
+  }
+  const long target = 256L * wg_per_cu * 2;
+  long S = (target + B - 1) / B;
+  const long smax = N / 8 > 1 ? N / 8 : 1;
+  if (S > smax) S = smax;
+  if (S < 1) S = 1;
+  p.seg_len = (int)((N + S - 1) / S);
+  p.S = (N + p.seg_len - 1) / p.seg_len;
+  return p;
+}
+
+// Runs one chained propagation (all modes) with the generic kernel, including the
+// ordered combine of segment products.  All pointers are device pointers.
+int run_chain_generic(DeviceWs* w, ChainArgs base, cplx* U_out, hipStream_t st) {
+  const int Dm = base.Dm;
+  if (Dm > kMaxGenericDm) return fail("matrix dimension %d exceeds the generic kernel limit %d", Dm, kMaxGenericDm);
+  const size_t msz = (size_t)Dm * Dm * sizeof(cplx);
+  ChainPlan p = plan_generic(base.B, base.N, Dm);
+  base.ld = Dm | 1;
+  base.S = p.S;
+  base.seg_len = p.seg_len;
+  const double* final_phase = base.fr_phase;
+  cplx* seg = U_out;
+  if (p.S > 1) {
+    void* v;
+    if (ws_get(w, SL_SEG_A, (size_t)base.B * p.S * msz, &v)) return -1;
+    seg = (cplx*)v;
+    base.fr_phase = nullptr;
+  }
+  base.seg_out = seg;
+  if (p.global_scratch) {
+    base.scratch_stride = (long)7 * base.ld * Dm;
+    void* v;
+    if (ws_get(w, SL_SCRATCH, (size_t)base.B * p.S * base.scratch_stride * sizeof(cplx), &v)) return -1;
+    base.scratch = (cplx*)v;
+  }
+  g_last_kernel = p.global_scratch ? C3P_KERNEL_GENERIC_GLOBAL : C3P_KERNEL_GENERIC_LDS;
+  if (g_profiling) {
+    if (!w->ev0) {
+      HIP_TRY(hipEventCreate(&w->ev0));
+      HIP_TRY(hipEventCreate(&w->ev1));
+    }
+    HIP_TRY(hipEventRecord(w->ev0, st));
+  }
+  HIP_TRY(c3p_launch_chain_generic(base, p.global_scratch, st));
+  if (g_profiling) {
+    HIP_TRY(hipEventRecord(w->ev1, st));
+    w->ev_valid = true;
+  }
+  // ordered combine of the S segment products: groups of 8 until <= 16 remain
+  int count = p.S;
+  cplx* cur = seg;
+  Slot next_slot = SL_SEG_B;
+  while (count > 1) {
+    ChainArgs c = {};
+    c.mode = C3P_MODE_GIVEN;
+    c.mats = cur;
+    c.B = base.B;
+    c.N = count;
+    c.D = base.D;
+    c.Dm = Dm;
+    c.ld = base.ld;
+    c.right_order = base.right_order;
+    bool global = p.global_scratch;
+    if (count <= 16) {
+      c.S = 1;
+      c.seg_len = count;
+      c.seg_out = U_out;
+      c.fr_phase = final_phase;
+    } else {
+      c.seg_len = 8;
+      c.S = (count + 7) / 8;
+      void* v;
+      if (ws_get(w, next_slot, (size_t)base.B * c.S * msz, &v)) return -1;
+      c.seg_out = (cplx*)v;
+    }
+    if (global) {
+      c.scratch_stride = (long)7 * c.ld * Dm;
+      void* v;
+      // the first launch sized SL_SCRATCH for B*S workgroups >= B*c.S
+      if (ws_get(w, SL_SCRATCH, (size_t)c.B * c.S * c.scratch_stride * sizeof(cplx), &v)) return -1;
+      c.scratch = (cplx*)v;
+    }
+    HIP_TRY(c3p_launch_chain_generic(c, global, st));
+    cur = c.seg_out;
+    count = c.S;
+    next_slot = (next_slot == SL_SEG_B) ? SL_SEG_A : SL_SEG_B;
+    if (c.seg_out == U_out) break;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Small-D MFMA path (Dm <= C3P_SMALLD_LIMIT): tables -> segment chains -> ordered combine
+// ---------------------------------------------------------------------------
+const int kSmallDLimit = 10;  // D = 11, 12 spill registers (hipcc 7.2); they use the generic kernel
+
+int record_start(DeviceWs* w, hipStream_t st) {
+  if (!g_profiling) return 0;
+  if (!w->ev0) {
+    HIP_TRY(hipEventCreate(&w->ev0));
+    HIP_TRY(hipEventCreate(&w->ev1));
+  }
+  HIP_TRY(hipEventRecord(w->ev0, st));
+  return 0;
+}
+int record_stop(DeviceWs* w, hipStream_t st) {
+  if (!g_profiling) return 0;
+  HIP_TRY(hipEventRecord(w->ev1, st));
+  w->ev_valid = true;
+  return 0;
+}
+
+// ordered combine of `count` matrices per sample (cur: [B,count,Dm,Dm]) into U_out
+int combine_smalld(DeviceWs* w, const cplx* cur, int B, int count, int Dm, int right_order,
+                   const double* fr_phase, cplx* U_out, hipStream_t st) {
+  const size_t msz = (size_t)Dm * Dm * sizeof(cplx);
+  Slot next_slot = SL_SEG_B;
+  while (true) {
+    SmallArgs c = {};
+    c.mode = C3P_MODE_GIVEN;
+    c.mats = cur;
+    c.B = B;
+    c.N = count;
+    c.Dm = Dm;
+    c.right_order = right_order;
+    if (count <= 8) {
+      c.S = 1;
+      c.seg_out = U_out;
+      c.fr_phase = fr_phase;
+    } else {
+      c.S = (count + 3) / 4;
+      void* v;
+      if (ws_get(w, next_slot, (size_t)B * c.S * msz, &v)) return -1;
+      c.seg_out = (cplx*)v;
+    }
+    c.Lmax = (count + c.S - 1) / c.S;
+    HIP_TRY(c3p_launch_smalld_chain(c, st));
+    if (c.seg_out == U_out) break;
+    cur = c.seg_out;
+    count = c.S;
+    next_slot = (next_slot == SL_SEG_B) ? SL_SEG_A : SL_SEG_B;
+  }
+  return 0;
+}
+
+int pick_segments(int B, int N, int K, int Dm, bool need_mult4) {
+  // one wave per SIMD (the D = 9 kernel uses ~450 registers): 256 CUs x 4 SIMDs x 4 chains
+  const long target = 4096;
+  long S = (target + B - 1) / B;
+  if (S > N) S = N;
+  if (S < 1) S = 1;
+  // the segment's control amplitudes live in LDS: 4 chains x K x Lmax doubles
+  const long lds_budget = 60 * 1024 - (long)(c3p_smalld_table_doubles(Dm, K) + 4 * c3p_smalld_mat_doubles(Dm)) * 8;
+  const long lmax_cap = K > 0 ? lds_budget / (32L * K) : (1L << 30);
+  while ((N + S - 1) / S > lmax_cap && S < N) ++S;
+  if (need_mult4) S = ((S + 3) / 4) * 4;
+  if (S > N) return -1;
+  return (int)S;
+}
+
+int run_pwc_smalld(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs,
+                   const double* signals, const cplx* clp, double dt, int B, int K, int N, int D, int Dm,
+                   const double* fr_phase, cplx* U_out, cplx* dUs_out, hipStream_t st) {
+  const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
+  const int S = pick_segments(B, N, K, Dm, per_sample);
+  if (S < 0) return 1;  // not applicable -> caller falls back to the generic kernel
+  const int nsamp = per_sample ? B : 1;
+  void* v;
+  if (ws_get(w, SL_TABLES, (size_t)nsamp * c3p_smalld_table_doubles(Dm, K) * sizeof(double), &v)) return -1;
+  PrepArgs p = {};
+  p.h0 = h0;
+  p.h0_bstride = h0_bs;
+  p.hks = hks;
+  p.hks_bstride = hk_bs;
+  p.clp = clp;
+  p.dt = dt;
+  p.K = K;
+  p.Dh = D;
+  p.lindblad = lindblad;
+  p.tables = (double*)v;
+  HIP_TRY(c3p_launch_smalld_prep(p, Dm, nsamp, st));
+  SmallArgs a = {};
+  a.tables = (const double*)v;
+  a.tab_per_sample = per_sample ? 1 : 0;
+  a.signals = signals;
+  a.B = B;
+  a.K = K;
+  a.N = N;
+  a.Dm = Dm;
+  a.S = S;
+  a.Lmax = (N + S - 1) / S;
+  a.mode = lindblad ? C3P_MODE_LINDBLAD : C3P_MODE_UNITARY;
+  a.dUs_out = dUs_out;
+  if (S == 1) {
+    a.seg_out = U_out;
+    a.fr_phase = fr_phase;
+  } else {
+    void* sv;
+    if (ws_get(w, SL_SEG_A, (size_t)B * S * Dm * Dm * sizeof(cplx), &sv)) return -1;
+    a.seg_out = (cplx*)sv;
+  }
+  g_last_kernel = C3P_KERNEL_SMALLD;
+  if (record_start(w, st)) return -1;
+  HIP_TRY(c3p_launch_smalld_chain(a, st));
+  if (record_stop(w, st)) return -1;
+  if (S > 1) return combine_smalld(w, a.seg_out, B, S, Dm, 0, fr_phase, U_out, st);
+  return 0;
+}
+
+// Host-pointer staging helpers --------------------------------------------------
+struct Stage {
+  DeviceWs* w;
+  hipStream_t st;
+  int in_slot = SL_IN0;
+  int out_slot = SL_OUT0;
+  struct Back {
+    void* host;
+    void* dev;
+    size_t bytes;
+  };
+  std::vector<Back> backs;
+  int in(const void* host, size_t bytes, const void** dev) {
+    if (!host || bytes == 0) {
+      *dev = nullptr;
+      return 0;
+    }
+    void* d;
+    if (ws_get(w, (Slot)in_slot++, bytes, &d)) return -1;
+    HIP_TRY(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, st));
+    *dev = d;
+    return 0;
+  }
+  int out(void* host, size_t bytes, void** dev) {
+    if (!host || bytes == 0) {
+      *dev = nullptr;
+      return 0;
+    }
+    void* d;
+    if (ws_get(w, (Slot)out_slot++, bytes, &d)) return -1;
+    backs.push_back({host, d, bytes});
+    *dev = d;
+    return 0;
+  }
+  int finish() {
+    for (auto& b : backs) HIP_TRY(hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+  }
+};
+
+int pwc_common(int lindblad, const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride,
+               const double* signals, const void* col_ops, int C, double dt, int B, int K, int N, int D,
+               int flags, const double* fr_phase, void* U_out, void* dUs_out, void* stream) {
+  if (B < 0 || N < 0 || D <= 0 || K < 0) return fail("bad sizes B=%d K=%d N=%d D=%d", B, K, N, D);
+  if (!U_out) return fail("U_out is NULL");
+  if (B == 0) return 0;
+  if (N == 0) return fail("empty time grid (N == 0)");
+  if (!h0) return fail("h0 is NULL");
+  if (K > 0 && (!hks || !signals)) return fail("K > 0 but hks/signals missing");
+  if (lindblad && (!col_ops || C <= 0)) return fail("lindblad propagation needs col_ops");
+  const bool per_slice = (flags & C3P_PER_SLICE_H) != 0;
+  const int Dm = lindblad ? D * D : D;
+  const size_t cs = sizeof(cplx);
+  hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lk(g_mu);
+  DeviceWs* w = ws_for_current_device();
+  if (!w) return fail("no HIP device");
+  Stage sg{w, st};
+  const void *d_h0 = h0, *d_hks = hks, *d_sig = signals, *d_col = col_ops, *d_ph = fr_phase;
+  void *d_U = U_out, *d_dUs = dUs_out;
+  if (flags & C3P_HOST_PTRS) {
+    const size_t h0_one = (size_t)(per_slice ? N : 1) * D * D;
+    const size_t h0_elems = h0_bstride ? (size_t)(B - 1) * h0_bstride + h0_one : h0_one;
+    const size_t hk_one = (size_t)K * D * D;
+    const size_t hk_elems = hks_bstride ? (size_t)(B - 1) * hks_bstride + hk_one : hk_one;
+    if (sg.in(h0, h0_elems * cs, &d_h0)) return -1;
+    if (sg.in(hks, K ? hk_elems * cs : 0, &d_hks)) return -1;
+    if (sg.in(signals, (size_t)B * K * N * sizeof(double), &d_sig)) return -1;
+    if (sg.in(col_ops, lindblad ? (size_t)C * D * D * cs : 0, &d_col)) return -1;
+    if (sg.in(fr_phase, fr_phase ? (size_t)B * Dm * sizeof(double) : 0, &d_ph)) return -1;
+    if (sg.out(U_out, (size_t)B * Dm * Dm * cs, &d_U)) return -1;
+    if (sg.out(dUs_out, dUs_out ? (size_t)B * N * Dm * Dm * cs : 0, &d_dUs)) return -1;
+  }
+  ChainArgs a = {};
+  a.h0 = (const cplx*)d_h0;
+  a.h0_bstride = h0_bstride;
+  a.h0_nstride = per_slice ? (long)D * D : 0;
+  a.hks = (const cplx*)d_hks;
+  a.hks_bstride = hks_bstride;
+  a.signals = (const double*)d_sig;
+  a.fr_phase = (const double*)d_ph;
+  a.dt = dt;
+  a.B = B;
+  a.K = K;
+  a.N = N;
+  a.D = D;
+  a.Dm = Dm;
+  a.mode = lindblad ? C3P_MODE_LINDBLAD : C3P_MODE_UNITARY;
+  a.dUs_out = (cplx*)d_dUs;
+  if (lindblad) {
+    void* v;
+    if (ws_get(w, SL_CLP, (size_t)Dm * Dm * cs, &v)) return -1;
+    HIP_TRY(c3p_launch_clp((const cplx*)d_col, C, D, (cplx*)v, st));
+    a.clp = (const cplx*)v;
+  }
+  bool done = false;
+  if (!(flags & C3P_FORCE_GENERIC) && !per_slice && Dm <= kSmallDLimit && c3p_smalld_supported(Dm) && K <= 8) {
+    const int rc = run_pwc_smalld(w, lindblad, a.h0, a.h0_bstride, a.hks, a.hks_bstride, a.signals, a.clp, dt,
+                                  B, K, N, D, Dm, a.fr_phase, (cplx*)d_U, a.dUs_out, st);
+    if (rc < 0) return -1;
+    done = (rc == 0);
+  }
+  if (!done && run_chain_generic(w, a, (cplx*)d_U, st)) return -1;
+  if (flags & C3P_HOST_PTRS) return sg.finish();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int c3p_version(void) { return 1; }
+
+int c3p_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+const char* c3p_last_error(void) { return g_err.c_str(); }
+int c3p_last_kernel(void) { return g_last_kernel; }
+
+int c3p_set_profiling(int enable) {
+  g_profiling = enable ? 1 : 0;
+  return 0;
+}
+
+double c3p_last_kernel_ms(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  DeviceWs* w = ws_for_current_device();
+  if (!w || !w->ev_valid) return -1.0;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, w->ev0, w->ev1) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1.0;
+  }
+  return (double)ms;
+}
+
+void c3p_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (size_t d = 0; d < g_ws.size(); ++d) {
+    bool any = g_ws[d].ev0 != nullptr;
+    for (int s = 0; s < SL_COUNT; ++s) any = any || g_ws[d].ptr[s];
+    if (!any) continue;
+    (void)hipSetDevice((int)d);
+    (void)hipDeviceSynchronize();
+    for (int s = 0; s < SL_COUNT; ++s) {
+      if (g_ws[d].ptr[s]) (void)hipFree(g_ws[d].ptr[s]);
+      g_ws[d].ptr[s] = nullptr;
+      g_ws[d].cap[s] = 0;
+    }
+    if (g_ws[d].ev0) {
+      (void)hipEventDestroy(g_ws[d].ev0);
+      (void)hipEventDestroy(g_ws[d].ev1);
+      g_ws[d].ev0 = g_ws[d].ev1 = nullptr;
+      g_ws[d].ev_valid = false;
+    }
+  }
+  (void)hipSetDevice(cur);
+}
+
+int c3p_pwc_unitary(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride,
+                    const double* signals, double dt, int B, int K, int N, int D, int flags,
+                    const double* fr_phase, void* U_out, void* dUs_out, void* stream) {
+  return pwc_common(0, h0, h0_bstride, hks, hks_bstride, signals, nullptr, 0, dt, B, K, N, D, flags,
+                    fr_phase, U_out, dUs_out, stream);
+}
+
+int c3p_pwc_lindblad(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride,
+                     const double* signals, const void* col_ops, int C, double dt, int B, int K,
+                     int N, int D, int flags, const double* fr_phase, void* U_out, void* dUs_out,
+                     void* stream) {
+  return pwc_common(1, h0, h0_bstride, hks, hks_bstride, signals, col_ops, C, dt, B, K, N, D, flags,
+                    fr_phase, U_out, dUs_out, stream);
+}
+
+int c3p_expm(const void* A, int n, int D, int flags, void* out, void* stream) {
+  if (n < 0 || D <= 0) return fail("bad sizes n=%d D=%d", n, D);
+  if (n == 0) return 0;
+  if (!A || !out) return fail("NULL matrix pointer");
+  hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lk(g_mu);
+  DeviceWs* w = ws_for_current_device();
+  if (!w) return fail("no HIP device");
+  Stage sg{w, st};
+  const void* d_A = A;
+  void* d_out = out;
+  const size_t bytes = (size_t)n * D * D * sizeof(cplx);
+  if (flags & C3P_HOST_PTRS) {
+    if (sg.in(A, bytes, &d_A)) return -1;
+    if (sg.out(out, bytes, &d_out)) return -1;
+  }
+  ChainArgs a = {};
+  a.mode = C3P_MODE_EXPM;
+  a.mats = (const cplx*)d_A;
+  a.B = n;
+  a.N = 1;
+  a.D = D;
+  a.Dm = D;
+  if (run_chain_generic(w, a, (cplx*)d_out, st)) return -1;
+  if (flags & C3P_HOST_PTRS) return sg.finish();
+  return 0;
+}
+
+int c3p_matmul_chain(const void* M, int B, int N, int D, int flags, void* out, void* stream) {
+  if (B < 0 || N < 0 || D <= 0) return fail("bad sizes B=%d N=%d D=%d", B, N, D);
+  if (B == 0) return 0;
+  if (N == 0) return fail("empty matrix list (N == 0)");
+  if (!M || !out) return fail("NULL matrix pointer");
+  hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lk(g_mu);
+  DeviceWs* w = ws_for_current_device();
+  if (!w) return fail("no HIP device");
+  Stage sg{w, st};
+  const void* d_M = M;
+  void* d_out = out;
+  if (flags & C3P_HOST_PTRS) {
+    if (sg.in(M, (size_t)B * N * D * D * sizeof(cplx), &d_M)) return -1;
+    if (sg.out(out, (size_t)B * D * D * sizeof(cplx), &d_out)) return -1;
+  }
+  ChainArgs a = {};
+  a.mode = C3P_MODE_GIVEN;
+  a.mats = (const cplx*)d_M;
+  a.B = B;
+  a.N = N;
+  a.D = D;
+  a.Dm = D;
+  a.right_order = (flags & C3P_ORDER_RIGHT) ? 1 : 0;
+  if (!(flags & C3P_FORCE_GENERIC) && D <= kSmallDLimit && c3p_smalld_supported(D)) {
+    g_last_kernel = C3P_KERNEL_SMALLD;
+    if (combine_smalld(w, (const cplx*)d_M, B, N, D, a.right_order, nullptr, (cplx*)d_out, st)) return -1;
+  } else if (run_chain_generic(w, a, (cplx*)d_out, st)) {
+    return -1;
+  }
+  if (flags & C3P_HOST_PTRS) return sg.finish();
+  return 0;
+}
+
+static int kron_common(const void* A, const void* Bm, int n, int Da, int Db, int which, int flags,
+                       void* out, void* stream) {
+  if (n < 0 || Da <= 0 || Db <= 0) return fail("bad sizes n=%d Da=%d Db=%d", n, Da, Db);
+  if (n == 0) return 0;
+  if (!A || !out || (which == 0 && !Bm)) return fail("NULL matrix pointer");
+  hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lk(g_mu);
+  DeviceWs* w = ws_for_current_device();
+  if (!w) return fail("no HIP device");
+  Stage sg{w, st};
+  const void *d_A = A, *d_B = Bm;
+  void* d_out = out;
+  const size_t Dm = (size_t)Da * Db;
+  if (flags & C3P_HOST_PTRS) {
+    if (sg.in(A, (size_t)n * Da * Da * sizeof(cplx), &d_A)) return -1;
+    if (sg.in(which == 0 ? Bm : nullptr, (size_t)n * Db * Db * sizeof(cplx), &d_B)) return -1;
+    if (sg.out(out, (size_t)n * Dm * Dm * sizeof(cplx), &d_out)) return -1;
+  }
+  HIP_TRY(c3p_launch_kron((const cplx*)d_A, (const cplx*)d_B, n, Da, Db, which, (cplx*)d_out, st));
+  if (flags & C3P_HOST_PTRS) return sg.finish();
+  return 0;
+}
+
+int c3p_kron(const void* A, const void* Bm, int n, int Da, int Db, int flags, void* out, void* stream) {
+  return kron_common(A, Bm, n, Da, Db, 0, flags, out, stream);
+}
+
+int c3p_superop(const void* A, int n, int D, int which, int flags, void* out, void* stream) {
+  if (which < 0 || which > 2) return fail("bad superoperator kind %d", which);
+  return kron_common(A, nullptr, n, D, D, which + 1, flags, out, stream);
+}
+
+int c3p_ode_solve(const void* h0, const void* hks, const double* signals, const void* col_ops,
+                  int C, double dt, int B, int K, int N, int D, int solver, int step,
+                  const void* init, int64_t init_bstride, int want_all, int flags, void* states,
+                  void* stream) {
+  if (B < 0 || N < 0 || D <= 0 || K < 0 || K > 32) return fail("bad sizes B=%d K=%d N=%d D=%d", B, K, N, D);
+  if (solver < 0 || solver > 3) return fail("unknown solver id %d", solver);
+  if (step < 0 || step > 2) return fail("unknown step function id %d", step);
+  if (B == 0) return 0;
+  if (N < 2) return fail("the ODE solver needs at least two time samples (N=%d)", N);
+  if (!h0 || !init || !states) return fail("NULL pointer argument");
+  if (K > 0 && (!hks || !signals)) return fail("K > 0 but hks/signals missing");
+  if (step == C3P_STEP_LINDBLAD && (!col_ops || C <= 0)) return fail("lindblad step needs col_ops");
+  if (step != C3P_STEP_LINDBLAD) C = 0;
+  const int M = (step == C3P_STEP_SCHRODINGER) ? 1 : D;
+  const size_t cs = sizeof(cplx);
+  hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lk(g_mu);
+  DeviceWs* w = ws_for_current_device();
+  if (!w) return fail("no HIP device");
+  Stage sg{w, st};
+  const void *d_h0 = h0, *d_hks = hks, *d_sig = signals, *d_col = col_ops, *d_init = init;
+  void* d_states = states;
+  const size_t out_elems = (size_t)B * (want_all ? N : 1) * D * M;
+  if (flags & C3P_HOST_PTRS) {
+    const size_t init_elems = init_bstride ? (size_t)(B - 1) * init_bstride + (size_t)D * M : (size_t)D * M;
+    if (sg.in(h0, (size_t)D * D * cs, &d_h0)) return -1;
+    if (sg.in(hks, (size_t)K * D * D * cs, &d_hks)) return -1;
+    if (sg.in(signals, (size_t)B * K * N * sizeof(double), &d_sig)) return -1;
+    if (sg.in(col_ops, (size_t)C * D * D * cs, &d_col)) return -1;
+    if (sg.in(init, init_elems * cs, &d_init)) return -1;
+    if (sg.out(states, out_elems * cs, &d_states)) return -1;
+  }
+  OdeArgs a = {};
+  a.h0 = (const cplx*)d_h0;
+  a.hks = (const cplx*)d_hks;
+  a.signals = (const double*)d_sig;
+  a.col_ops = (const cplx*)d_col;
+  a.init = (const cplx*)d_init;
+  a.init_bstride = init_bstride;
+  a.dt = dt;
+  a.B = B;
+  a.K = K;
+  a.N = N;
+  a.D = D;
+  a.M = M;
+  a.C = C;
+  a.solver = solver;
+  a.step = step;
+  a.want_all = want_all ? 1 : 0;
+  a.states = (cplx*)d_states;
+  const size_t elems = c3p_ode_elems(D, M, C);
+  const bool global = elems * cs > (size_t)(150 * 1024);
+  if (global) {
+    void* v;
+    if (ws_get(w, SL_SCRATCH, (size_t)B * elems * cs, &v)) return -1;
+    a.scratch = (cplx*)v;
+    a.scratch_stride = (long)elems;
+  }
+  HIP_TRY(c3p_launch_ode(a, global, st));
+  if (flags & C3P_HOST_PTRS) return sg.finish();
+  return 0;
+}
+
+}  // extern "C"

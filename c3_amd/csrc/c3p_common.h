@@ -1,0 +1,100 @@
+// Shared device/host helpers for libc3prop (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double2 cplx;  // interleaved complex128, same bytes as numpy / TF complex128
+
+__host__ __device__ __forceinline__ cplx cmake(double re, double im) { return make_double2(re, im); }
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return cmake(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return cmake(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+  return cmake(fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ cplx cscale(cplx a, double s) { return cmake(a.x * s, a.y * s); }
+__device__ __forceinline__ cplx cconj(cplx a) { return cmake(a.x, -a.y); }
+// acc += a*b  (4 real FMAs)
+__device__ __forceinline__ void cfma(cplx& acc, cplx a, cplx b) {
+  acc.x = fma(a.x, b.x, acc.x);
+  acc.x = fma(-a.y, b.y, acc.x);
+  acc.y = fma(a.x, b.y, acc.y);
+  acc.y = fma(a.y, b.x, acc.y);
+}
+__device__ __forceinline__ double cabs1(cplx a) { return hypot(a.x, a.y); }
+
+// ---------------------------------------------------------------------------
+// Truncated-Taylor / Paterson-Stockmeyer plan for exp(X), ||X||_1 = norm.
+//
+// The reference exponentiates with tf.linalg.expm (Higham 2005 Pade + solve).
+// On the GPU the LU solve is the awkward part (pivoting, divergent), so the
+// kernels use the mathematically equivalent scaled Taylor polynomial evaluated
+// with Paterson-Stockmeyer: only matrix products.  Degrees are the PS-optimal
+// ones; theta_m are the double-precision Taylor backward-error bounds of
+// Al-Mohy & Higham 2011 (SIAM J. Sci. Comput. 33, table 3.1) -- with
+// ||X||_1 <= theta_m the truncated series is exp(X + dX), ||dX|| <= 2^-53 ||X||.
+// ---------------------------------------------------------------------------
+struct TaylorPlan {
+  int m;  // polynomial degree
+  int q;  // block size: powers X^2..X^q are formed explicitly
+  int r;  // number of blocks, m = q*r
+  int s;  // squarings
+};
+
+#define C3P_NPLANS 7
+__host__ __device__ __forceinline__ TaylorPlan c3p_pick_plan(double norm) {
+  const int pm[C3P_NPLANS] = {2, 4, 6, 9, 12, 16, 20};
+  const int pq[C3P_NPLANS] = {2, 2, 2, 3, 3, 4, 4};
+  const int pr[C3P_NPLANS] = {1, 2, 3, 3, 4, 4, 5};
+  const double th[C3P_NPLANS] = {2.58e-8, 3.40e-4, 9.07e-3, 8.96e-2, 3.00e-1, 7.81e-1, 1.44};
+  int best = C3P_NPLANS - 1, best_cost = 1 << 30, best_s = 0;
+  for (int i = 0; i < C3P_NPLANS; ++i) {
+    int s = 0;
+    if (norm > th[i]) {
+      double ratio = norm / th[i];
+      // s = ceil(log2(ratio)) without libm differences between host and device
+      s = 0;
+      double p = 1.0;
+      while (p < ratio && s < 60) {
+        p *= 2.0;
+        ++s;
+      }
+    }
+    int cost = (pq[i] - 1) + (pr[i] - 1) + s;
+    if (cost < best_cost || (cost == best_cost && s <= best_s)) {
+      best = i;
+      best_cost = cost;
+      best_s = s;
+    }
+  }
+  TaylorPlan p;
+  p.m = pm[best];
+  p.q = pq[best];
+  p.r = pr[best];
+  p.s = best_s;
+  return p;
+}
+
+// 1/k!, k = 0..20
+__constant__ double c3p_inv_fact[21] = {
+    1.0,
+    1.0,
+    0.5,
+    1.0 / 6.0,
+    1.0 / 24.0,
+    1.0 / 120.0,
+    1.0 / 720.0,
+    1.0 / 5040.0,
+    1.0 / 40320.0,
+    1.0 / 362880.0,
+    1.0 / 3628800.0,
+    1.0 / 39916800.0,
+    1.0 / 479001600.0,
+    1.0 / 6227020800.0,
+    1.0 / 87178291200.0,
+    1.0 / 1307674368000.0,
+    1.0 / 20922789888000.0,
+    1.0 / 355687428096000.0,
+    1.0 / 6402373705728000.0,
+    1.0 / 121645100408832000.0,
+    1.0 / 2432902008176640000.0,
+};

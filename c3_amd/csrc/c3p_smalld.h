@@ -1,0 +1,37 @@
+// Launcher interface of the small-D MFMA chain kernel (c3p_smalld.hip).
+#pragma once
+#include "c3p_common.h"
+
+#define C3P_SMALLD_MAX 12
+
+struct SmallArgs {
+  const double* tables;    // [nsamp][(1+K)][MAT+4] images from smalld_prep (TABLE mode)
+  int tab_per_sample;      // tables differ per sample (then S % 4 == 0)
+  const double* signals;   // [B,K,N]
+  const cplx* mats;        // [B,N,Dm,Dm] (GIVEN mode)
+  const double* fr_phase;  // [B,Dm] or null
+  int B, K, N, Dm;
+  int S;     // segments per sample (balanced: segment s covers [s*N/S, (s+1)*N/S))
+  int Lmax;  // ceil(N/S)
+  int mode;  // C3P_MODE_UNITARY / C3P_MODE_LINDBLAD (tables) or C3P_MODE_GIVEN
+  int right_order;
+  cplx* seg_out;  // [B,S,Dm,Dm]
+  cplx* dUs_out;  // [B,N,Dm,Dm] or null
+};
+
+struct PrepArgs {
+  const cplx* h0;
+  long h0_bstride;
+  const cplx* hks;
+  long hks_bstride;
+  const cplx* clp;  // Lindblad dissipator [Dm*Dm] or null
+  double dt;
+  int K, Dh, lindblad;
+  double* tables;
+};
+
+int c3p_smalld_mat_doubles(int Dm);
+size_t c3p_smalld_table_doubles(int Dm, int K);
+bool c3p_smalld_supported(int Dm);
+hipError_t c3p_launch_smalld_chain(const SmallArgs& A, hipStream_t st);
+hipError_t c3p_launch_smalld_prep(const PrepArgs& P, int Dm, int nsamp, hipStream_t st);

@@ -1,0 +1,512 @@
+// Small-D propagator chains on the f64 matrix cores (D <= 12: cfg1 D=3, cfg2 D=9, the
+// 9x9 Lindblad superoperator of a qutrit, ...).
+//
+// Mapping (gfx950): v_mfma_f64_4x4x4_4b_f64 performs FOUR independent 4x4x4 real
+// products per instruction at the full fp64 rate (16 cycles; measured 72.8 TFLOP/s,
+// tools/ubench_f64.hip).  Block b of the instruction is given to chain b: one
+// wavefront owns four independent (sample, time-segment) chains, 16 lanes each, and
+// every matrix of a chain lives in registers as 4x4 real blocks.
+//
+// Complex arithmetic is carried by the real 2x2 representation z=a+ib -> [[a,-b],[b,a]]:
+//   R(A) (2D x 2D) times the "half" image Bh = first column of each 2x2 (2D x D)
+//   gives Ch = half image of C = A B.  No flop is redundant.
+//   * D-layout (MFMA C/D and B operand): register zh[I][J], lane (r=l/16, c=l%4) holds
+//       Zh[4I+r][4J+c] = (r even ? Re : Im) Z[2I + r/2][4J + c]
+//   * A-layout (MFMA A operand): register ra[I][K], lane (r,c) holds R(A)[4I+c][4K+r].
+//     Obtained from the D-layout through a per-chain LDS image (15 ds_write_b64 +
+//     25 ds_read_b64 + sign xor for D=9); row stride 4*NJ+1 doubles keeps both the
+//     16-lane writes and the 32-lane reads bank-conflict free.
+//
+// Per slice (reference: propagation.py:426-440 + tf_utils.py:144-193):
+//   X = G0 + sum_k c_k(n) G_k           (tables prepared by smalld_prep: G = -i dt (h - tr/D))
+//   E = exp(X): Taylor, Paterson-Stockmeyer with q=4 (powers X..X^4, Horner in X^4),
+//       degree 4r in {4,8,12,16,20} and s squarings chosen from a 1-norm bound, wave-uniform
+//   U <- E U ;  the scalar factors e^{mu_n} are summed and applied once per segment.
+#include "c3p_common.h"
+#include "c3p_kernels.h"
+#include "c3p_smalld.h"
+
+extern __shared__ __attribute__((aligned(16))) double c3p_sd_lds[];
+
+namespace {
+
+template <int D>
+struct SD {
+  static constexpr int NBI = (D + 1) / 2;  // 4-row blocks of the 2D-row half image
+  static constexpr int NJ = (D + 3) / 4;   // 4-column blocks
+  static constexpr int W = 4 * NJ + 1;     // LDS row stride in doubles
+  static constexpr int MAT = 4 * NBI * W;  // doubles per matrix image
+};
+
+__device__ __forceinline__ double mfma4(double a, double b, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ double readfirstlane_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readfirstlane(lo);
+  hi = __builtin_amdgcn_readfirstlane(hi);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double flip_sign(double v, unsigned mask_hi) {
+  unsigned long long u = __double_as_longlong(v);
+  u ^= ((unsigned long long)mask_hi) << 32;
+  return __longlong_as_double(u);
+}
+
+// acc += A * B   (A in A-layout, B and acc in D-layout)
+template <int NBI, int NJ>
+__device__ __forceinline__ void mm_acc(const double (&ra)[NBI][NBI], const double (&zb)[NBI][NJ],
+                                       double (&acc)[NBI][NJ]) {
+#pragma unroll
+  for (int K = 0; K < NBI; ++K)
+#pragma unroll
+    for (int I = 0; I < NBI; ++I)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) acc[I][J] = mfma4(ra[I][K], zb[K][J], acc[I][J]);
+}
+
+// D-layout -> A-layout through the chain's LDS image.
+template <int D>
+__device__ __forceinline__ void to_alayout(const double (&zh)[SD<D>::NBI][SD<D>::NJ],
+                                           double (&ra)[SD<D>::NBI][SD<D>::NBI], double* img, int woff,
+                                           int roff, unsigned negmask) {
+  using C = SD<D>;
+#pragma unroll
+  for (int I = 0; I < C::NBI; ++I)
+#pragma unroll
+    for (int J = 0; J < C::NJ; ++J) img[woff + I * 4 * C::W + J * 4] = zh[I][J];
+  __syncthreads();
+#pragma unroll
+  for (int I = 0; I < C::NBI; ++I)
+#pragma unroll
+    for (int K = 0; K < C::NBI; ++K) ra[I][K] = flip_sign(img[roff + I * 4 * C::W + K * 2], negmask);
+  __syncthreads();
+}
+
+struct LanePos {
+  int r, b, c;
+  int idx16;  // position among the chain's 16 lanes
+};
+
+// out = c1 X + c2 A2 + c3 A3 (+ c0 on the diagonal)
+template <int D>
+__device__ __forceinline__ void poly_block(double (&out)[SD<D>::NBI][SD<D>::NJ], double c0, double c1,
+                                           double c2, double c3, const double (&X)[SD<D>::NBI][SD<D>::NJ],
+                                           const double (&A2)[SD<D>::NBI][SD<D>::NJ],
+                                           const double (&A3)[SD<D>::NBI][SD<D>::NJ], int ddelta,
+                                           int rhalf) {
+  using C = SD<D>;
+#pragma unroll
+  for (int I = 0; I < C::NBI; ++I)
+#pragma unroll
+    for (int J = 0; J < C::NJ; ++J) {
+      double v = c1 * X[I][J];
+      v = fma(c2, A2[I][J], v);
+      v = fma(c3, A3[I][J], v);
+      // diagonal: row 2I + r/2 (real part, r even) == column 4J + c, inside the D x D matrix
+      if (2 * I - 4 * J >= -1 && 2 * I - 4 * J <= 3) {
+        const bool on = (ddelta == 4 * J - 2 * I) && (2 * I + rhalf < D);
+        v += on ? c0 : 0.0;
+      }
+      out[I][J] = v;
+    }
+}
+
+// q = 4 plan: degree 4r, s squarings, from a bound on ||X||_1
+__device__ __forceinline__ void plan_q4(double nrm, int& r, int& s) {
+  const double th[5] = {3.40e-4, 5.00e-2, 3.00e-1, 7.81e-1, 1.44};
+  int best_r = 5, best_s = 0, best_cost = 1 << 30;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    int si = 0;
+    double p = th[i];
+    while (p < nrm && si < 40) {
+      p *= 2.0;
+      ++si;
+    }
+    const int cost = i + si;
+    if (cost < best_cost || (cost == best_cost && si <= best_s)) {
+      best_cost = cost;
+      best_r = i + 1;
+      best_s = si;
+    }
+  }
+  r = best_r;
+  s = best_s;
+}
+
+// Write a D-layout matrix times the complex scalar (sr + i si), with optional row phases,
+// to a plain complex [D][D] array.
+template <int D>
+__device__ __forceinline__ void store_plain(const double (&zh)[SD<D>::NBI][SD<D>::NJ], double* dst,
+                                            double sr, double si, const double* row_phase,
+                                            const LanePos& lp, bool active) {
+  using C = SD<D>;
+#pragma unroll
+  for (int I = 0; I < C::NBI; ++I) {
+    const int row = 2 * I + (lp.r >> 1);
+    double pr = sr, pi = si;
+    if (row_phase != nullptr && row < D) {
+      double sn, cs;
+      sincos(row_phase[row], &sn, &cs);
+      pr = sr * cs - si * sn;
+      pi = sr * sn + si * cs;
+    }
+#pragma unroll
+    for (int J = 0; J < C::NJ; ++J) {
+      const double mine = zh[I][J];
+      const double other = __shfl_xor(mine, 16);
+      // r even: mine = Re, other = Im ; r odd: mine = Im, other = Re
+      const double outv = (lp.r & 1) ? fma(pr, mine, pi * other) : fma(pr, mine, -pi * other);
+      const int col = 4 * J + lp.c;
+      if (active && row < D && col < D) dst[(row * D + col) * 2 + (lp.r & 1)] = outv;
+    }
+  }
+}
+
+template <int D>
+__global__ void __launch_bounds__(64) smalld_chain_kernel(SmallArgs A) {
+  using C = SD<D>;
+  constexpr int NBI = C::NBI, NJ = C::NJ, W = C::W, MAT = C::MAT;
+  const int lane = threadIdx.x;
+  LanePos lp;
+  lp.r = lane >> 4;
+  lp.b = (lane >> 2) & 3;
+  lp.c = lane & 3;
+  lp.idx16 = lp.r * 4 + lp.c;
+  const int K = A.K;
+  double* tab = c3p_sd_lds;  // (1+K) images + scalars (table modes only)
+  double* img = tab + (A.mode == C3P_MODE_GIVEN ? 0 : (1 + K) * (MAT + 4));  // 4 chain images
+  double* sg = img + 4 * MAT;                   // 4 chains x K x Lmax signals
+
+  const long chain = (long)blockIdx.x * 4 + lp.b;
+  const long nchains = (long)A.B * A.S;
+  const bool valid = chain < nchains;
+  const long cc = valid ? chain : nchains - 1;
+  const int sample = (int)(cc / A.S);
+  const int seg = (int)(cc - (long)sample * A.S);
+  const int n0 = (int)(((long)seg * A.N) / A.S);
+  const int n1 = (int)(((long)(seg + 1) * A.N) / A.S);
+  const int len = n1 - n0;
+
+  // per-lane LDS offsets (doubles)
+  const int woff = lp.b * MAT + lp.r * W + lp.c;
+  const int roff = lp.b * MAT + (2 * (lp.c >> 1) + ((lp.c ^ lp.r) & 1)) * W + (lp.r >> 1);
+  const unsigned negmask = (((lp.c & 1) == 0) && ((lp.r & 1) == 1)) ? 0x80000000u : 0u;
+  const int toff = lp.r * W + lp.c;  // table read offset (D-layout)
+  const int ddelta = (lp.r & 1) ? 1000 : ((lp.r >> 1) - lp.c);
+  const int rhalf = lp.r >> 1;
+
+  double U[NBI][NJ];
+  double mus_r = 0.0, mus_i = 0.0;
+
+  if (A.mode == C3P_MODE_GIVEN) {
+    // ---- ordered product of supplied matrices ----
+    const double* base = reinterpret_cast<const double*>(A.mats) + ((long)sample * A.N + n0) * D * D * 2;
+    for (int t = 0; t < A.Lmax; ++t) {
+      const bool act = valid && t < len;
+      double P[NBI][NJ];
+      const double* src = base + (long)(act ? t : 0) * D * D * 2;
+#pragma unroll
+      for (int I = 0; I < NBI; ++I)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) {
+          const int row = 2 * I + (lp.r >> 1), col = 4 * J + lp.c;
+          P[I][J] = (act && row < D && col < D) ? src[(row * D + col) * 2 + (lp.r & 1)] : 0.0;
+        }
+      if (t == 0) {
+#pragma unroll
+        for (int I = 0; I < NBI; ++I)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) U[I][J] = P[I][J];
+      } else {
+        double ra[NBI][NBI];
+        double acc[NBI][NJ];
+#pragma unroll
+        for (int I = 0; I < NBI; ++I)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) acc[I][J] = 0.0;
+        if (A.right_order) {
+          to_alayout<D>(U, ra, img, woff, roff, negmask);
+          mm_acc<NBI, NJ>(ra, P, acc);
+        } else {
+          to_alayout<D>(P, ra, img, woff, roff, negmask);
+          mm_acc<NBI, NJ>(ra, U, acc);
+        }
+#pragma unroll
+        for (int I = 0; I < NBI; ++I)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) U[I][J] = act ? acc[I][J] : U[I][J];
+      }
+    }
+  } else {
+    // ---- prologue: tables and this segment's control amplitudes into LDS ----
+    // all four chains of a wave share the sample when tables are per sample (S % 4 == 0)
+    const double* gt0 = A.tables + (long)(A.tab_per_sample ? sample : 0) * (1 + K) * (MAT + 4);
+    for (int e = lane; e < (1 + K) * (MAT + 4); e += 64) tab[e] = gt0[e];
+    for (int k = 0; k < K; ++k) {
+      const double* s = A.signals + ((long)sample * K + k) * A.N + n0;
+      for (int t = lp.idx16; t < A.Lmax; t += 16) sg[(lp.b * K + k) * A.Lmax + t] = (valid && t < len) ? s[t] : 0.0;
+    }
+    __syncthreads();
+
+    for (int t = 0; t < A.Lmax; ++t) {
+      const bool act = valid && t < len;
+      // ---- scalars: norm bound, trace shift ----
+      double nrm = tab[MAT + 2];
+      double mu_r = tab[MAT + 0], mu_i = tab[MAT + 1];
+      for (int k = 0; k < K; ++k) {
+        const double ck = sg[(lp.b * K + k) * A.Lmax + t];
+        const double* tk = tab + (k + 1) * (MAT + 4) + MAT;
+        nrm = fma(fabs(ck), tk[2], nrm);
+        mu_r = fma(ck, tk[0], mu_r);
+        mu_i = fma(ck, tk[1], mu_i);
+      }
+      nrm = fmax(nrm, __shfl_xor(nrm, 4));
+      nrm = fmax(nrm, __shfl_xor(nrm, 8));
+      nrm = readfirstlane_f64(nrm);
+      int pr, ps;
+      plan_q4(nrm, pr, ps);
+      const double scale = ldexp(1.0, -ps);
+      // ---- X = scale (G0 + sum_k c_k G_k) in D-layout ----
+      double X[NBI][NJ];
+#pragma unroll
+      for (int I = 0; I < NBI; ++I)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) X[I][J] = scale * tab[toff + I * 4 * W + J * 4];
+      for (int k = 0; k < K; ++k) {
+        const double ck = scale * sg[(lp.b * K + k) * A.Lmax + t];
+        const double* tk = tab + (k + 1) * (MAT + 4);
+#pragma unroll
+        for (int I = 0; I < NBI; ++I)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) X[I][J] = fma(ck, tk[toff + I * 4 * W + J * 4], X[I][J]);
+      }
+      double ra[NBI][NBI];
+      to_alayout<D>(X, ra, img, woff, roff, negmask);
+      // ---- powers with the left operand X ----
+      double A2[NBI][NJ], A3[NBI][NJ], A4[NBI][NJ];
+#pragma unroll
+      for (int I = 0; I < NBI; ++I)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) A2[I][J] = A3[I][J] = A4[I][J] = 0.0;
+      mm_acc<NBI, NJ>(ra, X, A2);
+      mm_acc<NBI, NJ>(ra, A2, A3);
+      mm_acc<NBI, NJ>(ra, A3, A4);
+      // ---- Horner in X^4: P = c_m X^4 + B_{r-1};  P = X^4 P + B_j ----
+      double P[NBI][NJ];
+      {
+        const int j = pr - 1;
+        poly_block<D>(P, c3p_inv_fact[4 * j], c3p_inv_fact[4 * j + 1], c3p_inv_fact[4 * j + 2],
+                      c3p_inv_fact[4 * j + 3], X, A2, A3, ddelta, rhalf);
+        const double cm = c3p_inv_fact[4 * pr];
+#pragma unroll
+        for (int I = 0; I < NBI; ++I)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) P[I][J] = fma(cm, A4[I][J], P[I][J]);
+      }
+      if (pr > 1) {
+        to_alayout<D>(A4, ra, img, woff, roff, negmask);
+        for (int j = pr - 2; j >= 0; --j) {
+          double acc[NBI][NJ];
+          poly_block<D>(acc, c3p_inv_fact[4 * j], c3p_inv_fact[4 * j + 1], c3p_inv_fact[4 * j + 2],
+                        c3p_inv_fact[4 * j + 3], X, A2, A3, ddelta, rhalf);
+          mm_acc<NBI, NJ>(ra, P, acc);
+#pragma unroll
+          for (int I = 0; I < NBI; ++I)
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) P[I][J] = acc[I][J];
+        }
+      }
+      // ---- squarings ----
+      for (int it = 0; it < ps; ++it) {
+        to_alayout<D>(P, ra, img, woff, roff, negmask);
+        double acc[NBI][NJ];
+#pragma unroll
+        for (int I = 0; I < NBI; ++I)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) acc[I][J] = 0.0;
+        mm_acc<NBI, NJ>(ra, P, acc);
+#pragma unroll
+        for (int I = 0; I < NBI; ++I)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) P[I][J] = acc[I][J];
+      }
+      // ---- partial propagator write-out ----
+      if (A.dUs_out) {
+        double sn, cs;
+        sincos(mu_i, &sn, &cs);
+        const double er = exp(mu_r);
+        double* dst = reinterpret_cast<double*>(A.dUs_out) + ((long)sample * A.N + n0 + (act ? t : 0)) * D * D * 2;
+        store_plain<D>(P, dst, er * cs, er * sn, nullptr, lp, act);
+      }
+      // ---- chain ----
+      if (t == 0) {
+#pragma unroll
+        for (int I = 0; I < NBI; ++I)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) U[I][J] = P[I][J];
+        mus_r = mu_r;
+        mus_i = mu_i;
+      } else {
+        to_alayout<D>(P, ra, img, woff, roff, negmask);
+        double acc[NBI][NJ];
+#pragma unroll
+        for (int I = 0; I < NBI; ++I)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) acc[I][J] = 0.0;
+        mm_acc<NBI, NJ>(ra, U, acc);
+#pragma unroll
+        for (int I = 0; I < NBI; ++I)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) U[I][J] = act ? acc[I][J] : U[I][J];
+        mus_r += act ? mu_r : 0.0;
+        mus_i += act ? mu_i : 0.0;
+      }
+    }
+  }
+  // ---- segment result ----
+  double sn, cs;
+  sincos(mus_i, &sn, &cs);
+  const double er = exp(mus_r);
+  double* dst = reinterpret_cast<double*>(A.seg_out) + (long)cc * D * D * 2;
+  const double* ph = A.fr_phase ? A.fr_phase + (long)sample * D : nullptr;
+  store_plain<D>(U, dst, er * cs, er * sn, ph, lp, valid);
+}
+
+// Table preparation: one block per (sample, table index).  G = fac * h (unitary: fac = -i dt)
+// or the Lindblad generator (table 0 carries the dissipator).  Output image: Zh layout,
+// zero padded, followed by {Re mu, Im mu, ||G - mu||_1, 0}.
+template <int D>
+__global__ void __launch_bounds__(64) smalld_prep_kernel(PrepArgs P) {
+  using C = SD<D>;
+  constexpr int MAT = C::MAT, W = C::W;
+  __shared__ double g[D * D * 2];
+  __shared__ double colsum[D];
+  __shared__ double mu[2];
+  const int tid = threadIdx.x;
+  const int ti = blockIdx.x % (1 + P.K);
+  const int sample = blockIdx.x / (1 + P.K);
+  const int Dh = P.Dh;  // Hilbert dimension of the inputs (D for unitary, sqrt(D) for Lindblad)
+  const cplx* h = (ti == 0) ? P.h0 + (long)sample * P.h0_bstride
+                            : P.hks + (long)sample * P.hks_bstride + (long)(ti - 1) * Dh * Dh;
+  for (int e = tid; e < D * D; e += 64) {
+    const int row = e / D, col = e - row * D;
+    cplx v;
+    if (!P.lindblad) {
+      const cplx x = h[e];
+      v = cmake(x.y * P.dt, -x.x * P.dt);  // -i dt h
+    } else {
+      const int i = row / Dh, j = row - i * Dh, k = col / Dh, l = col - k * Dh;
+      v = (ti == 0) ? P.clp[e] : cmake(0, 0);
+      if (j == l) {
+        const cplx x = h[i * Dh + k];
+        v.x += x.y;
+        v.y -= x.x;
+      }
+      if (i == k) {
+        const cplx x = h[l * Dh + j];
+        v.x -= x.y;
+        v.y += x.x;
+      }
+      v = cscale(v, P.dt);
+    }
+    g[2 * e] = v.x;
+    g[2 * e + 1] = v.y;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double tr = 0, ti2 = 0;
+    for (int i = 0; i < D; ++i) {
+      tr += g[2 * (i * D + i)];
+      ti2 += g[2 * (i * D + i) + 1];
+    }
+    mu[0] = tr / D;
+    mu[1] = ti2 / D;
+  }
+  __syncthreads();
+  if (tid < D) {
+    g[2 * (tid * D + tid)] -= mu[0];
+    g[2 * (tid * D + tid) + 1] -= mu[1];
+  }
+  __syncthreads();
+  if (tid < D) {
+    double s = 0;
+    for (int i = 0; i < D; ++i) s += hypot(g[2 * (i * D + tid)], g[2 * (i * D + tid) + 1]);
+    colsum[tid] = s;
+  }
+  __syncthreads();
+  double* out = P.tables + ((long)sample * (1 + P.K) + ti) * (MAT + 4);
+  for (int e = tid; e < MAT; e += 64) {
+    const int rho = e / W, col = e - rho * W;
+    const int i = rho >> 1, p = rho & 1;
+    out[e] = (i < D && col < D) ? g[2 * (i * D + col) + p] : 0.0;
+  }
+  if (tid == 0) {
+    double nrm = 0;
+    for (int j = 0; j < D; ++j) nrm = fmax(nrm, colsum[j]);
+    out[MAT + 0] = mu[0];
+    out[MAT + 1] = mu[1];
+    out[MAT + 2] = nrm;
+    out[MAT + 3] = 0.0;
+  }
+}
+
+template <int D>
+hipError_t launch_chain_t(const SmallArgs& A, hipStream_t st) {
+  using C = SD<D>;
+  const long nchains = (long)A.B * A.S;
+  const unsigned grid = (unsigned)((nchains + 3) / 4);
+  size_t lds = 0;
+  if (A.mode == C3P_MODE_GIVEN)
+    lds = (size_t)(4 * C::MAT) * sizeof(double);
+  else
+    lds = (size_t)((1 + A.K) * (C::MAT + 4) + 4 * C::MAT + 4 * A.K * A.Lmax) * sizeof(double);
+  if (lds > 60 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(smalld_chain_kernel<D>, dim3(grid), dim3(64), lds, st, A);
+  return hipGetLastError();
+}
+
+template <int D>
+hipError_t launch_prep_t(const PrepArgs& P, int nsamp, hipStream_t st) {
+  hipLaunchKernelGGL(smalld_prep_kernel<D>, dim3((unsigned)(nsamp * (1 + P.K))), dim3(64), 0, st, P);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+int c3p_smalld_mat_doubles(int Dm) {
+  const int NBI = (Dm + 1) / 2, NJ = (Dm + 3) / 4;
+  return 4 * NBI * (4 * NJ + 1);
+}
+
+size_t c3p_smalld_table_doubles(int Dm, int K) { return (size_t)(1 + K) * (c3p_smalld_mat_doubles(Dm) + 4); }
+
+bool c3p_smalld_supported(int Dm) { return Dm >= 2 && Dm <= C3P_SMALLD_MAX; }
+
+#define SD_DISPATCH(FN, ...)                                   \
+  switch (Dm) {                                                \
+    case 2: return FN<2>(__VA_ARGS__);                         \
+    case 3: return FN<3>(__VA_ARGS__);                         \
+    case 4: return FN<4>(__VA_ARGS__);                         \
+    case 5: return FN<5>(__VA_ARGS__);                         \
+    case 6: return FN<6>(__VA_ARGS__);                         \
+    case 7: return FN<7>(__VA_ARGS__);                         \
+    case 8: return FN<8>(__VA_ARGS__);                         \
+    case 9: return FN<9>(__VA_ARGS__);                         \
+    case 10: return FN<10>(__VA_ARGS__);                       \
+    case 11: return FN<11>(__VA_ARGS__);                       \
+    case 12: return FN<12>(__VA_ARGS__);                       \
+    default: return hipErrorInvalidValue;                      \
+  }
+
+hipError_t c3p_launch_smalld_chain(const SmallArgs& A, hipStream_t st) {
+  const int Dm = A.Dm;
+  SD_DISPATCH(launch_chain_t, A, st)
+}
+
+hipError_t c3p_launch_smalld_prep(const PrepArgs& P, int Dm, int nsamp, hipStream_t st) {
+  SD_DISPATCH(launch_prep_t, P, nsamp, st)
+}

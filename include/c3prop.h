@@ -1,0 +1,142 @@
+/* c3prop.h -- C ABI of libc3prop.so, the MI355X (gfx950) implementation of
+ * C3's piecewise-constant propagator hot path.
+ *
+ * The reference (q-optimize/c3) is pure Python/TensorFlow: it has no FFI for
+ * this path.  The boundary it exposes is the Python plugin slot
+ * `Experiment.set_prop_method(callable)` (c3/experiment.py:76-91) whose callable
+ * is invoked as `propagation(model, gen, instr, folding_stack, batch_size)`
+ * (c3/experiment.py:472-478).  The numerical inner boundary that this library
+ * replaces is
+ *
+ *     dUs = tf_batch_propagate(h0, hks, signals, dt, batch_size, col_ops, lindbladian)
+ *                                               (c3/libraries/propagation.py:460-515)
+ *     U   = tf_matmul_n(dUs, folding_stack)     (c3/utils/tf_utils.py:144-163)
+ *
+ * plus the ODE state solver `ode_solver` (c3/libraries/propagation.py:687-752).
+ * Each entry point below cites the reference function it stands in for.
+ * `INTEGRATION.md` shows the ctypes binding a C3 maintainer would add.
+ *
+ * Conventions
+ *  - complex128 = interleaved (re, im) doubles, C (row-major) order -- numpy /
+ *    TensorFlow layout.  Pointers are typed `const void*` / `void*` for those.
+ *  - All pointers are DEVICE pointers unless C3P_HOST_PTRS is set in `flags`,
+ *    in which case the library stages inputs/outputs through its own device
+ *    buffers (synchronous).
+ *  - `stream` is a hipStream_t (NULL = the default stream).  Device-pointer
+ *    calls are asynchronous with respect to the host.
+ *  - Return value 0 = success; negative = error, message via c3p_last_error()
+ *    (thread-local).  The Python wrapper re-raises `Exception("C3:Error: ...")`
+ *    like the reference (c3/experiment.py:465-468).
+ *  - The caller owns every buffer it passes.  The library owns only a lazily
+ *    grown per-device workspace, released by c3p_shutdown().
+ *  - Re-entrant per (device, stream); the workspace is per device and guarded
+ *    by a mutex, so concurrent calls on one device serialise their launches.
+ */
+#ifndef C3PROP_H
+#define C3PROP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* flags */
+#define C3P_HOST_PTRS 0x1     /* all data pointers are host memory                    */
+#define C3P_PER_SLICE_H 0x2   /* h0 is [N,D,D] (or [B,N,D,D] with h0_bstride): branch B
+                                 of pwc, use_control_fields=False (propagation.py:295-308) */
+#define C3P_ORDER_RIGHT 0x4   /* c3p_matmul_chain: elems[0]@...@elems[N-1] (tf_matmul_right) */
+#define C3P_FORCE_GENERIC 0x8 /* use the generic LDS kernel even where a specialised one exists */
+
+/* kernels selected (returned by c3p_last_kernel, for tests/bench reporting) */
+#define C3P_KERNEL_NONE 0
+#define C3P_KERNEL_GENERIC_LDS 1
+#define C3P_KERNEL_GENERIC_GLOBAL 2
+#define C3P_KERNEL_SMALLD 3
+#define C3P_KERNEL_MFMA 4
+
+/* ODE solver / step ids (propagation.py:27-32 solver_slicing; :886-904 steps) */
+#define C3P_SOLVER_RK4 0
+#define C3P_SOLVER_RK38 1
+#define C3P_SOLVER_RK5 2
+#define C3P_SOLVER_TSIT5 3
+#define C3P_STEP_SCHRODINGER 0
+#define C3P_STEP_VON_NEUMANN 1
+#define C3P_STEP_LINDBLAD 2
+
+int c3p_version(void);
+int c3p_device_count(void);
+const char* c3p_last_error(void);
+int c3p_last_kernel(void);
+/* Device time (ms) of the most recent c3p_pwc_* call's main kernel, measured
+ * with hipEvents on the stream it was launched on; valid after that stream has
+ * been synchronised.  Only recorded when profiling was enabled with
+ * c3p_set_profiling(1).  Returns < 0 if nothing was recorded. */
+int c3p_set_profiling(int enable);
+double c3p_last_kernel_ms(void);
+void c3p_shutdown(void);
+
+/* U[b] = diag(exp(i fr_phase[b])) * prod_n exp(-i (h0 + sum_k signals[b,k,n] hks[k]) dt)
+ *
+ * Replaces, for B independent parameter samples at once:
+ *   tf_propagation_vectorized (propagation.py:426-440) via tf_batch_propagate (:460-515),
+ *   tf_matmul_n (tf_utils.py:144-193) / tf_matmul_left (:120-129),
+ *   and the frame-rotation left-multiply of compute_propagators (experiment.py:482-509).
+ *
+ *   h0       c128 [D,D]; with C3P_PER_SLICE_H: [N,D,D]; element stride between samples
+ *            h0_bstride (0 = shared by all samples)
+ *   hks      c128 [K,D,D] (ignored when K == 0); stride between samples hks_bstride (0 = shared)
+ *   signals  f64  [B,K,N]  real control amplitudes (propagation.py:293 casts them to c128)
+ *   fr_phase f64  [B,D] or NULL
+ *   U_out    c128 [B,D,D]
+ *   dUs_out  c128 [B,N,D,D] or NULL (partial propagators, experiment.py:523-533)
+ */
+int c3p_pwc_unitary(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride,
+                    const double* signals, double dt, int B, int K, int N, int D, int flags,
+                    const double* fr_phase, void* U_out, void* dUs_out, void* stream);
+
+/* Lindblad superoperator propagator (propagation.py:551-585):
+ *   L[n] = -i (H[n] (x) I - I (x) H[n]^T) + sum_c [ (C(x)I)(I(x)C^T)^+ - 1/2 (C(x)I)^+(C(x)I) - 1/2 (I(x)C^T)(I(x)C^T)^+ ]
+ *   U[b] = diag(exp(i fr_phase[b])) * prod_n exp(L[n] dt),   matrices are [D*D, D*D]
+ *   col_ops  c128 [C,D,D]
+ *   fr_phase f64 [B,D*D] or NULL (phases of tf_super(FR), experiment.py:499-503)
+ *   U_out    c128 [B,D*D,D*D];  dUs_out c128 [B,N,D*D,D*D] or NULL
+ */
+int c3p_pwc_lindblad(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride,
+                     const double* signals, const void* col_ops, int C, double dt, int B, int K,
+                     int N, int D, int flags, const double* fr_phase, void* U_out, void* dUs_out,
+                     void* stream);
+
+/* out[i] = expm(A[i]) for a batch of n [D,D] matrices: the tf.linalg.expm call sites
+ * (propagation.py:378,422,440,456,584). */
+int c3p_expm(const void* A, int n, int D, int flags, void* out, void* stream);
+
+/* Ordered product of a list: out[b] = M[b,N-1] @ ... @ M[b,1] @ M[b,0]
+ * (tf_matmul_n tf_utils.py:144-163 and tf_matmul_left :120-129; with C3P_ORDER_RIGHT
+ * tf_matmul_right :132-141).  M is c128 [B,N,D,D]. */
+int c3p_matmul_chain(const void* M, int B, int N, int D, int flags, void* out, void* stream);
+
+/* Superoperator builders (tf_utils.py:257-289) on a batch of n [D,D] matrices:
+ *   which = 0: spre(A) = A (x) I;  1: spost(A) = I (x) A^T;  2: super(A) = spre(A) spost(A^+) = A (x) conj(A)
+ *   out c128 [n, D*D, D*D] */
+int c3p_superop(const void* A, int n, int D, int which, int flags, void* out, void* stream);
+/* out[i] = kron(A[i], B[i]);  A [n,Da,Da], B [n,Db,Db], out [n,Da*Db,Da*Db] (tf_kron, tf_utils.py:257-267) */
+int c3p_kron(const void* A, const void* Bm, int n, int Da, int Db, int flags, void* out, void* stream);
+
+/* ODE state solver (propagation.py:687-752 + model.py:641-697 + tf_utils.py:521-559):
+ * integrates B independent samples with N RK steps each.
+ *   solver   C3P_SOLVER_*;  step C3P_STEP_* (LINDBLAD needs col_ops, C > 0)
+ *   ts0, dt  first sample time and spacing of the (uniform) signal grid
+ *   init     c128 [B, D, M] with M = 1 (state vector, SCHRODINGER) or M = D (density matrix);
+ *            init_bstride = 0 shares one initial state
+ *   states   c128 [B,N,D,M] if want_all else [B,D,M]
+ */
+int c3p_ode_solve(const void* h0, const void* hks, const double* signals, const void* col_ops,
+                  int C, double dt, int B, int K, int N, int D, int solver, int step,
+                  const void* init, int64_t init_bstride, int want_all, int flags, void* states,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* C3PROP_H */
