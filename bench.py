@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""Headline benchmark: full-gate propagators/s (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic pulse-parameter
+samples: U[b] = FR_b * prod_n exp(-i H_b[n] dt) for all b (config cfg2 of BASELINE.json:
+two-qubit CR gate, D=9, 1000 PWC slices, B=256 samples per GPU; weak scaling: every rank
+propagates its own 256 samples, then one RCCL all-gather of the U slabs).
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_TFLOPS = 78.6  # MI355X dense fp64 (vector = matrix; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+
+
+def algorithmic_flops_per_prop(wl, oracle):
+    """sum over slices of F_slice(D,K,m,s) with the Pade order/squarings the
+    reference's expm picks per slice; one chain product dropped per propagator."""
+    import numpy as np
+
+    H = oracle.sum_h0_hks(wl.h0, wl.hks, wl.signals[0])
+    if wl.lindblad:
+        A = oracle.lindblad_generator(H, wl.col_ops) * wl.dt
+        Dm = wl.D * wl.D
+    else:
+        A = -1j * H * wl.dt
+        Dm = wl.D
+    _, order, s = oracle.expm_plan(A)
+    tot = 0.0
+    for m, sq in zip(order, s):
+        tot += oracle.algorithmic_flops_per_slice(Dm, wl.K, int(m), int(sq))
+    tot -= 8.0 * Dm**3
+    if wl.lindblad:
+        tot += 4.0 * wl.D**3 * wl.N
+    return float(tot)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config index (2 = headline)")
+    ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default: config's B, capped at 256/GPU for cfg3/5)")
+    ap.add_argument("--slices", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--generic", action="store_true", help="force the generic LDS kernel")
+    ap.add_argument("--check", action="store_true", help="verify a few samples against the oracle")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from c3_amd import _lib, propagation, workloads
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    cfg = workloads.CONFIGS[args.config]
+    B = args.batch if args.batch is not None else min(cfg["B"], 256)
+    wl = workloads.make_workload(args.config, B=B, N=args.slices, b_offset=rank * B)
+    Dm = wl.D * wl.D if wl.lindblad else wl.D
+    fr = wl.fr_phase
+    if wl.lindblad:
+        fr = np.stack([(p[:, None] - p[None, :]).ravel() for p in wl.fr_phase])
+    bp = propagation.BatchPropagator(
+        torch.as_tensor(wl.h0, device=dev),
+        torch.as_tensor(wl.hks, device=dev),
+        torch.as_tensor(wl.signals, device=dev),
+        wl.dt,
+        col_ops=torch.as_tensor(wl.col_ops, device=dev) if wl.lindblad else None,
+        fr_phase=torch.as_tensor(fr, device=dev),
+        force_generic=args.generic,
+    )
+    gathered = torch.empty((world * B, Dm, Dm), dtype=torch.complex128, device=dev) if world > 1 else None
+
+    def step():
+        U = bp.run()
+        if world > 1:
+            dist.all_gather_into_tensor(torch.view_as_real(gathered), torch.view_as_real(U))
+        return U
+
+    lib = _lib.load()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_name = _lib.last_kernel()
+
+    # ---- dominant-kernel duration: HIP events on the launch stream, outside the timed region ----
+    lib.c3p_set_profiling(1)
+    kms = []
+    for _ in range(min(10, max(3, args.steps))):
+        bp.run()
+        torch.cuda.synchronize()
+        kms.append(lib.c3p_last_kernel_ms())
+    lib.c3p_set_profiling(0)
+    kernel_ms = float(np.mean(kms))
+
+    err = None
+    if args.check and rank == 0:
+        from oracle import c3_oracle
+
+        nchk = min(4, B)
+        U = bp.run()
+        torch.cuda.synchronize()
+        ref = c3_oracle.propagate_batch(
+            wl.h0, wl.hks, wl.signals[:nchk], wl.dt, col_ops=wl.col_ops, lindbladian=wl.lindblad, fr_phase=wl.fr_phase[:nchk]
+        )
+        Uh = U[:nchk].cpu().numpy()
+        err = float(max(np.linalg.norm(Uh[b] - ref[b]) for b in range(nchk)))
+
+    if rank == 0:
+        from oracle import c3_oracle
+
+        total_props = world * B * args.steps
+        value = total_props / elapsed
+        f_prop = algorithmic_flops_per_prop(wl, c3_oracle)
+        achieved = f_prop * B / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "full-gate propagators/s",
+            "value": value,
+            "unit": "propagators/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "c128",
+            "data": "synthetic",
+            "config": {
+                "workload": wl.name,
+                "D": wl.D,
+                "matrix_dim": Dm,
+                "slices": wl.N,
+                "controls": wl.K,
+                "batch_per_gpu": B,
+                "global_batch": world * B,
+                "parallelism": f"dp{world} (batch sharded; one RCCL all-gather of U per step)" if world > 1 else "single GPU",
+                "kernel": kernel_name,
+            },
+            "roofline": {
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": PEAK_FP64_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP64_TFLOPS,
+                "traffic": None,
+                "kernel": f"chain kernel ({kernel_name})",
+                "kernel_ms": kernel_ms,
+                "algorithmic_flop_per_propagator": f_prop,
+                "note": "fp64 compute-bound path: algorithmic flops (SURVEY 8d, reference Pade order per slice) / hipEvent kernel time; peak = dense fp64 (MFMA = vector on MI355X)",
+            },
+        }
+        if err is not None:
+            out["max_fro_err_vs_oracle"] = err
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, c3_oracle)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(wl, oracle):
+    """The numpy oracle (reference algorithm: batched per-slice Pade expm + pairwise tree
+    product) timed single-threaded on a bounded sample of the same workload."""
+    import numpy as np
+
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+
+    def run(nb):
+        t0 = time.perf_counter()
+        oracle.propagate_batch(
+            wl.h0, wl.hks, wl.signals[:nb], wl.dt, col_ops=wl.col_ops, lindbladian=wl.lindblad, fr_phase=wl.fr_phase[:nb]
+        )
+        return time.perf_counter() - t0
+
+    ctx = threadpool_limits(limits=1) if threadpool_limits else None
+    try:
+        if ctx is not None:
+            ctx.__enter__()
+        t1 = run(1)
+        nb = int(max(1, min(wl.B, round(12.0 / max(t1, 1e-3)))))
+        t = run(nb)
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+    return {
+        "value": nb / t,
+        "unit": "propagators/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{nb} of {wl.B} samples of {wl.name}, numpy oracle (Higham Pade expm per slice + tf_matmul_n tree), 1 thread, {os.cpu_count()} host cores present",
+    }
+
+
+if __name__ == "__main__":
+    main()

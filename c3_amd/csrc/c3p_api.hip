@@ -234,13 +234,13 @@ int combine_smalld(DeviceWs* w, const cplx* cur, int B, int count, int Dm, int r
 }
 
 int pick_segments(int B, int N, int K, int Dm, bool need_mult4) {
-  // one wave per SIMD (the D = 9 kernel uses ~450 registers): 256 CUs x 4 SIMDs x 4 chains
-  const long target = 4096;
+  // two waves per SIMD (the D = 9 kernel fits 256 registers): 256 CUs x 4 SIMDs x 2 x 4 chains
+  const long target = 8192;
   long S = (target + B - 1) / B;
   if (S > N) S = N;
   if (S < 1) S = 1;
   // the segment's control amplitudes live in LDS: 4 chains x K x Lmax doubles
-  const long lds_budget = 60 * 1024 - (long)(c3p_smalld_table_doubles(Dm, K) + 4 * c3p_smalld_mat_doubles(Dm)) * 8;
+  const long lds_budget = 20 * 1024 - (long)(c3p_smalld_table_doubles(Dm, K) + 4 * c3p_smalld_mat_doubles(Dm)) * 8;
   const long lmax_cap = K > 0 ? lds_budget / (32L * K) : (1L << 30);
   while ((N + S - 1) / S > lmax_cap && S < N) ++S;
   if (need_mult4) S = ((S + 3) / 4) * 4;

@@ -55,34 +55,44 @@ __device__ __forceinline__ double flip_sign(double v, unsigned mask_hi) {
   return __longlong_as_double(u);
 }
 
-// acc += A * B   (A in A-layout, B and acc in D-layout)
-template <int NBI, int NJ>
-__device__ __forceinline__ void mm_acc(const double (&ra)[NBI][NBI], const double (&zb)[NBI][NJ],
-                                       double (&acc)[NBI][NJ]) {
-#pragma unroll
-  for (int K = 0; K < NBI; ++K)
-#pragma unroll
-    for (int I = 0; I < NBI; ++I)
-#pragma unroll
-      for (int J = 0; J < NJ; ++J) acc[I][J] = mfma4(ra[I][K], zb[K][J], acc[I][J]);
+// Wave-level ordering point for the per-chain LDS images.  The workgroup is a single
+// wavefront and the LDS services one wave's instructions in issue order, so no s_barrier
+// is needed; the fence only stops the compiler from reordering image writes and reads.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 }
 
-// D-layout -> A-layout through the chain's LDS image.
+// D-layout registers -> the chain's LDS image (plain half image Zh, row stride W)
 template <int D>
-__device__ __forceinline__ void to_alayout(const double (&zh)[SD<D>::NBI][SD<D>::NJ],
-                                           double (&ra)[SD<D>::NBI][SD<D>::NBI], double* img, int woff,
-                                           int roff, unsigned negmask) {
+__device__ __forceinline__ void write_image(const double (&zh)[SD<D>::NBI][SD<D>::NJ], double* img, int woff) {
   using C = SD<D>;
+  wave_sync();
 #pragma unroll
   for (int I = 0; I < C::NBI; ++I)
 #pragma unroll
     for (int J = 0; J < C::NJ; ++J) img[woff + I * 4 * C::W + J * 4] = zh[I][J];
-  __syncthreads();
+  wave_sync();
+}
+
+// acc += M * B, where the left operand M is read from its LDS image as A-layout fragments
+// (one K-column of 4x4 blocks at a time: NBI ds_read_b64 + sign xor per 4*NBI*NJ... MFMAs)
+template <int D>
+__device__ __forceinline__ void mm_img(const double* img, int roff, unsigned negmask,
+                                       const double (&zb)[SD<D>::NBI][SD<D>::NJ],
+                                       double (&acc)[SD<D>::NBI][SD<D>::NJ]) {
+  using C = SD<D>;
 #pragma unroll
-  for (int I = 0; I < C::NBI; ++I)
+  for (int K = 0; K < C::NBI; ++K) {
+    double ra[C::NBI];
 #pragma unroll
-    for (int K = 0; K < C::NBI; ++K) ra[I][K] = flip_sign(img[roff + I * 4 * C::W + K * 2], negmask);
-  __syncthreads();
+    for (int I = 0; I < C::NBI; ++I) ra[I] = flip_sign(img[roff + I * 4 * C::W + K * 2], negmask);
+#pragma unroll
+    for (int I = 0; I < C::NBI; ++I)
+#pragma unroll
+      for (int J = 0; J < C::NJ; ++J) acc[I][J] = mfma4(ra[I], zb[K][J], acc[I][J]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 struct LanePos {
@@ -116,7 +126,8 @@ __device__ __forceinline__ void poly_block(double (&out)[SD<D>::NBI][SD<D>::NJ],
 
 // q = 4 plan: degree 4r, s squarings, from a bound on ||X||_1
 __device__ __forceinline__ void plan_q4(double nrm, int& r, int& s) {
-  const double th[5] = {3.40e-4, 5.00e-2, 3.00e-1, 7.81e-1, 1.44};
+  // Taylor backward-error bounds for unit roundoff 2^-52 (theta_m of Al-Mohy & Higham scaled by 2^(1/m))
+  const double th[5] = {4.0e-4, 5.45e-2, 3.18e-1, 8.16e-1, 1.49};
   int best_r = 5, best_s = 0, best_cost = 1 << 30;
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
@@ -166,8 +177,8 @@ __device__ __forceinline__ void store_plain(const double (&zh)[SD<D>::NBI][SD<D>
   }
 }
 
-template <int D>
-__global__ void __launch_bounds__(64) smalld_chain_kernel(SmallArgs A) {
+template <int D, bool GIVEN, bool DUS>
+__global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
   using C = SD<D>;
   constexpr int NBI = C::NBI, NJ = C::NJ, W = C::W, MAT = C::MAT;
   const int lane = threadIdx.x;
@@ -178,8 +189,8 @@ __global__ void __launch_bounds__(64) smalld_chain_kernel(SmallArgs A) {
   lp.idx16 = lp.r * 4 + lp.c;
   const int K = A.K;
   double* tab = c3p_sd_lds;  // (1+K) images + scalars (table modes only)
-  double* img = tab + (A.mode == C3P_MODE_GIVEN ? 0 : (1 + K) * (MAT + 4));  // 4 chain images
-  double* sg = img + 4 * MAT;                   // 4 chains x K x Lmax signals
+  double* img = tab + (GIVEN ? 0 : (1 + K) * (MAT + 4));  // 4 chain images
+  double* sg = img + 4 * MAT;  // 4 chains x K x Lmax signals
 
   const long chain = (long)blockIdx.x * 4 + lp.b;
   const long nchains = (long)A.B * A.S;
@@ -202,7 +213,7 @@ __global__ void __launch_bounds__(64) smalld_chain_kernel(SmallArgs A) {
   double U[NBI][NJ];
   double mus_r = 0.0, mus_i = 0.0;
 
-  if (A.mode == C3P_MODE_GIVEN) {
+  if constexpr (GIVEN) {
     // ---- ordered product of supplied matrices ----
     const double* base = reinterpret_cast<const double*>(A.mats) + ((long)sample * A.N + n0) * D * D * 2;
     for (int t = 0; t < A.Lmax; ++t) {
@@ -222,18 +233,17 @@ __global__ void __launch_bounds__(64) smalld_chain_kernel(SmallArgs A) {
 #pragma unroll
           for (int J = 0; J < NJ; ++J) U[I][J] = P[I][J];
       } else {
-        double ra[NBI][NBI];
         double acc[NBI][NJ];
 #pragma unroll
         for (int I = 0; I < NBI; ++I)
 #pragma unroll
           for (int J = 0; J < NJ; ++J) acc[I][J] = 0.0;
         if (A.right_order) {
-          to_alayout<D>(U, ra, img, woff, roff, negmask);
-          mm_acc<NBI, NJ>(ra, P, acc);
+          write_image<D>(U, img, woff);
+          mm_img<D>(img, roff, negmask, P, acc);
         } else {
-          to_alayout<D>(P, ra, img, woff, roff, negmask);
-          mm_acc<NBI, NJ>(ra, U, acc);
+          write_image<D>(P, img, woff);
+          mm_img<D>(img, roff, negmask, U, acc);
         }
 #pragma unroll
         for (int I = 0; I < NBI; ++I)
@@ -246,58 +256,73 @@ __global__ void __launch_bounds__(64) smalld_chain_kernel(SmallArgs A) {
     // all four chains of a wave share the sample when tables are per sample (S % 4 == 0)
     const double* gt0 = A.tables + (long)(A.tab_per_sample ? sample : 0) * (1 + K) * (MAT + 4);
     for (int e = lane; e < (1 + K) * (MAT + 4); e += 64) tab[e] = gt0[e];
+    __syncthreads();
+    // segment-wide bound on ||X||_1 <= ||G0|| + sum_k max_t |c_k(t)| ||G_k||  -> one plan per segment
+    double nrm = tab[MAT + 2];
     for (int k = 0; k < K; ++k) {
       const double* s = A.signals + ((long)sample * K + k) * A.N + n0;
-      for (int t = lp.idx16; t < A.Lmax; t += 16) sg[(lp.b * K + k) * A.Lmax + t] = (valid && t < len) ? s[t] : 0.0;
+      double cmax = 0.0;
+      for (int t = lp.idx16; t < A.Lmax; t += 16) {
+        const double v = (valid && t < len) ? s[t] : 0.0;
+        sg[(lp.b * K + k) * A.Lmax + t] = v;
+        cmax = fmax(cmax, fabs(v));
+      }
+      cmax = fmax(cmax, __shfl_xor(cmax, 1));
+      cmax = fmax(cmax, __shfl_xor(cmax, 2));
+      cmax = fmax(cmax, __shfl_xor(cmax, 16));
+      cmax = fmax(cmax, __shfl_xor(cmax, 32));
+      nrm = fma(cmax, tab[(k + 1) * (MAT + 4) + MAT + 2], nrm);
     }
+    nrm = fmax(nrm, __shfl_xor(nrm, 4));
+    nrm = fmax(nrm, __shfl_xor(nrm, 8));
+    nrm = readfirstlane_f64(nrm);
+    int pr, ps;
+    plan_q4(nrm, pr, ps);
+    pr = __builtin_amdgcn_readfirstlane(pr);
+    ps = __builtin_amdgcn_readfirstlane(ps);
+    const double scale = ldexp(1.0, -ps);
     __syncthreads();
 
     for (int t = 0; t < A.Lmax; ++t) {
       const bool act = valid && t < len;
-      // ---- scalars: norm bound, trace shift ----
-      double nrm = tab[MAT + 2];
-      double mu_r = tab[MAT + 0], mu_i = tab[MAT + 1];
-      for (int k = 0; k < K; ++k) {
-        const double ck = sg[(lp.b * K + k) * A.Lmax + t];
-        const double* tk = tab + (k + 1) * (MAT + 4) + MAT;
-        nrm = fma(fabs(ck), tk[2], nrm);
-        mu_r = fma(ck, tk[0], mu_r);
-        mu_i = fma(ck, tk[1], mu_i);
-      }
-      nrm = fmax(nrm, __shfl_xor(nrm, 4));
-      nrm = fmax(nrm, __shfl_xor(nrm, 8));
-      nrm = readfirstlane_f64(nrm);
-      int pr, ps;
-      plan_q4(nrm, pr, ps);
-      const double scale = ldexp(1.0, -ps);
-      // ---- X = scale (G0 + sum_k c_k G_k) in D-layout ----
+      // ---- X = scale (G0 + sum_k c_k G_k) in D-layout; trace shift mu ----
+      // chains past their segment end (lengths differ by at most one slice) take X = 0, E = I
+      const double sc = act ? scale : 0.0;
+      const double muw = act ? 1.0 : 0.0;
+      double mu_r = muw * tab[MAT + 0], mu_i = muw * tab[MAT + 1];
       double X[NBI][NJ];
 #pragma unroll
       for (int I = 0; I < NBI; ++I)
 #pragma unroll
-        for (int J = 0; J < NJ; ++J) X[I][J] = scale * tab[toff + I * 4 * W + J * 4];
+        for (int J = 0; J < NJ; ++J) X[I][J] = sc * tab[toff + I * 4 * W + J * 4];
       for (int k = 0; k < K; ++k) {
-        const double ck = scale * sg[(lp.b * K + k) * A.Lmax + t];
+        const double c0 = sg[(lp.b * K + k) * A.Lmax + t];
+        const double ck = sc * c0;
         const double* tk = tab + (k + 1) * (MAT + 4);
+        mu_r = fma(c0, tk[MAT + 0], mu_r);  // c0 = 0 for inactive slices (sg is zero padded)
+        mu_i = fma(c0, tk[MAT + 1], mu_i);
 #pragma unroll
         for (int I = 0; I < NBI; ++I)
 #pragma unroll
           for (int J = 0; J < NJ; ++J) X[I][J] = fma(ck, tk[toff + I * 4 * W + J * 4], X[I][J]);
       }
-      double ra[NBI][NBI];
-      to_alayout<D>(X, ra, img, woff, roff, negmask);
-      // ---- powers with the left operand X ----
-      double A2[NBI][NJ], A3[NBI][NJ], A4[NBI][NJ];
+      write_image<D>(X, img, woff);
+      // ---- powers with the left operand X (read from its image) ----
+      double A2[NBI][NJ], A3[NBI][NJ], P[NBI][NJ];
 #pragma unroll
       for (int I = 0; I < NBI; ++I)
 #pragma unroll
-        for (int J = 0; J < NJ; ++J) A2[I][J] = A3[I][J] = A4[I][J] = 0.0;
-      mm_acc<NBI, NJ>(ra, X, A2);
-      mm_acc<NBI, NJ>(ra, A2, A3);
-      mm_acc<NBI, NJ>(ra, A3, A4);
-      // ---- Horner in X^4: P = c_m X^4 + B_{r-1};  P = X^4 P + B_j ----
-      double P[NBI][NJ];
+        for (int J = 0; J < NJ; ++J) A2[I][J] = A3[I][J] = 0.0;
+      mm_img<D>(img, roff, negmask, X, A2);
+      mm_img<D>(img, roff, negmask, A2, A3);
       {
+        double A4[NBI][NJ];
+#pragma unroll
+        for (int I = 0; I < NBI; ++I)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) A4[I][J] = 0.0;
+        mm_img<D>(img, roff, negmask, A3, A4);
+        // ---- Horner in X^4: P = c_m X^4 + B_{r-1};  P = X^4 P + B_j ----
         const int j = pr - 1;
         poly_block<D>(P, c3p_inv_fact[4 * j], c3p_inv_fact[4 * j + 1], c3p_inv_fact[4 * j + 2],
                       c3p_inv_fact[4 * j + 3], X, A2, A3, ddelta, rhalf);
@@ -306,36 +331,34 @@ __global__ void __launch_bounds__(64) smalld_chain_kernel(SmallArgs A) {
         for (int I = 0; I < NBI; ++I)
 #pragma unroll
           for (int J = 0; J < NJ; ++J) P[I][J] = fma(cm, A4[I][J], P[I][J]);
+        if (pr > 1) write_image<D>(A4, img, woff);
       }
-      if (pr > 1) {
-        to_alayout<D>(A4, ra, img, woff, roff, negmask);
-        for (int j = pr - 2; j >= 0; --j) {
-          double acc[NBI][NJ];
-          poly_block<D>(acc, c3p_inv_fact[4 * j], c3p_inv_fact[4 * j + 1], c3p_inv_fact[4 * j + 2],
-                        c3p_inv_fact[4 * j + 3], X, A2, A3, ddelta, rhalf);
-          mm_acc<NBI, NJ>(ra, P, acc);
+      for (int j = pr - 2; j >= 0; --j) {
+        double acc[NBI][NJ];
+        poly_block<D>(acc, c3p_inv_fact[4 * j], c3p_inv_fact[4 * j + 1], c3p_inv_fact[4 * j + 2],
+                      c3p_inv_fact[4 * j + 3], X, A2, A3, ddelta, rhalf);
+        mm_img<D>(img, roff, negmask, P, acc);
 #pragma unroll
-          for (int I = 0; I < NBI; ++I)
+        for (int I = 0; I < NBI; ++I)
 #pragma unroll
-            for (int J = 0; J < NJ; ++J) P[I][J] = acc[I][J];
-        }
+          for (int J = 0; J < NJ; ++J) P[I][J] = acc[I][J];
       }
       // ---- squarings ----
       for (int it = 0; it < ps; ++it) {
-        to_alayout<D>(P, ra, img, woff, roff, negmask);
+        write_image<D>(P, img, woff);
         double acc[NBI][NJ];
 #pragma unroll
         for (int I = 0; I < NBI; ++I)
 #pragma unroll
           for (int J = 0; J < NJ; ++J) acc[I][J] = 0.0;
-        mm_acc<NBI, NJ>(ra, P, acc);
+        mm_img<D>(img, roff, negmask, P, acc);
 #pragma unroll
         for (int I = 0; I < NBI; ++I)
 #pragma unroll
           for (int J = 0; J < NJ; ++J) P[I][J] = acc[I][J];
       }
       // ---- partial propagator write-out ----
-      if (A.dUs_out) {
+      if constexpr (DUS) {
         double sn, cs;
         sincos(mu_i, &sn, &cs);
         const double er = exp(mu_r);
@@ -351,19 +374,19 @@ __global__ void __launch_bounds__(64) smalld_chain_kernel(SmallArgs A) {
         mus_r = mu_r;
         mus_i = mu_i;
       } else {
-        to_alayout<D>(P, ra, img, woff, roff, negmask);
+        write_image<D>(P, img, woff);
         double acc[NBI][NJ];
 #pragma unroll
         for (int I = 0; I < NBI; ++I)
 #pragma unroll
           for (int J = 0; J < NJ; ++J) acc[I][J] = 0.0;
-        mm_acc<NBI, NJ>(ra, U, acc);
+        mm_img<D>(img, roff, negmask, U, acc);
 #pragma unroll
         for (int I = 0; I < NBI; ++I)
 #pragma unroll
-          for (int J = 0; J < NJ; ++J) U[I][J] = act ? acc[I][J] : U[I][J];
-        mus_r += act ? mu_r : 0.0;
-        mus_i += act ? mu_i : 0.0;
+          for (int J = 0; J < NJ; ++J) U[I][J] = acc[I][J];
+        mus_r += mu_r;
+        mus_i += mu_i;
       }
     }
   }
@@ -465,7 +488,12 @@ hipError_t launch_chain_t(const SmallArgs& A, hipStream_t st) {
   else
     lds = (size_t)((1 + A.K) * (C::MAT + 4) + 4 * C::MAT + 4 * A.K * A.Lmax) * sizeof(double);
   if (lds > 60 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(smalld_chain_kernel<D>, dim3(grid), dim3(64), lds, st, A);
+  if (A.mode == C3P_MODE_GIVEN)
+    hipLaunchKernelGGL((smalld_chain_kernel<D, true, false>), dim3(grid), dim3(64), lds, st, A);
+  else if (A.dUs_out)
+    hipLaunchKernelGGL((smalld_chain_kernel<D, false, true>), dim3(grid), dim3(64), lds, st, A);
+  else
+    hipLaunchKernelGGL((smalld_chain_kernel<D, false, false>), dim3(grid), dim3(64), lds, st, A);
   return hipGetLastError();
 }
 
