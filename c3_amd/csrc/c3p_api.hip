@@ -623,6 +623,8 @@ int c3p_ode_solve(const void* h0, const void* hks, const double* signals, const 
   a.solver = solver;
   a.step = step;
   a.want_all = want_all ? 1 : 0;
+  a.n_steps = N;
+  a.u_stride = 1;
   a.states = (cplx*)d_states;
   const size_t elems = c3p_ode_elems(D, M, C);
   const bool global = elems * cs > (size_t)(150 * 1024);
@@ -633,6 +635,85 @@ int c3p_ode_solve(const void* h0, const void* hks, const double* signals, const 
     a.scratch_stride = (long)elems;
   }
   HIP_TRY(c3p_launch_ode(a, global, st));
+  if (flags & C3P_HOST_PTRS) return sg.finish();
+  return 0;
+}
+
+int c3p_rk4_unitary(const void* h0, const void* hks, const double* signals, const void* hs,
+                    int64_t hs_bstride, double dt, int B, int K, int Ns, int D, int flags,
+                    void* U_out, void* dUs_out, void* stream) {
+  if (B < 0 || Ns < 0 || D <= 0 || K < 0 || K > 32) return fail("bad sizes B=%d K=%d Ns=%d D=%d", B, K, Ns, D);
+  if (B == 0) return 0;
+  if (Ns < 3) return fail("rk4_unitary needs at least three Hamiltonian samples (Ns=%d)", Ns);
+  if (!U_out) return fail("U_out is NULL");
+  if (!hs && (!h0 || (K > 0 && (!hks || !signals)))) return fail("NULL Hamiltonian input");
+  const int n_steps = (Ns - 1) / 2;  // range(0, len(h) - 2, 2), propagation.py:79,251
+  const size_t cs = sizeof(cplx);
+  hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lk(g_mu);
+  DeviceWs* w = ws_for_current_device();
+  if (!w) return fail("no HIP device");
+  Stage sg{w, st};
+  const void *d_h0 = h0, *d_hks = hks, *d_sig = signals, *d_hs = hs;
+  void *d_U = U_out, *d_dUs = dUs_out;
+  if (flags & C3P_HOST_PTRS) {
+    if (hs) {
+      const size_t one = (size_t)Ns * D * D;
+      if (sg.in(hs, (hs_bstride ? (size_t)(B - 1) * hs_bstride + one : one) * cs, &d_hs)) return -1;
+    } else {
+      if (sg.in(h0, (size_t)D * D * cs, &d_h0)) return -1;
+      if (sg.in(hks, (size_t)K * D * D * cs, &d_hks)) return -1;
+      if (sg.in(signals, (size_t)B * K * Ns * sizeof(double), &d_sig)) return -1;
+    }
+    if (sg.out(U_out, (size_t)B * D * D * cs, &d_U)) return -1;
+    if (sg.out(dUs_out, dUs_out ? (size_t)B * n_steps * D * D * cs : 0, &d_dUs)) return -1;
+  }
+  // identity initial state, shared by all samples
+  void* v_id;
+  if (ws_get(w, SL_CLP, (size_t)D * D * cs, &v_id)) return -1;
+  {
+    std::vector<cplx> eye((size_t)D * D, cmake(0, 0));
+    for (int i = 0; i < D; ++i) eye[(size_t)i * D + i] = cmake(1, 0);
+    HIP_TRY(hipMemcpyAsync(v_id, eye.data(), eye.size() * cs, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  OdeArgs a = {};
+  a.h0 = (const cplx*)d_h0;
+  a.hks = (const cplx*)d_hks;
+  a.signals = (const double*)d_sig;
+  a.hs = (const cplx*)d_hs;
+  a.hs_bstride = hs_bstride;
+  a.init = (const cplx*)v_id;
+  a.init_bstride = 0;
+  a.dt = dt;
+  a.B = B;
+  a.K = hs ? 0 : K;
+  a.N = Ns;
+  a.D = D;
+  a.M = D;
+  a.C = 0;
+  a.solver = C3P_SOLVER_RK4;
+  a.step = C3P_STEP_PROPAGATOR_ID;
+  a.n_steps = n_steps;
+  a.u_stride = 2;
+  const size_t elems = c3p_ode_elems(D, D, 0);
+  const bool global = elems * cs > (size_t)(150 * 1024);
+  if (global) {
+    void* v;
+    if (ws_get(w, SL_SCRATCH, (size_t)B * elems * cs, &v)) return -1;
+    a.scratch = (cplx*)v;
+    a.scratch_stride = (long)elems;
+  }
+  a.want_all = 0;
+  a.states = (cplx*)d_U;
+  HIP_TRY(c3p_launch_ode(a, global, st));
+  if (d_dUs) {
+    a.want_all = 1;
+    a.reset_each_step = 1;
+    a.transpose_out = 1;
+    a.states = (cplx*)d_dUs;
+    HIP_TRY(c3p_launch_ode(a, global, st));
+  }
   if (flags & C3P_HOST_PTRS) return sg.finish();
   return 0;
 }

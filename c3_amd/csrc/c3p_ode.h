@@ -5,6 +5,7 @@
 #define C3P_STEP_SCHRODINGER_ID 0
 #define C3P_STEP_VON_NEUMANN_ID 1
 #define C3P_STEP_LINDBLAD_ID 2
+#define C3P_STEP_PROPAGATOR_ID 3  // Y <- -i dt H Y on a [D,D] matrix of column states (rk4_unitary)
 
 struct OdeArgs {
   const cplx* h0;         // [D,D]
@@ -16,6 +17,12 @@ struct OdeArgs {
   double dt;
   int B, K, N, D, M, C;
   int solver, step, want_all;
+  int n_steps;          // RK steps to take
+  int u_stride;         // stage position in signal-sample units: u = (n + node) * u_stride
+  const cplx* hs;       // optional per-sample-index Hamiltonians [B?,N,D,D] (then h0/hks unused)
+  long hs_bstride;
+  int reset_each_step;  // state <- init after every step (per-step propagators)
+  int transpose_out;    // store states transposed (gen_du_rk4 stacks propagated vectors as rows)
   cplx* states;
   cplx* scratch;
   long scratch_stride;

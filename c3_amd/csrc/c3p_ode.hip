@@ -143,12 +143,14 @@ __global__ void __launch_bounds__(256) ode_kernel(OdeArgs A) {
   }
   __syncthreads();
 
-  for (int n = 0; n < N; ++n) {
+  const cplx* hsb = A.hs ? A.hs + (long)b * A.hs_bstride : nullptr;
+  for (int n = 0; n < A.n_steps; ++n) {
     for (int s = 0; s < tb.stages; ++s) {
       // interpolated control amplitudes at u = n + node  (tf_utils.py:557-559: linear,
       // linear extrapolation past the last sample)
-      if (tid < K) {
-        const double u = (double)n + tb.node[s];
+      const double ustage = ((double)n + tb.node[s]) * (double)A.u_stride;
+      if (tid < K && !hsb) {
+        const double u = ustage;
         int lo = (int)floor(u);
         if (lo > N - 2) lo = N - 2;
         if (lo < 0) lo = 0;
@@ -157,14 +159,22 @@ __global__ void __launch_bounds__(256) ode_kernel(OdeArgs A) {
         sigv[tid] = (N > 1) ? fma(f, y[lo + 1] - y[lo], y[lo]) : y[0];
       }
       __syncthreads();
-      for (int e = tid; e < hsz; e += nt) {
-        cplx h = A.h0[e];
-        for (int k = 0; k < K; ++k) {
-          const cplx x = A.hks[(long)k * hsz + e];
-          h.x = fma(sigv[k], x.x, h.x);
-          h.y = fma(sigv[k], x.y, h.y);
+      if (hsb) {
+        // per-sample-index Hamiltonians (branch B of get_hs_of_t_ts, propagation.py:164-204):
+        // stage positions are integer sample indices there
+        int iu = (int)(ustage + 0.5);
+        if (iu > N - 1) iu = N - 1;
+        for (int e = tid; e < hsz; e += nt) M.st(oH + e, hsb[(long)iu * hsz + e]);
+      } else {
+        for (int e = tid; e < hsz; e += nt) {
+          cplx h = A.h0[e];
+          for (int k = 0; k < K; ++k) {
+            const cplx x = A.hks[(long)k * hsz + e];
+            h.x = fma(sigv[k], x.x, h.x);
+            h.y = fma(sigv[k], x.y, h.y);
+          }
+          M.st(oH + e, h);
         }
-        M.st(oH + e, h);
       }
       // y = state + sum_j a[s][j] k_j
       for (int e = tid; e < ssz; e += nt) {
@@ -183,7 +193,7 @@ __global__ void __launch_bounds__(256) ode_kernel(OdeArgs A) {
       const int ok = oK + s * ssz;
       const cplx mi_dt = cmake(0.0, -dt);  // -i dt
       mm_left(M, ok, oH, oY, D, Mc, mi_dt, false, tid, nt);  // -i dt H y
-      if (A.step != C3P_STEP_SCHRODINGER_ID) {
+      if (A.step == C3P_STEP_VON_NEUMANN_ID || A.step == C3P_STEP_LINDBLAD_ID) {
         mm_right(M, ok, oY, oH, D, cmake(0.0, dt), true, false, tid, nt);  // + i dt y H
         if (A.step == C3P_STEP_LINDBLAD_ID) {
           for (int c = 0; c < A.C; ++c) {
@@ -206,13 +216,19 @@ __global__ void __launch_bounds__(256) ode_kernel(OdeArgs A) {
           y.y = fma(bj, kj.y, y.y);
         }
       }
-      M.st(oS + e, y);
-      if (A.want_all) A.states[((long)b * N + n) * ssz + e] = y;
+      M.st(oS + e, A.reset_each_step ? init[e] : y);
+      if (A.want_all) {
+        const int eo = A.transpose_out ? (e % Mc) * D + (e / Mc) : e;
+        A.states[((long)b * A.n_steps + n) * ssz + eo] = y;
+      }
     }
     __syncthreads();
   }
   if (!A.want_all)
-    for (int e = tid; e < ssz; e += nt) A.states[(long)b * ssz + e] = M.ld(oS + e);
+    for (int e = tid; e < ssz; e += nt) {
+      const int eo = A.transpose_out ? (e % Mc) * D + (e / Mc) : e;
+      A.states[(long)b * ssz + eo] = M.ld(oS + e);
+    }
 }
 
 }  // namespace

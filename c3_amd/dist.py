@@ -1,0 +1,108 @@
+"""Multi-GPU sharding of the sample axis.
+
+Each parameter sample is an independent chain, so B samples are partitioned
+contiguously over the ranks of a `torch.distributed` group (one process per GPU,
+backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).  The shared
+operators (h0, hks, col_ops; a few KB) are simply present on every rank.  The ONLY
+data-path collective is the final all-gather of the per-rank U slabs
+(B/G x Dm x Dm complex128: 0.3 MB per GPU at cfg2, 6 MB at cfg3) -- no reduction,
+no exchange inside a chain.  The reference has no distributed code at all
+(SURVEY.md 2); this is the build's batch-axis extension.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+
+
+def shard_bounds(B: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of B samples for `rank`; sizes differ by at most one."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    base, rem = divmod(B, world)
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def max_shard(B: int, world: int) -> int:
+    return (B + world - 1) // world
+
+
+def gather_slabs(U_local, B: int, group=None):
+    """All-gather per-rank result slabs [b_local, ...] into [B, ...] on every rank.
+
+    Shards may be uneven: slabs are padded to the largest shard for the collective
+    (all_gather_into_tensor needs equal sizes) and trimmed afterwards.  complex128 is
+    moved as float64 pairs, which both RCCL and gloo support.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi = shard_bounds(B, world, rank)
+    if int(U_local.shape[0]) != hi - lo:
+        raise ValueError(f"rank {rank} holds {int(U_local.shape[0])} samples, expected {hi - lo}")
+    m = max_shard(B, world)
+    tail = tuple(U_local.shape[1:])
+    is_c = U_local.is_complex()
+    loc = torch.view_as_real(U_local.contiguous()) if is_c else U_local.contiguous()
+    if hi - lo < m:
+        pad = torch.zeros((m - (hi - lo),) + tuple(loc.shape[1:]), dtype=loc.dtype, device=loc.device)
+        loc = torch.cat([loc, pad], dim=0)
+    out = torch.empty((world * m,) + tuple(loc.shape[1:]), dtype=loc.dtype, device=loc.device)
+    dist.all_gather_into_tensor(out, loc, group=group)
+    pieces = []
+    for r in range(world):
+        l, h = shard_bounds(B, world, r)
+        pieces.append(out[r * m : r * m + (h - l)])
+    full = torch.cat(pieces, dim=0)
+    if is_c:
+        full = torch.view_as_complex(full)
+    return full.reshape((B,) + tail)
+
+
+def propagate_batch_sharded(
+    h0,
+    hks,
+    signals,
+    dt: float,
+    *,
+    compute: Optional[Callable] = None,
+    group=None,
+    gather: bool = True,
+    **kwargs,
+):
+    """Propagate the rank's shard of `signals` [B,K,N] and (optionally) gather all U.
+
+    `signals` is the GLOBAL batch (every rank holds or can build it; only the local
+    shard is touched).  `compute(h0, hks, signals_local, dt, **kwargs) -> {"U": ...}`
+    defaults to the HIP path `c3_amd.propagation.propagate_batch`; tests inject a CPU
+    stand-in to exercise the sharding/gather logic under gloo.
+    Per-sample extras (`fr_phase`) given for the global batch are sliced to the shard.
+    """
+    import torch
+    import torch.distributed as dist
+
+    if compute is None:
+        from .propagation import propagate_batch as compute
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B = int(signals.shape[0])
+    lo, hi = shard_bounds(B, world, rank)
+    local_kwargs = dict(kwargs)
+    if local_kwargs.get("fr_phase") is not None:
+        local_kwargs["fr_phase"] = local_kwargs["fr_phase"][lo:hi]
+    if hasattr(h0, "ndim") and h0.ndim == 3 and hks is not None and int(h0.shape[0]) == B:
+        h0 = h0[lo:hi]
+    if hks is not None and hasattr(hks, "ndim") and hks.ndim == 4:
+        hks = hks[lo:hi]
+    res = compute(h0, hks, signals[lo:hi], dt, **local_kwargs)
+    U_local = res["U"]
+    if not torch.is_tensor(U_local):
+        U_local = torch.as_tensor(np.asarray(U_local))
+    if not gather or world == 1:
+        return {"U": U_local, "bounds": (lo, hi)}
+    return {"U": gather_slabs(U_local, B, group), "bounds": (lo, hi)}

@@ -614,3 +614,119 @@ class BatchPropagator:
             )
         _lib.check(rc)
         return self.U
+
+
+# --------------------------------------------------------------------------
+# rk4_unitary family (propagation.py:71-101, 104-218, 221-255)
+# --------------------------------------------------------------------------
+
+
+def sum_h0_hks(h0, hks, cf_t):
+    """H(t) = H_0 + sum_k c_k H_k for one time (propagation.py:207-218); host helper."""
+    h = np.array(h0, dtype=np.complex128)
+    for k in range(len(hks)):
+        h = h + complex(cf_t[k]) * np.asarray(hks[k], dtype=np.complex128)
+    return h
+
+
+def get_hs_of_t_ts(model, gen, instr, prop_res=1) -> Dict:
+    """Hamiltonian samples for the RK "unitary" provider (propagation.py:104-204).
+
+    Returns {"Hs", "ts", "dt"} like the reference plus the raw pieces the device kernel
+    consumes ("h0", "hks", "signals" in branch A).  The generator resolution is multiplied
+    by `prop_res` for the signal generation as in the reference (:143,193) and restored
+    afterwards (the reference leaves it multiplied, which compounds on repeated calls).
+    """
+    old_res = gen.resolution
+    gen.resolution = prop_res * gen.resolution
+    try:
+        signal = gen.generate_signals(instr)
+    finally:
+        gen.resolution = old_res
+    out: Dict = {}
+    if model.controllability:
+        h0, hctrls = model.get_Hamiltonians()
+        signals, hks, ts = [], [], None
+        for key in signal:
+            signals.append(np.asarray(signal[key]["values"], dtype=np.float64))
+            ts = np.asarray(signal[key]["ts"])
+            hks.append(np.asarray(hctrls[key]))
+        signals = np.asarray(signals)
+        hks = np.asarray(hks, dtype=np.complex128)
+        out.update(h0=np.asarray(h0), hks=hks, signals=signals)
+        out["Hs"] = np.asarray(h0)[None] + np.einsum("kn,kij->nij", signals.astype(np.complex128), hks)
+    else:
+        out["Hs"] = np.asarray(model.get_Hamiltonian(signal))
+        ts = _uniform_ts([np.asarray(sig["ts"])[1:] for sig in signal.values()])
+    out["dt"] = complex(ts[1 * prop_res] - ts[0])
+    out["ts"] = ts[::prop_res]
+    return out
+
+
+def _rk4_unitary_device(Hs=None, h0=None, hks=None, signals=None, dt=0.0, want_dUs=True):
+    """One gate (B=1) through c3p_rk4_unitary.  Either Hs [Ns,D,D] or (h0, hks, signals[K,Ns])."""
+    lib = _lib.load()
+    call = _Call(Hs, h0, hks, signals)
+    if Hs is not None and signals is None:
+        hs = call.c128(Hs)
+        Ns, D = int(hs.shape[0]), int(hs.shape[-1])
+        h0p = hkp = sgp = None
+        K = 0
+    else:
+        hs = None
+        h0p = call.c128(h0)
+        hkp = call.c128(hks)
+        sgp = call.f64(np.asarray(signals)[None])
+        K, Ns, D = int(sgp.shape[1]), int(sgp.shape[2]), int(h0p.shape[-1])
+    nst = (Ns - 1) // 2
+    U = call.empty((1, D, D))
+    dUs = call.empty((1, nst, D, D)) if want_dUs else None
+    rc = lib.c3p_rk4_unitary(_ptr(h0p), _ptr(hkp), _ptr(sgp), _ptr(hs), 0, float(np.real(dt)), 1, K, Ns, D, call.flags,
+                             _ptr(U), _ptr(dUs), call.stream)
+    _lib.check(rc)
+    return U[0], (dUs[0] if want_dUs else None)
+
+
+def rk4_step(h, psi, dt):
+    """One RK4 step of psi under h[0], h[1], h[2] (propagation.py:95-101) on the device."""
+    h = _c128(h)
+    D = h.shape[-1]
+    U, _ = _rk4_unitary_device(Hs=h[:3], dt=dt, want_dUs=False)
+    return np.asarray(U) @ np.asarray(psi, dtype=np.complex128).reshape(D)
+
+
+def gen_du_rk4(h, dt, dim):
+    """Per-step map with propagated basis vectors as rows (propagation.py:85-92)."""
+    _, dUs = _rk4_unitary_device(Hs=_c128(h)[:3], dt=dt)
+    return np.asarray(dUs[0])
+
+
+@unitary_deco
+def gen_dus_rk4(h, dt, dim=None):
+    """List of per-step maps (propagation.py:71-82)."""
+    _, dUs = _rk4_unitary_device(Hs=_c128(h), dt=dt)
+    dUs = np.asarray(dUs)
+    return [dUs[i] for i in range(dUs.shape[0])]
+
+
+def gen_u_rk4(h, dt, dim):
+    """Total RK4 propagator, columns = propagated basis vectors (propagation.py:246-255)."""
+    U, _ = _rk4_unitary_device(Hs=_c128(h), dt=dt, want_dUs=False)
+    return np.asarray(U)
+
+
+@unitary_deco
+def rk4_unitary(model, gen, instr, init_state=None) -> Dict:
+    """RK4 "unitary" provider (propagation.py:221-243): prop_res = 2."""
+    prop_res = 2
+    d = get_hs_of_t_ts(model, gen, instr, prop_res)
+    if "signals" in d:
+        U, dUs = _rk4_unitary_device(h0=d["h0"], hks=d["hks"], signals=d["signals"], dt=d["dt"])
+    else:
+        U, dUs = _rk4_unitary_device(Hs=d["Hs"], dt=d["dt"])
+    U, dUs = np.asarray(U), np.asarray(dUs)
+    if model.max_excitations:
+        C = np.asarray(model.ex_cutter)
+        U = model.blowup_excitations(U)
+        dUs = np.einsum("ia,nij,jb->nab", C, dUs, C)
+    return {"U": U, "dUs": dUs, "ts": d["ts"]}

@@ -136,6 +136,20 @@ int c3p_ode_solve(const void* h0, const void* hks, const double* signals, const 
                   const void* init, int64_t init_bstride, int want_all, int flags, void* states,
                   void* stream);
 
+/* RK4 "unitary" provider (propagation.py:71-101,221-255: rk4_unitary, gen_u_rk4, gen_dus_rk4,
+ * gen_du_rk4, rk4_step; Hamiltonians from get_hs_of_t_ts :104-204 at prop_res = 2):
+ * every RK4 step consumes three consecutive Hamiltonian samples h[2j], h[2j+1], h[2j+2].
+ *   signals  f64 [B,K,Ns] on the doubled-resolution grid (branch A), or
+ *   hs       c128 [Ns,D,D] / [B,Ns,D,D] per-sample Hamiltonians (branch B; hs_bstride 0 = shared)
+ *   dt       the full RK step (ts[prop_res] - ts[0])
+ *   U_out    c128 [B,D,D]: columns are the propagated basis vectors (gen_u_rk4 :246-255)
+ *   dUs_out  c128 [B,(Ns-1)/2,D,D] or NULL: per-step maps with propagated basis vectors as ROWS,
+ *            exactly as gen_du_rk4 (:85-92) stacks them
+ */
+int c3p_rk4_unitary(const void* h0, const void* hks, const double* signals, const void* hs,
+                    int64_t hs_bstride, double dt, int B, int K, int Ns, int D, int flags,
+                    void* U_out, void* dUs_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

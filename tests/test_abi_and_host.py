@@ -1,0 +1,137 @@
+"""C-ABI surface and host logic, no GPU compute calls."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from c3_amd import _lib, propagation, workloads, dist as c3dist
+from oracle import c3_oracle as o
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "c3prop.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(c3p_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    syms = declared_symbols()
+    assert len(syms) >= 12
+    for name in syms:
+        assert hasattr(lib, name), f"libc3prop.so lacks {name}"
+        assert name in _lib.SIGNATURES, f"ctypes binding lacks {name}"
+    assert set(_lib.SIGNATURES) == set(syms)
+    assert lib.c3p_version() >= 1
+
+
+def test_no_gpu_fails_loudly(lib):
+    """The product path has no CPU fallback: without a device every entry point raises."""
+    if lib.c3p_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    wl = workloads.make_workload(1, B=1, N=4)
+    with pytest.raises(_lib.C3PropError, match="C3:Error"):
+        propagation.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt)
+    with pytest.raises(_lib.C3PropError):
+        propagation.tf_matmul_left(np.zeros((2, 3, 3), complex))
+    with pytest.raises(_lib.C3PropError):
+        propagation.ode_solve_batch(wl.h0, wl.hks, wl.signals, wl.dt, np.zeros((3, 1), complex))
+
+
+def test_product_code_does_not_import_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "c3_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# oracle", ""), f
+
+
+def test_registries_mirror_reference():
+    """propagation.py:18-21,39-68: provider names the reference registers on this path."""
+    assert set(propagation.unitary_provider) >= {"pwc", "tf_propagation", "rk4_unitary", "gen_dus_rk4"}
+    assert set(propagation.state_provider) >= {"ode_solver", "ode_solver_final_state"}
+    assert set(propagation.solver_dict) == {"rk4", "rk38", "rk5", "tsit5"}
+    assert set(propagation.step_dict) == {"lindblad", "schrodinger", "von_neumann"}
+    assert propagation.solver_slicing == o.solver_slicing
+
+
+def test_workload_is_deterministic_and_shardable():
+    a = workloads.make_workload(2, B=6, N=16)
+    b = workloads.make_workload(2, B=6, N=16)
+    assert np.array_equal(a.signals, b.signals)
+    lo = workloads.make_workload(2, B=3, N=16, b_offset=0)
+    hi = workloads.make_workload(2, B=3, N=16, b_offset=3)
+    assert np.array_equal(np.concatenate([lo.signals, hi.signals]), a.signals)
+    assert np.abs(a.h0 - a.h0.conj().T).max() < 1e-12 * np.abs(a.h0).max()
+    assert a.hks.shape == (2, 9, 9) and a.fr_phase.shape == (6, 9)
+    assert abs(a.ts[1] - a.ts[0] - a.dt) < 1e-25
+
+
+def test_time_grid_check_raises_like_reference():
+    """propagation.py:301-308: non-uniform time grids raise the reference's message."""
+    ts = np.linspace(0, 1, 10) ** 2
+    with pytest.raises(Exception, match="Something with the times happend"):
+        propagation._uniform_ts([ts, ts])
+    good = np.linspace(0.5e-11, 9.5e-11, 10)
+    assert np.allclose(propagation._uniform_ts([good, good]), good)
+
+
+class _Instr:
+    def __init__(self, name):
+        self.name = name
+
+    def get_key(self):
+        return self.name
+
+
+def test_gather_pwc_inputs_branches():
+    m = workloads.ChipModel((3, 3), (5e9, 5.6e9), (-210e6, -240e6), {(0, 1): 20e6}, {"d1": 0, "d2": 1}, t1=(27e-6, 23e-6), t2star=(39e-6, 31e-6))
+    ts = workloads.centred_time_grid(0.0, 2e-10, 100e9)
+    sig = {"g": {"d1": {"values": np.sin(ts * 1e10), "ts": ts}, "d2": {"values": np.cos(ts * 1e10), "ts": ts}}}
+    gen = workloads.SignalSource(sig)
+    h0, hks, signals, ts_out, dt, col = propagation.gather_pwc_inputs(m, gen, _Instr("g"))
+    assert h0.shape == (9, 9) and hks.shape == (2, 9, 9) and signals.shape == (2, 20) and col is None
+    assert abs(dt - 1e-11) < 1e-24
+    m.controllability = False
+    h0b, hksb, sigb, ts_b, dt_b, _ = propagation.gather_pwc_inputs(m, gen, _Instr("g"))
+    assert h0b.shape == (20, 9, 9) and hksb is None and sigb is None and ts_b.shape == (19,)
+    want = o.sum_h0_hks(h0, hks, signals)
+    assert np.abs(h0b - want).max() < 1e-6 * np.abs(want).max()
+    m.controllability = True
+    m.set_lindbladian(True)
+    m.set_max_excitations(2)
+    h0c, hksc, _, _, _, colc = propagation.gather_pwc_inputs(m, gen, _Instr("g"))
+    assert h0c.shape == (6, 6) and hksc.shape == (2, 6, 6) and len(colc) == 2 and colc[0].shape == (6, 6)
+
+
+def test_shard_bounds_cover_batch():
+    for B in (1, 7, 256, 4096):
+        for world in (1, 2, 3, 8):
+            spans = [c3dist.shard_bounds(B, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [h - l for l, h in spans]
+            assert max(sizes) - min(sizes) <= 1 and max(sizes) == c3dist.max_shard(B, world)
+
+
+def test_algorithmic_flops_formula():
+    # SURVEY.md 8d worked value: cfg2, Pade-9, s=0 -> 43 416 flop/slice
+    assert abs(o.algorithmic_flops_per_slice(9, 2, 9, 0) - 43416.0) < 1e-6
+    assert abs(o.algorithmic_flops_per_slice(3, 1, 7, 0) - 1404.0) < 1e-6
+
+
+def test_taylor_thresholds_are_safe():
+    """The device kernels replace Pade+solve by a scaled Taylor polynomial (c3p_common.h):
+    check on the CPU that degree m at its threshold reproduces expm to rounding level."""
+    import math
+
+    th = {4: 4.0e-4, 8: 5.45e-2, 12: 3.18e-1, 16: 8.16e-1, 20: 1.49}
+    rng = np.random.default_rng(0)
+    for m, theta in th.items():
+        A = rng.normal(size=(9, 9)) + 1j * rng.normal(size=(9, 9))
+        A = A - A.conj().T
+        A *= theta / np.abs(A).sum(0).max()
+        T = sum(np.linalg.matrix_power(A, k) / math.factorial(k) for k in range(m + 1))
+        assert np.abs(T - o.expm(A)).max() < 1e-15 * max(1.0, 10 * theta)

@@ -1,0 +1,248 @@
+"""GPU tests of the drop-in surface: providers, tf_utils counterparts, golden fixtures,
+edge cases.  Everything goes through the C ABI (libc3prop.so).  -m gpu."""
+import numpy as np
+import pytest
+
+from oracle import c3_oracle as o
+from c3_amd import workloads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def prop(lib):
+    from c3_amd import propagation, _lib
+
+    _lib.require_gpu()
+    return propagation
+
+
+class Instr:
+    def __init__(self, name, t_start=0.0, t_end=0.0):
+        self.name, self.t_start, self.t_end = name, t_start, t_end
+
+    def get_key(self):
+        return self.name
+
+
+def two_transmon_setup(N=60, lind=False):
+    m = workloads.ChipModel((3, 3), (5e9, 5.6e9), (-210e6, -240e6), {(0, 1): 20e6}, {"d1": 0, "d2": 1},
+                            t1=(27e-6, 23e-6), t2star=(39e-6, 31e-6))
+    ts = (np.arange(N) + 0.5) * 1e-11  # centred grid (devices.py:107-121)
+    T = N * 1e-11
+    env = np.exp(-((ts - T / 2) ** 2) / (2 * (T / 4) ** 2))
+    sig = {"g": {"d1": {"values": 2 * np.pi * 4e8 * env * np.cos(2 * np.pi * 5.05e9 * ts), "ts": ts},
+                 "d2": {"values": 2 * np.pi * 3e8 * env * np.cos(2 * np.pi * 5.65e9 * ts + 1.0), "ts": ts}}}
+    m.set_lindbladian(lind)
+    return m, workloads.SignalSource(sig), Instr("g", 0.0, T)
+
+
+@pytest.mark.parametrize("lind", [False, True])
+def test_pwc_provider_matches_oracle_pwc(prop, lind):
+    m, gen, instr = two_transmon_setup(N=40 if lind else 120, lind=lind)
+    stack = o.compute_folding_stack(len(gen.generate_signals(instr)["d1"]["ts"]))
+    got = prop.unitary_provider["pwc"](m, gen, instr, stack, None)
+    ref = o.pwc(m, gen, instr, stack, None)
+    assert np.linalg.norm(got["U"] - ref["U"]) < 1e-10
+    assert np.abs(got["dUs"] - ref["dUs"]).max() < 1e-12
+    assert np.array_equal(got["ts"], ref["ts"])
+
+
+def test_pwc_branch_b_and_excitation_cut(prop):
+    m, gen, instr = two_transmon_setup(N=50)
+    m.controllability = False  # use_control_fields = False (experiment.py:470)
+    m.set_max_excitations(2)
+    got = prop.pwc(m, gen, instr, [], 10)
+    ref = o.pwc(m, gen, instr, None, 10)
+    assert got["U"].shape == (9, 9) and got["dUs"].shape == (50, 9, 9)
+    assert np.linalg.norm(got["U"] - ref["U"]) < 1e-10
+    assert np.abs(got["dUs"] - ref["dUs"]).max() < 1e-12
+
+
+@pytest.mark.parametrize("q", ["q1", "q2"])
+def test_golden_transmon_expanded_on_device(prop, golden_dir, q):
+    """reference test/test_transmon_expanded.py:252-280 through the HIP path (D=24 cut to 14)."""
+    t = np.load(golden_dir + "/transmon_expanded.npz")
+    cut = o.excitation_cutter((6, 4), 4)
+    Hc = np.stack([o.cut_excitations(h, cut) for h in t["hamiltonians_" + q]])
+    ts = t["ts_" + q][1:]
+    r = prop.propagate_batch(Hc, None, None, ts[1] - ts[0], want_dUs=True)
+    U = o.blowup_excitations(np.asarray(r["U"][0]), cut)
+    dUs = np.stack([o.blowup_excitations(d, cut) for d in np.asarray(r["dUs"][0])])
+    assert np.abs(dUs - t["partial_propagators_" + q]).max() < 1e-12
+    assert np.linalg.norm(U - t["propagators_" + q]) < 1e-11
+
+
+def test_golden_lindblad_two_qubit_on_device(prop, golden_dir):
+    g = np.load(golden_dir + "/two_qubit.npz")
+    m = workloads.ChipModel((2, 2), (5e9, 5.6e9), (0, 0), {(0, 1): 20e6}, {"d1": 0, "d2": 1}, t1=(20e-6, 20e-6), t2star=(40e-6, 40e-6))
+    sig = np.stack([g["sig_d1"], g["sig_d2"]])
+    hks = np.stack([g["hk_d1"], g["hk_d2"]])
+    r = prop.propagate_batch(g["hdrift"], hks, sig[None], g["ts"][1] - g["ts"][0], col_ops=np.asarray(m.col_ops), lindbladian=True)
+    assert np.linalg.norm(np.asarray(r["U"][0]) - g["lindblad_propagator"]) < 1e-11
+
+
+def test_golden_tf_utils_on_device(prop, golden_dir):
+    g = np.load(golden_dir + "/tf_utils.npz")
+    for i in range(2):
+        np.testing.assert_allclose(prop.tf_kron(g[f"tf_kron_{i}_inA"], g[f"tf_kron_{i}_inB"]), g[f"tf_kron_{i}_desired"], rtol=1e-7)
+        np.testing.assert_allclose(prop.tf_spre(g[f"tf_spre_{i}_in"]), g[f"tf_spre_{i}_desired"], rtol=1e-7)
+        np.testing.assert_allclose(prop.tf_spost(g[f"tf_spost_{i}_in"]), g[f"tf_spost_{i}_desired"], rtol=1e-7)
+        np.testing.assert_allclose(prop.tf_super(g[f"tf_super_{i}_in"]), g[f"tf_super_{i}_desired"], rtol=1e-7)
+        np.testing.assert_allclose(prop.Id_like(g[f"Id_like_{i}_in"]), g[f"Id_like_{i}_desired"], rtol=1e-7)
+
+
+@pytest.mark.parametrize("D", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 24, 27])
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_every_dimension_and_kernel(prop, D, force_generic):
+    """Each small-D instantiation (2..10), the generic LDS kernel and their hand-over."""
+    from c3_amd import _lib
+
+    rng = np.random.default_rng(D)
+    B, K, N = 3, 2, 37
+    h0 = rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))
+    h0 = (h0 + h0.conj().T) * 2e10
+    hks = rng.normal(size=(K, D, D)) + 1j * rng.normal(size=(K, D, D))
+    hks = hks + np.conj(np.swapaxes(hks, -1, -2))
+    sig = rng.normal(size=(B, K, N)) * 1e9
+    dt = 1e-11 / max(1.0, D / 8)
+    r = prop.propagate_batch(h0, hks, sig, dt, force_generic=force_generic)
+    ref = o.propagate_batch(h0, hks, sig, dt)
+    assert max(np.linalg.norm(np.asarray(r["U"][b]) - ref[b]) for b in range(B)) < 1e-10
+    expect = "smalld" if (D <= 10 and not force_generic) else "generic_lds"
+    assert _lib.last_kernel() == expect
+
+
+def test_edge_cases(prop):
+    wl = workloads.make_workload(2, B=1, N=1)
+    r = prop.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt, want_dUs=True)
+    ref = o.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt)
+    assert np.abs(np.asarray(r["U"]) - ref).max() < 1e-13
+    assert np.abs(np.asarray(r["dUs"][0, 0]) - ref[0]).max() < 1e-13
+    # empty batch: nothing to do, no error
+    e = prop.propagate_batch(wl.h0, wl.hks, np.zeros((0, 2, 5)), wl.dt)
+    assert tuple(e["U"].shape) == (0, 9, 9)
+    # zero Hamiltonian -> identity; huge norm -> squarings
+    z = prop.propagate_batch(np.zeros((9, 9)), np.zeros((2, 9, 9)), np.zeros((2, 2, 7)), 1.0)
+    assert np.abs(np.asarray(z["U"]) - np.eye(9)).max() == 0.0
+    big = prop.propagate_batch(wl.h0 * 40, wl.hks, np.zeros((1, 2, 3)), wl.dt)
+    bref = o.propagate_batch(wl.h0 * 40, wl.hks, np.zeros((1, 2, 3)), wl.dt)
+    assert np.linalg.norm(np.asarray(big["U"][0]) - bref[0]) < 1e-10
+    # ragged segmentation: N prime, B not a multiple of 4
+    wl2 = workloads.make_workload(2, B=7, N=211)
+    r2 = prop.propagate_batch(wl2.h0, wl2.hks, wl2.signals, wl2.dt, fr_phase=wl2.fr_phase)
+    ref2 = o.propagate_batch(wl2.h0, wl2.hks, wl2.signals, wl2.dt, fr_phase=wl2.fr_phase)
+    assert max(np.linalg.norm(np.asarray(r2["U"][b]) - ref2[b]) for b in range(7)) < 1e-10
+
+
+def test_errors_carry_reference_prefix(prop):
+    from c3_amd._lib import C3PropError
+
+    wl = workloads.make_workload(1, B=2, N=4)
+    with pytest.raises(C3PropError, match="C3:Error"):
+        prop.propagate_batch(wl.h0, wl.hks, wl.signals[:, :, :0], wl.dt)  # empty time grid
+    with pytest.raises(C3PropError, match="C3:Error"):
+        prop.propagate_batch(wl.h0, wl.hks[:0], wl.signals, wl.dt)  # channel mismatch
+    with pytest.raises(C3PropError, match="C3:Error"):
+        prop.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt, lindbladian=True)  # no col_ops
+
+
+def test_per_sample_operators(prop):
+    """ModelLearning-style batches: every sample has its own drift/control Hamiltonians."""
+    wl = workloads.make_workload(2, B=6, N=45)
+    rng = np.random.default_rng(3)
+    h0b = np.stack([wl.h0 * (1 + 1e-3 * rng.normal()) for _ in range(6)])
+    hkb = np.stack([wl.hks * (1 + 1e-2 * rng.normal()) for _ in range(6)])
+    r = prop.propagate_batch(h0b, hkb, wl.signals, wl.dt)
+    for b in range(6):
+        ref = o.pwc_arrays(h0b[b], hkb[b], wl.signals[b], wl.dt)["U"]
+        assert np.linalg.norm(np.asarray(r["U"][b]) - ref) < 1e-10
+
+
+@pytest.mark.parametrize("D,N", [(3, 1), (9, 2), (9, 700), (14, 33), (27, 12)])
+def test_matmul_chain_orders(prop, D, N):
+    rng = np.random.default_rng(N)
+    M = (rng.normal(size=(2, N, D, D)) + 1j * rng.normal(size=(2, N, D, D))) / np.sqrt(D)
+    left = np.asarray(prop.tf_matmul_left(M))
+    right = np.asarray(prop.tf_matmul_right(M))
+    tree = np.asarray(prop.tf_matmul_n(M[0], o.compute_folding_stack(N)))
+    for b in range(2):
+        lref, rref = o.tf_matmul_left(M[b]), o.tf_matmul_right(M[b])
+        assert np.abs(left[b] - lref).max() < 1e-11 * max(1, np.abs(lref).max())
+        assert np.abs(right[b] - rref).max() < 1e-11 * max(1, np.abs(rref).max())
+    assert np.abs(tree - o.tf_matmul_n(M[0])).max() < 1e-11 * max(1, np.abs(tree).max())
+
+
+def test_expm_and_series(prop):
+    rng = np.random.default_rng(1)
+    for D, nrm in [(3, 0.01), (8, 1.0), (9, 6.0), (20, 2.5)]:
+        A = rng.normal(size=(5, D, D)) + 1j * rng.normal(size=(5, D, D))
+        A *= (nrm / np.abs(A).sum(axis=-2).max(axis=-1))[:, None, None]
+        assert np.abs(np.asarray(prop.expm(A)) - o.expm(A)).max() < 1e-12 * np.exp(nrm)
+    # reference test/test_exp.py:9-16: series expm against the closed form
+    theta = 0.7
+    P = np.kron(np.array([[0, 1], [1, 0]]), np.array([[1, 0], [0, -1]]))
+    want = np.cos(theta) * np.eye(4) + 1j * np.sin(theta) * P
+    assert np.abs(prop.tf_expm(1j * theta * P, 100) - want).max() < 1e-6
+    assert np.abs(prop.tf_expm_dynamic(1j * theta * P, 1e-12) - want).max() < 1e-10
+    assert np.abs(np.asarray(prop.expm(1j * theta * P)) - want).max() < 1e-14
+
+
+def test_rk4_unitary_provider(prop):
+    m, gen, instr = two_transmon_setup(N=30)
+    got = prop.rk4_unitary(m, gen, instr)
+    # oracle: same arrays through the restated gen_u_rk4 / gen_dus_rk4
+    d = prop.get_hs_of_t_ts(m, gen, instr, 2)
+    ref = o.rk4_unitary_arrays(d["Hs"], d["dt"], 9)
+    assert got["U"].shape == (9, 9) and got["dUs"].shape == ref["dUs"].shape
+    assert np.abs(got["U"] - ref["U"]).max() < 1e-12
+    assert np.abs(got["dUs"] - ref["dUs"]).max() < 1e-12
+    assert gen.resolution == 100e9
+    # branch B (per-sample Hamiltonians) and the list helpers
+    m.controllability = False
+    got_b = prop.rk4_unitary(m, gen, instr)
+    assert np.abs(got_b["U"] - ref["U"]).max() < 1e-9
+    lst = prop.gen_dus_rk4(d["Hs"], d["dt"])
+    assert len(lst) == ref["dUs"].shape[0] and np.abs(lst[3] - ref["dUs"][3]).max() < 1e-12
+    assert np.abs(prop.gen_u_rk4(d["Hs"], d["dt"], 9) - ref["U"]).max() < 1e-12
+    psi = np.zeros(9, complex)
+    psi[2] = 1
+    assert np.abs(prop.rk4_step(d["Hs"][:3], psi, d["dt"]) - o.rk4_step(d["Hs"][:3], psi, d["dt"])).max() < 1e-13
+
+
+def test_state_providers(prop):
+    m, gen, instr = two_transmon_setup(N=40)
+    psi0 = m.get_init_state()
+    for solver in ("rk4", "tsit5"):
+        got = prop.state_provider["ode_solver"](m, gen, instr, psi0, solver, "schrodinger")
+        ref = o.ode_solver(m, gen, instr, psi0, solver, "schrodinger")
+        assert np.abs(got["states"] - ref["states"]).max() < 1e-11
+        fin = prop.ode_solver_final_state(m, gen, instr, psi0, solver, "schrodinger")
+        assert np.abs(fin["states"] - ref["states"][-1]).max() < 1e-11
+    m.set_lindbladian(True)
+    rho0 = psi0 @ psi0.conj().T
+    got = prop.ode_solver(m, gen, instr, rho0, "rk4", "von_neumann")  # forced to lindblad (:693-695)
+    ref = o.ode_solver(m, gen, instr, rho0, "rk4", "von_neumann")
+    assert np.abs(got["states"] - ref["states"]).max() < 1e-11
+    assert abs(np.trace(got["states"][-1]) - 1) < 1e-6
+
+
+def test_full_size_cfg2_properties(prop):
+    """BASELINE cfg2 at full size (B=256, N=1000): size-independent properties + spot parity."""
+    import torch
+
+    wl = workloads.make_workload(2)
+    dev = torch.device("cuda:0")
+    r = prop.propagate_batch(torch.as_tensor(wl.h0, device=dev), torch.as_tensor(wl.hks, device=dev),
+                             torch.as_tensor(wl.signals, device=dev), wl.dt, fr_phase=torch.as_tensor(wl.fr_phase, device=dev))
+    U = r["U"].cpu().numpy()
+    eye = np.eye(9)
+    assert max(np.linalg.norm(U[b].conj().T @ U[b] - eye) for b in range(wl.B)) < 1e-11  # unitarity
+    ref = o.propagate_batch(wl.h0, wl.hks, wl.signals[[0, 97, 255]], wl.dt, fr_phase=wl.fr_phase[[0, 97, 255]])
+    assert max(np.linalg.norm(U[b] - ref[i]) for i, b in enumerate([0, 97, 255])) < 1e-10
+    # splitting the time axis: U(0..N) = U(N/2..N) U(0..N/2) (segment associativity)
+    a = prop.propagate_batch(wl.h0, wl.hks, wl.signals[:4, :, :500], wl.dt)["U"]
+    b = prop.propagate_batch(wl.h0, wl.hks, wl.signals[:4, :, 500:], wl.dt)["U"]
+    ph = np.exp(1j * wl.fr_phase[:4])
+    comb = ph[:, :, None] * (np.asarray(b) @ np.asarray(a))
+    assert max(np.linalg.norm(comb[i] - U[i]) for i in range(4)) < 1e-11

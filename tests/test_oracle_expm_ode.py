@@ -1,0 +1,164 @@
+"""Oracle self-consistency: expm vs scipy, ordered products, ODE solvers vs PWC.  No GPU."""
+import numpy as np
+import pytest
+import scipy.linalg as sl
+
+from oracle import c3_oracle as o
+from c3_amd import workloads
+
+
+@pytest.mark.parametrize("norm", [1e-3, 0.1, 0.5, 1.5, 3.0, 7.0, 30.0])
+@pytest.mark.parametrize("D", [3, 9, 27])
+def test_expm_vs_scipy(D, norm):
+    rng = np.random.default_rng(D * 1000 + int(norm * 10))
+    A = rng.normal(size=(6, D, D)) + 1j * rng.normal(size=(6, D, D))
+    A = A - np.conj(np.swapaxes(A, -1, -2))  # skew-Hermitian like -iH dt
+    A = A * (norm / np.abs(A).sum(axis=-2).max(axis=-1))[:, None, None]
+    E = o.expm(A)
+    ref = np.stack([sl.expm(a) for a in A])
+    assert np.abs(E - ref).max() < 2e-13 * max(1.0, norm)
+    eye = np.eye(D)
+    assert max(np.abs(e.conj().T @ e - eye).max() for e in E) < 1e-12 * max(1.0, norm)
+
+
+def test_expm_plan_orders():
+    th = o.PADE_THETA
+    for val, order in [(th[0] * 0.99, 3), (th[0] * 1.01, 5), (th[1] * 1.01, 7), (th[2] * 1.01, 9), (th[3] * 1.01, 13)]:
+        A = np.eye(4)[None] * val
+        assert int(o.expm_plan(A)[1][0]) == order
+    # TF's squaring rule: floor(log2(norm/theta13)) clipped at 0
+    assert int(o.expm_plan(np.eye(3)[None] * 6.95)[2][0]) == 0
+    assert int(o.expm_plan(np.eye(3)[None] * (2 * th[4] * 1.01))[2][0]) == 1
+    assert int(o.expm_plan(np.zeros((1, 3, 3)))[2][0]) == 0
+
+
+def test_expm_zero_and_real():
+    assert np.array_equal(o.expm(np.zeros((2, 5, 5))), np.broadcast_to(np.eye(5), (2, 5, 5)))
+    rng = np.random.default_rng(1)
+    A = rng.normal(size=(4, 4))
+    assert np.abs(o.expm(A) - sl.expm(A)).max() < 1e-13
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 7, 8, 700])
+def test_matmul_n_orders(N):
+    rng = np.random.default_rng(N)
+    M = rng.normal(size=(N, 3, 3)) + 1j * rng.normal(size=(N, 3, 3))
+    M /= 2.0
+    want = np.eye(3)
+    for k in range(N):
+        want = M[k] @ want
+    stack = o.compute_folding_stack(N)
+    assert np.abs(o.tf_matmul_n(M, stack) - want).max() < 1e-9 * max(1.0, np.abs(want).max())
+    assert np.abs(o.tf_matmul_left(M) - want).max() < 1e-9 * max(1.0, np.abs(want).max())
+    right = np.eye(3)
+    for k in range(N):
+        right = right @ M[k]
+    assert np.abs(o.tf_matmul_right(M) - right).max() < 1e-9 * max(1.0, np.abs(right).max())
+
+
+def test_folding_stack():
+    assert o.compute_folding_stack(1) == []
+    assert o.compute_folding_stack(8) == ["even", "even", "even"]
+    assert o.compute_folding_stack(700) == ["even", "even", "odd", "even", "even", "even", "odd", "even", "odd", "even"]
+
+
+def test_lindblad_without_collapse_is_unitary_superop():
+    wl = workloads.make_workload(4, B=1, N=12)
+    zero = np.zeros_like(wl.col_ops)
+    L = o.pwc_arrays(wl.h0, wl.hks, wl.signals[0], wl.dt, col_ops=zero, lindbladian=True)["U"]
+    U = o.pwc_arrays(wl.h0, wl.hks, wl.signals[0], wl.dt)["U"]
+    assert np.abs(L - np.kron(U, U.conj())).max() < 1e-12
+
+
+def test_lindblad_trace_preserving():
+    wl = workloads.make_workload(4, B=1, N=20)
+    L = o.pwc_arrays(wl.h0, wl.hks, wl.signals[0], wl.dt, col_ops=wl.col_ops, lindbladian=True)["U"]
+    vec_id = np.eye(wl.D).reshape(-1)
+    assert np.abs(vec_id @ L - vec_id).max() < 1e-12  # tr(rho) is conserved
+    assert np.abs(o.tf_dU_of_t_lind(wl.h0, wl.hks, wl.col_ops, wl.signals[0][:, 3], wl.dt)
+                  - o.tf_propagation_lind(wl.h0, wl.hks, wl.col_ops, wl.signals[0][:, 3:4], wl.dt)[0]).max() < 1e-13
+
+
+def test_interpolation_grid_and_values():
+    ts = (np.arange(10) + 0.5) * 1e-11
+    sig = np.sin(np.arange(10) * 0.7)
+    g = o.interpolation_times(ts, 2)
+    assert g.shape == (21,) and abs(g[-1] - (ts[-1] + 1e-11)) < 1e-25
+    v = o.interpolate_signal(ts, sig, 2)
+    assert np.allclose(v[0:19:2], sig, atol=1e-12)
+    assert np.allclose(v[1:18:2], 0.5 * (sig[:-1] + sig[1:]), atol=1e-12)
+    assert np.isclose(v[-1], sig[-1] + (sig[-1] - sig[-2]))  # linear extrapolation
+    for code in (-1, -2):
+        assert o.interpolation_times(ts, code).shape == (60,)
+
+
+def _fine_grid_problem(N=3000, dt=1e-12):
+    """cfg1 operators on a 10x finer grid so that ||H dt|| ~ 0.06 and RK errors are small."""
+    wl = workloads.make_workload(1, B=1, N=8)
+    ts = (np.arange(N) + 0.5) * dt
+    T = N * dt
+    f = lambda t: 2 * np.pi * 1e9 * 0.4 * np.exp(-((t - T / 2) ** 2) / (2 * (T / 4) ** 2)) * np.cos(2 * np.pi * 5.05e9 * t + 0.3)
+    # ODE step i integrates over [ts[i], ts[i]+dt] (window Hs[2i:2i+3], propagation.py:714-717),
+    # i.e. half a slice later than PWC slice i; the PWC comparison signal is sampled there.
+    return wl.h0, wl.hks, f(ts)[None], f(ts + dt / 2)[None], ts, dt
+
+
+@pytest.mark.parametrize("solver,tol", [("rk4", 2e-5), ("rk38", 2e-5), ("rk5", 1e-5), ("tsit5", 1e-5)])
+def test_ode_converges_to_pwc(solver, tol):
+    """ODE parity is unpinned by reference goldens: pin the oracle's solvers by
+    convergence to U psi0 of the PWC propagator on a fine grid."""
+    h0, hks, sig, sig_mid, ts, dt = _fine_grid_problem()
+    psi0 = np.zeros((3, 1), complex)
+    psi0[0, 0] = 1.0
+    out = o.ode_solver_arrays(h0, hks, sig, ts, psi0, solver, "schrodinger", final_only=True)
+    U = o.pwc_arrays(h0, hks, sig_mid, dt)["U"]
+    # PWC holds the signal constant over a slice, the ODE path interpolates it linearly:
+    # the two discretisations agree to O(dt^2) of the signal curvature plus the RK error.
+    assert np.abs(out["states"] - U @ psi0).max() < 50 * tol
+    assert abs(np.linalg.norm(out["states"]) - 1.0) < tol
+
+
+def test_ode_density_matrix_invariants():
+    """reference test/test_two_qubits.py:228-251: tr rho = 1 (6 decimals)."""
+    wl = workloads.make_workload(4, B=1, N=60)
+    psi = np.zeros((wl.D, 1), complex)
+    psi[1, 0] = 1.0
+    rho0 = psi @ psi.conj().T
+    for step, col in (("von_neumann", None), ("lindblad", wl.col_ops)):
+        out = o.ode_solver_arrays(wl.h0, wl.hks, wl.signals[0], wl.ts, rho0, "rk4", step, col=col)
+        assert out["states"].shape == (60, wl.D, wl.D)
+        assert abs(np.trace(out["states"][-1]) - 1.0) < 1e-6
+    h0, hks, sig, _, ts, dt = _fine_grid_problem(N=600)
+    p3 = np.zeros((3, 1), complex)
+    p3[1, 0] = 1.0
+    vn = o.ode_solver_arrays(h0, hks, sig, ts, p3 @ p3.conj().T, "rk4", "von_neumann")["states"][-1]
+    ps = o.ode_solver_arrays(h0, hks, sig, ts, p3, "rk4", "schrodinger")["states"][-1]
+    assert np.abs(vn - ps @ ps.conj().T).max() < 1e-6
+
+
+def test_rk4_unitary_family():
+    wl = workloads.make_workload(1, B=1, N=40)
+    # prop_res = 2: Hs on a grid twice as fine (propagation.py:143,225)
+    sig2 = np.repeat(wl.signals[0], 2, axis=1)
+    Hs = o.sum_h0_hks(wl.h0, wl.hks, sig2)
+    dt = wl.dt
+    r = o.rk4_unitary_arrays(Hs, dt, wl.D)
+    assert r["dUs"].shape == (39, wl.D, wl.D)
+    # gen_du_rk4 stacks propagated basis vectors as ROWS, gen_u_rk4 returns columns
+    chain = np.eye(wl.D)
+    for d in r["dUs"]:
+        chain = d.T @ chain
+    assert np.abs(chain - r["U"]).max() < 1e-12
+    assert np.abs(r["U"].conj().T @ r["U"] - np.eye(wl.D)).max() < 5e-2  # RK4 is not unitary at ||H dt|| ~ 0.6
+
+
+def test_evaluate_sequences_and_trott():
+    rng = np.random.default_rng(3)
+    gates = {k: rng.normal(size=(3, 3)) + 0j for k in "abc"}
+    out = o.evaluate_sequences(gates, [["a", "b", "c"], []])
+    assert np.allclose(out[0], gates["c"] @ gates["b"] @ gates["a"])
+    assert np.array_equal(out[1], np.eye(3))
+    wl = workloads.make_workload(1, B=1, N=4)
+    d = o.pwc_trott_drift(wl.h0, wl.hks, np.array([wl.signals[0, 0, 2]]).reshape(1, 1, 1), wl.dt)
+    e = o.tf_dU_of_t(wl.h0, wl.hks, [wl.signals[0, 0, 2]], wl.dt)
+    assert d.shape == e.shape

@@ -1,0 +1,93 @@
+"""Pin the CPU oracle to the golden arrays the reference's own tests hold for the path
+ and to closed forms.  Runs without a GPU."""
+import numpy as np
+import pytest
+
+from oracle import c3_oracle as o
+from c3_amd import workloads
+
+
+@pytest.fixture(scope="module")
+def two_qubit(golden_dir):
+    return np.load(golden_dir + "/two_qubit.npz")
+
+
+def test_two_qubit_unitary_kat(two_qubit):
+    """reference test/test_two_qubits.py:46-62 (6 decimals there; here 1e-12)."""
+    g = two_qubit
+    sig = np.stack([g["sig_d1"], g["sig_d2"]])
+    hks = np.stack([g["hk_d1"], g["hk_d2"]])
+    dt = g["ts"][1] - g["ts"][0]
+    r = o.pwc_arrays(g["hdrift"], hks, sig, dt, folding_stack=o.compute_folding_stack(700))
+    assert np.linalg.norm(r["U"] - g["propagator"]) < 1e-12
+    assert r["dUs"].shape == (700, 4, 4)
+
+
+def test_two_qubit_lindblad_kat(two_qubit):
+    """reference test/test_two_qubits.py:193-213, propagate_batch_size=360; collapse
+    operators rebuilt from conftest.py:263-285 (t1=20us, t2*=40us) via chip.py:205-242."""
+    g = two_qubit
+    m = workloads.ChipModel((2, 2), (5e9, 5.6e9), (0, 0), {(0, 1): 20e6}, {"d1": 0, "d2": 1}, t1=(20e-6, 20e-6), t2star=(40e-6, 40e-6))
+    assert np.abs(m.drift_ham - g["hdrift"]).max() / np.abs(g["hdrift"]).max() < 1e-14
+    assert np.abs(m.control_hams["d1"] - g["hk_d1"]).max() < 1e-14
+    sig = np.stack([g["sig_d1"], g["sig_d2"]])
+    hks = np.stack([g["hk_d1"], g["hk_d2"]])
+    dt = g["ts"][1] - g["ts"][0]
+    r = o.pwc_arrays(g["hdrift"], hks, sig, dt, col_ops=m.col_ops, lindbladian=True, batch_size=360)
+    assert np.linalg.norm(r["U"] - g["lindblad_propagator"]) < 1e-12
+    # dissipation is genuinely pinned: the result is far from the unitary superoperator
+    U = g["propagator"]
+    assert np.linalg.norm(np.kron(U, U.conj()) - g["lindblad_propagator"]) > 1e-5
+
+
+@pytest.mark.parametrize("q", ["q1", "q2"])
+def test_transmon_expanded_kat(golden_dir, q):
+    """reference test/test_transmon_expanded.py:252-280: branch B (per-slice H), dims (6,4),
+    max_excitations=4 -> 14-dim cut, blow-up of U and of every partial propagator."""
+    t = np.load(golden_dir + "/transmon_expanded.npz")
+    cut = o.excitation_cutter((6, 4), 4)
+    assert cut.shape == (14, 24)
+    H = t["hamiltonians_" + q]
+    Hc = np.stack([o.cut_excitations(h, cut) for h in H])
+    ts = t["ts_" + q][1:]
+    dt = ts[1] - ts[0]
+    r = o.pwc_arrays(Hc, None, None, dt, cutter=cut)
+    assert np.abs(r["dUs"] - t["partial_propagators_" + q]).max() < 1e-13
+    assert np.linalg.norm(r["U"] - t["propagators_" + q]) < 1e-12
+
+
+def test_tf_utils_goldens(golden_dir):
+    """reference test/test_tf_utils.py:79-111."""
+    g = np.load(golden_dir + "/tf_utils.npz")
+    for i in range(2):
+        np.testing.assert_allclose(o.tf_kron(g[f"tf_kron_{i}_inA"], g[f"tf_kron_{i}_inB"]), g[f"tf_kron_{i}_desired"], rtol=1e-7)
+        np.testing.assert_allclose(o.tf_spre(g[f"tf_spre_{i}_in"]), g[f"tf_spre_{i}_desired"], rtol=1e-7)
+        np.testing.assert_allclose(o.tf_spost(g[f"tf_spost_{i}_in"]), g[f"tf_spost_{i}_desired"], rtol=1e-7)
+        np.testing.assert_allclose(o.tf_super(g[f"tf_super_{i}_in"]), g[f"tf_super_{i}_desired"], rtol=1e-7)
+        np.testing.assert_allclose(o.Id_like(g[f"Id_like_{i}_in"]), g[f"Id_like_{i}_desired"], rtol=1e-7)
+
+
+def test_tunable_coupler_dUs_are_unitary(golden_dir):
+    """reference test/test_tunable_coupler.py:393-403 stores every 50th dU (D=27); the model
+    behind them is out of scope, so only the size-independent property is used."""
+    g = np.load(golden_dir + "/tunable_coupler.npz")
+    d = g["dUs"]
+    eye = np.eye(27)
+    assert max(np.abs(x.conj().T @ x - eye).max() for x in d) < 1e-12
+
+
+def _pauli_problem(theta, rng):
+    """reference test/conftest.py:41-60 + test/test_exp.py:9-32: exp(i theta P) = cos I + i sin P."""
+    paulis = [np.array([[0, 1], [1, 0]]), np.array([[0, -1j], [1j, 0]]), np.array([[1, 0], [0, -1]])]
+    P = np.eye(1)
+    for _ in range(3):
+        P = np.kron(P, paulis[rng.integers(3)])
+    return 1j * theta * P, np.cos(theta) * np.eye(8) + 1j * np.sin(theta) * P
+
+
+@pytest.mark.parametrize("theta", [1e-3, 0.3, 1.0, 2 * np.pi * 0.7, 11.0])
+def test_exp_closed_form(theta):
+    rng = np.random.default_rng(5)
+    A, want = _pauli_problem(theta, rng)
+    assert np.abs(o.expm(A) - want).max() < 1e-13 * max(1.0, theta)
+    assert np.abs(o.tf_expm(A, 100) - want).max() < 1e-6 * max(1.0, np.exp(theta) * 1e-8)
