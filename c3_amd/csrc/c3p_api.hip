@@ -11,6 +11,7 @@
 #include "c3p_kernels.h"
 #include "c3p_ode.h"
 #include "c3p_smalld.h"
+#include "c3p_midd.h"
 
 namespace {
 
@@ -297,6 +298,105 @@ int run_pwc_smalld(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const 
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Mid-D MFMA path (13 <= Dm <= 40): one 4-wave workgroup per chain, matrices as LDS images
+// ---------------------------------------------------------------------------
+int combine_midd(DeviceWs* w, const cplx* cur, int B, int count, int Dm, int right_order,
+                 const double* fr_phase, cplx* U_out, hipStream_t st) {
+  const size_t msz = (size_t)Dm * Dm * sizeof(cplx);
+  Slot next_slot = SL_SEG_B;
+  while (true) {
+    MidArgs c = {};
+    c.mode = C3P_MODE_GIVEN;
+    c.mats = cur;
+    c.B = B;
+    c.N = count;
+    c.Dm = Dm;
+    c.right_order = right_order;
+    if (count <= 8) {
+      c.S = 1;
+      c.seg_out = U_out;
+      c.fr_phase = fr_phase;
+    } else {
+      c.S = (count + 3) / 4;
+      void* v;
+      if (ws_get(w, next_slot, (size_t)B * c.S * msz, &v)) return -1;
+      c.seg_out = (cplx*)v;
+    }
+    c.Lmax = (count + c.S - 1) / c.S;
+    HIP_TRY(c3p_launch_midd_chain(c, st));
+    if (c.seg_out == U_out) break;
+    cur = c.seg_out;
+    count = c.S;
+    next_slot = (next_slot == SL_SEG_B) ? SL_SEG_A : SL_SEG_B;
+  }
+  return 0;
+}
+
+int run_pwc_midd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs,
+                 const double* signals, const cplx* clp, double dt, int B, int K, int N, int D, int Dm,
+                 const double* fr_phase, cplx* U_out, cplx* dUs_out, hipStream_t st) {
+  int nig, nj, wd;
+  if (!c3p_midd_geometry(Dm, &nig, &nj, &wd)) return 1;
+  const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
+  // workgroups resident at once: LDS-limited (2 per CU up to D = 28, else 1); aim at >= 2 rounds
+  const size_t lds0 = c3p_midd_lds_bytes(Dm, K, 0);
+  const int wg_per_cu = lds0 <= 76 * 1024 ? 2 : 1;
+  const long target = 256L * wg_per_cu * 2;
+  long S = (target + B - 1) / B;
+  const long smax = N / 8 > 1 ? N / 8 : 1;
+  if (S > smax) S = smax;
+  if (S < 1) S = 1;
+  // the segment's control amplitudes live in LDS next to the images
+  const size_t budget = (wg_per_cu == 2 ? 80 * 1024 : 158 * 1024);
+  while (c3p_midd_lds_bytes(Dm, K, (int)((N + S - 1) / S)) > budget && S < N) ++S;
+  if (c3p_midd_lds_bytes(Dm, K, (int)((N + S - 1) / S)) > 158 * 1024) return 1;
+  const int nsamp = per_sample ? B : 1;
+  void* v;
+  if (ws_get(w, SL_TABLES, (size_t)nsamp * c3p_midd_table_doubles(Dm, K) * sizeof(double), &v)) return -1;
+  MidPrepArgs p = {};
+  p.h0 = h0;
+  p.h0_bstride = h0_bs;
+  p.hks = hks;
+  p.hks_bstride = hk_bs;
+  p.clp = clp;
+  p.dt = dt;
+  p.K = K;
+  p.Dh = D;
+  p.Dm = Dm;
+  p.lindblad = lindblad;
+  p.rows = 16 * nig;
+  p.W = wd;
+  p.tables = (double*)v;
+  HIP_TRY(c3p_launch_midd_prep(p, nsamp, st));
+  MidArgs a = {};
+  a.tables = (const double*)v;
+  a.tab_per_sample = per_sample ? 1 : 0;
+  a.signals = signals;
+  a.B = B;
+  a.K = K;
+  a.N = N;
+  a.Dm = Dm;
+  a.S = (int)S;
+  a.Lmax = (int)((N + S - 1) / S);
+  a.mode = lindblad ? C3P_MODE_LINDBLAD : C3P_MODE_UNITARY;
+  a.dUs_out = dUs_out;
+  if (S == 1) {
+    a.seg_out = U_out;
+    a.fr_phase = fr_phase;
+  } else {
+    void* sv;
+    if (ws_get(w, SL_SEG_A, (size_t)B * S * Dm * Dm * sizeof(cplx), &sv)) return -1;
+    a.seg_out = (cplx*)sv;
+  }
+  g_last_kernel = C3P_KERNEL_MFMA;
+  if (record_start(w, st)) return -1;
+  HIP_TRY(c3p_launch_midd_chain(a, st));
+  if (record_stop(w, st)) return -1;
+  if (S > 1) return combine_midd(w, a.seg_out, B, (int)S, Dm, 0, fr_phase, U_out, st);
+  return 0;
+}
+
 // Host-pointer staging helpers --------------------------------------------------
 struct Stage {
   DeviceWs* w;
@@ -397,6 +497,12 @@ int pwc_common(int lindblad, const void* h0, int64_t h0_bstride, const void* hks
   if (!(flags & C3P_FORCE_GENERIC) && !per_slice && Dm <= kSmallDLimit && c3p_smalld_supported(Dm) && K <= 8) {
     const int rc = run_pwc_smalld(w, lindblad, a.h0, a.h0_bstride, a.hks, a.hks_bstride, a.signals, a.clp, dt,
                                   B, K, N, D, Dm, a.fr_phase, (cplx*)d_U, a.dUs_out, st);
+    if (rc < 0) return -1;
+    done = (rc == 0);
+  }
+  if (!done && !(flags & C3P_FORCE_GENERIC) && !per_slice && Dm >= 13 && Dm <= 40 && K <= 16) {
+    const int rc = run_pwc_midd(w, lindblad, a.h0, a.h0_bstride, a.hks, a.hks_bstride, a.signals, a.clp, dt, B,
+                                K, N, D, Dm, a.fr_phase, (cplx*)d_U, a.dUs_out, st);
     if (rc < 0) return -1;
     done = (rc == 0);
   }
@@ -535,6 +641,9 @@ int c3p_matmul_chain(const void* M, int B, int N, int D, int flags, void* out, v
   if (!(flags & C3P_FORCE_GENERIC) && D <= kSmallDLimit && c3p_smalld_supported(D)) {
     g_last_kernel = C3P_KERNEL_SMALLD;
     if (combine_smalld(w, (const cplx*)d_M, B, N, D, a.right_order, nullptr, (cplx*)d_out, st)) return -1;
+  } else if (!(flags & C3P_FORCE_GENERIC) && D >= 13 && D <= 40) {
+    g_last_kernel = C3P_KERNEL_MFMA;
+    if (combine_midd(w, (const cplx*)d_M, B, N, D, a.right_order, nullptr, (cplx*)d_out, st)) return -1;
   } else if (run_chain_generic(w, a, (cplx*)d_out, st)) {
     return -1;
   }

@@ -74,6 +74,33 @@ __host__ __device__ __forceinline__ TaylorPlan c3p_pick_plan(double norm) {
   return p;
 }
 
+// q = 4 only (powers X..X^4, Horner in X^4): degree 4r, r = 1..5.  Thresholds are the Taylor
+// backward-error bounds for unit roundoff 2^-52 (theta_m * 2^(1/m)).
+__host__ __device__ __forceinline__ TaylorPlan c3p_pick_plan_q4(double nrm) {
+  const double th[5] = {4.0e-4, 5.45e-2, 3.18e-1, 8.16e-1, 1.49};
+  int best_r = 5, best_s = 0, best_cost = 1 << 30;
+  for (int i = 0; i < 5; ++i) {
+    int si = 0;
+    double p = th[i];
+    while (p < nrm && si < 40) {
+      p *= 2.0;
+      ++si;
+    }
+    const int cost = i + si;
+    if (cost < best_cost || (cost == best_cost && si <= best_s)) {
+      best_cost = cost;
+      best_r = i + 1;
+      best_s = si;
+    }
+  }
+  TaylorPlan p;
+  p.q = 4;
+  p.r = best_r;
+  p.m = 4 * best_r;
+  p.s = best_s;
+  return p;
+}
+
 // 1/k!, k = 0..20
 __constant__ double c3p_inv_fact[21] = {
     1.0,

@@ -1,0 +1,34 @@
+// Launcher interface of the mid-D MFMA chain kernel (c3p_midd.hip).
+#pragma once
+#include "c3p_common.h"
+
+struct MidArgs {
+  const double* tables;   // [nsamp][(1+K)][IMG+4]
+  int tab_per_sample;
+  const double* signals;  // [B,K,N]
+  const cplx* mats;       // [B,N,Dm,Dm] (GIVEN mode)
+  const double* fr_phase;
+  int B, K, N, Dm;
+  int S, Lmax;
+  int mode, right_order;
+  cplx* seg_out;
+  cplx* dUs_out;
+};
+
+struct MidPrepArgs {
+  const cplx* h0;
+  long h0_bstride;
+  const cplx* hks;
+  long hks_bstride;
+  const cplx* clp;
+  double dt;
+  int K, Dh, Dm, lindblad;
+  int rows, W;
+  double* tables;
+};
+
+bool c3p_midd_geometry(int Dm, int* nig, int* nj, int* w);
+size_t c3p_midd_table_doubles(int Dm, int K);
+size_t c3p_midd_lds_bytes(int Dm, int K, int Lmax);
+hipError_t c3p_launch_midd_chain(const MidArgs& A, hipStream_t st);
+hipError_t c3p_launch_midd_prep(const MidPrepArgs& P, int nsamp, hipStream_t st);

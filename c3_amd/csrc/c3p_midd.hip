@@ -1,0 +1,524 @@
+// Mid-D propagator chains on the f64 matrix cores (13 <= D <= 40: cfg3 D=27, cfg5 D=36,
+// the excitation-cut D=14/24 fixtures).
+//
+// One workgroup of 4 wavefronts (one per SIMD) owns one (sample, time-segment) chain.
+// Every matrix of the chain lives in LDS as a "half image" Zh of the real 2x2
+// representation (rows 2i+p = Re/Im of row i, D columns; see c3p_smalld.hip):
+//     R(A) * Bh = Ch ,   C = A B complex,
+// computed with v_mfma_f64_4x4x4_4b_f64.  The four blocks of an instruction are four
+// consecutive 4-row blocks of the output ("I-group", 16 real rows) times one 4-column block:
+//   A operand  : lane (r,b,c) <- R(A)[16 Ig + 4b + c][4K + r]   (16x4 slab, sign-fixed on read)
+//   B operand  : lane (r,b,c) <- Bh[4K + r][4J + c]             (4x4 block, LDS-broadcast over b)
+//   acc (tile) : lane (r,b,c) -> Ch[16 Ig + 4b + r][4J + c]
+// The NIG x NJ output tiles are dealt to the 4 waves as contiguous runs of the flat index
+// t = J*NIG + Ig, compile-time per wave, so each wave loads every A slab it needs once per
+// K step and at most 3-4 B blocks: ~0.6 LDS reads per MFMA.
+// Row stride W (doubles) is chosen with 2W mod 64 in {12,...,52} step 8 or +-4 so that the
+// 16 rows of an A-slab read fall on distinct bank pairs.
+//
+// Per slice: X (registers, from pre-shifted global tables) -> image; X^2, X^3, X^4 images;
+// Horner in X^4 with block polynomials read from the images; squarings; U <- E U with U
+// parked in registers between slices.  Same plan logic as the small-D kernel.
+#include "c3p_common.h"
+#include "c3p_kernels.h"
+#include "c3p_midd.h"
+
+extern __shared__ __attribute__((aligned(16))) double c3p_md_lds[];
+
+namespace {
+
+constexpr int NW = 4;  // wavefronts per workgroup
+
+__device__ __forceinline__ double md_mfma4(double a, double b, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ double md_flip(double v, unsigned mask_hi) {
+  unsigned long long u = __double_as_longlong(v);
+  u ^= ((unsigned long long)mask_hi) << 32;
+  return __longlong_as_double(u);
+}
+__device__ __forceinline__ double md_rfl(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readfirstlane(lo);
+  hi = __builtin_amdgcn_readfirstlane(hi);
+  return __hiloint2double(hi, lo);
+}
+
+template <int NIG, int NJ>
+struct MD {
+  static constexpr int NT = NIG * NJ;
+  static constexpr int TPW = (NT + NW - 1) / NW;  // tiles per wave
+  static constexpr int ROWS = 16 * NIG;
+};
+
+// acc[i] += (A image) * (B image) for the tiles of wave WV.
+template <int NIG, int NJ, int W, int WV>
+__device__ __forceinline__ void mm_tiles(const double* imgA, const double* imgB, int aoff, int boff,
+                                         unsigned negmask, int nbk, double (&acc)[MD<NIG, NJ>::TPW]) {
+  using C = MD<NIG, NJ>;
+  constexpr int T0 = WV * C::TPW;
+  constexpr int T1 = (T0 + C::TPW < C::NT) ? T0 + C::TPW : C::NT;
+  constexpr int J0 = T0 / NIG;
+  constexpr int J1 = (T1 > T0) ? (T1 - 1) / NIG : J0;
+  constexpr int JS = J1 - J0 + 1;
+#pragma unroll 2
+  for (int K = 0; K < nbk; ++K) {
+    double a[NIG];
+    double bb[JS];
+#pragma unroll
+    for (int Ig = 0; Ig < NIG; ++Ig) {
+      // is this slab used by any tile of the wave?
+      bool used = false;
+#pragma unroll
+      for (int t = T0; t < T1; ++t) used = used || (t % NIG == Ig);
+      a[Ig] = used ? md_flip(imgA[aoff + Ig * 16 * W + 2 * K], negmask) : 0.0;
+    }
+#pragma unroll
+    for (int jj = 0; jj < JS; ++jj) bb[jj] = imgB[boff + K * 4 * W + (J0 + jj) * 4];
+#pragma unroll
+    for (int t = T0; t < T1; ++t) acc[t - T0] = md_mfma4(a[t % NIG], bb[t / NIG - J0], acc[t - T0]);
+  }
+}
+
+template <int NIG, int NJ, int W>
+__device__ __forceinline__ void mm_dispatch(int wave, const double* imgA, const double* imgB, int aoff,
+                                            int boff, unsigned negmask, int nbk,
+                                            double (&acc)[MD<NIG, NJ>::TPW]) {
+  switch (wave) {
+    case 0: mm_tiles<NIG, NJ, W, 0>(imgA, imgB, aoff, boff, negmask, nbk, acc); break;
+    case 1: mm_tiles<NIG, NJ, W, 1>(imgA, imgB, aoff, boff, negmask, nbk, acc); break;
+    case 2: mm_tiles<NIG, NJ, W, 2>(imgA, imgB, aoff, boff, negmask, nbk, acc); break;
+    default: mm_tiles<NIG, NJ, W, 3>(imgA, imgB, aoff, boff, negmask, nbk, acc); break;
+  }
+}
+
+struct TileGeo {
+  int doff;   // D-layout offset of the lane's element inside an image (doubles), or -1 for a dummy tile
+  int row;    // complex row index of the lane's element
+  int col;    // column index
+};
+
+template <int NIG, int NJ, int W, bool GIVEN, bool DUS>
+__global__ void __launch_bounds__(256) midd_chain_kernel(MidArgs A) {
+  using C = MD<NIG, NJ>;
+  constexpr int TPW = C::TPW, ROWS = C::ROWS, IMG = ROWS * W;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane >> 4, b = (lane >> 2) & 3, c = lane & 3;
+  const int D = A.Dm;
+  const int nbk = (2 * D + 3) / 4;
+  const int K = A.K;
+
+  double* imgX = c3p_md_lds;
+  double* imgA2 = imgX + IMG;
+  double* imgA3 = imgA2 + IMG;
+  double* imgA4 = imgA3 + IMG;
+  double* imgP = imgA4 + IMG;
+  double* sg = imgP + IMG;  // K x Lmax control amplitudes of the segment
+  __shared__ double red[NW];
+
+  const long chain = blockIdx.x;
+  const int sample = (int)(chain / A.S);
+  const int seg = (int)(chain - (long)sample * A.S);
+  const int n0 = (int)(((long)seg * A.N) / A.S);
+  const int n1 = (int)(((long)(seg + 1) * A.N) / A.S);
+  const int len = n1 - n0;
+
+  // lane geometry
+  const int aoff = (4 * b + (c & ~1) + ((c ^ r) & 1)) * W + (r >> 1);
+  const int boff = r * W + c;
+  const unsigned negmask = (((c & 1) == 0) && ((r & 1) == 1)) ? 0x80000000u : 0u;
+  TileGeo geo[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int t = wave * TPW + i;
+    if (t < C::NT) {
+      const int J = t / NIG, Ig = t - J * NIG;
+      const int rr = 16 * Ig + 4 * b + r;
+      geo[i].doff = rr * W + 4 * J + c;
+      geo[i].row = rr;  // real row: complex row rr>>1, part rr&1
+      geo[i].col = 4 * J + c;
+    } else {
+      geo[i].doff = -1;
+      geo[i].row = 1 << 20;
+      geo[i].col = 1 << 20;
+    }
+  }
+
+  // zero all images once (padding rows/columns must stay zero)
+  for (int e = tid; e < 5 * IMG; e += 256) c3p_md_lds[e] = 0.0;
+  __syncthreads();
+
+  double U[TPW];
+  double mus_r = 0.0, mus_i = 0.0;
+  const double* tabs = A.tables + (long)(A.tab_per_sample ? sample : 0) * (1 + K) * (IMG + 4);
+
+  int pr = 1, ps = 0;
+  double scale = 1.0;
+  if constexpr (!GIVEN) {
+    // segment-wide plan from ||G0|| + sum_k max_t |c_k(t)| ||G_k||
+    double nrm = tabs[IMG + 2];
+    for (int k = 0; k < K; ++k) {
+      const double* s = A.signals + ((long)sample * K + k) * A.N + n0;
+      double cmax = 0.0;
+      for (int t = tid; t < len; t += 256) {
+        const double v = s[t];
+        sg[k * A.Lmax + t] = v;
+        cmax = fmax(cmax, fabs(v));
+      }
+      for (int o = 32; o >= 1; o >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, o));
+      if (lane == 0) red[wave] = cmax;
+      __syncthreads();
+      cmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+      __syncthreads();
+      nrm = fma(cmax, tabs[(long)(k + 1) * (IMG + 4) + IMG + 2], nrm);
+    }
+    nrm = md_rfl(nrm);
+    const TaylorPlan p = c3p_pick_plan_q4(nrm);
+    pr = p.r;
+    ps = p.s;
+    scale = ldexp(1.0, -ps);
+    __syncthreads();
+  }
+
+  const int nsl = GIVEN ? len : len;
+  for (int t = 0; t < nsl; ++t) {
+    double P[TPW];
+    double mu_r = 0.0, mu_i = 0.0;
+    if constexpr (GIVEN) {
+      const double* src = reinterpret_cast<const double*>(A.mats) + ((long)sample * A.N + n0 + t) * D * D * 2;
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const int ci = geo[i].row >> 1;
+        P[i] = (ci < D && geo[i].col < D) ? src[(ci * D + geo[i].col) * 2 + (geo[i].row & 1)] : 0.0;
+      }
+    } else {
+      // ---- X = scale (G0 + sum_k c_k G_k) at the lane's tile positions ----
+      double X[TPW];
+      mu_r = tabs[IMG + 0];
+      mu_i = tabs[IMG + 1];
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) X[i] = (geo[i].doff >= 0) ? scale * tabs[geo[i].doff] : 0.0;
+      for (int k = 0; k < K; ++k) {
+        const double c0 = sg[k * A.Lmax + t];
+        const double ck = scale * c0;
+        const double* tk = tabs + (long)(k + 1) * (IMG + 4);
+        mu_r = fma(c0, tk[IMG + 0], mu_r);
+        mu_i = fma(c0, tk[IMG + 1], mu_i);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+          if (geo[i].doff >= 0) X[i] = fma(ck, tk[geo[i].doff], X[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < TPW; ++i)
+        if (geo[i].doff >= 0) imgX[geo[i].doff] = X[i];
+      __syncthreads();
+      // ---- powers: A2 = X X, A3 = X A2, A4 = X A3 ----
+      double acc[TPW];
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) acc[i] = 0.0;
+      mm_dispatch<NIG, NJ, W>(wave, imgX, imgX, aoff, boff, negmask, nbk, acc);
+#pragma unroll
+      for (int i = 0; i < TPW; ++i)
+        if (geo[i].doff >= 0) imgA2[geo[i].doff] = acc[i];
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) acc[i] = 0.0;
+      mm_dispatch<NIG, NJ, W>(wave, imgX, imgA2, aoff, boff, negmask, nbk, acc);
+#pragma unroll
+      for (int i = 0; i < TPW; ++i)
+        if (geo[i].doff >= 0) imgA3[geo[i].doff] = acc[i];
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) acc[i] = 0.0;
+      mm_dispatch<NIG, NJ, W>(wave, imgX, imgA3, aoff, boff, negmask, nbk, acc);
+      // ---- Horner init: P = c_m X^4 + B_{r-1} ----
+      {
+        const int j = pr - 1;
+        const double c0 = c3p_inv_fact[4 * j], c1 = c3p_inv_fact[4 * j + 1], c2 = c3p_inv_fact[4 * j + 2],
+                     c3 = c3p_inv_fact[4 * j + 3], cm = c3p_inv_fact[4 * pr];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+          double v = 0.0;
+          if (geo[i].doff >= 0) {
+            v = cm * acc[i];
+            v = fma(c1, X[i], v);
+            v = fma(c2, imgA2[geo[i].doff], v);
+            v = fma(c3, imgA3[geo[i].doff], v);
+            if ((geo[i].row & 1) == 0 && (geo[i].row >> 1) == geo[i].col && geo[i].col < D) v += c0;
+            if (pr > 1) imgA4[geo[i].doff] = acc[i];
+          }
+          P[i] = v;
+        }
+      }
+      for (int j = pr - 2; j >= 0; --j) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+          if (geo[i].doff >= 0) imgP[geo[i].doff] = P[i];
+        __syncthreads();
+        const double c0 = c3p_inv_fact[4 * j], c1 = c3p_inv_fact[4 * j + 1], c2 = c3p_inv_fact[4 * j + 2],
+                     c3 = c3p_inv_fact[4 * j + 3];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+          double v = 0.0;
+          if (geo[i].doff >= 0) {
+            v = c1 * X[i];
+            v = fma(c2, imgA2[geo[i].doff], v);
+            v = fma(c3, imgA3[geo[i].doff], v);
+            if ((geo[i].row & 1) == 0 && (geo[i].row >> 1) == geo[i].col && geo[i].col < D) v += c0;
+          }
+          acc[i] = v;
+        }
+        mm_dispatch<NIG, NJ, W>(wave, imgA4, imgP, aoff, boff, negmask, nbk, acc);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) P[i] = acc[i];
+        __syncthreads();  // every wave is done reading imgP before it is rewritten
+      }
+      // ---- squarings ----
+      for (int it = 0; it < ps; ++it) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+          if (geo[i].doff >= 0) imgP[geo[i].doff] = P[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) acc[i] = 0.0;
+        mm_dispatch<NIG, NJ, W>(wave, imgP, imgP, aoff, boff, negmask, nbk, acc);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) P[i] = acc[i];
+        __syncthreads();
+      }
+    }
+    // ---- partial propagator write-out ----
+    if constexpr (DUS) {
+      double sn, cs;
+      sincos(mu_i, &sn, &cs);
+      const double er = exp(mu_r);
+      const double sr = er * cs, si = er * sn;
+      double* dst = reinterpret_cast<double*>(A.dUs_out) + ((long)sample * A.N + n0 + t) * D * D * 2;
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const double mine = P[i];
+        const double other = __shfl_xor(mine, 16);
+        const double outv = (r & 1) ? fma(sr, mine, si * other) : fma(sr, mine, -si * other);
+        const int ci = geo[i].row >> 1;
+        if (ci < D && geo[i].col < D) dst[(ci * D + geo[i].col) * 2 + (r & 1)] = outv;
+      }
+    }
+    // ---- chain: U <- E U (or U E for the right-ordered list product) ----
+    if (t == 0) {
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) U[i] = P[i];
+      mus_r = mu_r;
+      mus_i = mu_i;
+    } else {
+      // imgP <- E, imgX <- U (imgX is free after the Horner phase; make sure every wave has
+      // left the last product that read it)
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < TPW; ++i)
+        if (geo[i].doff >= 0) {
+          imgP[geo[i].doff] = P[i];
+          imgX[geo[i].doff] = U[i];
+        }
+      __syncthreads();
+      double acc[TPW];
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) acc[i] = 0.0;
+      if (GIVEN && A.right_order)
+        mm_dispatch<NIG, NJ, W>(wave, imgX, imgP, aoff, boff, negmask, nbk, acc);
+      else
+        mm_dispatch<NIG, NJ, W>(wave, imgP, imgX, aoff, boff, negmask, nbk, acc);
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) U[i] = acc[i];
+      mus_r += mu_r;
+      mus_i += mu_i;
+      __syncthreads();  // imgX / imgP are rewritten by the next slice
+    }
+  }
+  // ---- segment result: scalar e^{sum mu}, optional row phases ----
+  double sn, cs;
+  sincos(mus_i, &sn, &cs);
+  const double er = exp(mus_r);
+  double* dst = reinterpret_cast<double*>(A.seg_out) + chain * D * D * 2;
+  const double* ph = A.fr_phase ? A.fr_phase + (long)sample * D : nullptr;
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int ci = geo[i].row >> 1;
+    double sr = er * cs, si = er * sn;
+    if (ph != nullptr && ci < D) {
+      double s2, c2;
+      sincos(ph[ci], &s2, &c2);
+      const double tr = sr * c2 - si * s2;
+      si = sr * s2 + si * c2;
+      sr = tr;
+    }
+    const double mine = U[i];
+    const double other = __shfl_xor(mine, 16);
+    const double outv = (r & 1) ? fma(sr, mine, si * other) : fma(sr, mine, -si * other);
+    if (ci < D && geo[i].col < D) dst[(ci * D + geo[i].col) * 2 + (r & 1)] = outv;
+  }
+}
+
+// Tables for the mid-D kernel: one workgroup per (sample, table).  Image = Zh layout of
+// G - mu I (G = -i dt h, or the Lindblad generator pieces), ROWS x W doubles zero padded,
+// followed by {Re mu, Im mu, ||G - mu I||_1, 0}.
+__global__ void __launch_bounds__(256) midd_prep_kernel(MidPrepArgs P) {
+  __shared__ double redr[256], redi[256];
+  __shared__ double mu[2];
+  const int tid = threadIdx.x;
+  const int ti = blockIdx.x % (1 + P.K);
+  const int sample = blockIdx.x / (1 + P.K);
+  const int D = P.Dm, Dh = P.Dh;
+  const cplx* h = (ti == 0) ? P.h0 + (long)sample * P.h0_bstride
+                            : P.hks + (long)sample * P.hks_bstride + (long)(ti - 1) * Dh * Dh;
+  auto gelem = [&](int row, int col) -> cplx {
+    cplx v;
+    if (!P.lindblad) {
+      const cplx x = h[row * D + col];
+      v = cmake(x.y * P.dt, -x.x * P.dt);
+    } else {
+      const int i = row / Dh, j = row - i * Dh, k = col / Dh, l = col - k * Dh;
+      v = (ti == 0) ? P.clp[(long)row * D + col] : cmake(0, 0);
+      if (j == l) {
+        const cplx x = h[i * Dh + k];
+        v.x += x.y;
+        v.y -= x.x;
+      }
+      if (i == k) {
+        const cplx x = h[l * Dh + j];
+        v.x -= x.y;
+        v.y += x.x;
+      }
+      v = cscale(v, P.dt);
+    }
+    return v;
+  };
+  double tr = 0, tim = 0;
+  for (int i = tid; i < D; i += 256) {
+    const cplx v = gelem(i, i);
+    tr += v.x;
+    tim += v.y;
+  }
+  redr[tid] = tr;
+  redi[tid] = tim;
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0, bq = 0;
+    for (int i = 0; i < 256; ++i) {
+      a += redr[i];
+      bq += redi[i];
+    }
+    mu[0] = a / D;
+    mu[1] = bq / D;
+  }
+  __syncthreads();
+  double cs = 0;
+  for (int j = tid; j < D; j += 256) {
+    double s = 0;
+    for (int i = 0; i < D; ++i) {
+      cplx v = gelem(i, j);
+      if (i == j) {
+        v.x -= mu[0];
+        v.y -= mu[1];
+      }
+      s += hypot(v.x, v.y);
+    }
+    cs = fmax(cs, s);
+  }
+  redr[tid] = cs;
+  __syncthreads();
+  const int IMG = P.rows * P.W;
+  double* out = P.tables + ((long)sample * (1 + P.K) + ti) * (IMG + 4);
+  for (int e = tid; e < IMG; e += 256) {
+    const int rho = e / P.W, col = e - rho * P.W;
+    const int i = rho >> 1, p = rho & 1;
+    double v = 0.0;
+    if (i < D && col < D) {
+      cplx g = gelem(i, col);
+      if (i == col) {
+        g.x -= mu[0];
+        g.y -= mu[1];
+      }
+      v = p ? g.y : g.x;
+    }
+    out[e] = v;
+  }
+  if (tid == 0) {
+    double nrm = 0;
+    for (int i = 0; i < 256; ++i) nrm = fmax(nrm, redr[i]);
+    out[IMG + 0] = mu[0];
+    out[IMG + 1] = mu[1];
+    out[IMG + 2] = nrm;
+    out[IMG + 3] = 0.0;
+  }
+}
+
+template <int NIG, int NJ, int W>
+hipError_t launch_t(const MidArgs& A, hipStream_t st) {
+  constexpr int IMG = MD<NIG, NJ>::ROWS * W;
+  const size_t lds = (size_t)(5 * IMG + (A.mode == C3P_MODE_GIVEN ? 0 : A.K * A.Lmax)) * sizeof(double);
+  const unsigned grid = (unsigned)((long)A.B * A.S);
+  auto go = [&](auto kern) -> hipError_t {
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, A);
+    return hipGetLastError();
+  };
+  if (A.mode == C3P_MODE_GIVEN) return go(midd_chain_kernel<NIG, NJ, W, true, false>);
+  if (A.dUs_out) return go(midd_chain_kernel<NIG, NJ, W, false, true>);
+  return go(midd_chain_kernel<NIG, NJ, W, false, false>);
+}
+
+}  // namespace
+
+// geometry classes: Dm -> (NIG, NJ, W)
+bool c3p_midd_geometry(int Dm, int* nig, int* nj, int* w) {
+  if (Dm < 13 || Dm > 40) return false;
+  const int NBI = (Dm + 1) / 2;
+  *nig = (NBI + 3) / 4;
+  *nj = (Dm + 3) / 4;
+  switch (*nj) {
+    case 4: *w = 18; break;   // D 13..16
+    case 5: *w = 22; break;   // D 17..20
+    case 6: *w = 26; break;   // D 21..24
+    case 7: *w = 30; break;   // D 25..28
+    case 8: *w = 34; break;   // D 29..32
+    case 9: *w = 38; break;   // D 33..36
+    default: *w = 42; break;  // D 37..40
+  }
+  return true;
+}
+
+size_t c3p_midd_table_doubles(int Dm, int K) {
+  int nig, nj, w;
+  if (!c3p_midd_geometry(Dm, &nig, &nj, &w)) return 0;
+  return (size_t)(1 + K) * ((size_t)16 * nig * w + 4);
+}
+
+size_t c3p_midd_lds_bytes(int Dm, int K, int Lmax) {
+  int nig, nj, w;
+  if (!c3p_midd_geometry(Dm, &nig, &nj, &w)) return 0;
+  return ((size_t)5 * 16 * nig * w + (size_t)K * Lmax) * sizeof(double);
+}
+
+hipError_t c3p_launch_midd_chain(const MidArgs& A, hipStream_t st) {
+  int nig, nj, w;
+  if (!c3p_midd_geometry(A.Dm, &nig, &nj, &w)) return hipErrorInvalidValue;
+  if (nig == 2 && nj == 4) return launch_t<2, 4, 18>(A, st);
+  if (nig == 3 && nj == 5) return launch_t<3, 5, 22>(A, st);
+  if (nig == 3 && nj == 6) return launch_t<3, 6, 26>(A, st);
+  if (nig == 4 && nj == 7) return launch_t<4, 7, 30>(A, st);
+  if (nig == 4 && nj == 8) return launch_t<4, 8, 34>(A, st);
+  if (nig == 5 && nj == 9) return launch_t<5, 9, 38>(A, st);
+  if (nig == 5 && nj == 10) return launch_t<5, 10, 42>(A, st);
+  return hipErrorInvalidValue;
+}
+
+hipError_t c3p_launch_midd_prep(const MidPrepArgs& P, int nsamp, hipStream_t st) {
+  hipLaunchKernelGGL(midd_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K))), dim3(256), 0, st, P);
+  return hipGetLastError();
+}

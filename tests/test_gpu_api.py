@@ -109,7 +109,7 @@ def test_every_dimension_and_kernel(prop, D, force_generic):
     r = prop.propagate_batch(h0, hks, sig, dt, force_generic=force_generic)
     ref = o.propagate_batch(h0, hks, sig, dt)
     assert max(np.linalg.norm(np.asarray(r["U"][b]) - ref[b]) for b in range(B)) < 1e-10
-    expect = "smalld" if (D <= 10 and not force_generic) else "generic_lds"
+    expect = "generic_lds" if (force_generic or D in (11, 12)) else ("smalld" if D <= 10 else "mfma")
     assert _lib.last_kernel() == expect
 
 
