@@ -22,6 +22,18 @@ __device__ __forceinline__ void cfma(cplx& acc, cplx a, cplx b) {
 }
 __device__ __forceinline__ double cabs1(cplx a) { return hypot(a.x, a.y); }
 
+// Running sum of the imaginary trace shifts, kept in [-pi, pi] (two-constant reduction):
+// the phase e^{i sum mu_n} needs ABSOLUTE accuracy in the angle, and an unreduced sum over
+// thousands of slices (|sum| ~ 1e4 rad) would lose ~1e-12 per addition.
+__device__ __forceinline__ double c3p_phase_add(double acc, double inc) {
+  const double two_pi_hi = 6.283185307179586, two_pi_lo = 2.4492935982947064e-16;
+  double s = acc + inc;
+  const double k = rint(s * 0.15915494309189535);
+  s = fma(-k, two_pi_hi, s);
+  s = fma(-k, two_pi_lo, s);
+  return s;
+}
+
 // ---------------------------------------------------------------------------
 // Truncated-Taylor / Paterson-Stockmeyer plan for exp(X), ||X||_1 = norm.
 //

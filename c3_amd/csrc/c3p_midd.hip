@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256) midd_chain_kernel(MidArgs A) {
 #pragma unroll
       for (int i = 0; i < TPW; ++i) U[i] = P[i];
       mus_r = mu_r;
-      mus_i = mu_i;
+      mus_i = c3p_phase_add(0.0, mu_i);
     } else {
       // imgP <- E, imgX <- U (imgX is free after the Horner phase; make sure every wave has
       // left the last product that read it)
@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(256) midd_chain_kernel(MidArgs A) {
 #pragma unroll
       for (int i = 0; i < TPW; ++i) U[i] = acc[i];
       mus_r += mu_r;
-      mus_i += mu_i;
+      mus_i = c3p_phase_add(mus_i, mu_i);
       __syncthreads();  // imgX / imgP are rewritten by the next slice
     }
   }

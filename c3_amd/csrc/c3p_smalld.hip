@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
 #pragma unroll
           for (int J = 0; J < NJ; ++J) U[I][J] = P[I][J];
         mus_r = mu_r;
-        mus_i = mu_i;
+        mus_i = c3p_phase_add(0.0, mu_i);
       } else {
         write_image<D>(P, img, woff);
         double acc[NBI][NJ];
@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
 #pragma unroll
           for (int J = 0; J < NJ; ++J) U[I][J] = acc[I][J];
         mus_r += mu_r;
-        mus_i += mu_i;
+        mus_i = c3p_phase_add(mus_i, mu_i);
       }
     }
   }
