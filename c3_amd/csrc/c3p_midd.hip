@@ -61,229 +61,197 @@ __device__ __forceinline__ void mm_tiles(const double* imgA, const double* imgB,
   constexpr int J0 = T0 / NIG;
   constexpr int J1 = (T1 > T0) ? (T1 - 1) / NIG : J0;
   constexpr int JS = J1 - J0 + 1;
-#pragma unroll 2
-  for (int K = 0; K < nbk; ++K) {
-    double a[NIG];
-    double bb[JS];
+  // software pipelined over K: the operands of step K+1 are in flight while step K's MFMAs issue
+  double a0[NIG], a1[NIG], b0[JS], b1[JS];
+  auto load = [&](double (&a)[NIG], double (&bb)[JS], int K) {
 #pragma unroll
     for (int Ig = 0; Ig < NIG; ++Ig) {
-      // is this slab used by any tile of the wave?
-      bool used = false;
+      bool used = false;  // is this slab used by any tile of the wave?
 #pragma unroll
       for (int t = T0; t < T1; ++t) used = used || (t % NIG == Ig);
       a[Ig] = used ? md_flip(imgA[aoff + Ig * 16 * W + 2 * K], negmask) : 0.0;
     }
 #pragma unroll
     for (int jj = 0; jj < JS; ++jj) bb[jj] = imgB[boff + K * 4 * W + (J0 + jj) * 4];
+  };
+  auto fmas = [&](const double (&a)[NIG], const double (&bb)[JS]) {
 #pragma unroll
     for (int t = T0; t < T1; ++t) acc[t - T0] = md_mfma4(a[t % NIG], bb[t / NIG - J0], acc[t - T0]);
+  };
+  load(a0, b0, 0);
+  for (int K = 0; K < nbk; K += 2) {
+    const int K1 = (K + 1 < nbk) ? K + 1 : K;
+    load(a1, b1, K1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA group
+    fmas(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int K2 = (K + 2 < nbk) ? K + 2 : K;
+    load(a0, b0, K2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (K + 1 < nbk) fmas(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-template <int NIG, int NJ, int W>
-__device__ __forceinline__ void mm_dispatch(int wave, const double* imgA, const double* imgB, int aoff,
-                                            int boff, unsigned negmask, int nbk,
-                                            double (&acc)[MD<NIG, NJ>::TPW]) {
-  switch (wave) {
-    case 0: mm_tiles<NIG, NJ, W, 0>(imgA, imgB, aoff, boff, negmask, nbk, acc); break;
-    case 1: mm_tiles<NIG, NJ, W, 1>(imgA, imgB, aoff, boff, negmask, nbk, acc); break;
-    case 2: mm_tiles<NIG, NJ, W, 2>(imgA, imgB, aoff, boff, negmask, nbk, acc); break;
-    default: mm_tiles<NIG, NJ, W, 3>(imgA, imgB, aoff, boff, negmask, nbk, acc); break;
-  }
-}
-
-struct TileGeo {
-  int doff;   // D-layout offset of the lane's element inside an image (doubles), or -1 for a dummy tile
-  int row;    // complex row index of the lane's element
-  int col;    // column index
+// Compile-time geometry of tile i of wave WV
+template <int NIG, int NJ, int W, int WV>
+struct WaveTiles {
+  using C = MD<NIG, NJ>;
+  static constexpr int T0 = WV * C::TPW;
+  static constexpr int T1 = (T0 + C::TPW < C::NT) ? T0 + C::TPW : C::NT;
+  static constexpr int NTILE = T1 - T0;  // real tiles of this wave (<= TPW)
+  static constexpr int J(int i) { return (T0 + i) / NIG; }
+  static constexpr int Ig(int i) { return (T0 + i) % NIG; }
+  static constexpr int off(int i) { return 16 * Ig(i) * W + 4 * J(i); }  // + lane base (4b+r)*W + c
 };
 
-template <int NIG, int NJ, int W, bool GIVEN, bool DUS>
-__global__ void __launch_bounds__(256) midd_chain_kernel(MidArgs A) {
+struct MidCommon {
+  int lane, r, b, c;
+  int D, nbk, K;
+  int sample, n0, len;
+  int aoff, boff, dbase;
+  unsigned negmask;
+  int pr, ps;
+  double scale;
+  const double* tabs;
+  double *imgX, *imgA2, *imgA3, *imgA4, *imgP, *sg;
+};
+
+// The whole slice loop, specialised per wave so that every tile index is a compile-time
+// constant (LDS offsets become instruction immediates; no per-tile predication).
+template <int NIG, int NJ, int W, bool GIVEN, bool DUS, int WV>
+__device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm, long chain) {
   using C = MD<NIG, NJ>;
-  constexpr int TPW = C::TPW, ROWS = C::ROWS, IMG = ROWS * W;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane >> 4, b = (lane >> 2) & 3, c = lane & 3;
-  const int D = A.Dm;
-  const int nbk = (2 * D + 3) / 4;
-  const int K = A.K;
-
-  double* imgX = c3p_md_lds;
-  double* imgA2 = imgX + IMG;
-  double* imgA3 = imgA2 + IMG;
-  double* imgA4 = imgA3 + IMG;
-  double* imgP = imgA4 + IMG;
-  double* sg = imgP + IMG;  // K x Lmax control amplitudes of the segment
-  __shared__ double red[NW];
-
-  const long chain = blockIdx.x;
-  const int sample = (int)(chain / A.S);
-  const int seg = (int)(chain - (long)sample * A.S);
-  const int n0 = (int)(((long)seg * A.N) / A.S);
-  const int n1 = (int)(((long)(seg + 1) * A.N) / A.S);
-  const int len = n1 - n0;
-
-  // lane geometry
-  const int aoff = (4 * b + (c & ~1) + ((c ^ r) & 1)) * W + (r >> 1);
-  const int boff = r * W + c;
-  const unsigned negmask = (((c & 1) == 0) && ((r & 1) == 1)) ? 0x80000000u : 0u;
-  TileGeo geo[TPW];
-#pragma unroll
-  for (int i = 0; i < TPW; ++i) {
-    const int t = wave * TPW + i;
-    if (t < C::NT) {
-      const int J = t / NIG, Ig = t - J * NIG;
-      const int rr = 16 * Ig + 4 * b + r;
-      geo[i].doff = rr * W + 4 * J + c;
-      geo[i].row = rr;  // real row: complex row rr>>1, part rr&1
-      geo[i].col = 4 * J + c;
-    } else {
-      geo[i].doff = -1;
-      geo[i].row = 1 << 20;
-      geo[i].col = 1 << 20;
-    }
-  }
-
-  // zero all images once (padding rows/columns must stay zero)
-  for (int e = tid; e < 5 * IMG; e += 256) c3p_md_lds[e] = 0.0;
-  __syncthreads();
-
+  using T = WaveTiles<NIG, NJ, W, WV>;
+  constexpr int TPW = C::TPW, IMG = C::ROWS * W, NTL = T::NTILE;
+  const int D = cm.D, K = cm.K, r = cm.r;
+  const int dbase = cm.dbase;
+  // per-tile lane coordinates
+  const int rrow = 4 * cm.b + cm.r;  // real row inside the 16-row I-group
   double U[TPW];
   double mus_r = 0.0, mus_i = 0.0;
-  const double* tabs = A.tables + (long)(A.tab_per_sample ? sample : 0) * (1 + K) * (IMG + 4);
+  const double* tabs = cm.tabs;
 
-  int pr = 1, ps = 0;
-  double scale = 1.0;
-  if constexpr (!GIVEN) {
-    // segment-wide plan from ||G0|| + sum_k max_t |c_k(t)| ||G_k||
-    double nrm = tabs[IMG + 2];
-    for (int k = 0; k < K; ++k) {
-      const double* s = A.signals + ((long)sample * K + k) * A.N + n0;
-      double cmax = 0.0;
-      for (int t = tid; t < len; t += 256) {
-        const double v = s[t];
-        sg[k * A.Lmax + t] = v;
-        cmax = fmax(cmax, fabs(v));
+  auto store_tiles = [&](double* img, const double (&v)[TPW]) {
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) img[dbase + T::off(i)] = v[i];
+  };
+  auto zero = [&](double (&v)[TPW]) {
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) v[i] = 0.0;
+  };
+  auto product = [&](const double* imgA, const double* imgB, double (&acc)[TPW]) {
+    mm_tiles<NIG, NJ, W, WV>(imgA, imgB, cm.aoff, cm.boff, cm.negmask, cm.nbk, acc);
+  };
+  // is the lane's element of tile i a diagonal (real-part) entry inside the D x D matrix?
+  auto is_diag = [&](int i) -> bool {
+    const int row = 16 * T::Ig(i) + rrow, col = 4 * T::J(i) + cm.c;
+    return ((row & 1) == 0) && ((row >> 1) == col) && (col < D);
+  };
+  // store a tile set to a plain complex [D][D] array times the scalar (sr + i si) (row phases opt.)
+  auto store_plain = [&](double* dst, const double (&v)[TPW], double sr0, double si0, const double* ph) {
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) {
+      const int row = 16 * T::Ig(i) + rrow, col = 4 * T::J(i) + cm.c;
+      const int ci = row >> 1;
+      double sr = sr0, si = si0;
+      if (ph != nullptr && ci < D) {
+        double s2, c2;
+        sincos(ph[ci], &s2, &c2);
+        const double tr = sr * c2 - si * s2;
+        si = sr * s2 + si * c2;
+        sr = tr;
       }
-      for (int o = 32; o >= 1; o >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, o));
-      if (lane == 0) red[wave] = cmax;
-      __syncthreads();
-      cmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-      __syncthreads();
-      nrm = fma(cmax, tabs[(long)(k + 1) * (IMG + 4) + IMG + 2], nrm);
+      const double mine = v[i];
+      const double other = __shfl_xor(mine, 16);
+      const double outv = (r & 1) ? fma(sr, mine, si * other) : fma(sr, mine, -si * other);
+      if (ci < D && col < D) dst[(ci * D + col) * 2 + (r & 1)] = outv;
     }
-    nrm = md_rfl(nrm);
-    const TaylorPlan p = c3p_pick_plan_q4(nrm);
-    pr = p.r;
-    ps = p.s;
-    scale = ldexp(1.0, -ps);
-    __syncthreads();
-  }
+  };
 
-  const int nsl = GIVEN ? len : len;
-  for (int t = 0; t < nsl; ++t) {
+  for (int t = 0; t < cm.len; ++t) {
     double P[TPW];
+    zero(P);
     double mu_r = 0.0, mu_i = 0.0;
     if constexpr (GIVEN) {
-      const double* src = reinterpret_cast<const double*>(A.mats) + ((long)sample * A.N + n0 + t) * D * D * 2;
+      const double* src = reinterpret_cast<const double*>(A.mats) + ((long)cm.sample * A.N + cm.n0 + t) * D * D * 2;
 #pragma unroll
-      for (int i = 0; i < TPW; ++i) {
-        const int ci = geo[i].row >> 1;
-        P[i] = (ci < D && geo[i].col < D) ? src[(ci * D + geo[i].col) * 2 + (geo[i].row & 1)] : 0.0;
+      for (int i = 0; i < NTL; ++i) {
+        const int row = 16 * T::Ig(i) + rrow, col = 4 * T::J(i) + cm.c;
+        const int ci = row >> 1;
+        P[i] = (ci < D && col < D) ? src[(ci * D + col) * 2 + (row & 1)] : 0.0;
       }
     } else {
       // ---- X = scale (G0 + sum_k c_k G_k) at the lane's tile positions ----
       double X[TPW];
+      zero(X);
       mu_r = tabs[IMG + 0];
       mu_i = tabs[IMG + 1];
 #pragma unroll
-      for (int i = 0; i < TPW; ++i) X[i] = (geo[i].doff >= 0) ? scale * tabs[geo[i].doff] : 0.0;
+      for (int i = 0; i < NTL; ++i) X[i] = cm.scale * tabs[dbase + T::off(i)];
       for (int k = 0; k < K; ++k) {
-        const double c0 = sg[k * A.Lmax + t];
-        const double ck = scale * c0;
+        const double c0 = cm.sg[k * A.Lmax + t];
+        const double ck = cm.scale * c0;
         const double* tk = tabs + (long)(k + 1) * (IMG + 4);
         mu_r = fma(c0, tk[IMG + 0], mu_r);
         mu_i = fma(c0, tk[IMG + 1], mu_i);
 #pragma unroll
-        for (int i = 0; i < TPW; ++i)
-          if (geo[i].doff >= 0) X[i] = fma(ck, tk[geo[i].doff], X[i]);
+        for (int i = 0; i < NTL; ++i) X[i] = fma(ck, tk[dbase + T::off(i)], X[i]);
       }
-#pragma unroll
-      for (int i = 0; i < TPW; ++i)
-        if (geo[i].doff >= 0) imgX[geo[i].doff] = X[i];
+      store_tiles(cm.imgX, X);
       __syncthreads();
       // ---- powers: A2 = X X, A3 = X A2, A4 = X A3 ----
       double acc[TPW];
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) acc[i] = 0.0;
-      mm_dispatch<NIG, NJ, W>(wave, imgX, imgX, aoff, boff, negmask, nbk, acc);
-#pragma unroll
-      for (int i = 0; i < TPW; ++i)
-        if (geo[i].doff >= 0) imgA2[geo[i].doff] = acc[i];
+      zero(acc);
+      product(cm.imgX, cm.imgX, acc);
+      store_tiles(cm.imgA2, acc);
       __syncthreads();
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) acc[i] = 0.0;
-      mm_dispatch<NIG, NJ, W>(wave, imgX, imgA2, aoff, boff, negmask, nbk, acc);
-#pragma unroll
-      for (int i = 0; i < TPW; ++i)
-        if (geo[i].doff >= 0) imgA3[geo[i].doff] = acc[i];
+      zero(acc);
+      product(cm.imgX, cm.imgA2, acc);
+      store_tiles(cm.imgA3, acc);
       __syncthreads();
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) acc[i] = 0.0;
-      mm_dispatch<NIG, NJ, W>(wave, imgX, imgA3, aoff, boff, negmask, nbk, acc);
+      zero(acc);
+      product(cm.imgX, cm.imgA3, acc);
       // ---- Horner init: P = c_m X^4 + B_{r-1} ----
       {
-        const int j = pr - 1;
+        const int j = cm.pr - 1;
         const double c0 = c3p_inv_fact[4 * j], c1 = c3p_inv_fact[4 * j + 1], c2 = c3p_inv_fact[4 * j + 2],
-                     c3 = c3p_inv_fact[4 * j + 3], cm = c3p_inv_fact[4 * pr];
+                     c3 = c3p_inv_fact[4 * j + 3], cmm = c3p_inv_fact[4 * cm.pr];
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-          double v = 0.0;
-          if (geo[i].doff >= 0) {
-            v = cm * acc[i];
-            v = fma(c1, X[i], v);
-            v = fma(c2, imgA2[geo[i].doff], v);
-            v = fma(c3, imgA3[geo[i].doff], v);
-            if ((geo[i].row & 1) == 0 && (geo[i].row >> 1) == geo[i].col && geo[i].col < D) v += c0;
-            if (pr > 1) imgA4[geo[i].doff] = acc[i];
-          }
+        for (int i = 0; i < NTL; ++i) {
+          double v = cmm * acc[i];
+          v = fma(c1, X[i], v);
+          v = fma(c2, cm.imgA2[dbase + T::off(i)], v);
+          v = fma(c3, cm.imgA3[dbase + T::off(i)], v);
+          v += is_diag(i) ? c0 : 0.0;
           P[i] = v;
         }
+        if (cm.pr > 1) store_tiles(cm.imgA4, acc);
       }
-      for (int j = pr - 2; j >= 0; --j) {
-#pragma unroll
-        for (int i = 0; i < TPW; ++i)
-          if (geo[i].doff >= 0) imgP[geo[i].doff] = P[i];
+      for (int j = cm.pr - 2; j >= 0; --j) {
+        store_tiles(cm.imgP, P);
         __syncthreads();
         const double c0 = c3p_inv_fact[4 * j], c1 = c3p_inv_fact[4 * j + 1], c2 = c3p_inv_fact[4 * j + 2],
                      c3 = c3p_inv_fact[4 * j + 3];
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-          double v = 0.0;
-          if (geo[i].doff >= 0) {
-            v = c1 * X[i];
-            v = fma(c2, imgA2[geo[i].doff], v);
-            v = fma(c3, imgA3[geo[i].doff], v);
-            if ((geo[i].row & 1) == 0 && (geo[i].row >> 1) == geo[i].col && geo[i].col < D) v += c0;
-          }
+        for (int i = 0; i < NTL; ++i) {
+          double v = c1 * X[i];
+          v = fma(c2, cm.imgA2[dbase + T::off(i)], v);
+          v = fma(c3, cm.imgA3[dbase + T::off(i)], v);
+          v += is_diag(i) ? c0 : 0.0;
           acc[i] = v;
         }
-        mm_dispatch<NIG, NJ, W>(wave, imgA4, imgP, aoff, boff, negmask, nbk, acc);
+        product(cm.imgA4, cm.imgP, acc);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) P[i] = acc[i];
         __syncthreads();  // every wave is done reading imgP before it is rewritten
       }
       // ---- squarings ----
-      for (int it = 0; it < ps; ++it) {
-#pragma unroll
-        for (int i = 0; i < TPW; ++i)
-          if (geo[i].doff >= 0) imgP[geo[i].doff] = P[i];
+      for (int it = 0; it < cm.ps; ++it) {
+        store_tiles(cm.imgP, P);
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) acc[i] = 0.0;
-        mm_dispatch<NIG, NJ, W>(wave, imgP, imgP, aoff, boff, negmask, nbk, acc);
+        zero(acc);
+        product(cm.imgP, cm.imgP, acc);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) P[i] = acc[i];
         __syncthreads();
@@ -294,16 +262,8 @@ __global__ void __launch_bounds__(256) midd_chain_kernel(MidArgs A) {
       double sn, cs;
       sincos(mu_i, &sn, &cs);
       const double er = exp(mu_r);
-      const double sr = er * cs, si = er * sn;
-      double* dst = reinterpret_cast<double*>(A.dUs_out) + ((long)sample * A.N + n0 + t) * D * D * 2;
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) {
-        const double mine = P[i];
-        const double other = __shfl_xor(mine, 16);
-        const double outv = (r & 1) ? fma(sr, mine, si * other) : fma(sr, mine, -si * other);
-        const int ci = geo[i].row >> 1;
-        if (ci < D && geo[i].col < D) dst[(ci * D + geo[i].col) * 2 + (r & 1)] = outv;
-      }
+      double* dst = reinterpret_cast<double*>(A.dUs_out) + ((long)cm.sample * A.N + cm.n0 + t) * D * D * 2;
+      store_plain(dst, P, er * cs, er * sn, nullptr);
     }
     // ---- chain: U <- E U (or U E for the right-ordered list product) ----
     if (t == 0) {
@@ -315,20 +275,15 @@ __global__ void __launch_bounds__(256) midd_chain_kernel(MidArgs A) {
       // imgP <- E, imgX <- U (imgX is free after the Horner phase; make sure every wave has
       // left the last product that read it)
       __syncthreads();
-#pragma unroll
-      for (int i = 0; i < TPW; ++i)
-        if (geo[i].doff >= 0) {
-          imgP[geo[i].doff] = P[i];
-          imgX[geo[i].doff] = U[i];
-        }
+      store_tiles(cm.imgP, P);
+      store_tiles(cm.imgX, U);
       __syncthreads();
       double acc[TPW];
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) acc[i] = 0.0;
+      zero(acc);
       if (GIVEN && A.right_order)
-        mm_dispatch<NIG, NJ, W>(wave, imgX, imgP, aoff, boff, negmask, nbk, acc);
+        product(cm.imgX, cm.imgP, acc);
       else
-        mm_dispatch<NIG, NJ, W>(wave, imgP, imgX, aoff, boff, negmask, nbk, acc);
+        product(cm.imgP, cm.imgX, acc);
 #pragma unroll
       for (int i = 0; i < TPW; ++i) U[i] = acc[i];
       mus_r += mu_r;
@@ -341,22 +296,85 @@ __global__ void __launch_bounds__(256) midd_chain_kernel(MidArgs A) {
   sincos(mus_i, &sn, &cs);
   const double er = exp(mus_r);
   double* dst = reinterpret_cast<double*>(A.seg_out) + chain * D * D * 2;
-  const double* ph = A.fr_phase ? A.fr_phase + (long)sample * D : nullptr;
-#pragma unroll
-  for (int i = 0; i < TPW; ++i) {
-    const int ci = geo[i].row >> 1;
-    double sr = er * cs, si = er * sn;
-    if (ph != nullptr && ci < D) {
-      double s2, c2;
-      sincos(ph[ci], &s2, &c2);
-      const double tr = sr * c2 - si * s2;
-      si = sr * s2 + si * c2;
-      sr = tr;
+  const double* ph = A.fr_phase ? A.fr_phase + (long)cm.sample * D : nullptr;
+  store_plain(dst, U, er * cs, er * sn, ph);
+}
+
+template <int NIG, int NJ, int W, bool GIVEN, bool DUS>
+__global__ void __launch_bounds__(256) midd_chain_kernel(MidArgs A) {
+  using C = MD<NIG, NJ>;
+  constexpr int IMG = C::ROWS * W;
+  const int tid = threadIdx.x;
+  MidCommon cm;
+  cm.lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  cm.r = cm.lane >> 4;
+  cm.b = (cm.lane >> 2) & 3;
+  cm.c = cm.lane & 3;
+  cm.D = A.Dm;
+  cm.nbk = (2 * cm.D + 3) / 4;
+  cm.K = A.K;
+  const int K = A.K;
+
+  cm.imgX = c3p_md_lds;
+  cm.imgA2 = cm.imgX + IMG;
+  cm.imgA3 = cm.imgA2 + IMG;
+  cm.imgA4 = cm.imgA3 + IMG;
+  cm.imgP = cm.imgA4 + IMG;
+  cm.sg = cm.imgP + IMG;  // K x Lmax control amplitudes of the segment
+  __shared__ double red[NW];
+
+  const long chain = blockIdx.x;
+  cm.sample = (int)(chain / A.S);
+  const int seg = (int)(chain - (long)cm.sample * A.S);
+  cm.n0 = (int)(((long)seg * A.N) / A.S);
+  const int n1 = (int)(((long)(seg + 1) * A.N) / A.S);
+  cm.len = n1 - cm.n0;
+
+  // lane geometry
+  cm.aoff = (4 * cm.b + (cm.c & ~1) + ((cm.c ^ cm.r) & 1)) * W + (cm.r >> 1);
+  cm.boff = cm.r * W + cm.c;
+  cm.dbase = (4 * cm.b + cm.r) * W + cm.c;
+  cm.negmask = (((cm.c & 1) == 0) && ((cm.r & 1) == 1)) ? 0x80000000u : 0u;
+
+  // zero all images once (padding rows/columns must stay zero)
+  for (int e = tid; e < 5 * IMG; e += 256) c3p_md_lds[e] = 0.0;
+  __syncthreads();
+
+  cm.tabs = A.tables + (long)(A.tab_per_sample ? cm.sample : 0) * (1 + K) * (IMG + 4);
+  cm.pr = 1;
+  cm.ps = 0;
+  cm.scale = 1.0;
+  if constexpr (!GIVEN) {
+    // segment-wide plan from ||G0|| + sum_k max_t |c_k(t)| ||G_k||
+    double nrm = cm.tabs[IMG + 2];
+    for (int k = 0; k < K; ++k) {
+      const double* s = A.signals + ((long)cm.sample * K + k) * A.N + cm.n0;
+      double cmax = 0.0;
+      for (int t = tid; t < cm.len; t += 256) {
+        const double v = s[t];
+        cm.sg[k * A.Lmax + t] = v;
+        cmax = fmax(cmax, fabs(v));
+      }
+      for (int o = 32; o >= 1; o >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, o));
+      if (cm.lane == 0) red[wave] = cmax;
+      __syncthreads();
+      cmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+      __syncthreads();
+      nrm = fma(cmax, cm.tabs[(long)(k + 1) * (IMG + 4) + IMG + 2], nrm);
     }
-    const double mine = U[i];
-    const double other = __shfl_xor(mine, 16);
-    const double outv = (r & 1) ? fma(sr, mine, si * other) : fma(sr, mine, -si * other);
-    if (ci < D && geo[i].col < D) dst[(ci * D + geo[i].col) * 2 + (r & 1)] = outv;
+    nrm = md_rfl(nrm);
+    const TaylorPlan p = c3p_pick_plan_q4(nrm);
+    cm.pr = __builtin_amdgcn_readfirstlane(p.r);
+    cm.ps = __builtin_amdgcn_readfirstlane(p.s);
+    cm.scale = ldexp(1.0, -cm.ps);
+    __syncthreads();
+  }
+  switch (wave) {
+    case 0: midd_body<NIG, NJ, W, GIVEN, DUS, 0>(A, cm, chain); break;
+    case 1: midd_body<NIG, NJ, W, GIVEN, DUS, 1>(A, cm, chain); break;
+    case 2: midd_body<NIG, NJ, W, GIVEN, DUS, 2>(A, cm, chain); break;
+    default: midd_body<NIG, NJ, W, GIVEN, DUS, 3>(A, cm, chain); break;
   }
 }
 

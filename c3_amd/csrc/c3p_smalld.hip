@@ -82,15 +82,20 @@ __device__ __forceinline__ void mm_img(const double* img, int roff, unsigned neg
                                        const double (&zb)[SD<D>::NBI][SD<D>::NJ],
                                        double (&acc)[SD<D>::NBI][SD<D>::NJ]) {
   using C = SD<D>;
+  // software pipelined: the A fragments of step K+1 are in flight while step K's MFMAs issue
+  double ra[2][C::NBI];
+#pragma unroll
+  for (int I = 0; I < C::NBI; ++I) ra[0][I] = flip_sign(img[roff + I * 4 * C::W], negmask);
 #pragma unroll
   for (int K = 0; K < C::NBI; ++K) {
-    double ra[C::NBI];
+    if (K + 1 < C::NBI) {
 #pragma unroll
-    for (int I = 0; I < C::NBI; ++I) ra[I] = flip_sign(img[roff + I * 4 * C::W + K * 2], negmask);
+      for (int I = 0; I < C::NBI; ++I) ra[(K + 1) & 1][I] = flip_sign(img[roff + I * 4 * C::W + (K + 1) * 2], negmask);
+    }
 #pragma unroll
     for (int I = 0; I < C::NBI; ++I)
 #pragma unroll
-      for (int J = 0; J < C::NJ; ++J) acc[I][J] = mfma4(ra[I], zb[K][J], acc[I][J]);
+      for (int J = 0; J < C::NJ; ++J) acc[I][J] = mfma4(ra[K & 1][I], zb[K][J], acc[I][J]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
