@@ -339,16 +339,18 @@ int run_pwc_midd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   int nig, nj, wd;
   if (!c3p_midd_geometry(Dm, &nig, &nj, &wd)) return 1;
   const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
-  // workgroups resident at once: LDS-limited (2 per CU up to D = 28, else 1); aim at >= 2 rounds
+  // workgroups resident at once are LDS-limited (three images per workgroup); aim at two rounds
   const size_t lds0 = c3p_midd_lds_bytes(Dm, K, 0);
-  const int wg_per_cu = lds0 <= 76 * 1024 ? 2 : 1;
+  int wg_per_cu = (int)((156 * 1024) / (lds0 + 4096));
+  if (wg_per_cu > 3) wg_per_cu = 3;
+  if (wg_per_cu < 1) wg_per_cu = 1;
   const long target = 256L * wg_per_cu * 2;
   long S = (target + B - 1) / B;
   const long smax = N / 8 > 1 ? N / 8 : 1;
   if (S > smax) S = smax;
   if (S < 1) S = 1;
   // the segment's control amplitudes live in LDS next to the images
-  const size_t budget = (wg_per_cu == 2 ? 80 * 1024 : 158 * 1024);
+  const size_t budget = (size_t)(158 * 1024) / wg_per_cu;
   while (c3p_midd_lds_bytes(Dm, K, (int)((N + S - 1) / S)) > budget && S < N) ++S;
   if (c3p_midd_lds_bytes(Dm, K, (int)((N + S - 1) / S)) > 158 * 1024) return 1;
   const int nsamp = per_sample ? B : 1;

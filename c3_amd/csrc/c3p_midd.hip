@@ -16,9 +16,11 @@
 // Row stride W (doubles) is chosen with 2W mod 64 in {12,...,52} step 8 or +-4 so that the
 // 16 rows of an A-slab read fall on distinct bank pairs.
 //
-// Per slice: X (registers, from pre-shifted global tables) -> image; X^2, X^3, X^4 images;
-// Horner in X^4 with block polynomials read from the images; squarings; U <- E U with U
-// parked in registers between slices.  Same plan logic as the small-D kernel.
+// Per slice: X (registers, from pre-shifted global tables) -> image; X^2, X^3, X^4; Horner in
+// X^4; squarings; U <- E U.  Every wave keeps ITS tiles of X, X^2, X^3, P and U in registers
+// (the block polynomials B_j are lane-local), so only three LDS images are live at any time:
+// buf0 = X then P/E, buf1 = X^2 then X^3 then U, buf2 = X^4  (73 KB at D = 36 -> two
+// workgroups = two waves per SIMD per CU).  Same plan logic as the small-D kernel.
 #include "c3p_common.h"
 #include "c3p_kernels.h"
 #include "c3p_midd.h"
@@ -114,7 +116,7 @@ struct MidCommon {
   int pr, ps;
   double scale;
   const double* tabs;
-  double *imgX, *imgA2, *imgA3, *imgA4, *imgP, *sg;
+  double *buf0, *buf1, *buf2, *sg;
 };
 
 // The whole slice loop, specialised per wave so that every tile index is a compile-time
@@ -198,20 +200,22 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
 #pragma unroll
         for (int i = 0; i < NTL; ++i) X[i] = fma(ck, tk[dbase + T::off(i)], X[i]);
       }
-      store_tiles(cm.imgX, X);
+      store_tiles(cm.buf0, X);
       __syncthreads();
-      // ---- powers: A2 = X X, A3 = X A2, A4 = X A3 ----
-      double acc[TPW];
-      zero(acc);
-      product(cm.imgX, cm.imgX, acc);
-      store_tiles(cm.imgA2, acc);
+      // ---- powers: A2 = X X, A3 = X A2, A4 = X A3.  buf0 = X (left operand of all three),
+      //      buf1 = A2 then A3 (right operands); A2, A3 also stay in registers for the B_j ----
+      double A2[TPW], A3[TPW], acc[TPW];
+      zero(A2);
+      product(cm.buf0, cm.buf0, A2);
+      store_tiles(cm.buf1, A2);
+      __syncthreads();
+      zero(A3);
+      product(cm.buf0, cm.buf1, A3);
+      __syncthreads();  // all waves done reading A2 from buf1
+      store_tiles(cm.buf1, A3);
       __syncthreads();
       zero(acc);
-      product(cm.imgX, cm.imgA2, acc);
-      store_tiles(cm.imgA3, acc);
-      __syncthreads();
-      zero(acc);
-      product(cm.imgX, cm.imgA3, acc);
+      product(cm.buf0, cm.buf1, acc);
       // ---- Horner init: P = c_m X^4 + B_{r-1} ----
       {
         const int j = cm.pr - 1;
@@ -221,40 +225,40 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
         for (int i = 0; i < NTL; ++i) {
           double v = cmm * acc[i];
           v = fma(c1, X[i], v);
-          v = fma(c2, cm.imgA2[dbase + T::off(i)], v);
-          v = fma(c3, cm.imgA3[dbase + T::off(i)], v);
+          v = fma(c2, A2[i], v);
+          v = fma(c3, A3[i], v);
           v += is_diag(i) ? c0 : 0.0;
           P[i] = v;
         }
-        if (cm.pr > 1) store_tiles(cm.imgA4, acc);
+        if (cm.pr > 1) store_tiles(cm.buf2, acc);  // buf2 = X^4, the Horner left operand
       }
       for (int j = cm.pr - 2; j >= 0; --j) {
-        store_tiles(cm.imgP, P);
+        __syncthreads();  // buf0 (X, then the previous P) is no longer read by any wave
+        store_tiles(cm.buf0, P);
         __syncthreads();
         const double c0 = c3p_inv_fact[4 * j], c1 = c3p_inv_fact[4 * j + 1], c2 = c3p_inv_fact[4 * j + 2],
                      c3 = c3p_inv_fact[4 * j + 3];
 #pragma unroll
         for (int i = 0; i < NTL; ++i) {
           double v = c1 * X[i];
-          v = fma(c2, cm.imgA2[dbase + T::off(i)], v);
-          v = fma(c3, cm.imgA3[dbase + T::off(i)], v);
+          v = fma(c2, A2[i], v);
+          v = fma(c3, A3[i], v);
           v += is_diag(i) ? c0 : 0.0;
           acc[i] = v;
         }
-        product(cm.imgA4, cm.imgP, acc);
+        product(cm.buf2, cm.buf0, acc);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) P[i] = acc[i];
-        __syncthreads();  // every wave is done reading imgP before it is rewritten
       }
       // ---- squarings ----
       for (int it = 0; it < cm.ps; ++it) {
-        store_tiles(cm.imgP, P);
+        __syncthreads();
+        store_tiles(cm.buf0, P);
         __syncthreads();
         zero(acc);
-        product(cm.imgP, cm.imgP, acc);
+        product(cm.buf0, cm.buf0, acc);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) P[i] = acc[i];
-        __syncthreads();
       }
     }
     // ---- partial propagator write-out ----
@@ -271,24 +275,24 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
       for (int i = 0; i < TPW; ++i) U[i] = P[i];
       mus_r = mu_r;
       mus_i = c3p_phase_add(0.0, mu_i);
+      __syncthreads();  // buf0 is rewritten by the next slice
     } else {
-      // imgP <- E, imgX <- U (imgX is free after the Horner phase; make sure every wave has
-      // left the last product that read it)
+      // buf0 <- E, buf1 <- U (both free now; make sure every wave has left the last product)
       __syncthreads();
-      store_tiles(cm.imgP, P);
-      store_tiles(cm.imgX, U);
+      store_tiles(cm.buf0, P);
+      store_tiles(cm.buf1, U);
       __syncthreads();
-      double acc[TPW];
-      zero(acc);
+      double cacc[TPW];
+      zero(cacc);
       if (GIVEN && A.right_order)
-        product(cm.imgX, cm.imgP, acc);
+        product(cm.buf1, cm.buf0, cacc);
       else
-        product(cm.imgP, cm.imgX, acc);
+        product(cm.buf0, cm.buf1, cacc);
 #pragma unroll
-      for (int i = 0; i < TPW; ++i) U[i] = acc[i];
+      for (int i = 0; i < TPW; ++i) U[i] = cacc[i];
       mus_r += mu_r;
       mus_i = c3p_phase_add(mus_i, mu_i);
-      __syncthreads();  // imgX / imgP are rewritten by the next slice
+      __syncthreads();  // buf0 / buf1 are rewritten by the next slice
     }
   }
   // ---- segment result: scalar e^{sum mu}, optional row phases ----
@@ -316,12 +320,10 @@ __global__ void __launch_bounds__(256) midd_chain_kernel(MidArgs A) {
   cm.K = A.K;
   const int K = A.K;
 
-  cm.imgX = c3p_md_lds;
-  cm.imgA2 = cm.imgX + IMG;
-  cm.imgA3 = cm.imgA2 + IMG;
-  cm.imgA4 = cm.imgA3 + IMG;
-  cm.imgP = cm.imgA4 + IMG;
-  cm.sg = cm.imgP + IMG;  // K x Lmax control amplitudes of the segment
+  cm.buf0 = c3p_md_lds;
+  cm.buf1 = cm.buf0 + IMG;
+  cm.buf2 = cm.buf1 + IMG;
+  cm.sg = cm.buf2 + IMG;  // K x Lmax control amplitudes of the segment
   __shared__ double red[NW];
 
   const long chain = blockIdx.x;
@@ -338,7 +340,7 @@ __global__ void __launch_bounds__(256) midd_chain_kernel(MidArgs A) {
   cm.negmask = (((cm.c & 1) == 0) && ((cm.r & 1) == 1)) ? 0x80000000u : 0u;
 
   // zero all images once (padding rows/columns must stay zero)
-  for (int e = tid; e < 5 * IMG; e += 256) c3p_md_lds[e] = 0.0;
+  for (int e = tid; e < 3 * IMG; e += 256) c3p_md_lds[e] = 0.0;
   __syncthreads();
 
   cm.tabs = A.tables + (long)(A.tab_per_sample ? cm.sample : 0) * (1 + K) * (IMG + 4);
@@ -475,7 +477,7 @@ __global__ void __launch_bounds__(256) midd_prep_kernel(MidPrepArgs P) {
 template <int NIG, int NJ, int W>
 hipError_t launch_t(const MidArgs& A, hipStream_t st) {
   constexpr int IMG = MD<NIG, NJ>::ROWS * W;
-  const size_t lds = (size_t)(5 * IMG + (A.mode == C3P_MODE_GIVEN ? 0 : A.K * A.Lmax)) * sizeof(double);
+  const size_t lds = (size_t)(3 * IMG + (A.mode == C3P_MODE_GIVEN ? 0 : A.K * A.Lmax)) * sizeof(double);
   const unsigned grid = (unsigned)((long)A.B * A.S);
   auto go = [&](auto kern) -> hipError_t {
     if (lds > 64 * 1024) {
@@ -520,7 +522,7 @@ size_t c3p_midd_table_doubles(int Dm, int K) {
 size_t c3p_midd_lds_bytes(int Dm, int K, int Lmax) {
   int nig, nj, w;
   if (!c3p_midd_geometry(Dm, &nig, &nj, &w)) return 0;
-  return ((size_t)5 * 16 * nig * w + (size_t)K * Lmax) * sizeof(double);
+  return ((size_t)3 * 16 * nig * w + (size_t)K * Lmax) * sizeof(double);
 }
 
 hipError_t c3p_launch_midd_chain(const MidArgs& A, hipStream_t st) {
