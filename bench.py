@@ -68,7 +68,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dist = None
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -94,11 +95,11 @@ def main():
         fr_phase=torch.as_tensor(fr, device=dev),
         force_generic=args.generic,
     )
-    gathered = torch.empty((world * B, Dm, Dm), dtype=torch.complex128, device=dev) if world > 1 else None
+    gathered = torch.empty((world * B, Dm, Dm), dtype=torch.complex128, device=dev) if use_dist else None
 
     def step():
         U = bp.run()
-        if world > 1:
+        if use_dist:  # the only data-path collective: final gather of the U slabs (RCCL)
             dist.all_gather_into_tensor(torch.view_as_real(gathered), torch.view_as_real(U))
         return U
 
@@ -106,18 +107,18 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -195,7 +196,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, c3_oracle)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
+        if args.check and rank == 0 and gathered is not None:
+            # the gathered slab of rank 0 must equal its own result
+            assert torch.equal(gathered[:B], bp.U), "all-gather mismatch"
         dist.destroy_process_group()
 
 

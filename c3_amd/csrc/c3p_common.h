@@ -113,6 +113,67 @@ __host__ __device__ __forceinline__ TaylorPlan c3p_pick_plan_q4(double nrm) {
   return p;
 }
 
+// Degree-18 Taylor polynomial in 5 products (Bader, Blanes & Casas, "Computing the matrix
+// exponential with an optimized Taylor polynomial approximation", Mathematics 7 (2019) 1174):
+//   A2 = A^2, A3 = A2 A, A6 = A3^2,
+//   B1 = a11 A + a21 A2 + a31 A3,                  B5 = b24 A2 + b34 A3 + b64 A6,
+//   B4 = b03 I + b13 A + b23 A2 + b33 A3 + b63 A6, A9 = B1 B5 + B4,
+//   B3 = b02 I + b12 A + b22 A2 + b32 A3 + b62 A6, B2 = b11 A + b21 A2 + b31 A3 + b61 A6,
+//   T18 = B2 + (B3 + A9) A9.
+// Expanding it reproduces 1/k!, k <= 18, to 1e-15 (tests/test_abi_and_host.py).  Backward-error
+// bound theta_18 = 1.09 (u = 2^-53); 1.13 for 2^-52.
+#define C3P_T18_THETA 1.13
+#define C3P_T18_A11 (-0.10036558103014462001)
+#define C3P_T18_A21 (-0.00802924648241156960)
+#define C3P_T18_A31 (-0.00089213849804572995)
+#define C3P_T18_B11 (0.39784974949964507614)
+#define C3P_T18_B21 (1.36783778460411719922)
+#define C3P_T18_B31 (0.49828962252538267755)
+#define C3P_T18_B61 (-0.00063789819459472330)
+#define C3P_T18_B02 (-10.9676396052962062593)
+#define C3P_T18_B12 (1.68015813878906197182)
+#define C3P_T18_B22 (0.05717798464788655127)
+#define C3P_T18_B32 (-0.00698210122488052084)
+#define C3P_T18_B62 (0.00003349750170860705)
+#define C3P_T18_B03 (-0.09043168323908105619)
+#define C3P_T18_B13 (-0.06764045190713819075)
+#define C3P_T18_B23 (0.06759613017704596460)
+#define C3P_T18_B33 (0.02955525704293155274)
+#define C3P_T18_B63 (-0.00001391802575160607)
+#define C3P_T18_B24 (-0.09233646193671185927)
+#define C3P_T18_B34 (-0.01693649390020817171)
+#define C3P_T18_B64 (-0.00001400867981820361)
+
+// Plan for the MFMA kernels: either the q = 4 Paterson-Stockmeyer polynomial (degree 4r,
+// 3 + (r-1) products) or T18 (5 products), plus s squarings; fewest products wins, ties go
+// to Paterson-Stockmeyer (less element-wise work).
+struct MfmaPlan {
+  int t18;  // 1: use T18
+  int r;    // q = 4 degree 4r (when !t18)
+  int s;    // squarings
+};
+__host__ __device__ __forceinline__ MfmaPlan c3p_pick_plan_mfma(double nrm) {
+  const TaylorPlan q = c3p_pick_plan_q4(nrm);
+  int s18 = 0;
+  double p = C3P_T18_THETA;
+  while (p < nrm && s18 < 40) {
+    p *= 2.0;
+    ++s18;
+  }
+  MfmaPlan m;
+  const int cost_q = 3 + (q.r - 1) + q.s, cost_t = 5 + s18;
+  if (cost_t < cost_q) {
+    m.t18 = 1;
+    m.r = 0;
+    m.s = s18;
+  } else {
+    m.t18 = 0;
+    m.r = q.r;
+    m.s = q.s;
+  }
+  return m;
+}
+
 // 1/k!, k = 0..20
 __constant__ double c3p_inv_fact[21] = {
     1.0,

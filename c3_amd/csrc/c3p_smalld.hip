@@ -129,6 +129,30 @@ __device__ __forceinline__ void poly_block(double (&out)[SD<D>::NBI][SD<D>::NJ],
     }
 }
 
+// out = cx X + c2 A2 + c3 A3 + c6 A6 (+ c0 on the diagonal) (+ add)
+template <int D>
+__device__ __forceinline__ void lincomb6(double (&out)[SD<D>::NBI][SD<D>::NJ], double c0, double cx, double c2,
+                                         double c3, double c6, const double (&X)[SD<D>::NBI][SD<D>::NJ],
+                                         const double (&A2)[SD<D>::NBI][SD<D>::NJ],
+                                         const double (&A3)[SD<D>::NBI][SD<D>::NJ],
+                                         const double (&A6)[SD<D>::NBI][SD<D>::NJ], int ddelta, int rhalf) {
+  using C = SD<D>;
+#pragma unroll
+  for (int I = 0; I < C::NBI; ++I)
+#pragma unroll
+    for (int J = 0; J < C::NJ; ++J) {
+      double v = cx * X[I][J];
+      v = fma(c2, A2[I][J], v);
+      v = fma(c3, A3[I][J], v);
+      if (c6 != 0.0) v = fma(c6, A6[I][J], v);
+      if (c0 != 0.0 && 2 * I - 4 * J >= -1 && 2 * I - 4 * J <= 3) {
+        const bool on = (ddelta == 4 * J - 2 * I) && (2 * I + rhalf < D);
+        v += on ? c0 : 0.0;
+      }
+      out[I][J] = v;
+    }
+}
+
 // q = 4 plan: degree 4r, s squarings, from a bound on ||X||_1
 __device__ __forceinline__ void plan_q4(double nrm, int& r, int& s) {
   // Taylor backward-error bounds for unit roundoff 2^-52 (theta_m of Al-Mohy & Higham scaled by 2^(1/m))
@@ -281,10 +305,10 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
     nrm = fmax(nrm, __shfl_xor(nrm, 4));
     nrm = fmax(nrm, __shfl_xor(nrm, 8));
     nrm = readfirstlane_f64(nrm);
-    int pr, ps;
-    plan_q4(nrm, pr, ps);
-    pr = __builtin_amdgcn_readfirstlane(pr);
-    ps = __builtin_amdgcn_readfirstlane(ps);
+    const MfmaPlan plan = c3p_pick_plan_mfma(nrm);
+    const int pr = __builtin_amdgcn_readfirstlane(plan.r);
+    const int ps = __builtin_amdgcn_readfirstlane(plan.s);
+    const int t18 = __builtin_amdgcn_readfirstlane(plan.t18);
     const double scale = ldexp(1.0, -ps);
     __syncthreads();
 
@@ -320,33 +344,64 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
         for (int J = 0; J < NJ; ++J) A2[I][J] = A3[I][J] = 0.0;
       mm_img<D>(img, roff, negmask, X, A2);
       mm_img<D>(img, roff, negmask, A2, A3);
-      {
-        double A4[NBI][NJ];
+      if (t18) {
+        // ---- T18 (Bader-Blanes-Casas): 5 products in total ----
+        double A6[NBI][NJ];
 #pragma unroll
         for (int I = 0; I < NBI; ++I)
 #pragma unroll
-          for (int J = 0; J < NJ; ++J) A4[I][J] = 0.0;
-        mm_img<D>(img, roff, negmask, A3, A4);
-        // ---- Horner in X^4: P = c_m X^4 + B_{r-1};  P = X^4 P + B_j ----
-        const int j = pr - 1;
-        poly_block<D>(P, c3p_inv_fact[4 * j], c3p_inv_fact[4 * j + 1], c3p_inv_fact[4 * j + 2],
-                      c3p_inv_fact[4 * j + 3], X, A2, A3, ddelta, rhalf);
-        const double cm = c3p_inv_fact[4 * pr];
-#pragma unroll
-        for (int I = 0; I < NBI; ++I)
-#pragma unroll
-          for (int J = 0; J < NJ; ++J) P[I][J] = fma(cm, A4[I][J], P[I][J]);
-        if (pr > 1) write_image<D>(A4, img, woff);
-      }
-      for (int j = pr - 2; j >= 0; --j) {
+          for (int J = 0; J < NJ; ++J) A6[I][J] = 0.0;
+        write_image<D>(A3, img, woff);
+        mm_img<D>(img, roff, negmask, A3, A6);
         double acc[NBI][NJ];
-        poly_block<D>(acc, c3p_inv_fact[4 * j], c3p_inv_fact[4 * j + 1], c3p_inv_fact[4 * j + 2],
-                      c3p_inv_fact[4 * j + 3], X, A2, A3, ddelta, rhalf);
-        mm_img<D>(img, roff, negmask, P, acc);
+        {
+          double B1[NBI][NJ], B5[NBI][NJ];
+          lincomb6<D>(B1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0, X, A2, A3, A6, ddelta, rhalf);
+          write_image<D>(B1, img, woff);
+          lincomb6<D>(B5, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64, X, A2, A3, A6, ddelta, rhalf);
+          lincomb6<D>(acc, C3P_T18_B03, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63, X, A2, A3, A6, ddelta, rhalf);
+          mm_img<D>(img, roff, negmask, B5, acc);  // acc = A9 = B1 B5 + B4
+        }
+        {
+          double L[NBI][NJ];
+          lincomb6<D>(L, C3P_T18_B02, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62, X, A2, A3, A6, ddelta, rhalf);
 #pragma unroll
-        for (int I = 0; I < NBI; ++I)
+          for (int I = 0; I < NBI; ++I)
 #pragma unroll
-          for (int J = 0; J < NJ; ++J) P[I][J] = acc[I][J];
+            for (int J = 0; J < NJ; ++J) L[I][J] += acc[I][J];
+          write_image<D>(L, img, woff);
+        }
+        lincomb6<D>(P, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61, X, A2, A3, A6, ddelta, rhalf);
+        mm_img<D>(img, roff, negmask, acc, P);  // P = B2 + (B3 + A9) A9
+      } else {
+        {
+          double A4[NBI][NJ];
+  #pragma unroll
+          for (int I = 0; I < NBI; ++I)
+  #pragma unroll
+            for (int J = 0; J < NJ; ++J) A4[I][J] = 0.0;
+          mm_img<D>(img, roff, negmask, A3, A4);
+          // ---- Horner in X^4: P = c_m X^4 + B_{r-1};  P = X^4 P + B_j ----
+          const int j = pr - 1;
+          poly_block<D>(P, c3p_inv_fact[4 * j], c3p_inv_fact[4 * j + 1], c3p_inv_fact[4 * j + 2],
+                        c3p_inv_fact[4 * j + 3], X, A2, A3, ddelta, rhalf);
+          const double cm = c3p_inv_fact[4 * pr];
+  #pragma unroll
+          for (int I = 0; I < NBI; ++I)
+  #pragma unroll
+            for (int J = 0; J < NJ; ++J) P[I][J] = fma(cm, A4[I][J], P[I][J]);
+          if (pr > 1) write_image<D>(A4, img, woff);
+        }
+        for (int j = pr - 2; j >= 0; --j) {
+          double acc[NBI][NJ];
+          poly_block<D>(acc, c3p_inv_fact[4 * j], c3p_inv_fact[4 * j + 1], c3p_inv_fact[4 * j + 2],
+                        c3p_inv_fact[4 * j + 3], X, A2, A3, ddelta, rhalf);
+          mm_img<D>(img, roff, negmask, P, acc);
+  #pragma unroll
+          for (int I = 0; I < NBI; ++I)
+  #pragma unroll
+            for (int J = 0; J < NJ; ++J) P[I][J] = acc[I][J];
+        }
       }
       // ---- squarings ----
       for (int it = 0; it < ps; ++it) {
