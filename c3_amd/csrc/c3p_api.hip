@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdarg>
 #include <cstring>
+#include <cstdlib>
 
 #include "../../include/c3prop.h"
 #include "c3p_kernels.h"
@@ -383,6 +384,7 @@ int run_pwc_midd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   a.Lmax = (int)((N + S - 1) / S);
   a.mode = lindblad ? C3P_MODE_LINDBLAD : C3P_MODE_UNITARY;
   a.dUs_out = dUs_out;
+  a.no_t18 = getenv("C3P_NO_T18") ? 1 : 0;
   if (S == 1) {
     a.seg_out = U_out;
     a.fr_phase = fr_phase;

@@ -11,6 +11,7 @@ struct MidArgs {
   int B, K, N, Dm;
   int S, Lmax;
   int mode, right_order;
+  int no_t18;  // debug/tuning: force the Paterson-Stockmeyer plan
   cplx* seg_out;
   cplx* dUs_out;
 };

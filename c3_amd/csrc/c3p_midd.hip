@@ -113,7 +113,7 @@ struct MidCommon {
   int sample, n0, len;
   int aoff, boff, dbase;
   unsigned negmask;
-  int pr, ps;
+  int pr, ps, t18;
   double scale;
   const double* tabs;
   double *buf0, *buf1, *buf2, *sg;
@@ -215,40 +215,76 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
       store_tiles(cm.buf1, A3);
       __syncthreads();
       zero(acc);
-      product(cm.buf0, cm.buf1, acc);
-      // ---- Horner init: P = c_m X^4 + B_{r-1} ----
-      {
-        const int j = cm.pr - 1;
-        const double c0 = c3p_inv_fact[4 * j], c1 = c3p_inv_fact[4 * j + 1], c2 = c3p_inv_fact[4 * j + 2],
-                     c3 = c3p_inv_fact[4 * j + 3], cmm = c3p_inv_fact[4 * cm.pr];
+      if (cm.t18) {
+        // ---- T18 (Bader-Blanes-Casas), 5 products: A6 = A3 A3; A9 = B1 B5 + B4; P = B2 + (B3 + A9) A9
+        product(cm.buf1, cm.buf1, acc);  // acc = A6
+        auto comb = [&](double (&out)[TPW], double c0, double cx, double c2, double c3, double c6) {
 #pragma unroll
-        for (int i = 0; i < NTL; ++i) {
-          double v = cmm * acc[i];
-          v = fma(c1, X[i], v);
-          v = fma(c2, A2[i], v);
-          v = fma(c3, A3[i], v);
-          v += is_diag(i) ? c0 : 0.0;
-          P[i] = v;
-        }
-        if (cm.pr > 1) store_tiles(cm.buf2, acc);  // buf2 = X^4, the Horner left operand
-      }
-      for (int j = cm.pr - 2; j >= 0; --j) {
-        __syncthreads();  // buf0 (X, then the previous P) is no longer read by any wave
-        store_tiles(cm.buf0, P);
+          for (int i = 0; i < NTL; ++i) {
+            double v = cx * X[i];
+            v = fma(c2, A2[i], v);
+            v = fma(c3, A3[i], v);
+            v = fma(c6, acc[i], v);
+            v += (c0 != 0.0 && is_diag(i)) ? c0 : 0.0;
+            out[i] = v;
+          }
+        };
+        double T1[TPW], T2[TPW];
+        zero(T1);
+        zero(T2);
+        comb(T1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0);              // B1
+        comb(T2, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64);              // B5
+        __syncthreads();  // buf0 (X) no longer read
+        store_tiles(cm.buf0, T1);
+        store_tiles(cm.buf2, T2);
+        comb(T1, C3P_T18_B03, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63);  // B4
         __syncthreads();
-        const double c0 = c3p_inv_fact[4 * j], c1 = c3p_inv_fact[4 * j + 1], c2 = c3p_inv_fact[4 * j + 2],
-                     c3 = c3p_inv_fact[4 * j + 3];
+        product(cm.buf0, cm.buf2, T1);  // T1 = A9
+        comb(T2, C3P_T18_B02, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62);  // B3
 #pragma unroll
-        for (int i = 0; i < NTL; ++i) {
-          double v = c1 * X[i];
-          v = fma(c2, A2[i], v);
-          v = fma(c3, A3[i], v);
-          v += is_diag(i) ? c0 : 0.0;
-          acc[i] = v;
+        for (int i = 0; i < TPW; ++i) T2[i] += T1[i];
+        comb(P, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61);  // B2
+        __syncthreads();  // buf0 / buf2 no longer read
+        store_tiles(cm.buf0, T2);
+        store_tiles(cm.buf2, T1);
+        __syncthreads();
+        product(cm.buf0, cm.buf2, P);
+      } else {
+        product(cm.buf0, cm.buf1, acc);
+        // ---- Horner init: P = c_m X^4 + B_{r-1} ----
+        {
+          const int j = cm.pr - 1;
+          const double c0 = c3p_inv_fact[4 * j], c1 = c3p_inv_fact[4 * j + 1], c2 = c3p_inv_fact[4 * j + 2],
+                       c3 = c3p_inv_fact[4 * j + 3], cmm = c3p_inv_fact[4 * cm.pr];
+  #pragma unroll
+          for (int i = 0; i < NTL; ++i) {
+            double v = cmm * acc[i];
+            v = fma(c1, X[i], v);
+            v = fma(c2, A2[i], v);
+            v = fma(c3, A3[i], v);
+            v += is_diag(i) ? c0 : 0.0;
+            P[i] = v;
+          }
+          if (cm.pr > 1) store_tiles(cm.buf2, acc);  // buf2 = X^4, the Horner left operand
         }
-        product(cm.buf2, cm.buf0, acc);
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) P[i] = acc[i];
+        for (int j = cm.pr - 2; j >= 0; --j) {
+          __syncthreads();  // buf0 (X, then the previous P) is no longer read by any wave
+          store_tiles(cm.buf0, P);
+          __syncthreads();
+          const double c0 = c3p_inv_fact[4 * j], c1 = c3p_inv_fact[4 * j + 1], c2 = c3p_inv_fact[4 * j + 2],
+                       c3 = c3p_inv_fact[4 * j + 3];
+  #pragma unroll
+          for (int i = 0; i < NTL; ++i) {
+            double v = c1 * X[i];
+            v = fma(c2, A2[i], v);
+            v = fma(c3, A3[i], v);
+            v += is_diag(i) ? c0 : 0.0;
+            acc[i] = v;
+          }
+          product(cm.buf2, cm.buf0, acc);
+  #pragma unroll
+          for (int i = 0; i < TPW; ++i) P[i] = acc[i];
+        }
       }
       // ---- squarings ----
       for (int it = 0; it < cm.ps; ++it) {
@@ -304,8 +340,15 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
   store_plain(dst, U, er * cs, er * sn, ph);
 }
 
+// Workgroups per CU the LDS allows (three images each): the register budget follows from it.
+template <int NIG, int W>
+struct MidOcc {
+  static constexpr int IMG_BYTES = 16 * NIG * W * 8;
+  static constexpr int WGS = (3 * IMG_BYTES + 6144) * 3 <= 160 * 1024 ? 3 : 2;
+};
+
 template <int NIG, int NJ, int W, bool GIVEN, bool DUS>
-__global__ void __launch_bounds__(256) midd_chain_kernel(MidArgs A) {
+__global__ void __launch_bounds__(256, (MidOcc<NIG, W>::WGS)) midd_chain_kernel(MidArgs A) {
   using C = MD<NIG, NJ>;
   constexpr int IMG = C::ROWS * W;
   const int tid = threadIdx.x;
@@ -346,6 +389,7 @@ __global__ void __launch_bounds__(256) midd_chain_kernel(MidArgs A) {
   cm.tabs = A.tables + (long)(A.tab_per_sample ? cm.sample : 0) * (1 + K) * (IMG + 4);
   cm.pr = 1;
   cm.ps = 0;
+  cm.t18 = 0;
   cm.scale = 1.0;
   if constexpr (!GIVEN) {
     // segment-wide plan from ||G0|| + sum_k max_t |c_k(t)| ||G_k||
@@ -366,9 +410,16 @@ __global__ void __launch_bounds__(256) midd_chain_kernel(MidArgs A) {
       nrm = fma(cmax, cm.tabs[(long)(k + 1) * (IMG + 4) + IMG + 2], nrm);
     }
     nrm = md_rfl(nrm);
-    const TaylorPlan p = c3p_pick_plan_q4(nrm);
+    const MfmaPlan p = c3p_pick_plan_mfma(nrm);
     cm.pr = __builtin_amdgcn_readfirstlane(p.r);
     cm.ps = __builtin_amdgcn_readfirstlane(p.s);
+    cm.t18 = __builtin_amdgcn_readfirstlane(p.t18);
+    if (A.no_t18 && cm.t18) {
+      const TaylorPlan q = c3p_pick_plan_q4(nrm);
+      cm.t18 = 0;
+      cm.pr = __builtin_amdgcn_readfirstlane(q.r);
+      cm.ps = __builtin_amdgcn_readfirstlane(q.s);
+    }
     cm.scale = ldexp(1.0, -cm.ps);
     __syncthreads();
   }
