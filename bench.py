@@ -95,17 +95,30 @@ def main():
         fr_phase=torch.as_tensor(fr, device=dev),
         force_generic=args.generic,
     )
-    gathered = torch.empty((world * B, Dm, Dm), dtype=torch.complex128, device=dev) if use_dist else None
+    # The only data-path collective is the final all-gather of the U slabs (RCCL over xGMI),
+    # issued in stream order after each batch.  (An asynchronous, double-buffered gather was
+    # measured SLOWER: the RCCL kernel then runs beside the chain kernel, takes CUs away from a
+    # grid sized to fill the chip exactly, and creates a partial second round of waves.)
+    nbuf = 2
+    Ubuf = [torch.empty((B, Dm, Dm), dtype=torch.complex128, device=dev) for _ in range(nbuf)]
+    gathered = [torch.empty((world * B, Dm, Dm), dtype=torch.complex128, device=dev) for _ in range(nbuf)] if use_dist else None
+    counter = [0]
 
     def step():
-        U = bp.run()
-        if use_dist:  # the only data-path collective: final gather of the U slabs (RCCL)
-            dist.all_gather_into_tensor(torch.view_as_real(gathered), torch.view_as_real(U))
+        i = counter[0] % nbuf
+        counter[0] += 1
+        U = bp.run(out=Ubuf[i])
+        if use_dist:
+            dist.all_gather_into_tensor(torch.view_as_real(gathered[i]), torch.view_as_real(U))
         return U
+
+    def drain():
+        pass
 
     lib = _lib.load()
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -113,6 +126,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -197,9 +211,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl, c3_oracle)
         print(json.dumps(out), flush=True)
     if use_dist:
-        if args.check and rank == 0 and gathered is not None:
-            # the gathered slab of rank 0 must equal its own result
-            assert torch.equal(gathered[:B], bp.U), "all-gather mismatch"
+        if args.check and gathered is not None:
+            # the gathered slab of this rank must equal its own result
+            last = (counter[0] - 1) % nbuf
+            assert torch.equal(gathered[last][rank * B : (rank + 1) * B], Ubuf[last]), "all-gather mismatch"
         dist.destroy_process_group()
 
 

@@ -597,23 +597,26 @@ class BatchPropagator:
         self.dUs = torch.empty((self.B, self.N, self.Dm, self.Dm), dtype=c128, device=dev) if want_dUs else None
         self.flags = _lib.FORCE_GENERIC if force_generic else 0
 
-    def run(self):
+    def run(self, out=None):
+        """One C-ABI call on torch's current stream; `out` overrides the result tensor
+        (lets callers double-buffer results, e.g. to overlap a gather with the next batch)."""
+        U = self.U if out is None else out
         st = self.torch.cuda.current_stream(self.dev).cuda_stream
         if self.lind:
             rc = self.lib.c3p_pwc_lindblad(
                 self.h0.data_ptr(), self.h0_bs, self.hks.data_ptr(), self.hk_bs, self.signals.data_ptr(),
                 self.col.data_ptr(), int(self.col.shape[0]), self.dt, self.B, self.K, self.N, self.D, self.flags,
-                None if self.fr is None else self.fr.data_ptr(), self.U.data_ptr(),
+                None if self.fr is None else self.fr.data_ptr(), U.data_ptr(),
                 None if self.dUs is None else self.dUs.data_ptr(), st,
             )
         else:
             rc = self.lib.c3p_pwc_unitary(
                 self.h0.data_ptr(), self.h0_bs, self.hks.data_ptr(), self.hk_bs, self.signals.data_ptr(), self.dt,
                 self.B, self.K, self.N, self.D, self.flags, None if self.fr is None else self.fr.data_ptr(),
-                self.U.data_ptr(), None if self.dUs is None else self.dUs.data_ptr(), st,
+                U.data_ptr(), None if self.dUs is None else self.dUs.data_ptr(), st,
             )
         _lib.check(rc)
-        return self.U
+        return U
 
 
 # --------------------------------------------------------------------------

@@ -135,3 +135,39 @@ def test_taylor_thresholds_are_safe():
         A *= theta / np.abs(A).sum(0).max()
         T = sum(np.linalg.matrix_power(A, k) / math.factorial(k) for k in range(m + 1))
         assert np.abs(T - o.expm(A)).max() < 1e-15 * max(1.0, 10 * theta)
+
+
+def test_t18_coefficients_reproduce_taylor_series():
+    """The Bader-Blanes-Casas T18 constants in c3p_common.h, expanded as a scalar polynomial,
+    must equal sum_{k<=18} x^k/k! (the kernels rely on it for degree-18 accuracy)."""
+    import math
+    from numpy.polynomial import polynomial as Pn
+
+    text = open(os.path.join(ROOT, "c3_amd", "csrc", "c3p_common.h")).read()
+    c = {m.group(1): float(m.group(2)) for m in re.finditer(r"#define C3P_T18_([AB]\d\d) \((-?[0-9.]+)\)", text)}
+    assert len(c) == 20
+
+    def poly(c0, c1, c2, c3, c6):
+        p = np.zeros(7)
+        p[0], p[1], p[2], p[3], p[6] = c0, c1, c2, c3, c6
+        return p
+
+    B1 = poly(0, c["A11"], c["A21"], c["A31"], 0)
+    B2 = poly(0, c["B11"], c["B21"], c["B31"], c["B61"])
+    B3 = poly(c["B02"], c["B12"], c["B22"], c["B32"], c["B62"])
+    B4 = poly(c["B03"], c["B13"], c["B23"], c["B33"], c["B63"])
+    B5 = poly(0, 0, c["B24"], c["B34"], c["B64"])
+    A9 = Pn.polyadd(Pn.polymul(B1, B5), B4)
+    T = Pn.polyadd(B2, Pn.polymul(Pn.polyadd(B3, A9), A9))
+    assert len(T) == 19
+    for k in range(19):
+        assert abs(T[k] * math.factorial(k) - 1.0) < 5e-15, (k, T[k])
+    # and as a matrix function at its threshold
+    rng = np.random.default_rng(2)
+    A = rng.normal(size=(9, 9)) + 1j * rng.normal(size=(9, 9))
+    A = A - A.conj().T
+    A *= 1.13 / np.abs(A).sum(0).max()
+    M = lambda p: sum(p[k] * np.linalg.matrix_power(A, k) for k in range(len(p)) if p[k] != 0)
+    A9m = M(B1) @ M(B5) + M(B4)
+    T18 = M(B2) + (M(B3) + A9m) @ A9m
+    assert np.abs(T18 - o.expm(A)).max() < 2e-14
