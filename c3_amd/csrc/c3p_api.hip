@@ -37,7 +37,7 @@ int fail(const char* fmt, ...) {
   } while (0)
 
 // Per-device workspace slots, grown lazily, freed by c3p_shutdown().
-enum Slot { SL_SEG_A = 0, SL_SEG_B, SL_SCRATCH, SL_CLP, SL_TABLES, SL_IN0, SL_IN1, SL_IN2, SL_IN3, SL_IN4, SL_OUT0, SL_OUT1, SL_COUNT };
+enum Slot { SL_SEG_A = 0, SL_SEG_B, SL_SCRATCH, SL_CLP, SL_TABLES, SL_COUNTERS, SL_IN0, SL_IN1, SL_IN2, SL_IN3, SL_IN4, SL_OUT0, SL_OUT1, SL_COUNT };
 
 struct DeviceWs {
   void* ptr[SL_COUNT] = {};
@@ -245,6 +245,8 @@ int pick_segments(int B, int N, int K, int Dm, bool need_mult4) {
   const long lds_budget = 20 * 1024 - (long)(c3p_smalld_table_doubles(Dm, K) + 4 * c3p_smalld_mat_doubles(Dm)) * 8;
   const long lmax_cap = K > 0 ? lds_budget / (32L * K) : (1L << 30);
   while ((N + S - 1) / S > lmax_cap && S < N) ++S;
+  // a multiple of four lets every wave fold its four segments in registers (fused combine)
+  if (S > 1 && ((S + 3) / 4) * 4 <= N) S = ((S + 3) / 4) * 4;
   if (need_mult4) S = ((S + 3) / 4) * 4;
   if (S > N) return -1;
   return (int)S;
@@ -270,6 +272,13 @@ int run_pwc_smalld(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const 
   p.Dh = D;
   p.lindblad = lindblad;
   p.tables = (double*)v;
+  const bool fuse = (S > 1) && (S % 4 == 0) && !getenv("C3P_NO_FUSE");
+  if (fuse) {
+    void* cv;
+    if (ws_get(w, SL_COUNTERS, (size_t)B * sizeof(int), &cv)) return -1;
+    p.counters = (int*)cv;
+    p.ncounters = B;
+  }
   HIP_TRY(c3p_launch_smalld_prep(p, Dm, nsamp, st));
   SmallArgs a = {};
   a.tables = (const double*)v;
@@ -290,12 +299,18 @@ int run_pwc_smalld(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const 
     void* sv;
     if (ws_get(w, SL_SEG_A, (size_t)B * S * Dm * Dm * sizeof(cplx), &sv)) return -1;
     a.seg_out = (cplx*)sv;
+    if (fuse) {
+      a.fuse = 1;
+      a.counters = p.counters;
+      a.final_out = U_out;
+      a.fr_phase = fr_phase;
+    }
   }
   g_last_kernel = C3P_KERNEL_SMALLD;
   if (record_start(w, st)) return -1;
   HIP_TRY(c3p_launch_smalld_chain(a, st));
   if (record_stop(w, st)) return -1;
-  if (S > 1) return combine_smalld(w, a.seg_out, B, S, Dm, 0, fr_phase, U_out, st);
+  if (S > 1 && !fuse) return combine_smalld(w, a.seg_out, B, S, Dm, 0, fr_phase, U_out, st);
   return 0;
 }
 

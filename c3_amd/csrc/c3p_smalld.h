@@ -15,8 +15,14 @@ struct SmallArgs {
   int Lmax;  // ceil(N/S)
   int mode;  // C3P_MODE_UNITARY / C3P_MODE_LINDBLAD (tables) or C3P_MODE_GIVEN
   int right_order;
-  cplx* seg_out;  // [B,S,Dm,Dm]
+  cplx* seg_out;  // [B,S,Dm,Dm]   (fused combine: [B,S/4,Dm,Dm] wave partials)
   cplx* dUs_out;  // [B,N,Dm,Dm] or null
+  // Fused ordered combine (table modes, S % 4 == 0): every wave folds its four consecutive
+  // segments in registers, publishes one partial product, and the last wave to arrive for a
+  // sample (per-sample counter, agent-scope release/acquire) folds the S/4 partials into U.
+  int fuse;
+  int* counters;   // [B], zeroed by the prep kernel of the same call
+  cplx* final_out;  // [B,Dm,Dm]
 };
 
 struct PrepArgs {
@@ -28,6 +34,8 @@ struct PrepArgs {
   double dt;
   int K, Dh, lindblad;
   double* tables;
+  int* counters;  // zeroed here (one launch fewer than a memset node); may be null
+  int ncounters;
 };
 
 int c3p_smalld_mat_doubles(int Dm);

@@ -179,7 +179,7 @@ __device__ __forceinline__ void plan_q4(double nrm, int& r, int& s) {
 
 // Write a D-layout matrix times the complex scalar (sr + i si), with optional row phases,
 // to a plain complex [D][D] array.
-template <int D>
+template <int D, bool WRITE_THROUGH = false>
 __device__ __forceinline__ void store_plain(const double (&zh)[SD<D>::NBI][SD<D>::NJ], double* dst,
                                             double sr, double si, const double* row_phase,
                                             const LanePos& lp, bool active) {
@@ -201,7 +201,16 @@ __device__ __forceinline__ void store_plain(const double (&zh)[SD<D>::NBI][SD<D>
       // r even: mine = Re, other = Im ; r odd: mine = Im, other = Re
       const double outv = (lp.r & 1) ? fma(pr, mine, pi * other) : fma(pr, mine, -pi * other);
       const int col = 4 * J + lp.c;
-      if (active && row < D && col < D) dst[(row * D + col) * 2 + (lp.r & 1)] = outv;
+      if (active && row < D && col < D) {
+        double* p = dst + (row * D + col) * 2 + (lp.r & 1);
+        if constexpr (WRITE_THROUGH) {
+          // sc1 (write-through) store: visible to other CUs/XCDs without a release fence
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(outv),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          *p = outv;
+        }
+      }
     }
   }
 }
@@ -451,6 +460,99 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
     }
   }
   // ---- segment result ----
+  if constexpr (!GIVEN) {
+    if (A.fuse) {
+      // (1) fold the wave's four consecutive segments: W = U3 U2 U1 U0 (later segment on the left)
+      double tr = mus_r, ti = mus_i;
+      tr += __shfl_xor(tr, 4);
+      tr += __shfl_xor(tr, 8);
+      ti = c3p_phase_add(ti, __shfl_xor(ti, 4));
+      ti = c3p_phase_add(ti, __shfl_xor(ti, 8));
+      const int rrest = roff - lp.b * MAT;
+      const int roff1 = ((lp.b + 1) & 3) * MAT + rrest;  // A fragments of the NEXT chain's image
+      const int roff2 = ((lp.b + 2) & 3) * MAT + rrest;
+      double V[NBI][NJ], Wt[NBI][NJ];
+#pragma unroll
+      for (int I = 0; I < NBI; ++I)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) V[I][J] = Wt[I][J] = 0.0;
+      write_image<D>(U, img, woff);
+      mm_img<D>(img, roff1, negmask, U, V);  // slots 0, 2: U_{b+1} U_b
+      write_image<D>(V, img, woff);
+      mm_img<D>(img, roff2, negmask, V, Wt);  // slot 0: (U3 U2)(U1 U0)
+      const int nW = A.S >> 2;
+      const int wq = seg >> 2;
+      double sn, cs;
+      sincos(ti, &sn, &cs);
+      const double er = exp(tr);
+      const double* ph = A.fr_phase ? A.fr_phase + (long)sample * D : nullptr;
+      if (nW == 1) {
+        double* dst = reinterpret_cast<double*>(A.final_out) + (long)sample * D * D * 2;
+        store_plain<D>(Wt, dst, er * cs, er * sn, ph, lp, valid && lp.b == 0);
+        return;
+      }
+      {
+        double* dst = reinterpret_cast<double*>(A.seg_out) + ((long)sample * nW + wq) * D * D * 2;
+        store_plain<D, true>(Wt, dst, er * cs, er * sn, nullptr, lp, valid && lp.b == 0);
+      }
+      // (2) publish and arrive (cdna guide G16, form R1: write-through payload, drain, relaxed ticket)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      int old = 0;
+      if (lane == 0)
+        old = __hip_atomic_fetch_add(A.counters + sample, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = __builtin_amdgcn_readfirstlane(old);
+      if (old != nW - 1) return;
+      // (3) last arriver of this sample: fold the nW partials (slot b takes a contiguous quarter)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const int lo = (lp.b * nW) >> 2, hi = ((lp.b + 1) * nW) >> 2;
+      const int cnt = hi - lo;
+      const int cmax = (nW + 3) >> 2;
+      const double* base = reinterpret_cast<const double*>(A.seg_out) + ((long)sample * nW + lo) * D * D * 2;
+      for (int t = 0; t < cmax; ++t) {
+        const bool act = t < cnt;
+        const double* src = base + (long)(act ? t : 0) * D * D * 2;
+        double P[NBI][NJ];
+#pragma unroll
+        for (int I = 0; I < NBI; ++I)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) {
+            const int row = 2 * I + (lp.r >> 1), col = 4 * J + lp.c;
+            const bool in = row < D && col < D;
+            const double idv = (in && row == col && (lp.r & 1) == 0) ? 1.0 : 0.0;  // identity when idle
+            P[I][J] = (act && in) ? src[(row * D + col) * 2 + (lp.r & 1)] : idv;
+          }
+        if (t == 0) {
+#pragma unroll
+          for (int I = 0; I < NBI; ++I)
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) U[I][J] = P[I][J];
+        } else {
+          double acc[NBI][NJ];
+#pragma unroll
+          for (int I = 0; I < NBI; ++I)
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) acc[I][J] = 0.0;
+          write_image<D>(P, img, woff);
+          mm_img<D>(img, roff, negmask, U, acc);
+#pragma unroll
+          for (int I = 0; I < NBI; ++I)
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) U[I][J] = acc[I][J];
+        }
+      }
+#pragma unroll
+      for (int I = 0; I < NBI; ++I)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) V[I][J] = Wt[I][J] = 0.0;
+      write_image<D>(U, img, woff);
+      mm_img<D>(img, roff1, negmask, U, V);
+      write_image<D>(V, img, woff);
+      mm_img<D>(img, roff2, negmask, V, Wt);
+      double* dst = reinterpret_cast<double*>(A.final_out) + (long)sample * D * D * 2;
+      store_plain<D>(Wt, dst, 1.0, 0.0, ph, lp, lp.b == 0);
+      return;
+    }
+  }
   double sn, cs;
   sincos(mus_i, &sn, &cs);
   const double er = exp(mus_r);
@@ -472,6 +574,8 @@ __global__ void __launch_bounds__(64) smalld_prep_kernel(PrepArgs P) {
   const int tid = threadIdx.x;
   const int ti = blockIdx.x % (1 + P.K);
   const int sample = blockIdx.x / (1 + P.K);
+  if (P.counters != nullptr && blockIdx.x == 0)
+    for (int e = tid; e < P.ncounters; e += 64) P.counters[e] = 0;
   const int Dh = P.Dh;  // Hilbert dimension of the inputs (D for unitary, sqrt(D) for Lindblad)
   const cplx* h = (ti == 0) ? P.h0 + (long)sample * P.h0_bstride
                             : P.hks + (long)sample * P.hks_bstride + (long)(ti - 1) * Dh * Dh;
