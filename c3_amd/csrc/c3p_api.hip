@@ -13,6 +13,7 @@
 #include "c3p_ode.h"
 #include "c3p_smalld.h"
 #include "c3p_midd.h"
+#include "c3p_bigd.h"
 
 namespace {
 
@@ -416,6 +417,86 @@ int run_pwc_midd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Big-D MFMA path (81 x 81 Lindblad superoperators): 8-wave workgroup per chain, global arena
+// ---------------------------------------------------------------------------
+int run_pwc_bigd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs,
+                 const double* signals, const cplx* clp, double dt, int B, int K, int N, int D, int Dm,
+                 const double* fr_phase, cplx* U_out, cplx* dUs_out, hipStream_t st) {
+  int nig, nj, wd;
+  if (!c3p_bigd_geometry(Dm, &nig, &nj, &wd)) return 1;
+  const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
+  long S = (C3P_BIGD_MAX_WGS + B - 1) / B;
+  const long smax = N / 8 > 1 ? N / 8 : 1;
+  if (S > smax) S = smax;
+  if (S < 1) S = 1;
+  while (c3p_bigd_lds_bytes(Dm, K, (int)((N + S - 1) / S)) > 150 * 1024 && S < N) ++S;
+  if (c3p_bigd_lds_bytes(Dm, K, (int)((N + S - 1) / S)) > 150 * 1024) return 1;
+  const int nsamp = per_sample ? B : 1;
+  void* v;
+  if (ws_get(w, SL_TABLES, (size_t)nsamp * c3p_bigd_table_doubles(Dm, K) * sizeof(double), &v)) return -1;
+  MidPrepArgs p = {};
+  p.h0 = h0;
+  p.h0_bstride = h0_bs;
+  p.hks = hks;
+  p.hks_bstride = hk_bs;
+  p.clp = clp;
+  p.dt = dt;
+  p.K = K;
+  p.Dh = D;
+  p.Dm = Dm;
+  p.lindblad = lindblad;
+  p.rows = 16 * nig;
+  p.W = wd;
+  p.tables = (double*)v;
+  HIP_TRY(c3p_launch_midd_prep(p, nsamp, st));
+  void* av;
+  if (ws_get(w, SL_SCRATCH, c3p_bigd_arena_doubles(Dm) * sizeof(double), &av)) return -1;
+  MidArgs a = {};
+  a.tables = (const double*)v;
+  a.tab_per_sample = per_sample ? 1 : 0;
+  a.signals = signals;
+  a.B = B;
+  a.K = K;
+  a.N = N;
+  a.Dm = Dm;
+  a.S = (int)S;
+  a.Lmax = (int)((N + S - 1) / S);
+  a.mode = lindblad ? C3P_MODE_LINDBLAD : C3P_MODE_UNITARY;
+  a.dUs_out = dUs_out;
+  cplx* seg = U_out;
+  if (S > 1) {
+    void* sv;
+    if (ws_get(w, SL_SEG_A, (size_t)B * S * Dm * Dm * sizeof(cplx), &sv)) return -1;
+    seg = (cplx*)sv;
+  }
+  a.seg_out = seg;
+  g_last_kernel = C3P_KERNEL_MFMA;
+  if (record_start(w, st)) return -1;
+  HIP_TRY(c3p_launch_bigd_chain(a, (double*)av, st));
+  if (record_stop(w, st)) return -1;
+  if (S == 1 && fr_phase) HIP_TRY(c3p_launch_rowphase(U_out, fr_phase, B, Dm, st));
+  if (S > 1) {
+    // ordered combine of the few segment products with the generic kernel (GIVEN mode)
+    ChainArgs c = {};
+    c.mode = C3P_MODE_GIVEN;
+    c.mats = seg;
+    c.B = B;
+    c.N = (int)S;
+    c.D = D;
+    c.Dm = Dm;
+    c.fr_phase = fr_phase;
+    const int keep = g_last_kernel;
+    const int prof = g_profiling;
+    g_profiling = 0;  // keep the event pair on the main kernel
+    const int rc = run_chain_generic(w, c, U_out, st);
+    g_profiling = prof;
+    g_last_kernel = keep;
+    if (rc) return -1;
+  }
+  return 0;
+}
+
 // Host-pointer staging helpers --------------------------------------------------
 struct Stage {
   DeviceWs* w;
@@ -521,6 +602,12 @@ int pwc_common(int lindblad, const void* h0, int64_t h0_bstride, const void* hks
   }
   if (!done && !(flags & C3P_FORCE_GENERIC) && !per_slice && Dm >= 13 && Dm <= 40 && K <= 16) {
     const int rc = run_pwc_midd(w, lindblad, a.h0, a.h0_bstride, a.hks, a.hks_bstride, a.signals, a.clp, dt, B,
+                                K, N, D, Dm, a.fr_phase, (cplx*)d_U, a.dUs_out, st);
+    if (rc < 0) return -1;
+    done = (rc == 0);
+  }
+  if (!done && !(flags & C3P_FORCE_GENERIC) && !per_slice && K <= 16) {
+    const int rc = run_pwc_bigd(w, lindblad, a.h0, a.h0_bstride, a.hks, a.hks_bstride, a.signals, a.clp, dt, B,
                                 K, N, D, Dm, a.fr_phase, (cplx*)d_U, a.dUs_out, st);
     if (rc < 0) return -1;
     done = (rc == 0);

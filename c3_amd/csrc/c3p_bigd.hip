@@ -1,0 +1,442 @@
+// Big-D propagator chains on the f64 matrix cores: 41 <= Dm <= 96, in particular the
+// 81 x 81 Lindblad superoperator of two qutrits (BASELINE cfg4).
+//
+// Same arithmetic as c3p_midd.hip (half images of the real 2x2 representation, 16x4 output
+// tiles on v_mfma_f64_4x4x4_4b_f64, T18 + scaling/squaring), but a half image of an 81 x 81
+// matrix is 176 x 86 doubles = 121 KB: only ONE fits in LDS.  So
+//   * every matrix of a chain lives in a per-workgroup GLOBAL scratch arena (MALL/L2 resident),
+//   * for each product the LEFT operand's image is copied global -> LDS once (it is reused by
+//     all 41 K-steps of all 231 tiles), and the RIGHT operand's 4x4 blocks are read straight
+//     from global memory, prefetched one K-step ahead (16 distinct 8-byte words per wave load),
+//   * one workgroup = 8 wavefronts (2 per SIMD) owns a chain; the 231 tiles are dealt
+//     29 per wave, compile-time, so a K-step is 11 LDS reads + 3-4 global loads for 29 MFMAs.
+// Algorithmic intensity per product: 4.25 Mflop for 363 KB of image traffic = 11.7 flop/B,
+// i.e. the kernel sits near the MI355X fp64-compute / HBM ridge; the arena (1 MB per
+// workgroup) is sized to stay in the 256 MB Infinity Cache.
+#include "c3p_common.h"
+#include "c3p_kernels.h"
+#include "c3p_midd.h"
+#include "c3p_bigd.h"
+
+extern __shared__ __attribute__((aligned(16))) double c3p_bd_lds[];
+
+namespace {
+
+constexpr int BW = 8;  // wavefronts per workgroup
+
+// An opaque copy of a lane offset: stops LLVM from hoisting the (loop-invariant) per-tile 64-bit
+// addresses of every image out of the slice loop, which would need hundreds of live registers.
+__device__ __forceinline__ int bd_opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+__device__ __forceinline__ double bd_mfma4(double a, double b, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ double bd_flip(double v, unsigned mask_hi) {
+  unsigned long long u = __double_as_longlong(v);
+  u ^= ((unsigned long long)mask_hi) << 32;
+  return __longlong_as_double(u);
+}
+__device__ __forceinline__ double bd_rfl(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readfirstlane(lo);
+  hi = __builtin_amdgcn_readfirstlane(hi);
+  return __hiloint2double(hi, lo);
+}
+
+template <int NIG, int NJ>
+struct BD {
+  static constexpr int ROWS = 16 * NIG;
+  static constexpr int JB = NJ / BW;        // column blocks per wave: the first NJ % BW waves take JB + 1
+  static constexpr int JR = NJ % BW;
+  static constexpr int JS = JB + (JR ? 1 : 0);  // register tiles per wave: JS x NIG
+};
+
+struct BigCommon {
+  int tid, lane, r, b, c;
+  int D, nbk, K;
+  int sample, n0, len;
+  int aoff, boff, dbase;
+  int J0, nJ;  // this wave's column blocks [J0, J0 + nJ)
+  unsigned negmask;
+  int ps;
+  double scale;
+  const double* tabs;
+  double* arena;  // this workgroup's global images
+  double* ldsA;
+  double* sg;
+};
+
+// arena image slots
+enum { G_X = 0, G_A2, G_A3, G_A6, G_T1, G_T2, G_U, G_NIMG };
+
+// acc[jj][Ig] += (A image in LDS) * (B image in global) for the wave's column blocks.
+// All waves run the same code; only J0 / nJ differ (runtime, wave-uniform).
+template <int NIG, int NJ, int W>
+__device__ __forceinline__ void bd_mm(const BigCommon& cm, const double* gB, double (&acc)[BD<NIG, NJ>::JS][NIG]) {
+  constexpr int JS = BD<NIG, NJ>::JS;
+  const double* ldsA = cm.ldsA + bd_opaque(cm.aoff);
+  const double* pB = gB + bd_opaque(cm.boff + cm.J0 * 4);
+  const bool last = cm.nJ == JS;  // does the wave use its last register column?
+  double a0[NIG], a1[NIG], b0[JS], b1[JS];
+  auto load = [&](double (&a)[NIG], double (&bb)[JS], int K) {
+#pragma unroll
+    for (int jj = 0; jj < JS; ++jj) bb[jj] = (jj < JS - 1 || last) ? pB[K * 4 * W + jj * 4] : 0.0;
+#pragma unroll
+    for (int Ig = 0; Ig < NIG; ++Ig) a[Ig] = bd_flip(ldsA[Ig * 16 * W + 2 * K], cm.negmask);
+  };
+  auto fmas = [&](const double (&a)[NIG], const double (&bb)[JS]) {
+#pragma unroll
+    for (int jj = 0; jj < JS - 1; ++jj)
+#pragma unroll
+      for (int Ig = 0; Ig < NIG; ++Ig) acc[jj][Ig] = bd_mfma4(a[Ig], bb[jj], acc[jj][Ig]);
+    if (last) {
+#pragma unroll
+      for (int Ig = 0; Ig < NIG; ++Ig) acc[JS - 1][Ig] = bd_mfma4(a[Ig], bb[JS - 1], acc[JS - 1][Ig]);
+    }
+  };
+  load(a0, b0, 0);
+  for (int K = 0; K < cm.nbk; K += 2) {
+    const int K1 = (K + 1 < cm.nbk) ? K + 1 : K;
+    load(a1, b1, K1);
+    __builtin_amdgcn_sched_barrier(0);
+    fmas(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int K2 = (K + 2 < cm.nbk) ? K + 2 : K;
+    load(a0, b0, K2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (K + 1 < cm.nbk) fmas(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int NIG, int NJ, int W, bool DUS>
+__device__ __forceinline__ void bigd_body(const MidArgs& A, const BigCommon& cm, long chain) {
+  using C = BD<NIG, NJ>;
+  constexpr int JS = C::JS, IMG = C::ROWS * W;
+  const int D = cm.D, K = cm.K, r = cm.r;
+  const int rrow = 4 * cm.b + cm.r;
+  const int tbase = cm.dbase + 4 * cm.J0;  // tile (jj, Ig) element: tbase + 16 Ig W + 4 jj
+  double mus_r = 0.0, mus_i = 0.0;
+  const double* tabs = cm.tabs;
+  auto gimg = [&](int slot) -> double* { return cm.arena + (long)slot * IMG; };
+  typedef double Tile[JS][NIG];
+
+  auto jj_on = [&](int jj) -> bool { return jj < cm.nJ; };
+  auto store_tiles = [&](double* img, const Tile& v) {
+    const int tb = bd_opaque(tbase);
+#pragma unroll
+    for (int jj = 0; jj < JS; ++jj)
+      if (jj_on(jj)) {
+#pragma unroll
+        for (int Ig = 0; Ig < NIG; ++Ig) img[tb + 16 * Ig * W + 4 * jj] = v[jj][Ig];
+      }
+  };
+  auto zero = [&](Tile& v) {
+#pragma unroll
+    for (int jj = 0; jj < JS; ++jj)
+#pragma unroll
+      for (int Ig = 0; Ig < NIG; ++Ig) v[jj][Ig] = 0.0;
+  };
+  // workgroup-wide: copy the left operand's image to LDS, then multiply
+  auto product = [&](const double* gA, const double* gB, Tile& acc) {
+    __syncthreads();  // previous product done with ldsA; global images written by all waves
+    for (int e = cm.tid * 2; e < IMG; e += BW * 64 * 2) {
+      const double2 v = *reinterpret_cast<const double2*>(gA + e);
+      *reinterpret_cast<double2*>(cm.ldsA + e) = v;
+    }
+    __syncthreads();
+    bd_mm<NIG, NJ, W>(cm, gB, acc);
+  };
+  // out = cx X + c2 A2 + c3 A3 + c6 A6 + c0 I at the lane's tile positions (images in global)
+  auto comb = [&](Tile& out, double c0, double cx, double c2, double c3, double c6) {
+    const double *gx = gimg(G_X), *g2 = gimg(G_A2), *g3 = gimg(G_A3), *g6 = gimg(G_A6);
+    const int tb = bd_opaque(tbase);
+#pragma unroll
+    for (int jj = 0; jj < JS; ++jj) {
+      if (!jj_on(jj)) continue;
+      const int col = 4 * (cm.J0 + jj) + cm.c;
+#pragma unroll
+      for (int Ig = 0; Ig < NIG; ++Ig) {
+        const int o = tb + 16 * Ig * W + 4 * jj;
+        double v = c2 * g2[o];
+        v = fma(c3, g3[o], v);
+        if (cx != 0.0) v = fma(cx, gx[o], v);
+        if (c6 != 0.0) v = fma(c6, g6[o], v);
+        const int row = 16 * Ig + rrow;
+        const bool diag = ((row & 1) == 0) && ((row >> 1) == col) && (col < D);
+        v += (c0 != 0.0 && diag) ? c0 : 0.0;
+        out[jj][Ig] = v;
+        if ((Ig & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the loads in flight (registers)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto store_plain = [&](double* dst, const Tile& v, double sr, double si) {
+#pragma unroll
+    for (int jj = 0; jj < JS; ++jj) {
+      if (!jj_on(jj)) continue;
+      const int col = 4 * (cm.J0 + jj) + cm.c;
+#pragma unroll
+      for (int Ig = 0; Ig < NIG; ++Ig) {
+        const int ci = (16 * Ig + rrow) >> 1;
+        const double mine = v[jj][Ig];
+        const double other = __shfl_xor(mine, 16);
+        const double outv = (r & 1) ? fma(sr, mine, si * other) : fma(sr, mine, -si * other);
+        if (ci < D && col < D) dst[(ci * D + col) * 2 + (r & 1)] = outv;
+      }
+    }
+  };
+
+  Tile P, acc;
+  for (int t = 0; t < cm.len; ++t) {
+    // ---- X = scale (G0 + sum_k c_k G_k) ----
+    double mu_r = tabs[IMG + 0], mu_i = tabs[IMG + 1];
+    {
+      zero(acc);
+      const int tb = bd_opaque(tbase);
+#pragma unroll
+      for (int jj = 0; jj < JS; ++jj) {
+        if (!jj_on(jj)) continue;
+#pragma unroll
+        for (int Ig = 0; Ig < NIG; ++Ig) acc[jj][Ig] = cm.scale * tabs[tb + 16 * Ig * W + 4 * jj];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      for (int k = 0; k < K; ++k) {
+        const double c0 = cm.sg[k * A.Lmax + t];
+        const double ck = cm.scale * c0;
+        const double* tk = tabs + (long)(k + 1) * (IMG + 4);
+        mu_r = fma(c0, tk[IMG + 0], mu_r);
+        mu_i = fma(c0, tk[IMG + 1], mu_i);
+#pragma unroll
+        for (int jj = 0; jj < JS; ++jj) {
+          if (!jj_on(jj)) continue;
+#pragma unroll
+          for (int Ig = 0; Ig < NIG; ++Ig) acc[jj][Ig] = fma(ck, tk[tb + 16 * Ig * W + 4 * jj], acc[jj][Ig]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      store_tiles(gimg(G_X), acc);
+    }
+    // ---- T18: A2 = X X, A3 = X A2, A6 = A3 A3 ----
+    zero(acc);
+    product(gimg(G_X), gimg(G_X), acc);
+    store_tiles(gimg(G_A2), acc);
+    zero(acc);
+    product(gimg(G_X), gimg(G_A2), acc);
+    store_tiles(gimg(G_A3), acc);
+    zero(acc);
+    product(gimg(G_A3), gimg(G_A3), acc);
+    store_tiles(gimg(G_A6), acc);
+    // ---- A9 = B1 B5 + B4 ----
+    comb(acc, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0);
+    store_tiles(gimg(G_T1), acc);  // B1
+    comb(acc, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64);
+    store_tiles(gimg(G_T2), acc);  // B5
+    comb(acc, C3P_T18_B03, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63);  // B4
+    product(gimg(G_T1), gimg(G_T2), acc);  // acc = A9
+    // ---- P = B2 + (B3 + A9) A9 ----
+    comb(P, C3P_T18_B02, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62);  // B3
+#pragma unroll
+    for (int jj = 0; jj < JS; ++jj)
+#pragma unroll
+      for (int Ig = 0; Ig < NIG; ++Ig) P[jj][Ig] += acc[jj][Ig];
+    __syncthreads();  // every wave is done reading T1 / T2
+    store_tiles(gimg(G_T1), P);    // L = B3 + A9
+    store_tiles(gimg(G_T2), acc);  // A9
+    comb(P, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61);  // B2
+    product(gimg(G_T1), gimg(G_T2), P);
+    // ---- squarings ----
+    for (int it = 0; it < cm.ps; ++it) {
+      __syncthreads();
+      store_tiles(gimg(G_T1), P);
+      zero(acc);
+      product(gimg(G_T1), gimg(G_T1), acc);
+#pragma unroll
+      for (int jj = 0; jj < JS; ++jj)
+#pragma unroll
+        for (int Ig = 0; Ig < NIG; ++Ig) P[jj][Ig] = acc[jj][Ig];
+    }
+    if constexpr (DUS) {
+      double sn, cs;
+      sincos(mu_i, &sn, &cs);
+      const double er = exp(mu_r);
+      double* dst = reinterpret_cast<double*>(A.dUs_out) + ((long)cm.sample * A.N + cm.n0 + t) * D * D * 2;
+      store_plain(dst, P, er * cs, er * sn);
+    }
+    // ---- chain: U <- E U ; U lives in the arena ----
+    if (t == 0) {
+      __syncthreads();
+      store_tiles(gimg(G_U), P);
+      mus_r = mu_r;
+      mus_i = c3p_phase_add(0.0, mu_i);
+    } else {
+      __syncthreads();
+      store_tiles(gimg(G_T1), P);
+      zero(acc);
+      product(gimg(G_T1), gimg(G_U), acc);
+      __syncthreads();  // every wave has read the old U
+      store_tiles(gimg(G_U), acc);
+      mus_r += mu_r;
+      mus_i = c3p_phase_add(mus_i, mu_i);
+    }
+  }
+  // ---- result ----
+  __syncthreads();
+  zero(P);
+#pragma unroll
+  for (int jj = 0; jj < JS; ++jj)
+    if (jj_on(jj)) {
+#pragma unroll
+      for (int Ig = 0; Ig < NIG; ++Ig) P[jj][Ig] = gimg(G_U)[bd_opaque(tbase) + 16 * Ig * W + 4 * jj];
+    }
+  double sn, cs;
+  sincos(mus_i, &sn, &cs);
+  const double er = exp(mus_r);
+  double* dst = reinterpret_cast<double*>(A.seg_out) + chain * D * D * 2;
+  store_plain(dst, P, er * cs, er * sn);  // row phases: separate epilogue kernel (c3p_launch_rowphase)
+}
+
+template <int NIG, int NJ, int W, bool DUS>
+__global__ void __launch_bounds__(512, 2) bigd_chain_kernel(MidArgs A, double* arena_base) {
+  using C = BD<NIG, NJ>;
+  constexpr int IMG = C::ROWS * W;
+  BigCommon cm;
+  cm.tid = threadIdx.x;
+  cm.lane = cm.tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(cm.tid >> 6);
+  cm.r = cm.lane >> 4;
+  cm.b = (cm.lane >> 2) & 3;
+  cm.c = cm.lane & 3;
+  cm.D = A.Dm;
+  cm.nbk = (2 * cm.D + 3) / 4;
+  cm.K = A.K;
+  const int K = A.K;
+  cm.ldsA = c3p_bd_lds;
+  cm.sg = cm.ldsA + IMG;
+  __shared__ double red[BW];
+  // column blocks of this wave
+  cm.nJ = C::JB + (wave < C::JR ? 1 : 0);
+  cm.J0 = wave * C::JB + (wave < C::JR ? wave : C::JR);
+
+  cm.aoff = (4 * cm.b + (cm.c & ~1) + ((cm.c ^ cm.r) & 1)) * W + (cm.r >> 1);
+  cm.boff = cm.r * W + cm.c;
+  cm.dbase = (4 * cm.b + cm.r) * W + cm.c;
+  cm.negmask = (((cm.c & 1) == 0) && ((cm.r & 1) == 1)) ? 0x80000000u : 0u;
+
+  // one arena per WORKGROUP (re-used for every chain it processes): the resident set is
+  // gridDim.x x 7 images, sized by the launcher to stay inside the Infinity Cache
+  cm.arena = arena_base + (long)blockIdx.x * G_NIMG * IMG;
+  // zero it once: padding rows / columns of every image must stay zero
+  for (long e = cm.tid; e < (long)G_NIMG * IMG; e += BW * 64) cm.arena[e] = 0.0;
+
+  const long nchains = (long)A.B * A.S;
+  for (long chain = blockIdx.x; chain < nchains; chain += gridDim.x) {
+    cm.sample = (int)(chain / A.S);
+    const int seg = (int)(chain - (long)cm.sample * A.S);
+    cm.n0 = (int)(((long)seg * A.N) / A.S);
+    const int n1 = (int)(((long)(seg + 1) * A.N) / A.S);
+    cm.len = n1 - cm.n0;
+    cm.tabs = A.tables + (long)(A.tab_per_sample ? cm.sample : 0) * (1 + K) * (IMG + 4);
+    __syncthreads();  // previous chain's use of sg / red is over
+    double nrm = cm.tabs[IMG + 2];
+    for (int k = 0; k < K; ++k) {
+      const double* s = A.signals + ((long)cm.sample * K + k) * A.N + cm.n0;
+      double cmax = 0.0;
+      for (int t = cm.tid; t < cm.len; t += BW * 64) {
+        const double v = s[t];
+        cm.sg[k * A.Lmax + t] = v;
+        cmax = fmax(cmax, fabs(v));
+      }
+      for (int o = 32; o >= 1; o >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, o));
+      if (cm.lane == 0) red[wave] = cmax;
+      __syncthreads();
+      cmax = 0.0;
+      for (int w = 0; w < BW; ++w) cmax = fmax(cmax, red[w]);
+      __syncthreads();
+      nrm = fma(cmax, cm.tabs[(long)(k + 1) * (IMG + 4) + IMG + 2], nrm);
+    }
+    nrm = bd_rfl(nrm);
+    int s18 = 0;
+    {
+      double p = C3P_T18_THETA;
+      while (p < nrm && s18 < 40) {
+        p *= 2.0;
+        ++s18;
+      }
+    }
+    cm.ps = __builtin_amdgcn_readfirstlane(s18);
+    cm.scale = ldexp(1.0, -cm.ps);
+    __syncthreads();
+    bigd_body<NIG, NJ, W, DUS>(A, cm, chain);
+  }
+}
+
+// U[b][i][:] *= exp(i phase[b][i])  (frame-rotation row phases, experiment.py:482-509)
+__global__ void rowphase_kernel(cplx* U, const double* phase, int Dm, long total) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const long row = e / Dm;  // = b * Dm + i
+  double sn, cs;
+  sincos(phase[row], &sn, &cs);
+  U[e] = cmul(cmake(cs, sn), U[e]);
+}
+
+template <int NIG, int NJ, int W>
+hipError_t launch_b(const MidArgs& A, double* arena, hipStream_t st) {
+  constexpr int IMG = BD<NIG, NJ>::ROWS * W;
+  const size_t lds = (size_t)(IMG + A.K * A.Lmax) * sizeof(double);
+  const long nchains = (long)A.B * A.S;
+  const unsigned grid = (unsigned)(nchains < C3P_BIGD_MAX_WGS ? nchains : C3P_BIGD_MAX_WGS);
+  auto go = [&](auto kern) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BW * 64), lds, st, A, arena);
+    return hipGetLastError();
+  };
+  if (A.dUs_out) return go(bigd_chain_kernel<NIG, NJ, W, true>);
+  return go(bigd_chain_kernel<NIG, NJ, W, false>);
+}
+
+}  // namespace
+
+bool c3p_bigd_geometry(int Dm, int* nig, int* nj, int* w) {
+  if (Dm < 77 || Dm > 84) return false;  // one geometry class for now: 81 x 81 superoperators
+  *nig = 11;
+  *nj = 21;
+  *w = 86;
+  return true;
+}
+
+size_t c3p_bigd_table_doubles(int Dm, int K) {
+  int nig, nj, w;
+  if (!c3p_bigd_geometry(Dm, &nig, &nj, &w)) return 0;
+  return (size_t)(1 + K) * ((size_t)16 * nig * w + 4);
+}
+
+size_t c3p_bigd_arena_doubles(int Dm) {  // for the whole launch (one arena per workgroup)
+  int nig, nj, w;
+  if (!c3p_bigd_geometry(Dm, &nig, &nj, &w)) return 0;
+  return (size_t)C3P_BIGD_MAX_WGS * G_NIMG * 16 * nig * w;
+}
+
+size_t c3p_bigd_lds_bytes(int Dm, int K, int Lmax) {
+  int nig, nj, w;
+  if (!c3p_bigd_geometry(Dm, &nig, &nj, &w)) return 0;
+  return ((size_t)16 * nig * w + (size_t)K * Lmax) * sizeof(double);
+}
+
+hipError_t c3p_launch_rowphase(cplx* U, const double* phase, int B, int Dm, hipStream_t st) {
+  const long total = (long)B * Dm * Dm;
+  hipLaunchKernelGGL(rowphase_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, U, phase, Dm, total);
+  return hipGetLastError();
+}
+
+hipError_t c3p_launch_bigd_chain(const MidArgs& A, double* arena, hipStream_t st) {
+  int nig, nj, w;
+  if (!c3p_bigd_geometry(A.Dm, &nig, &nj, &w)) return hipErrorInvalidValue;
+  return launch_b<11, 21, 86>(A, arena, st);
+}
