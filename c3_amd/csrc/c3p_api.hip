@@ -448,6 +448,8 @@ int run_pwc_bigd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   p.lindblad = lindblad;
   p.rows = 16 * nig;
   p.W = wd;
+  p.tile_nig = nig;
+  p.tile_nj = nj;
   p.tables = (double*)v;
   HIP_TRY(c3p_launch_midd_prep(p, nsamp, st));
   void* av;

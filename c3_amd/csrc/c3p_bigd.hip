@@ -78,14 +78,24 @@ template <int NIG, int NJ, int W>
 __device__ __forceinline__ void bd_mm(const BigCommon& cm, const double* gB, double (&acc)[BD<NIG, NJ>::JS][NIG]) {
   constexpr int JS = BD<NIG, NJ>::JS;
   const double* ldsA = cm.ldsA + bd_opaque(cm.aoff);
-  const double* pB = gB + bd_opaque(cm.boff + cm.J0 * 4);
+  // global images are TILE-MAJOR (tile (J,Ig) = 64 contiguous doubles in lane order): element
+  // Bh[4K + r][4J + c] sits at ((J NIG + K/4) 64) + 16 r + 4 (K%4) + c
+  const double* pB = gB + bd_opaque(16 * cm.r + cm.c + cm.J0 * NIG * 64);
   const bool last = cm.nJ == JS;  // does the wave use its last register column?
-  double a0[NIG], a1[NIG], b0[JS], b1[JS];
-  auto load = [&](double (&a)[NIG], double (&bb)[JS], int K) {
+  // A fragments come from LDS (prefetched one K-step ahead); B blocks come from global memory
+  // (Infinity Cache / HBM latency ~1-2 us), prefetched three K-steps ahead through a 4-deep ring.
+  double a0[NIG], a1[NIG], bq[4][JS];
+  const int kl = cm.nbk - 1;
+  auto load_b = [&](double (&bb)[JS], int K) {
+    const int Kc = K < kl ? K : kl;
+    const int kb = 64 * (Kc >> 2) + 4 * (Kc & 3);
 #pragma unroll
-    for (int jj = 0; jj < JS; ++jj) bb[jj] = (jj < JS - 1 || last) ? pB[K * 4 * W + jj * 4] : 0.0;
+    for (int jj = 0; jj < JS; ++jj) bb[jj] = (jj < JS - 1 || last) ? pB[kb + jj * NIG * 64] : 0.0;
+  };
+  auto load_a = [&](double (&a)[NIG], int K) {
+    const int Kc = K < kl ? K : kl;
 #pragma unroll
-    for (int Ig = 0; Ig < NIG; ++Ig) a[Ig] = bd_flip(ldsA[Ig * 16 * W + 2 * K], cm.negmask);
+    for (int Ig = 0; Ig < NIG; ++Ig) a[Ig] = bd_flip(ldsA[Ig * 16 * W + 2 * Kc], cm.negmask);
   };
   auto fmas = [&](const double (&a)[NIG], const double (&bb)[JS]) {
 #pragma unroll
@@ -97,17 +107,30 @@ __device__ __forceinline__ void bd_mm(const BigCommon& cm, const double* gB, dou
       for (int Ig = 0; Ig < NIG; ++Ig) acc[JS - 1][Ig] = bd_mfma4(a[Ig], bb[JS - 1], acc[JS - 1][Ig]);
     }
   };
-  load(a0, b0, 0);
-  for (int K = 0; K < cm.nbk; K += 2) {
-    const int K1 = (K + 1 < cm.nbk) ? K + 1 : K;
-    load(a1, b1, K1);
+  load_b(bq[0], 0);
+  load_b(bq[1], 1);
+  load_b(bq[2], 2);
+  load_a(a0, 0);
+  for (int K = 0; K < cm.nbk; K += 4) {
+    load_b(bq[3], K + 3);
+    load_a(a1, K + 1);
     __builtin_amdgcn_sched_barrier(0);
-    fmas(a0, b0);
+    fmas(a0, bq[0]);
     __builtin_amdgcn_sched_barrier(0);
-    const int K2 = (K + 2 < cm.nbk) ? K + 2 : K;
-    load(a0, b0, K2);
+    load_b(bq[0], K + 4);
+    load_a(a0, K + 2);
     __builtin_amdgcn_sched_barrier(0);
-    if (K + 1 < cm.nbk) fmas(a1, b1);
+    if (K + 1 < cm.nbk) fmas(a1, bq[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(bq[1], K + 5);
+    load_a(a1, K + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (K + 2 < cm.nbk) fmas(a0, bq[2]);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(bq[2], K + 6);
+    load_a(a0, K + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    if (K + 3 < cm.nbk) fmas(a1, bq[3]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -115,10 +138,10 @@ __device__ __forceinline__ void bd_mm(const BigCommon& cm, const double* gB, dou
 template <int NIG, int NJ, int W, bool DUS>
 __device__ __forceinline__ void bigd_body(const MidArgs& A, const BigCommon& cm, long chain) {
   using C = BD<NIG, NJ>;
-  constexpr int JS = C::JS, IMG = C::ROWS * W;
+  constexpr int JS = C::JS, IMG = NIG * NJ * 64;  // global images are tile-major
   const int D = cm.D, K = cm.K, r = cm.r;
   const int rrow = 4 * cm.b + cm.r;
-  const int tbase = cm.dbase + 4 * cm.J0;  // tile (jj, Ig) element: tbase + 16 Ig W + 4 jj
+  const int tbase = cm.lane + cm.J0 * NIG * 64;  // tile (jj, Ig) element in a tile-major global image: tbase + (jj NIG + Ig) 64
   double mus_r = 0.0, mus_i = 0.0;
   const double* tabs = cm.tabs;
   auto gimg = [&](int slot) -> double* { return cm.arena + (long)slot * IMG; };
@@ -131,7 +154,7 @@ __device__ __forceinline__ void bigd_body(const MidArgs& A, const BigCommon& cm,
     for (int jj = 0; jj < JS; ++jj)
       if (jj_on(jj)) {
 #pragma unroll
-        for (int Ig = 0; Ig < NIG; ++Ig) img[tb + 16 * Ig * W + 4 * jj] = v[jj][Ig];
+        for (int Ig = 0; Ig < NIG; ++Ig) img[tb + (jj * NIG + Ig) * 64] = v[jj][Ig];
       }
   };
   auto zero = [&](Tile& v) {
@@ -143,35 +166,122 @@ __device__ __forceinline__ void bigd_body(const MidArgs& A, const BigCommon& cm,
   // workgroup-wide: copy the left operand's image to LDS, then multiply
   auto product = [&](const double* gA, const double* gB, Tile& acc) {
     __syncthreads();  // previous product done with ldsA; global images written by all waves
-    for (int e = cm.tid * 2; e < IMG; e += BW * 64 * 2) {
-      const double2 v = *reinterpret_cast<const double2*>(gA + e);
-      *reinterpret_cast<double2*>(cm.ldsA + e) = v;
+    // tile-major global image -> row-major (stride W) LDS image; one coalesced 512 B read per tile
+    // (15 loads in flight per wave: the global latency is paid twice, not 29 times)
+    {
+      constexpr int NTT = NIG * NJ, CH = 15;
+      const int w0 = cm.tid >> 6;
+      const double* src = gA + bd_opaque(cm.lane);
+      double* dstl = cm.ldsA + bd_opaque(cm.dbase);
+      for (int t0 = w0; t0 < NTT; t0 += BW * CH) {
+        double v[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int tile = t0 + u * BW;
+          v[u] = tile < NTT ? src[tile * 64] : 0.0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int tile = t0 + u * BW;
+          if (tile < NTT) {
+            const int J = tile / NIG, Ig = tile - J * NIG;
+            dstl[16 * Ig * W + 4 * J] = v[u];
+          }
+        }
+      }
     }
     __syncthreads();
     bd_mm<NIG, NJ, W>(cm, gB, acc);
   };
-  // out = cx X + c2 A2 + c3 A3 + c6 A6 + c0 I at the lane's tile positions (images in global)
-  auto comb = [&](Tile& out, double c0, double cx, double c2, double c3, double c6) {
+  // The T18 block polynomials are lane-local linear combinations of X, A2, A3, A6 at the lane's
+  // tile positions.  Those values live in the global arena (too many for registers), so the
+  // combinations are fused into two passes, each loading the four images once per column block
+  // (44 independent loads in flight): pass 1 -> B1, B5 (stored), B4, B2 (registers);
+  // pass 2 -> L = B3 + A9 (stored).
+  auto is_diag = [&](int Ig, int col) -> bool {
+    const int row = 16 * Ig + rrow;
+    return ((row & 1) == 0) && ((row >> 1) == col) && (col < D);
+  };
+  constexpr int NH = (NIG + 1) / 2;  // row groups are processed in two halves to bound registers
+  auto pass1 = [&](Tile& b4) {       // T1 <- B1, T2 <- B5, b4 <- B4
     const double *gx = gimg(G_X), *g2 = gimg(G_A2), *g3 = gimg(G_A3), *g6 = gimg(G_A6);
+    double *t1 = gimg(G_T1), *t2 = gimg(G_T2);
     const int tb = bd_opaque(tbase);
 #pragma unroll
     for (int jj = 0; jj < JS; ++jj) {
       if (!jj_on(jj)) continue;
       const int col = 4 * (cm.J0 + jj) + cm.c;
 #pragma unroll
-      for (int Ig = 0; Ig < NIG; ++Ig) {
-        const int o = tb + 16 * Ig * W + 4 * jj;
-        double v = c2 * g2[o];
-        v = fma(c3, g3[o], v);
-        if (cx != 0.0) v = fma(cx, gx[o], v);
-        if (c6 != 0.0) v = fma(c6, g6[o], v);
-        const int row = 16 * Ig + rrow;
-        const bool diag = ((row & 1) == 0) && ((row >> 1) == col) && (col < D);
-        v += (c0 != 0.0 && diag) ? c0 : 0.0;
-        out[jj][Ig] = v;
-        if ((Ig & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the loads in flight (registers)
+      for (int h = 0; h < 2; ++h) {
+        double vx[NH], v2[NH], v3[NH], v6[NH];
+#pragma unroll
+        for (int u = 0; u < NH; ++u) {
+          const int Ig = h * NH + u;
+          if (Ig < NIG) {
+            const int o = tb + (jj * NIG + Ig) * 64;
+            vx[u] = gx[o];
+            v2[u] = g2[o];
+            v3[u] = g3[o];
+            v6[u] = g6[o];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NH; ++u) {
+          const int Ig = h * NH + u;
+          if (Ig < NIG) {
+            const int o = tb + (jj * NIG + Ig) * 64;
+            const double dg = is_diag(Ig, col) ? 1.0 : 0.0;
+            t1[o] = fma(C3P_T18_A31, v3[u], fma(C3P_T18_A21, v2[u], C3P_T18_A11 * vx[u]));  // B1
+            t2[o] = fma(C3P_T18_B64, v6[u], fma(C3P_T18_B34, v3[u], C3P_T18_B24 * v2[u]));  // B5
+            b4[jj][Ig] = fma(C3P_T18_B63, v6[u], fma(C3P_T18_B33, v3[u], fma(C3P_T18_B23, v2[u],
+                             fma(C3P_T18_B13, vx[u], C3P_T18_B03 * dg))));                   // B4
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto pass2 = [&](const Tile& a9, Tile& b2) {  // T1 <- B3 + A9, T2 <- A9, b2 <- B2
+    const double *gx = gimg(G_X), *g2 = gimg(G_A2), *g3 = gimg(G_A3), *g6 = gimg(G_A6);
+    double *t1 = gimg(G_T1), *t2 = gimg(G_T2);
+    const int tb = bd_opaque(tbase);
+#pragma unroll
+    for (int jj = 0; jj < JS; ++jj) {
+      if (!jj_on(jj)) continue;
+      const int col = 4 * (cm.J0 + jj) + cm.c;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        double vx[NH], v2[NH], v3[NH], v6[NH];
+#pragma unroll
+        for (int u = 0; u < NH; ++u) {
+          const int Ig = h * NH + u;
+          if (Ig < NIG) {
+            const int o = tb + (jj * NIG + Ig) * 64;
+            vx[u] = gx[o];
+            v2[u] = g2[o];
+            v3[u] = g3[o];
+            v6[u] = g6[o];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NH; ++u) {
+          const int Ig = h * NH + u;
+          if (Ig < NIG) {
+            const int o = tb + (jj * NIG + Ig) * 64;
+            const double dg = is_diag(Ig, col) ? 1.0 : 0.0;
+            const double b3 = fma(C3P_T18_B62, v6[u], fma(C3P_T18_B32, v3[u], fma(C3P_T18_B22, v2[u],
+                                  fma(C3P_T18_B12, vx[u], C3P_T18_B02 * dg))));
+            t1[o] = b3 + a9[jj][Ig];
+            t2[o] = a9[jj][Ig];
+            b2[jj][Ig] = fma(C3P_T18_B61, v6[u], fma(C3P_T18_B31, v3[u], fma(C3P_T18_B21, v2[u],
+                             C3P_T18_B11 * vx[u])));                                         // B2
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
   auto store_plain = [&](double* dst, const Tile& v, double sr, double si) {
@@ -197,27 +307,29 @@ __device__ __forceinline__ void bigd_body(const MidArgs& A, const BigCommon& cm,
     {
       zero(acc);
       const int tb = bd_opaque(tbase);
+      // control amplitudes of this slice (K <= 16), trace shift
+      double ck[16];
 #pragma unroll
-      for (int jj = 0; jj < JS; ++jj) {
-        if (!jj_on(jj)) continue;
-#pragma unroll
-        for (int Ig = 0; Ig < NIG; ++Ig) acc[jj][Ig] = cm.scale * tabs[tb + 16 * Ig * W + 4 * jj];
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      for (int k = 0; k < 16; ++k) ck[k] = 0.0;
       for (int k = 0; k < K; ++k) {
         const double c0 = cm.sg[k * A.Lmax + t];
-        const double ck = cm.scale * c0;
         const double* tk = tabs + (long)(k + 1) * (IMG + 4);
         mu_r = fma(c0, tk[IMG + 0], mu_r);
         mu_i = fma(c0, tk[IMG + 1], mu_i);
-#pragma unroll
-        for (int jj = 0; jj < JS; ++jj) {
-          if (!jj_on(jj)) continue;
-#pragma unroll
-          for (int Ig = 0; Ig < NIG; ++Ig) acc[jj][Ig] = fma(ck, tk[tb + 16 * Ig * W + 4 * jj], acc[jj][Ig]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
       }
+#pragma unroll
+      for (int jj = 0; jj < JS; ++jj) {
+        if (!jj_on(jj)) continue;
+        // all (1+K) table loads of a column block are issued back to back
+        for (int k = -1; k < K; ++k) {
+          const double* tk = tabs + (long)(k + 1) * (IMG + 4);
+          const double w = (k < 0) ? cm.scale : cm.scale * cm.sg[k * A.Lmax + t];
+#pragma unroll
+          for (int Ig = 0; Ig < NIG; ++Ig) acc[jj][Ig] = fma(w, tk[tb + (jj * NIG + Ig) * 64], acc[jj][Ig]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      (void)ck;
       store_tiles(gimg(G_X), acc);
     }
     // ---- T18: A2 = X X, A3 = X A2, A6 = A3 A3 ----
@@ -230,23 +342,12 @@ __device__ __forceinline__ void bigd_body(const MidArgs& A, const BigCommon& cm,
     zero(acc);
     product(gimg(G_A3), gimg(G_A3), acc);
     store_tiles(gimg(G_A6), acc);
-    // ---- A9 = B1 B5 + B4 ----
-    comb(acc, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0);
-    store_tiles(gimg(G_T1), acc);  // B1
-    comb(acc, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64);
-    store_tiles(gimg(G_T2), acc);  // B5
-    comb(acc, C3P_T18_B03, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63);  // B4
+    // ---- A9 = B1 B5 + B4 ;  P = B2 + (B3 + A9) A9 ----
+    pass1(acc);                            // T1 = B1, T2 = B5, acc = B4
     product(gimg(G_T1), gimg(G_T2), acc);  // acc = A9
-    // ---- P = B2 + (B3 + A9) A9 ----
-    comb(P, C3P_T18_B02, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62);  // B3
-#pragma unroll
-    for (int jj = 0; jj < JS; ++jj)
-#pragma unroll
-      for (int Ig = 0; Ig < NIG; ++Ig) P[jj][Ig] += acc[jj][Ig];
-    __syncthreads();  // every wave is done reading T1 / T2
-    store_tiles(gimg(G_T1), P);    // L = B3 + A9
-    store_tiles(gimg(G_T2), acc);  // A9
-    comb(P, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61);  // B2
+    __syncthreads();                       // every wave is done reading T1 / T2
+    zero(P);
+    pass2(acc, P);                         // T1 = B3 + A9, T2 = A9, P = B2
     product(gimg(G_T1), gimg(G_T2), P);
     // ---- squarings ----
     for (int it = 0; it < cm.ps; ++it) {
@@ -290,7 +391,7 @@ __device__ __forceinline__ void bigd_body(const MidArgs& A, const BigCommon& cm,
   for (int jj = 0; jj < JS; ++jj)
     if (jj_on(jj)) {
 #pragma unroll
-      for (int Ig = 0; Ig < NIG; ++Ig) P[jj][Ig] = gimg(G_U)[bd_opaque(tbase) + 16 * Ig * W + 4 * jj];
+      for (int Ig = 0; Ig < NIG; ++Ig) P[jj][Ig] = gimg(G_U)[bd_opaque(tbase) + (jj * NIG + Ig) * 64];
     }
   double sn, cs;
   sincos(mus_i, &sn, &cs);
@@ -302,7 +403,8 @@ __device__ __forceinline__ void bigd_body(const MidArgs& A, const BigCommon& cm,
 template <int NIG, int NJ, int W, bool DUS>
 __global__ void __launch_bounds__(512, 2) bigd_chain_kernel(MidArgs A, double* arena_base) {
   using C = BD<NIG, NJ>;
-  constexpr int IMG = C::ROWS * W;
+  constexpr int IMG = NIG * NJ * 64;      // tile-major global image (tables, arena)
+  constexpr int LIMG = C::ROWS * W;       // row-major LDS image of the left operand
   BigCommon cm;
   cm.tid = threadIdx.x;
   cm.lane = cm.tid & 63;
@@ -315,7 +417,7 @@ __global__ void __launch_bounds__(512, 2) bigd_chain_kernel(MidArgs A, double* a
   cm.K = A.K;
   const int K = A.K;
   cm.ldsA = c3p_bd_lds;
-  cm.sg = cm.ldsA + IMG;
+  cm.sg = cm.ldsA + LIMG;
   __shared__ double red[BW];
   // column blocks of this wave
   cm.nJ = C::JB + (wave < C::JR ? 1 : 0);
@@ -329,8 +431,9 @@ __global__ void __launch_bounds__(512, 2) bigd_chain_kernel(MidArgs A, double* a
   // one arena per WORKGROUP (re-used for every chain it processes): the resident set is
   // gridDim.x x 7 images, sized by the launcher to stay inside the Infinity Cache
   cm.arena = arena_base + (long)blockIdx.x * G_NIMG * IMG;
-  // zero it once: padding rows / columns of every image must stay zero
+  // zero it once: padding rows / columns of every image must stay zero (also the LDS image)
   for (long e = cm.tid; e < (long)G_NIMG * IMG; e += BW * 64) cm.arena[e] = 0.0;
+  for (int e = cm.tid; e < LIMG; e += BW * 64) cm.ldsA[e] = 0.0;
 
   const long nchains = (long)A.B * A.S;
   for (long chain = blockIdx.x; chain < nchains; chain += gridDim.x) {
@@ -386,8 +489,8 @@ __global__ void rowphase_kernel(cplx* U, const double* phase, int Dm, long total
 
 template <int NIG, int NJ, int W>
 hipError_t launch_b(const MidArgs& A, double* arena, hipStream_t st) {
-  constexpr int IMG = BD<NIG, NJ>::ROWS * W;
-  const size_t lds = (size_t)(IMG + A.K * A.Lmax) * sizeof(double);
+  constexpr int LIMG = BD<NIG, NJ>::ROWS * W;
+  const size_t lds = (size_t)(LIMG + A.K * A.Lmax) * sizeof(double);
   const long nchains = (long)A.B * A.S;
   const unsigned grid = (unsigned)(nchains < C3P_BIGD_MAX_WGS ? nchains : C3P_BIGD_MAX_WGS);
   auto go = [&](auto kern) -> hipError_t {
@@ -414,13 +517,13 @@ bool c3p_bigd_geometry(int Dm, int* nig, int* nj, int* w) {
 size_t c3p_bigd_table_doubles(int Dm, int K) {
   int nig, nj, w;
   if (!c3p_bigd_geometry(Dm, &nig, &nj, &w)) return 0;
-  return (size_t)(1 + K) * ((size_t)16 * nig * w + 4);
+  return (size_t)(1 + K) * ((size_t)nig * nj * 64 + 4);
 }
 
 size_t c3p_bigd_arena_doubles(int Dm) {  // for the whole launch (one arena per workgroup)
   int nig, nj, w;
   if (!c3p_bigd_geometry(Dm, &nig, &nj, &w)) return 0;
-  return (size_t)C3P_BIGD_MAX_WGS * G_NIMG * 16 * nig * w;
+  return (size_t)C3P_BIGD_MAX_WGS * G_NIMG * nig * nj * 64;
 }
 
 size_t c3p_bigd_lds_bytes(int Dm, int K, int Lmax) {

@@ -25,6 +25,7 @@ struct MidPrepArgs {
   double dt;
   int K, Dh, Dm, lindblad;
   int rows, W;
+  int tile_nig, tile_nj;  // != 0: emit tile-major images (big-D kernel) instead of rows x W
   double* tables;
 };
 

@@ -499,10 +499,20 @@ __global__ void __launch_bounds__(256) midd_prep_kernel(MidPrepArgs P) {
   }
   redr[tid] = cs;
   __syncthreads();
-  const int IMG = P.rows * P.W;
+  const int IMG = P.tile_nig ? P.tile_nig * P.tile_nj * 64 : P.rows * P.W;
   double* out = P.tables + ((long)sample * (1 + P.K) + ti) * (IMG + 4);
   for (int e = tid; e < IMG; e += 256) {
-    const int rho = e / P.W, col = e - rho * P.W;
+    int rho, col;
+    if (P.tile_nig) {
+      // tile-major image (c3p_bigd.hip): tile (J,Ig) = 64 doubles in MFMA C/D lane order
+      const int tile = e >> 6, l = e & 63;
+      const int J = tile / P.tile_nig, Ig = tile - J * P.tile_nig;
+      rho = 16 * Ig + 4 * ((l >> 2) & 3) + (l >> 4);
+      col = 4 * J + (l & 3);
+    } else {
+      rho = e / P.W;
+      col = e - rho * P.W;
+    }
     const int i = rho >> 1, p = rho & 1;
     double v = 0.0;
     if (i < D && col < D) {
