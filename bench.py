@@ -168,6 +168,13 @@ def main():
         value = total_props / elapsed
         f_prop = algorithmic_flops_per_prop(wl, c3_oracle)
         achieved = f_prop * B / (kernel_ms * 1e-3) / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+        if os.path.exists(tfile) and args.batch is None and args.slices is None and not args.generic:
+            try:
+                traffic = json.load(open(tfile)).get(f"cfg{args.config}", {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
         out = {
             "metric": "full-gate propagators/s",
             "value": value,
@@ -198,11 +205,11 @@ def main():
                 "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
                 "kernel": f"chain kernel ({kernel_name})",
                 "kernel_ms": kernel_ms,
                 "algorithmic_flop_per_propagator": f_prop,
-                "note": "fp64 compute-bound path: algorithmic flops (SURVEY 8d, reference Pade order per slice) / hipEvent kernel time; peak = dense fp64 (MFMA = vector on MI355X)",
+                "note": "fp64 compute-bound path: algorithmic flops (SURVEY 8d, reference Pade order per slice) / hipEvent kernel time; peak = dense fp64 (MFMA = vector on MI355X); traffic = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/traffic.json), null when not profiled for this configuration",
             },
         }
         if err is not None:
