@@ -217,6 +217,25 @@ class ChipModel:
         a = self.ann_opers[self.drive_lines[line]]
         return a.conj().T @ a
 
+    def get_Frame_Rotation(self, t_final, freqs: Dict[str, float], framechanges: Dict[str, float]) -> np.ndarray:
+        """FR = expm(i sum_line n_q (w_line T + framechange)) (model.py:536-578); diagonal here."""
+        if len(freqs) == 0:
+            return np.eye(self.tot_dim, dtype=np.complex128)
+        return np.diag(np.exp(1.0j * self.frame_rotation_phases(t_final, freqs, framechanges)))
+
+    def get_dephasing_channel(self, t_final, amps: Dict[str, complex]) -> np.ndarray:
+        """Element-wise product of per-line channels (model.py:597-639)."""
+        Id = np.ones((self.tot_dim**2, self.tot_dim**2), dtype=np.complex128) * np.kron(np.eye(self.tot_dim), np.eye(self.tot_dim))
+        ch = Id
+        for line, amp in amps.items():
+            z = np.exp(1.0j * np.pi * np.real(np.diag(self.number_operator(line))))
+            Z = np.diag(np.kron(z, np.conj(z)))
+            p = t_final * amp * self.dephasing_strength
+            if np.real(p) > 1 or np.real(p) < 0:
+                raise ValueError("Dephasing channel strength {strength} is outside [0,1] range".format(strength=p))
+            ch = ch * ((1 - p) * Id + p * Z)
+        return ch
+
     def frame_rotation_phases(self, t_final: float, freqs: Dict[str, float], framechanges: Dict[str, float]) -> np.ndarray:
         """Diagonal of i*exponent of model.py:536-578: FR = diag(exp(i*phase)); the number
         operators are diagonal in the product basis so FR is a row-phase."""

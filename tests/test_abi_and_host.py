@@ -106,6 +106,40 @@ def test_gather_pwc_inputs_branches():
     assert h0c.shape == (6, 6) and hksc.shape == (2, 6, 6) and len(colc) == 2 and colc[0].shape == (6, 6)
 
 
+def test_experiment_folding_stack_and_slot():
+    """experiment.py:76-107 on the host mirror (no GPU needed)."""
+    from c3_amd.experiment import Experiment, _tf_matmul_n_even, _tf_matmul_n_odd
+
+    class PM:
+        model = None
+        generator = None
+        instructions = {"a": workloads.Gate("a", 0.0, 7e-9), "b": workloads.Gate("b", 0.0, 1e-10)}
+
+    exp = Experiment(PM(), sim_res=100e9)
+    assert exp.propagation is propagation.unitary_provider["pwc"]
+    assert set(exp.folding_stack) == {700, 10}
+    kinds = ["even" if f is _tf_matmul_n_even else "odd" for f in exp.folding_stack[700]]
+    assert kinds == o.compute_folding_stack(700)
+    exp.set_prop_method("ode_solver")
+    assert exp.propagation is propagation.state_provider["ode_solver"]
+    f = lambda *a, **k: None
+    exp.set_prop_method(f)
+    assert exp.propagation is f
+    exp.set_opt_gates("a")
+    assert exp.opt_gates == ["a"]
+    exp.set_opt_gates_seq([["a", "b"], ["b"]])
+    assert sorted(exp.opt_gates) == ["a", "b"]
+    # the stack functions multiply like tf_matmul_n's levels
+    rng = np.random.default_rng(0)
+    M = rng.normal(size=(5, 2, 2))
+    cur = M
+    for fn in Experiment(PM(), sim_res=5 / 1e-10 ).folding_stack.get(5, []):
+        cur = fn(cur[1::2], cur[0::2])
+    # 5 steps at that resolution: ((M4)(M3 M2))(M1 M0) ordering
+    if cur.shape[0] == 1:
+        assert np.allclose(cur[0], M[4] @ M[3] @ M[2] @ M[1] @ M[0])
+
+
 def test_shard_bounds_cover_batch():
     for B in (1, 7, 256, 4096):
         for world in (1, 2, 3, 8):
