@@ -935,4 +935,30 @@ int c3p_rk4_unitary(const void* h0, const void* hks, const double* signals, cons
   return 0;
 }
 
+int c3p_gate_overlap(const void* U, int B, int D, const int32_t* comp_rows, int L, const void* ideal,
+                     int flags, void* overlap_out, void* stream) {
+  if (B < 0 || D <= 0 || L <= 0 || L > D) return fail("bad sizes B=%d D=%d L=%d", B, D, L);
+  if (B == 0) return 0;
+  if (!U || !comp_rows || !ideal || !overlap_out) return fail("NULL pointer argument");
+  const size_t cs = sizeof(cplx);
+  hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lk(g_mu);
+  DeviceWs* w = ws_for_current_device();
+  if (!w) return fail("no HIP device");
+  Stage sg{w, st};
+  const void *d_U = U, *d_rows = comp_rows, *d_G = ideal;
+  void* d_out = overlap_out;
+  if (flags & C3P_HOST_PTRS) {
+    for (int a = 0; a < L; ++a)
+      if (comp_rows[a] < 0 || comp_rows[a] >= D) return fail("comp_rows[%d]=%d outside [0,%d)", a, comp_rows[a], D);
+    if (sg.in(U, (size_t)B * D * D * cs, &d_U)) return -1;
+    if (sg.in(comp_rows, (size_t)L * sizeof(int32_t), &d_rows)) return -1;
+    if (sg.in(ideal, (size_t)L * L * cs, &d_G)) return -1;
+    if (sg.out(overlap_out, (size_t)B * cs, &d_out)) return -1;
+  }
+  HIP_TRY(c3p_launch_overlap((const cplx*)d_U, B, D, (const int*)d_rows, L, (const cplx*)d_G, (cplx*)d_out, st));
+  if (flags & C3P_HOST_PTRS) return sg.finish();
+  return 0;
+}
+
 }  // extern "C"

@@ -324,6 +324,28 @@ __global__ void kron_kernel(const cplx* A, const cplx* Bm, int Da, int Db, int w
   out[e] = v;
 }
 
+// s[b] = tr(P^T U[b] P G^+) = sum_{a,c} U[b][rows[a]][rows[c]] conj(G[a][c]): the one number both
+// unitary_infid and average_infid need (fidelities.py:154-184,290-313; tf_utils.py:330-436).
+// One wavefront per sample.
+__global__ void __launch_bounds__(64) overlap_kernel(const cplx* U, int D, const int* rows, int L,
+                                                     const cplx* ideal, cplx* out) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const cplx* Ub = U + (long)b * D * D;
+  double sr = 0.0, si = 0.0;
+  for (int e = lane; e < L * L; e += 64) {
+    const int a = e / L, c = e - a * L;
+    const cplx u = Ub[rows[a] * D + rows[c]];
+    const cplx g = ideal[e];
+    sr += u.x * g.x + u.y * g.y;
+    si += u.y * g.x - u.x * g.y;
+  }
+  for (int o = 32; o >= 1; o >>= 1) {
+    sr += __shfl_xor(sr, o);
+    si += __shfl_xor(si, o);
+  }
+  if (lane == 0) out[b] = cmake(sr, si);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -375,5 +397,12 @@ hipError_t c3p_launch_kron(const cplx* A, const cplx* Bm, int n, int Da, int Db,
   if (total == 0) return hipSuccess;
   hipLaunchKernelGGL(kron_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, A, Bm, Da,
                      Db, which, total, out);
+  return hipGetLastError();
+}
+
+hipError_t c3p_launch_overlap(const cplx* U, int B, int D, const int* rows, int L, const cplx* ideal,
+                              cplx* out, hipStream_t st) {
+  if (B == 0) return hipSuccess;
+  hipLaunchKernelGGL(overlap_kernel, dim3((unsigned)B), dim3(64), 0, st, U, D, rows, L, ideal, out);
   return hipGetLastError();
 }

@@ -1,0 +1,101 @@
+"""Fidelity epilogue on the device -- counterpart of the goal functions that directly consume
+the propagators (`c3/libraries/fidelities.py:154-218,290-347`).
+
+Both `unitary_infid` and `average_infid` reduce to one complex number per propagator,
+    s = tr(P^T U P G^+),     P = projector(dims, index)   (tf_project_to_comp, qt_utils.projector)
+        unitary_infid = 1 - |s / L|^2                      (tf_unitary_overlap, tf_utils.py:330-366)
+        average_infid = 1 - (|s|^2 / L + 1) / (L + 1)      (tf_average_fidelity -> chi_00 = |tr Lambda|^2,
+                                                            tf_utils.py:380-401; checked against the literal
+                                                            super -> choi -> chi chain in tests)
+with L = 2^len(index).  `c3p_gate_overlap` computes s for a whole batch U[B,D,D] on the GPU, so a
+batched optimiser step moves B scalars instead of B matrices off the device.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .propagation import _Call, _ptr, C3PropError
+
+fidelities: Dict[str, object] = dict()
+
+
+def fid_reg_deco(func):
+    """Registry decorator (fidelities.py:35-40)."""
+    fidelities[str(func.__name__)] = func
+    return func
+
+
+def computational_rows(dims: Sequence[int], index: Optional[Sequence[int]] = None) -> np.ndarray:
+    """Row indices selected by `projector(dims, index)` (qt_utils.py:178-193): subsystems in
+    `index` keep levels {0,1}, the others level 0; columns ordered as the Kronecker product."""
+    if not index:
+        index = list(range(len(dims)))
+    rows = [0]
+    for q, d in enumerate(dims):
+        lv = (0, 1) if q in index else (0,)
+        rows = [r * d + l for r in rows for l in lv]
+    return np.asarray(rows, dtype=np.int32)
+
+
+def gate_overlaps(ideal, actual, index=None, dims=None):
+    """s[b] = tr(P^T U[b] P G^+) for actual [B,D,D] (or [D,D]) on the device."""
+    call = _Call(actual, ideal)
+    U = call.c128(actual)
+    squeeze = U.ndim == 2
+    if squeeze:
+        U = U[None]
+    B, D = int(U.shape[0]), int(U.shape[-1])
+    if dims is None:
+        raise C3PropError("C3:Error: dims are needed to project onto the computational subspace")
+    if int(np.prod(dims)) != D:
+        raise C3PropError(f"C3:Error: dims {list(dims)} do not match the propagator dimension {D}")
+    rows = computational_rows(dims, index)
+    L = int(rows.shape[0])
+    G = call.c128(ideal)
+    if tuple(G.shape) != (L, L):
+        raise C3PropError(f"C3:Error: ideal gate must be [{L},{L}] for index {index}, got {tuple(G.shape)}")
+    if call.device:
+        rows_d = call.torch.as_tensor(rows, device=call.dev)
+        out = call.torch.empty((B,), dtype=call.torch.complex128, device=call.dev)
+    else:
+        rows_d = rows
+        out = np.empty((B,), dtype=np.complex128)
+    _lib.check(_lib.load().c3p_gate_overlap(_ptr(U), B, D, _ptr(rows_d), L, _ptr(G), call.flags, _ptr(out), call.stream))
+    return (out[0] if squeeze else out), L
+
+
+@fid_reg_deco
+def unitary_infid(ideal, actual, index: List[int] = None, dims=None):
+    """fidelities.py:154-184; `actual` may be a batch [B,D,D] (returns [B])."""
+    s, L = gate_overlaps(ideal, actual, index, dims)
+    return 1 - abs(s / L) ** 2
+
+
+@fid_reg_deco
+def average_infid(ideal, actual, index: List[int] = [0], dims=[2]):
+    """fidelities.py:290-313; `actual` may be a batch [B,D,D] (returns [B])."""
+    s, L = gate_overlaps(ideal, actual, index, dims)
+    return 1 - (abs(s) ** 2 / L + 1) / (L + 1)
+
+
+def _ideal_of(instructions, gate, dims, index):
+    g = instructions[gate]
+    return g.get_ideal_gate(dims, index) if hasattr(g, "get_ideal_gate") else g
+
+
+@fid_reg_deco
+def unitary_infid_set(propagators: dict, instructions: dict, index, dims, n_eval=-1):
+    """Mean over gates (fidelities.py:187-218).  `instructions[gate]` is a reference Instruction
+    (`get_ideal_gate`) or directly the ideal matrix."""
+    vals = [np.asarray(unitary_infid(_ideal_of(instructions, g, dims, index), U, index, dims)) for g, U in propagators.items()]
+    return np.mean(vals, axis=0)
+
+
+@fid_reg_deco
+def average_infid_set(propagators: dict, instructions: dict, index, dims, n_eval=-1):
+    """Mean over gates (fidelities.py:316-347)."""
+    vals = [np.asarray(average_infid(_ideal_of(instructions, g, dims, index), U, index, dims)) for g, U in propagators.items()]
+    return np.mean(vals, axis=0)

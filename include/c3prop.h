@@ -150,6 +150,17 @@ int c3p_rk4_unitary(const void* h0, const void* hks, const double* signals, cons
                     int64_t hs_bstride, double dt, int B, int K, int Ns, int D, int flags,
                     void* U_out, void* dUs_out, void* stream);
 
+/* Fidelity epilogue: overlap[b] = tr(P^T U[b] P G^+), the number behind
+ * unitary_infid = 1 - |overlap/L|^2 (c3/libraries/fidelities.py:154-184, tf_unitary_overlap
+ * c3/utils/tf_utils.py:330-366) and average_infid = 1 - (|overlap|^2/L + 1)/(L + 1)
+ * (fidelities.py:290-313, tf_average_fidelity tf_utils.py:380-401).  The projector of
+ * tf_project_to_comp (tf_utils.py:428-436, qt_utils.py:178-193) is a 0/1 selection, passed
+ * as the L row indices `comp_rows` of the computational states in the full space.
+ *   U c128 [B,D,D]; comp_rows int32 [L]; ideal c128 [L,L]; overlap_out c128 [B]
+ */
+int c3p_gate_overlap(const void* U, int B, int D, const int32_t* comp_rows, int L, const void* ideal,
+                     int flags, void* overlap_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -908,3 +908,128 @@ def propagate_batch(h0, hks, signals_b, dt, *, col_ops=None, lindbladian=False, 
 def algorithmic_flops_per_slice(D: int, K: int, order: int, squarings: int) -> float:
     """F_slice = 8 D^3 (pi_m + s + 1) + (32/3) D^3 + 4 K D^2."""
     return 8.0 * D**3 * (PADE_PRODUCTS[order] + squarings + 1) + (32.0 / 3.0) * D**3 + 4.0 * K * D**2
+
+
+# --------------------------------------------------------------------------
+# Fidelity epilogue (SURVEY.md 8f rank 1): c3/libraries/fidelities.py:154-218,290-347 and the
+# helpers tf_project_to_comp / tf_unitary_overlap / tf_average_fidelity (tf_utils.py:330-436),
+# projector / pauli_basis (qt_utils.py:10-56,178-193) -- restated literally.
+# --------------------------------------------------------------------------
+
+_PAULIS = (
+    np.array([[1, 0], [0, 1]], dtype=np.complex128),
+    np.array([[0, 1], [1, 0]], dtype=np.complex128),
+    np.array([[0, -1j], [1j, 0]], dtype=np.complex128),
+    np.array([[1, 0], [0, -1]], dtype=np.complex128),
+)
+
+
+def _kron_n(mats):
+    out = np.eye(1)
+    for m in mats:
+        out = np.kron(out, m)
+    return out
+
+
+def projector(dims, indices, outdims=None):
+    """qt_utils.py:178-193: selected subspaces keep their lowest two states, the rest the lowest one."""
+    if outdims is None:
+        outdims = [2] * len(dims)
+    ids = []
+    for index, dim in enumerate(dims):
+        ids.append(np.eye(dim, outdims[index]) if index in indices else np.eye(dim, 1))
+    return _kron_n(ids)
+
+
+def tf_project_to_comp(A, dims, index=None, to_super=False):
+    """tf_utils.py:428-436: P^T A P."""
+    if not index:
+        index = list(range(len(dims)))
+    proj = projector(dims, index)
+    if to_super:
+        proj = np.kron(proj, proj)
+    P = proj.astype(np.asarray(A).dtype)
+    return P.T @ np.asarray(A) @ P
+
+
+def tf_unitary_overlap(A, B, lvls=None):
+    """tf_utils.py:330-366: |tr(A B^+)/lvls|^2."""
+    if lvls is None:
+        lvls = B.shape[0]
+    return np.abs(np.trace(A @ np.conj(B.T)) / lvls) ** 2
+
+
+def unitary_infid(ideal, actual, index=None, dims=None):
+    """fidelities.py:154-184."""
+    if index is None:
+        index = list(range(len(dims)))
+    actual_comp = tf_project_to_comp(actual, dims=dims, index=index)
+    return 1 - tf_unitary_overlap(actual_comp, ideal, lvls=2 ** len(index))
+
+
+def pauli_basis(dims=(2,)):
+    """qt_utils.py:10-44."""
+    paulis = []
+    for dim in dims:
+        padded = []
+        for P in _PAULIS:
+            o_ = np.zeros((dim, dim), dtype=np.complex128)
+            o_[:2, :2] = P
+            padded.append(o_)
+        paulis.append(padded)
+    result = [[]]
+    for pauli_set in paulis:
+        result = [x + [y] for x in result for y in pauli_set]
+    size = int(np.prod(np.array(dims) ** 2))
+    B = np.zeros((size, size), dtype=complex)
+    for idx, op_tuple in enumerate(result):
+        op = _kron_n(op_tuple)
+        vec = np.reshape(np.transpose(op), [-1, 1])
+        B[:, idx] = vec.T.conj()
+    return B
+
+
+def super_to_choi(A):
+    """tf_utils.py:416-425."""
+    n = int(np.sqrt(A.shape[0]))
+    return np.reshape(np.transpose(np.reshape(A, [n] * 4), (3, 1, 2, 0)), A.shape)
+
+
+def tf_choi_to_chi(U, dims=None):
+    """tf_utils.py:404-412."""
+    if dims is None:
+        dims = [int(np.sqrt(U.shape[0]))]
+    B = pauli_basis([2] * len(dims))
+    return np.conj(B.T) @ U @ B
+
+
+def tf_super_to_fid(err, lvls):
+    """tf_utils.py:396-401."""
+    lambda_chi = tf_choi_to_chi(super_to_choi(err), dims=lvls)
+    d = 2 ** len(lvls)
+    return np.abs((lambda_chi[0, 0] / d + 1) / (d + 1))
+
+
+def tf_average_fidelity(A, B, lvls=None):
+    """tf_utils.py:380-385."""
+    if lvls is None:
+        lvls = [B.shape[0]]
+    Lambda = np.conj(A.T) @ B
+    return tf_super_to_fid(tf_super(Lambda), lvls)
+
+
+def average_infid(ideal, actual, index=(0,), dims=(2,)):
+    """fidelities.py:290-313."""
+    index = list(index)
+    actual_comp = tf_project_to_comp(actual, dims=list(dims), index=index)
+    return 1 - tf_average_fidelity(actual_comp, ideal, lvls=[2] * len(index))
+
+
+def unitary_infid_set(propagators: Dict, ideals: Dict, index, dims):
+    """fidelities.py:187-218 with the ideal gates given directly (instructions[gate].get_ideal_gate)."""
+    return float(np.mean([unitary_infid(ideals[g], U, index, dims) for g, U in propagators.items()]))
+
+
+def average_infid_set(propagators: Dict, ideals: Dict, index, dims):
+    """fidelities.py:316-347."""
+    return float(np.mean([average_infid(ideals[g], U, index, dims) for g, U in propagators.items()]))

@@ -205,3 +205,13 @@ def test_t18_coefficients_reproduce_taylor_series():
     A9m = M(B1) @ M(B5) + M(B4)
     T18 = M(B2) + (M(B3) + A9m) @ A9m
     assert np.abs(T18 - o.expm(A)).max() < 2e-14
+
+
+def test_computational_rows_match_projector():
+    from c3_amd import fidelities
+
+    for dims, index in (([3, 3], [0, 1]), ([3, 3], [1]), ([3, 4, 2], [0, 2]), ([2, 2], None)):
+        P = o.projector(dims, index if index else list(range(len(dims))))
+        want = [int(np.argmax(P[:, a])) for a in range(P.shape[1])]
+        assert list(fidelities.computational_rows(dims, index)) == want
+    assert set(fidelities.fidelities) >= {"unitary_infid", "unitary_infid_set", "average_infid", "average_infid_set"}

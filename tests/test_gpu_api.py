@@ -331,3 +331,35 @@ def test_long_chain_precision(prop):
     r = prop.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt, fr_phase=wl.fr_phase)
     ref = o.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt, fr_phase=wl.fr_phase)
     assert np.linalg.norm(np.asarray(r["U"][0]) - ref[0]) < 2e-11
+
+
+def test_fidelity_epilogue(prop):
+    """unitary_infid / average_infid (+ _set) on device-resident propagator batches."""
+    import torch
+    from c3_amd import fidelities as F
+
+    wl = workloads.make_workload(2, B=6, N=50)
+    U = prop.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt, fr_phase=wl.fr_phase)["U"]
+    rng = np.random.default_rng(4)
+    for index in ([0, 1], [0], [1]):
+        L = 2 ** len(index)
+        G = np.linalg.qr(rng.normal(size=(L, L)) + 1j * rng.normal(size=(L, L)))[0]
+        got_u = np.asarray(F.unitary_infid(G, U, index, [3, 3]))
+        got_a = np.asarray(F.average_infid(G, U, index, [3, 3]))
+        for b in range(6):
+            assert abs(got_u[b] - o.unitary_infid(G, np.asarray(U[b]), index, [3, 3])) < 1e-13
+            assert abs(got_a[b] - o.average_infid(G, np.asarray(U[b]), index, [3, 3])) < 1e-13
+    # single matrix, device tensors, and the set variants
+    G = np.eye(4, dtype=complex)
+    one = F.unitary_infid(G, np.asarray(U[0]), [0, 1], [3, 3])
+    assert abs(one - o.unitary_infid(G, np.asarray(U[0]), [0, 1], [3, 3])) < 1e-13
+    Ud = torch.as_tensor(np.asarray(U), device="cuda:0")
+    dev = F.average_infid(torch.as_tensor(G, device="cuda:0"), Ud, [0, 1], [3, 3])
+    assert dev.is_cuda and abs(dev[2].item() - o.average_infid(G, np.asarray(U[2]), [0, 1], [3, 3])) < 1e-13
+    props = {"a": np.asarray(U[0]), "b": np.asarray(U[1])}
+    ideals = {"a": G, "b": G}
+    assert abs(F.unitary_infid_set(props, ideals, [0, 1], [3, 3]) - o.unitary_infid_set(props, ideals, [0, 1], [3, 3])) < 1e-13
+    assert abs(F.average_infid_set(props, ideals, [0, 1], [3, 3]) - o.average_infid_set(props, ideals, [0, 1], [3, 3])) < 1e-13
+    from c3_amd._lib import C3PropError
+    with pytest.raises(C3PropError, match="C3:Error"):
+        F.unitary_infid(np.eye(2), U, [0, 1], [3, 3])

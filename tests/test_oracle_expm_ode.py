@@ -162,3 +162,21 @@ def test_evaluate_sequences_and_trott():
     d = o.pwc_trott_drift(wl.h0, wl.hks, np.array([wl.signals[0, 0, 2]]).reshape(1, 1, 1), wl.dt)
     e = o.tf_dU_of_t(wl.h0, wl.hks, [wl.signals[0, 0, 2]], wl.dt)
     assert d.shape == e.shape
+
+
+def test_fidelity_closed_forms_match_literal_chain():
+    """average_infid through super -> choi -> chi (tf_utils.py:380-425) equals the closed form the
+    device epilogue uses; unitary_infid likewise (fidelities.py:154-184,290-313)."""
+    rng = np.random.default_rng(0)
+    for dims, index in (([3, 3], [0, 1]), ([3, 3], [0]), ([3, 3], [1]), ([3, 3, 4], [0, 2]), ([2, 2], [0, 1])):
+        D = int(np.prod(dims))
+        L = 2 ** len(index)
+        G = np.linalg.qr(rng.normal(size=(L, L)) + 1j * rng.normal(size=(L, L)))[0]
+        U = np.linalg.qr(rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))[0]
+        P = o.projector(dims, index)
+        rows = [int(np.argmax(P[:, a])) for a in range(P.shape[1])]
+        s = np.sum(U[np.ix_(rows, rows)] * np.conj(G))
+        assert abs(o.unitary_infid(G, U, index, dims) - (1 - abs(s / L) ** 2)) < 1e-13
+        assert abs(o.average_infid(G, U, index, dims) - (1 - (abs(s) ** 2 / L + 1) / (L + 1))) < 1e-13
+    X = np.array([[0, 1], [1, 0]], dtype=complex)
+    assert o.unitary_infid(X, X, [0], [2]) < 1e-15 and o.average_infid(X, X, [0], [2]) < 1e-15
