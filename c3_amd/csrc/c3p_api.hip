@@ -185,7 +185,7 @@ int run_chain_generic(DeviceWs* w, ChainArgs base, cplx* U_out, hipStream_t st) 
 // ---------------------------------------------------------------------------
 // Small-D MFMA path (Dm <= C3P_SMALLD_LIMIT): tables -> segment chains -> ordered combine
 // ---------------------------------------------------------------------------
-const int kSmallDLimit = 10;  // D = 11, 12 spill registers (hipcc 7.2); they use the generic kernel
+const int kSmallDLimit = 12;  // D = 11, 12 spill ~100 registers but still beat the generic kernel
 
 int record_start(DeviceWs* w, hipStream_t st) {
   if (!g_profiling) return 0;

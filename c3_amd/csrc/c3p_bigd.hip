@@ -1,4 +1,4 @@
-// Big-D propagator chains on the f64 matrix cores: 41 <= Dm <= 96, in particular the
+// Big-D propagator chains on the f64 matrix cores: 41 <= Dm <= 92, in particular the
 // 81 x 81 Lindblad superoperator of two qutrits (BASELINE cfg4).
 //
 // Same arithmetic as c3p_midd.hip (half images of the real 2x2 representation, 16x4 output
@@ -507,10 +507,11 @@ hipError_t launch_b(const MidArgs& A, double* arena, hipStream_t st) {
 }  // namespace
 
 bool c3p_bigd_geometry(int Dm, int* nig, int* nj, int* w) {
-  if (Dm < 77 || Dm > 84) return false;  // one geometry class for now: 81 x 81 superoperators
-  *nig = 11;
-  *nj = 21;
-  *w = 86;
+  if (Dm < 41 || Dm > 92) return false;
+  const int NBI = (Dm + 1) / 2;
+  *nig = (NBI + 3) / 4;
+  *nj = (Dm + 3) / 4;
+  *w = 4 * (*nj) + 2;  // = 2 mod 4: the 16 rows of an A-slab read fall on distinct LDS bank pairs
   return true;
 }
 
@@ -541,5 +542,21 @@ hipError_t c3p_launch_rowphase(cplx* U, const double* phase, int B, int Dm, hipS
 hipError_t c3p_launch_bigd_chain(const MidArgs& A, double* arena, hipStream_t st) {
   int nig, nj, w;
   if (!c3p_bigd_geometry(A.Dm, &nig, &nj, &w)) return hipErrorInvalidValue;
-  return launch_b<11, 21, 86>(A, arena, st);
+  // one instantiation per geometry class (4 consecutive dimensions each)
+  switch (nj) {
+    case 11: return launch_b<6, 11, 46>(A, arena, st);
+    case 12: return launch_b<6, 12, 50>(A, arena, st);
+    case 13: return launch_b<7, 13, 54>(A, arena, st);
+    case 14: return launch_b<7, 14, 58>(A, arena, st);
+    case 15: return launch_b<8, 15, 62>(A, arena, st);
+    case 16: return launch_b<8, 16, 66>(A, arena, st);
+    case 17: return launch_b<9, 17, 70>(A, arena, st);
+    case 18: return launch_b<9, 18, 74>(A, arena, st);
+    case 19: return launch_b<10, 19, 78>(A, arena, st);
+    case 20: return launch_b<10, 20, 82>(A, arena, st);
+    case 21: return launch_b<11, 21, 86>(A, arena, st);
+    case 22: return launch_b<11, 22, 90>(A, arena, st);
+    case 23: return launch_b<12, 23, 94>(A, arena, st);
+    default: return hipErrorInvalidValue;
+  }
 }

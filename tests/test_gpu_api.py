@@ -92,7 +92,7 @@ def test_golden_tf_utils_on_device(prop, golden_dir):
         np.testing.assert_allclose(prop.Id_like(g[f"Id_like_{i}_in"]), g[f"Id_like_{i}_desired"], rtol=1e-7)
 
 
-@pytest.mark.parametrize("D", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 24, 27])
+@pytest.mark.parametrize("D", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 24, 27, 40])
 @pytest.mark.parametrize("force_generic", [False, True])
 def test_every_dimension_and_kernel(prop, D, force_generic):
     """Each small-D instantiation (2..10), the generic LDS kernel and their hand-over."""
@@ -109,8 +109,28 @@ def test_every_dimension_and_kernel(prop, D, force_generic):
     r = prop.propagate_batch(h0, hks, sig, dt, force_generic=force_generic)
     ref = o.propagate_batch(h0, hks, sig, dt)
     assert max(np.linalg.norm(np.asarray(r["U"][b]) - ref[b]) for b in range(B)) < 1e-10
-    expect = "generic_lds" if (force_generic or D in (11, 12)) else ("smalld" if D <= 10 else "mfma")
+    expect = ("generic_lds" if D <= 37 else "generic_global") if force_generic else ("smalld" if D <= 12 else "mfma")
     assert _lib.last_kernel() == expect
+
+
+@pytest.mark.parametrize("D", [41, 48, 49, 64, 77, 92])
+def test_big_dimension_classes(prop, D):
+    """Every geometry class of the big-D MFMA kernel (41..92), a couple of samples and slices."""
+    from c3_amd import _lib
+
+    rng = np.random.default_rng(D)
+    B, K, N = 2, 2, 9
+    h0 = rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))
+    h0 = (h0 + h0.conj().T) * (2e11 / D)
+    hks = rng.normal(size=(K, D, D)) + 1j * rng.normal(size=(K, D, D))
+    hks = hks + np.conj(np.swapaxes(hks, -1, -2))
+    sig = rng.normal(size=(B, K, N)) * 1e9 / D
+    r = prop.propagate_batch(h0, hks, sig, 1e-11, want_dUs=True)
+    ref = o.propagate_batch(h0, hks, sig, 1e-11)
+    assert _lib.last_kernel() == "mfma"
+    assert max(np.linalg.norm(np.asarray(r["U"][b]) - ref[b]) for b in range(B)) < 1e-10
+    dref = o.tf_propagation_vectorized(h0, hks, sig[1], 1e-11)
+    assert np.abs(np.asarray(r["dUs"][1]) - dref).max() < 1e-12
 
 
 def test_edge_cases(prop):
