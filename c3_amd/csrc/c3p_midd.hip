@@ -46,72 +46,117 @@ __device__ __forceinline__ double md_rfl(double v) {
   return __hiloint2double(hi, lo);
 }
 
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ d4 md_mfma16(double a, double b, d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
 template <int NIG, int NJ>
 struct MD {
-  static constexpr int NT = NIG * NJ;
-  static constexpr int TPW = (NT + NW - 1) / NW;  // tiles per wave
   static constexpr int ROWS = 16 * NIG;
 };
 
-// acc[i] += (A image) * (B image) for the tiles of wave WV.
-template <int NIG, int NJ, int W, int WV>
-__device__ __forceinline__ void mm_tiles(const double* imgA, const double* imgB, int aoff, int boff,
-                                         unsigned negmask, int nbk, double (&acc)[MD<NIG, NJ>::TPW]) {
-  using C = MD<NIG, NJ>;
-  constexpr int T0 = WV * C::TPW;
-  constexpr int T1 = (T0 + C::TPW < C::NT) ? T0 + C::TPW : C::NT;
-  constexpr int J0 = T0 / NIG;
-  constexpr int J1 = (T1 > T0) ? (T1 - 1) / NIG : J0;
-  constexpr int JS = J1 - J0 + 1;
-  // software pipelined over K: the operands of step K+1 are in flight while step K's MFMAs issue
-  double a0[NIG], a1[NIG], b0[JS], b1[JS];
-  auto load = [&](double (&a)[NIG], double (&bb)[JS], int K) {
-#pragma unroll
-    for (int Ig = 0; Ig < NIG; ++Ig) {
-      bool used = false;  // is this slab used by any tile of the wave?
-#pragma unroll
-      for (int t = T0; t < T1; ++t) used = used || (t % NIG == Ig);
-      a[Ig] = used ? md_flip(imgA[aoff + Ig * 16 * W + 2 * K], negmask) : 0.0;
+// Compile-time deal of the output tiles to the four wavefronts.
+//  * "big" units: 16 x 16 tiles (one v_mfma_f64_16x16x4_f64, 64 cycles) = four adjacent column
+//    blocks of one 16-row group; one instruction per K-step instead of four, and one
+//    non-replicated B read instead of four broadcast ones.
+//  * "small" units: the NJ % 4 leftover 16 x 4 tiles (v_mfma_f64_4x4x4_4b_f64, 16 cycles).
+// Bigs are dealt round-robin (cost 4 each), smalls greedily to the least loaded wave.
+template <int NIG, int NJ>
+struct Sched {
+  static constexpr int NB16 = NJ / 4;
+  static constexpr int JR = NJ % 4;
+  static constexpr int NBIG = NIG * NB16;
+  static constexpr int NSMALL = NIG * JR;
+  static constexpr int nbig(int w) { return w < NBIG ? (NBIG - w + NW - 1) / NW : 0; }
+  static constexpr int small_owner(int us) {
+    int load[NW] = {4 * nbig(0), 4 * nbig(1), 4 * nbig(2), 4 * nbig(3)};
+    int owner = 0;
+    for (int u = 0; u <= us; ++u) {
+      int best = 0;
+      for (int w = 1; w < NW; ++w)
+        if (load[w] < load[best]) best = w;
+      load[best] += 1;
+      owner = best;
     }
-#pragma unroll
-    for (int jj = 0; jj < JS; ++jj) bb[jj] = imgB[boff + K * 4 * W + (J0 + jj) * 4];
-  };
-  auto fmas = [&](const double (&a)[NIG], const double (&bb)[JS]) {
-#pragma unroll
-    for (int t = T0; t < T1; ++t) acc[t - T0] = md_mfma4(a[t % NIG], bb[t / NIG - J0], acc[t - T0]);
-  };
-  load(a0, b0, 0);
-  for (int K = 0; K < nbk; K += 2) {
-    const int K1 = (K + 1 < nbk) ? K + 1 : K;
-    load(a1, b1, K1);
-    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA group
-    fmas(a0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    const int K2 = (K + 2 < nbk) ? K + 2 : K;
-    load(a0, b0, K2);
-    __builtin_amdgcn_sched_barrier(0);
-    if (K + 1 < nbk) fmas(a1, b1);
-    __builtin_amdgcn_sched_barrier(0);
+    return owner;
   }
-}
+  static constexpr int nsmall(int w) {
+    int n = 0;
+    for (int u = 0; u < NSMALL; ++u)
+      if (small_owner(u) == w) ++n;
+    return n;
+  }
+  static constexpr int small_us(int w, int i) {
+    int n = 0;
+    for (int u = 0; u < NSMALL; ++u)
+      if (small_owner(u) == w) {
+        if (n == i) return u;
+        ++n;
+      }
+    return 0;
+  }
+};
 
-// Compile-time geometry of tile i of wave WV
+// The units of wave WV and the geometry of every register element it owns.
 template <int NIG, int NJ, int W, int WV>
 struct WaveTiles {
-  using C = MD<NIG, NJ>;
-  static constexpr int T0 = WV * C::TPW;
-  static constexpr int T1 = (T0 + C::TPW < C::NT) ? T0 + C::TPW : C::NT;
-  static constexpr int NTILE = T1 - T0;  // real tiles of this wave (<= TPW)
-  static constexpr int J(int i) { return (T0 + i) / NIG; }
-  static constexpr int Ig(int i) { return (T0 + i) % NIG; }
-  static constexpr int off(int i) { return 16 * Ig(i) * W + 4 * J(i); }  // + lane base (4b+r)*W + c
+  using S = Sched<NIG, NJ>;
+  static constexpr int NBW = S::nbig(WV);
+  static constexpr int NSW = S::nsmall(WV);
+  static constexpr int NE = 4 * NBW + NSW;  // doubles per matrix held by each lane of this wave
+  // big unit i: ub = WV + 4 i -> (Jg, Ig)
+  static constexpr int bIg(int i) { return (WV + NW * i) % NIG; }
+  static constexpr int bJg(int i) { return (WV + NW * i) / NIG; }
+  // small unit i: us -> (J, Ig)
+  static constexpr int sIg(int i) { return S::small_us(WV, i) % NIG; }
+  static constexpr int sJ(int i) { return 4 * S::NB16 + S::small_us(WV, i) / NIG; }
+  // element e: big tile i = e/4, accumulator register q = e%4 (rows 4q + r of the 16-row group),
+  //            or small tile e - 4 NBW
+  static constexpr bool is_big(int e) { return e < 4 * NBW; }
+  static constexpr int row0(int e) { return is_big(e) ? 16 * bIg(e / 4) + 4 * (e % 4) : 16 * sIg(e - 4 * NBW); }
+  static constexpr int col0(int e) { return is_big(e) ? 16 * bJg(e / 4) : 4 * sJ(e - 4 * NBW); }
+  static constexpr int off0(int e) { return row0(e) * W + col0(e); }
+  // which A slabs / B blocks does the wave read in a K-step
+  static constexpr bool uses_ig(int Ig) {
+    for (int i = 0; i < NBW; ++i)
+      if (bIg(i) == Ig) return true;
+    for (int i = 0; i < NSW; ++i)
+      if (sIg(i) == Ig) return true;
+    return false;
+  }
+  static constexpr bool uses_jg(int Jg) {
+    for (int i = 0; i < NBW; ++i)
+      if (bJg(i) == Jg) return true;
+    return false;
+  }
+  static constexpr bool uses_j(int J) {
+    for (int i = 0; i < NSW; ++i)
+      if (sJ(i) == J) return true;
+    return false;
+  }
+};
+
+// Register tile set of one matrix for wave WV.
+template <int NBW, int NSW>
+struct TileRegs {
+  d4 big[NBW > 0 ? NBW : 1];
+  double sm[NSW > 0 ? NSW : 1];
+  __device__ __forceinline__ double get(int e) const { return e < 4 * NBW ? big[e / 4][e % 4] : sm[e - 4 * NBW]; }
+  __device__ __forceinline__ void set(int e, double v) {
+    if (e < 4 * NBW)
+      big[e / 4][e % 4] = v;
+    else
+      sm[e - 4 * NBW] = v;
+  }
 };
 
 struct MidCommon {
   int lane, r, b, c;
   int D, nbk, K;
   int sample, n0, len;
-  int aoff, boff, dbase;
+  int aoff, boff, lbig, lsmall;
   unsigned negmask;
   int pr, ps, t18;
   double scale;
@@ -119,42 +164,88 @@ struct MidCommon {
   double *buf0, *buf1, *buf2, *sg;
 };
 
+// acc += (A image) * (B image) for the units of wave WV
+template <int NIG, int NJ, int W, int WV>
+__device__ __forceinline__ void mm_tiles(const double* imgA, const double* imgB, const MidCommon& cm,
+                                         TileRegs<WaveTiles<NIG, NJ, W, WV>::NBW, WaveTiles<NIG, NJ, W, WV>::NSW>& acc) {
+  using T = WaveTiles<NIG, NJ, W, WV>;
+  using S = Sched<NIG, NJ>;
+  constexpr int NB16 = S::NB16 > 0 ? S::NB16 : 1;
+  constexpr int JR = S::JR > 0 ? S::JR : 1;
+  // software pipelined over K: operands of step K+1 are in flight while step K's MFMAs issue
+  double a0[NIG], a1[NIG], g0[NB16], g1[NB16], s0[JR], s1[JR];
+  const double* pa = imgA + cm.aoff;
+  const double* pg = imgB + cm.lbig;     // row r, columns 4b + c of a 16-column group
+  const double* ps4 = imgB + cm.boff;    // row r, column c of a 4-column block (broadcast over b)
+  auto load = [&](double (&a)[NIG], double (&g)[NB16], double (&sb)[JR], int K) {
+#pragma unroll
+    for (int Ig = 0; Ig < NIG; ++Ig) a[Ig] = T::uses_ig(Ig) ? md_flip(pa[Ig * 16 * W + 2 * K], cm.negmask) : 0.0;
+#pragma unroll
+    for (int Jg = 0; Jg < S::NB16; ++Jg) g[Jg] = T::uses_jg(Jg) ? pg[K * 4 * W + 16 * Jg] : 0.0;
+#pragma unroll
+    for (int js = 0; js < S::JR; ++js) sb[js] = T::uses_j(4 * S::NB16 + js) ? ps4[K * 4 * W + 4 * (4 * S::NB16 + js)] : 0.0;
+  };
+  auto fmas = [&](const double (&a)[NIG], const double (&g)[NB16], const double (&sb)[JR]) {
+#pragma unroll
+    for (int i = 0; i < T::NBW; ++i) acc.big[i] = md_mfma16(a[T::bIg(i)], g[T::bJg(i)], acc.big[i]);
+#pragma unroll
+    for (int i = 0; i < T::NSW; ++i) acc.sm[i] = md_mfma4(a[T::sIg(i)], sb[T::sJ(i) - 4 * S::NB16], acc.sm[i]);
+  };
+  const int nbk = cm.nbk;
+  load(a0, g0, s0, 0);
+  for (int K = 0; K < nbk; K += 2) {
+    const int K1 = (K + 1 < nbk) ? K + 1 : K;
+    load(a1, g1, s1, K1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA group
+    fmas(a0, g0, s0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int K2 = (K + 2 < nbk) ? K + 2 : K;
+    load(a0, g0, s0, K2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (K + 1 < nbk) fmas(a1, g1, s1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // The whole slice loop, specialised per wave so that every tile index is a compile-time
 // constant (LDS offsets become instruction immediates; no per-tile predication).
 template <int NIG, int NJ, int W, bool GIVEN, bool DUS, int WV>
 __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm, long chain) {
-  using C = MD<NIG, NJ>;
   using T = WaveTiles<NIG, NJ, W, WV>;
-  constexpr int TPW = C::TPW, IMG = C::ROWS * W, NTL = T::NTILE;
+  constexpr int IMG = MD<NIG, NJ>::ROWS * W, NE = T::NE;
+  typedef TileRegs<T::NBW, T::NSW> Regs;
   const int D = cm.D, K = cm.K, r = cm.r;
-  const int dbase = cm.dbase;
-  // per-tile lane coordinates
-  const int rrow = 4 * cm.b + cm.r;  // real row inside the 16-row I-group
-  double U[TPW];
+  // lane parts of an element's image offset / row / column
+  const int lbig = cm.lbig, lsmall = cm.lsmall;
+  const int rbig = cm.r, rsmall = 4 * cm.b + cm.r;   // row inside the 16-row group (+ 4q for bigs)
+  const int cbig = 4 * cm.b + cm.c, csmall = cm.c;   // column inside the unit
   double mus_r = 0.0, mus_i = 0.0;
   const double* tabs = cm.tabs;
+  Regs U;
 
-  auto store_tiles = [&](double* img, const double (&v)[TPW]) {
+  auto eoff = [&](int e) -> int { return T::off0(e) + (T::is_big(e) ? lbig : lsmall); };
+  auto erow = [&](int e) -> int { return T::row0(e) + (T::is_big(e) ? rbig : rsmall); };
+  auto ecol = [&](int e) -> int { return T::col0(e) + (T::is_big(e) ? cbig : csmall); };
+  auto store_tiles = [&](double* img, const Regs& v) {
 #pragma unroll
-    for (int i = 0; i < NTL; ++i) img[dbase + T::off(i)] = v[i];
+    for (int e = 0; e < NE; ++e) img[eoff(e)] = v.get(e);
   };
-  auto zero = [&](double (&v)[TPW]) {
+  auto zero = [&](Regs& v) {
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) v[i] = 0.0;
+    for (int e = 0; e < NE; ++e) v.set(e, 0.0);
   };
-  auto product = [&](const double* imgA, const double* imgB, double (&acc)[TPW]) {
-    mm_tiles<NIG, NJ, W, WV>(imgA, imgB, cm.aoff, cm.boff, cm.negmask, cm.nbk, acc);
+  auto product = [&](const double* imgA, const double* imgB, Regs& acc) {
+    mm_tiles<NIG, NJ, W, WV>(imgA, imgB, cm, acc);
   };
-  // is the lane's element of tile i a diagonal (real-part) entry inside the D x D matrix?
-  auto is_diag = [&](int i) -> bool {
-    const int row = 16 * T::Ig(i) + rrow, col = 4 * T::J(i) + cm.c;
+  auto is_diag = [&](int e) -> bool {
+    const int row = erow(e), col = ecol(e);
     return ((row & 1) == 0) && ((row >> 1) == col) && (col < D);
   };
   // store a tile set to a plain complex [D][D] array times the scalar (sr + i si) (row phases opt.)
-  auto store_plain = [&](double* dst, const double (&v)[TPW], double sr0, double si0, const double* ph) {
+  auto store_plain = [&](double* dst, const Regs& v, double sr0, double si0, const double* ph) {
 #pragma unroll
-    for (int i = 0; i < NTL; ++i) {
-      const int row = 16 * T::Ig(i) + rrow, col = 4 * T::J(i) + cm.c;
+    for (int e = 0; e < NE; ++e) {
+      const int row = erow(e), col = ecol(e);
       const int ci = row >> 1;
       double sr = sr0, si = si0;
       if (ph != nullptr && ci < D) {
@@ -164,33 +255,32 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
         si = sr * s2 + si * c2;
         sr = tr;
       }
-      const double mine = v[i];
-      const double other = __shfl_xor(mine, 16);
+      const double mine = v.get(e);
+      const double other = __shfl_xor(mine, 16);  // partner row r^1 (Re <-> Im) in both unit kinds
       const double outv = (r & 1) ? fma(sr, mine, si * other) : fma(sr, mine, -si * other);
       if (ci < D && col < D) dst[(ci * D + col) * 2 + (r & 1)] = outv;
     }
   };
 
   for (int t = 0; t < cm.len; ++t) {
-    double P[TPW];
+    Regs P;
     zero(P);
     double mu_r = 0.0, mu_i = 0.0;
     if constexpr (GIVEN) {
       const double* src = reinterpret_cast<const double*>(A.mats) + ((long)cm.sample * A.N + cm.n0 + t) * D * D * 2;
 #pragma unroll
-      for (int i = 0; i < NTL; ++i) {
-        const int row = 16 * T::Ig(i) + rrow, col = 4 * T::J(i) + cm.c;
+      for (int e = 0; e < NE; ++e) {
+        const int row = erow(e), col = ecol(e);
         const int ci = row >> 1;
-        P[i] = (ci < D && col < D) ? src[(ci * D + col) * 2 + (row & 1)] : 0.0;
+        P.set(e, (ci < D && col < D) ? src[(ci * D + col) * 2 + (row & 1)] : 0.0);
       }
     } else {
-      // ---- X = scale (G0 + sum_k c_k G_k) at the lane's tile positions ----
-      double X[TPW];
-      zero(X);
+      // ---- X = scale (G0 + sum_k c_k G_k) at the lane's element positions ----
+      Regs X;
       mu_r = tabs[IMG + 0];
       mu_i = tabs[IMG + 1];
 #pragma unroll
-      for (int i = 0; i < NTL; ++i) X[i] = cm.scale * tabs[dbase + T::off(i)];
+      for (int e = 0; e < NE; ++e) X.set(e, cm.scale * tabs[eoff(e)]);
       for (int k = 0; k < K; ++k) {
         const double c0 = cm.sg[k * A.Lmax + t];
         const double ck = cm.scale * c0;
@@ -198,13 +288,13 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
         mu_r = fma(c0, tk[IMG + 0], mu_r);
         mu_i = fma(c0, tk[IMG + 1], mu_i);
 #pragma unroll
-        for (int i = 0; i < NTL; ++i) X[i] = fma(ck, tk[dbase + T::off(i)], X[i]);
+        for (int e = 0; e < NE; ++e) X.set(e, fma(ck, tk[eoff(e)], X.get(e)));
       }
       store_tiles(cm.buf0, X);
       __syncthreads();
-      // ---- powers: A2 = X X, A3 = X A2, A4 = X A3.  buf0 = X (left operand of all three),
-      //      buf1 = A2 then A3 (right operands); A2, A3 also stay in registers for the B_j ----
-      double A2[TPW], A3[TPW], acc[TPW];
+      // ---- powers: A2 = X X, A3 = X A2.  buf0 = X (left operand), buf1 = A2 then A3 (right
+      //      operands); A2, A3 also stay in registers for the lane-local block polynomials ----
+      Regs A2, A3, acc;
       zero(A2);
       product(cm.buf0, cm.buf0, A2);
       store_tiles(cm.buf1, A2);
@@ -218,22 +308,20 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
       if (cm.t18) {
         // ---- T18 (Bader-Blanes-Casas), 5 products: A6 = A3 A3; A9 = B1 B5 + B4; P = B2 + (B3 + A9) A9
         product(cm.buf1, cm.buf1, acc);  // acc = A6
-        auto comb = [&](double (&out)[TPW], double c0, double cx, double c2, double c3, double c6) {
+        auto comb = [&](Regs& out, double c0, double cx, double c2, double c3, double c6) {
 #pragma unroll
-          for (int i = 0; i < NTL; ++i) {
-            double v = cx * X[i];
-            v = fma(c2, A2[i], v);
-            v = fma(c3, A3[i], v);
-            v = fma(c6, acc[i], v);
-            v += (c0 != 0.0 && is_diag(i)) ? c0 : 0.0;
-            out[i] = v;
+          for (int e = 0; e < NE; ++e) {
+            double v = cx * X.get(e);
+            v = fma(c2, A2.get(e), v);
+            v = fma(c3, A3.get(e), v);
+            v = fma(c6, acc.get(e), v);
+            v += (c0 != 0.0 && is_diag(e)) ? c0 : 0.0;
+            out.set(e, v);
           }
         };
-        double T1[TPW], T2[TPW];
-        zero(T1);
-        zero(T2);
-        comb(T1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0);              // B1
-        comb(T2, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64);              // B5
+        Regs T1, T2;
+        comb(T1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0);  // B1
+        comb(T2, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64);  // B5
         __syncthreads();  // buf0 (X) no longer read
         store_tiles(cm.buf0, T1);
         store_tiles(cm.buf2, T2);
@@ -242,7 +330,7 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
         product(cm.buf0, cm.buf2, T1);  // T1 = A9
         comb(T2, C3P_T18_B02, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62);  // B3
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) T2[i] += T1[i];
+        for (int e = 0; e < NE; ++e) T2.set(e, T2.get(e) + T1.get(e));
         comb(P, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61);  // B2
         __syncthreads();  // buf0 / buf2 no longer read
         store_tiles(cm.buf0, T2);
@@ -250,20 +338,20 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
         __syncthreads();
         product(cm.buf0, cm.buf2, P);
       } else {
-        product(cm.buf0, cm.buf1, acc);
+        product(cm.buf0, cm.buf1, acc);  // acc = X^4
         // ---- Horner init: P = c_m X^4 + B_{r-1} ----
         {
           const int j = cm.pr - 1;
           const double c0 = c3p_inv_fact[4 * j], c1 = c3p_inv_fact[4 * j + 1], c2 = c3p_inv_fact[4 * j + 2],
                        c3 = c3p_inv_fact[4 * j + 3], cmm = c3p_inv_fact[4 * cm.pr];
-  #pragma unroll
-          for (int i = 0; i < NTL; ++i) {
-            double v = cmm * acc[i];
-            v = fma(c1, X[i], v);
-            v = fma(c2, A2[i], v);
-            v = fma(c3, A3[i], v);
-            v += is_diag(i) ? c0 : 0.0;
-            P[i] = v;
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            double v = cmm * acc.get(e);
+            v = fma(c1, X.get(e), v);
+            v = fma(c2, A2.get(e), v);
+            v = fma(c3, A3.get(e), v);
+            v += is_diag(e) ? c0 : 0.0;
+            P.set(e, v);
           }
           if (cm.pr > 1) store_tiles(cm.buf2, acc);  // buf2 = X^4, the Horner left operand
         }
@@ -273,17 +361,16 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
           __syncthreads();
           const double c0 = c3p_inv_fact[4 * j], c1 = c3p_inv_fact[4 * j + 1], c2 = c3p_inv_fact[4 * j + 2],
                        c3 = c3p_inv_fact[4 * j + 3];
-  #pragma unroll
-          for (int i = 0; i < NTL; ++i) {
-            double v = c1 * X[i];
-            v = fma(c2, A2[i], v);
-            v = fma(c3, A3[i], v);
-            v += is_diag(i) ? c0 : 0.0;
-            acc[i] = v;
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            double v = c1 * X.get(e);
+            v = fma(c2, A2.get(e), v);
+            v = fma(c3, A3.get(e), v);
+            v += is_diag(e) ? c0 : 0.0;
+            acc.set(e, v);
           }
           product(cm.buf2, cm.buf0, acc);
-  #pragma unroll
-          for (int i = 0; i < TPW; ++i) P[i] = acc[i];
+          P = acc;
         }
       }
       // ---- squarings ----
@@ -293,8 +380,7 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
         __syncthreads();
         zero(acc);
         product(cm.buf0, cm.buf0, acc);
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) P[i] = acc[i];
+        P = acc;
       }
     }
     // ---- partial propagator write-out ----
@@ -307,8 +393,7 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
     }
     // ---- chain: U <- E U (or U E for the right-ordered list product) ----
     if (t == 0) {
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) U[i] = P[i];
+      U = P;
       mus_r = mu_r;
       mus_i = c3p_phase_add(0.0, mu_i);
       __syncthreads();  // buf0 is rewritten by the next slice
@@ -318,14 +403,13 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
       store_tiles(cm.buf0, P);
       store_tiles(cm.buf1, U);
       __syncthreads();
-      double cacc[TPW];
+      Regs cacc;
       zero(cacc);
       if (GIVEN && A.right_order)
         product(cm.buf1, cm.buf0, cacc);
       else
         product(cm.buf0, cm.buf1, cacc);
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) U[i] = cacc[i];
+      U = cacc;
       mus_r += mu_r;
       mus_i = c3p_phase_add(mus_i, mu_i);
       __syncthreads();  // buf0 / buf1 are rewritten by the next slice
@@ -340,7 +424,6 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
   store_plain(dst, U, er * cs, er * sn, ph);
 }
 
-// Workgroups per CU the LDS allows (three images each): the register budget follows from it.
 template <int NIG, int W>
 struct MidOcc {
   static constexpr int IMG_BYTES = 16 * NIG * W * 8;
@@ -379,7 +462,8 @@ __global__ void __launch_bounds__(256, (MidOcc<NIG, W>::WGS)) midd_chain_kernel(
   // lane geometry
   cm.aoff = (4 * cm.b + (cm.c & ~1) + ((cm.c ^ cm.r) & 1)) * W + (cm.r >> 1);
   cm.boff = cm.r * W + cm.c;
-  cm.dbase = (4 * cm.b + cm.r) * W + cm.c;
+  cm.lsmall = (4 * cm.b + cm.r) * W + cm.c;  // element of a 16x4 unit: row 4b + r, column c
+  cm.lbig = cm.r * W + 4 * cm.b + cm.c;      // element of a 16x16 unit (register q adds 4q rows): row r, column 4b + c
   cm.negmask = (((cm.c & 1) == 0) && ((cm.r & 1) == 1)) ? 0x80000000u : 0u;
 
   // zero all images once (padding rows/columns must stay zero)
