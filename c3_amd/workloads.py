@@ -114,6 +114,34 @@ def centred_time_grid(t_start: float, t_end: float, resolution: float) -> np.nda
 # --------------------------------------------------------------------------
 
 
+def transmon_factor(phi: float, phi_0: float, d: float = 0.0) -> float:
+    """SQUID tuning factor (cos^2 + d^2 sin^2)^(1/4) of a flux-tunable transmon (chip.py:355-371)."""
+    x = np.pi * phi / phi_0
+    return float(np.sqrt(np.sqrt(np.cos(x) ** 2 + d**2 * np.sin(x) ** 2)))
+
+
+def transmon_freq(freq_hz: float, anhar_hz: float, phi: float, phi_0: float, d: float = 0.0) -> float:
+    """Biased frequency (freq - anhar) * factor + anhar (chip.py:377-382)."""
+    return (freq_hz - anhar_hz) * transmon_factor(phi, phi_0, d) + anhar_hz
+
+
+def tunable_coupler_problem():
+    """Operators of the reference's tunable-coupler integration test (test/test_tunable_coupler.py:30-157).
+
+    Subsystem order [TC, Q1, Q2] (3 levels each, D = 27), XX couplings Q1-TC and Q2-TC, dressed;
+    the only driven line in the `crzp` gate is the flux line, whose signal is the TC frequency
+    shift in rad/s (FluxTuning, devices.py:497-525) multiplying the dressed number operator
+    (z_drive, hamiltonians.py:166-182).  Returns (h0 [27,27], hk_tc [27,27]).
+    """
+    phi_0 = 10.0
+    f_tc = transmon_freq(8.1e9, -235e6, phi_0 * 0.23, phi_0, 0.36)
+    dims = [3, 3, 3]
+    H = bare_drift(dims, [f_tc, 6.189e9, 5.089e9], [-235e6, -286e6, -310e6], {(1, 0): 142e6, (2, 0): 116e6})
+    T = dressing_transform(H)
+    a = annihilators(dims)
+    return dress(H, T), dress(a[0].conj().T @ a[0], T)
+
+
 @dataclass
 class Gate:
     """The attributes of `Instruction` the path reads (experiment.py:471; gates.py)."""

@@ -51,6 +51,27 @@ def test_golden_two_qubit(prop, golden_dir):
     assert np.linalg.norm(np.asarray(r["U"][0]) - g["propagator"]) < 1e-11
 
 
+def test_golden_tunable_coupler(prop, golden_dir):
+    """D = 27 known-answer test on the MFMA mid-D kernel: the reference's stored partial propagators of
+    the 10 000-slice CPHASE gate (test/test_tunable_coupler.py:393-403), branch A and branch B."""
+    from c3_amd.workloads import tunable_coupler_problem
+
+    g = np.load(golden_dir + "/tunable_coupler.npz")
+    h0, hk = tunable_coupler_problem()
+    sig = g["tc_signal"]
+    dt = g["tc_ts"][1] - g["tc_ts"][0]
+    r = prop.propagate_batch(h0, hk[None], sig[None, None, :], dt, want_dUs=True)
+    dUs = np.asarray(r["dUs"][0])
+    assert np.abs(dUs[g["dU_slice_index"]] - g["dUs"]).max() < 1e-12
+    U_ref = o.tf_matmul_left(o.expm(-1j * dt * (h0[None] + sig[:, None, None] * hk[None])))
+    assert np.linalg.norm(np.asarray(r["U"][0]) - U_ref) < TOL
+    # branch B: the per-slice Hamiltonians handed over whole (propagation.py:296-298)
+    n = 1500
+    H = h0[None] + sig[:n, None, None] * hk[None]
+    rb = prop.tf_batch_propagate(H, None, None, dt, batch_size=n)
+    assert np.abs(np.asarray(rb)[g["dU_slice_index"][:6]] - g["dUs"][:6]).max() < 1e-12
+
+
 @pytest.mark.parametrize("solver", ["rk4", "rk38", "rk5", "tsit5"])
 @pytest.mark.parametrize("step", ["schrodinger", "von_neumann", "lindblad"])
 def test_ode_vs_oracle(prop, solver, step):
