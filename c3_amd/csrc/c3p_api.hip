@@ -14,6 +14,7 @@
 #include "c3p_smalld.h"
 #include "c3p_midd.h"
 #include "c3p_bigd.h"
+#include "c3p_signal.h"
 
 namespace {
 
@@ -957,6 +958,56 @@ int c3p_gate_overlap(const void* U, int B, int D, const int32_t* comp_rows, int 
     if (sg.out(overlap_out, (size_t)B * cs, &d_out)) return -1;
   }
   HIP_TRY(c3p_launch_overlap((const cplx*)d_U, B, D, (const int*)d_rows, L, (const cplx*)d_G, (cplx*)d_out, st));
+  if (flags & C3P_HOST_PTRS) return sg.finish();
+  return 0;
+}
+
+int c3p_synth_signals(const double* env_params, const int32_t* env_shapes, const double* carrier,
+                      double t_start, double t_end, double awg_res, double sim_res, int B, int K,
+                      int E, int flags, double* awg_iq_out, double* signals_out, void* stream) {
+  if (B < 0 || K <= 0 || E <= 0) return fail("bad sizes B=%d K=%d E=%d", B, K, E);
+  if (!(awg_res > 0.0) || !(sim_res > 0.0)) return fail("resolutions must be positive");
+  const double span = t_end > t_start ? t_end - t_start : t_start - t_end;
+  const int N = (int)(span * sim_res), Na = (int)(span * awg_res);  // devices.py:72-84
+  if (N <= 0 || Na <= 1) return fail("empty time grid: N=%d Na=%d", N, Na);
+  if (B == 0) return 0;
+  if (!env_params || !env_shapes || !carrier || !signals_out) return fail("NULL pointer argument");
+  hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lk(g_mu);
+  DeviceWs* w = ws_for_current_device();
+  if (!w) return fail("no HIP device");
+  Stage sg{w, st};
+  const void *d_env = env_params, *d_shape = env_shapes, *d_car = carrier;
+  void *d_iq = awg_iq_out, *d_sig = signals_out;
+  const size_t iq_bytes = (size_t)B * K * 2 * Na * sizeof(double);
+  if (flags & C3P_HOST_PTRS) {
+    for (int a = 0; a < K * E; ++a)
+      if (env_shapes[a] >= C3P_ENV_NSHAPES) return fail("env_shapes[%d]=%d is not a C3P_ENV_* id", a, env_shapes[a]);
+    if (sg.in(env_params, (size_t)B * K * E * C3P_ENV_NPAR * sizeof(double), &d_env)) return -1;
+    if (sg.in(env_shapes, (size_t)K * E * sizeof(int32_t), &d_shape)) return -1;
+    if (sg.in(carrier, (size_t)B * K * 2 * sizeof(double), &d_car)) return -1;
+    if (sg.out(signals_out, (size_t)B * K * N * sizeof(double), &d_sig)) return -1;
+    if (awg_iq_out && sg.out(awg_iq_out, iq_bytes, &d_iq)) return -1;
+  }
+  if (!d_iq) {
+    if (ws_get(w, SL_SCRATCH, iq_bytes, &d_iq)) return -1;
+  }
+  SynthArgs A;
+  A.env = (const double*)d_env;
+  A.shape = (const int*)d_shape;
+  A.carrier = (const double*)d_car;
+  A.t_start = t_start;
+  A.t_end = t_end;
+  A.awg_res = awg_res;
+  A.sim_res = sim_res;
+  A.B = B;
+  A.K = K;
+  A.E = E;
+  A.Na = Na;
+  A.N = N;
+  A.iq = (double*)d_iq;
+  A.signals = (double*)d_sig;
+  HIP_TRY(c3p_launch_synth(A, st));
   if (flags & C3P_HOST_PTRS) return sg.finish();
   return 0;
 }

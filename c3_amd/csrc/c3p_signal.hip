@@ -1,0 +1,170 @@
+// Control-signal synthesis for the standard drive line
+//   LO + AWG -> DigitalToAnalog -> Mixer -> VoltsToHertz
+// (reference: c3/signal/gates.py:341-370 get_awg_signal, c3/signal/pulse.py:88-180 envelopes/mask/DRAG,
+//  c3/generator/devices.py:72-122 create_ts, :306-351 DAC, :914-939 Mixer, :1073-1130 LO, :203-221 V->Hz).
+// A batch is described by B x K x E envelope-parameter rows instead of B x K x N samples; the samples
+// are produced in HBM where the propagator kernels read them.  Two launches: the AWG-resolution I/Q
+// (a few hundred samples per line), then upsampling + mixing, one thread per output sample (HBM-bound,
+// 8 B written per sample, nothing re-read from HBM: the I/Q rows stay in L2).
+#include <hip/hip_runtime.h>
+
+#include "c3p_signal.h"
+
+namespace {
+
+// numpy.linspace(start, stop, num)[j]: j * step + start with separate roundings, last sample = stop
+__device__ __forceinline__ double linspace_at(double start, double stop, int num, int j) {
+  if (num <= 1) return start;
+  if (j == num - 1) return stop;
+  const double step = __ddiv_rn(__dsub_rn(stop, start), (double)(num - 1));
+  return __dadd_rn(__dmul_rn((double)j, step), start);
+}
+
+__device__ __forceinline__ double sigmoid(double x) { return 1.0 / (1.0 + exp(-x)); }
+
+struct EnvP {
+  double amp, xy, fo, delta, t_final, sigma, t_up, t_down, risefall, delay;
+  int use_t_before, drag;
+};
+
+__device__ __forceinline__ EnvP load_env(const double* p) {
+  EnvP e;
+  e.amp = p[C3P_ENV_AMP];
+  e.xy = p[C3P_ENV_XY_ANGLE];
+  e.fo = p[C3P_ENV_FREQ_OFFSET];
+  e.delta = p[C3P_ENV_DELTA];
+  e.t_final = p[C3P_ENV_T_FINAL];
+  e.sigma = p[C3P_ENV_SIGMA];
+  e.t_up = p[C3P_ENV_T_UP];
+  e.t_down = p[C3P_ENV_T_DOWN];
+  e.risefall = p[C3P_ENV_RISEFALL];
+  e.delay = p[C3P_ENV_DELAY];
+  const int fl = (int)p[C3P_ENV_FLAGS];
+  e.use_t_before = fl & C3P_ENVF_T_BEFORE;
+  e.drag = fl & C3P_ENVF_DRAG;
+  return e;
+}
+
+__device__ double shape_val(int shape, double t, const EnvP& p) {
+  switch (shape) {
+    case C3P_ENV_RECT:
+      return 1.0;
+    case C3P_ENV_GAUSSIAN_NONORM: {
+      const double u = t - p.t_final / 2;
+      return exp(-(u * u) / (2 * p.sigma * p.sigma));
+    }
+    case C3P_ENV_FLATTOP:
+    case C3P_ENV_FLATTOP_RISEFALL: {
+      const double rf = p.risefall;
+      const double tu = shape == C3P_ENV_FLATTOP ? p.t_up : rf;
+      const double td = shape == C3P_ENV_FLATTOP ? p.t_down : p.t_final - rf;
+      return (1 + erf((t - tu) / rf)) / 2 * (1 + erf((-t + td) / rf)) / 2;
+    }
+    case C3P_ENV_COSINE:
+      return 0.5 * (1 - cos(2 * M_PI * t / p.t_final));
+    default:
+      return 0.0;
+  }
+}
+
+__device__ double shape_der(int shape, double t, const EnvP& p) {
+  switch (shape) {
+    case C3P_ENV_GAUSSIAN_NONORM:
+      return -(t - p.t_final / 2) / (p.sigma * p.sigma) * shape_val(shape, t, p);
+    case C3P_ENV_FLATTOP:
+    case C3P_ENV_FLATTOP_RISEFALL: {
+      const double rf = p.risefall;
+      const double tu = shape == C3P_ENV_FLATTOP ? p.t_up : rf;
+      const double td = shape == C3P_ENV_FLATTOP ? p.t_down : p.t_final - rf;
+      const double u = (t - tu) / rf, d = (-t + td) / rf;
+      const double c = 2 / sqrt(M_PI) / rf;
+      return (c * exp(-u * u) * (1 + erf(d)) - (1 + erf(u)) * c * exp(-d * d)) / 4;
+    }
+    case C3P_ENV_COSINE: {
+      const double w = 2 * M_PI / p.t_final;
+      return 0.5 * w * sin(w * t);
+    }
+    default:
+      return 0.0;
+  }
+}
+
+__device__ __forceinline__ double mask_val(double ts_off, double dt, double tf_) {
+  return sigmoid((ts_off / dt + 0.001) * 1e6) * sigmoid((0.999 * tf_ - ts_off) / dt * 1e6);
+}
+
+// one thread per AWG sample (b, k, j)
+__global__ void awg_iq_kernel(SynthArgs A) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)A.B * A.K * A.Na;
+  if (gid >= total) return;
+  const int j = (int)(gid % A.Na);
+  const long bk = gid / A.Na;
+  const int k = (int)(bk % A.K);
+  const double dta = 1.0 / A.awg_res;
+  const double a0 = A.t_start + dta / 2, a1 = A.t_end - dta / 2;
+  const double t = linspace_at(a0, a1, A.Na, j);
+  const double t_first = linspace_at(a0, a1, A.Na, 0), t_second = linspace_at(a0, a1, A.Na, A.Na > 1 ? 1 : 0);
+  double re = 0.0, im = 0.0;
+  for (int e = 0; e < A.E; ++e) {
+    const int shape = A.shape[k * A.E + e];
+    if (shape < 0) continue;
+    const EnvP p = load_env(A.env + (bk * A.E + e) * C3P_ENV_NPAR);
+    const double t0 = A.t_start + p.delay;
+    const double ts_off = t - t0, off0 = t_first - t0, off1 = t_second - t0;
+    const double dt = off1 - off0;
+    const double tf_ = p.t_final;  // window = t_final of the component (gates.py:293-297)
+    const double m = mask_val(ts_off, dt, tf_);
+    const double t_before = 2 * off0 - off1;
+    const double offset = p.use_t_before ? shape_val(shape, t_before, p) : 0.0;
+    const double er = m * (shape_val(shape, ts_off, p) - offset);
+    double ei = 0.0;
+    if (p.drag) {
+      double denv = m * shape_der(shape, ts_off, p);
+      if (p.use_t_before && j < 2) {
+        double msum = 0.0;
+        for (int i = 0; i < A.Na; ++i) msum += mask_val(linspace_at(a0, a1, A.Na, i) - t0, dt, tf_);
+        const double doff = shape_der(shape, t_before, p) * msum;
+        denv += (j == 0) ? -2 * doff : doff;
+      }
+      ei = -denv * dt * p.delta;
+    }
+    double sn, cs;
+    sincos(p.xy - p.fo * ts_off, &sn, &cs);
+    re += p.amp * (er * cs - ei * sn);
+    im += p.amp * (er * sn + ei * cs);
+  }
+  double* iq = A.iq + bk * 2 * A.Na;
+  iq[j] = re;
+  iq[A.Na + j] = im;
+}
+
+// one thread per simulation sample (b, k, n): nearest-neighbour upsampling, IQ mixing, V -> Hz
+__global__ void mix_kernel(SynthArgs A) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)A.B * A.K * A.N;
+  if (gid >= total) return;
+  const int n = (int)(gid % A.N);
+  const long bk = gid / A.N;
+  const double dts = 1.0 / A.sim_res;
+  const double t = linspace_at(A.t_start + dts / 2, A.t_end - dts / 2, A.N, n);
+  int src = (int)floor(((double)n + 0.5) * ((double)A.Na / (double)A.N));
+  src = src < A.Na - 1 ? src : A.Na - 1;
+  const double* iq = A.iq + bk * 2 * A.Na;
+  const double w = A.carrier[bk * 2 + 0], v2hz = A.carrier[bk * 2 + 1];
+  double sn, cs;
+  sincos(w * t, &sn, &cs);
+  A.signals[gid] = (cs * iq[src] + sn * iq[A.Na + src]) * v2hz;
+}
+
+}  // namespace
+
+hipError_t c3p_launch_synth(const SynthArgs& A, hipStream_t st) {
+  const long ta = (long)A.B * A.K * A.Na, ts = (long)A.B * A.K * A.N;
+  if (ta == 0 || ts == 0) return hipSuccess;
+  hipLaunchKernelGGL(awg_iq_kernel, dim3((unsigned)((ta + 127) / 128)), dim3(128), 0, st, A);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(mix_kernel, dim3((unsigned)((ts + 255) / 256)), dim3(256), 0, st, A);
+  return hipGetLastError();
+}

@@ -150,6 +150,49 @@ int c3p_rk4_unitary(const void* h0, const void* hks, const double* signals, cons
                     int64_t hs_bstride, double dt, int B, int K, int Ns, int D, int flags,
                     void* U_out, void* dUs_out, void* stream);
 
+/* Control-signal synthesis for the standard drive line LO + AWG -> DAC -> Mixer -> VoltsToHertz
+ * (Instruction.get_awg_signal c3/signal/gates.py:341-370, Envelope/EnvelopeDrag
+ * c3/signal/pulse.py:88-180, Device.create_ts c3/generator/devices.py:72-122, DigitalToAnalog :306-351,
+ * Mixer :914-939, LO :1073-1130 noiseless branch, VoltsToHertz :203-221, envelope shapes
+ * c3/libraries/envelopes.py:26,195,228,254,421,470).  A batch is described by B x K x E envelope
+ * parameter rows instead of B x K x N samples:
+ *   signals[b,k,n] = v2hz * (cos(w t_n) I(t_n) + sin(w t_n) Q(t_n)),
+ *   I + iQ = nearest-neighbour upsampling of sum_e amp_e env_e(t - t0_e) exp(i (xy_e - fo_e (t - t0_e)))
+ *   sampled on the AWG grid, env_e = mask * (shape - shape(t_before)) [+ i DRAG term].
+ *   env_params  f64 [B,K,E,C3P_ENV_NPAR]   rows laid out by the C3P_ENV_* slots below
+ *   env_shapes  int32 [K,E]                C3P_ENV_* shape ids, negative = unused slot
+ *   carrier     f64 [B,K,2]                {LO angular frequency [rad/s], V_to_Hz factor}
+ *   N = (int)(|t_end - t_start| * sim_res), Na = (int)(|t_end - t_start| * awg_res)
+ *   awg_iq_out  f64 [B,K,2,Na] or NULL     AWG-resolution inphase, quadrature
+ *   signals_out f64 [B,K,N]                what c3p_pwc_* take as `signals`
+ */
+#define C3P_ENV_NO_DRIVE 0
+#define C3P_ENV_RECT 1
+#define C3P_ENV_GAUSSIAN_NONORM 2
+#define C3P_ENV_FLATTOP 3
+#define C3P_ENV_FLATTOP_RISEFALL 4
+#define C3P_ENV_COSINE 5
+#define C3P_ENV_NSHAPES 6
+
+#define C3P_ENV_AMP 0
+#define C3P_ENV_XY_ANGLE 1
+#define C3P_ENV_FREQ_OFFSET 2
+#define C3P_ENV_DELTA 3
+#define C3P_ENV_T_FINAL 4
+#define C3P_ENV_SIGMA 5
+#define C3P_ENV_T_UP 6
+#define C3P_ENV_T_DOWN 7
+#define C3P_ENV_RISEFALL 8
+#define C3P_ENV_DELAY 9
+#define C3P_ENV_FLAGS 10 /* C3P_ENVF_* bits stored as a double */
+#define C3P_ENV_NPAR 12
+#define C3P_ENVF_T_BEFORE 1 /* Envelope(use_t_before=True) */
+#define C3P_ENVF_DRAG 2     /* EnvelopeDrag: imag = -delta * dt * d env/dt */
+
+int c3p_synth_signals(const double* env_params, const int32_t* env_shapes, const double* carrier,
+                      double t_start, double t_end, double awg_res, double sim_res, int B, int K,
+                      int E, int flags, double* awg_iq_out, double* signals_out, void* stream);
+
 /* Fidelity epilogue: overlap[b] = tr(P^T U[b] P G^+), the number behind
  * unitary_infid = 1 - |overlap/L|^2 (c3/libraries/fidelities.py:154-184, tf_unitary_overlap
  * c3/utils/tf_utils.py:330-366) and average_infid = 1 - (|overlap|^2/L + 1)/(L + 1)

@@ -81,6 +81,10 @@ def main():
         dU_slice_index=np.arange(0, 10000, 50)[::5],
         tc_signal=np.asarray(d["tc_signal"]),
         tc_ts=np.asarray(d["tc_ts"]),
+        # AWG-resolution I/Q of the flux line (test_tunable_coupler.py:429-445): pins the flattop envelope
+        tc_awg_I=np.asarray(d["tc_awg_I"]),
+        tc_awg_Q=np.asarray(d["tc_awg_Q"]),
+        tc_awg_ts=np.asarray(d["tc_awg_ts"]),
     )
 
     d = load("test_tf_utils.pickle")
