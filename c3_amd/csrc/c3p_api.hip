@@ -15,6 +15,7 @@
 #include "c3p_midd.h"
 #include "c3p_bigd.h"
 #include "c3p_signal.h"
+#include "c3p_grad.h"
 
 namespace {
 
@@ -1008,6 +1009,83 @@ int c3p_synth_signals(const double* env_params, const int32_t* env_shapes, const
   A.iq = (double*)d_iq;
   A.signals = (double*)d_sig;
   HIP_TRY(c3p_launch_synth(A, st));
+  if (flags & C3P_HOST_PTRS) return sg.finish();
+  return 0;
+}
+
+int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride,
+                        const double* signals, double dt, int B, int K, int N, int D, int flags,
+                        const double* fr_phase, const void* U_bar, double* grad_signals, void* stream) {
+  if (B < 0 || K <= 0 || N <= 0 || D <= 0) return fail("bad sizes B=%d K=%d N=%d D=%d", B, K, N, D);
+  if (D > 64) return fail("gradient kernels support D <= 64, got %d", D);
+  if (flags & (C3P_PER_SLICE_H | C3P_ORDER_RIGHT)) return fail("c3p_pwc_unitary_vjp: unsupported flag");
+  if (B == 0) return 0;
+  if (!h0 || !hks || !signals || !U_bar || !grad_signals) return fail("NULL pointer argument");
+  const size_t cs = sizeof(cplx);
+  hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lk(g_mu);
+  DeviceWs* w = ws_for_current_device();
+  if (!w) return fail("no HIP device");
+  Stage sg{w, st};
+  const void *d_h0 = h0, *d_hks = hks, *d_sig = signals, *d_ph = fr_phase, *d_ub = U_bar;
+  void* d_grad = grad_signals;
+  if (flags & C3P_HOST_PTRS) {
+    // the adjoint recurrence M_n = dU_n^H M_{n+1} dU_n needs unitary slices: Hermitian generators
+    const cplx* hh[2] = {(const cplx*)h0, (const cplx*)hks};
+    const long cnt[2] = {h0_bstride ? (long)B : 1L, (hks_bstride ? (long)B : 1L) * K};
+    for (int a = 0; a < 2; ++a)
+      for (long m = 0; m < cnt[a]; ++m) {
+        const cplx* H = hh[a] + m * D * D;
+        double dev = 0.0, mag = 0.0;
+        for (int i = 0; i < D; ++i)
+          for (int j = 0; j < D; ++j) {
+            dev = fmax(dev, hypot(H[i * D + j].x - H[j * D + i].x, H[i * D + j].y + H[j * D + i].y));
+            mag = fmax(mag, hypot(H[i * D + j].x, H[i * D + j].y));
+          }
+        if (dev > 1e-9 * mag) return fail("c3p_pwc_unitary_vjp needs Hermitian Hamiltonians (deviation %.3g)", dev);
+      }
+    if (sg.in(h0, (size_t)(h0_bstride ? B : 1) * D * D * cs, &d_h0)) return -1;
+    if (sg.in(hks, (size_t)(hks_bstride ? B : 1) * K * D * D * cs, &d_hks)) return -1;
+    if (sg.in(signals, (size_t)B * K * N * sizeof(double), &d_sig)) return -1;
+    if (sg.in(U_bar, (size_t)B * D * D * cs, &d_ub)) return -1;
+    if (fr_phase && sg.in(fr_phase, (size_t)B * D * sizeof(double), &d_ph)) return -1;
+    if (sg.out(grad_signals, (size_t)B * K * N * sizeof(double), &d_grad)) return -1;
+  }
+  GradArgs A = {};
+  A.h0 = (const cplx*)d_h0;
+  A.h0_bstride = h0_bstride;
+  A.hks = (const cplx*)d_hks;
+  A.hks_bstride = hks_bstride;
+  A.signals = (const double*)d_sig;
+  A.fr_phase = (const double*)d_ph;
+  A.Ubar = (const cplx*)d_ub;
+  A.dt = dt;
+  A.B = B;
+  A.K = K;
+  A.N = N;
+  A.D = D;
+  A.ld = D | 1;
+  long S = 4096 / B;
+  if (S > N / 8) S = N / 8;
+  if (S < 1) S = 1;
+  A.seg_len = (int)((N + S - 1) / S);
+  A.S = (N + A.seg_len - 1) / A.seg_len;
+  void* v;
+  if (ws_get(w, SL_SEG_A, (size_t)B * A.S * D * D * cs, &v)) return -1;
+  A.seg = (cplx*)v;
+  if (ws_get(w, SL_SEG_B, (size_t)B * A.S * D * D * cs, &v)) return -1;
+  A.Mb = (cplx*)v;
+  A.grad = (double*)d_grad;
+  const bool global = c3p_grad_lds_bytes(D) > 150 * 1024;
+  if (global) {
+    A.scratch_stride = (long)C3P_GRAD_NMAT * A.ld * D;
+    if (ws_get(w, SL_SCRATCH, (size_t)B * A.S * A.scratch_stride * cs, &v)) return -1;
+    A.scratch = (cplx*)v;
+  }
+  g_last_kernel = global ? C3P_KERNEL_GENERIC_GLOBAL : C3P_KERNEL_GENERIC_LDS;
+  if (record_start(w, st)) return -1;
+  HIP_TRY(c3p_launch_grad(A, global, st));
+  if (record_stop(w, st)) return -1;
   if (flags & C3P_HOST_PTRS) return sg.finish();
   return 0;
 }

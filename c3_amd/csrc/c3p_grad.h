@@ -1,0 +1,27 @@
+// Launcher interface of the control-gradient kernels (c3p_grad.hip).
+#pragma once
+#include "c3p_common.h"
+
+struct GradArgs {
+  const cplx* h0;
+  long h0_bstride;  // elements between samples (0 = shared)
+  const cplx* hks;
+  long hks_bstride;
+  const double* signals;   // [B,K,N]
+  const double* fr_phase;  // [B,D] or null
+  const cplx* Ubar;        // [B,D,D] cotangent of U
+  double dt;
+  int B, K, N, D, ld;
+  int S, seg_len;
+  cplx* seg;     // [B,S,D,D] segment products (no frame rotation)
+  cplx* Mb;      // [B,S,D,D] adjoint state at the END of each segment
+  double* grad;  // [B,K,N]
+  cplx* scratch;  // GLOBAL variant: scratch_stride elements per workgroup
+  long scratch_stride;
+};
+
+#define C3P_GRAD_NMAT 19  // matrices a backward workgroup keeps (LDS or scratch)
+
+int c3p_grad_threads(int D);
+size_t c3p_grad_lds_bytes(int D);  // LDS variant footprint; > 150 KB => use the GLOBAL variant
+hipError_t c3p_launch_grad(const GradArgs& A, bool global_scratch, hipStream_t st);

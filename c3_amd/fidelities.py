@@ -99,3 +99,39 @@ def average_infid_set(propagators: dict, instructions: dict, index, dims, n_eval
     """Mean over gates (fidelities.py:316-347)."""
     vals = [np.asarray(average_infid(_ideal_of(instructions, g, dims, index), U, index, dims)) for g, U in propagators.items()]
     return np.mean(vals, axis=0)
+
+
+def _cotangent(ideal, actual, index, dims, scale_of_L):
+    s, L = gate_overlaps(ideal, actual, index, dims)
+    rows = computational_rows(dims, index)
+    call = _Call(actual)
+    G = call.c128(ideal)
+    U = call.c128(actual)
+    squeeze = U.ndim == 2
+    B, D = (1 if squeeze else int(U.shape[0])), int(U.shape[-1])
+    sv = s.reshape(1) if squeeze else s
+    if call.device:
+        t = call.torch
+        emb = t.zeros((D, D), dtype=t.complex128, device=call.dev)
+        r = t.as_tensor(rows, device=call.dev, dtype=t.long)
+        emb[r[:, None], r[None, :]] = G
+        Ubar = (scale_of_L(L) * sv)[:, None, None] * emb[None]
+    else:
+        emb = np.zeros((D, D), dtype=np.complex128)
+        emb[np.ix_(rows, rows)] = G
+        Ubar = (scale_of_L(L) * np.asarray(sv))[:, None, None] * emb[None]
+    return (Ubar[0] if squeeze else Ubar), s, L
+
+
+def unitary_infid_cotangent(ideal, actual, index: List[int] = None, dims=None):
+    """(U_bar, infid): U_bar[b] = d unitary_infid / d U[b] in the convention of
+    `propagation.propagate_batch_vjp` (d loss = Re sum conj(U_bar) dU); from 1 - |s/L|^2 with
+    s = tr(G^+ P^T U P) (fidelities.py:154-184): U_bar = -(2/L^2) s P G P^T."""
+    Ubar, s, L = _cotangent(ideal, actual, index, dims, lambda L: -2.0 / L**2)
+    return Ubar, 1 - abs(s / L) ** 2
+
+
+def average_infid_cotangent(ideal, actual, index: List[int] = [0], dims=[2]):
+    """(U_bar, infid) for 1 - (|s|^2/L + 1)/(L + 1) (fidelities.py:290-313): U_bar = -2 s P G P^T / (L (L+1))."""
+    Ubar, s, L = _cotangent(ideal, actual, index, dims, lambda L: -2.0 / (L * (L + 1)))
+    return Ubar, 1 - (abs(s) ** 2 / L + 1) / (L + 1)

@@ -202,6 +202,45 @@ def propagate_batch(
     return {"U": U, "dUs": dUs}
 
 
+def propagate_batch_vjp(h0, hks, signals, dt: float, U_bar, *, fr_phase=None):
+    """Vector-Jacobian product of `propagate_batch` (unitary, branch A) w.r.t. the control samples.
+
+    The reference tapes the goal function (optimizers/optimizer.py:206-216) and lets TensorFlow
+    differentiate propagation.py:426-440 + tf_utils.py:144-193; here the adjoint sweep runs on the
+    device.  With d loss = Re sum conj(U_bar) dU, returns d loss / d signals as f64 [B,K,N].
+    `U_bar` [B,D,D] for unitary_infid / average_infid comes from `fidelities.*_cotangent`.
+    """
+    call = _Call(h0, hks, signals, U_bar, fr_phase)
+    h0 = call.c128(h0)
+    hks = call.c128(hks)
+    signals = call.f64(signals)
+    if signals.ndim != 3:
+        raise C3PropError(f"C3:Error: signals must be [B,K,N], got {tuple(signals.shape)}")
+    B, K, N = (int(s) for s in signals.shape)
+    D = int(h0.shape[-1])
+    h0_bs = _bstride(h0, 2, B, "h0")
+    hk_bs = _bstride(hks, 3, B, "hks")
+    if int(hks.shape[-3]) != K:
+        raise C3PropError(f"C3:Error: {K} signal channels but {int(hks.shape[-3])} control Hamiltonians")
+    U_bar = call.c128(U_bar)
+    if tuple(U_bar.shape) != (B, D, D):
+        raise C3PropError(f"C3:Error: U_bar must be [{B},{D},{D}], got {tuple(U_bar.shape)}")
+    if fr_phase is not None:
+        fr_phase = call.f64(fr_phase)
+        if tuple(fr_phase.shape) != (B, D):
+            raise C3PropError(f"C3:Error: fr_phase must be [{B},{D}], got {tuple(fr_phase.shape)}")
+    if call.device:
+        grad = call.torch.empty((B, K, N), dtype=call.torch.float64, device=call.dev)
+    else:
+        grad = np.empty((B, K, N), dtype=np.float64)
+    _lib.check(
+        _lib.load().c3p_pwc_unitary_vjp(
+            _ptr(h0), h0_bs, _ptr(hks), hk_bs, _ptr(signals), float(dt), B, K, N, D, call.flags, _ptr(fr_phase), _ptr(U_bar), _ptr(grad), call.stream
+        )
+    )
+    return grad
+
+
 # --------------------------------------------------------------------------
 # tf_utils counterparts on the device (tf_utils.py:120-193, 240-289)
 # --------------------------------------------------------------------------

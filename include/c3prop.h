@@ -150,6 +150,18 @@ int c3p_rk4_unitary(const void* h0, const void* hks, const double* signals, cons
                     int64_t hs_bstride, double dt, int B, int K, int Ns, int D, int flags,
                     void* U_out, void* dUs_out, void* stream);
 
+/* Gradient of the propagators with respect to the control samples.  The reference obtains
+ * it by taping the goal function (c3/optimizers/optimizer.py:206-216, optimalcontrol.py:219-226); the
+ * taped path is c3p_pwc_unitary's (propagation.py:426-440, tf_utils.py:144-193, experiment.py:482-509).
+ * Vector-Jacobian product: with d loss = Re sum_ij conj(U_bar[b,i,j]) dU[b,i,j],
+ *   grad_signals[b,k,n] = d loss / d signals[b,k,n]      (exact: Frechet derivative of every slice)
+ *   U_bar c128 [B,D,D]; grad_signals f64 [B,K,N]; other arguments as c3p_pwc_unitary (branch A only,
+ *   Hermitian h0 / hks: the adjoint sweep uses the unitarity of the slices; checked for host pointers).
+ */
+int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride,
+                        const double* signals, double dt, int B, int K, int N, int D, int flags,
+                        const double* fr_phase, const void* U_bar, double* grad_signals, void* stream);
+
 /* Control-signal synthesis for the standard drive line LO + AWG -> DAC -> Mixer -> VoltsToHertz
  * (Instruction.get_awg_signal c3/signal/gates.py:341-370, Envelope/EnvelopeDrag
  * c3/signal/pulse.py:88-180, Device.create_ts c3/generator/devices.py:72-122, DigitalToAnalog :306-351,

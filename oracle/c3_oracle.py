@@ -1167,3 +1167,52 @@ def generate_signal(components: Sequence[Dict], lo_freq: float, v_to_hz: float, 
     I, Q = dac_nearest(inph, ts.shape[0]), dac_nearest(quad, ts.shape[0])
     values = (np.cos(lo_freq * ts) * I + np.sin(lo_freq * ts) * Q) * v_to_hz
     return {"values": values, "ts": ts, "inphase": inph, "quadrature": quad, "ts_awg": ts_awg}
+
+
+# --------------------------------------------------------------------------
+# Gradient of the PWC propagator w.r.t. the control samples
+# --------------------------------------------------------------------------
+
+
+def expm_frechet(X: np.ndarray, E: np.ndarray) -> np.ndarray:
+    """L(X, E) = d/de exp(X + e E)|_0 as the (0,1) block of exp([[X, E], [0, X]]) -- the exact derivative
+    the reference obtains by differentiating `tf.linalg.expm` with a GradientTape
+    (c3/optimizers/optimizer.py:206-216 wraps the goal function; propagation.py:440 is on the tape)."""
+    D = X.shape[-1]
+    aug = np.zeros((2 * D, 2 * D), dtype=np.complex128)
+    aug[:D, :D] = X
+    aug[D:, D:] = X
+    aug[:D, D:] = E
+    return expm(aug)[:D, D:]
+
+
+def pwc_signal_gradient(h0, hks, signals, dt, Ubar, fr_phase=None) -> np.ndarray:
+    """d loss / d signals[k, n] for one sample, where d loss = Re sum_ij conj(Ubar_ij) dU_ij and
+    U = FR . dU_{N-1} ... dU_0, dU_n = exp(-i dt (h0 + sum_k c_k(n) hk)) (propagation.py:426-440,
+    tf_utils.py:144-193, experiment.py:482-509).  Direct evaluation: prefix / suffix products and one
+    Frechet derivative per (k, n)."""
+    K, N = signals.shape
+    D = h0.shape[-1]
+    Xs = [-1j * dt * (h0 + sum(signals[k, n] * hks[k] for k in range(K))) for n in range(N)]
+    dUs = [expm(X) for X in Xs]
+    P = [np.eye(D, dtype=np.complex128)]
+    for n in range(N):
+        P.append(dUs[n] @ P[-1])
+    lam = Ubar.astype(np.complex128)
+    if fr_phase is not None:
+        lam = np.exp(-1j * np.asarray(fr_phase))[:, None] * lam  # FR^H Ubar
+    g = np.zeros((K, N))
+    for n in range(N - 1, -1, -1):
+        W = lam @ P[n].conj().T  # cotangent of dU_n
+        for k in range(K):
+            g[k, n] = np.real(np.vdot(W, expm_frechet(Xs[n], -1j * dt * hks[k])))
+        lam = dUs[n].conj().T @ lam
+    return g
+
+
+def unitary_infid_cotangent(ideal, U, index, dims):
+    """Ubar for loss = unitary_infid (fidelities.py:154-184): 1 - |tr(G^+ P^T U P) / L|^2."""
+    Pm = projector(dims, index)
+    L = Pm.shape[1]
+    s = np.trace(ideal.conj().T @ (Pm.T @ U @ Pm))
+    return -(2.0 / L**2) * s * (Pm @ ideal @ Pm.T)

@@ -1,0 +1,101 @@
+"""Gradient of the propagators w.r.t. the control samples."""
+import numpy as np
+import pytest
+
+from c3_amd.workloads import make_workload
+from oracle import c3_oracle as o
+
+
+@pytest.fixture(scope="module")
+def prop(lib):
+    from c3_amd import propagation, _lib
+
+    _lib.require_gpu()
+    return propagation
+
+
+def test_oracle_gradient_matches_finite_differences():
+    w = make_workload(1, B=1, N=5)
+    rng = np.random.default_rng(3)
+    D = w.D
+    Ubar = rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))
+    g = o.pwc_signal_gradient(w.h0, w.hks, w.signals[0], w.dt, Ubar, w.fr_phase[0])
+
+    def loss(sig):
+        U = o.propagate_batch(w.h0, w.hks, sig[None], w.dt, fr_phase=w.fr_phase[:1])[0]
+        return np.real(np.vdot(Ubar, U))
+
+    for k in range(w.K):
+        for n in range(5):
+            h = 2e3
+            sp, sm = w.signals[0].copy(), w.signals[0].copy()
+            sp[k, n] += h
+            sm[k, n] -= h
+            fd = (loss(sp) - loss(sm)) / (2 * h)
+            assert abs(fd - g[k, n]) < 1e-6 * np.abs(g).max()
+
+
+def test_oracle_infid_cotangent():
+    rng = np.random.default_rng(4)
+    ideal = np.kron(np.array([[1, -1j], [-1j, 1]]) / np.sqrt(2), np.eye(2))
+    U = np.linalg.qr(rng.normal(size=(9, 9)) + 1j * rng.normal(size=(9, 9)))[0]
+    Ub = o.unitary_infid_cotangent(ideal, U, [0, 1], [3, 3])
+    dU = rng.normal(size=(9, 9)) + 1j * rng.normal(size=(9, 9))
+    f = lambda V: o.unitary_infid(ideal, V, index=[0, 1], dims=[3, 3])
+    eps = 1e-6
+    assert abs((f(U + eps * dU) - f(U - eps * dU)) / (2 * eps) - np.real(np.vdot(Ub, dU))) < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,B,N", [(1, 3, 40), (2, 5, 64), (2, 2, 333), (3, 2, 24), (5, 1, 12)])
+def test_vjp_vs_oracle(prop, cfg, B, N):
+    w = make_workload(cfg, B=B, N=N)
+    rng = np.random.default_rng(10 + cfg)
+    D = w.D
+    Ubar = rng.normal(size=(B, D, D)) + 1j * rng.normal(size=(B, D, D))
+    g = np.asarray(prop.propagate_batch_vjp(w.h0, w.hks, w.signals, w.dt, Ubar, fr_phase=w.fr_phase))
+    for b in range(B):
+        want = o.pwc_signal_gradient(w.h0, w.hks, w.signals[b], w.dt, Ubar[b], w.fr_phase[b])
+        assert np.abs(g[b] - want).max() < 1e-10 * np.abs(want).max()
+
+
+@pytest.mark.gpu
+def test_vjp_device_resident_infid_gradient(prop):
+    """propagate -> unitary_infid cotangent -> vjp, all on the device; checked by a directional finite
+    difference of the oracle's infidelity."""
+    import torch
+    from c3_amd import fidelities
+
+    w = make_workload(2, B=4, N=200)
+    ideal = np.kron(np.array([[1, -1j], [-1j, 1]]) / np.sqrt(2), np.eye(2))
+    dev = "cuda:0"
+    h0, hks = torch.as_tensor(w.h0, device=dev), torch.as_tensor(w.hks, device=dev)
+    sig, ph = torch.as_tensor(w.signals, device=dev), torch.as_tensor(w.fr_phase, device=dev)
+    U = prop.propagate_batch(h0, hks, sig, w.dt, fr_phase=ph)["U"]
+    Ubar, infid = fidelities.unitary_infid_cotangent(ideal, U, [0, 1], [3, 3])
+    g = prop.propagate_batch_vjp(h0, hks, sig, w.dt, Ubar, fr_phase=ph)
+    assert g.is_cuda and tuple(g.shape) == (4, 2, 200)
+    g = g.cpu().numpy()
+    rng = np.random.default_rng(0)
+    dirn = rng.normal(size=w.signals.shape[1:])
+    for b in range(2):
+        def f(sig_b):
+            Ub = o.propagate_batch(w.h0, w.hks, sig_b[None], w.dt, fr_phase=w.fr_phase[b : b + 1])[0]
+            return o.unitary_infid(ideal, Ub, index=[0, 1], dims=[3, 3])
+
+        assert abs(float(infid[b]) - f(w.signals[b])) < 1e-12
+        eps = 1e4
+        fd = (f(w.signals[b] + eps * dirn) - f(w.signals[b] - eps * dirn)) / (2 * eps)
+        an = float((g[b] * dirn).sum())
+        assert abs(fd - an) < 1e-5 * abs(an) + 1e-18
+
+
+@pytest.mark.gpu
+def test_vjp_errors(prop):
+    w = make_workload(1, B=2, N=8)
+    with pytest.raises(Exception, match="C3:Error"):
+        prop.propagate_batch_vjp(w.h0, w.hks, w.signals, w.dt, np.zeros((1, 3, 3), complex))
+    bad = w.h0.copy()
+    bad[0, 1] += 1e6
+    with pytest.raises(Exception, match="Hermitian"):
+        prop.propagate_batch_vjp(bad, w.hks, w.signals, w.dt, np.zeros((2, 3, 3), complex))
