@@ -317,6 +317,63 @@ int run_pwc_smalld(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const 
   return 0;
 }
 
+// Gradient on the small-D MFMA kernels: forward segment products (unfused smalld chain kernel), the
+// per-sample scan of c3p_grad.hip, then the pair-T18 backward sweep.  Returns 1 when not applicable.
+int run_vjp_smalld(DeviceWs* w, GradArgs& G, hipStream_t st) {
+  const int D = G.D, B = G.B, K = G.K, N = G.N;
+  const bool per_sample = (G.h0_bstride != 0) || (G.hks_bstride != 0);
+  const int S = pick_segments(B, N, K, D, per_sample);
+  if (S < 0) return 1;
+  const int nsamp = per_sample ? B : 1;
+  void* v;
+  if (ws_get(w, SL_TABLES, (size_t)nsamp * c3p_smalld_table_doubles(D, K) * sizeof(double), &v)) return -1;
+  PrepArgs p = {};
+  p.h0 = G.h0;
+  p.h0_bstride = G.h0_bstride;
+  p.hks = G.hks;
+  p.hks_bstride = G.hks_bstride;
+  p.dt = G.dt;
+  p.K = K;
+  p.Dh = D;
+  p.tables = (double*)v;
+  HIP_TRY(c3p_launch_smalld_prep(p, D, nsamp, st));
+  const size_t segb = (size_t)B * S * D * D * sizeof(cplx);
+  void *sv, *mv;
+  if (ws_get(w, SL_SEG_A, segb, &sv)) return -1;
+  if (ws_get(w, SL_SEG_B, segb, &mv)) return -1;
+  SmallArgs a = {};
+  a.tables = p.tables;
+  a.tab_per_sample = per_sample ? 1 : 0;
+  a.signals = G.signals;
+  a.B = B;
+  a.K = K;
+  a.N = N;
+  a.Dm = D;
+  a.S = S;
+  a.Lmax = (N + S - 1) / S;
+  a.mode = C3P_MODE_UNITARY;
+  a.seg_out = (cplx*)sv;
+  HIP_TRY(c3p_launch_smalld_chain(a, st));
+  G.S = S;
+  G.seg = (cplx*)sv;
+  G.Mb = (cplx*)mv;
+  HIP_TRY(c3p_launch_grad_scan(G, false, st));
+  SmallGradArgs g = {};
+  g.tables = p.tables;
+  g.tab_per_sample = a.tab_per_sample;
+  g.signals = G.signals;
+  g.Mb = G.Mb;
+  g.grad = G.grad;
+  g.B = B;
+  g.K = K;
+  g.N = N;
+  g.Dm = D;
+  g.S = S;
+  g.Lmax = a.Lmax;
+  HIP_TRY(c3p_launch_smalld_grad(g, st));
+  return 0;
+}
+
 // ---------------------------------------------------------------------------
 // Mid-D MFMA path (13 <= Dm <= 40): one 4-wave workgroup per chain, matrices as LDS images
 // ---------------------------------------------------------------------------
@@ -1065,26 +1122,36 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
   A.N = N;
   A.D = D;
   A.ld = D | 1;
-  long S = 4096 / B;
-  if (S > N / 8) S = N / 8;
-  if (S < 1) S = 1;
-  A.seg_len = (int)((N + S - 1) / S);
-  A.S = (N + A.seg_len - 1) / A.seg_len;
-  void* v;
-  if (ws_get(w, SL_SEG_A, (size_t)B * A.S * D * D * cs, &v)) return -1;
-  A.seg = (cplx*)v;
-  if (ws_get(w, SL_SEG_B, (size_t)B * A.S * D * D * cs, &v)) return -1;
-  A.Mb = (cplx*)v;
   A.grad = (double*)d_grad;
-  const bool global = c3p_grad_lds_bytes(D) > 150 * 1024;
-  if (global) {
-    A.scratch_stride = (long)C3P_GRAD_NMAT * A.ld * D;
-    if (ws_get(w, SL_SCRATCH, (size_t)B * A.S * A.scratch_stride * cs, &v)) return -1;
-    A.scratch = (cplx*)v;
-  }
-  g_last_kernel = global ? C3P_KERNEL_GENERIC_GLOBAL : C3P_KERNEL_GENERIC_LDS;
   if (record_start(w, st)) return -1;
-  HIP_TRY(c3p_launch_grad(A, global, st));
+  bool done = false;
+  if (!(flags & C3P_FORCE_GENERIC) && D <= kSmallDLimit && c3p_smalld_supported(D) && K <= 8) {
+    const int rc = run_vjp_smalld(w, A, st);
+    if (rc < 0) return -1;
+    done = (rc == 0);
+    if (done) g_last_kernel = C3P_KERNEL_SMALLD;
+  }
+  if (!done) {
+    long S = 4096 / B;
+    if (S > N / 8) S = N / 8;
+    if (S < 1) S = 1;
+    A.S = (int)S;
+    void* v;
+    if (ws_get(w, SL_SEG_A, (size_t)B * A.S * D * D * cs, &v)) return -1;
+    A.seg = (cplx*)v;
+    if (ws_get(w, SL_SEG_B, (size_t)B * A.S * D * D * cs, &v)) return -1;
+    A.Mb = (cplx*)v;
+    const bool global = c3p_grad_lds_bytes(D) > 150 * 1024;
+    if (global) {
+      A.scratch_stride = (long)C3P_GRAD_NMAT * A.ld * D;
+      if (ws_get(w, SL_SCRATCH, (size_t)B * A.S * A.scratch_stride * cs, &v)) return -1;
+      A.scratch = (cplx*)v;
+    }
+    g_last_kernel = global ? C3P_KERNEL_GENERIC_GLOBAL : C3P_KERNEL_GENERIC_LDS;
+    HIP_TRY(c3p_launch_grad_seg(A, global, st));
+    HIP_TRY(c3p_launch_grad_scan(A, global, st));
+    HIP_TRY(c3p_launch_grad_bwd(A, global, st));
+  }
   if (record_stop(w, st)) return -1;
   if (flags & C3P_HOST_PTRS) return sg.finish();
   return 0;

@@ -12,7 +12,7 @@ struct GradArgs {
   const cplx* Ubar;        // [B,D,D] cotangent of U
   double dt;
   int B, K, N, D, ld;
-  int S, seg_len;
+  int S;  // time segments per sample, balanced: segment s covers [s N / S, (s+1) N / S)
   cplx* seg;     // [B,S,D,D] segment products (no frame rotation)
   cplx* Mb;      // [B,S,D,D] adjoint state at the END of each segment
   double* grad;  // [B,K,N]
@@ -24,4 +24,6 @@ struct GradArgs {
 
 int c3p_grad_threads(int D);
 size_t c3p_grad_lds_bytes(int D);  // LDS variant footprint; > 150 KB => use the GLOBAL variant
-hipError_t c3p_launch_grad(const GradArgs& A, bool global_scratch, hipStream_t st);
+hipError_t c3p_launch_grad_seg(const GradArgs& A, bool global_scratch, hipStream_t st);   // segment products
+hipError_t c3p_launch_grad_scan(const GradArgs& A, bool global_scratch, hipStream_t st);  // adjoint state at segment ends
+hipError_t c3p_launch_grad_bwd(const GradArgs& A, bool global_scratch, hipStream_t st);   // backward sweep, writes grad

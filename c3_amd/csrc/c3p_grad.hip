@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256) grad_seg_kernel(GradArgs A) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int wg = blockIdx.x;
   const int b = wg / A.S, seg = wg - b * A.S;
-  const int n0 = seg * A.seg_len, n1 = min(A.N, n0 + A.seg_len);
+  const int n0 = (int)(((long)seg * A.N) / A.S), n1 = (int)(((long)(seg + 1) * A.N) / A.S);
   const int D = A.D, ld = A.ld, msz = ld * D;
   GMem<GLOBAL> M;
   M.g = GLOBAL ? A.scratch + (long)wg * A.scratch_stride : nullptr;
@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(256) grad_bwd_kernel(GradArgs A) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int wg = blockIdx.x;
   const int b = wg / A.S, seg = wg - b * A.S;
-  const int n0 = seg * A.seg_len, n1 = min(A.N, n0 + A.seg_len);
+  const int n0 = (int)(((long)seg * A.N) / A.S), n1 = (int)(((long)(seg + 1) * A.N) / A.S);
   const int D = A.D, ld = A.ld, msz = ld * D;
   GMem<GLOBAL> M;
   M.g = GLOBAL ? A.scratch + (long)wg * A.scratch_stride : nullptr;
@@ -423,27 +423,29 @@ __global__ void __launch_bounds__(256) grad_bwd_kernel(GradArgs A) {
 int c3p_grad_threads(int D) { return D <= 10 ? 64 : (D <= 20 ? 128 : 256); }
 size_t c3p_grad_lds_bytes(int D) { return (size_t)C3P_GRAD_NMAT * (D | 1) * D * sizeof(cplx); }
 
-hipError_t c3p_launch_grad(const GradArgs& A, bool global_scratch, hipStream_t st) {
+namespace {
+template <typename KT>
+hipError_t launch_one(KT kern, unsigned grid, const GradArgs& A, bool global_scratch, hipStream_t st) {
   const int nt = c3p_grad_threads(A.D);
   const size_t lds = global_scratch ? 0 : c3p_grad_lds_bytes(A.D);
-  const dim3 chains((unsigned)(A.B * A.S)), samples((unsigned)A.B), blk(nt);
-  hipError_t e;
-  if (global_scratch) {
-    hipLaunchKernelGGL(grad_seg_kernel<true>, chains, blk, 0, st, A);
-    hipLaunchKernelGGL(grad_scan_kernel<true>, samples, blk, 0, st, A);
-    hipLaunchKernelGGL(grad_bwd_kernel<true>, chains, blk, 0, st, A);
-  } else {
-    if (lds > 48 * 1024) {
-      e = hipFuncSetAttribute((const void*)grad_seg_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      e = hipFuncSetAttribute((const void*)grad_scan_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      e = hipFuncSetAttribute((const void*)grad_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(grad_seg_kernel<false>, chains, blk, lds, st, A);
-    hipLaunchKernelGGL(grad_scan_kernel<false>, samples, blk, lds, st, A);
-    hipLaunchKernelGGL(grad_bwd_kernel<false>, chains, blk, lds, st, A);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
   }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), lds, st, A);
   return hipGetLastError();
+}
+}  // namespace
+
+hipError_t c3p_launch_grad_seg(const GradArgs& A, bool global_scratch, hipStream_t st) {
+  return global_scratch ? launch_one(grad_seg_kernel<true>, (unsigned)(A.B * A.S), A, true, st)
+                        : launch_one(grad_seg_kernel<false>, (unsigned)(A.B * A.S), A, false, st);
+}
+hipError_t c3p_launch_grad_scan(const GradArgs& A, bool global_scratch, hipStream_t st) {
+  return global_scratch ? launch_one(grad_scan_kernel<true>, (unsigned)A.B, A, true, st)
+                        : launch_one(grad_scan_kernel<false>, (unsigned)A.B, A, false, st);
+}
+hipError_t c3p_launch_grad_bwd(const GradArgs& A, bool global_scratch, hipStream_t st) {
+  return global_scratch ? launch_one(grad_bwd_kernel<true>, (unsigned)(A.B * A.S), A, true, st)
+                        : launch_one(grad_bwd_kernel<false>, (unsigned)(A.B * A.S), A, false, st);
 }

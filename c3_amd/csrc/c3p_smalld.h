@@ -25,6 +25,16 @@ struct SmallArgs {
   cplx* final_out;  // [B,Dm,Dm]
 };
 
+// Backward sweep of the control gradient (c3p_grad.hip for the method)
+struct SmallGradArgs {
+  const double* tables;  // as SmallArgs
+  int tab_per_sample;
+  const double* signals;  // [B,K,N]
+  const cplx* Mb;         // [B,S,Dm,Dm] adjoint state at the end of each segment
+  double* grad;           // [B,K,N]
+  int B, K, N, Dm, S, Lmax;
+};
+
 struct PrepArgs {
   const cplx* h0;
   long h0_bstride;
@@ -42,4 +52,5 @@ int c3p_smalld_mat_doubles(int Dm);
 size_t c3p_smalld_table_doubles(int Dm, int K);
 bool c3p_smalld_supported(int Dm);
 hipError_t c3p_launch_smalld_chain(const SmallArgs& A, hipStream_t st);
+hipError_t c3p_launch_smalld_grad(const SmallGradArgs& A, hipStream_t st);
 hipError_t c3p_launch_smalld_prep(const PrepArgs& P, int Dm, int nsamp, hipStream_t st);

@@ -661,6 +661,262 @@ hipError_t launch_chain_t(const SmallArgs& A, hipStream_t st) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward sweep of the control gradient (method in c3p_grad.hip) on the matrix cores.
+// Same mapping as the forward kernel (chain = MFMA block), but ONE wave per SIMD: the pair evaluation
+// of T18 keeps ~13 matrices live (X, X^2, X^3, X^6 and their derivatives, accumulators), which fits
+// the 512-register budget of a single-wave SIMD and not the 256 of two.  Two LDS images (value and
+// derivative left operands); per slice 18 + 3s products:
+//   (T, dT) = pair-T18(X~, M) ; Z = T^H dT ; grad[k] = <Z, G_k> ; M <- T^H (M T).
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void write_image_H(const double (&zh)[SD<D>::NBI][SD<D>::NJ], double* img, const LanePos& lp) {
+  using C = SD<D>;
+  wave_sync();
+#pragma unroll
+  for (int I = 0; I < C::NBI; ++I)
+#pragma unroll
+    for (int J = 0; J < C::NJ; ++J) {
+      // lane holds (r even ? Re : Im) Z[i][j], i = 2I + r/2, j = 4J + c; Y = Z^H: Yh[2j + p][i] = p ? -Im Z[i][j] : Re Z[i][j]
+      const int trow = 2 * (4 * J + lp.c) + (lp.r & 1), tcol = 2 * I + (lp.r >> 1);
+      const double v = (lp.r & 1) ? -zh[I][J] : zh[I][J];
+      if (trow < 4 * C::NBI) img[lp.b * C::MAT + trow * C::W + tcol] = v;
+    }
+  wave_sync();
+}
+
+template <int D>
+__device__ __forceinline__ void mat_zero(double (&m)[SD<D>::NBI][SD<D>::NJ]) {
+#pragma unroll
+  for (int I = 0; I < SD<D>::NBI; ++I)
+#pragma unroll
+    for (int J = 0; J < SD<D>::NJ; ++J) m[I][J] = 0.0;
+}
+
+template <int D>
+__global__ void __launch_bounds__(64, 1) smalld_grad_kernel(SmallGradArgs A) {
+  using C = SD<D>;
+  constexpr int NBI = C::NBI, NJ = C::NJ, W = C::W, MAT = C::MAT;
+  typedef double Mat[NBI][NJ];
+  const int lane = threadIdx.x;
+  LanePos lp;
+  lp.r = lane >> 4;
+  lp.b = (lane >> 2) & 3;
+  lp.c = lane & 3;
+  lp.idx16 = lp.r * 4 + lp.c;
+  const int K = A.K;
+  double* tab = c3p_sd_lds;
+  double* img0 = tab + (1 + K) * (MAT + 4);
+  double* img1 = img0 + 4 * MAT;
+  double* sg = img1 + 4 * MAT;
+
+  const long chain = (long)blockIdx.x * 4 + lp.b;
+  const long nchains = (long)A.B * A.S;
+  const bool valid = chain < nchains;
+  const long cc = valid ? chain : nchains - 1;
+  const int sample = (int)(cc / A.S);
+  const int seg = (int)(cc - (long)sample * A.S);
+  const int n0 = (int)(((long)seg * A.N) / A.S);
+  const int n1 = (int)(((long)(seg + 1) * A.N) / A.S);
+  const int len = n1 - n0;
+
+  const int woff = lp.b * MAT + lp.r * W + lp.c;
+  const int roff = lp.b * MAT + (2 * (lp.c >> 1) + ((lp.c ^ lp.r) & 1)) * W + (lp.r >> 1);
+  const unsigned negmask = (((lp.c & 1) == 0) && ((lp.r & 1) == 1)) ? 0x80000000u : 0u;
+  const int toff = lp.r * W + lp.c;
+  const int ddelta = (lp.r & 1) ? 1000 : ((lp.r >> 1) - lp.c);
+  const int rhalf = lp.r >> 1;
+
+  const double* gt0 = A.tables + (long)(A.tab_per_sample ? sample : 0) * (1 + K) * (MAT + 4);
+  for (int e = lane; e < (1 + K) * (MAT + 4); e += 64) tab[e] = gt0[e];
+  __syncthreads();
+  double nrm = tab[MAT + 2];
+  for (int k = 0; k < K; ++k) {
+    const double* s = A.signals + ((long)sample * K + k) * A.N + n0;
+    double cmax = 0.0;
+    for (int t = lp.idx16; t < A.Lmax; t += 16) {
+      const double v = (valid && t < len) ? s[t] : 0.0;
+      sg[(lp.b * K + k) * A.Lmax + t] = v;
+      cmax = fmax(cmax, fabs(v));
+    }
+    cmax = fmax(cmax, __shfl_xor(cmax, 1));
+    cmax = fmax(cmax, __shfl_xor(cmax, 2));
+    cmax = fmax(cmax, __shfl_xor(cmax, 16));
+    cmax = fmax(cmax, __shfl_xor(cmax, 32));
+    nrm = fma(cmax, tab[(k + 1) * (MAT + 4) + MAT + 2], nrm);
+  }
+  nrm = fmax(nrm, __shfl_xor(nrm, 4));
+  nrm = fmax(nrm, __shfl_xor(nrm, 8));
+  nrm = readfirstlane_f64(nrm);
+  int ps = 0;
+  {
+    double p = C3P_T18_THETA;
+    while (p < nrm && ps < 40) {
+      p *= 2.0;
+      ++ps;
+    }
+  }
+  ps = __builtin_amdgcn_readfirstlane(ps);
+  const double scale = ldexp(1.0, -ps);
+  __syncthreads();
+
+  // adjoint state at the end of this segment, D-layout
+  Mat M;
+  {
+    const double* src = reinterpret_cast<const double*>(A.Mb) + cc * D * D * 2;
+#pragma unroll
+    for (int I = 0; I < NBI; ++I)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) {
+        const int row = 2 * I + (lp.r >> 1), col = 4 * J + lp.c;
+        M[I][J] = (valid && row < D && col < D) ? src[(row * D + col) * 2 + (lp.r & 1)] : 0.0;
+      }
+  }
+
+  for (int t = A.Lmax - 1; t >= 0; --t) {
+    const bool act = valid && t < len;
+    const double sc = act ? scale : 0.0;
+    Mat X, dX;
+#pragma unroll
+    for (int I = 0; I < NBI; ++I)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) {
+        X[I][J] = sc * tab[toff + I * 4 * W + J * 4];
+        dX[I][J] = scale * M[I][J];
+      }
+    for (int k = 0; k < K; ++k) {
+      const double ck = sc * sg[(lp.b * K + k) * A.Lmax + t];
+      const double* tk = tab + (k + 1) * (MAT + 4);
+#pragma unroll
+      for (int I = 0; I < NBI; ++I)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) X[I][J] = fma(ck, tk[toff + I * 4 * W + J * 4], X[I][J]);
+    }
+    write_image<D>(X, img0, woff);
+    write_image<D>(dX, img1, woff);
+    Mat A2, dA2, A3, dA3, A6, dA6;
+    mat_zero<D>(A2), mat_zero<D>(dA2), mat_zero<D>(A3), mat_zero<D>(dA3), mat_zero<D>(A6), mat_zero<D>(dA6);
+    mm_img<D>(img0, roff, negmask, X, A2);
+    mm_img<D>(img0, roff, negmask, dX, dA2);
+    mm_img<D>(img1, roff, negmask, X, dA2);
+    mm_img<D>(img0, roff, negmask, A2, A3);
+    mm_img<D>(img0, roff, negmask, dA2, dA3);
+    mm_img<D>(img1, roff, negmask, A2, dA3);
+    write_image<D>(A3, img0, woff);
+    write_image<D>(dA3, img1, woff);
+    mm_img<D>(img0, roff, negmask, A3, A6);
+    mm_img<D>(img0, roff, negmask, dA3, dA6);
+    mm_img<D>(img1, roff, negmask, A3, dA6);
+    Mat A9, dA9;
+    {
+      Mat B1, dB1;
+      lincomb6<D>(B1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0, X, A2, A3, A6, ddelta, rhalf);
+      lincomb6<D>(dB1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0, dX, dA2, dA3, dA6, ddelta, rhalf);
+      write_image<D>(B1, img0, woff);
+      write_image<D>(dB1, img1, woff);
+    }
+    {
+      Mat B5, dB5;
+      lincomb6<D>(B5, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64, X, A2, A3, A6, ddelta, rhalf);
+      lincomb6<D>(dB5, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64, dX, dA2, dA3, dA6, ddelta, rhalf);
+      lincomb6<D>(A9, C3P_T18_B03, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63, X, A2, A3, A6, ddelta, rhalf);
+      lincomb6<D>(dA9, 0.0, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63, dX, dA2, dA3, dA6, ddelta, rhalf);
+      mm_img<D>(img0, roff, negmask, B5, A9);
+      mm_img<D>(img0, roff, negmask, dB5, dA9);
+      mm_img<D>(img1, roff, negmask, B5, dA9);
+    }
+    Mat T, dT;
+    {
+      Mat L, dL;
+      lincomb6<D>(L, C3P_T18_B02, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62, X, A2, A3, A6, ddelta, rhalf);
+      lincomb6<D>(dL, 0.0, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62, dX, dA2, dA3, dA6, ddelta, rhalf);
+#pragma unroll
+      for (int I = 0; I < NBI; ++I)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) {
+          L[I][J] += A9[I][J];
+          dL[I][J] += dA9[I][J];
+        }
+      write_image<D>(L, img0, woff);
+      write_image<D>(dL, img1, woff);
+    }
+    lincomb6<D>(T, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61, X, A2, A3, A6, ddelta, rhalf);
+    lincomb6<D>(dT, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61, dX, dA2, dA3, dA6, ddelta, rhalf);
+    mm_img<D>(img0, roff, negmask, A9, T);
+    mm_img<D>(img0, roff, negmask, dA9, dT);
+    mm_img<D>(img1, roff, negmask, A9, dT);
+    for (int it = 0; it < ps; ++it) {
+      write_image<D>(T, img0, woff);
+      write_image<D>(dT, img1, woff);
+      Mat T2, dT2;
+      mat_zero<D>(T2), mat_zero<D>(dT2);
+      mm_img<D>(img0, roff, negmask, T, T2);
+      mm_img<D>(img0, roff, negmask, dT, dT2);
+      mm_img<D>(img1, roff, negmask, T, dT2);
+#pragma unroll
+      for (int I = 0; I < NBI; ++I)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) {
+          T[I][J] = T2[I][J];
+          dT[I][J] = dT2[I][J];
+        }
+    }
+    // ---- Z = T^H dT, grad[k] = Re<Z, G_k> = sum Zh.G~h + Re(mu_k conj(tr Z)) ----
+    write_image_H<D>(T, img0, lp);
+    write_image<D>(M, img1, woff);
+    {
+      Mat Z;
+      mat_zero<D>(Z);
+      mm_img<D>(img0, roff, negmask, dT, Z);
+      double trr = 0.0, tri = 0.0;
+#pragma unroll
+      for (int I = 0; I < NBI; ++I)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J)
+          if (2 * I - 4 * J >= -1 && 2 * I - 4 * J <= 3) {
+            const bool on = (((lp.r >> 1) - lp.c) == 4 * J - 2 * I) && (2 * I + rhalf < D);
+            const double v = on ? Z[I][J] : 0.0;
+            if (lp.r & 1)
+              tri += v;
+            else
+              trr += v;
+          }
+      for (int k = 0; k < K; ++k) {
+        const double* tk = tab + (k + 1) * (MAT + 4);
+        double part = fma(tk[MAT + 0], trr, tk[MAT + 1] * tri);
+#pragma unroll
+        for (int I = 0; I < NBI; ++I)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) part = fma(Z[I][J], tk[toff + I * 4 * W + J * 4], part);
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (act && lp.idx16 == 0) A.grad[((long)sample * K + k) * A.N + n0 + t] = part;
+      }
+    }
+    // ---- M <- T^H (M T) ----
+    {
+      Mat V;
+      mat_zero<D>(V);
+      mm_img<D>(img1, roff, negmask, T, V);
+      mat_zero<D>(M);
+      mm_img<D>(img0, roff, negmask, V, M);
+    }
+  }
+}
+
+template <int D>
+hipError_t launch_grad_t(const SmallGradArgs& A, hipStream_t st) {
+  using C = SD<D>;
+  const long nchains = (long)A.B * A.S;
+  const unsigned grid = (unsigned)((nchains + 3) / 4);
+  const size_t lds = (size_t)((1 + A.K) * (C::MAT + 4) + 8 * C::MAT + 4 * A.K * A.Lmax) * sizeof(double);
+  if (lds > 60 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(smalld_grad_kernel<D>, dim3(grid), dim3(64), lds, st, A);
+  return hipGetLastError();
+}
+
 template <int D>
 hipError_t launch_prep_t(const PrepArgs& P, int nsamp, hipStream_t st) {
   hipLaunchKernelGGL(smalld_prep_kernel<D>, dim3((unsigned)(nsamp * (1 + P.K))), dim3(64), 0, st, P);
@@ -697,6 +953,11 @@ bool c3p_smalld_supported(int Dm) { return Dm >= 2 && Dm <= C3P_SMALLD_MAX; }
 hipError_t c3p_launch_smalld_chain(const SmallArgs& A, hipStream_t st) {
   const int Dm = A.Dm;
   SD_DISPATCH(launch_chain_t, A, st)
+}
+
+hipError_t c3p_launch_smalld_grad(const SmallGradArgs& A, hipStream_t st) {
+  const int Dm = A.Dm;
+  SD_DISPATCH(launch_grad_t, A, st)
 }
 
 hipError_t c3p_launch_smalld_prep(const PrepArgs& P, int Dm, int nsamp, hipStream_t st) {

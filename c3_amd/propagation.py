@@ -202,7 +202,7 @@ def propagate_batch(
     return {"U": U, "dUs": dUs}
 
 
-def propagate_batch_vjp(h0, hks, signals, dt: float, U_bar, *, fr_phase=None):
+def propagate_batch_vjp(h0, hks, signals, dt: float, U_bar, *, fr_phase=None, force_generic: bool = False):
     """Vector-Jacobian product of `propagate_batch` (unitary, branch A) w.r.t. the control samples.
 
     The reference tapes the goal function (optimizers/optimizer.py:206-216) and lets TensorFlow
@@ -235,7 +235,7 @@ def propagate_batch_vjp(h0, hks, signals, dt: float, U_bar, *, fr_phase=None):
         grad = np.empty((B, K, N), dtype=np.float64)
     _lib.check(
         _lib.load().c3p_pwc_unitary_vjp(
-            _ptr(h0), h0_bs, _ptr(hks), hk_bs, _ptr(signals), float(dt), B, K, N, D, call.flags, _ptr(fr_phase), _ptr(U_bar), _ptr(grad), call.stream
+            _ptr(h0), h0_bs, _ptr(hks), hk_bs, _ptr(signals), float(dt), B, K, N, D, call.flags | (_lib.FORCE_GENERIC if force_generic else 0), _ptr(fr_phase), _ptr(U_bar), _ptr(grad), call.stream
         )
     )
     return grad

@@ -47,13 +47,16 @@ def test_oracle_infid_cotangent():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("generic", [False, True])
 @pytest.mark.parametrize("cfg,B,N", [(1, 3, 40), (2, 5, 64), (2, 2, 333), (3, 2, 24), (5, 1, 12)])
-def test_vjp_vs_oracle(prop, cfg, B, N):
+def test_vjp_vs_oracle(prop, cfg, B, N, generic):
+    if generic and cfg > 2:
+        pytest.skip("D > 12 already runs the generic gradient kernels")
     w = make_workload(cfg, B=B, N=N)
     rng = np.random.default_rng(10 + cfg)
     D = w.D
     Ubar = rng.normal(size=(B, D, D)) + 1j * rng.normal(size=(B, D, D))
-    g = np.asarray(prop.propagate_batch_vjp(w.h0, w.hks, w.signals, w.dt, Ubar, fr_phase=w.fr_phase))
+    g = np.asarray(prop.propagate_batch_vjp(w.h0, w.hks, w.signals, w.dt, Ubar, fr_phase=w.fr_phase, force_generic=generic))
     for b in range(B):
         want = o.pwc_signal_gradient(w.h0, w.hks, w.signals[b], w.dt, Ubar[b], w.fr_phase[b])
         assert np.abs(g[b] - want).max() < 1e-10 * np.abs(want).max()
@@ -88,6 +91,25 @@ def test_vjp_device_resident_infid_gradient(prop):
         fd = (f(w.signals[b] + eps * dirn) - f(w.signals[b] - eps * dirn)) / (2 * eps)
         an = float((g[b] * dirn).sum())
         assert abs(fd - an) < 1e-5 * abs(an) + 1e-18
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [2, 4, 5, 7, 11, 12])
+def test_vjp_small_dims(prop, D):
+    """every small-D template instance of the MFMA backward kernel, per-sample Hamiltonians included"""
+    rng = np.random.default_rng(D)
+    B, K, N = 3, 2, 37
+    def herm():
+        a = rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))
+        return (a + a.conj().T) / 2
+    h0 = np.stack([herm() * 3e10 for _ in range(B)])
+    hks = np.stack([herm() for _ in range(K)])
+    sig = rng.normal(size=(B, K, N)) * 2e9
+    Ubar = rng.normal(size=(B, D, D)) + 1j * rng.normal(size=(B, D, D))
+    g = np.asarray(prop.propagate_batch_vjp(h0, hks, sig, 1e-11, Ubar))
+    for b in range(B):
+        want = o.pwc_signal_gradient(h0[b], hks, sig[b], 1e-11, Ubar[b])
+        assert np.abs(g[b] - want).max() < 1e-10 * np.abs(want).max()
 
 
 @pytest.mark.gpu
