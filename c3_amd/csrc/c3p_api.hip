@@ -1157,4 +1157,57 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
   return 0;
 }
 
+int c3p_synth_signals_vjp(const double* env_params, const int32_t* env_shapes, const double* carrier,
+                          double t_start, double t_end, double awg_res, double sim_res, int B, int K,
+                          int E, int flags, const double* grad_signals, double* grad_env, double* grad_carrier,
+                          void* stream) {
+  if (B < 0 || K <= 0 || E <= 0) return fail("bad sizes B=%d K=%d E=%d", B, K, E);
+  if (!(awg_res > 0.0) || !(sim_res > 0.0)) return fail("resolutions must be positive");
+  const double span = t_end > t_start ? t_end - t_start : t_start - t_end;
+  const int N = (int)(span * sim_res), Na = (int)(span * awg_res);
+  if (N <= 0 || Na <= 1) return fail("empty time grid: N=%d Na=%d", N, Na);
+  if (B == 0) return 0;
+  if (!env_params || !env_shapes || !carrier || !grad_signals || !grad_env || !grad_carrier)
+    return fail("NULL pointer argument");
+  hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lk(g_mu);
+  DeviceWs* w = ws_for_current_device();
+  if (!w) return fail("no HIP device");
+  Stage sg{w, st};
+  const void *d_env = env_params, *d_shape = env_shapes, *d_car = carrier, *d_gs = grad_signals;
+  void *d_ge = grad_env, *d_gc = grad_carrier;
+  if (flags & C3P_HOST_PTRS) {
+    for (int a = 0; a < K * E; ++a)
+      if (env_shapes[a] >= C3P_ENV_NSHAPES) return fail("env_shapes[%d]=%d is not a C3P_ENV_* id", a, env_shapes[a]);
+    if (sg.in(env_params, (size_t)B * K * E * C3P_ENV_NPAR * sizeof(double), &d_env)) return -1;
+    if (sg.in(env_shapes, (size_t)K * E * sizeof(int32_t), &d_shape)) return -1;
+    if (sg.in(carrier, (size_t)B * K * 2 * sizeof(double), &d_car)) return -1;
+    if (sg.in(grad_signals, (size_t)B * K * N * sizeof(double), &d_gs)) return -1;
+    if (sg.out(grad_env, (size_t)B * K * E * C3P_ENV_NPAR * sizeof(double), &d_ge)) return -1;
+    if (sg.out(grad_carrier, (size_t)B * K * 2 * sizeof(double), &d_gc)) return -1;
+  }
+  // scratch: iq | giq | gcar_part, each B*K*2*Na doubles
+  const size_t part = (size_t)B * K * 2 * Na;
+  void* v;
+  if (ws_get(w, SL_SCRATCH, 3 * part * sizeof(double), &v)) return -1;
+  SynthArgs A;
+  A.env = (const double*)d_env;
+  A.shape = (const int*)d_shape;
+  A.carrier = (const double*)d_car;
+  A.t_start = t_start;
+  A.t_end = t_end;
+  A.awg_res = awg_res;
+  A.sim_res = sim_res;
+  A.B = B;
+  A.K = K;
+  A.E = E;
+  A.Na = Na;
+  A.N = N;
+  A.iq = (double*)v;
+  A.signals = nullptr;
+  HIP_TRY(c3p_launch_synth_vjp(A, (const double*)d_gs, A.iq + part, A.iq + 2 * part, (double*)d_ge, (double*)d_gc, st));
+  if (flags & C3P_HOST_PTRS) return sg.finish();
+  return 0;
+}
+
 }  // extern "C"

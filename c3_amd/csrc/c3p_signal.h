@@ -15,3 +15,7 @@ struct SynthArgs {
 };
 
 hipError_t c3p_launch_synth(const SynthArgs& A, hipStream_t st);
+// d loss/d signals [B,K,N] -> d loss/d env_params [B,K,E,NPAR] (amp, xy_angle, freq_offset, delta slots) and
+// d loss/d carrier [B,K,2]; giq [B,K,2,Na] and gcar_part [B,K,Na,2] are scratch, A.iq is recomputed.
+hipError_t c3p_launch_synth_vjp(const SynthArgs& A, const double* gsig, double* giq, double* gcar_part, double* genv,
+                                double* gcar, hipStream_t st);

@@ -1,0 +1,83 @@
+"""Batched goal-with-gradient for pulse parameters -- the loop body of the reference's optimizers.
+
+Reference: `Optimizer.goal_run_with_grad` tapes the goal (optimizers/optimizer.py:206-216),
+`OptimalControl.goal_run` is `fid_func(compute_propagators())` (optimalcontrol.py:200-228) and
+`OptimalControlRobust.goal_run_with_grad` averages goal and gradient over noise instances in a
+serial Python loop (optimalcontrol_robust.py:49-70).  Here the B instances are one batch:
+
+  envelope rows --synthesize--> signals --propagate--> U --fidelity--> goal[b]
+  d goal/d rows <--synth vjp-- d/d signals <--adjoint sweep-- U_bar <--cotangent--
+
+everything resident in HBM.  The mapping between optimizer coordinates and physical parameter values
+(`Quantity` scaling, c3objs.py) stays with the caller: it is element-wise host arithmetic.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import fidelities, propagation, signals
+from ._lib import C3PropError
+
+_COTANGENTS = {"unitary_infid": fidelities.unitary_infid_cotangent, "average_infid": fidelities.average_infid_cotangent}
+
+
+def goal_run_with_grad(
+    h0,
+    hks,
+    env_params,
+    env_shapes,
+    carrier,
+    t_start: float,
+    t_end: float,
+    awg_res: float,
+    sim_res: float,
+    ideal,
+    index,
+    dims,
+    *,
+    fr_phase=None,
+    fid_func: str = "unitary_infid",
+    device="cuda:0",
+) -> Dict:
+    """goals [B] and their gradients w.r.t. every envelope row, carrier pair and frame-rotation phase.
+
+    Returns {"goal": [B], "grad_env": [B,K,E,NPAR], "grad_carrier": [B,K,2], "grad_fr_phase": [B,D] or None,
+    "U": [B,D,D]} as torch CUDA tensors.
+    """
+    import torch
+
+    if fid_func not in _COTANGENTS:
+        raise C3PropError(f"C3:Error: no cotangent for fidelity '{fid_func}' (have {sorted(_COTANGENTS)})")
+    ts = signals.create_ts(t_start, t_end, sim_res)
+    if ts.shape[0] < 2:
+        raise C3PropError("C3:Error: need at least two time slices")
+    dt = float(ts[1] - ts[0])  # propagation.py:310
+    as_dev = lambda x, dt_: x.to(device) if torch.is_tensor(x) else torch.as_tensor(np.asarray(x, dtype=dt_), device=device)
+    env = as_dev(env_params, np.float64)
+    car = as_dev(carrier, np.float64)
+    h0d, hkd = as_dev(h0, np.complex128), as_dev(hks, np.complex128)
+    ph = None if fr_phase is None else as_dev(fr_phase, np.float64)
+    sig = signals.synthesize_signals(env, env_shapes, car, t_start, t_end, awg_res, sim_res)
+    U = propagation.propagate_batch(h0d, hkd, sig, dt, fr_phase=ph)["U"]
+    U_bar, goal = _COTANGENTS[fid_func](ideal, U, index, dims)
+    g_sig = propagation.propagate_batch_vjp(h0d, hkd, sig, dt, U_bar, fr_phase=ph)
+    g_env, g_car = signals.synthesize_signals_vjp(env, env_shapes, car, t_start, t_end, awg_res, sim_res, g_sig)
+    g_ph = None
+    if ph is not None:
+        # U = diag(e^{i phi}) P  =>  d loss/d phi_i = Re sum_j conj(U_bar_ij) (i U_ij) = -Im sum_j conj(U_bar_ij) U_ij
+        g_ph = -(torch.conj(U_bar) * U).sum(dim=-1).imag
+    return {"goal": goal, "grad_env": g_env, "grad_carrier": g_car, "grad_fr_phase": g_ph, "U": U}
+
+
+def robust_goal_run_with_grad(*args, **kwargs) -> Dict:
+    """Mean goal and mean gradient over the batch of noise instances (optimalcontrol_robust.py:49-70),
+    plus the per-instance values and their standard deviation the reference logs (:64-69)."""
+    r = goal_run_with_grad(*args, **kwargs)
+    out = {"goal": r["goal"].mean(), "goals_individual": r["goal"], "goal_std": r["goal"].std(unbiased=False),
+           "grad_env": r["grad_env"].mean(dim=0), "grad_carrier": r["grad_carrier"].mean(dim=0),
+           "gradient_std": r["grad_env"].std(dim=0, unbiased=False)}
+    if r["grad_fr_phase"] is not None:
+        out["grad_fr_phase"] = r["grad_fr_phase"].mean(dim=0)
+    return out

@@ -123,6 +123,47 @@ def synthesize_signals(env_params, env_shapes, carrier, t_start: float, t_end: f
     return (sig, iq) if want_iq else sig
 
 
+def synthesize_signals_vjp(env_params, env_shapes, carrier, t_start: float, t_end: float, awg_res: float, sim_res: float, grad_signals):
+    """(grad_env [B,K,E,NPAR], grad_carrier [B,K,2]) from d loss / d signals [B,K,N].
+
+    Differentiates amp, xy_angle, freq_offset, delta (their ENV_SLOTS) and the carrier pair; the
+    reference gets the same numbers from the tape that also covers the propagation
+    (optimizers/optimizer.py:206-216, gates.py:341-370).  Chain with `propagate_batch_vjp`.
+    """
+    call = _Call(env_params, carrier, grad_signals)
+    env = call.f64(env_params)
+    if env.ndim != 4 or env.shape[-1] != ENV_NPAR:
+        raise C3PropError(f"C3:Error: env_params must be [B,K,E,{ENV_NPAR}], got {tuple(env.shape)}")
+    B, K, E = (int(x) for x in env.shape[:3])
+    shapes_np = np.ascontiguousarray(np.asarray(env_shapes.cpu() if _is_torch(env_shapes) else env_shapes, dtype=np.int32))
+    if shapes_np.shape != (K, E) or shapes_np.max(initial=-1) >= len(ENV_SHAPES):
+        raise C3PropError(f"C3:Error: env_shapes must be [{K},{E}] of known shape ids")
+    car = call.f64(carrier)
+    if tuple(car.shape) != (B, K, 2):
+        raise C3PropError(f"C3:Error: carrier must be [{B},{K},2], got {tuple(car.shape)}")
+    N, Na = slice_num(t_start, t_end, sim_res), slice_num(t_start, t_end, awg_res)
+    if N <= 0 or Na <= 1:
+        raise C3PropError(f"C3:Error: empty time grid (N={N}, AWG samples={Na})")
+    gs = call.f64(grad_signals)
+    if tuple(gs.shape) != (B, K, N):
+        raise C3PropError(f"C3:Error: grad_signals must be [{B},{K},{N}], got {tuple(gs.shape)}")
+    if call.device:
+        t = call.torch
+        shp = t.as_tensor(shapes_np, device=call.dev)
+        genv = t.empty((B, K, E, ENV_NPAR), dtype=t.float64, device=call.dev)
+        gcar = t.empty((B, K, 2), dtype=t.float64, device=call.dev)
+    else:
+        shp = shapes_np
+        genv = np.empty((B, K, E, ENV_NPAR), dtype=np.float64)
+        gcar = np.empty((B, K, 2), dtype=np.float64)
+    _lib.check(
+        _lib.load().c3p_synth_signals_vjp(
+            _ptr(env), _ptr(shp), _ptr(car), float(t_start), float(t_end), float(awg_res), float(sim_res), B, K, E, call.flags, _ptr(gs), _ptr(genv), _ptr(gcar), call.stream
+        )
+    )
+    return genv, gcar
+
+
 def create_ts(t_start: float, t_end: float, resolution: float) -> np.ndarray:
     """Centred sample times (devices.py:86-122)."""
     num = slice_num(t_start, t_end, resolution)

@@ -205,6 +205,18 @@ int c3p_synth_signals(const double* env_params, const int32_t* env_shapes, const
                       double t_start, double t_end, double awg_res, double sim_res, int B, int K,
                       int E, int flags, double* awg_iq_out, double* signals_out, void* stream);
 
+/* Vector-Jacobian product of c3p_synth_signals for the commonly optimised pulse parameters (the same
+ * GradientTape of optimizers/optimizer.py:206-216 covers Instruction.get_awg_signal gates.py:341-370):
+ *   grad_signals f64 [B,K,N]             d loss / d signals (e.g. from c3p_pwc_unitary_vjp)
+ *   grad_env     f64 [B,K,E,C3P_ENV_NPAR] d loss / d {amp, xy_angle, freq_offset, delta} in their slots,
+ *                                        0 in every other slot (times, sigma, flags are not differentiated)
+ *   grad_carrier f64 [B,K,2]             d loss / d {LO angular frequency, V_to_Hz}
+ */
+int c3p_synth_signals_vjp(const double* env_params, const int32_t* env_shapes, const double* carrier,
+                          double t_start, double t_end, double awg_res, double sim_res, int B, int K,
+                          int E, int flags, const double* grad_signals, double* grad_env, double* grad_carrier,
+                          void* stream);
+
 /* Fidelity epilogue: overlap[b] = tr(P^T U[b] P G^+), the number behind
  * unitary_infid = 1 - |overlap/L|^2 (c3/libraries/fidelities.py:154-184, tf_unitary_overlap
  * c3/utils/tf_utils.py:330-366) and average_infid = 1 - (|overlap|^2/L + 1)/(L + 1)

@@ -1216,3 +1216,39 @@ def unitary_infid_cotangent(ideal, U, index, dims):
     L = Pm.shape[1]
     s = np.trace(ideal.conj().T @ (Pm.T @ U @ Pm))
     return -(2.0 / L**2) * s * (Pm @ ideal @ Pm.T)
+
+
+def generate_signal_vjp(components: Sequence[Dict], lo_freq: float, v_to_hz: float, t_start: float, t_end: float, awg_res: float, sim_res: float, gsig: np.ndarray):
+    """Vector-Jacobian product of `generate_signal` for the commonly optimised pulse parameters
+    (opt_map entries of the reference's examples: amp, xy_angle, freq_offset, delta) and the carrier.
+    `gsig` = d loss / d values [N].  Returns (list of dicts per component, {"lo_freq", "v_to_hz"}).
+    The reference gets these from the same GradientTape that covers the propagation
+    (optimizers/optimizer.py:206-216; Instruction.get_awg_signal gates.py:341-370 is on the tape)."""
+    ts_awg = create_ts(t_start, t_end, awg_res)
+    ts = create_ts(t_start, t_end, sim_res)
+    N, Na = ts.shape[0], ts_awg.shape[0]
+    idx = np.minimum(np.floor((np.arange(N) + 0.5) * (Na / N)).astype(np.int64), Na - 1)
+    cs, sn = np.cos(lo_freq * ts), np.sin(lo_freq * ts)
+    inph, quad = awg_iq(components, ts_awg, t_start)
+    gI = np.zeros(Na)
+    gQ = np.zeros(Na)
+    np.add.at(gI, idx, gsig * cs * v_to_hz)
+    np.add.at(gQ, idx, gsig * sn * v_to_hz)
+    I, Q = inph[idx], quad[idx]
+    gcar = {"lo_freq": float(np.sum(gsig * v_to_hz * ts * (-sn * I + cs * Q))), "v_to_hz": float(np.sum(gsig * (cs * I + sn * Q)))}
+    out = []
+    for comp in components:
+        t0 = t_start + comp.get("delay", 0.0)
+        ts_off = ts_awg - t0
+        ph = np.exp(1j * (comp.get("xy_angle", 0.0) - comp.get("freq_offset", 0.0) * ts_off))
+        env = envelope_values(comp, ts_off, comp["t_final"] if "t_final" in comp else np.inf)
+        z = comp["amp"] * env * ph
+        g = {"amp": float(np.sum(gI * (env * ph).real + gQ * (env * ph).imag)), "xy_angle": float(np.sum(-gI * z.imag + gQ * z.real)),
+             "freq_offset": float(np.sum(ts_off * (gI * z.imag - gQ * z.real))), "delta": 0.0}
+        if comp.get("drag", False):
+            env0 = envelope_values(dict(comp, delta=0.0), ts_off, comp["t_final"])
+            env1 = envelope_values(dict(comp, delta=1.0), ts_off, comp["t_final"])
+            dz = comp["amp"] * (env1 - env0) * ph  # the envelope is affine in delta
+            g["delta"] = float(np.sum(gI * dz.real + gQ * dz.imag))
+        out.append(g)
+    return out, gcar

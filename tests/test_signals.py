@@ -169,6 +169,60 @@ def test_synthesis_vs_oracle(prop, device_resident):
     assert np.abs(sig - want).max() < 1e-12 * np.abs(want).max()
 
 
+def test_oracle_synthesis_vjp_matches_finite_differences():
+    rng = np.random.default_rng(1)
+    T = 12e-9
+    comps = [
+        dict(shape=o.ENV_GAUSSIAN_NONORM, amp=0.4, xy_angle=0.3, freq_offset=-50e6 * TWO_PI, delta=0.7, t_final=T, sigma=T / 4, use_t_before=True, drag=True),
+        dict(shape=o.ENV_FLATTOP, amp=0.2, xy_angle=-0.5, freq_offset=20e6 * TWO_PI, delta=-0.4, t_final=T * 0.9, t_up=1e-9, t_down=8e-9, risefall=1e-9, delay=0.5e-9, drag=True),
+    ]
+    lo, v = 5.05e9 * TWO_PI, 1e9 * TWO_PI
+    gs = rng.normal(size=int(T * 100e9))
+    gr, gc = o.generate_signal_vjp(comps, lo, v, 0.0, T, 2.4e9, 100e9, gs)
+    f = lambda cc, lo_=lo, v_=v: float(np.sum(gs * o.generate_signal(cc, lo_, v_, 0.0, T, 2.4e9, 100e9)["values"]))
+    for e in range(2):
+        for key, h in (("amp", 1e-6), ("xy_angle", 1e-6), ("freq_offset", 1e2), ("delta", 1e-6)):
+            cp, cm = [dict(c) for c in comps], [dict(c) for c in comps]
+            cp[e][key] += h
+            cm[e][key] -= h
+            fd = (f(cp) - f(cm)) / (2 * h)
+            assert abs(fd - gr[e][key]) < 1e-7 * abs(fd)
+    assert abs((f(comps, lo_=lo + 1e2) - f(comps, lo_=lo - 1e2)) / 2e2 - gc["lo_freq"]) < 1e-6 * abs(gc["lo_freq"])
+    assert abs((f(comps, v_=v * (1 + 1e-6)) - f(comps, v_=v * (1 - 1e-6))) / (2e-6 * v) - gc["v_to_hz"]) < 1e-7 * abs(gc["v_to_hz"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_resident", [False, True])
+def test_synthesis_vjp_vs_oracle(prop, device_resident):
+    rng = np.random.default_rng(78)
+    T, awg_res, sim_res = 12e-9, 2.4e9, 100e9
+    B = 4
+    channels_b, lo, v2hz = _random_problem(rng, B, T)
+    env, shapes = _pack_batch(channels_b)
+    carrier = np.stack([lo, v2hz], axis=-1)
+    N = sg.slice_num(0.0, T, sim_res)
+    gs = rng.normal(size=(B, 3, N))
+    if device_resident:
+        import torch
+
+        genv, gcar = sg.synthesize_signals_vjp(torch.as_tensor(env, device="cuda:0"), shapes, carrier, 0.0, T, awg_res, sim_res, torch.as_tensor(gs, device="cuda:0"))
+        genv, gcar = genv.cpu().numpy(), gcar.cpu().numpy()
+    else:
+        genv, gcar = sg.synthesize_signals_vjp(env, shapes, carrier, 0.0, T, awg_res, sim_res, gs)
+    for b in range(B):
+        for k in range(3):
+            oc = [dict(c, shape=sg.ENV_SHAPES[c["shape"]]) for c in channels_b[b][k]]
+            want, wcar = o.generate_signal_vjp(oc, lo[b][k], v2hz[b][k], 0.0, T, awg_res, sim_res, gs[b, k])
+            for e, wg in enumerate(want):
+                for key in ("amp", "xy_angle", "freq_offset", "delta"):
+                    scale = max(abs(wg[key]), 1e-12 * np.abs(gs).max() * v2hz[b][k])
+                    assert abs(genv[b, k, e, sg.ENV_SLOTS[key]] - wg[key]) < 1e-10 * max(scale, max(abs(x) for x in wg.values()) * (1e-9 if key == "freq_offset" else 1.0)), (b, k, e, key)
+            assert abs(gcar[b, k, 0] - wcar["lo_freq"]) < 1e-10 * abs(wcar["lo_freq"]) + 1e-20
+            assert abs(gcar[b, k, 1] - wcar["v_to_hz"]) < 1e-10 * abs(wcar["v_to_hz"]) + 1e-20
+    # untouched slots are zero
+    assert np.all(genv[..., 4:] == 0.0)
+
+
 @pytest.mark.gpu
 def test_synthesis_golden_two_qubit(prop, golden_dir):
     g = np.load(golden_dir + "/two_qubit.npz")
