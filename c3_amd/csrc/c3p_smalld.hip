@@ -153,6 +153,74 @@ __device__ __forceinline__ void lincomb6(double (&out)[SD<D>::NBI][SD<D>::NJ], d
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Real-Hamiltonian fast path.  When h0 and every hk are real (lab-frame transmon models in the dressed
+// basis are: model.py:453-534 dresses with the real eigenvectors of a real symmetric matrix),
+// X = -i Y with Y = dt (H - tr H / D) real symmetric and
+//     exp(X) = cos Y - i sin Y,   cos Y = sum_j (-1)^j W^j/(2j)!,  sin Y = Y sum_j (-1)^j W^j/(2j+1)!,  W = Y^2,
+// i.e. the even and odd parts of the SAME degree-18 Taylor polynomial the complex path evaluates (T18), so
+// the truncation / scaling rule (theta = 1.13) is unchanged.  Everything up to the chain product is REAL
+// D x D arithmetic: 8 real products (27 MFMAs each at D = 9) instead of 5 complex ones (75 each).
+// Real matrices live in registers as NB x NB tiles of 4x4 (lane (r,c) of the chain's block holds
+// M[4I+r][4J+c]); the left operand is read from a row-major LDS image (A layout: M[4I+c][4K+r]).
+// ---------------------------------------------------------------------------------------------
+template <int D>
+struct RD {
+  static constexpr int NB = (D + 3) / 4;
+};
+
+template <int D>
+__device__ __forceinline__ void write_rimage(const double (&m)[RD<D>::NB][RD<D>::NB], double* img, int woff) {
+  using C = SD<D>;
+  wave_sync();
+#pragma unroll
+  for (int I = 0; I < RD<D>::NB; ++I)
+#pragma unroll
+    for (int J = 0; J < RD<D>::NB; ++J) img[woff + I * 4 * C::W + J * 4] = m[I][J];
+  wave_sync();
+}
+
+// acc += IMG * B for real tiles
+template <int D>
+__device__ __forceinline__ void mm_real(const double* img, int rroff, const double (&zb)[RD<D>::NB][RD<D>::NB],
+                                        double (&acc)[RD<D>::NB][RD<D>::NB]) {
+  using C = SD<D>;
+  constexpr int NB = RD<D>::NB;
+  double ra[2][NB];
+#pragma unroll
+  for (int I = 0; I < NB; ++I) ra[0][I] = img[rroff + I * 4 * C::W];
+#pragma unroll
+  for (int K = 0; K < NB; ++K) {
+    if (K + 1 < NB) {
+#pragma unroll
+      for (int I = 0; I < NB; ++I) ra[(K + 1) & 1][I] = img[rroff + I * 4 * C::W + (K + 1) * 4];
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) acc[I][J] = mfma4(ra[K & 1][I], zb[K][J], acc[I][J]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// out = c0 I + c1 W + c2 W2 (+ c3 W3)
+template <int D, bool WITH3>
+__device__ __forceinline__ void rcomb(double (&out)[RD<D>::NB][RD<D>::NB], double c0, double c1, double c2, double c3,
+                                      const double (&W1)[RD<D>::NB][RD<D>::NB], const double (&W2)[RD<D>::NB][RD<D>::NB],
+                                      const double (&W3)[RD<D>::NB][RD<D>::NB], const LanePos& lp) {
+  constexpr int NB = RD<D>::NB;
+#pragma unroll
+  for (int I = 0; I < NB; ++I)
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+      double v = c1 * W1[I][J];
+      v = fma(c2, W2[I][J], v);
+      if constexpr (WITH3) v = fma(c3, W3[I][J], v);
+      if (I == J) v += (lp.r == lp.c && 4 * I + lp.r < D) ? c0 : 0.0;
+      out[I][J] = v;
+    }
+}
+
 // q = 4 plan: degree 4r, s squarings, from a bound on ||X||_1
 __device__ __forceinline__ void plan_q4(double nrm, int& r, int& s) {
   // Taylor backward-error bounds for unit roundoff 2^-52 (theta_m of Al-Mohy & Higham scaled by 2^(1/m))
@@ -321,6 +389,142 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
     const double scale = ldexp(1.0, -ps);
     __syncthreads();
 
+    // every table of this sample purely imaginary (real Hamiltonians) -> real fast path
+    bool realH = (A.mode == C3P_MODE_UNITARY);
+    for (int k = 0; k <= K; ++k) realH = realH && (tab[k * (MAT + 4) + MAT + 3] == 0.0);
+    realH = __builtin_amdgcn_readfirstlane((int)realH) != 0;
+    if (realH) {
+      constexpr int NB = RD<D>::NB;
+      typedef double RMat[NB][NB];
+      int ps18 = 0;
+      {
+        double p = C3P_T18_THETA;
+        while (p < nrm && ps18 < 40) {
+          p *= 2.0;
+          ++ps18;
+        }
+      }
+      ps18 = __builtin_amdgcn_readfirstlane(ps18);
+      const double rscale = ldexp(1.0, -ps18);
+      const int rroff = lp.b * MAT + lp.c * W + lp.r;  // A-layout read of a row-major real image
+      const int toffr = (2 * lp.r + 1) * W + lp.c;     // Im row of the half-image tables: -Y
+      for (int t = 0; t < A.Lmax; ++t) {
+        const bool act = valid && t < len;
+        const double sc = act ? rscale : 0.0;
+        const double muw = act ? 1.0 : 0.0;
+        double mu_r = muw * tab[MAT + 0], mu_i = muw * tab[MAT + 1];
+        // ---- Y = scale dt (H - tr H / D) = -Im(G0 + sum_k c_k G_k) ----
+        RMat Y;
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+          for (int J = 0; J < NB; ++J) Y[I][J] = (4 * I + lp.r < D) ? -sc * tab[toffr + I * 8 * W + J * 4] : 0.0;
+        for (int k = 0; k < K; ++k) {
+          const double c0 = sg[(lp.b * K + k) * A.Lmax + t];
+          const double ck = sc * c0;
+          const double* tk = tab + (k + 1) * (MAT + 4);
+          mu_r = fma(c0, tk[MAT + 0], mu_r);
+          mu_i = fma(c0, tk[MAT + 1], mu_i);
+#pragma unroll
+          for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int J = 0; J < NB; ++J)
+              Y[I][J] = (4 * I + lp.r < D) ? fma(-ck, tk[toffr + I * 8 * W + J * 4], Y[I][J]) : 0.0;
+        }
+        RMat W1, W2, W3, Cm, Sp, acc;
+        write_rimage<D>(Y, img, woff);
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+          for (int J = 0; J < NB; ++J) W1[I][J] = W2[I][J] = W3[I][J] = 0.0;
+        mm_real<D>(img, rroff, Y, W1);  // W = Y^2
+        write_rimage<D>(W1, img, woff);
+        mm_real<D>(img, rroff, W1, W2);  // W^2
+        mm_real<D>(img, rroff, W2, W3);  // W^3
+        write_rimage<D>(W3, img, woff);
+        // cos: c_j = (-1)^j / (2j)!, Horner in W^3
+        rcomb<D, true>(Cm, c3p_inv_fact[12], -c3p_inv_fact[14], c3p_inv_fact[16], -c3p_inv_fact[18], W1, W2, W3, lp);
+        rcomb<D, false>(acc, -c3p_inv_fact[6], c3p_inv_fact[8], -c3p_inv_fact[10], 0.0, W1, W2, W3, lp);
+        mm_real<D>(img, rroff, Cm, acc);
+        rcomb<D, false>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], 0.0, W1, W2, W3, lp);
+        mm_real<D>(img, rroff, acc, Cm);  // Cm = cos Y
+        // sin / Y: s_j = (-1)^j / (2j+1)!
+        rcomb<D, false>(Sp, c3p_inv_fact[13], -c3p_inv_fact[15], c3p_inv_fact[17], 0.0, W1, W2, W3, lp);
+        rcomb<D, false>(acc, -c3p_inv_fact[7], c3p_inv_fact[9], -c3p_inv_fact[11], 0.0, W1, W2, W3, lp);
+        mm_real<D>(img, rroff, Sp, acc);
+        rcomb<D, false>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], 0.0, W1, W2, W3, lp);
+        mm_real<D>(img, rroff, acc, Sp);  // Sp = sin(Y) / Y
+        write_rimage<D>(Y, img, woff);
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+          for (int J = 0; J < NB; ++J) acc[I][J] = 0.0;
+        mm_real<D>(img, rroff, Sp, acc);  // acc = sin Y
+        // ---- E = cos Y - i sin Y as the chain's left-operand image (half image: rows 2i / 2i+1 = Re / Im) ----
+        wave_sync();
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+          for (int J = 0; J < NB; ++J) {
+            const int i = 4 * I + lp.r, j = 4 * J + lp.c;
+            if (2 * i + 1 < 4 * NBI) {
+              img[lp.b * MAT + (2 * i) * W + j] = Cm[I][J];
+              img[lp.b * MAT + (2 * i + 1) * W + j] = -acc[I][J];
+            }
+          }
+        wave_sync();
+        const bool need_P = DUS || ps18 > 0 || t == 0;
+        double P[NBI][NJ];
+        if (need_P) {
+#pragma unroll
+          for (int I = 0; I < NBI; ++I)
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) P[I][J] = img[woff + I * 4 * W + J * 4];
+          for (int it = 0; it < ps18; ++it) {
+            if (it > 0) write_image<D>(P, img, woff);
+            double sq[NBI][NJ];
+#pragma unroll
+            for (int I = 0; I < NBI; ++I)
+#pragma unroll
+              for (int J = 0; J < NJ; ++J) sq[I][J] = 0.0;
+            mm_img<D>(img, roff, negmask, P, sq);
+#pragma unroll
+            for (int I = 0; I < NBI; ++I)
+#pragma unroll
+              for (int J = 0; J < NJ; ++J) P[I][J] = sq[I][J];
+          }
+          if (ps18 > 0 && t > 0) write_image<D>(P, img, woff);
+          if constexpr (DUS) {
+            double sn, cs;
+            sincos(mu_i, &sn, &cs);
+            const double er = exp(mu_r);
+            double* dst = reinterpret_cast<double*>(A.dUs_out) + ((long)sample * A.N + n0 + (act ? t : 0)) * D * D * 2;
+            store_plain<D>(P, dst, er * cs, er * sn, nullptr, lp, act);
+          }
+        }
+        if (t == 0) {
+#pragma unroll
+          for (int I = 0; I < NBI; ++I)
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) U[I][J] = P[I][J];
+          mus_r = mu_r;
+          mus_i = c3p_phase_add(0.0, mu_i);
+        } else {
+          double cacc[NBI][NJ];
+#pragma unroll
+          for (int I = 0; I < NBI; ++I)
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) cacc[I][J] = 0.0;
+          mm_img<D>(img, roff, negmask, U, cacc);
+#pragma unroll
+          for (int I = 0; I < NBI; ++I)
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) U[I][J] = cacc[I][J];
+          mus_r += mu_r;
+          mus_i = c3p_phase_add(mus_i, mu_i);
+        }
+      }
+    } else {
     for (int t = 0; t < A.Lmax; ++t) {
       const bool act = valid && t < len;
       // ---- X = scale (G0 + sum_k c_k G_k) in D-layout; trace shift mu ----
@@ -458,6 +662,7 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
         mus_i = c3p_phase_add(mus_i, mu_i);
       }
     }
+    }  // complex path
   }
   // ---- segment result ----
   if constexpr (!GIVEN) {
@@ -637,7 +842,10 @@ __global__ void __launch_bounds__(64) smalld_prep_kernel(PrepArgs P) {
     out[MAT + 0] = mu[0];
     out[MAT + 1] = mu[1];
     out[MAT + 2] = nrm;
-    out[MAT + 3] = 0.0;
+    // 0 exactly when the Hamiltonian is real (the generator is purely imaginary): selects the real fast path
+    double remax = 0;
+    for (int e = 0; e < D * D; ++e) remax = fmax(remax, fabs(g[2 * e]));
+    out[MAT + 3] = P.lindblad ? 1.0 : remax;
   }
 }
 
