@@ -113,6 +113,50 @@ def test_every_dimension_and_kernel(prop, D, force_generic):
     assert _lib.last_kernel() == expect
 
 
+@pytest.mark.parametrize("D", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("strength", [1.0, 6.0])
+def test_real_hamiltonian_fast_path(prop, D, strength):
+    """Real symmetric h0 / hk take the cos / sin path of the small-D kernel (every template instance, with and
+    without squarings, partial propagators, per-sample operators); one complex hk sends the same call back
+    to the complex path -- both must agree with the oracle."""
+    rng = np.random.default_rng(100 + D)
+    B, K, N = 4, 2, 29
+
+    def sym(n=None):
+        a = rng.normal(size=(D, D) if n is None else (n, D, D))
+        return a + np.swapaxes(a, -1, -2)
+
+    h0 = sym(B) * 2e10 * strength
+    hks = sym(K) + 0j
+    sig = rng.normal(size=(B, K, N)) * 1e9
+    dt = 1e-11 / max(1.0, D / 8)
+    ph = rng.uniform(0, 6, size=(B, D))
+    r = prop.propagate_batch(h0, hks, sig, dt, want_dUs=True, fr_phase=ph)
+    # The oracle restates TF's expm including its floor(log2) squaring count, which applies Pade-13 up to
+    # ||A||_1 = 2 theta_13 = 10.7 and is itself only ~1e-9 accurate there.  In the strong-drive case the
+    # per-slice truth is therefore scipy's expm (ceil rule), and the oracle is only required to be close.
+    import scipy.linalg as sla
+
+    for b in range(B):
+        Xs = -1j * dt * (h0[b][None] + np.einsum("kn,kij->nij", sig[b], hks))
+        if strength == 1.0:
+            dref = o.tf_propagation_vectorized(h0[b], hks, sig[b], dt)
+        else:
+            dref = np.stack([sla.expm(x) for x in Xs])
+            assert np.abs(o.tf_propagation_vectorized(h0[b], hks, sig[b], dt) - dref).max() < 1e-8
+        ref = np.exp(1j * ph[b])[:, None] * o.tf_matmul_left(dref)
+        assert np.linalg.norm(np.asarray(r["U"][b]) - ref) < 1e-10
+        assert np.abs(np.asarray(r["dUs"][b]) - dref).max() < 1e-12
+    hkc = hks.copy()
+    hkc[1, 0, 1] += 0.3j
+    hkc[1, 1, 0] -= 0.3j
+    r2 = prop.propagate_batch(h0[0], hkc, sig, dt)
+    for b in range(B):
+        Xs = -1j * dt * (h0[0][None] + np.einsum("kn,kij->nij", sig[b], hkc))
+        ref2 = o.tf_matmul_left(np.stack([sla.expm(x) for x in Xs]))
+        assert np.linalg.norm(np.asarray(r2["U"][b]) - ref2) < 1e-10
+
+
 @pytest.mark.parametrize("D", [41, 48, 49, 64, 77, 92])
 def test_big_dimension_classes(prop, D):
     """Every geometry class of the big-D MFMA kernel (41..92), a couple of samples and slices."""
