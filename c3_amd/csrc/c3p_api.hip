@@ -245,7 +245,7 @@ int pick_segments(int B, int N, int K, int Dm, bool need_mult4) {
   if (S > N) S = N;
   if (S < 1) S = 1;
   // the segment's control amplitudes live in LDS: 4 chains x K x Lmax doubles
-  const long lds_budget = 20 * 1024 - (long)(c3p_smalld_table_doubles(Dm, K) + 4 * c3p_smalld_mat_doubles(Dm)) * 8;
+  const long lds_budget = 20 * 1024 - (long)(c3p_smalld_table_doubles(Dm, K) + 4 * c3p_smalld_img_doubles(Dm)) * 8;
   const long lmax_cap = K > 0 ? lds_budget / (32L * K) : (1L << 30);
   while ((N + S - 1) / S > lmax_cap && S < N) ++S;
   // a multiple of four lets every wave fold its four segments in registers (fused combine)

@@ -49,6 +49,7 @@ struct PrepArgs {
 };
 
 int c3p_smalld_mat_doubles(int Dm);
+int c3p_smalld_img_doubles(int Dm);  // per-chain LDS image buffer of the forward kernel
 size_t c3p_smalld_table_doubles(int Dm, int K);
 bool c3p_smalld_supported(int Dm);
 hipError_t c3p_launch_smalld_chain(const SmallArgs& A, hipStream_t st);

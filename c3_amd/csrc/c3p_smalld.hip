@@ -36,6 +36,10 @@ struct SD {
   static constexpr int NJ = (D + 3) / 4;   // 4-column blocks
   static constexpr int W = 4 * NJ + 1;     // LDS row stride in doubles
   static constexpr int MAT = 4 * NBI * W;  // doubles per matrix image
+  // per-chain image buffer of the forward kernel: a complex half image (4 NBI rows) or two real images
+  // (the real fast path keeps Y at rows [4 NB, 8 NB) while W / W^3 occupy rows [0, 4 NB))
+  static constexpr int IROWS = (4 * NBI > 8 * NJ) ? 4 * NBI : 8 * NJ;
+  static constexpr int IMG = IROWS * W;
 };
 
 __device__ __forceinline__ double mfma4(double a, double b, double c) {
@@ -203,6 +207,33 @@ __device__ __forceinline__ void mm_real(const double* img, int rroff, const doub
   }
 }
 
+// two products with the same left operand: acc1 += IMG * B1, acc2 += IMG * B2
+template <int D>
+__device__ __forceinline__ void mm_real2(const double* img, int rroff, const double (&zb1)[RD<D>::NB][RD<D>::NB],
+                                         double (&acc1)[RD<D>::NB][RD<D>::NB], const double (&zb2)[RD<D>::NB][RD<D>::NB],
+                                         double (&acc2)[RD<D>::NB][RD<D>::NB]) {
+  using C = SD<D>;
+  constexpr int NB = RD<D>::NB;
+  double ra[2][NB];
+#pragma unroll
+  for (int I = 0; I < NB; ++I) ra[0][I] = img[rroff + I * 4 * C::W];
+#pragma unroll
+  for (int K = 0; K < NB; ++K) {
+    if (K + 1 < NB) {
+#pragma unroll
+      for (int I = 0; I < NB; ++I) ra[(K + 1) & 1][I] = img[rroff + I * 4 * C::W + (K + 1) * 4];
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) {
+        acc1[I][J] = mfma4(ra[K & 1][I], zb1[K][J], acc1[I][J]);
+        acc2[I][J] = mfma4(ra[K & 1][I], zb2[K][J], acc2[I][J]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // out = c0 I + c1 W + c2 W2 (+ c3 W3)
 template <int D, bool WITH3>
 __device__ __forceinline__ void rcomb(double (&out)[RD<D>::NB][RD<D>::NB], double c0, double c1, double c2, double c3,
@@ -286,7 +317,7 @@ __device__ __forceinline__ void store_plain(const double (&zh)[SD<D>::NBI][SD<D>
 template <int D, bool GIVEN, bool DUS>
 __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
   using C = SD<D>;
-  constexpr int NBI = C::NBI, NJ = C::NJ, W = C::W, MAT = C::MAT;
+  constexpr int NBI = C::NBI, NJ = C::NJ, W = C::W, MAT = C::MAT, IMG = C::IMG;
   const int lane = threadIdx.x;
   LanePos lp;
   lp.r = lane >> 4;
@@ -296,7 +327,7 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
   const int K = A.K;
   double* tab = c3p_sd_lds;  // (1+K) images + scalars (table modes only)
   double* img = tab + (GIVEN ? 0 : (1 + K) * (MAT + 4));  // 4 chain images
-  double* sg = img + 4 * MAT;  // 4 chains x K x Lmax signals
+  double* sg = img + 4 * IMG;  // 4 chains x K x Lmax signals
 
   const long chain = (long)blockIdx.x * 4 + lp.b;
   const long nchains = (long)A.B * A.S;
@@ -309,8 +340,8 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
   const int len = n1 - n0;
 
   // per-lane LDS offsets (doubles)
-  const int woff = lp.b * MAT + lp.r * W + lp.c;
-  const int roff = lp.b * MAT + (2 * (lp.c >> 1) + ((lp.c ^ lp.r) & 1)) * W + (lp.r >> 1);
+  const int woff = lp.b * IMG + lp.r * W + lp.c;
+  const int roff = lp.b * IMG + (2 * (lp.c >> 1) + ((lp.c ^ lp.r) & 1)) * W + (lp.r >> 1);
   const unsigned negmask = (((lp.c & 1) == 0) && ((lp.r & 1) == 1)) ? 0x80000000u : 0u;
   const int toff = lp.r * W + lp.c;  // table read offset (D-layout)
   const int ddelta = (lp.r & 1) ? 1000 : ((lp.r >> 1) - lp.c);
@@ -406,7 +437,7 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
       }
       ps18 = __builtin_amdgcn_readfirstlane(ps18);
       const double rscale = ldexp(1.0, -ps18);
-      const int rroff = lp.b * MAT + lp.c * W + lp.r;  // A-layout read of a row-major real image
+      const int rroff = lp.b * IMG + lp.c * W + lp.r;  // A-layout read of a row-major real image
       const int toffr = (2 * lp.r + 1) * W + lp.c;     // Im row of the half-image tables: -Y
       for (int t = 0; t < A.Lmax; ++t) {
         const bool act = valid && t < len;
@@ -431,35 +462,33 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
             for (int J = 0; J < NB; ++J)
               Y[I][J] = (4 * I + lp.r < D) ? fma(-ck, tk[toffr + I * 8 * W + J * 4], Y[I][J]) : 0.0;
         }
-        RMat W1, W2, W3, Cm, Sp, acc;
-        write_rimage<D>(Y, img, woff);
+        RMat W1, W2, W3, Cm, Sp, acc, acs;
+        constexpr int YOFF = 4 * NB * W;  // Y stays at rows [4 NB, 8 NB) until sin Y = Y (sin Y / Y) is formed
+        write_rimage<D>(Y, img, woff + YOFF);
 #pragma unroll
         for (int I = 0; I < NB; ++I)
 #pragma unroll
           for (int J = 0; J < NB; ++J) W1[I][J] = W2[I][J] = W3[I][J] = 0.0;
-        mm_real<D>(img, rroff, Y, W1);  // W = Y^2
+        mm_real<D>(img, rroff + YOFF, Y, W1);  // W = Y^2
         write_rimage<D>(W1, img, woff);
         mm_real<D>(img, rroff, W1, W2);  // W^2
         mm_real<D>(img, rroff, W2, W3);  // W^3
         write_rimage<D>(W3, img, woff);
-        // cos: c_j = (-1)^j / (2j)!, Horner in W^3
+        // cos: c_j = (-1)^j / (2j)!;  sin / Y: s_j = (-1)^j / (2j+1)!;  both by Horner in W^3, the two
+        // independent chains share every A-fragment read
         rcomb<D, true>(Cm, c3p_inv_fact[12], -c3p_inv_fact[14], c3p_inv_fact[16], -c3p_inv_fact[18], W1, W2, W3, lp);
-        rcomb<D, false>(acc, -c3p_inv_fact[6], c3p_inv_fact[8], -c3p_inv_fact[10], 0.0, W1, W2, W3, lp);
-        mm_real<D>(img, rroff, Cm, acc);
-        rcomb<D, false>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], 0.0, W1, W2, W3, lp);
-        mm_real<D>(img, rroff, acc, Cm);  // Cm = cos Y
-        // sin / Y: s_j = (-1)^j / (2j+1)!
         rcomb<D, false>(Sp, c3p_inv_fact[13], -c3p_inv_fact[15], c3p_inv_fact[17], 0.0, W1, W2, W3, lp);
-        rcomb<D, false>(acc, -c3p_inv_fact[7], c3p_inv_fact[9], -c3p_inv_fact[11], 0.0, W1, W2, W3, lp);
-        mm_real<D>(img, rroff, Sp, acc);
+        rcomb<D, false>(acc, -c3p_inv_fact[6], c3p_inv_fact[8], -c3p_inv_fact[10], 0.0, W1, W2, W3, lp);
+        rcomb<D, false>(acs, -c3p_inv_fact[7], c3p_inv_fact[9], -c3p_inv_fact[11], 0.0, W1, W2, W3, lp);
+        mm_real2<D>(img, rroff, Cm, acc, Sp, acs);
+        rcomb<D, false>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], 0.0, W1, W2, W3, lp);
         rcomb<D, false>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], 0.0, W1, W2, W3, lp);
-        mm_real<D>(img, rroff, acc, Sp);  // Sp = sin(Y) / Y
-        write_rimage<D>(Y, img, woff);
+        mm_real2<D>(img, rroff, acc, Cm, acs, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
 #pragma unroll
         for (int I = 0; I < NB; ++I)
 #pragma unroll
           for (int J = 0; J < NB; ++J) acc[I][J] = 0.0;
-        mm_real<D>(img, rroff, Sp, acc);  // acc = sin Y
+        mm_real<D>(img, rroff + YOFF, Sp, acc);  // acc = sin Y
         // ---- E = cos Y - i sin Y as the chain's left-operand image (half image: rows 2i / 2i+1 = Re / Im) ----
         wave_sync();
 #pragma unroll
@@ -468,8 +497,8 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
           for (int J = 0; J < NB; ++J) {
             const int i = 4 * I + lp.r, j = 4 * J + lp.c;
             if (2 * i + 1 < 4 * NBI) {
-              img[lp.b * MAT + (2 * i) * W + j] = Cm[I][J];
-              img[lp.b * MAT + (2 * i + 1) * W + j] = -acc[I][J];
+              img[lp.b * IMG + (2 * i) * W + j] = Cm[I][J];
+              img[lp.b * IMG + (2 * i + 1) * W + j] = -acc[I][J];
             }
           }
         wave_sync();
@@ -673,9 +702,9 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
       tr += __shfl_xor(tr, 8);
       ti = c3p_phase_add(ti, __shfl_xor(ti, 4));
       ti = c3p_phase_add(ti, __shfl_xor(ti, 8));
-      const int rrest = roff - lp.b * MAT;
-      const int roff1 = ((lp.b + 1) & 3) * MAT + rrest;  // A fragments of the NEXT chain's image
-      const int roff2 = ((lp.b + 2) & 3) * MAT + rrest;
+      const int rrest = roff - lp.b * IMG;
+      const int roff1 = ((lp.b + 1) & 3) * IMG + rrest;  // A fragments of the NEXT chain's image
+      const int roff2 = ((lp.b + 2) & 3) * IMG + rrest;
       double V[NBI][NJ], Wt[NBI][NJ];
 #pragma unroll
       for (int I = 0; I < NBI; ++I)
@@ -856,9 +885,9 @@ hipError_t launch_chain_t(const SmallArgs& A, hipStream_t st) {
   const unsigned grid = (unsigned)((nchains + 3) / 4);
   size_t lds = 0;
   if (A.mode == C3P_MODE_GIVEN)
-    lds = (size_t)(4 * C::MAT) * sizeof(double);
+    lds = (size_t)(4 * C::IMG) * sizeof(double);
   else
-    lds = (size_t)((1 + A.K) * (C::MAT + 4) + 4 * C::MAT + 4 * A.K * A.Lmax) * sizeof(double);
+    lds = (size_t)((1 + A.K) * (C::MAT + 4) + 4 * C::IMG + 4 * A.K * A.Lmax) * sizeof(double);
   if (lds > 60 * 1024) return hipErrorInvalidValue;
   if (A.mode == C3P_MODE_GIVEN)
     hipLaunchKernelGGL((smalld_chain_kernel<D, true, false>), dim3(grid), dim3(64), lds, st, A);
@@ -1136,6 +1165,12 @@ hipError_t launch_prep_t(const PrepArgs& P, int nsamp, hipStream_t st) {
 int c3p_smalld_mat_doubles(int Dm) {
   const int NBI = (Dm + 1) / 2, NJ = (Dm + 3) / 4;
   return 4 * NBI * (4 * NJ + 1);
+}
+
+int c3p_smalld_img_doubles(int Dm) {
+  const int NBI = (Dm + 1) / 2, NJ = (Dm + 3) / 4;
+  const int rows = (4 * NBI > 8 * NJ) ? 4 * NBI : 8 * NJ;
+  return rows * (4 * NJ + 1);
 }
 
 size_t c3p_smalld_table_doubles(int Dm, int K) { return (size_t)(1 + K) * (c3p_smalld_mat_doubles(Dm) + 4); }
