@@ -38,8 +38,13 @@ struct SD {
   static constexpr int MAT = 4 * NBI * W;  // doubles per matrix image
   // per-chain image buffer of the forward kernel: a complex half image (4 NBI rows) or two real images
   // (the real fast path keeps Y at rows [4 NB, 8 NB) while W / W^3 occupy rows [0, 4 NB))
-  static constexpr int IROWS = (4 * NBI > 8 * NJ) ? 4 * NBI : 8 * NJ;
-  static constexpr int IMG = IROWS * W;
+  // Real images use row stride WR = 12; with IMG = 12 (mod 32) doubles every LDS pattern of the kernel is
+  // bank-conflict free under the gfx950 rules (ds_read_b64: 32-lane groups on 64 dword banks; ds_write_b64:
+  // 16-lane groups on 32): real A-fragment reads b IMG + c WR + r, image writes b IMG + r W + c, complex
+  // A-fragment reads b IMG + rho W.
+  static constexpr int WR = 12;
+  static constexpr int NEED = (MAT > 8 * NJ * WR) ? MAT : 8 * NJ * WR;
+  static constexpr int IMG = ((NEED - 12 + 31) / 32) * 32 + 12;
 };
 
 __device__ __forceinline__ double mfma4(double a, double b, double c) {
@@ -52,6 +57,13 @@ __device__ __forceinline__ double readfirstlane_f64(double v) {
   hi = __builtin_amdgcn_readfirstlane(hi);
   return __hiloint2double(hi, lo);
 }
+
+// LDS read that the backend may not pair into ds_read2_b64: a wave64 ds_read_b64 costs 2 LDS cycles
+// (256 B/clk), a ds_read2_b64 8 for two (128 B/clk), and the image strides are laid out for the bank
+// rule of the single form (32-lane groups, 64 dword banks).  With eight waves per CU the LDS pipe, not
+// the matrix cores, was the busiest unit of the real fast path before this.
+typedef __attribute__((address_space(3))) const volatile double c3p_lds_cvd;
+__device__ __forceinline__ double lds_ld(const double* p) { return *(c3p_lds_cvd*)p; }
 
 __device__ __forceinline__ double flip_sign(double v, unsigned mask_hi) {
   unsigned long long u = __double_as_longlong(v);
@@ -89,12 +101,12 @@ __device__ __forceinline__ void mm_img(const double* img, int roff, unsigned neg
   // software pipelined: the A fragments of step K+1 are in flight while step K's MFMAs issue
   double ra[2][C::NBI];
 #pragma unroll
-  for (int I = 0; I < C::NBI; ++I) ra[0][I] = flip_sign(img[roff + I * 4 * C::W], negmask);
+  for (int I = 0; I < C::NBI; ++I) ra[0][I] = flip_sign(lds_ld(img + roff + I * 4 * C::W), negmask);
 #pragma unroll
   for (int K = 0; K < C::NBI; ++K) {
     if (K + 1 < C::NBI) {
 #pragma unroll
-      for (int I = 0; I < C::NBI; ++I) ra[(K + 1) & 1][I] = flip_sign(img[roff + I * 4 * C::W + (K + 1) * 2], negmask);
+      for (int I = 0; I < C::NBI; ++I) ra[(K + 1) & 1][I] = flip_sign(lds_ld(img + roff + I * 4 * C::W + (K + 1) * 2), negmask);
     }
 #pragma unroll
     for (int I = 0; I < C::NBI; ++I)
@@ -180,7 +192,7 @@ __device__ __forceinline__ void write_rimage(const double (&m)[RD<D>::NB][RD<D>:
 #pragma unroll
   for (int I = 0; I < RD<D>::NB; ++I)
 #pragma unroll
-    for (int J = 0; J < RD<D>::NB; ++J) img[woff + I * 4 * C::W + J * 4] = m[I][J];
+    for (int J = 0; J < RD<D>::NB; ++J) img[woff + I * 4 * C::WR + J * 4] = m[I][J];
   wave_sync();
 }
 
@@ -192,12 +204,12 @@ __device__ __forceinline__ void mm_real(const double* img, int rroff, const doub
   constexpr int NB = RD<D>::NB;
   double ra[2][NB];
 #pragma unroll
-  for (int I = 0; I < NB; ++I) ra[0][I] = img[rroff + I * 4 * C::W];
+  for (int I = 0; I < NB; ++I) ra[0][I] = lds_ld(img + rroff + I * 4 * C::WR);
 #pragma unroll
   for (int K = 0; K < NB; ++K) {
     if (K + 1 < NB) {
 #pragma unroll
-      for (int I = 0; I < NB; ++I) ra[(K + 1) & 1][I] = img[rroff + I * 4 * C::W + (K + 1) * 4];
+      for (int I = 0; I < NB; ++I) ra[(K + 1) & 1][I] = lds_ld(img + rroff + I * 4 * C::WR + (K + 1) * 4);
     }
 #pragma unroll
     for (int I = 0; I < NB; ++I)
@@ -216,12 +228,12 @@ __device__ __forceinline__ void mm_real2(const double* img, int rroff, const dou
   constexpr int NB = RD<D>::NB;
   double ra[2][NB];
 #pragma unroll
-  for (int I = 0; I < NB; ++I) ra[0][I] = img[rroff + I * 4 * C::W];
+  for (int I = 0; I < NB; ++I) ra[0][I] = lds_ld(img + rroff + I * 4 * C::WR);
 #pragma unroll
   for (int K = 0; K < NB; ++K) {
     if (K + 1 < NB) {
 #pragma unroll
-      for (int I = 0; I < NB; ++I) ra[(K + 1) & 1][I] = img[rroff + I * 4 * C::W + (K + 1) * 4];
+      for (int I = 0; I < NB; ++I) ra[(K + 1) & 1][I] = lds_ld(img + rroff + I * 4 * C::WR + (K + 1) * 4);
     }
 #pragma unroll
     for (int I = 0; I < NB; ++I)
@@ -327,7 +339,8 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
   const int K = A.K;
   double* tab = c3p_sd_lds;  // (1+K) images + scalars (table modes only)
   double* img = tab + (GIVEN ? 0 : (1 + K) * (MAT + 4));  // 4 chain images
-  double* sg = img + 4 * IMG;  // 4 chains x K x Lmax signals
+  double* sg = img + 4 * IMG;  // 4 chains x K x Lmax signals, odd chain stride (bank spread)
+  const int SG = (K * A.Lmax) | 1;
 
   const long chain = (long)blockIdx.x * 4 + lp.b;
   const long nchains = (long)A.B * A.S;
@@ -401,7 +414,7 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
       double cmax = 0.0;
       for (int t = lp.idx16; t < A.Lmax; t += 16) {
         const double v = (valid && t < len) ? s[t] : 0.0;
-        sg[(lp.b * K + k) * A.Lmax + t] = v;
+        sg[lp.b * SG + k * A.Lmax + t] = v;
         cmax = fmax(cmax, fabs(v));
       }
       cmax = fmax(cmax, __shfl_xor(cmax, 1));
@@ -437,43 +450,56 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
       }
       ps18 = __builtin_amdgcn_readfirstlane(ps18);
       const double rscale = ldexp(1.0, -ps18);
-      const int rroff = lp.b * IMG + lp.c * W + lp.r;  // A-layout read of a row-major real image
-      const int toffr = (2 * lp.r + 1) * W + lp.c;     // Im row of the half-image tables: -Y
+      constexpr int WR = C::WR;
+      const int rroff = lp.b * IMG + lp.c * WR + lp.r;  // A-layout read of a row-major real image
+      const int rwoff = lp.b * IMG + lp.r * WR + lp.c;  // D-layout write of a real image
+      int yo[NB];        // Im rows of the half-image tables hold -Y
+      double ymask[NB];
+#pragma unroll
+      for (int I = 0; I < NB; ++I) {
+        const bool ok = 4 * I + lp.r < D;
+        yo[I] = (2 * (ok ? 4 * I + lp.r : 0) + 1) * W + lp.c;
+        ymask[I] = ok ? 1.0 : 0.0;
+      }
       for (int t = 0; t < A.Lmax; ++t) {
         const bool act = valid && t < len;
         const double sc = act ? rscale : 0.0;
         const double muw = act ? 1.0 : 0.0;
         double mu_r = muw * tab[MAT + 0], mu_i = muw * tab[MAT + 1];
         // ---- Y = scale dt (H - tr H / D) = -Im(G0 + sum_k c_k G_k) ----
+        // (rows past the table are clamped to a valid row and masked: no exec-mask branches around LDS loads)
         RMat Y;
 #pragma unroll
-        for (int I = 0; I < NB; ++I)
+        for (int I = 0; I < NB; ++I) {
+          const double f = -sc * ymask[I];
 #pragma unroll
-          for (int J = 0; J < NB; ++J) Y[I][J] = (4 * I + lp.r < D) ? -sc * tab[toffr + I * 8 * W + J * 4] : 0.0;
+          for (int J = 0; J < NB; ++J) Y[I][J] = f * lds_ld(tab + yo[I] + J * 4);
+        }
         for (int k = 0; k < K; ++k) {
-          const double c0 = sg[(lp.b * K + k) * A.Lmax + t];
+          const double c0 = sg[lp.b * SG + k * A.Lmax + t];
           const double ck = sc * c0;
           const double* tk = tab + (k + 1) * (MAT + 4);
           mu_r = fma(c0, tk[MAT + 0], mu_r);
           mu_i = fma(c0, tk[MAT + 1], mu_i);
 #pragma unroll
-          for (int I = 0; I < NB; ++I)
+          for (int I = 0; I < NB; ++I) {
+            const double f = -ck * ymask[I];
 #pragma unroll
-            for (int J = 0; J < NB; ++J)
-              Y[I][J] = (4 * I + lp.r < D) ? fma(-ck, tk[toffr + I * 8 * W + J * 4], Y[I][J]) : 0.0;
+            for (int J = 0; J < NB; ++J) Y[I][J] = fma(f, lds_ld(tk + yo[I] + J * 4), Y[I][J]);
+          }
         }
         RMat W1, W2, W3, Cm, Sp, acc, acs;
-        constexpr int YOFF = 4 * NB * W;  // Y stays at rows [4 NB, 8 NB) until sin Y = Y (sin Y / Y) is formed
-        write_rimage<D>(Y, img, woff + YOFF);
+        constexpr int YOFF = 4 * NB * WR;  // Y stays at rows [4 NB, 8 NB) until sin Y = Y (sin Y / Y) is formed
+        write_rimage<D>(Y, img, rwoff + YOFF);
 #pragma unroll
         for (int I = 0; I < NB; ++I)
 #pragma unroll
           for (int J = 0; J < NB; ++J) W1[I][J] = W2[I][J] = W3[I][J] = 0.0;
         mm_real<D>(img, rroff + YOFF, Y, W1);  // W = Y^2
-        write_rimage<D>(W1, img, woff);
+        write_rimage<D>(W1, img, rwoff);
         mm_real<D>(img, rroff, W1, W2);  // W^2
         mm_real<D>(img, rroff, W2, W3);  // W^3
-        write_rimage<D>(W3, img, woff);
+        write_rimage<D>(W3, img, rwoff);
         // cos: c_j = (-1)^j / (2j)!;  sin / Y: s_j = (-1)^j / (2j+1)!;  both by Horner in W^3, the two
         // independent chains share every A-fragment read
         rcomb<D, true>(Cm, c3p_inv_fact[12], -c3p_inv_fact[14], c3p_inv_fact[16], -c3p_inv_fact[18], W1, W2, W3, lp);
@@ -567,7 +593,7 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
 #pragma unroll
         for (int J = 0; J < NJ; ++J) X[I][J] = sc * tab[toff + I * 4 * W + J * 4];
       for (int k = 0; k < K; ++k) {
-        const double c0 = sg[(lp.b * K + k) * A.Lmax + t];
+        const double c0 = sg[lp.b * SG + k * A.Lmax + t];
         const double ck = sc * c0;
         const double* tk = tab + (k + 1) * (MAT + 4);
         mu_r = fma(c0, tk[MAT + 0], mu_r);  // c0 = 0 for inactive slices (sg is zero padded)
@@ -887,7 +913,7 @@ hipError_t launch_chain_t(const SmallArgs& A, hipStream_t st) {
   if (A.mode == C3P_MODE_GIVEN)
     lds = (size_t)(4 * C::IMG) * sizeof(double);
   else
-    lds = (size_t)((1 + A.K) * (C::MAT + 4) + 4 * C::IMG + 4 * A.K * A.Lmax) * sizeof(double);
+    lds = (size_t)((1 + A.K) * (C::MAT + 4) + 4 * C::IMG + 4 * ((A.K * A.Lmax) | 1)) * sizeof(double);
   if (lds > 60 * 1024) return hipErrorInvalidValue;
   if (A.mode == C3P_MODE_GIVEN)
     hipLaunchKernelGGL((smalld_chain_kernel<D, true, false>), dim3(grid), dim3(64), lds, st, A);
@@ -1169,8 +1195,9 @@ int c3p_smalld_mat_doubles(int Dm) {
 
 int c3p_smalld_img_doubles(int Dm) {
   const int NBI = (Dm + 1) / 2, NJ = (Dm + 3) / 4;
-  const int rows = (4 * NBI > 8 * NJ) ? 4 * NBI : 8 * NJ;
-  return rows * (4 * NJ + 1);
+  const int mat = 4 * NBI * (4 * NJ + 1), two_real = 8 * NJ * 12;
+  const int need = mat > two_real ? mat : two_real;
+  return ((need - 12 + 31) / 32) * 32 + 12;
 }
 
 size_t c3p_smalld_table_doubles(int Dm, int K) { return (size_t)(1 + K) * (c3p_smalld_mat_doubles(Dm) + 4); }
