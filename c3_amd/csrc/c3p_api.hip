@@ -317,6 +317,106 @@ int run_pwc_smalld(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const 
   return 0;
 }
 
+int combine_midd(DeviceWs* w, const cplx* cur, int B, int count, int Dm, int right_order, const double* fr_phase,
+                 cplx* U_out, hipStream_t st);
+
+// Supplied generators on the mid-D MFMA kernel (13 <= D <= 40); see run_xg_smalld.
+int run_xg_midd(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, double coef_i, int B, int N, int D,
+                const double* fr_phase, cplx* U_out, cplx* dUs_out, hipStream_t st) {
+  int nig, nj, wd;
+  if (!c3p_midd_geometry(D, &nig, &nj, &wd)) return 1;
+  const size_t lds0 = c3p_midd_lds_bytes(D, 0, 0);
+  int wg_per_cu = (int)((156 * 1024) / (lds0 + 4096));
+  if (wg_per_cu > 3) wg_per_cu = 3;
+  if (wg_per_cu < 1) wg_per_cu = 1;
+  const long target = 256L * wg_per_cu * 2;
+  long S = (target + B - 1) / B;
+  const long smax = N / 8 > 1 ? N / 8 : 1;
+  if (S > smax) S = smax;
+  if (S < 1) S = 1;
+  void* mv;
+  if (ws_get(w, SL_TABLES, (size_t)B * N * 4 * sizeof(double), &mv)) return -1;
+  HIP_TRY(c3p_launch_hmeta(hs, hs_bstride, (long)B * N, N, D, coef_r, coef_i, (double*)mv, st));
+  MidArgs a = {};
+  a.hs = hs;
+  a.hs_bstride = hs_bstride;
+  a.meta = (const double*)mv;
+  a.coef_r = coef_r;
+  a.coef_i = coef_i;
+  a.B = B;
+  a.K = 0;
+  a.N = N;
+  a.Dm = D;
+  a.S = (int)S;
+  a.Lmax = (int)((N + S - 1) / S);
+  a.mode = C3P_MODE_EXPM;
+  a.dUs_out = dUs_out;
+  a.no_t18 = getenv("C3P_NO_T18") ? 1 : 0;
+  if (S == 1) {
+    a.seg_out = U_out;
+    a.fr_phase = fr_phase;
+  } else {
+    void* sv;
+    if (ws_get(w, SL_SEG_A, (size_t)B * S * D * D * sizeof(cplx), &sv)) return -1;
+    a.seg_out = (cplx*)sv;
+  }
+  g_last_kernel = C3P_KERNEL_MFMA;
+  if (record_start(w, st)) return -1;
+  HIP_TRY(c3p_launch_midd_chain(a, st));
+  if (record_stop(w, st)) return -1;
+  if (S > 1) return combine_midd(w, a.seg_out, B, (int)S, D, 0, fr_phase, U_out, st);
+  return 0;
+}
+
+// Supplied generators (branch B of pwc: per-slice Hamiltonians, and c3p_expm) on the small-D MFMA kernel:
+// X_n = coef * hs[b,n]; the hmeta pre-pass supplies the trace shift and the norm of every matrix.
+int run_xg_smalld(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, double coef_i, int B, int N, int D,
+                  const double* fr_phase, cplx* U_out, cplx* dUs_out, hipStream_t st) {
+  const int S = pick_segments(B, N, 0, D, false);
+  if (S < 0) return 1;
+  void* mv;
+  if (ws_get(w, SL_TABLES, (size_t)B * N * 4 * sizeof(double), &mv)) return -1;
+  HIP_TRY(c3p_launch_hmeta(hs, hs_bstride, (long)B * N, N, D, coef_r, coef_i, (double*)mv, st));
+  SmallArgs a = {};
+  a.hs = hs;
+  a.hs_bstride = hs_bstride;
+  a.meta = (const double*)mv;
+  a.coef_r = coef_r;
+  a.coef_i = coef_i;
+  a.B = B;
+  a.K = 0;
+  a.N = N;
+  a.Dm = D;
+  a.S = S;
+  a.Lmax = (N + S - 1) / S;
+  a.mode = C3P_MODE_EXPM;
+  a.dUs_out = dUs_out;
+  const bool fuse = (S > 1) && (S % 4 == 0) && !getenv("C3P_NO_FUSE");
+  if (S == 1) {
+    a.seg_out = U_out;
+    a.fr_phase = fr_phase;
+  } else {
+    void* sv;
+    if (ws_get(w, SL_SEG_A, (size_t)B * S * D * D * sizeof(cplx), &sv)) return -1;
+    a.seg_out = (cplx*)sv;
+    if (fuse) {
+      void* cv;
+      if (ws_get(w, SL_COUNTERS, (size_t)B * sizeof(int), &cv)) return -1;
+      HIP_TRY(hipMemsetAsync(cv, 0, (size_t)B * sizeof(int), st));
+      a.fuse = 1;
+      a.counters = (int*)cv;
+      a.final_out = U_out;
+      a.fr_phase = fr_phase;
+    }
+  }
+  g_last_kernel = C3P_KERNEL_SMALLD;
+  if (record_start(w, st)) return -1;
+  HIP_TRY(c3p_launch_smalld_chain(a, st));
+  if (record_stop(w, st)) return -1;
+  if (S > 1 && !fuse) return combine_smalld(w, a.seg_out, B, S, D, 0, fr_phase, U_out, st);
+  return 0;
+}
+
 // Gradient on the small-D MFMA kernels: forward segment products (unfused smalld chain kernel), the
 // per-sample scan of c3p_grad.hip, then the pair-T18 backward sweep.  Returns 1 when not applicable.
 int run_vjp_smalld(DeviceWs* w, GradArgs& G, hipStream_t st) {
@@ -655,7 +755,18 @@ int pwc_common(int lindblad, const void* h0, int64_t h0_bstride, const void* hks
     a.clp = (const cplx*)v;
   }
   bool done = false;
-  if (!(flags & C3P_FORCE_GENERIC) && !per_slice && Dm <= kSmallDLimit && c3p_smalld_supported(Dm) && K <= 8) {
+  if (!(flags & C3P_FORCE_GENERIC) && per_slice && !lindblad && K == 0 && D <= kSmallDLimit && c3p_smalld_supported(D)) {
+    // branch B (propagation.py:295-308): X_n = -i dt H_n
+    const int rc = run_xg_smalld(w, a.h0, a.h0_bstride, 0.0, -dt, B, N, D, a.fr_phase, (cplx*)d_U, a.dUs_out, st);
+    if (rc < 0) return -1;
+    done = (rc == 0);
+  }
+  if (!done && !(flags & C3P_FORCE_GENERIC) && per_slice && !lindblad && K == 0 && D >= 13 && D <= 40) {
+    const int rc = run_xg_midd(w, a.h0, a.h0_bstride, 0.0, -dt, B, N, D, a.fr_phase, (cplx*)d_U, a.dUs_out, st);
+    if (rc < 0) return -1;
+    done = (rc == 0);
+  }
+  if (!done && !(flags & C3P_FORCE_GENERIC) && !per_slice && Dm <= kSmallDLimit && c3p_smalld_supported(Dm) && K <= 8) {
     const int rc = run_pwc_smalld(w, lindblad, a.h0, a.h0_bstride, a.hks, a.hks_bstride, a.signals, a.clp, dt,
                                   B, K, N, D, Dm, a.fr_phase, (cplx*)d_U, a.dUs_out, st);
     if (rc < 0) return -1;
@@ -769,6 +880,17 @@ int c3p_expm(const void* A, int n, int D, int flags, void* out, void* stream) {
     if (sg.in(A, bytes, &d_A)) return -1;
     if (sg.out(out, bytes, &d_out)) return -1;
   }
+  bool done = false;
+  if (!(flags & C3P_FORCE_GENERIC) && D <= kSmallDLimit && c3p_smalld_supported(D)) {
+    const int rc = run_xg_smalld(w, (const cplx*)d_A, (long)D * D, 1.0, 0.0, n, 1, D, nullptr, (cplx*)d_out, nullptr, st);
+    if (rc < 0) return -1;
+    done = (rc == 0);
+  }
+  if (!done && !(flags & C3P_FORCE_GENERIC) && D >= 13 && D <= 40) {
+    const int rc = run_xg_midd(w, (const cplx*)d_A, (long)D * D, 1.0, 0.0, n, 1, D, nullptr, (cplx*)d_out, nullptr, st);
+    if (rc < 0) return -1;
+    done = (rc == 0);
+  }
   ChainArgs a = {};
   a.mode = C3P_MODE_EXPM;
   a.mats = (const cplx*)d_A;
@@ -776,7 +898,7 @@ int c3p_expm(const void* A, int n, int D, int flags, void* out, void* stream) {
   a.N = 1;
   a.D = D;
   a.Dm = D;
-  if (run_chain_generic(w, a, (cplx*)d_out, st)) return -1;
+  if (!done && run_chain_generic(w, a, (cplx*)d_out, st)) return -1;
   if (flags & C3P_HOST_PTRS) return sg.finish();
   return 0;
 }

@@ -346,6 +346,62 @@ __global__ void __launch_bounds__(64) overlap_kernel(const cplx* U, int D, const
   if (lane == 0) out[b] = cmake(sr, si);
 }
 
+// Pre-pass of the supplied-generator modes (branch B of pwc, c3p_expm): one workgroup per matrix,
+// X = coef * H;  meta = {Re mu, Im mu, ||X - mu I||_1, 0},  mu = tr X / D.
+__global__ void __launch_bounds__(64) hmeta_kernel(const cplx* hs, long bstride, int N, int D, double cr, double ci,
+                                                   double* meta) {
+  __shared__ double rr[64], ri[64];
+  __shared__ double mu[2];
+  const int tid = threadIdx.x;
+  const long m = blockIdx.x;
+  const long b = m / N, n = m - b * N;
+  const cplx* h = hs + b * bstride + n * (long)D * D;
+  double tr = 0, ti = 0;
+  for (int i = tid; i < D; i += 64) {
+    const cplx x = h[i * D + i];
+    tr += cr * x.x - ci * x.y;
+    ti += cr * x.y + ci * x.x;
+  }
+  rr[tid] = tr;
+  ri[tid] = ti;
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0, c = 0;
+    for (int i = 0; i < 64; ++i) {
+      a += rr[i];
+      c += ri[i];
+    }
+    mu[0] = a / D;
+    mu[1] = c / D;
+  }
+  __syncthreads();
+  double cs = 0;
+  for (int j = tid; j < D; j += 64) {
+    double sum = 0;
+    for (int i = 0; i < D; ++i) {
+      const cplx x = h[i * D + j];
+      double vr = cr * x.x - ci * x.y, vi = cr * x.y + ci * x.x;
+      if (i == j) {
+        vr -= mu[0];
+        vi -= mu[1];
+      }
+      sum += hypot(vr, vi);
+    }
+    cs = fmax(cs, sum);
+  }
+  rr[tid] = cs;
+  __syncthreads();
+  if (tid == 0) {
+    double nrm = 0;
+    for (int i = 0; i < 64; ++i) nrm = fmax(nrm, rr[i]);
+    double* o = meta + m * 4;
+    o[0] = mu[0];
+    o[1] = mu[1];
+    o[2] = nrm;
+    o[3] = 0.0;
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -404,5 +460,12 @@ hipError_t c3p_launch_overlap(const cplx* U, int B, int D, const int* rows, int 
                               cplx* out, hipStream_t st) {
   if (B == 0) return hipSuccess;
   hipLaunchKernelGGL(overlap_kernel, dim3((unsigned)B), dim3(64), 0, st, U, D, rows, L, ideal, out);
+  return hipGetLastError();
+}
+
+hipError_t c3p_launch_hmeta(const cplx* hs, long bstride, long nmat, int N, int D, double cr, double ci, double* meta,
+                            hipStream_t st) {
+  if (nmat == 0) return hipSuccess;
+  hipLaunchKernelGGL(hmeta_kernel, dim3((unsigned)nmat), dim3(64), 0, st, hs, bstride, N, D, cr, ci, meta);
   return hipGetLastError();
 }

@@ -36,3 +36,6 @@ hipError_t c3p_launch_kron(const cplx* A, const cplx* Bm, int n, int Da, int Db,
                            hipStream_t st);
 hipError_t c3p_launch_overlap(const cplx* U, int B, int D, const int* rows, int L, const cplx* ideal,
                               cplx* out, hipStream_t st);
+// pre-pass of the supplied-generator modes: meta[m] = {Re mu, Im mu, ||coef H_m - mu||_1, 0}, m = b * N + n
+hipError_t c3p_launch_hmeta(const cplx* hs, long bstride, long nmat, int N, int D, double cr, double ci, double* meta,
+                            hipStream_t st);

@@ -7,6 +7,11 @@ struct MidArgs {
   int tab_per_sample;
   const double* signals;  // [B,K,N]
   const cplx* mats;       // [B,N,Dm,Dm] (GIVEN mode)
+  // C3P_MODE_EXPM: generators supplied per slice, X_n = coef hs[b,n] (see SmallArgs)
+  const cplx* hs;
+  long hs_bstride;
+  const double* meta;
+  double coef_r, coef_i;
   const double* fr_phase;
   int B, K, N, Dm;
   int S, Lmax;

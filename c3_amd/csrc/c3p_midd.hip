@@ -209,7 +209,7 @@ __device__ __forceinline__ void mm_tiles(const double* imgA, const double* imgB,
 
 // The whole slice loop, specialised per wave so that every tile index is a compile-time
 // constant (LDS offsets become instruction immediates; no per-tile predication).
-template <int NIG, int NJ, int W, bool GIVEN, bool DUS, int WV>
+template <int NIG, int NJ, int W, bool GIVEN, bool DUS, bool XG, int WV>
 __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm, long chain) {
   using T = WaveTiles<NIG, NJ, W, WV>;
   constexpr int IMG = MD<NIG, NJ>::ROWS * W, NE = T::NE;
@@ -277,6 +277,23 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
     } else {
       // ---- X = scale (G0 + sum_k c_k G_k) at the lane's element positions ----
       Regs X;
+      if constexpr (XG) {
+        // supplied generator: X = scale (coef * hs[b,n] - mu), mu from the hmeta pre-pass
+        const long m = (long)cm.sample * A.N + cm.n0 + t;
+        mu_r = A.meta[m * 4 + 0];
+        mu_i = A.meta[m * 4 + 1];
+        const double2* src = reinterpret_cast<const double2*>(A.hs) + (long)cm.sample * A.hs_bstride + (long)(cm.n0 + t) * D * D;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const int row = erow(e), col = ecol(e);
+          const int ci = row >> 1;
+          const bool in = ci < D && col < D;
+          const double2 h = src[in ? ci * D + col : 0];
+          double v = (row & 1) ? fma(A.coef_r, h.y, A.coef_i * h.x) : fma(A.coef_r, h.x, -A.coef_i * h.y);
+          v -= (ci == col) ? ((row & 1) ? mu_i : mu_r) : 0.0;
+          X.set(e, in ? cm.scale * v : 0.0);
+        }
+      } else {
       mu_r = tabs[IMG + 0];
       mu_i = tabs[IMG + 1];
 #pragma unroll
@@ -289,6 +306,7 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
         mu_i = fma(c0, tk[IMG + 1], mu_i);
 #pragma unroll
         for (int e = 0; e < NE; ++e) X.set(e, fma(ck, tk[eoff(e)], X.get(e)));
+      }
       }
       store_tiles(cm.buf0, X);
       __syncthreads();
@@ -430,7 +448,7 @@ struct MidOcc {
   static constexpr int WGS = (3 * IMG_BYTES + 6144) * 3 <= 160 * 1024 ? 3 : 2;
 };
 
-template <int NIG, int NJ, int W, bool GIVEN, bool DUS>
+template <int NIG, int NJ, int W, bool GIVEN, bool DUS, bool XG = false>
 __global__ void __launch_bounds__(256, (MidOcc<NIG, W>::WGS)) midd_chain_kernel(MidArgs A) {
   using C = MD<NIG, NJ>;
   constexpr int IMG = C::ROWS * W;
@@ -470,15 +488,26 @@ __global__ void __launch_bounds__(256, (MidOcc<NIG, W>::WGS)) midd_chain_kernel(
   for (int e = tid; e < 3 * IMG; e += 256) c3p_md_lds[e] = 0.0;
   __syncthreads();
 
-  cm.tabs = A.tables + (long)(A.tab_per_sample ? cm.sample : 0) * (1 + K) * (IMG + 4);
+  cm.tabs = XG ? nullptr : A.tables + (long)(A.tab_per_sample ? cm.sample : 0) * (1 + K) * (IMG + 4);
   cm.pr = 1;
   cm.ps = 0;
   cm.t18 = 0;
   cm.scale = 1.0;
   if constexpr (!GIVEN) {
-    // segment-wide plan from ||G0|| + sum_k max_t |c_k(t)| ||G_k||
-    double nrm = cm.tabs[IMG + 2];
-    for (int k = 0; k < K; ++k) {
+    // segment-wide plan from ||G0|| + sum_k max_t |c_k(t)| ||G_k||  (XG: max of the per-slice norms)
+    double nrm = 0.0;
+    if constexpr (XG) {
+      const double* mt = A.meta + ((long)cm.sample * A.N + cm.n0) * 4;
+      for (int t = tid; t < cm.len; t += 256) nrm = fmax(nrm, mt[(long)t * 4 + 2]);
+      for (int o = 32; o >= 1; o >>= 1) nrm = fmax(nrm, __shfl_xor(nrm, o));
+      if (cm.lane == 0) red[wave] = nrm;
+      __syncthreads();
+      nrm = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+      __syncthreads();
+    } else {
+      nrm = cm.tabs[IMG + 2];
+    }
+    for (int k = 0; k < (XG ? 0 : K); ++k) {
       const double* s = A.signals + ((long)cm.sample * K + k) * A.N + cm.n0;
       double cmax = 0.0;
       for (int t = tid; t < cm.len; t += 256) {
@@ -508,10 +537,10 @@ __global__ void __launch_bounds__(256, (MidOcc<NIG, W>::WGS)) midd_chain_kernel(
     __syncthreads();
   }
   switch (wave) {
-    case 0: midd_body<NIG, NJ, W, GIVEN, DUS, 0>(A, cm, chain); break;
-    case 1: midd_body<NIG, NJ, W, GIVEN, DUS, 1>(A, cm, chain); break;
-    case 2: midd_body<NIG, NJ, W, GIVEN, DUS, 2>(A, cm, chain); break;
-    default: midd_body<NIG, NJ, W, GIVEN, DUS, 3>(A, cm, chain); break;
+    case 0: midd_body<NIG, NJ, W, GIVEN, DUS, XG, 0>(A, cm, chain); break;
+    case 1: midd_body<NIG, NJ, W, GIVEN, DUS, XG, 1>(A, cm, chain); break;
+    case 2: midd_body<NIG, NJ, W, GIVEN, DUS, XG, 2>(A, cm, chain); break;
+    default: midd_body<NIG, NJ, W, GIVEN, DUS, XG, 3>(A, cm, chain); break;
   }
 }
 
@@ -634,6 +663,8 @@ hipError_t launch_t(const MidArgs& A, hipStream_t st) {
     return hipGetLastError();
   };
   if (A.mode == C3P_MODE_GIVEN) return go(midd_chain_kernel<NIG, NJ, W, true, false>);
+  if (A.mode == C3P_MODE_EXPM)
+    return A.dUs_out ? go(midd_chain_kernel<NIG, NJ, W, false, true, true>) : go(midd_chain_kernel<NIG, NJ, W, false, false, true>);
   if (A.dUs_out) return go(midd_chain_kernel<NIG, NJ, W, false, true>);
   return go(midd_chain_kernel<NIG, NJ, W, false, false>);
 }

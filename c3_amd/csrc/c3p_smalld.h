@@ -9,6 +9,11 @@ struct SmallArgs {
   int tab_per_sample;      // tables differ per sample (then S % 4 == 0)
   const double* signals;   // [B,K,N]
   const cplx* mats;        // [B,N,Dm,Dm] (GIVEN mode)
+  // C3P_MODE_EXPM (generators supplied per slice: X_n = coef hs[b,n], shifted by meta's mu_n)
+  const cplx* hs;          // [B,N,Dm,Dm] or [N,Dm,Dm] (hs_bstride 0)
+  long hs_bstride;         // complex elements between samples
+  const double* meta;      // [B*N][4] = {Re mu, Im mu, ||X - mu||_1, 0} from c3p_launch_hmeta
+  double coef_r, coef_i;   // -i dt -> (0, -dt); 1 for c3p_expm
   const double* fr_phase;  // [B,Dm] or null
   int B, K, N, Dm;
   int S;     // segments per sample (balanced: segment s covers [s*N/S, (s+1)*N/S))

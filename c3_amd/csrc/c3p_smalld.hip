@@ -326,7 +326,9 @@ __device__ __forceinline__ void store_plain(const double (&zh)[SD<D>::NBI][SD<D>
   }
 }
 
-template <int D, bool GIVEN, bool DUS>
+// XG: the generators are supplied per slice (branch B of pwc, propagation.py:295-308, and c3p_expm):
+// X_n = coef * hs[b,n] - mu_n with (mu_n, ||X_n - mu_n||_1) from the hmeta pre-pass; no tables, no signals.
+template <int D, bool GIVEN, bool DUS, bool XG = false>
 __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
   using C = SD<D>;
   constexpr int NBI = C::NBI, NJ = C::NJ, W = C::W, MAT = C::MAT, IMG = C::IMG;
@@ -338,7 +340,7 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
   lp.idx16 = lp.r * 4 + lp.c;
   const int K = A.K;
   double* tab = c3p_sd_lds;  // (1+K) images + scalars (table modes only)
-  double* img = tab + (GIVEN ? 0 : (1 + K) * (MAT + 4));  // 4 chain images
+  double* img = tab + ((GIVEN || XG) ? 0 : (1 + K) * (MAT + 4));  // 4 chain images
   double* sg = img + 4 * IMG;  // 4 chains x K x Lmax signals, odd chain stride (bank spread)
   const int SG = (K * A.Lmax) | 1;
 
@@ -404,11 +406,21 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
   } else {
     // ---- prologue: tables and this segment's control amplitudes into LDS ----
     // all four chains of a wave share the sample when tables are per sample (S % 4 == 0)
+    double nrm = 0.0;
+    if constexpr (XG) {
+      const double* mt = A.meta + ((long)sample * A.N + n0) * 4;
+      for (int t = lp.idx16; t < A.Lmax; t += 16)
+        if (valid && t < len) nrm = fmax(nrm, mt[(long)t * 4 + 2]);
+      nrm = fmax(nrm, __shfl_xor(nrm, 1));
+      nrm = fmax(nrm, __shfl_xor(nrm, 2));
+      nrm = fmax(nrm, __shfl_xor(nrm, 16));
+      nrm = fmax(nrm, __shfl_xor(nrm, 32));
+    } else {
     const double* gt0 = A.tables + (long)(A.tab_per_sample ? sample : 0) * (1 + K) * (MAT + 4);
     for (int e = lane; e < (1 + K) * (MAT + 4); e += 64) tab[e] = gt0[e];
     __syncthreads();
     // segment-wide bound on ||X||_1 <= ||G0|| + sum_k max_t |c_k(t)| ||G_k||  -> one plan per segment
-    double nrm = tab[MAT + 2];
+    nrm = tab[MAT + 2];
     for (int k = 0; k < K; ++k) {
       const double* s = A.signals + ((long)sample * K + k) * A.N + n0;
       double cmax = 0.0;
@@ -423,6 +435,7 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
       cmax = fmax(cmax, __shfl_xor(cmax, 32));
       nrm = fma(cmax, tab[(k + 1) * (MAT + 4) + MAT + 2], nrm);
     }
+    }
     nrm = fmax(nrm, __shfl_xor(nrm, 4));
     nrm = fmax(nrm, __shfl_xor(nrm, 8));
     nrm = readfirstlane_f64(nrm);
@@ -434,8 +447,9 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
     __syncthreads();
 
     // every table of this sample purely imaginary (real Hamiltonians) -> real fast path
-    bool realH = (A.mode == C3P_MODE_UNITARY);
-    for (int k = 0; k <= K; ++k) realH = realH && (tab[k * (MAT + 4) + MAT + 3] == 0.0);
+    bool realH = !XG && (A.mode == C3P_MODE_UNITARY);
+    if constexpr (!XG)
+      for (int k = 0; k <= K; ++k) realH = realH && (tab[k * (MAT + 4) + MAT + 3] == 0.0);
     realH = __builtin_amdgcn_readfirstlane((int)realH) != 0;
     if (realH) {
       constexpr int NB = RD<D>::NB;
@@ -586,8 +600,28 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
       // chains past their segment end (lengths differ by at most one slice) take X = 0, E = I
       const double sc = act ? scale : 0.0;
       const double muw = act ? 1.0 : 0.0;
-      double mu_r = muw * tab[MAT + 0], mu_i = muw * tab[MAT + 1];
+      double mu_r, mu_i;
       double X[NBI][NJ];
+      if constexpr (XG) {
+        const long m = (long)sample * A.N + n0 + (act ? t : 0);
+        mu_r = muw * A.meta[m * 4 + 0];
+        mu_i = muw * A.meta[m * 4 + 1];
+        const double2* src = reinterpret_cast<const double2*>(A.hs) + (long)sample * A.hs_bstride + (long)(n0 + (act ? t : 0)) * D * D;
+        const double mine = (lp.r & 1) ? mu_i : mu_r;
+#pragma unroll
+        for (int I = 0; I < NBI; ++I)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) {
+            const int row = 2 * I + (lp.r >> 1), col = 4 * J + lp.c;
+            const bool in = row < D && col < D;
+            const double2 h = src[in ? row * D + col : 0];
+            double v = (lp.r & 1) ? fma(A.coef_r, h.y, A.coef_i * h.x) : fma(A.coef_r, h.x, -A.coef_i * h.y);
+            v -= (row == col) ? mine : 0.0;
+            X[I][J] = in ? sc * v : 0.0;
+          }
+      } else {
+      mu_r = muw * tab[MAT + 0];
+      mu_i = muw * tab[MAT + 1];
 #pragma unroll
       for (int I = 0; I < NBI; ++I)
 #pragma unroll
@@ -602,6 +636,7 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
         for (int I = 0; I < NBI; ++I)
 #pragma unroll
           for (int J = 0; J < NJ; ++J) X[I][J] = fma(ck, tk[toff + I * 4 * W + J * 4], X[I][J]);
+      }
       }
       write_image<D>(X, img, woff);
       // ---- powers with the left operand X (read from its image) ----
@@ -910,12 +945,17 @@ hipError_t launch_chain_t(const SmallArgs& A, hipStream_t st) {
   const long nchains = (long)A.B * A.S;
   const unsigned grid = (unsigned)((nchains + 3) / 4);
   size_t lds = 0;
-  if (A.mode == C3P_MODE_GIVEN)
+  if (A.mode == C3P_MODE_GIVEN || A.mode == C3P_MODE_EXPM)
     lds = (size_t)(4 * C::IMG) * sizeof(double);
   else
     lds = (size_t)((1 + A.K) * (C::MAT + 4) + 4 * C::IMG + 4 * ((A.K * A.Lmax) | 1)) * sizeof(double);
   if (lds > 60 * 1024) return hipErrorInvalidValue;
-  if (A.mode == C3P_MODE_GIVEN)
+  if (A.mode == C3P_MODE_EXPM) {
+    if (A.dUs_out)
+      hipLaunchKernelGGL((smalld_chain_kernel<D, false, true, true>), dim3(grid), dim3(64), lds, st, A);
+    else
+      hipLaunchKernelGGL((smalld_chain_kernel<D, false, false, true>), dim3(grid), dim3(64), lds, st, A);
+  } else if (A.mode == C3P_MODE_GIVEN)
     hipLaunchKernelGGL((smalld_chain_kernel<D, true, false>), dim3(grid), dim3(64), lds, st, A);
   else if (A.dUs_out)
     hipLaunchKernelGGL((smalld_chain_kernel<D, false, true>), dim3(grid), dim3(64), lds, st, A);

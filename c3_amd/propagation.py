@@ -275,7 +275,7 @@ def _chain(dUs, order_flag):
     return out[0] if squeeze else out
 
 
-def expm(A):
+def expm(A, force_generic: bool = False):
     """Batched matrix exponential on the device: the tf.linalg.expm call sites
     (propagation.py:378,422,440,456,584)."""
     call = _Call(A)
@@ -287,7 +287,7 @@ def expm(A):
         n *= int(s)
     Mf = M.reshape((n, D, D))
     out = call.empty((n, D, D))
-    _lib.check(_lib.load().c3p_expm(_ptr(Mf), n, D, call.flags, _ptr(out), call.stream))
+    _lib.check(_lib.load().c3p_expm(_ptr(Mf), n, D, call.flags | (_lib.FORCE_GENERIC if force_generic else 0), _ptr(out), call.stream))
     return out.reshape(shp)
 
 

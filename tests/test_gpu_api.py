@@ -157,6 +157,39 @@ def test_real_hamiltonian_fast_path(prop, D, strength):
         assert np.linalg.norm(np.asarray(r2["U"][b]) - ref2) < 1e-10
 
 
+@pytest.mark.parametrize("D", [2, 3, 5, 8, 9, 12, 13, 14, 24, 27, 36, 40, 45])
+def test_supplied_generators_every_kernel(prop, D):
+    """Branch B of pwc (per-slice Hamiltonians, propagation.py:295-308) and c3p_expm on the MFMA kernels
+    (small-D <= 12, mid-D 13..40; the generic kernel beyond and under FORCE_GENERIC): general complex,
+    non-Hermitian generators, shared and per-sample stacks, partial propagators, frame phases."""
+    import scipy.linalg as sla
+    from c3_amd import _lib
+
+    rng = np.random.default_rng(300 + D)
+    B, N = 3, 21
+    dt = 1e-11
+    H = (rng.normal(size=(B, N, D, D)) + 1j * rng.normal(size=(B, N, D, D))) * (0.9e11 / D)
+    H = H + np.conj(np.swapaxes(H, -1, -2))
+    ph = rng.uniform(0, 6, size=(B, D))
+    want_d = np.stack([[sla.expm(-1j * dt * H[b, n]) for n in range(N)] for b in range(B)])
+    want_U = np.stack([np.exp(1j * ph[b])[:, None] * o.tf_matmul_left(want_d[b]) for b in range(B)])
+    for gen in (False, True):
+        r = prop.propagate_batch(H, None, None, dt, want_dUs=True, fr_phase=ph, force_generic=gen)
+        kern = _lib.last_kernel()
+        assert kern == (("generic_lds" if D <= 37 else "generic_global") if (gen or D > 40) else ("smalld" if D <= 12 else "mfma"))
+        assert np.abs(np.asarray(r["dUs"]) - want_d).max() < 1e-12
+        assert max(np.linalg.norm(np.asarray(r["U"][b]) - want_U[b]) for b in range(B)) < 1e-10
+    r1 = prop.propagate_batch(H[1], None, None, dt)  # one shared stack [N,D,D]
+    assert np.linalg.norm(np.asarray(r1["U"][0]) - o.tf_matmul_left(want_d[1])) < 1e-10
+    # c3p_expm: arbitrary (non-normal) matrices, norms needing squarings
+    A = rng.normal(size=(7, D, D)) + 1j * rng.normal(size=(7, D, D))
+    A *= (np.array([0.01, 0.3, 1.0, 2.5, 6.0, 0.0, 1e-9]) / np.maximum(np.abs(A).sum(axis=-2).max(axis=-1), 1e-300))[:, None, None]
+    want = np.stack([sla.expm(x) for x in A])
+    for gen in (False, True):
+        got = np.asarray(prop.expm(A, force_generic=gen))
+        assert np.abs(got - want).max() < 1e-12 * np.exp(6.0)
+
+
 @pytest.mark.parametrize("D", [41, 48, 49, 64, 77, 92])
 def test_big_dimension_classes(prop, D):
     """Every geometry class of the big-D MFMA kernel (41..92), a couple of samples and slices."""
