@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config index (2 = headline)")
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default: config's B, capped at 256/GPU for cfg3/5)")
     ap.add_argument("--slices", type=int, default=None)
+    ap.add_argument("--gather-every", type=int, default=8, help="batches exchanged per all-gather (multi-GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the generic LDS kernel")
     ap.add_argument("--check", action="store_true", help="verify a few samples against the oracle")
@@ -95,27 +96,45 @@ def main():
         fr_phase=torch.as_tensor(fr, device=dev),
         force_generic=args.generic,
     )
-    # The only data-path collective is the final all-gather of the U slabs (RCCL over xGMI),
-    # issued in stream order after each batch.  (An asynchronous, double-buffered gather was
-    # measured SLOWER: the RCCL kernel then runs beside the chain kernel, takes CUs away from a
-    # grid sized to fill the chip exactly, and creates a partial second round of waves.)
-    nbuf = 2
-    Ubuf = [torch.empty((B, Dm, Dm), dtype=torch.complex128, device=dev) for _ in range(nbuf)]
-    gathered = [torch.empty((world * B, Dm, Dm), dtype=torch.complex128, device=dev) for _ in range(nbuf)] if use_dist else None
+    # The only data-path collective is the all-gather of the U slabs (RCCL over xGMI), in stream order.
+    # xGMI all-gathers of 0.33 MB per rank are latency-bound (tens of microseconds against a 0.25 ms
+    # batch), so the slabs of `--gather-every` consecutive batches (default 8) are exchanged by ONE
+    # collective: fewer, larger messages; every batch's propagators still reach every rank inside the
+    # timed region.  (An asynchronous gather beside the chain kernel was measured SLOWER: the RCCL kernel
+    # takes CUs away from a grid sized to fill the chip exactly and creates a partial second round.)
+    G = max(1, int(args.gather_every))
+    Ubuf = torch.empty((G, B, Dm, Dm), dtype=torch.complex128, device=dev)
+    gathered = torch.empty((world * G * B * Dm * Dm,), dtype=torch.complex128, device=dev) if use_dist else None
     counter = [0]
+    pending = [0]
+
+    def flush():
+        g = pending[0]
+        if use_dist and g > 0:
+            n = g * B * Dm * Dm
+            dist.all_gather_into_tensor(torch.view_as_real(gathered[: world * n]), torch.view_as_real(Ubuf[:g].reshape(-1)))
+        pending[0] = 0
 
     def step():
-        i = counter[0] % nbuf
+        i = counter[0] % G
         counter[0] += 1
         U = bp.run(out=Ubuf[i])
-        if use_dist:
-            dist.all_gather_into_tensor(torch.view_as_real(gathered[i]), torch.view_as_real(U))
+        pending[0] += 1
+        if pending[0] == G:
+            flush()
         return U
 
     def drain():
-        pass
+        flush()
+        counter[0] = 0
 
     lib = _lib.load()
+    if use_dist:
+        # the communicator and every message size of the run are set up before anything is timed
+        for g in sorted({min(G, max(1, args.steps)), args.steps % G, args.warmup % G, min(G, max(1, args.warmup))} - {0}):
+            pending[0] = g
+            flush()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     drain()
@@ -196,7 +215,7 @@ def main():
                 "controls": wl.K,
                 "batch_per_gpu": B,
                 "global_batch": world * B,
-                "parallelism": f"dp{world} (batch sharded; one RCCL all-gather of U per step)" if world > 1 else "single GPU",
+                "parallelism": f"dp{world} (batch sharded; one RCCL all-gather of U per {G} batches)" if world > 1 else "single GPU",
                 "kernel": kernel_name,
             },
             "roofline": {
