@@ -71,6 +71,8 @@ int ws_get(DeviceWs* w, Slot s, size_t bytes, void** out) {
     size_t want = bytes + bytes / 8;
     HIP_TRY(hipMalloc(&w->ptr[s], want));
     w->cap[s] = want;
+    // the arrival counters of the fused combine are self-resetting: zero once, at allocation
+    if (s == SL_COUNTERS) HIP_TRY(hipMemset(w->ptr[s], 0, want));
   }
   *out = w->ptr[s];
   return 0;
@@ -262,29 +264,40 @@ int run_pwc_smalld(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const 
   const int S = pick_segments(B, N, K, Dm, per_sample);
   if (S < 0) return 1;  // not applicable -> caller falls back to the generic kernel
   const int nsamp = per_sample ? B : 1;
-  void* v;
-  if (ws_get(w, SL_TABLES, (size_t)nsamp * c3p_smalld_table_doubles(Dm, K) * sizeof(double), &v)) return -1;
-  PrepArgs p = {};
-  p.h0 = h0;
-  p.h0_bstride = h0_bs;
-  p.hks = hks;
-  p.hks_bstride = hk_bs;
-  p.clp = clp;
-  p.dt = dt;
-  p.K = K;
-  p.Dh = D;
-  p.lindblad = lindblad;
-  p.tables = (double*)v;
   const bool fuse = (S > 1) && (S % 4 == 0) && !getenv("C3P_NO_FUSE");
+  const bool inline_tables = !lindblad && !getenv("C3P_PREP_KERNEL");
+  int* counters = nullptr;
   if (fuse) {
     void* cv;
     if (ws_get(w, SL_COUNTERS, (size_t)B * sizeof(int), &cv)) return -1;
-    p.counters = (int*)cv;
-    p.ncounters = B;
+    counters = (int*)cv;
   }
-  HIP_TRY(c3p_launch_smalld_prep(p, Dm, nsamp, st));
   SmallArgs a = {};
-  a.tables = (const double*)v;
+  if (inline_tables) {
+    // unitary mode: the chain kernel builds its tables itself (no dependent launch in front of it)
+    a.inline_tables = 1;
+    a.h0 = h0;
+    a.h0_bstride = h0_bs;
+    a.hks = hks;
+    a.hks_bstride = hk_bs;
+    a.dt = dt;
+  } else {
+    void* v;
+    if (ws_get(w, SL_TABLES, (size_t)nsamp * c3p_smalld_table_doubles(Dm, K) * sizeof(double), &v)) return -1;
+    PrepArgs p = {};
+    p.h0 = h0;
+    p.h0_bstride = h0_bs;
+    p.hks = hks;
+    p.hks_bstride = hk_bs;
+    p.clp = clp;
+    p.dt = dt;
+    p.K = K;
+    p.Dh = D;
+    p.lindblad = lindblad;
+    p.tables = (double*)v;
+    HIP_TRY(c3p_launch_smalld_prep(p, Dm, nsamp, st));
+    a.tables = (const double*)v;
+  }
   a.tab_per_sample = per_sample ? 1 : 0;
   a.signals = signals;
   a.B = B;
@@ -304,7 +317,7 @@ int run_pwc_smalld(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const 
     a.seg_out = (cplx*)sv;
     if (fuse) {
       a.fuse = 1;
-      a.counters = p.counters;
+      a.counters = counters;
       a.final_out = U_out;
       a.fr_phase = fr_phase;
     }
@@ -402,7 +415,6 @@ int run_xg_smalld(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, d
     if (fuse) {
       void* cv;
       if (ws_get(w, SL_COUNTERS, (size_t)B * sizeof(int), &cv)) return -1;
-      HIP_TRY(hipMemsetAsync(cv, 0, (size_t)B * sizeof(int), st));
       a.fuse = 1;
       a.counters = (int*)cv;
       a.final_out = U_out;

@@ -6,6 +6,13 @@
 
 struct SmallArgs {
   const double* tables;    // [nsamp][(1+K)][MAT+4] images from smalld_prep (TABLE mode)
+  // inline_tables (unitary mode): every wave builds the tables of its sample in LDS from h0 / hks itself
+  int inline_tables;
+  const cplx* h0;
+  long h0_bstride;
+  const cplx* hks;
+  long hks_bstride;
+  double dt;
   int tab_per_sample;      // tables differ per sample (then S % 4 == 0)
   const double* signals;   // [B,K,N]
   const cplx* mats;        // [B,N,Dm,Dm] (GIVEN mode)

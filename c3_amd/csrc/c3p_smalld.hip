@@ -326,6 +326,79 @@ __device__ __forceinline__ void store_plain(const double (&zh)[SD<D>::NBI][SD<D>
   }
 }
 
+__device__ __forceinline__ double wave_sum64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_max64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+
+// The wave builds its own tables in LDS (unitary mode): G = -i dt (h - tr h / D) as half images plus
+// {Re mu, Im mu, ||G||_1, max |Re G|} -- what smalld_prep_kernel writes, without a dependent launch in
+// front of the chain kernel (~12 us of a 250 us batch).
+template <int D>
+__device__ __forceinline__ void build_tables(const SmallArgs& A, int sample, double* tab, int lane) {
+  using C = SD<D>;
+  constexpr int MAT = C::MAT, W = C::W;
+  constexpr int NE = (D * D + 63) / 64;
+  for (int ti = 0; ti <= A.K; ++ti) {
+    double* out = tab + ti * (MAT + 4);
+    const cplx* h = (ti == 0) ? A.h0 + (long)sample * A.h0_bstride
+                              : A.hks + (long)sample * A.hks_bstride + (long)(ti - 1) * D * D;
+    for (int e = lane; e < MAT; e += 64) out[e] = 0.0;
+    double gr[NE], gi[NE];
+    double tr = 0.0, tim = 0.0;
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const int e = lane + 64 * q;
+      gr[q] = gi[q] = 0.0;
+      if (e < D * D) {
+        const cplx x = h[e];
+        gr[q] = x.y * A.dt;  // -i dt h
+        gi[q] = -x.x * A.dt;
+        if (e / D == e % D) {
+          tr += gr[q];
+          tim += gi[q];
+        }
+      }
+    }
+    const double mur = wave_sum64(tr) / D, mui = wave_sum64(tim) / D;
+    wave_sync();
+    double remax = 0.0;
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const int e = lane + 64 * q;
+      if (e < D * D) {
+        const int i = e / D, j = e - i * D;
+        if (i == j) {
+          gr[q] -= mur;
+          gi[q] -= mui;
+        }
+        out[(2 * i) * W + j] = gr[q];
+        out[(2 * i + 1) * W + j] = gi[q];
+        remax = fmax(remax, fabs(gr[q]));
+      }
+    }
+    wave_sync();
+    double cs = 0.0;
+    if (lane < D)
+      for (int i = 0; i < D; ++i) cs += hypot(out[(2 * i) * W + lane], out[(2 * i + 1) * W + lane]);
+    const double nrm = wave_max64(cs);
+    remax = wave_max64(remax);
+    if (lane == 0) {
+      out[MAT + 0] = mur;
+      out[MAT + 1] = mui;
+      out[MAT + 2] = nrm;
+      out[MAT + 3] = remax;
+    }
+  }
+  wave_sync();
+}
+
 // XG: the generators are supplied per slice (branch B of pwc, propagation.py:295-308, and c3p_expm):
 // X_n = coef * hs[b,n] - mu_n with (mu_n, ||X_n - mu_n||_1) from the hmeta pre-pass; no tables, no signals.
 template <int D, bool GIVEN, bool DUS, bool XG = false>
@@ -416,8 +489,12 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
       nrm = fmax(nrm, __shfl_xor(nrm, 16));
       nrm = fmax(nrm, __shfl_xor(nrm, 32));
     } else {
-    const double* gt0 = A.tables + (long)(A.tab_per_sample ? sample : 0) * (1 + K) * (MAT + 4);
-    for (int e = lane; e < (1 + K) * (MAT + 4); e += 64) tab[e] = gt0[e];
+    if (A.inline_tables) {
+      build_tables<D>(A, __builtin_amdgcn_readfirstlane(sample), tab, lane);
+    } else {
+      const double* gt0 = A.tables + (long)(A.tab_per_sample ? sample : 0) * (1 + K) * (MAT + 4);
+      for (int e = lane; e < (1 + K) * (MAT + 4); e += 64) tab[e] = gt0[e];
+    }
     __syncthreads();
     // segment-wide bound on ||X||_1 <= ||G0|| + sum_k max_t |c_k(t)| ||G_k||  -> one plan per segment
     nrm = tab[MAT + 2];
@@ -797,6 +874,7 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
         old = __hip_atomic_fetch_add(A.counters + sample, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       old = __builtin_amdgcn_readfirstlane(old);
       if (old != nW - 1) return;
+      if (lane == 0) A.counters[sample] = 0;  // self-resetting: the next launch finds it zero
       // (3) last arriver of this sample: fold the nW partials (slot b takes a contiguous quarter)
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       const int lo = (lp.b * nW) >> 2, hi = ((lp.b + 1) * nW) >> 2;
