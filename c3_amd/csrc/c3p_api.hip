@@ -333,6 +333,83 @@ int run_pwc_smalld(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const 
 int combine_midd(DeviceWs* w, const cplx* cur, int B, int count, int Dm, int right_order, const double* fr_phase,
                  cplx* U_out, hipStream_t st);
 
+// Gradient on the mid-D MFMA kernels (13 <= D <= 40): tables, forward segment products (chain kernel, no
+// combine), the per-sample scan of c3p_grad.hip, then the pair-T18 backward sweep.  1 = not applicable.
+int run_vjp_midd(DeviceWs* w, GradArgs& G, hipStream_t st) {
+  const int D = G.D, B = G.B, K = G.K, N = G.N;
+  int nig, nj, wd;
+  if (!c3p_midd_geometry(D, &nig, &nj, &wd) || K > 16) return 1;
+  const size_t img_bytes = (size_t)16 * nig * wd * sizeof(double);
+  // one workgroup per CU in the backward sweep (four images); aim at two rounds
+  long S = (512 + B - 1) / B;
+  const long smax = N / 8 > 1 ? N / 8 : 1;
+  if (S > smax) S = smax;
+  if (S < 1) S = 1;
+  auto lds_need = [&](long s) { return 4 * img_bytes + (size_t)K * ((N + s - 1) / s) * sizeof(double); };
+  while (lds_need(S) > (size_t)150 * 1024 && S < N) ++S;
+  if (lds_need(S) > (size_t)150 * 1024) return 1;
+  const bool per_sample = (G.h0_bstride != 0) || (G.hks_bstride != 0);
+  const int nsamp = per_sample ? B : 1;
+  void* v;
+  if (ws_get(w, SL_TABLES, (size_t)nsamp * c3p_midd_table_doubles(D, K) * sizeof(double), &v)) return -1;
+  MidPrepArgs p = {};
+  p.h0 = G.h0;
+  p.h0_bstride = G.h0_bstride;
+  p.hks = G.hks;
+  p.hks_bstride = G.hks_bstride;
+  p.dt = G.dt;
+  p.K = K;
+  p.Dh = D;
+  p.Dm = D;
+  p.rows = 16 * nig;
+  p.W = wd;
+  p.tables = (double*)v;
+  HIP_TRY(c3p_launch_midd_prep(p, nsamp, st));
+  const size_t segb = (size_t)B * S * D * D * sizeof(cplx);
+  void *sv, *mv;
+  if (ws_get(w, SL_SEG_A, segb, &sv)) return -1;
+  if (ws_get(w, SL_SEG_B, segb, &mv)) return -1;
+  MidArgs a = {};
+  a.tables = p.tables;
+  a.tab_per_sample = per_sample ? 1 : 0;
+  a.signals = G.signals;
+  a.B = B;
+  a.K = K;
+  a.N = N;
+  a.Dm = D;
+  a.S = (int)S;
+  a.Lmax = (int)((N + S - 1) / S);
+  a.mode = C3P_MODE_UNITARY;
+  a.seg_out = (cplx*)sv;
+  HIP_TRY(c3p_launch_midd_chain(a, st));
+  G.S = (int)S;
+  G.seg = (cplx*)sv;
+  G.Mb = (cplx*)mv;
+  const bool scan_global = c3p_grad_lds_bytes(D) > 150 * 1024;
+  if (scan_global) {
+    // the scan keeps four matrices per sample: one small scratch region per workgroup
+    G.scratch_stride = ((long)4 * G.ld * D + G.S - 1) / G.S;
+    void* gv;
+    if (ws_get(w, SL_SCRATCH, (size_t)B * G.S * G.scratch_stride * sizeof(cplx), &gv)) return -1;
+    G.scratch = (cplx*)gv;
+  }
+  HIP_TRY(c3p_launch_grad_scan(G, scan_global, st));
+  MidGradArgs g = {};
+  g.tables = p.tables;
+  g.tab_per_sample = a.tab_per_sample;
+  g.signals = G.signals;
+  g.Mb = G.Mb;
+  g.grad = G.grad;
+  g.B = B;
+  g.K = K;
+  g.N = N;
+  g.Dm = D;
+  g.S = (int)S;
+  g.Lmax = a.Lmax;
+  HIP_TRY(c3p_launch_midd_grad(g, st));
+  return 0;
+}
+
 // Supplied generators on the mid-D MFMA kernel (13 <= D <= 40); see run_xg_smalld.
 int run_xg_midd(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, double coef_i, int B, int N, int D,
                 const double* fr_phase, cplx* U_out, cplx* dUs_out, hipStream_t st) {
@@ -1264,6 +1341,12 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
     if (rc < 0) return -1;
     done = (rc == 0);
     if (done) g_last_kernel = C3P_KERNEL_SMALLD;
+  }
+  if (!done && !(flags & C3P_FORCE_GENERIC) && D >= 13 && D <= 40) {
+    const int rc = run_vjp_midd(w, A, st);
+    if (rc < 0) return -1;
+    done = (rc == 0);
+    if (done) g_last_kernel = C3P_KERNEL_MFMA;
   }
   if (!done) {
     long S = 4096 / B;

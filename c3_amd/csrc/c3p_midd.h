@@ -21,6 +21,16 @@ struct MidArgs {
   cplx* dUs_out;
 };
 
+// Backward sweep of the control gradient (c3p_grad.hip for the method)
+struct MidGradArgs {
+  const double* tables;  // as MidArgs
+  int tab_per_sample;
+  const double* signals;  // [B,K,N]
+  const cplx* Mb;         // [B,S,Dm,Dm] adjoint state at the end of each segment
+  double* grad;           // [B,K,N]
+  int B, K, N, Dm, S, Lmax;
+};
+
 struct MidPrepArgs {
   const cplx* h0;
   long h0_bstride;
@@ -38,4 +48,5 @@ bool c3p_midd_geometry(int Dm, int* nig, int* nj, int* w);
 size_t c3p_midd_table_doubles(int Dm, int K);
 size_t c3p_midd_lds_bytes(int Dm, int K, int Lmax);
 hipError_t c3p_launch_midd_chain(const MidArgs& A, hipStream_t st);
+hipError_t c3p_launch_midd_grad(const MidGradArgs& A, hipStream_t st);
 hipError_t c3p_launch_midd_prep(const MidPrepArgs& P, int nsamp, hipStream_t st);

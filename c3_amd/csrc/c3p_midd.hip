@@ -669,6 +669,302 @@ hipError_t launch_t(const MidArgs& A, hipStream_t st) {
   return go(midd_chain_kernel<NIG, NJ, W, false, false>);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward sweep of the control gradient (method in c3p_grad.hip) in the mid-D layout.
+// Four LDS images (value / derivative left and right operands of the pair products) and every tile
+// set in registers: one workgroup per CU (1 wave per SIMD, up to 512 registers).  Per slice 18 + 3s
+// products:  (T, dT) = pair-T18(X~, M);  Z = T^H dT;  grad[k] = <Z, G_k>;  M <- T^H (M T).
+// ---------------------------------------------------------------------------------------------
+template <int NIG, int NJ, int W, int WV>
+__device__ __forceinline__ void midd_grad_body(const MidGradArgs& A, const MidCommon& cm, long chain, double* i0,
+                                               double* i1, double* i2, double* i3, double* red) {
+  using T = WaveTiles<NIG, NJ, W, WV>;
+  constexpr int IMG = MD<NIG, NJ>::ROWS * W, NE = T::NE;
+  typedef TileRegs<T::NBW, T::NSW> Regs;
+  const int D = cm.D, K = cm.K;
+  const int lbig = cm.lbig, lsmall = cm.lsmall;
+  const int rbig = cm.r, rsmall = 4 * cm.b + cm.r;
+  const int cbig = 4 * cm.b + cm.c, csmall = cm.c;
+  const double* tabs = cm.tabs;
+  auto eoff = [&](int e) -> int { return T::off0(e) + (T::is_big(e) ? lbig : lsmall); };
+  auto erow = [&](int e) -> int { return T::row0(e) + (T::is_big(e) ? rbig : rsmall); };
+  auto ecol = [&](int e) -> int { return T::col0(e) + (T::is_big(e) ? cbig : csmall); };
+  auto store_tiles = [&](double* img, const Regs& v) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) img[eoff(e)] = v.get(e);
+  };
+  // image of the conjugate transpose: Yh[2j + p][i] = p ? -Im Z[i][j] : Re Z[i][j]
+  auto store_tiles_H = [&](double* img, const Regs& v) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int row = erow(e), col = ecol(e);
+      const int ci = row >> 1, p = row & 1;
+      if (ci < D && col < D) img[(2 * col + p) * W + ci] = p ? -v.get(e) : v.get(e);
+    }
+  };
+  auto zero = [&](Regs& v) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v.set(e, 0.0);
+  };
+  auto product = [&](const double* imgA, const double* imgB, Regs& acc) { mm_tiles<NIG, NJ, W, WV>(imgA, imgB, cm, acc); };
+  auto is_diag = [&](int e) -> bool {
+    const int row = erow(e), col = ecol(e);
+    return ((row & 1) == 0) && ((row >> 1) == col) && (col < D);
+  };
+  auto comb = [&](Regs& out, double c0, double cx, double c2, double c3, double c6, const Regs& X, const Regs& A2,
+                  const Regs& A3, const Regs& A6) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      double v = cx * X.get(e);
+      v = fma(c2, A2.get(e), v);
+      v = fma(c3, A3.get(e), v);
+      v = fma(c6, A6.get(e), v);
+      v += (c0 != 0.0 && is_diag(e)) ? c0 : 0.0;
+      out.set(e, v);
+    }
+  };
+
+  Regs M;
+  {
+    const double* src = reinterpret_cast<const double*>(A.Mb) + chain * D * D * 2;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int row = erow(e), col = ecol(e);
+      const int ci = row >> 1;
+      M.set(e, (ci < D && col < D) ? src[(ci * D + col) * 2 + (row & 1)] : 0.0);
+    }
+  }
+  for (int t = cm.len - 1; t >= 0; --t) {
+    Regs X, dX;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      X.set(e, cm.scale * tabs[eoff(e)]);
+      dX.set(e, cm.scale * M.get(e));
+    }
+    for (int k = 0; k < K; ++k) {
+      const double ck = cm.scale * cm.sg[k * A.Lmax + t];
+      const double* tk = tabs + (long)(k + 1) * (IMG + 4);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) X.set(e, fma(ck, tk[eoff(e)], X.get(e)));
+    }
+    __syncthreads();  // the previous slice's last product has left the images
+    store_tiles(i0, X);
+    store_tiles(i1, dX);
+    __syncthreads();
+    Regs A2, dA2, A3, dA3, A6, dA6;
+    zero(A2), zero(dA2), zero(A3), zero(dA3), zero(A6), zero(dA6);
+    product(i0, i0, A2);
+    product(i0, i1, dA2);
+    product(i1, i0, dA2);
+    store_tiles(i2, A2);
+    store_tiles(i3, dA2);
+    __syncthreads();
+    product(i0, i2, A3);
+    product(i0, i3, dA3);
+    product(i1, i2, dA3);
+    __syncthreads();
+    store_tiles(i0, A3);
+    store_tiles(i1, dA3);
+    __syncthreads();
+    product(i0, i0, A6);
+    product(i0, i1, dA6);
+    product(i1, i0, dA6);
+    Regs A9, dA9;
+    {
+      Regs B1, dB1, B5, dB5;
+      comb(B1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0, X, A2, A3, A6);
+      comb(dB1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0, dX, dA2, dA3, dA6);
+      comb(B5, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64, X, A2, A3, A6);
+      comb(dB5, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64, dX, dA2, dA3, dA6);
+      __syncthreads();
+      store_tiles(i0, B1);
+      store_tiles(i1, dB1);
+      store_tiles(i2, B5);
+      store_tiles(i3, dB5);
+    }
+    comb(A9, C3P_T18_B03, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63, X, A2, A3, A6);
+    comb(dA9, 0.0, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63, dX, dA2, dA3, dA6);
+    __syncthreads();
+    product(i0, i2, A9);
+    product(i0, i3, dA9);
+    product(i1, i2, dA9);
+    Regs Tm, dT;
+    {
+      Regs L, dL;
+      comb(L, C3P_T18_B02, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62, X, A2, A3, A6);
+      comb(dL, 0.0, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62, dX, dA2, dA3, dA6);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        L.set(e, L.get(e) + A9.get(e));
+        dL.set(e, dL.get(e) + dA9.get(e));
+      }
+      __syncthreads();
+      store_tiles(i0, L);
+      store_tiles(i1, dL);
+      store_tiles(i2, A9);
+      store_tiles(i3, dA9);
+    }
+    comb(Tm, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61, X, A2, A3, A6);
+    comb(dT, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61, dX, dA2, dA3, dA6);
+    __syncthreads();
+    product(i0, i2, Tm);
+    product(i0, i3, dT);
+    product(i1, i2, dT);
+    for (int it = 0; it < cm.ps; ++it) {
+      __syncthreads();
+      store_tiles(i0, Tm);
+      store_tiles(i1, dT);
+      __syncthreads();
+      Regs T2, dT2;
+      zero(T2), zero(dT2);
+      product(i0, i0, T2);
+      product(i0, i1, dT2);
+      product(i1, i0, dT2);
+      Tm = T2;
+      dT = dT2;
+    }
+    // ---- Z = T^H dT, V = M T ----
+    __syncthreads();
+    store_tiles_H(i0, Tm);
+    store_tiles(i1, dT);
+    store_tiles(i2, M);
+    store_tiles(i3, Tm);
+    __syncthreads();
+    Regs Z, V;
+    zero(Z), zero(V);
+    product(i0, i1, Z);
+    product(i2, i3, V);
+    // ---- grad[k] = sum Zh . G~_k h + Re(mu_k conj(tr Z)) ----
+    {
+      double trr = 0.0, tri = 0.0;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int row = erow(e), col = ecol(e);
+        const bool dg = ((row >> 1) == col) && (col < D);
+        const double v = dg ? Z.get(e) : 0.0;
+        if (row & 1)
+          tri += v;
+        else
+          trr += v;
+      }
+      for (int o = 32; o >= 1; o >>= 1) {
+        trr += __shfl_xor(trr, o);
+        tri += __shfl_xor(tri, o);
+      }
+      for (int k = 0; k < K; ++k) {
+        const double* tk = tabs + (long)(k + 1) * (IMG + 4);
+        double part = fma(tk[IMG + 0], trr, tk[IMG + 1] * tri);
+        double dot = 0.0;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) dot = fma(Z.get(e), tk[eoff(e)], dot);
+        for (int o = 32; o >= 1; o >>= 1) dot += __shfl_xor(dot, o);
+        if (cm.lane == 0) red[WV * 16 + k] = dot + part;
+      }
+    }
+    __syncthreads();  // Z / V products done in every wave, partial sums visible
+    if (WV == 0 && cm.lane < K)
+      A.grad[((long)cm.sample * K + cm.lane) * A.N + cm.n0 + t] =
+          red[cm.lane] + red[16 + cm.lane] + red[32 + cm.lane] + red[48 + cm.lane];
+    if (t > 0) {
+      store_tiles(i1, V);
+      __syncthreads();
+      zero(M);
+      product(i0, i1, M);  // M <- T^H (M T)
+    }
+  }
+}
+
+template <int NIG, int NJ, int W>
+__global__ void __launch_bounds__(256, 1) midd_grad_kernel(MidGradArgs A) {
+  using C = MD<NIG, NJ>;
+  constexpr int IMG = C::ROWS * W;
+  const int tid = threadIdx.x;
+  MidCommon cm;
+  cm.lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  cm.r = cm.lane >> 4;
+  cm.b = (cm.lane >> 2) & 3;
+  cm.c = cm.lane & 3;
+  cm.D = A.Dm;
+  cm.nbk = (2 * cm.D + 3) / 4;
+  cm.K = A.K;
+  const int K = A.K;
+  double* i0 = c3p_md_lds;
+  double* i1 = i0 + IMG;
+  double* i2 = i1 + IMG;
+  double* i3 = i2 + IMG;
+  cm.sg = i3 + IMG;
+  __shared__ double red[64];
+  __shared__ double redn[NW];
+  const long chain = blockIdx.x;
+  cm.sample = (int)(chain / A.S);
+  const int seg = (int)(chain - (long)cm.sample * A.S);
+  cm.n0 = (int)(((long)seg * A.N) / A.S);
+  const int n1 = (int)(((long)(seg + 1) * A.N) / A.S);
+  cm.len = n1 - cm.n0;
+  cm.aoff = (4 * cm.b + (cm.c & ~1) + ((cm.c ^ cm.r) & 1)) * W + (cm.r >> 1);
+  cm.boff = cm.r * W + cm.c;
+  cm.lsmall = (4 * cm.b + cm.r) * W + cm.c;
+  cm.lbig = cm.r * W + 4 * cm.b + cm.c;
+  cm.negmask = (((cm.c & 1) == 0) && ((cm.r & 1) == 1)) ? 0x80000000u : 0u;
+  for (int e = tid; e < 4 * IMG; e += 256) c3p_md_lds[e] = 0.0;
+  __syncthreads();
+  cm.tabs = A.tables + (long)(A.tab_per_sample ? cm.sample : 0) * (1 + K) * (IMG + 4);
+  double nrm = cm.tabs[IMG + 2];
+  for (int k = 0; k < K; ++k) {
+    const double* s = A.signals + ((long)cm.sample * K + k) * A.N + cm.n0;
+    double cmax = 0.0;
+    for (int t = tid; t < cm.len; t += 256) {
+      const double v = s[t];
+      cm.sg[k * A.Lmax + t] = v;
+      cmax = fmax(cmax, fabs(v));
+    }
+    for (int o = 32; o >= 1; o >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, o));
+    if (cm.lane == 0) redn[wave] = cmax;
+    __syncthreads();
+    cmax = fmax(fmax(redn[0], redn[1]), fmax(redn[2], redn[3]));
+    __syncthreads();
+    nrm = fma(cmax, cm.tabs[(long)(k + 1) * (IMG + 4) + IMG + 2], nrm);
+  }
+  nrm = md_rfl(nrm);
+  int ps = 0;
+  {
+    double p = C3P_T18_THETA;
+    while (p < nrm && ps < 40) {
+      p *= 2.0;
+      ++ps;
+    }
+  }
+  cm.ps = __builtin_amdgcn_readfirstlane(ps);
+  cm.pr = 0;
+  cm.t18 = 1;
+  cm.scale = ldexp(1.0, -cm.ps);
+  cm.buf0 = i0;
+  cm.buf1 = i1;
+  cm.buf2 = i2;
+  __syncthreads();
+  switch (wave) {
+    case 0: midd_grad_body<NIG, NJ, W, 0>(A, cm, chain, i0, i1, i2, i3, red); break;
+    case 1: midd_grad_body<NIG, NJ, W, 1>(A, cm, chain, i0, i1, i2, i3, red); break;
+    case 2: midd_grad_body<NIG, NJ, W, 2>(A, cm, chain, i0, i1, i2, i3, red); break;
+    default: midd_grad_body<NIG, NJ, W, 3>(A, cm, chain, i0, i1, i2, i3, red); break;
+  }
+}
+
+template <int NIG, int NJ, int W>
+hipError_t launch_grad_t(const MidGradArgs& A, hipStream_t st) {
+  constexpr int IMG = MD<NIG, NJ>::ROWS * W;
+  const size_t lds = (size_t)(4 * IMG + A.K * A.Lmax) * sizeof(double);
+  if (lds > 158 * 1024) return hipErrorInvalidValue;
+  auto kern = midd_grad_kernel<NIG, NJ, W>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((long)A.B * A.S)), dim3(256), lds, st, A);
+  return hipGetLastError();
+}
+
 }  // namespace
 
 // geometry classes: Dm -> (NIG, NJ, W)
@@ -717,4 +1013,17 @@ hipError_t c3p_launch_midd_chain(const MidArgs& A, hipStream_t st) {
 hipError_t c3p_launch_midd_prep(const MidPrepArgs& P, int nsamp, hipStream_t st) {
   hipLaunchKernelGGL(midd_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K))), dim3(256), 0, st, P);
   return hipGetLastError();
+}
+
+hipError_t c3p_launch_midd_grad(const MidGradArgs& A, hipStream_t st) {
+  int nig, nj, w;
+  if (!c3p_midd_geometry(A.Dm, &nig, &nj, &w)) return hipErrorInvalidValue;
+  if (nig == 2 && nj == 4) return launch_grad_t<2, 4, 18>(A, st);
+  if (nig == 3 && nj == 5) return launch_grad_t<3, 5, 22>(A, st);
+  if (nig == 3 && nj == 6) return launch_grad_t<3, 6, 26>(A, st);
+  if (nig == 4 && nj == 7) return launch_grad_t<4, 7, 30>(A, st);
+  if (nig == 4 && nj == 8) return launch_grad_t<4, 8, 34>(A, st);
+  if (nig == 5 && nj == 9) return launch_grad_t<5, 9, 38>(A, st);
+  if (nig == 5 && nj == 10) return launch_grad_t<5, 10, 42>(A, st);
+  return hipErrorInvalidValue;
 }

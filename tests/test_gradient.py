@@ -50,8 +50,6 @@ def test_oracle_infid_cotangent():
 @pytest.mark.parametrize("generic", [False, True])
 @pytest.mark.parametrize("cfg,B,N", [(1, 3, 40), (2, 5, 64), (2, 2, 333), (3, 2, 24), (5, 1, 12)])
 def test_vjp_vs_oracle(prop, cfg, B, N, generic):
-    if generic and cfg > 2:
-        pytest.skip("D > 12 already runs the generic gradient kernels")
     w = make_workload(cfg, B=B, N=N)
     rng = np.random.default_rng(10 + cfg)
     D = w.D
@@ -109,6 +107,31 @@ def test_vjp_small_dims(prop, D):
     g = np.asarray(prop.propagate_batch_vjp(h0, hks, sig, 1e-11, Ubar))
     for b in range(B):
         want = o.pwc_signal_gradient(h0[b], hks, sig[b], 1e-11, Ubar[b])
+        assert np.abs(g[b] - want).max() < 1e-10 * np.abs(want).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [13, 16, 20, 24, 27, 32, 36, 40])
+def test_vjp_mid_dims(prop, D):
+    """every geometry class of the mid-D MFMA backward kernel (strong drive: squarings included)"""
+    from c3_amd import _lib
+
+    rng = np.random.default_rng(D)
+    B, K, N = 2, 3, 19
+
+    def herm():
+        a = rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))
+        return (a + a.conj().T) / 2
+
+    h0 = herm() * (6e11 / D)
+    hks = np.stack([herm() for _ in range(K)])
+    sig = rng.normal(size=(B, K, N)) * 2e9
+    Ubar = rng.normal(size=(B, D, D)) + 1j * rng.normal(size=(B, D, D))
+    ph = rng.uniform(0, 6, size=(B, D))
+    g = np.asarray(prop.propagate_batch_vjp(h0, hks, sig, 1e-11, Ubar, fr_phase=ph))
+    assert _lib.last_kernel() == "mfma"
+    for b in range(B):
+        want = o.pwc_signal_gradient(h0, hks, sig[b], 1e-11, Ubar[b], ph[b])
         assert np.abs(g[b] - want).max() < 1e-10 * np.abs(want).max()
 
 
