@@ -345,6 +345,55 @@ def test_full_size_cfg2_properties(prop):
     assert max(np.linalg.norm(comb[i] - U[i]) for i in range(4)) < 1e-11
 
 
+@pytest.mark.parametrize("cfg", [1, 3, 4, 5])
+def test_full_size_other_configs_properties(prop, cfg):
+    """BASELINE cfg1 / cfg3 / cfg4 / cfg5 at their FULL sizes (B x N = 1 x 200, 4096 x 2000, 512 x 1000
+    Lindblad 81 x 81, 8192 x 5000): size-independent properties -- unitarity (trace preservation and
+    Hermiticity preservation for the Lindblad superoperator), time-axis splitting, invariance under a
+    permutation of the sample axis, bit-reproducibility -- plus spot parity against the oracle."""
+    import torch
+
+    wl = workloads.make_workload(cfg)
+    dev = torch.device("cuda:0")
+    lind = wl.lindblad
+    D = wl.D
+    Dm = D * D if lind else D
+    h0, hks = torch.as_tensor(wl.h0, device=dev), torch.as_tensor(wl.hks, device=dev)
+    col = torch.as_tensor(wl.col_ops, device=dev) if lind else None
+    B = wl.B
+    chunk = 1024  # bounds device memory for the 8192-sample configuration (signals stay on the host)
+    U = np.empty((B, Dm, Dm), dtype=np.complex128)
+    for b0 in range(0, B, chunk):
+        sl = slice(b0, min(B, b0 + chunk))
+        r = prop.propagate_batch(h0, hks, torch.as_tensor(wl.signals[sl], device=dev), wl.dt, col_ops=col, lindbladian=lind)
+        U[sl] = r["U"].cpu().numpy()
+    eye = np.eye(Dm)
+    pick = sorted(set([0, B // 3, B - 1]))
+    if not lind:
+        dev_unit = np.abs(np.einsum("bji,bjk->bik", U.conj(), U) - eye).max()
+        assert dev_unit < 1e-10  # unitarity of every propagator of the batch
+    else:
+        vecI = np.eye(D).reshape(-1)
+        assert np.abs(np.einsum("i,bij->bj", vecI, U) - vecI).max() < 1e-10  # trace preservation
+        # Hermiticity preservation: S vec(rho^+) = vec((S rho)^+)  <=>  S[(ij),(kl)] = conj(S[(ji),(lk)])
+        S4 = U[pick].reshape(len(pick), D, D, D, D)
+        assert np.abs(S4 - np.conj(S4.transpose(0, 2, 1, 4, 3))).max() < 1e-10
+    ref = o.propagate_batch(wl.h0, wl.hks, wl.signals[pick], wl.dt, col_ops=wl.col_ops, lindbladian=lind)
+    assert max(np.linalg.norm(U[b] - ref[i]) for i, b in enumerate(pick)) < 1e-10
+    # splitting the time axis, a permutation of the sample axis, and a bit-identical repeat (first samples)
+    nb = min(B, 8)
+    half = wl.N // 2
+    sig = wl.signals[:nb]
+    full = np.asarray(prop.propagate_batch(wl.h0, wl.hks, sig, wl.dt, col_ops=wl.col_ops, lindbladian=lind)["U"])
+    a = np.asarray(prop.propagate_batch(wl.h0, wl.hks, sig[:, :, :half], wl.dt, col_ops=wl.col_ops, lindbladian=lind)["U"])
+    bb = np.asarray(prop.propagate_batch(wl.h0, wl.hks, sig[:, :, half:], wl.dt, col_ops=wl.col_ops, lindbladian=lind)["U"])
+    assert max(np.linalg.norm(bb[i] @ a[i] - full[i]) for i in range(nb)) < 1e-10
+    assert max(np.linalg.norm(full[i] - U[i]) for i in range(nb)) < 1e-10  # independent of batch size / segmentation
+    perm = np.random.default_rng(0).permutation(nb)
+    again = np.asarray(prop.propagate_batch(wl.h0, wl.hks, sig[perm], wl.dt, col_ops=wl.col_ops, lindbladian=lind)["U"])
+    assert np.array_equal(again, full[perm])  # same plan per sample -> bit-identical
+
+
 class _PMap:
     def __init__(self, model, generator, instructions):
         self.model, self.generator, self.instructions = model, generator, instructions
