@@ -196,7 +196,20 @@ __device__ __forceinline__ void write_rimage(const double (&m)[RD<D>::NB][RD<D>:
   wave_sync();
 }
 
-// acc += IMG * B for real tiles
+// Every matrix of the real path is a polynomial in the real SYMMETRIC Y, hence symmetric: products only
+// compute the tiles on and above the diagonal (6 of 9 at D = 9) and sym_fill mirrors them.
+// lane (r, c) of tile (I, J) holds M[4I + r][4J + c]; its mirror element M[4J + c][4I + r] is held by lane
+// (c, r) of tile (J, I): one in-chain lane swap per lower tile (ds_bpermute).
+template <int D>
+__device__ __forceinline__ void sym_fill(double (&m)[RD<D>::NB][RD<D>::NB], int swap_lane) {
+  constexpr int NB = RD<D>::NB;
+#pragma unroll
+  for (int I = 1; I < NB; ++I)
+#pragma unroll
+    for (int J = 0; J < I; ++J) m[I][J] = __shfl(m[J][I], swap_lane);
+}
+
+// acc += IMG * B for real symmetric results (tiles J >= I only)
 template <int D>
 __device__ __forceinline__ void mm_real(const double* img, int rroff, const double (&zb)[RD<D>::NB][RD<D>::NB],
                                         double (&acc)[RD<D>::NB][RD<D>::NB]) {
@@ -214,12 +227,12 @@ __device__ __forceinline__ void mm_real(const double* img, int rroff, const doub
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
-      for (int J = 0; J < NB; ++J) acc[I][J] = mfma4(ra[K & 1][I], zb[K][J], acc[I][J]);
+      for (int J = I; J < NB; ++J) acc[I][J] = mfma4(ra[K & 1][I], zb[K][J], acc[I][J]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// two products with the same left operand: acc1 += IMG * B1, acc2 += IMG * B2
+// two products with the same left operand: acc1 += IMG * B1, acc2 += IMG * B2 (tiles J >= I only)
 template <int D>
 __device__ __forceinline__ void mm_real2(const double* img, int rroff, const double (&zb1)[RD<D>::NB][RD<D>::NB],
                                          double (&acc1)[RD<D>::NB][RD<D>::NB], const double (&zb2)[RD<D>::NB][RD<D>::NB],
@@ -238,7 +251,7 @@ __device__ __forceinline__ void mm_real2(const double* img, int rroff, const dou
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
-      for (int J = 0; J < NB; ++J) {
+      for (int J = I; J < NB; ++J) {
         acc1[I][J] = mfma4(ra[K & 1][I], zb1[K][J], acc1[I][J]);
         acc2[I][J] = mfma4(ra[K & 1][I], zb2[K][J], acc2[I][J]);
       }
@@ -388,6 +401,20 @@ __device__ __forceinline__ void build_tables(const SmallArgs& A, int sample, dou
     if (lane < D)
       for (int i = 0; i < D; ++i) cs += hypot(out[(2 * i) * W + lane], out[(2 * i + 1) * W + lane]);
     const double nrm = wave_max64(cs);
+    // the real fast path also needs Y = -Im G symmetric (Hermitian input).  Dressed operators V^T H V are
+    // symmetric only to rounding (measured 5e-16 relative), so asymmetry below 1e-14 ||G|| counts as none;
+    // anything larger is folded into the flag and sends the sample to the complex path.
+    double asym = 0.0;
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const int e = lane + 64 * q;
+      if (e < D * D) {
+        const int i = e / D, j = e - i * D;
+        asym = fmax(asym, fabs(gi[q] - out[(2 * j + 1) * W + i]));
+      }
+    }
+    asym = wave_max64(asym);
+    if (asym > 1e-14 * nrm) remax = fmax(remax, asym);
     remax = wave_max64(remax);
     if (lane == 0) {
       out[MAT + 0] = mur;
@@ -544,6 +571,7 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
       constexpr int WR = C::WR;
       const int rroff = lp.b * IMG + lp.c * WR + lp.r;  // A-layout read of a row-major real image
       const int rwoff = lp.b * IMG + lp.r * WR + lp.c;  // D-layout write of a real image
+      const int swap_lane = 16 * lp.c + 4 * lp.b + lp.r;  // (r, c) <-> (c, r) inside the chain's block
       int yo[NB];        // Im rows of the half-image tables hold -Y
       double ymask[NB];
 #pragma unroll
@@ -587,9 +615,12 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
 #pragma unroll
           for (int J = 0; J < NB; ++J) W1[I][J] = W2[I][J] = W3[I][J] = 0.0;
         mm_real<D>(img, rroff + YOFF, Y, W1);  // W = Y^2
+        sym_fill<D>(W1, swap_lane);
         write_rimage<D>(W1, img, rwoff);
         mm_real<D>(img, rroff, W1, W2);  // W^2
+        sym_fill<D>(W2, swap_lane);
         mm_real<D>(img, rroff, W2, W3);  // W^3
+        sym_fill<D>(W3, swap_lane);
         write_rimage<D>(W3, img, rwoff);
         // cos: c_j = (-1)^j / (2j)!;  sin / Y: s_j = (-1)^j / (2j+1)!;  both by Horner in W^3, the two
         // independent chains share every A-fragment read
@@ -598,14 +629,19 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
         rcomb<D, false>(acc, -c3p_inv_fact[6], c3p_inv_fact[8], -c3p_inv_fact[10], 0.0, W1, W2, W3, lp);
         rcomb<D, false>(acs, -c3p_inv_fact[7], c3p_inv_fact[9], -c3p_inv_fact[11], 0.0, W1, W2, W3, lp);
         mm_real2<D>(img, rroff, Cm, acc, Sp, acs);
+        sym_fill<D>(acc, swap_lane);
+        sym_fill<D>(acs, swap_lane);
         rcomb<D, false>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], 0.0, W1, W2, W3, lp);
         rcomb<D, false>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], 0.0, W1, W2, W3, lp);
         mm_real2<D>(img, rroff, acc, Cm, acs, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
+        sym_fill<D>(Cm, swap_lane);
+        sym_fill<D>(Sp, swap_lane);
 #pragma unroll
         for (int I = 0; I < NB; ++I)
 #pragma unroll
           for (int J = 0; J < NB; ++J) acc[I][J] = 0.0;
         mm_real<D>(img, rroff + YOFF, Sp, acc);  // acc = sin Y
+        sym_fill<D>(acc, swap_lane);
         // ---- E = cos Y - i sin Y as the chain's left-operand image (half image: rows 2i / 2i+1 = Re / Im) ----
         wave_sync();
 #pragma unroll
@@ -1011,8 +1047,13 @@ __global__ void __launch_bounds__(64) smalld_prep_kernel(PrepArgs P) {
     out[MAT + 1] = mu[1];
     out[MAT + 2] = nrm;
     // 0 exactly when the Hamiltonian is real (the generator is purely imaginary): selects the real fast path
-    double remax = 0;
-    for (int e = 0; e < D * D; ++e) remax = fmax(remax, fabs(g[2 * e]));
+    double remax = 0, asym = 0;  // real AND symmetric (to rounding: see build_tables)
+    for (int e = 0; e < D * D; ++e) {
+      const int i = e / D, j = e - i * D;
+      remax = fmax(remax, fabs(g[2 * e]));
+      asym = fmax(asym, fabs(g[2 * e + 1] - g[2 * (j * D + i) + 1]));
+    }
+    if (asym > 1e-14 * nrm) remax = fmax(remax, asym);
     out[MAT + 3] = P.lindblad ? 1.0 : remax;
   }
 }

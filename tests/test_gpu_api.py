@@ -147,6 +147,14 @@ def test_real_hamiltonian_fast_path(prop, D, strength):
         ref = np.exp(1j * ph[b])[:, None] * o.tf_matmul_left(dref)
         assert np.linalg.norm(np.asarray(r["U"][b]) - ref) < 1e-10
         assert np.abs(np.asarray(r["dUs"][b]) - dref).max() < 1e-12
+    # real but NOT symmetric (non-Hermitian) drift: the symmetric shortcut of the fast path must not be taken
+    hn = h0[0].copy()
+    hn[0, D - 1] += 3e9
+    r3 = prop.propagate_batch(hn, hks, sig, dt)
+    for b in range(B):
+        Xs = -1j * dt * (hn[None] + np.einsum("kn,kij->nij", sig[b], hks))
+        ref3 = o.tf_matmul_left(np.stack([sla.expm(x) for x in Xs]))
+        assert np.linalg.norm(np.asarray(r3["U"][b]) - ref3) < 1e-10 * max(1.0, np.linalg.norm(ref3))
     hkc = hks.copy()
     hkc[1, 0, 1] += 0.3j
     hkc[1, 1, 0] -= 0.3j
