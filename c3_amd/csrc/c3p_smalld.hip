@@ -259,6 +259,48 @@ __device__ __forceinline__ void mm_real2(const double* img, int rroff, const dou
   }
 }
 
+// All A fragments of a real image (NB x NB doubles per lane): loaded once when the same left operand
+// serves two consecutive products (W for W^2 and W^3; W^3 for both Horner steps).
+template <int D>
+__device__ __forceinline__ void load_frags(const double* img, int rroff, double (&fr)[RD<D>::NB][RD<D>::NB]) {
+  using C = SD<D>;
+  constexpr int NB = RD<D>::NB;
+#pragma unroll
+  for (int K = 0; K < NB; ++K)
+#pragma unroll
+    for (int I = 0; I < NB; ++I) fr[K][I] = lds_ld(img + rroff + I * 4 * C::WR + K * 4);
+}
+template <int D>
+__device__ __forceinline__ void mm_frag(const double (&fr)[RD<D>::NB][RD<D>::NB], const double (&zb)[RD<D>::NB][RD<D>::NB],
+                                        double (&acc)[RD<D>::NB][RD<D>::NB]) {
+  constexpr int NB = RD<D>::NB;
+#pragma unroll
+  for (int K = 0; K < NB; ++K) {
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = I; J < NB; ++J) acc[I][J] = mfma4(fr[K][I], zb[K][J], acc[I][J]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <int D>
+__device__ __forceinline__ void mm_frag2(const double (&fr)[RD<D>::NB][RD<D>::NB], const double (&zb1)[RD<D>::NB][RD<D>::NB],
+                                         double (&acc1)[RD<D>::NB][RD<D>::NB], const double (&zb2)[RD<D>::NB][RD<D>::NB],
+                                         double (&acc2)[RD<D>::NB][RD<D>::NB]) {
+  constexpr int NB = RD<D>::NB;
+#pragma unroll
+  for (int K = 0; K < NB; ++K) {
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = I; J < NB; ++J) {
+        acc1[I][J] = mfma4(fr[K][I], zb1[K][J], acc1[I][J]);
+        acc2[I][J] = mfma4(fr[K][I], zb2[K][J], acc2[I][J]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // out = c0 I + c1 W + c2 W2 (+ c3 W3)
 template <int D, bool WITH3>
 __device__ __forceinline__ void rcomb(double (&out)[RD<D>::NB][RD<D>::NB], double c0, double c1, double c2, double c3,
@@ -617,23 +659,26 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
         mm_real<D>(img, rroff + YOFF, Y, W1);  // W = Y^2
         sym_fill<D>(W1, swap_lane);
         write_rimage<D>(W1, img, rwoff);
-        mm_real<D>(img, rroff, W1, W2);  // W^2
+        RMat fr;
+        load_frags<D>(img, rroff, fr);
+        mm_frag<D>(fr, W1, W2);  // W^2
         sym_fill<D>(W2, swap_lane);
-        mm_real<D>(img, rroff, W2, W3);  // W^3
+        mm_frag<D>(fr, W2, W3);  // W^3
         sym_fill<D>(W3, swap_lane);
         write_rimage<D>(W3, img, rwoff);
+        load_frags<D>(img, rroff, fr);
         // cos: c_j = (-1)^j / (2j)!;  sin / Y: s_j = (-1)^j / (2j+1)!;  both by Horner in W^3, the two
         // independent chains share every A-fragment read
         rcomb<D, true>(Cm, c3p_inv_fact[12], -c3p_inv_fact[14], c3p_inv_fact[16], -c3p_inv_fact[18], W1, W2, W3, lp);
         rcomb<D, false>(Sp, c3p_inv_fact[13], -c3p_inv_fact[15], c3p_inv_fact[17], 0.0, W1, W2, W3, lp);
         rcomb<D, false>(acc, -c3p_inv_fact[6], c3p_inv_fact[8], -c3p_inv_fact[10], 0.0, W1, W2, W3, lp);
         rcomb<D, false>(acs, -c3p_inv_fact[7], c3p_inv_fact[9], -c3p_inv_fact[11], 0.0, W1, W2, W3, lp);
-        mm_real2<D>(img, rroff, Cm, acc, Sp, acs);
+        mm_frag2<D>(fr, Cm, acc, Sp, acs);
         sym_fill<D>(acc, swap_lane);
         sym_fill<D>(acs, swap_lane);
         rcomb<D, false>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], 0.0, W1, W2, W3, lp);
         rcomb<D, false>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], 0.0, W1, W2, W3, lp);
-        mm_real2<D>(img, rroff, acc, Cm, acs, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
+        mm_frag2<D>(fr, acc, Cm, acs, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
         sym_fill<D>(Cm, swap_lane);
         sym_fill<D>(Sp, swap_lane);
 #pragma unroll
