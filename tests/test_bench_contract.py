@@ -1,0 +1,37 @@
+"""The driver's bench.py contract: one JSON line with the agreed keys (GPU box only)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_json_line(lib):
+    from c3_amd import _lib
+
+    _lib.require_gpu()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--check"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["metric"] == "full-gate propagators/s" and d["unit"] == "propagators/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "cfg2" in d["config"]["workload"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert set(r) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert 0.0 < r["frac"] < 1.5
+    c = d["cpu_baseline"]
+    assert set(c) >= {"value", "unit", "cores", "kind", "sample"} and c["kind"] in ("reference", "port") and c["cores"] >= 1
+    assert abs(d["value"] - 256 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
+    assert d["max_fro_err_vs_oracle"] < 1e-10
