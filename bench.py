@@ -188,10 +188,13 @@ def main():
         f_prop = algorithmic_flops_per_prop(wl, c3_oracle)
         achieved = f_prop * B / (kernel_ms * 1e-3) / 1e12
         traffic = None
+        issued = None
         tfile = os.path.join(ROOT, "profiles", "r01", "traffic.json")
         if os.path.exists(tfile) and args.batch is None and args.slices is None and not args.generic:
             try:
-                traffic = json.load(open(tfile)).get(f"cfg{args.config}", {}).get("bytes_per_launch")
+                prof = json.load(open(tfile)).get(f"cfg{args.config}", {})
+                traffic = prof.get("bytes_per_launch")
+                issued = prof.get("issued_mfma_flop_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -225,6 +228,8 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_TFLOPS,
                 "traffic": traffic,
+                "issued_flop_per_launch": issued,
+                "algorithmic_flop_per_launch": f_prop * B,
                 "kernel": f"chain kernel ({kernel_name})",
                 "kernel_ms": kernel_ms,
                 "algorithmic_flop_per_propagator": f_prop,
