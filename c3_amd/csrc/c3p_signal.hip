@@ -62,6 +62,22 @@ __device__ double shape_val(int shape, double t, const EnvP& p) {
     }
     case C3P_ENV_COSINE:
       return 0.5 * (1 - cos(2 * M_PI * t / p.t_final));
+    case C3P_ENV_GAUSSIAN_SIGMA:
+    case C3P_ENV_GAUSSIAN: {
+      const double T = p.t_final;
+      const double sg = shape == C3P_ENV_GAUSSIAN_SIGMA ? p.sigma : T / 6;
+      const double u = t - T / 2;
+      const double offset = exp(-(T * T) / (8 * sg * sg));
+      const double norm = sqrt(2 * M_PI * sg * sg) * erf(T / (sqrt(8.0) * sg)) - T * offset;
+      return (exp(-(u * u) / (2 * sg * sg)) - offset) / norm;
+    }
+    case C3P_ENV_TRAPEZOID: {
+      const double w = p.risefall * 2.5;
+      double env = 1.0;
+      if (t <= w) env = t / w;
+      if (t >= p.t_final - w) env = (p.t_final - t) / w;
+      return env;
+    }
     default:
       return 0.0;
   }
@@ -83,6 +99,22 @@ __device__ double shape_der(int shape, double t, const EnvP& p) {
     case C3P_ENV_COSINE: {
       const double w = 2 * M_PI / p.t_final;
       return 0.5 * w * sin(w * t);
+    }
+    case C3P_ENV_GAUSSIAN_SIGMA:
+    case C3P_ENV_GAUSSIAN: {
+      const double T = p.t_final;
+      const double sg = shape == C3P_ENV_GAUSSIAN_SIGMA ? p.sigma : T / 6;
+      const double u = t - T / 2;
+      const double offset = exp(-(T * T) / (8 * sg * sg));
+      const double norm = sqrt(2 * M_PI * sg * sg) * erf(T / (sqrt(8.0) * sg)) - T * offset;
+      return -u / (sg * sg) * exp(-(u * u) / (2 * sg * sg)) / norm;
+    }
+    case C3P_ENV_TRAPEZOID: {
+      const double w = p.risefall * 2.5;
+      double d = 0.0;
+      if (t <= w) d = 1.0 / w;
+      if (t >= p.t_final - w) d = -1.0 / w;
+      return d;
     }
     default:
       return 0.0;

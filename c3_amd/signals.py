@@ -25,6 +25,9 @@ ENV_SHAPES = {
     "flattop": 3,
     "flattop_risefall": 4,
     "cosine": 5,
+    "gaussian_sigma": 6,
+    "gaussian": 7,
+    "trapezoid": 8,
 }
 ENV_SLOTS = {
     "amp": 0,

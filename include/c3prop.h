@@ -166,7 +166,7 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
  * (Instruction.get_awg_signal c3/signal/gates.py:341-370, Envelope/EnvelopeDrag
  * c3/signal/pulse.py:88-180, Device.create_ts c3/generator/devices.py:72-122, DigitalToAnalog :306-351,
  * Mixer :914-939, LO :1073-1130 noiseless branch, VoltsToHertz :203-221, envelope shapes
- * c3/libraries/envelopes.py:26,195,228,254,421,470).  A batch is described by B x K x E envelope
+ * c3/libraries/envelopes.py:26,195,201,228,254,374,401,421,470).  A batch is described by B x K x E envelope
  * parameter rows instead of B x K x N samples:
  *   signals[b,k,n] = v2hz * (cos(w t_n) I(t_n) + sin(w t_n) Q(t_n)),
  *   I + iQ = nearest-neighbour upsampling of sum_e amp_e env_e(t - t0_e) exp(i (xy_e - fo_e (t - t0_e)))
@@ -184,7 +184,10 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
 #define C3P_ENV_FLATTOP 3
 #define C3P_ENV_FLATTOP_RISEFALL 4
 #define C3P_ENV_COSINE 5
-#define C3P_ENV_NSHAPES 6
+#define C3P_ENV_GAUSSIAN_SIGMA 6 /* envelopes.py:374-398 */
+#define C3P_ENV_GAUSSIAN 7       /* envelopes.py:401-418: sigma = t_final / 6 */
+#define C3P_ENV_TRAPEZOID 8      /* envelopes.py:201-225 */
+#define C3P_ENV_NSHAPES 9
 
 #define C3P_ENV_AMP 0
 #define C3P_ENV_XY_ANGLE 1

@@ -1046,6 +1046,9 @@ ENV_GAUSSIAN_NONORM = 2  # envelopes.py:470-487
 ENV_FLATTOP = 3  # envelopes.py:254-279
 ENV_FLATTOP_RISEFALL = 4  # envelopes.py:228-251
 ENV_COSINE = 5  # envelopes.py:421-438
+ENV_GAUSSIAN_SIGMA = 6  # envelopes.py:374-398 (area-normalised, offset removed)
+ENV_GAUSSIAN = 7  # envelopes.py:401-418 (gaussian_sigma with sigma = t_final / 6)
+ENV_TRAPEZOID = 8  # envelopes.py:201-225
 
 
 def create_ts(t_start: float, t_end: float, resolution: float) -> np.ndarray:
@@ -1078,6 +1081,21 @@ def envelope_shape(shape: int, t, p: Dict) -> np.ndarray:
         return (1 + erf((t - t_up) / rf)) / 2 * (1 + erf((-t + t_down) / rf)) / 2
     if shape == ENV_COSINE:
         return 0.5 * (1 - np.cos(2 * np.pi * t / p["t_final"]))
+    if shape in (ENV_GAUSSIAN_SIGMA, ENV_GAUSSIAN):
+        from scipy.special import erf
+
+        T = p["t_final"]
+        sigma = p["sigma"] if shape == ENV_GAUSSIAN_SIGMA else T / 6
+        gauss = np.exp(-((t - T / 2) ** 2) / (2 * sigma**2))
+        offset = np.exp(-(T**2) / (8 * sigma**2))
+        norm = np.sqrt(2 * np.pi * sigma**2) * erf(T / (np.sqrt(8) * sigma)) - T * offset
+        return (gauss - offset) / norm
+    if shape == ENV_TRAPEZOID:
+        rf, T = p["risefall"], p["t_final"]
+        env = np.ones_like(t)
+        env = np.where(t <= rf * 2.5, t / (rf * 2.5), env)
+        env = np.where(t >= T - rf * 2.5, (T - t) / (rf * 2.5), env)
+        return env
     raise ValueError(f"unknown envelope shape {shape}")
 
 
@@ -1099,6 +1117,20 @@ def envelope_shape_der(shape: int, t, p: Dict) -> np.ndarray:
     if shape == ENV_COSINE:
         w = 2 * np.pi / p["t_final"]
         return 0.5 * w * np.sin(w * t)
+    if shape in (ENV_GAUSSIAN_SIGMA, ENV_GAUSSIAN):
+        from scipy.special import erf
+
+        T = p["t_final"]
+        sigma = p["sigma"] if shape == ENV_GAUSSIAN_SIGMA else T / 6
+        offset = np.exp(-(T**2) / (8 * sigma**2))
+        norm = np.sqrt(2 * np.pi * sigma**2) * erf(T / (np.sqrt(8) * sigma)) - T * offset
+        return -(t - T / 2) / sigma**2 * np.exp(-((t - T / 2) ** 2) / (2 * sigma**2)) / norm
+    if shape == ENV_TRAPEZOID:
+        rf, T = p["risefall"], p["t_final"]
+        d = np.zeros_like(t)
+        d = np.where(t <= rf * 2.5, 1.0 / (rf * 2.5), d)
+        d = np.where(t >= T - rf * 2.5, -1.0 / (rf * 2.5), d)
+        return d
     raise ValueError(f"unknown envelope shape {shape}")
 
 

@@ -45,7 +45,7 @@ def test_oracle_reproduces_tunable_coupler_awg(golden_dir):
     assert np.abs(I - z["tc_awg_I"]).max() < 1e-15 and np.abs(Q - z["tc_awg_Q"]).max() < 1e-15
 
 
-@pytest.mark.parametrize("shape", [o.ENV_GAUSSIAN_NONORM, o.ENV_FLATTOP, o.ENV_FLATTOP_RISEFALL, o.ENV_COSINE])
+@pytest.mark.parametrize("shape", [o.ENV_GAUSSIAN_NONORM, o.ENV_FLATTOP, o.ENV_FLATTOP_RISEFALL, o.ENV_COSINE, o.ENV_GAUSSIAN_SIGMA, o.ENV_GAUSSIAN, o.ENV_TRAPEZOID])
 def test_oracle_shape_derivative(shape):
     p = dict(t_final=20e-9, sigma=4e-9, t_up=3e-9, t_down=16e-9, risefall=2e-9)
     t = np.linspace(0.5e-9, 19.5e-9, 41)
@@ -109,10 +109,11 @@ def _oracle_batch(channels_b, lo, v2hz, t0, t1, awg_res, sim_res):
 
 def _random_problem(rng, B, T):
     names = ["gaussian_nonorm", "flattop", "flattop_risefall", "cosine", "rect", "no_drive"]
-    K = 3
+    K = 5
     # the shape table is shared by the batch; parameters vary per sample
-    layout = [[names[0], names[1]], [names[2], names[3]], [names[4], names[5]]]
-    flags = [[(True, True), (False, True)], [(True, False), (False, True)], [(False, False), (False, False)]]
+    layout = [[names[0], names[1]], [names[2], names[3]], [names[4], names[5]], ["gaussian_sigma", "trapezoid"], ["gaussian", "gaussian_sigma"]]
+    flags = [[(True, True), (False, True)], [(True, False), (False, True)], [(False, False), (False, False)],
+             [(True, True), (False, True)], [(False, True), (True, False)]]
     channels_b = []
     for b in range(B):
         chans = []
@@ -201,7 +202,7 @@ def test_synthesis_vjp_vs_oracle(prop, device_resident):
     env, shapes = _pack_batch(channels_b)
     carrier = np.stack([lo, v2hz], axis=-1)
     N = sg.slice_num(0.0, T, sim_res)
-    gs = rng.normal(size=(B, 3, N))
+    gs = rng.normal(size=(B, 5, N))
     if device_resident:
         import torch
 
@@ -210,7 +211,7 @@ def test_synthesis_vjp_vs_oracle(prop, device_resident):
     else:
         genv, gcar = sg.synthesize_signals_vjp(env, shapes, carrier, 0.0, T, awg_res, sim_res, gs)
     for b in range(B):
-        for k in range(3):
+        for k in range(5):
             oc = [dict(c, shape=sg.ENV_SHAPES[c["shape"]]) for c in channels_b[b][k]]
             want, wcar = o.generate_signal_vjp(oc, lo[b][k], v2hz[b][k], 0.0, T, awg_res, sim_res, gs[b, k])
             for e, wg in enumerate(want):
