@@ -400,6 +400,7 @@ int run_vjp_midd(DeviceWs* w, GradArgs& G, hipStream_t st) {
   g.signals = G.signals;
   g.Mb = G.Mb;
   g.grad = G.grad;
+  g.zout = G.zout;
   g.B = B;
   g.K = K;
   g.N = N;
@@ -553,6 +554,7 @@ int run_vjp_smalld(DeviceWs* w, GradArgs& G, hipStream_t st) {
   g.signals = G.signals;
   g.Mb = G.Mb;
   g.grad = G.grad;
+  g.zout = G.zout;
   g.B = B;
   g.K = K;
   g.N = N;
@@ -1283,7 +1285,8 @@ int c3p_synth_signals(const double* env_params, const int32_t* env_shapes, const
 
 int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride,
                         const double* signals, double dt, int B, int K, int N, int D, int flags,
-                        const double* fr_phase, const void* U_bar, double* grad_signals, void* stream) {
+                        const double* fr_phase, const void* U_bar, double* grad_signals, void* gen_bar_out,
+                        void* stream) {
   if (B < 0 || K <= 0 || N <= 0 || D <= 0) return fail("bad sizes B=%d K=%d N=%d D=%d", B, K, N, D);
   if (D > 64) return fail("gradient kernels support D <= 64, got %d", D);
   if (flags & (C3P_PER_SLICE_H | C3P_ORDER_RIGHT)) return fail("c3p_pwc_unitary_vjp: unsupported flag");
@@ -1297,6 +1300,7 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
   Stage sg{w, st};
   const void *d_h0 = h0, *d_hks = hks, *d_sig = signals, *d_ph = fr_phase, *d_ub = U_bar;
   void* d_grad = grad_signals;
+  void* d_zout = gen_bar_out;
   if (flags & C3P_HOST_PTRS) {
     // the adjoint recurrence M_n = dU_n^H M_{n+1} dU_n needs unitary slices: Hermitian generators
     const cplx* hh[2] = {(const cplx*)h0, (const cplx*)hks};
@@ -1318,6 +1322,7 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
     if (sg.in(U_bar, (size_t)B * D * D * cs, &d_ub)) return -1;
     if (fr_phase && sg.in(fr_phase, (size_t)B * D * sizeof(double), &d_ph)) return -1;
     if (sg.out(grad_signals, (size_t)B * K * N * sizeof(double), &d_grad)) return -1;
+    if (gen_bar_out && sg.out(gen_bar_out, (size_t)B * N * D * D * cs, &d_zout)) return -1;
   }
   GradArgs A = {};
   A.h0 = (const cplx*)d_h0;
@@ -1334,6 +1339,7 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
   A.D = D;
   A.ld = D | 1;
   A.grad = (double*)d_grad;
+  A.zout = (cplx*)d_zout;
   if (record_start(w, st)) return -1;
   bool done = false;
   if (!(flags & C3P_FORCE_GENERIC) && D <= kSmallDLimit && c3p_smalld_supported(D) && K <= 8) {

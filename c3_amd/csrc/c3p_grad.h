@@ -16,6 +16,7 @@ struct GradArgs {
   cplx* seg;     // [B,S,D,D] segment products (no frame rotation)
   cplx* Mb;      // [B,S,D,D] adjoint state at the END of each segment
   double* grad;  // [B,K,N]
+  cplx* zout;    // [B,N,D,D] or null: Z_n = dU_n^H L(X_n, M_{n+1}), the cotangent of the generator G_n = -i dt H_n
   cplx* scratch;  // GLOBAL variant: scratch_stride elements per workgroup
   long scratch_stride;
 };

@@ -393,6 +393,7 @@ __global__ void __launch_bounds__(256) grad_bwd_kernel(GradArgs A) {
     __syncthreads();
     t18_pair<GLOBAL, true>(M, q, s, D, ld, tid, nt);  // T = e^{-mu} dU_n, dT = e^{-mu} L(X_n, M_{n+1})
     gmm<GLOBAL, false, true, false>(M, bZ, q.T, q.dT, D, ld, tid, nt);  // Z = dU^H L (the shift cancels)
+    if (A.zout != nullptr) copy_out(M, A.zout + ((long)b * A.N + n) * D * D, bZ, D, ld, tid, nt);
     // grad[k,n] = Re <Z, -i dt hk> = dt sum (Zx hk_y - Zy hk_x)
     for (int k = 0; k < A.K; ++k) {
       double part = 0.0;

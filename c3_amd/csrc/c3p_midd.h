@@ -28,6 +28,7 @@ struct MidGradArgs {
   const double* signals;  // [B,K,N]
   const cplx* Mb;         // [B,S,Dm,Dm] adjoint state at the end of each segment
   double* grad;           // [B,K,N]
+  cplx* zout;             // [B,N,Dm,Dm] or null: Z_n, the cotangent of G_n = -i dt H_n
   int B, K, N, Dm, S, Lmax;
 };
 

@@ -834,6 +834,15 @@ __device__ __forceinline__ void midd_grad_body(const MidGradArgs& A, const MidCo
     zero(Z), zero(V);
     product(i0, i1, Z);
     product(i2, i3, V);
+    if (A.zout != nullptr) {  // per-slice cotangent of the generator G_n = -i dt H_n
+      double* dst = reinterpret_cast<double*>(A.zout) + ((long)cm.sample * A.N + cm.n0 + t) * D * D * 2;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int row = erow(e), col = ecol(e);
+        const int ci = row >> 1;
+        if (ci < D && col < D) dst[(ci * D + col) * 2 + (row & 1)] = Z.get(e);
+      }
+    }
     // ---- grad[k] = sum Zh . G~_k h + Re(mu_k conj(tr Z)) ----
     {
       double trr = 0.0, tri = 0.0;

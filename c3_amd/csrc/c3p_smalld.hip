@@ -1335,6 +1335,10 @@ __global__ void __launch_bounds__(64, 1) smalld_grad_kernel(SmallGradArgs A) {
       Mat Z;
       mat_zero<D>(Z);
       mm_img<D>(img0, roff, negmask, dT, Z);
+      if (A.zout != nullptr) {  // per-slice cotangent of the generator G_n = -i dt H_n
+        double* dst = reinterpret_cast<double*>(A.zout) + ((long)sample * A.N + n0 + (act ? t : 0)) * D * D * 2;
+        store_plain<D>(Z, dst, 1.0, 0.0, nullptr, lp, act);
+      }
       double trr = 0.0, tri = 0.0;
 #pragma unroll
       for (int I = 0; I < NBI; ++I)

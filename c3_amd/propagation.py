@@ -202,13 +202,17 @@ def propagate_batch(
     return {"U": U, "dUs": dUs}
 
 
-def propagate_batch_vjp(h0, hks, signals, dt: float, U_bar, *, fr_phase=None, force_generic: bool = False):
+def propagate_batch_vjp(h0, hks, signals, dt: float, U_bar, *, fr_phase=None, force_generic: bool = False, want_model_grads: bool = False):
     """Vector-Jacobian product of `propagate_batch` (unitary, branch A) w.r.t. the control samples.
 
     The reference tapes the goal function (optimizers/optimizer.py:206-216) and lets TensorFlow
     differentiate propagation.py:426-440 + tf_utils.py:144-193; here the adjoint sweep runs on the
     device.  With d loss = Re sum conj(U_bar) dU, returns d loss / d signals as f64 [B,K,N].
     `U_bar` [B,D,D] for unitary_infid / average_infid comes from `fidelities.*_cotangent`.
+
+    With `want_model_grads` returns `(grad_signals, grad_h0 [B,D,D], grad_hks [B,K,D,D])`: the cotangents of the
+    Hamiltonians themselves (d loss = Re sum conj(grad_h) dh), contracted from the per-slice generator
+    cotangents Z[b,n] -- what a model-parameter fit differentiates (optimizers/modellearning.py:300-341).
     """
     call = _Call(h0, hks, signals, U_bar, fr_phase)
     h0 = call.c128(h0)
@@ -233,12 +237,23 @@ def propagate_batch_vjp(h0, hks, signals, dt: float, U_bar, *, fr_phase=None, fo
         grad = call.torch.empty((B, K, N), dtype=call.torch.float64, device=call.dev)
     else:
         grad = np.empty((B, K, N), dtype=np.float64)
+    Z = call.empty((B, N, D, D)) if want_model_grads else None
     _lib.check(
         _lib.load().c3p_pwc_unitary_vjp(
-            _ptr(h0), h0_bs, _ptr(hks), hk_bs, _ptr(signals), float(dt), B, K, N, D, call.flags | (_lib.FORCE_GENERIC if force_generic else 0), _ptr(fr_phase), _ptr(U_bar), _ptr(grad), call.stream
+            _ptr(h0), h0_bs, _ptr(hks), hk_bs, _ptr(signals), float(dt), B, K, N, D, call.flags | (_lib.FORCE_GENERIC if force_generic else 0), _ptr(fr_phase), _ptr(U_bar), _ptr(grad), _ptr(Z), call.stream
         )
     )
-    return grad
+    if not want_model_grads:
+        return grad
+    # G_n = -i dt (h0 + sum_k c_k(n) hk)  =>  h0_bar = conj(-i dt) sum_n Z_n,  hk_bar = conj(-i dt) sum_n c_k(n) Z_n
+    if call.device:
+        t = call.torch
+        g0 = (1j * dt) * Z.sum(dim=1)
+        gk = (1j * dt) * t.einsum("bkn,bnij->bkij", signals.to(t.complex128), Z)
+    else:
+        g0 = (1j * dt) * Z.sum(axis=1)
+        gk = (1j * dt) * np.einsum("bkn,bnij->bkij", signals, Z)
+    return grad, g0, gk
 
 
 # --------------------------------------------------------------------------

@@ -157,10 +157,14 @@ int c3p_rk4_unitary(const void* h0, const void* hks, const double* signals, cons
  *   grad_signals[b,k,n] = d loss / d signals[b,k,n]      (exact: Frechet derivative of every slice)
  *   U_bar c128 [B,D,D]; grad_signals f64 [B,K,N]; other arguments as c3p_pwc_unitary (branch A only,
  *   Hermitian h0 / hks: the adjoint sweep uses the unitarity of the slices; checked for host pointers).
+ *   gen_bar_out c128 [B,N,D,D] or NULL: Z[b,n], the cotangent of the slice generator G_n = -i dt H_n
+ *   (d loss = Re sum conj(Z) dG); the gradient w.r.t. MODEL parameters follows by contraction, e.g.
+ *   d loss / d h0 = i dt sum_n Z[b,n] (what ModelLearning differentiates, c3/optimizers/modellearning.py:300-341).
  */
 int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride,
                         const double* signals, double dt, int B, int K, int N, int D, int flags,
-                        const double* fr_phase, const void* U_bar, double* grad_signals, void* stream);
+                        const double* fr_phase, const void* U_bar, double* grad_signals, void* gen_bar_out,
+                        void* stream);
 
 /* Control-signal synthesis for the standard drive line LO + AWG -> DAC -> Mixer -> VoltsToHertz
  * (Instruction.get_awg_signal c3/signal/gates.py:341-370, Envelope/EnvelopeDrag
