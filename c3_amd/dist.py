@@ -106,3 +106,33 @@ def propagate_batch_sharded(
     if not gather or world == 1:
         return {"U": U_local, "bounds": (lo, hi)}
     return {"U": gather_slabs(U_local, B, group), "bounds": (lo, hi)}
+
+
+def robust_goal_sharded(goal_and_grad: Callable, B: int, *, group=None):
+    """Mean goal and mean gradient over B noise instances sharded across the ranks -- the multi-GPU form of
+    `OptimalControlRobust.goal_run_with_grad` (optimizers/optimalcontrol_robust.py:49-70), whose serial loop
+    averages goals and gradients.  `goal_and_grad(lo, hi)` evaluates the rank's instances [lo, hi) and returns
+    `(goals [hi-lo], grads [hi-lo, ...])` (on the GPU box: `optimal_control.goal_run_with_grad` on the shard).
+    Here the path HAS an exchange step: one all-reduce(sum) of the B-weighted partial sums (a few hundred
+    bytes over RCCL / xGMI), instead of gathering propagators.
+    Returns {"goal": mean, "grad": mean gradient, "goal_std": std over all B instances, "bounds": (lo, hi)}.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds(B, world, rank)
+    goals, grads = goal_and_grad(lo, hi)
+    goals = torch.as_tensor(goals, dtype=torch.float64)
+    grads = torch.as_tensor(grads, dtype=torch.float64)
+    if hi > lo:
+        part = torch.cat([goals.sum().reshape(1), (goals * goals).sum().reshape(1), grads.sum(dim=0).reshape(-1)])
+    else:
+        part = torch.zeros(2 + int(np.prod(grads.shape[1:])), dtype=torch.float64, device=grads.device)
+    part = part.contiguous()
+    if world > 1:
+        dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
+    mean = part[0] / B
+    var = torch.clamp(part[1] / B - mean * mean, min=0.0)
+    return {"goal": mean, "goal_std": torch.sqrt(var), "grad": (part[2:] / B).reshape(tuple(grads.shape[1:])), "bounds": (lo, hi)}

@@ -55,3 +55,31 @@ def test_sharded_batch_matches_single_process(tmp_path, B):
         assert np.abs(U - ref).max() < 1e-12  # every rank holds the full, ordered result
         spans.append(tuple(np.load(tmp_path / f"b_rank{r}.npy")))
     assert spans == [c3dist.shard_bounds(B, world, r) for r in range(world)]
+
+
+def _robust_worker(rank, world, port, B, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(9)
+        goals = rng.uniform(size=B)
+        grads = rng.normal(size=(B, 2, 3))
+        r = c3dist.robust_goal_sharded(lambda lo, hi: (goals[lo:hi], grads[lo:hi]), B)
+        np.save(os.path.join(out_dir, f"g_rank{rank}.npy"), np.concatenate([[float(r["goal"]), float(r["goal_std"])], r["grad"].numpy().ravel()]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [1, 4, 7])
+def test_robust_goal_all_reduce(tmp_path, B):
+    """mean goal / gradient / std over instances sharded on two ranks (uneven and empty shards included)"""
+    world = 2
+    mp.spawn(_robust_worker, args=(world, _free_port(), B, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(9)
+    goals = rng.uniform(size=B)
+    grads = rng.normal(size=(B, 2, 3))
+    want = np.concatenate([[goals.mean(), goals.std()], grads.mean(axis=0).ravel()])
+    for r in range(world):
+        got = np.load(tmp_path / f"g_rank{r}.npy")
+        assert np.abs(got - want).max() < 1e-12
