@@ -402,6 +402,55 @@ __global__ void __launch_bounds__(64) hmeta_kernel(const cplx* hs, long bstride,
   }
 }
 
+// Small matrices (D <= 16): one wavefront per matrix, four per workgroup, coalesced 16-byte loads staged in LDS
+// (the one-workgroup-per-matrix kernel above spends its time on launch slots and strided column reads: 0.36 ms for
+// the 256k 9x9 generators of a cfg2 batch, as much as the exponentials themselves).
+__global__ void __launch_bounds__(256) hmeta_small_kernel(const cplx* hs, long bstride, int N, int D, double cr, double ci,
+                                                          double* meta, long nmat) {
+  __shared__ cplx stage[4][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long m = (long)blockIdx.x * 4 + w;
+  if (m >= nmat) return;  // whole wavefront
+  const long b = m / N, n = m - b * N;
+  const cplx* h = hs + b * bstride + n * (long)D * D;
+  const int DD = D * D;
+  double tr = 0.0, ti = 0.0;
+  for (int e = lane; e < DD; e += 64) {
+    const cplx x = h[e];
+    const cplx v = cmake(cr * x.x - ci * x.y, cr * x.y + ci * x.x);
+    stage[w][e] = v;
+    if (e / D == e % D) {
+      tr += v.x;
+      ti += v.y;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    tr += __shfl_xor(tr, o);
+    ti += __shfl_xor(ti, o);
+  }
+  const double mur = tr / D, mui = ti / D;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  double cs = 0.0;
+  if (lane < D)
+    for (int i = 0; i < D; ++i) {
+      cplx v = stage[w][i * D + lane];
+      if (i == lane) {
+        v.x -= mur;
+        v.y -= mui;
+      }
+      cs += hypot(v.x, v.y);
+    }
+  for (int o = 32; o > 0; o >>= 1) cs = fmax(cs, __shfl_xor(cs, o));
+  if (lane == 0) {
+    double* o4 = meta + m * 4;
+    o4[0] = mur;
+    o4[1] = mui;
+    o4[2] = cs;
+    o4[3] = 0.0;
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -466,6 +515,11 @@ hipError_t c3p_launch_overlap(const cplx* U, int B, int D, const int* rows, int 
 hipError_t c3p_launch_hmeta(const cplx* hs, long bstride, long nmat, int N, int D, double cr, double ci, double* meta,
                             hipStream_t st) {
   if (nmat == 0) return hipSuccess;
+  if (D <= 16) {
+    hipLaunchKernelGGL(hmeta_small_kernel, dim3((unsigned)((nmat + 3) / 4)), dim3(256), 0, st, hs, bstride, N, D, cr, ci, meta,
+                       nmat);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(hmeta_kernel, dim3((unsigned)nmat), dim3(64), 0, st, hs, bstride, N, D, cr, ci, meta);
   return hipGetLastError();
 }
