@@ -302,7 +302,7 @@ __device__ __forceinline__ void mm_frag2(const double (&fr)[RD<D>::NB][RD<D>::NB
 }
 
 // out = c0 I + c1 W + c2 W2 (+ c3 W3)
-template <int D, bool WITH3>
+template <int D, bool WITH3, bool UPPER = false>
 __device__ __forceinline__ void rcomb(double (&out)[RD<D>::NB][RD<D>::NB], double c0, double c1, double c2, double c3,
                                       const double (&W1)[RD<D>::NB][RD<D>::NB], const double (&W2)[RD<D>::NB][RD<D>::NB],
                                       const double (&W3)[RD<D>::NB][RD<D>::NB], const LanePos& lp) {
@@ -310,7 +310,7 @@ __device__ __forceinline__ void rcomb(double (&out)[RD<D>::NB][RD<D>::NB], doubl
 #pragma unroll
   for (int I = 0; I < NB; ++I)
 #pragma unroll
-    for (int J = 0; J < NB; ++J) {
+    for (int J = UPPER ? I : 0; J < NB; ++J) {  // UPPER: accumulators of a symmetric product (mirrored afterwards)
       double v = c1 * W1[I][J];
       v = fma(c2, W2[I][J], v);
       if constexpr (WITH3) v = fma(c3, W3[I][J], v);
@@ -671,13 +671,13 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
         // independent chains share every A-fragment read
         rcomb<D, true>(Cm, c3p_inv_fact[12], -c3p_inv_fact[14], c3p_inv_fact[16], -c3p_inv_fact[18], W1, W2, W3, lp);
         rcomb<D, false>(Sp, c3p_inv_fact[13], -c3p_inv_fact[15], c3p_inv_fact[17], 0.0, W1, W2, W3, lp);
-        rcomb<D, false>(acc, -c3p_inv_fact[6], c3p_inv_fact[8], -c3p_inv_fact[10], 0.0, W1, W2, W3, lp);
-        rcomb<D, false>(acs, -c3p_inv_fact[7], c3p_inv_fact[9], -c3p_inv_fact[11], 0.0, W1, W2, W3, lp);
+        rcomb<D, false, true>(acc, -c3p_inv_fact[6], c3p_inv_fact[8], -c3p_inv_fact[10], 0.0, W1, W2, W3, lp);
+        rcomb<D, false, true>(acs, -c3p_inv_fact[7], c3p_inv_fact[9], -c3p_inv_fact[11], 0.0, W1, W2, W3, lp);
         mm_frag2<D>(fr, Cm, acc, Sp, acs);
         sym_fill<D>(acc, swap_lane);
         sym_fill<D>(acs, swap_lane);
-        rcomb<D, false>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], 0.0, W1, W2, W3, lp);
-        rcomb<D, false>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], 0.0, W1, W2, W3, lp);
+        rcomb<D, false, true>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], 0.0, W1, W2, W3, lp);
+        rcomb<D, false, true>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], 0.0, W1, W2, W3, lp);
         mm_frag2<D>(fr, acc, Cm, acs, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
         sym_fill<D>(Cm, swap_lane);
         sym_fill<D>(Sp, swap_lane);
