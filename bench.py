@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default: config's B, capped at 256/GPU for cfg3/5)")
     ap.add_argument("--slices", type=int, default=None)
     ap.add_argument("--gather-every", type=int, default=8, help="batches exchanged per all-gather (multi-GPU)")
+    ap.add_argument("--ramp-ms", type=float, default=60.0, help="untimed device clock ramp before the W warmup steps (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the generic LDS kernel")
     ap.add_argument("--check", action="store_true", help="verify a few samples against the oracle")
@@ -155,6 +156,15 @@ def main():
             pending[0] = g
             flush()
         torch.cuda.synchronize()
+    # Untimed clock ramp: the MI355X needs tens of milliseconds of sustained work to reach its steady clocks
+    # (measured: 0.210 ms per batch after 5 warmup batches, 0.194 ms after 300).  The metric is sustained
+    # throughput, so the device is brought to steady state before the W warmup steps and the K timed steps.
+    if args.ramp_ms > 0:
+        t_r = time.perf_counter()
+        while (time.perf_counter() - t_r) * 1e3 < args.ramp_ms:
+            for _ in range(16):
+                bp.run(out=Ubuf[0])
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     drain()
@@ -236,6 +246,7 @@ def main():
                 "controls": wl.K,
                 "batch_per_gpu": B,
                 "global_batch": world * B,
+                "clock_ramp_ms": args.ramp_ms,
                 "parallelism": f"dp{world} (batch sharded; one RCCL all-gather of U per {G} batches)" if world > 1 else "single GPU",
                 "kernel": kernel_name,
             },
