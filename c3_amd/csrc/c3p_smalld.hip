@@ -301,6 +301,37 @@ __device__ __forceinline__ void mm_frag2(const double (&fr)[RD<D>::NB][RD<D>::NB
   }
 }
 
+// The left operand of every real product is SYMMETRIC, and for a symmetric M the A-layout fragment of tile
+// (I, K) -- lane (r, c) <- M[4I + c][4K + r] -- equals M[4K + r][4I + c], the D-layout register of tile (K, I)
+// the same lane already holds: the real stage needs NO LDS image, no fragment loads, no round trips.
+//   acc[I][J] += sum_K A(I,K) B(K,J) = sum_K mfma(Areg[K][I], Breg[K][J])     (tiles J >= I, mirrored afterwards)
+template <int D>
+__device__ __forceinline__ void mm_sym(const double (&za)[RD<D>::NB][RD<D>::NB], const double (&zb)[RD<D>::NB][RD<D>::NB],
+                                       double (&acc)[RD<D>::NB][RD<D>::NB]) {
+  constexpr int NB = RD<D>::NB;
+#pragma unroll
+  for (int K = 0; K < NB; ++K)
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = I; J < NB; ++J) acc[I][J] = mfma4(za[K][I], zb[K][J], acc[I][J]);
+}
+template <int D>
+__device__ __forceinline__ void mm_sym2(const double (&za)[RD<D>::NB][RD<D>::NB], const double (&zb1)[RD<D>::NB][RD<D>::NB],
+                                        double (&acc1)[RD<D>::NB][RD<D>::NB], const double (&zb2)[RD<D>::NB][RD<D>::NB],
+                                        double (&acc2)[RD<D>::NB][RD<D>::NB]) {
+  constexpr int NB = RD<D>::NB;
+#pragma unroll
+  for (int K = 0; K < NB; ++K)
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = I; J < NB; ++J) {
+        acc1[I][J] = mfma4(za[K][I], zb1[K][J], acc1[I][J]);
+        acc2[I][J] = mfma4(za[K][I], zb2[K][J], acc2[I][J]);
+      }
+}
+
 // out = c0 I + c1 W + c2 W2 (+ c3 W3)
 template <int D, bool WITH3, bool UPPER = false>
 __device__ __forceinline__ void rcomb(double (&out)[RD<D>::NB][RD<D>::NB], double c0, double c1, double c2, double c3,
@@ -650,42 +681,34 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
           }
         }
         RMat W1, W2, W3, Cm, Sp, acc, acs;
-        constexpr int YOFF = 4 * NB * WR;  // Y stays at rows [4 NB, 8 NB) until sin Y = Y (sin Y / Y) is formed
-        write_rimage<D>(Y, img, rwoff + YOFF);
 #pragma unroll
         for (int I = 0; I < NB; ++I)
 #pragma unroll
           for (int J = 0; J < NB; ++J) W1[I][J] = W2[I][J] = W3[I][J] = 0.0;
-        mm_real<D>(img, rroff + YOFF, Y, W1);  // W = Y^2
+        mm_sym<D>(Y, Y, W1);  // W = Y^2
         sym_fill<D>(W1, swap_lane);
-        write_rimage<D>(W1, img, rwoff);
-        RMat fr;
-        load_frags<D>(img, rroff, fr);
-        mm_frag<D>(fr, W1, W2);  // W^2
+        mm_sym<D>(W1, W1, W2);  // W^2
         sym_fill<D>(W2, swap_lane);
-        mm_frag<D>(fr, W2, W3);  // W^3
+        mm_sym<D>(W1, W2, W3);  // W^3
         sym_fill<D>(W3, swap_lane);
-        write_rimage<D>(W3, img, rwoff);
-        load_frags<D>(img, rroff, fr);
-        // cos: c_j = (-1)^j / (2j)!;  sin / Y: s_j = (-1)^j / (2j+1)!;  both by Horner in W^3, the two
-        // independent chains share every A-fragment read
+        // cos: c_j = (-1)^j / (2j)!;  sin / Y: s_j = (-1)^j / (2j+1)!;  both by Horner in W^3, interleaved
         rcomb<D, true>(Cm, c3p_inv_fact[12], -c3p_inv_fact[14], c3p_inv_fact[16], -c3p_inv_fact[18], W1, W2, W3, lp);
         rcomb<D, false>(Sp, c3p_inv_fact[13], -c3p_inv_fact[15], c3p_inv_fact[17], 0.0, W1, W2, W3, lp);
         rcomb<D, false, true>(acc, -c3p_inv_fact[6], c3p_inv_fact[8], -c3p_inv_fact[10], 0.0, W1, W2, W3, lp);
         rcomb<D, false, true>(acs, -c3p_inv_fact[7], c3p_inv_fact[9], -c3p_inv_fact[11], 0.0, W1, W2, W3, lp);
-        mm_frag2<D>(fr, Cm, acc, Sp, acs);
+        mm_sym2<D>(W3, Cm, acc, Sp, acs);
         sym_fill<D>(acc, swap_lane);
         sym_fill<D>(acs, swap_lane);
         rcomb<D, false, true>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], 0.0, W1, W2, W3, lp);
         rcomb<D, false, true>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], 0.0, W1, W2, W3, lp);
-        mm_frag2<D>(fr, acc, Cm, acs, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
+        mm_sym2<D>(W3, acc, Cm, acs, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
         sym_fill<D>(Cm, swap_lane);
         sym_fill<D>(Sp, swap_lane);
 #pragma unroll
         for (int I = 0; I < NB; ++I)
 #pragma unroll
           for (int J = 0; J < NB; ++J) acc[I][J] = 0.0;
-        mm_real<D>(img, rroff + YOFF, Sp, acc);  // acc = sin Y
+        mm_sym<D>(Y, Sp, acc);  // acc = sin Y
         sym_fill<D>(acc, swap_lane);
         // ---- E = cos Y - i sin Y as the chain's left-operand image (half image: rows 2i / 2i+1 = Re / Im) ----
         wave_sync();
