@@ -36,15 +36,10 @@ struct SD {
   static constexpr int NJ = (D + 3) / 4;   // 4-column blocks
   static constexpr int W = 4 * NJ + 1;     // LDS row stride in doubles
   static constexpr int MAT = 4 * NBI * W;  // doubles per matrix image
-  // per-chain image buffer of the forward kernel: a complex half image (4 NBI rows) or two real images
-  // (the real fast path keeps Y at rows [4 NB, 8 NB) while W / W^3 occupy rows [0, 4 NB))
-  // Real images use row stride WR = 12; with IMG = 12 (mod 32) doubles every LDS pattern of the kernel is
-  // bank-conflict free under the gfx950 rules (ds_read_b64: 32-lane groups on 64 dword banks; ds_write_b64:
-  // 16-lane groups on 32): real A-fragment reads b IMG + c WR + r, image writes b IMG + r W + c, complex
-  // A-fragment reads b IMG + rho W.
-  static constexpr int WR = 12;
-  static constexpr int NEED = (MAT > 8 * NJ * WR) ? MAT : 8 * NJ * WR;
-  static constexpr int IMG = ((NEED - 12 + 31) / 32) * 32 + 12;
+  // per-chain image buffer of the forward kernel: one complex half image.  IMG = 12 (mod 32) doubles keeps the
+  // LDS patterns bank-conflict free under the gfx950 rules (ds_read_b64: 32-lane groups on 64 dword banks;
+  // ds_write_b64: 16-lane groups on 32): image writes b IMG + r W + c, A-fragment reads b IMG + rho W.
+  static constexpr int IMG = ((MAT - 12 + 31) / 32) * 32 + 12;
 };
 
 __device__ __forceinline__ double mfma4(double a, double b, double c) {
@@ -185,17 +180,6 @@ struct RD {
   static constexpr int NB = (D + 3) / 4;
 };
 
-template <int D>
-__device__ __forceinline__ void write_rimage(const double (&m)[RD<D>::NB][RD<D>::NB], double* img, int woff) {
-  using C = SD<D>;
-  wave_sync();
-#pragma unroll
-  for (int I = 0; I < RD<D>::NB; ++I)
-#pragma unroll
-    for (int J = 0; J < RD<D>::NB; ++J) img[woff + I * 4 * C::WR + J * 4] = m[I][J];
-  wave_sync();
-}
-
 // Every matrix of the real path is a polynomial in the real SYMMETRIC Y, hence symmetric: products only
 // compute the tiles on and above the diagonal (6 of 9 at D = 9) and sym_fill mirrors them.
 // lane (r, c) of tile (I, J) holds M[4I + r][4J + c]; its mirror element M[4J + c][4I + r] is held by lane
@@ -207,98 +191,6 @@ __device__ __forceinline__ void sym_fill(double (&m)[RD<D>::NB][RD<D>::NB], int 
   for (int I = 1; I < NB; ++I)
 #pragma unroll
     for (int J = 0; J < I; ++J) m[I][J] = __shfl(m[J][I], swap_lane);
-}
-
-// acc += IMG * B for real symmetric results (tiles J >= I only)
-template <int D>
-__device__ __forceinline__ void mm_real(const double* img, int rroff, const double (&zb)[RD<D>::NB][RD<D>::NB],
-                                        double (&acc)[RD<D>::NB][RD<D>::NB]) {
-  using C = SD<D>;
-  constexpr int NB = RD<D>::NB;
-  double ra[2][NB];
-#pragma unroll
-  for (int I = 0; I < NB; ++I) ra[0][I] = lds_ld(img + rroff + I * 4 * C::WR);
-#pragma unroll
-  for (int K = 0; K < NB; ++K) {
-    if (K + 1 < NB) {
-#pragma unroll
-      for (int I = 0; I < NB; ++I) ra[(K + 1) & 1][I] = lds_ld(img + rroff + I * 4 * C::WR + (K + 1) * 4);
-    }
-#pragma unroll
-    for (int I = 0; I < NB; ++I)
-#pragma unroll
-      for (int J = I; J < NB; ++J) acc[I][J] = mfma4(ra[K & 1][I], zb[K][J], acc[I][J]);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// two products with the same left operand: acc1 += IMG * B1, acc2 += IMG * B2 (tiles J >= I only)
-template <int D>
-__device__ __forceinline__ void mm_real2(const double* img, int rroff, const double (&zb1)[RD<D>::NB][RD<D>::NB],
-                                         double (&acc1)[RD<D>::NB][RD<D>::NB], const double (&zb2)[RD<D>::NB][RD<D>::NB],
-                                         double (&acc2)[RD<D>::NB][RD<D>::NB]) {
-  using C = SD<D>;
-  constexpr int NB = RD<D>::NB;
-  double ra[2][NB];
-#pragma unroll
-  for (int I = 0; I < NB; ++I) ra[0][I] = lds_ld(img + rroff + I * 4 * C::WR);
-#pragma unroll
-  for (int K = 0; K < NB; ++K) {
-    if (K + 1 < NB) {
-#pragma unroll
-      for (int I = 0; I < NB; ++I) ra[(K + 1) & 1][I] = lds_ld(img + rroff + I * 4 * C::WR + (K + 1) * 4);
-    }
-#pragma unroll
-    for (int I = 0; I < NB; ++I)
-#pragma unroll
-      for (int J = I; J < NB; ++J) {
-        acc1[I][J] = mfma4(ra[K & 1][I], zb1[K][J], acc1[I][J]);
-        acc2[I][J] = mfma4(ra[K & 1][I], zb2[K][J], acc2[I][J]);
-      }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// All A fragments of a real image (NB x NB doubles per lane): loaded once when the same left operand
-// serves two consecutive products (W for W^2 and W^3; W^3 for both Horner steps).
-template <int D>
-__device__ __forceinline__ void load_frags(const double* img, int rroff, double (&fr)[RD<D>::NB][RD<D>::NB]) {
-  using C = SD<D>;
-  constexpr int NB = RD<D>::NB;
-#pragma unroll
-  for (int K = 0; K < NB; ++K)
-#pragma unroll
-    for (int I = 0; I < NB; ++I) fr[K][I] = lds_ld(img + rroff + I * 4 * C::WR + K * 4);
-}
-template <int D>
-__device__ __forceinline__ void mm_frag(const double (&fr)[RD<D>::NB][RD<D>::NB], const double (&zb)[RD<D>::NB][RD<D>::NB],
-                                        double (&acc)[RD<D>::NB][RD<D>::NB]) {
-  constexpr int NB = RD<D>::NB;
-#pragma unroll
-  for (int K = 0; K < NB; ++K) {
-#pragma unroll
-    for (int I = 0; I < NB; ++I)
-#pragma unroll
-      for (int J = I; J < NB; ++J) acc[I][J] = mfma4(fr[K][I], zb[K][J], acc[I][J]);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-template <int D>
-__device__ __forceinline__ void mm_frag2(const double (&fr)[RD<D>::NB][RD<D>::NB], const double (&zb1)[RD<D>::NB][RD<D>::NB],
-                                         double (&acc1)[RD<D>::NB][RD<D>::NB], const double (&zb2)[RD<D>::NB][RD<D>::NB],
-                                         double (&acc2)[RD<D>::NB][RD<D>::NB]) {
-  constexpr int NB = RD<D>::NB;
-#pragma unroll
-  for (int K = 0; K < NB; ++K) {
-#pragma unroll
-    for (int I = 0; I < NB; ++I)
-#pragma unroll
-      for (int J = I; J < NB; ++J) {
-        acc1[I][J] = mfma4(fr[K][I], zb1[K][J], acc1[I][J]);
-        acc2[I][J] = mfma4(fr[K][I], zb2[K][J], acc2[I][J]);
-      }
-    __builtin_amdgcn_sched_barrier(0);
-  }
 }
 
 // The left operand of every real product is SYMMETRIC, and for a symmetric M the A-layout fragment of tile
@@ -641,9 +533,6 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
       }
       ps18 = __builtin_amdgcn_readfirstlane(ps18);
       const double rscale = ldexp(1.0, -ps18);
-      constexpr int WR = C::WR;
-      const int rroff = lp.b * IMG + lp.c * WR + lp.r;  // A-layout read of a row-major real image
-      const int rwoff = lp.b * IMG + lp.r * WR + lp.c;  // D-layout write of a real image
       const int swap_lane = 16 * lp.c + 4 * lp.b + lp.r;  // (r, c) <-> (c, r) inside the chain's block
       int yo[NB];        // Im rows of the half-image tables hold -Y
       double ymask[NB];
@@ -1426,9 +1315,8 @@ int c3p_smalld_mat_doubles(int Dm) {
 
 int c3p_smalld_img_doubles(int Dm) {
   const int NBI = (Dm + 1) / 2, NJ = (Dm + 3) / 4;
-  const int mat = 4 * NBI * (4 * NJ + 1), two_real = 8 * NJ * 12;
-  const int need = mat > two_real ? mat : two_real;
-  return ((need - 12 + 31) / 32) * 32 + 12;
+  const int mat = 4 * NBI * (4 * NJ + 1);
+  return ((mat - 12 + 31) / 32) * 32 + 12;
 }
 
 size_t c3p_smalld_table_doubles(int Dm, int K) { return (size_t)(1 + K) * (c3p_smalld_mat_doubles(Dm) + 4); }
