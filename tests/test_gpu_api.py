@@ -198,6 +198,32 @@ def test_supplied_generators_every_kernel(prop, D):
         assert np.abs(got - want).max() < 1e-12 * np.exp(6.0)
 
 
+def test_mixed_real_and_complex_samples_in_one_launch(prop):
+    """per-sample operators: real symmetric, complex Hermitian and real non-symmetric drifts in ONE batch -- every
+    wave picks its path from its own sample's flag"""
+    import scipy.linalg as sla
+
+    rng = np.random.default_rng(77)
+    D, B, K, N = 9, 6, 2, 41
+    a = rng.normal(size=(B, D, D))
+    h0 = (a + np.swapaxes(a, -1, -2)).astype(np.complex128) * 2e10
+    im = rng.normal(size=(D, D))
+    h0[1] += 1j * (im - im.T) * 1e10          # complex Hermitian
+    h0[3] += 1j * (im - im.T) * 3e9
+    h0[4, 0, D - 1] += 4e9                      # real, not symmetric
+    hk = rng.normal(size=(K, D, D))
+    hks = (hk + np.swapaxes(hk, -1, -2)).astype(np.complex128)
+    sig = rng.normal(size=(B, K, N)) * 1e9
+    dt = 1e-11
+    r = prop.propagate_batch(h0, hks, sig, dt, want_dUs=True)
+    for b in range(B):
+        Xs = -1j * dt * (h0[b][None] + np.einsum("kn,kij->nij", sig[b], hks))
+        d = np.stack([sla.expm(x) for x in Xs])
+        assert np.abs(np.asarray(r["dUs"][b]) - d).max() < 1e-12
+        ref = o.tf_matmul_left(d)
+        assert np.linalg.norm(np.asarray(r["U"][b]) - ref) < 1e-10 * max(1.0, np.linalg.norm(ref))
+
+
 @pytest.mark.parametrize("D", [41, 48, 49, 64, 77, 92])
 def test_big_dimension_classes(prop, D):
     """Every geometry class of the big-D MFMA kernel (41..92), a couple of samples and slices."""
