@@ -197,24 +197,55 @@ __device__ __forceinline__ void sym_fill(double (&m)[RD<D>::NB][RD<D>::NB], int 
 // (I, K) -- lane (r, c) <- M[4I + c][4K + r] -- equals M[4K + r][4I + c], the D-layout register of tile (K, I)
 // the same lane already holds: the real stage needs NO LDS image, no fragment loads, no round trips.
 //   acc[I][J] += sum_K A(I,K) B(K,J) = sum_K mfma(Areg[K][I], Breg[K][J])     (tiles J >= I, mirrored afterwards)
+// broadcast of the quad's lane 0 (column c = 0 of a tile) to its four lanes: DPP quad_perm [0,0,0,0], no LDS
+__device__ __forceinline__ double quad_bcast0(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x00, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x00, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+// When D = 1 (mod 4) the last K-step of a product carries ONE valid k (k = D-1; D = 9: a third of the MFMAs doing
+// a quarter of their work).  It is applied as a rank-1 update on the vector unit instead:
+//   acc(I,J) += a_I (x) b_J,   a_I[lane (r,c)] = A[4I+r][D-1]   (tile (I,NB-1), column 0, quad broadcast)
+//                              b_J[lane (r,c)] = B[D-1][4J+c] = B[4J+c][D-1]   (tile (J,NB-1) of the lane (c,0))
+// Both vectors come from tiles on or above the diagonal, i.e. they do not wait for the mirror.
+template <int D>
+struct SymTail {
+  static constexpr bool ON = (D % 4 == 1) && (RD<D>::NB > 1);
+  static constexpr int KM = ON ? RD<D>::NB - 1 : RD<D>::NB;
+};
+
 template <int D>
 __device__ __forceinline__ void mm_sym(const double (&za)[RD<D>::NB][RD<D>::NB], const double (&zb)[RD<D>::NB][RD<D>::NB],
-                                       double (&acc)[RD<D>::NB][RD<D>::NB]) {
+                                       double (&acc)[RD<D>::NB][RD<D>::NB], int tail_lane) {
   constexpr int NB = RD<D>::NB;
 #pragma unroll
-  for (int K = 0; K < NB; ++K)
+  for (int K = 0; K < SymTail<D>::KM; ++K)
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
       for (int J = I; J < NB; ++J) acc[I][J] = mfma4(za[K][I], zb[K][J], acc[I][J]);
+  if constexpr (SymTail<D>::ON) {
+    double av[NB], bv[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      av[I] = quad_bcast0(za[I][NB - 1]);
+      bv[I] = __shfl(zb[I][NB - 1], tail_lane);
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = I; J < NB; ++J) acc[I][J] = fma(av[I], bv[J], acc[I][J]);
+  }
 }
 template <int D>
 __device__ __forceinline__ void mm_sym2(const double (&za)[RD<D>::NB][RD<D>::NB], const double (&zb1)[RD<D>::NB][RD<D>::NB],
                                         double (&acc1)[RD<D>::NB][RD<D>::NB], const double (&zb2)[RD<D>::NB][RD<D>::NB],
-                                        double (&acc2)[RD<D>::NB][RD<D>::NB]) {
+                                        double (&acc2)[RD<D>::NB][RD<D>::NB], int tail_lane) {
   constexpr int NB = RD<D>::NB;
 #pragma unroll
-  for (int K = 0; K < NB; ++K)
+  for (int K = 0; K < SymTail<D>::KM; ++K)
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
@@ -222,6 +253,22 @@ __device__ __forceinline__ void mm_sym2(const double (&za)[RD<D>::NB][RD<D>::NB]
         acc1[I][J] = mfma4(za[K][I], zb1[K][J], acc1[I][J]);
         acc2[I][J] = mfma4(za[K][I], zb2[K][J], acc2[I][J]);
       }
+  if constexpr (SymTail<D>::ON) {
+    double av[NB], bv1[NB], bv2[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      av[I] = quad_bcast0(za[I][NB - 1]);
+      bv1[I] = __shfl(zb1[I][NB - 1], tail_lane);
+      bv2[I] = __shfl(zb2[I][NB - 1], tail_lane);
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = I; J < NB; ++J) {
+        acc1[I][J] = fma(av[I], bv1[J], acc1[I][J]);
+        acc2[I][J] = fma(av[I], bv2[J], acc2[I][J]);
+      }
+  }
 }
 
 // out = c0 I + c1 W + c2 W2 (+ c3 W3)
@@ -534,6 +581,7 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
       ps18 = __builtin_amdgcn_readfirstlane(ps18);
       const double rscale = ldexp(1.0, -ps18);
       const int swap_lane = 16 * lp.c + 4 * lp.b + lp.r;  // (r, c) <-> (c, r) inside the chain's block
+      const int tail_lane = 16 * lp.c + 4 * lp.b;         // lane (c, 0): source of the rank-1 tail's row vector
       int yo[NB];        // Im rows of the half-image tables hold -Y
       double ymask[NB];
 #pragma unroll
@@ -574,30 +622,30 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
         for (int I = 0; I < NB; ++I)
 #pragma unroll
           for (int J = 0; J < NB; ++J) W1[I][J] = W2[I][J] = W3[I][J] = 0.0;
-        mm_sym<D>(Y, Y, W1);  // W = Y^2
+        mm_sym<D>(Y, Y, W1, tail_lane);  // W = Y^2
         sym_fill<D>(W1, swap_lane);
-        mm_sym<D>(W1, W1, W2);  // W^2
+        mm_sym<D>(W1, W1, W2, tail_lane);  // W^2
         sym_fill<D>(W2, swap_lane);
-        mm_sym<D>(W1, W2, W3);  // W^3
+        mm_sym<D>(W1, W2, W3, tail_lane);  // W^3
         sym_fill<D>(W3, swap_lane);
         // cos: c_j = (-1)^j / (2j)!;  sin / Y: s_j = (-1)^j / (2j+1)!;  both by Horner in W^3, interleaved
         rcomb<D, true>(Cm, c3p_inv_fact[12], -c3p_inv_fact[14], c3p_inv_fact[16], -c3p_inv_fact[18], W1, W2, W3, lp);
         rcomb<D, false>(Sp, c3p_inv_fact[13], -c3p_inv_fact[15], c3p_inv_fact[17], 0.0, W1, W2, W3, lp);
         rcomb<D, false, true>(acc, -c3p_inv_fact[6], c3p_inv_fact[8], -c3p_inv_fact[10], 0.0, W1, W2, W3, lp);
         rcomb<D, false, true>(acs, -c3p_inv_fact[7], c3p_inv_fact[9], -c3p_inv_fact[11], 0.0, W1, W2, W3, lp);
-        mm_sym2<D>(W3, Cm, acc, Sp, acs);
+        mm_sym2<D>(W3, Cm, acc, Sp, acs, tail_lane);
         sym_fill<D>(acc, swap_lane);
         sym_fill<D>(acs, swap_lane);
         rcomb<D, false, true>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], 0.0, W1, W2, W3, lp);
         rcomb<D, false, true>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], 0.0, W1, W2, W3, lp);
-        mm_sym2<D>(W3, acc, Cm, acs, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
+        mm_sym2<D>(W3, acc, Cm, acs, Sp, tail_lane);  // Cm = cos Y, Sp = sin(Y) / Y
         sym_fill<D>(Cm, swap_lane);
         sym_fill<D>(Sp, swap_lane);
 #pragma unroll
         for (int I = 0; I < NB; ++I)
 #pragma unroll
           for (int J = 0; J < NB; ++J) acc[I][J] = 0.0;
-        mm_sym<D>(Y, Sp, acc);  // acc = sin Y
+        mm_sym<D>(Y, Sp, acc, tail_lane);  // acc = sin Y
         sym_fill<D>(acc, swap_lane);
         // ---- E = cos Y - i sin Y as the chain's left-operand image (half image: rows 2i / 2i+1 = Re / Im) ----
         wave_sync();
