@@ -22,6 +22,8 @@
 //   E = exp(X): Taylor, Paterson-Stockmeyer with q=4 (powers X..X^4, Horner in X^4),
 //       degree 4r in {4,8,12,16,20} and s squarings chosen from a 1-norm bound, wave-uniform
 //   U <- E U ;  the scalar factors e^{mu_n} are summed and applied once per segment.
+#include <type_traits>
+
 #include "c3p_common.h"
 #include "c3p_kernels.h"
 #include "c3p_smalld.h"
@@ -590,6 +592,12 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
         yo[I] = (2 * (ok ? 4 * I + lp.r : 0) + 1) * W + lp.c;
         ymask[I] = ok ? 1.0 : 0.0;
       }
+      // theta_16 (unit roundoff 2^-52) = 0.816: below it the degree-16 / 17 polynomials are exact to roundoff and the
+      // shallower 7-product evaluation is used.  The variant is chosen per segment OUTSIDE the slice loop (the loop is
+      // instantiated twice) so that neither variant's registers burden the other's schedule.
+      const bool deg16 = __builtin_amdgcn_readfirstlane((int)(nrm * rscale <= 8.16e-1)) != 0;
+      auto real_loop = [&](auto deg16_tag) {
+      constexpr bool DEG16 = decltype(deg16_tag)::value;
       for (int t = 0; t < A.Lmax; ++t) {
         const bool act = valid && t < len;
         const double sc = act ? rscale : 0.0;
@@ -626,6 +634,32 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
         sym_fill<D>(W1, swap_lane);
         mm_sym<D>(W1, W1, W2, tail_lane);  // W^2
         sym_fill<D>(W2, swap_lane);
+        if constexpr (DEG16) {
+          // cos to W^8, sin/Y to W^8 (Taylor degree 16 / 17), Paterson-Stockmeyer with q = 4: W^3 = W W^2 and
+          // W^4 = W^2 W^2 are independent, then ONE paired Horner step  P = B0 + W^4 (B1 + c8 W^4):
+          // 7 products, dependency depth 5 (Y^2, W^2, {W^3, W^4}, {cos, sin/Y}, sin) instead of 8 and 7.
+          RMat W4;
+#pragma unroll
+          for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int J = 0; J < NB; ++J) W4[I][J] = 0.0;
+          mm_sym<D>(W1, W2, W3, tail_lane);
+          mm_sym<D>(W2, W2, W4, tail_lane);
+          sym_fill<D>(W3, swap_lane);
+          sym_fill<D>(W4, swap_lane);
+          rcomb<D, true>(acc, c3p_inv_fact[8], -c3p_inv_fact[10], c3p_inv_fact[12], -c3p_inv_fact[14], W1, W2, W3, lp);
+          rcomb<D, true>(acs, c3p_inv_fact[9], -c3p_inv_fact[11], c3p_inv_fact[13], -c3p_inv_fact[15], W1, W2, W3, lp);
+#pragma unroll
+          for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int J = 0; J < NB; ++J) {
+              acc[I][J] = fma(c3p_inv_fact[16], W4[I][J], acc[I][J]);
+              acs[I][J] = fma(c3p_inv_fact[17], W4[I][J], acs[I][J]);
+            }
+          rcomb<D, true, true>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], -c3p_inv_fact[6], W1, W2, W3, lp);
+          rcomb<D, true, true>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7], W1, W2, W3, lp);
+          mm_sym2<D>(W4, acc, Cm, acs, Sp, tail_lane);  // Cm = cos Y, Sp = sin(Y) / Y
+        } else {
         mm_sym<D>(W1, W2, W3, tail_lane);  // W^3
         sym_fill<D>(W3, swap_lane);
         // cos: c_j = (-1)^j / (2j)!;  sin / Y: s_j = (-1)^j / (2j+1)!;  both by Horner in W^3, interleaved
@@ -639,6 +673,7 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
         rcomb<D, false, true>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], 0.0, W1, W2, W3, lp);
         rcomb<D, false, true>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], 0.0, W1, W2, W3, lp);
         mm_sym2<D>(W3, acc, Cm, acs, Sp, tail_lane);  // Cm = cos Y, Sp = sin(Y) / Y
+        }
         sym_fill<D>(Cm, swap_lane);
         sym_fill<D>(Sp, swap_lane);
 #pragma unroll
@@ -711,6 +746,11 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
           mus_i = c3p_phase_add(mus_i, mu_i);
         }
       }
+      };
+      if (deg16)
+        real_loop(std::true_type{});
+      else
+        real_loop(std::false_type{});
     } else {
     for (int t = 0; t < A.Lmax; ++t) {
       const bool act = valid && t < len;
