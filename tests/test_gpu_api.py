@@ -224,6 +224,28 @@ def test_mixed_real_and_complex_samples_in_one_launch(prop):
         assert np.linalg.norm(np.asarray(r["U"][b]) - ref) < 1e-10 * max(1.0, np.linalg.norm(ref))
 
 
+@pytest.mark.parametrize("D", [3, 5, 9, 12])
+@pytest.mark.parametrize("nrm", [0.5, 0.80, 0.83, 1.0, 1.12, 1.2, 1.7, 2.4])
+def test_real_path_polynomial_variants(prop, D, nrm):
+    """both evaluations of the real path (degree 16 below ||Y|| = 0.816, degree 18 up to 1.13, squarings beyond) at
+    norms on either side of every threshold, against scipy's expm"""
+    import scipy.linalg as sla
+
+    rng = np.random.default_rng(1000 + D)
+    a = rng.normal(size=(D, D))
+    h = a + a.T
+    hs = h - np.trace(h) / D * np.eye(D)
+    h = h / np.abs(hs).sum(axis=0).max()  # shifted 1-norm = 1
+    dt = 1e-11
+    h0 = (h * nrm / dt).astype(np.complex128)
+    hk = np.zeros((1, D, D), dtype=np.complex128)
+    N = 7
+    r = prop.propagate_batch(h0, hk, np.zeros((2, 1, N)), dt, want_dUs=True)
+    E = sla.expm(-1j * dt * h0)
+    assert np.abs(np.asarray(r["dUs"][1, 3]) - E).max() < 5e-15 * max(1.0, nrm)
+    assert np.linalg.norm(np.asarray(r["U"][0]) - np.linalg.matrix_power(E, N)) < 1e-12
+
+
 @pytest.mark.parametrize("D", [41, 48, 49, 64, 77, 92])
 def test_big_dimension_classes(prop, D):
     """Every geometry class of the big-D MFMA kernel (41..92), a couple of samples and slices."""
