@@ -752,6 +752,9 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
       else
         real_loop(std::false_type{});
     } else {
+    // the slice loop is instantiated per plan (T18 / Paterson-Stockmeyer) with the branch outside, as on the real path
+    auto complex_loop = [&](auto t18_tag) {
+    constexpr bool T18 = decltype(t18_tag)::value;
     for (int t = 0; t < A.Lmax; ++t) {
       const bool act = valid && t < len;
       // ---- X = scale (G0 + sum_k c_k G_k) in D-layout; trace shift mu ----
@@ -805,7 +808,7 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
         for (int J = 0; J < NJ; ++J) A2[I][J] = A3[I][J] = 0.0;
       mm_img<D>(img, roff, negmask, X, A2);
       mm_img<D>(img, roff, negmask, A2, A3);
-      if (t18) {
+      if constexpr (T18) {
         // ---- T18 (Bader-Blanes-Casas): 5 products in total ----
         double A6[NBI][NJ];
 #pragma unroll
@@ -910,6 +913,11 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
         mus_i = c3p_phase_add(mus_i, mu_i);
       }
     }
+    };
+    if (t18)
+      complex_loop(std::true_type{});
+    else
+      complex_loop(std::false_type{});
     }  // complex path
   }
   // ---- segment result ----
