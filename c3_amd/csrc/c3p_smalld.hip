@@ -273,6 +273,33 @@ __device__ __forceinline__ void mm_sym2(const double (&za)[RD<D>::NB][RD<D>::NB]
   }
 }
 
+// acc += A B for a SYMMETRIC left operand A (A fragments = registers, as in mm_sym) and a general right operand
+// B (all tiles): the chain product of the real path, E U with E = C - iS split into real blocks.
+// The single-k tail takes the row D-1 of B from the lanes r = 0 (broadcast over r by one lane swap).
+template <int D>
+__device__ __forceinline__ void mm_symA(const double (&za)[RD<D>::NB][RD<D>::NB], const double (&zb)[RD<D>::NB][RD<D>::NB],
+                                        double (&acc)[RD<D>::NB][RD<D>::NB], int row0_lane, double asign) {
+  constexpr int NB = RD<D>::NB;
+#pragma unroll
+  for (int K = 0; K < SymTail<D>::KM; ++K)
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) acc[I][J] = mfma4(za[K][I], zb[K][J], acc[I][J]);
+  if constexpr (SymTail<D>::ON) {
+    double av[NB], bv[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      av[I] = asign * quad_bcast0(za[I][NB - 1]);
+      bv[I] = __shfl(zb[NB - 1][I], row0_lane);
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) acc[I][J] = fma(av[I], bv[J], acc[I][J]);
+  }
+}
+
 // out = c0 I + c1 W + c2 W2 (+ c3 W3)
 template <int D, bool WITH3, bool UPPER = false>
 __device__ __forceinline__ void rcomb(double (&out)[RD<D>::NB][RD<D>::NB], double c0, double c1, double c2, double c3,
@@ -584,6 +611,8 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
       const double rscale = ldexp(1.0, -ps18);
       const int swap_lane = 16 * lp.c + 4 * lp.b + lp.r;  // (r, c) <-> (c, r) inside the chain's block
       const int tail_lane = 16 * lp.c + 4 * lp.b;         // lane (c, 0): source of the rank-1 tail's row vector
+      const int row0_lane = 4 * lp.b + lp.c;               // lane (0, c): row D-1 of a general right operand
+      RMat Ur, Ui;  // the chain state in real blocks
       int yo[NB];        // Im rows of the half-image tables hold -Y
       double ymask[NB];
 #pragma unroll
@@ -682,66 +711,75 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
           for (int J = 0; J < NB; ++J) acc[I][J] = 0.0;
         mm_sym<D>(Y, Sp, acc, tail_lane);  // acc = sin Y
         sym_fill<D>(acc, swap_lane);
-        // ---- E = cos Y - i sin Y as the chain's left-operand image (half image: rows 2i / 2i+1 = Re / Im) ----
-        wave_sync();
+        // ---- E = cos Y - i sin Y (Cm, acc) ; squarings in real form: cos 2Y = C^2 - S^2, sin 2Y = 2 S C ----
+        for (int it = 0; it < ps18; ++it) {
+          RMat C2, S2, SC;
 #pragma unroll
-        for (int I = 0; I < NB; ++I)
+          for (int I = 0; I < NB; ++I)
 #pragma unroll
-          for (int J = 0; J < NB; ++J) {
-            const int i = 4 * I + lp.r, j = 4 * J + lp.c;
-            if (2 * i + 1 < 4 * NBI) {
-              img[lp.b * IMG + (2 * i) * W + j] = Cm[I][J];
-              img[lp.b * IMG + (2 * i + 1) * W + j] = -acc[I][J];
+            for (int J = 0; J < NB; ++J) C2[I][J] = S2[I][J] = SC[I][J] = 0.0;
+          mm_sym<D>(Cm, Cm, C2, tail_lane);
+          mm_sym<D>(acc, acc, S2, tail_lane);
+          mm_sym<D>(acc, Cm, SC, tail_lane);
+#pragma unroll
+          for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int J = I; J < NB; ++J) {
+              Cm[I][J] = C2[I][J] - S2[I][J];
+              acc[I][J] = 2.0 * SC[I][J];
             }
-          }
-        wave_sync();
-        const bool need_P = DUS || ps18 > 0 || t == 0;
-        double P[NBI][NJ];
-        if (need_P) {
-#pragma unroll
-          for (int I = 0; I < NBI; ++I)
-#pragma unroll
-            for (int J = 0; J < NJ; ++J) P[I][J] = img[woff + I * 4 * W + J * 4];
-          for (int it = 0; it < ps18; ++it) {
-            if (it > 0) write_image<D>(P, img, woff);
-            double sq[NBI][NJ];
-#pragma unroll
-            for (int I = 0; I < NBI; ++I)
-#pragma unroll
-              for (int J = 0; J < NJ; ++J) sq[I][J] = 0.0;
-            mm_img<D>(img, roff, negmask, P, sq);
-#pragma unroll
-            for (int I = 0; I < NBI; ++I)
-#pragma unroll
-              for (int J = 0; J < NJ; ++J) P[I][J] = sq[I][J];
-          }
-          if (ps18 > 0 && t > 0) write_image<D>(P, img, woff);
-          if constexpr (DUS) {
-            double sn, cs;
-            sincos(mu_i, &sn, &cs);
-            const double er = exp(mu_r);
-            double* dst = reinterpret_cast<double*>(A.dUs_out) + ((long)sample * A.N + n0 + (act ? t : 0)) * D * D * 2;
-            store_plain<D>(P, dst, er * cs, er * sn, nullptr, lp, act);
-          }
+          sym_fill<D>(Cm, swap_lane);
+          sym_fill<D>(acc, swap_lane);
         }
+        if constexpr (DUS) {
+          // dU = e^{mu} (C - iS)
+          double sn, cs;
+          sincos(mu_i, &sn, &cs);
+          const double er = exp(mu_r);
+          const double pr = er * cs, pi = er * sn;
+          double* dst = reinterpret_cast<double*>(A.dUs_out) + ((long)sample * A.N + n0 + (act ? t : 0)) * D * D * 2;
+#pragma unroll
+          for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int J = 0; J < NB; ++J) {
+              const int i = 4 * I + lp.r, j = 4 * J + lp.c;
+              if (act && i < D && j < D) {
+                dst[(i * D + j) * 2 + 0] = fma(pr, Cm[I][J], pi * acc[I][J]);
+                dst[(i * D + j) * 2 + 1] = fma(pi, Cm[I][J], -pr * acc[I][J]);
+              }
+            }
+        }
+        // ---- chain in real blocks (no LDS): Ur' = C Ur + S Ui,  Ui' = C Ui - S Ur ----
         if (t == 0) {
 #pragma unroll
-          for (int I = 0; I < NBI; ++I)
+          for (int I = 0; I < NB; ++I)
 #pragma unroll
-            for (int J = 0; J < NJ; ++J) U[I][J] = P[I][J];
+            for (int J = 0; J < NB; ++J) {
+              Ur[I][J] = Cm[I][J];
+              Ui[I][J] = -acc[I][J];
+            }
           mus_r = mu_r;
           mus_i = c3p_phase_add(0.0, mu_i);
         } else {
-          double cacc[NBI][NJ];
+          RMat nS, Vr, Vi;
 #pragma unroll
-          for (int I = 0; I < NBI; ++I)
+          for (int I = 0; I < NB; ++I)
 #pragma unroll
-            for (int J = 0; J < NJ; ++J) cacc[I][J] = 0.0;
-          mm_img<D>(img, roff, negmask, U, cacc);
+            for (int J = 0; J < NB; ++J) {
+              nS[I][J] = -acc[I][J];
+              Vr[I][J] = Vi[I][J] = 0.0;
+            }
+          mm_symA<D>(Cm, Ur, Vr, row0_lane, 1.0);
+          mm_symA<D>(Cm, Ui, Vi, row0_lane, 1.0);
+          mm_symA<D>(acc, Ui, Vr, row0_lane, 1.0);
+          mm_symA<D>(nS, Ur, Vi, row0_lane, 1.0);
 #pragma unroll
-          for (int I = 0; I < NBI; ++I)
+          for (int I = 0; I < NB; ++I)
 #pragma unroll
-            for (int J = 0; J < NJ; ++J) U[I][J] = cacc[I][J];
+            for (int J = 0; J < NB; ++J) {
+              Ur[I][J] = Vr[I][J];
+              Ui[I][J] = Vi[I][J];
+            }
           mus_r += mu_r;
           mus_i = c3p_phase_add(mus_i, mu_i);
         }
@@ -751,6 +789,24 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
         real_loop(std::true_type{});
       else
         real_loop(std::false_type{});
+      // back to the complex half-image layout of the epilogue (once per segment, through the chain's image)
+      wave_sync();
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) {
+          const int i = 4 * I + lp.r, j = 4 * J + lp.c;
+          if (2 * i + 1 < 4 * NBI) {
+            img[lp.b * IMG + (2 * i) * W + j] = Ur[I][J];
+            img[lp.b * IMG + (2 * i + 1) * W + j] = Ui[I][J];
+          }
+        }
+      wave_sync();
+#pragma unroll
+      for (int I = 0; I < NBI; ++I)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) U[I][J] = img[woff + I * 4 * W + J * 4];
+      wave_sync();
     } else {
     // the slice loop is instantiated per plan (T18 / Paterson-Stockmeyer) with the branch outside, as on the real path
     auto complex_loop = [&](auto t18_tag) {
