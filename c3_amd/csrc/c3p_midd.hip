@@ -21,6 +21,8 @@
 // (the block polynomials B_j are lane-local), so only three LDS images are live at any time:
 // buf0 = X then P/E, buf1 = X^2 then X^3 then U, buf2 = X^4  (73 KB at D = 36 -> two
 // workgroups = two waves per SIMD per CU).  Same plan logic as the small-D kernel.
+#include <type_traits>
+
 #include "c3p_common.h"
 #include "c3p_kernels.h"
 #include "c3p_midd.h"
@@ -262,6 +264,10 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
     }
   };
 
+  // the slice loop is instantiated per plan (T18 / Paterson-Stockmeyer), branch outside: inside the loop the two
+  // variants' live ranges merge
+  auto slice_loop = [&](auto t18_tag) {
+  constexpr bool T18 = decltype(t18_tag)::value;
   for (int t = 0; t < cm.len; ++t) {
     Regs P;
     zero(P);
@@ -323,7 +329,7 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
       store_tiles(cm.buf1, A3);
       __syncthreads();
       zero(acc);
-      if (cm.t18) {
+      if constexpr (T18) {
         // ---- T18 (Bader-Blanes-Casas), 5 products: A6 = A3 A3; A9 = B1 B5 + B4; P = B2 + (B3 + A9) A9
         product(cm.buf1, cm.buf1, acc);  // acc = A6
         auto comb = [&](Regs& out, double c0, double cx, double c2, double c3, double c6) {
@@ -433,6 +439,11 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
       __syncthreads();  // buf0 / buf1 are rewritten by the next slice
     }
   }
+  };
+  if (cm.t18)
+    slice_loop(std::true_type{});
+  else
+    slice_loop(std::false_type{});
   // ---- segment result: scalar e^{sum mu}, optional row phases ----
   double sn, cs;
   sincos(mus_i, &sn, &cs);
