@@ -443,6 +443,7 @@ int run_xg_midd(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, dou
   a.mode = C3P_MODE_EXPM;
   a.dUs_out = dUs_out;
   a.no_t18 = getenv("C3P_NO_T18") ? 1 : 0;
+  a.no_real = getenv("C3P_NO_REAL") ? 1 : 0;
   if (S == 1) {
     a.seg_out = U_out;
     a.fr_phase = fr_phase;
@@ -651,6 +652,7 @@ int run_pwc_midd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   a.mode = lindblad ? C3P_MODE_LINDBLAD : C3P_MODE_UNITARY;
   a.dUs_out = dUs_out;
   a.no_t18 = getenv("C3P_NO_T18") ? 1 : 0;
+  a.no_real = getenv("C3P_NO_REAL") ? 1 : 0;
   if (S == 1) {
     a.seg_out = U_out;
     a.fr_phase = fr_phase;

@@ -17,6 +17,7 @@ struct MidArgs {
   int S, Lmax;
   int mode, right_order;
   int no_t18;  // debug/tuning: force the Paterson-Stockmeyer plan
+  int no_real;  // debug/tuning: keep real Hamiltonians on the complex path
   cplx* seg_out;
   cplx* dUs_out;
 };

@@ -159,6 +159,7 @@ struct MidCommon {
   int D, nbk, K;
   int sample, n0, len;
   int aoff, boff, lbig, lsmall;
+  int aoffR, nbkR, realH;  // real-Hamiltonian path: A-slab offset of a REAL image, its K-steps, the flag
   unsigned negmask;
   int pr, ps, t18;
   double scale;
@@ -209,6 +210,280 @@ __device__ __forceinline__ void mm_tiles(const double* imgA, const double* imgB,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Real-Hamiltonian path (unitary mode, every table purely imaginary: H real).  X = -iY with Y real, so
+//   exp(X) = cos Y - i sin Y,  cos Y = p_c(W),  sin Y = Y p_s(W),  W = Y^2  (Taylor degree 18 / 17, the
+// T18 scaling rule), all in REAL D x D products: a real image has 16 NIGR rows (NIGR = ceil(NIG / 2)) and
+// a real product runs ceil(D / 4) K-steps -- a quarter of the complex product's MFMA work.  Per slice
+// 8 + 2 s + 4 real products (W, W^2, W^3, two paired Horner steps in W^3, Y p_s; squarings
+// cos 2Y = 2 C^2 - I, sin 2Y = 2 S C; chain Ur' = C Ur + S Ui, Ui' = C Ui - S Ur) instead of
+// (5 + s + 1) complex = 24 + 4 s real-equivalent ones.  Products that share an operand are issued
+// together (MODE 1: shared left operand, MODE 2: shared right operand) and share its LDS reads.
+// ---------------------------------------------------------------------------------------------
+template <int NIGR, int NJ, int W, int WV, int MODE>
+__device__ __forceinline__ void mm_real(const double* A1, const double* A2, const double* B1, const double* B2,
+                                        const MidCommon& cm,
+                                        TileRegs<WaveTiles<NIGR, NJ, W, WV>::NBW, WaveTiles<NIGR, NJ, W, WV>::NSW>& acc1,
+                                        TileRegs<WaveTiles<NIGR, NJ, W, WV>::NBW, WaveTiles<NIGR, NJ, W, WV>::NSW>& acc2) {
+  using T = WaveTiles<NIGR, NJ, W, WV>;
+  using S = Sched<NIGR, NJ>;
+  constexpr int NB16 = S::NB16 > 0 ? S::NB16 : 1;
+  constexpr int JR = S::JR > 0 ? S::JR : 1;
+  constexpr bool TWOA = MODE == 2, TWOB = MODE == 1;
+  double a0[NIGR], a1[NIGR], g0[NB16], g1[NB16], s0[JR], s1[JR];
+  double x0[NIGR], x1[NIGR], h0[NB16], h1[NB16], u0[JR], u1[JR];  // second left / right operand
+  const double* pa = A1 + cm.aoffR;
+  const double* px = A2 + cm.aoffR;
+  const double* pg = B1 + cm.lbig;
+  const double* ph = B2 + cm.lbig;
+  const double* ps4 = B1 + cm.boff;
+  const double* pu4 = B2 + cm.boff;
+  auto load = [&](double (&a)[NIGR], double (&x)[NIGR], double (&g)[NB16], double (&h)[NB16], double (&sb)[JR],
+                  double (&ub)[JR], int K) {
+#pragma unroll
+    for (int Ig = 0; Ig < NIGR; ++Ig) {
+      a[Ig] = T::uses_ig(Ig) ? pa[Ig * 16 * W + 4 * K] : 0.0;
+      x[Ig] = (TWOA && T::uses_ig(Ig)) ? px[Ig * 16 * W + 4 * K] : 0.0;
+    }
+#pragma unroll
+    for (int Jg = 0; Jg < S::NB16; ++Jg) {
+      g[Jg] = T::uses_jg(Jg) ? pg[K * 4 * W + 16 * Jg] : 0.0;
+      h[Jg] = (TWOB && T::uses_jg(Jg)) ? ph[K * 4 * W + 16 * Jg] : 0.0;
+    }
+#pragma unroll
+    for (int js = 0; js < S::JR; ++js) {
+      sb[js] = T::uses_j(4 * S::NB16 + js) ? ps4[K * 4 * W + 4 * (4 * S::NB16 + js)] : 0.0;
+      ub[js] = (TWOB && T::uses_j(4 * S::NB16 + js)) ? pu4[K * 4 * W + 4 * (4 * S::NB16 + js)] : 0.0;
+    }
+  };
+  auto fmas = [&](const double (&a)[NIGR], const double (&x)[NIGR], const double (&g)[NB16], const double (&h)[NB16],
+                  const double (&sb)[JR], const double (&ub)[JR]) {
+#pragma unroll
+    for (int i = 0; i < T::NBW; ++i) {
+      acc1.big[i] = md_mfma16(a[T::bIg(i)], g[T::bJg(i)], acc1.big[i]);
+      if constexpr (TWOB) acc2.big[i] = md_mfma16(a[T::bIg(i)], h[T::bJg(i)], acc2.big[i]);
+      if constexpr (TWOA) acc2.big[i] = md_mfma16(x[T::bIg(i)], g[T::bJg(i)], acc2.big[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < T::NSW; ++i) {
+      acc1.sm[i] = md_mfma4(a[T::sIg(i)], sb[T::sJ(i) - 4 * S::NB16], acc1.sm[i]);
+      if constexpr (TWOB) acc2.sm[i] = md_mfma4(a[T::sIg(i)], ub[T::sJ(i) - 4 * S::NB16], acc2.sm[i]);
+      if constexpr (TWOA) acc2.sm[i] = md_mfma4(x[T::sIg(i)], sb[T::sJ(i) - 4 * S::NB16], acc2.sm[i]);
+    }
+  };
+  const int nbk = cm.nbkR;
+  load(a0, x0, g0, h0, s0, u0, 0);
+  for (int K = 0; K < nbk; K += 2) {
+    const int K1 = (K + 1 < nbk) ? K + 1 : K;
+    load(a1, x1, g1, h1, s1, u1, K1);
+    __builtin_amdgcn_sched_barrier(0);
+    fmas(a0, x0, g0, h0, s0, u0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int K2 = (K + 2 < nbk) ? K + 2 : K;
+    load(a0, x0, g0, h0, s0, u0, K2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (K + 1 < nbk) fmas(a1, x1, g1, h1, s1, u1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int NIG>
+struct MDR {
+  static constexpr int NIGR = (NIG + 1) / 2;
+  static constexpr int NIMG = 5;  // real images of the slice pipeline
+  // LDS rows of the image area: three complex images or NIMG real ones
+  static constexpr int AREA_ROWS = 3 * 16 * NIG > NIMG * 16 * NIGR ? 3 * 16 * NIG : NIMG * 16 * NIGR;
+};
+
+template <int NIG, int NJ, int W, bool DUS, int WV>
+__device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon& cm, long chain) {
+  constexpr int NIGR = MDR<NIG>::NIGR;
+  using T = WaveTiles<NIGR, NJ, W, WV>;
+  constexpr int IMG = MD<NIG, NJ>::ROWS * W;  // complex table image
+  constexpr int IMGR = 16 * NIGR * W, NE = T::NE;
+  typedef TileRegs<T::NBW, T::NSW> Regs;
+  const int D = cm.D, K = cm.K;
+  const int lbig = cm.lbig, lsmall = cm.lsmall;
+  const int rbig = cm.r, rsmall = 4 * cm.b + cm.r;
+  const int cbig = 4 * cm.b + cm.c, csmall = cm.c;
+  const double* tabs = cm.tabs;
+  double* R0 = c3p_md_lds;
+  double* R1 = R0 + IMGR;
+  double* R2 = R1 + IMGR;
+  double* R3 = R2 + IMGR;
+  double* R4 = R3 + IMGR;
+  auto eoff = [&](int e) -> int { return T::off0(e) + (T::is_big(e) ? lbig : lsmall); };
+  auto erow = [&](int e) -> int { return T::row0(e) + (T::is_big(e) ? rbig : rsmall); };
+  auto ecol = [&](int e) -> int { return T::col0(e) + (T::is_big(e) ? cbig : csmall); };
+  auto store_tiles = [&](double* img, const Regs& v) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) img[eoff(e)] = v.get(e);
+  };
+  auto zero = [&](Regs& v) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v.set(e, 0.0);
+  };
+  // Im rows of the half-image tables hold -Y; positions outside the matrix are clamped and masked
+  constexpr int NE1 = NE > 0 ? NE : 1;
+  int yoff[NE1];
+  double ymask[NE1], dmask[NE1];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int row = erow(e), col = ecol(e);
+    const bool in = row < D && col < D;
+    yoff[e] = in ? (2 * row + 1) * W + col : 0;
+    ymask[e] = in ? 1.0 : 0.0;
+    dmask[e] = (in && row == col) ? 1.0 : 0.0;
+  }
+  Regs Ur, Ui;
+  double mus_r = 0.0, mus_i = 0.0;
+  Regs dummy;
+
+  for (int t = 0; t < cm.len; ++t) {
+    double mu_r = tabs[IMG + 0], mu_i = tabs[IMG + 1];
+    Regs Y;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) Y.set(e, -cm.scale * ymask[e] * tabs[yoff[e]]);
+    for (int k = 0; k < K; ++k) {
+      const double c0 = cm.sg[k * A.Lmax + t];
+      const double ck = -cm.scale * c0;
+      const double* tk = tabs + (long)(k + 1) * (IMG + 4);
+      mu_r = fma(c0, tk[IMG + 0], mu_r);
+      mu_i = fma(c0, tk[IMG + 1], mu_i);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) Y.set(e, fma(ck * ymask[e], tk[yoff[e]], Y.get(e)));
+    }
+    store_tiles(R0, Y);
+    __syncthreads();
+    Regs W1, W2, W3, Cm, Sp, acc, acs;
+    zero(W1);
+    mm_real<NIGR, NJ, W, WV, 0>(R0, R0, R0, R0, cm, W1, dummy);  // W = Y^2
+    store_tiles(R1, W1);
+    __syncthreads();
+    zero(W2);
+    mm_real<NIGR, NJ, W, WV, 0>(R1, R1, R1, R1, cm, W2, dummy);  // W^2
+    store_tiles(R2, W2);
+    __syncthreads();
+    zero(W3);
+    mm_real<NIGR, NJ, W, WV, 0>(R1, R1, R2, R2, cm, W3, dummy);  // W^3
+    auto rc = [&](Regs& out, double c0, double c1, double c2, double c3) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        double v = c1 * W1.get(e);
+        v = fma(c2, W2.get(e), v);
+        v = fma(c3, W3.get(e), v);
+        out.set(e, fma(c0, dmask[e], v));
+      }
+    };
+    // cos: c_j = (-1)^j / (2j)!;  sin / Y: s_j = (-1)^j / (2j+1)!;  both by Horner in W^3, paired
+    rc(Cm, c3p_inv_fact[12], -c3p_inv_fact[14], c3p_inv_fact[16], -c3p_inv_fact[18]);
+    rc(Sp, c3p_inv_fact[13], -c3p_inv_fact[15], c3p_inv_fact[17], 0.0);
+    store_tiles(R3, W3);
+    store_tiles(R0, Cm);
+    store_tiles(R4, Sp);
+    __syncthreads();
+    rc(acc, -c3p_inv_fact[6], c3p_inv_fact[8], -c3p_inv_fact[10], 0.0);
+    rc(acs, -c3p_inv_fact[7], c3p_inv_fact[9], -c3p_inv_fact[11], 0.0);
+    mm_real<NIGR, NJ, W, WV, 1>(R3, R3, R0, R4, cm, acc, acs);
+    store_tiles(R1, acc);
+    store_tiles(R2, acs);
+    __syncthreads();
+    rc(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], 0.0);
+    rc(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], 0.0);
+    mm_real<NIGR, NJ, W, WV, 1>(R3, R3, R1, R2, cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
+    store_tiles(R0, Sp);
+    store_tiles(R4, Y);
+    __syncthreads();
+    Regs Sn;
+    zero(Sn);
+    mm_real<NIGR, NJ, W, WV, 0>(R4, R4, R0, R0, cm, Sn, dummy);  // sin Y
+    // ---- squarings in real form: cos 2Y = 2 C^2 - I, sin 2Y = 2 S C (image pairs alternate: no extra barrier) ----
+    for (int it = 0; it < cm.ps; ++it) {
+      double* Ra = (it & 1) ? R3 : R1;
+      double* Rb = (it & 1) ? R4 : R2;
+      store_tiles(Ra, Cm);
+      store_tiles(Rb, Sn);
+      __syncthreads();
+      Regs C2, SC;
+      zero(C2);
+      zero(SC);
+      mm_real<NIGR, NJ, W, WV, 2>(Ra, Rb, Ra, Ra, cm, C2, SC);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        Cm.set(e, fma(2.0, C2.get(e), -dmask[e]));
+        Sn.set(e, 2.0 * SC.get(e));
+      }
+    }
+    if constexpr (DUS) {
+      // dU = e^{mu} (C - iS)
+      double sn, cs;
+      sincos(mu_i, &sn, &cs);
+      const double er = exp(mu_r);
+      const double pr = er * cs, pi = er * sn;
+      double* dst = reinterpret_cast<double*>(A.dUs_out) + ((long)cm.sample * A.N + cm.n0 + t) * D * D * 2;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int row = erow(e), col = ecol(e);
+        if (row < D && col < D) {
+          dst[(row * D + col) * 2 + 0] = fma(pr, Cm.get(e), pi * Sn.get(e));
+          dst[(row * D + col) * 2 + 1] = fma(pi, Cm.get(e), -pr * Sn.get(e));
+        }
+      }
+    }
+    // ---- chain in real blocks: Ur' = C Ur + S Ui,  Ui' = C Ui - S Ur ----
+    if (t == 0) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        Ur.set(e, Cm.get(e));
+        Ui.set(e, -Sn.get(e));
+      }
+      mus_r = mu_r;
+      mus_i = c3p_phase_add(0.0, mu_i);
+      __syncthreads();  // R0 is rewritten by the next slice
+    } else {
+      __syncthreads();  // the last product's operands are no longer read
+      store_tiles(R1, Cm);
+      store_tiles(R2, Sn);
+      store_tiles(R3, Ur);
+      store_tiles(R4, Ui);
+      __syncthreads();
+      Regs Vr, Vi;
+      zero(Vr);
+      zero(Vi);
+      mm_real<NIGR, NJ, W, WV, 1>(R2, R2, R4, R3, cm, Vr, Vi);  // S Ui, S Ur
+#pragma unroll
+      for (int e = 0; e < NE; ++e) Vi.set(e, -Vi.get(e));
+      mm_real<NIGR, NJ, W, WV, 1>(R1, R1, R3, R4, cm, Vr, Vi);  // + C Ur, + C Ui
+      Ur = Vr;
+      Ui = Vi;
+      mus_r += mu_r;
+      mus_i = c3p_phase_add(mus_i, mu_i);
+    }
+  }
+  // ---- segment result: e^{sum mu} (Ur + i Ui), optional row phases ----
+  double sn, cs;
+  sincos(mus_i, &sn, &cs);
+  const double er = exp(mus_r);
+  double* dst = reinterpret_cast<double*>(A.seg_out) + chain * D * D * 2;
+  const double* ph = A.fr_phase ? A.fr_phase + (long)cm.sample * D : nullptr;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int row = erow(e), col = ecol(e);
+    if (row < D && col < D) {
+      double sr = er * cs, si = er * sn;
+      if (ph != nullptr) {
+        double s2, c2;
+        sincos(ph[row], &s2, &c2);
+        const double tr = sr * c2 - si * s2;
+        si = sr * s2 + si * c2;
+        sr = tr;
+      }
+      dst[(row * D + col) * 2 + 0] = fma(sr, Ur.get(e), -si * Ui.get(e));
+      dst[(row * D + col) * 2 + 1] = fma(sr, Ui.get(e), si * Ur.get(e));
+    }
+  }
+}
+
 // The whole slice loop, specialised per wave so that every tile index is a compile-time
 // constant (LDS offsets become instruction immediates; no per-tile predication).
 template <int NIG, int NJ, int W, bool GIVEN, bool DUS, bool XG, int WV>
@@ -223,6 +498,12 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
   const int cbig = 4 * cm.b + cm.c, csmall = cm.c;   // column inside the unit
   double mus_r = 0.0, mus_i = 0.0;
   const double* tabs = cm.tabs;
+  if constexpr (!GIVEN && !XG) {
+    if (cm.realH) {
+      midd_real_body<NIG, NJ, W, DUS, WV>(A, cm, chain);
+      return;
+    }
+  }
   Regs U;
 
   auto eoff = [&](int e) -> int { return T::off0(e) + (T::is_big(e) ? lbig : lsmall); };
@@ -455,8 +736,8 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
 
 template <int NIG, int W>
 struct MidOcc {
-  static constexpr int IMG_BYTES = 16 * NIG * W * 8;
-  static constexpr int WGS = (3 * IMG_BYTES + 6144) * 3 <= 160 * 1024 ? 3 : 2;
+  static constexpr int AREA_BYTES = MDR<NIG>::AREA_ROWS * W * 8;
+  static constexpr int WGS = (AREA_BYTES + 6144) * 3 <= 160 * 1024 ? 3 : 2;
 };
 
 template <int NIG, int NJ, int W, bool GIVEN, bool DUS, bool XG = false>
@@ -472,13 +753,15 @@ __global__ void __launch_bounds__(256, (MidOcc<NIG, W>::WGS)) midd_chain_kernel(
   cm.c = cm.lane & 3;
   cm.D = A.Dm;
   cm.nbk = (2 * cm.D + 3) / 4;
+  cm.nbkR = (cm.D + 3) / 4;
   cm.K = A.K;
   const int K = A.K;
+  constexpr int AREA = MDR<NIG>::AREA_ROWS * W;  // image area: 3 complex images or 5 real ones
 
   cm.buf0 = c3p_md_lds;
   cm.buf1 = cm.buf0 + IMG;
   cm.buf2 = cm.buf1 + IMG;
-  cm.sg = cm.buf2 + IMG;  // K x Lmax control amplitudes of the segment
+  cm.sg = cm.buf0 + AREA;  // K x Lmax control amplitudes of the segment
   __shared__ double red[NW];
 
   const long chain = blockIdx.x;
@@ -490,13 +773,14 @@ __global__ void __launch_bounds__(256, (MidOcc<NIG, W>::WGS)) midd_chain_kernel(
 
   // lane geometry
   cm.aoff = (4 * cm.b + (cm.c & ~1) + ((cm.c ^ cm.r) & 1)) * W + (cm.r >> 1);
+  cm.aoffR = (4 * cm.b + cm.c) * W + cm.r;  // real image: row 4b + c of the 16-row group, column r of the K-step
   cm.boff = cm.r * W + cm.c;
   cm.lsmall = (4 * cm.b + cm.r) * W + cm.c;  // element of a 16x4 unit: row 4b + r, column c
   cm.lbig = cm.r * W + 4 * cm.b + cm.c;      // element of a 16x16 unit (register q adds 4q rows): row r, column 4b + c
   cm.negmask = (((cm.c & 1) == 0) && ((cm.r & 1) == 1)) ? 0x80000000u : 0u;
 
   // zero all images once (padding rows/columns must stay zero)
-  for (int e = tid; e < 3 * IMG; e += 256) c3p_md_lds[e] = 0.0;
+  for (int e = tid; e < AREA; e += 256) c3p_md_lds[e] = 0.0;
   __syncthreads();
 
   cm.tabs = XG ? nullptr : A.tables + (long)(A.tab_per_sample ? cm.sample : 0) * (1 + K) * (IMG + 4);
@@ -504,6 +788,7 @@ __global__ void __launch_bounds__(256, (MidOcc<NIG, W>::WGS)) midd_chain_kernel(
   cm.ps = 0;
   cm.t18 = 0;
   cm.scale = 1.0;
+  cm.realH = 0;
   if constexpr (!GIVEN) {
     // segment-wide plan from ||G0|| + sum_k max_t |c_k(t)| ||G_k||  (XG: max of the per-slice norms)
     double nrm = 0.0;
@@ -543,6 +828,21 @@ __global__ void __launch_bounds__(256, (MidOcc<NIG, W>::WGS)) midd_chain_kernel(
       cm.t18 = 0;
       cm.pr = __builtin_amdgcn_readfirstlane(q.r);
       cm.ps = __builtin_amdgcn_readfirstlane(q.s);
+    }
+    if constexpr (!XG) {
+      // every table purely imaginary (real Hamiltonian, unitary mode): real cos / sin path, T18 scaling rule
+      bool realH = A.mode == C3P_MODE_UNITARY && !A.no_real;
+      for (int k = 0; k <= K; ++k) realH = realH && (cm.tabs[(long)k * (IMG + 4) + IMG + 3] == 0.0);
+      cm.realH = __builtin_amdgcn_readfirstlane((int)realH);
+      if (cm.realH) {
+        int s18 = 0;
+        double p = C3P_T18_THETA;
+        while (p < nrm && s18 < 40) {
+          p *= 2.0;
+          ++s18;
+        }
+        cm.ps = __builtin_amdgcn_readfirstlane(s18);
+      }
     }
     cm.scale = ldexp(1.0, -cm.ps);
     __syncthreads();
@@ -608,7 +908,7 @@ __global__ void __launch_bounds__(256) midd_prep_kernel(MidPrepArgs P) {
     mu[1] = bq / D;
   }
   __syncthreads();
-  double cs = 0;
+  double cs = 0, remax = 0;
   for (int j = tid; j < D; j += 256) {
     double s = 0;
     for (int i = 0; i < D; ++i) {
@@ -618,10 +918,12 @@ __global__ void __launch_bounds__(256) midd_prep_kernel(MidPrepArgs P) {
         v.y -= mu[1];
       }
       s += hypot(v.x, v.y);
+      remax = fmax(remax, fabs(v.x));
     }
     cs = fmax(cs, s);
   }
   redr[tid] = cs;
+  redi[tid] = remax;
   __syncthreads();
   const int IMG = P.tile_nig ? P.tile_nig * P.tile_nj * 64 : P.rows * P.W;
   double* out = P.tables + ((long)sample * (1 + P.K) + ti) * (IMG + 4);
@@ -650,19 +952,22 @@ __global__ void __launch_bounds__(256) midd_prep_kernel(MidPrepArgs P) {
     out[e] = v;
   }
   if (tid == 0) {
-    double nrm = 0;
-    for (int i = 0; i < 256; ++i) nrm = fmax(nrm, redr[i]);
+    double nrm = 0, re = 0;
+    for (int i = 0; i < 256; ++i) {
+      nrm = fmax(nrm, redr[i]);
+      re = fmax(re, redi[i]);
+    }
     out[IMG + 0] = mu[0];
     out[IMG + 1] = mu[1];
     out[IMG + 2] = nrm;
-    out[IMG + 3] = 0.0;
+    out[IMG + 3] = P.lindblad ? 1.0 : re;  // 0: G purely imaginary (real Hamiltonian) -> real path of the mid-D kernel
   }
 }
 
 template <int NIG, int NJ, int W>
 hipError_t launch_t(const MidArgs& A, hipStream_t st) {
   constexpr int IMG = MD<NIG, NJ>::ROWS * W;
-  const size_t lds = (size_t)(3 * IMG + (A.mode == C3P_MODE_GIVEN ? 0 : A.K * A.Lmax)) * sizeof(double);
+  const size_t lds = (size_t)(MDR<NIG>::AREA_ROWS * W + (A.mode == C3P_MODE_GIVEN ? 0 : A.K * A.Lmax)) * sizeof(double);
   const unsigned grid = (unsigned)((long)A.B * A.S);
   auto go = [&](auto kern) -> hipError_t {
     if (lds > 64 * 1024) {
@@ -1014,7 +1319,9 @@ size_t c3p_midd_table_doubles(int Dm, int K) {
 size_t c3p_midd_lds_bytes(int Dm, int K, int Lmax) {
   int nig, nj, w;
   if (!c3p_midd_geometry(Dm, &nig, &nj, &w)) return 0;
-  return ((size_t)3 * 16 * nig * w + (size_t)K * Lmax) * sizeof(double);
+  const int nigr = (nig + 1) / 2;
+  const int rows = 3 * 16 * nig > 5 * 16 * nigr ? 3 * 16 * nig : 5 * 16 * nigr;  // MDR<NIG>::AREA_ROWS
+  return ((size_t)rows * w + (size_t)K * Lmax) * sizeof(double);
 }
 
 hipError_t c3p_launch_midd_chain(const MidArgs& A, hipStream_t st) {

@@ -113,12 +113,12 @@ def test_every_dimension_and_kernel(prop, D, force_generic):
     assert _lib.last_kernel() == expect
 
 
-@pytest.mark.parametrize("D", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("D", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 17, 20, 23, 24, 27, 28, 31, 32, 36, 37, 40])
 @pytest.mark.parametrize("strength", [1.0, 6.0])
 def test_real_hamiltonian_fast_path(prop, D, strength):
-    """Real symmetric h0 / hk take the cos / sin path of the small-D kernel (every template instance, with and
-    without squarings, partial propagators, per-sample operators); one complex hk sends the same call back
-    to the complex path -- both must agree with the oracle."""
+    """Real symmetric h0 / hk take the cos / sin path of the small-D (D <= 12) and mid-D (13..40) kernels (every
+    template instance, with and without squarings, partial propagators, per-sample operators); one complex hk
+    sends the same call back to the complex path -- both must agree with the oracle."""
     rng = np.random.default_rng(100 + D)
     B, K, N = 4, 2, 29
 
