@@ -411,6 +411,24 @@ int run_vjp_midd(DeviceWs* w, GradArgs& G, hipStream_t st) {
   return 0;
 }
 
+// Time segments per sample for the workgroup-per-chain kernels.  B S chains run in ceil(B S / slots) rounds of
+// `slots` resident workgroups, each N / S slices long (+ a few slices' worth of prologue): take the S that
+// minimises rounds x segment length, so that the last round is not a mostly idle tail.
+static long pick_segments(long B, long N, long slots, long smax) {
+  long best = 1;
+  double best_cost = 1e300;
+  if (smax > 96) smax = 96;
+  for (long S = 1; S <= smax; ++S) {
+    const long rounds = (B * S + slots - 1) / slots;
+    const double cost = (double)rounds * (double)((N + S - 1) / S + 4);
+    if (cost < best_cost * (1.0 - 1e-9)) {
+      best_cost = cost;
+      best = S;
+    }
+  }
+  return best;
+}
+
 // Supplied generators on the mid-D MFMA kernel (13 <= D <= 40); see run_xg_smalld.
 int run_xg_midd(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, double coef_i, int B, int N, int D,
                 const double* fr_phase, cplx* U_out, cplx* dUs_out, hipStream_t st) {
@@ -420,11 +438,8 @@ int run_xg_midd(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, dou
   int wg_per_cu = (int)((156 * 1024) / (lds0 + 4096));
   if (wg_per_cu > 3) wg_per_cu = 3;
   if (wg_per_cu < 1) wg_per_cu = 1;
-  const long target = 256L * wg_per_cu * 2;
-  long S = (target + B - 1) / B;
   const long smax = N / 8 > 1 ? N / 8 : 1;
-  if (S > smax) S = smax;
-  if (S < 1) S = 1;
+  const long S = pick_segments(B, N, 256L * wg_per_cu, smax);
   void* mv;
   if (ws_get(w, SL_TABLES, (size_t)B * N * 4 * sizeof(double), &mv)) return -1;
   HIP_TRY(c3p_launch_hmeta(hs, hs_bstride, (long)B * N, N, D, coef_r, coef_i, (double*)mv, st));
@@ -612,15 +627,9 @@ int run_pwc_midd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   int wg_per_cu = (int)((156 * 1024) / (lds0 + 4096));
   if (wg_per_cu > 3) wg_per_cu = 3;
   if (wg_per_cu < 1) wg_per_cu = 1;
-  const long target = 256L * wg_per_cu * 2;
-  long S = (target + B - 1) / B;
   const long smax = N / 8 > 1 ? N / 8 : 1;
-  if (S > smax) S = smax;
-  if (S < 1) S = 1;
-  // the segment's control amplitudes live in LDS next to the images
-  const size_t budget = (size_t)(158 * 1024) / wg_per_cu;
-  while (c3p_midd_lds_bytes(Dm, K, (int)((N + S - 1) / S)) > budget && S < N) ++S;
-  if (c3p_midd_lds_bytes(Dm, K, (int)((N + S - 1) / S)) > 158 * 1024) return 1;
+  const long S = pick_segments(B, N, 256L * wg_per_cu, smax);
+  if (lds0 > 158 * 1024) return 1;
   const int nsamp = per_sample ? B : 1;
   void* v;
   if (ws_get(w, SL_TABLES, (size_t)nsamp * c3p_midd_table_doubles(Dm, K) * sizeof(double), &v)) return -1;

@@ -32,6 +32,7 @@ extern __shared__ __attribute__((aligned(16))) double c3p_md_lds[];
 namespace {
 
 constexpr int NW = 4;  // wavefronts per workgroup
+constexpr int SGC = 64;  // slices of control amplitudes staged in LDS at a time (chain kernel)
 
 __device__ __forceinline__ double md_mfma4(double a, double b, double c) {
   return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
@@ -210,6 +211,19 @@ __device__ __forceinline__ void mm_tiles(const double* imgA, const double* imgB,
   }
 }
 
+// Stage the control amplitudes of slices [t0, t0 + SGC) of the chain's segment in LDS (all four waves call this
+// at the same t0).  Readers of the previous chunk are at least one barrier behind its last use.
+template <int WV>
+__device__ __forceinline__ void md_stage_signals(const MidArgs& A, const MidCommon& cm, int t0) {
+  const int tid = WV * 64 + cm.lane;
+  __syncthreads();
+  for (int i = tid; i < cm.K * SGC; i += 256) {
+    const int k = i / SGC, j = i - k * SGC;
+    if (t0 + j < cm.len) cm.sg[i] = A.signals[((long)cm.sample * cm.K + k) * A.N + cm.n0 + t0 + j];
+  }
+  __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------
 // Real-Hamiltonian path (unitary mode, every table purely imaginary: H real).  X = -iY with Y real, so
 //   exp(X) = cos Y - i sin Y,  cos Y = p_c(W),  sin Y = Y p_s(W),  W = Y^2  (Taylor degree 18 / 17, the
@@ -339,13 +353,18 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
   double mus_r = 0.0, mus_i = 0.0;
   Regs dummy;
 
+  // instantiated per polynomial variant with the branch outside the loop (as in the small-D kernel): below
+  // theta_16 = 0.816 the degree-16 / 17 polynomials are exact to roundoff and W^3, W^4 are one paired product
+  auto real_loop = [&](auto deg16_tag) {
+  constexpr bool DEG16 = decltype(deg16_tag)::value;
   for (int t = 0; t < cm.len; ++t) {
+    if ((t & (SGC - 1)) == 0) md_stage_signals<WV>(A, cm, t);
     double mu_r = tabs[IMG + 0], mu_i = tabs[IMG + 1];
     Regs Y;
 #pragma unroll
     for (int e = 0; e < NE; ++e) Y.set(e, -cm.scale * ymask[e] * tabs[yoff[e]]);
     for (int k = 0; k < K; ++k) {
-      const double c0 = cm.sg[k * A.Lmax + t];
+      const double c0 = cm.sg[k * SGC + (t & (SGC - 1))];
       const double ck = -cm.scale * c0;
       const double* tk = tabs + (long)(k + 1) * (IMG + 4);
       mu_r = fma(c0, tk[IMG + 0], mu_r);
@@ -365,7 +384,6 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
     store_tiles(R2, W2);
     __syncthreads();
     zero(W3);
-    mm_real<NIGR, NJ, W, WV, 0>(R1, R1, R2, R2, cm, W3, dummy);  // W^3
     auto rc = [&](Regs& out, double c0, double c1, double c2, double c3) {
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
@@ -375,32 +393,61 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
         out.set(e, fma(c0, dmask[e], v));
       }
     };
-    // cos: c_j = (-1)^j / (2j)!;  sin / Y: s_j = (-1)^j / (2j+1)!;  both by Horner in W^3, paired
-    rc(Cm, c3p_inv_fact[12], -c3p_inv_fact[14], c3p_inv_fact[16], -c3p_inv_fact[18]);
-    rc(Sp, c3p_inv_fact[13], -c3p_inv_fact[15], c3p_inv_fact[17], 0.0);
-    store_tiles(R3, W3);
-    store_tiles(R0, Cm);
-    store_tiles(R4, Sp);
-    __syncthreads();
-    rc(acc, -c3p_inv_fact[6], c3p_inv_fact[8], -c3p_inv_fact[10], 0.0);
-    rc(acs, -c3p_inv_fact[7], c3p_inv_fact[9], -c3p_inv_fact[11], 0.0);
-    mm_real<NIGR, NJ, W, WV, 1>(R3, R3, R0, R4, cm, acc, acs);
-    store_tiles(R1, acc);
-    store_tiles(R2, acs);
-    __syncthreads();
-    rc(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], 0.0);
-    rc(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], 0.0);
-    mm_real<NIGR, NJ, W, WV, 1>(R3, R3, R1, R2, cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
-    store_tiles(R0, Sp);
-    store_tiles(R4, Y);
-    __syncthreads();
     Regs Sn;
     zero(Sn);
-    mm_real<NIGR, NJ, W, WV, 0>(R4, R4, R0, R0, cm, Sn, dummy);  // sin Y
+    // cos: c_j = (-1)^j / (2j)!;  sin / Y: s_j = (-1)^j / (2j+1)!
+    if constexpr (DEG16) {
+      // q = 4: {W^3, W^4} = {W, W^2} W^2 as one paired product, then ONE paired Horner step in W^4
+      Regs W4;
+      zero(W4);
+      mm_real<NIGR, NJ, W, WV, 2>(R1, R2, R2, R2, cm, W3, W4);
+      rc(acc, c3p_inv_fact[8], -c3p_inv_fact[10], c3p_inv_fact[12], -c3p_inv_fact[14]);
+      rc(acs, c3p_inv_fact[9], -c3p_inv_fact[11], c3p_inv_fact[13], -c3p_inv_fact[15]);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        acc.set(e, fma(c3p_inv_fact[16], W4.get(e), acc.get(e)));
+        acs.set(e, fma(c3p_inv_fact[17], W4.get(e), acs.get(e)));
+      }
+      store_tiles(R3, W4);
+      store_tiles(R0, acc);
+      store_tiles(R4, acs);
+      __syncthreads();
+      rc(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], -c3p_inv_fact[6]);
+      rc(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7]);
+      mm_real<NIGR, NJ, W, WV, 1>(R3, R3, R0, R4, cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
+      store_tiles(R1, Sp);
+      store_tiles(R2, Y);
+      __syncthreads();
+      mm_real<NIGR, NJ, W, WV, 0>(R2, R2, R1, R1, cm, Sn, dummy);  // sin Y
+    } else {
+      // degree 18 / 17: two paired Horner steps in W^3
+      mm_real<NIGR, NJ, W, WV, 0>(R1, R1, R2, R2, cm, W3, dummy);  // W^3
+      rc(Cm, c3p_inv_fact[12], -c3p_inv_fact[14], c3p_inv_fact[16], -c3p_inv_fact[18]);
+      rc(Sp, c3p_inv_fact[13], -c3p_inv_fact[15], c3p_inv_fact[17], 0.0);
+      store_tiles(R3, W3);
+      store_tiles(R0, Cm);
+      store_tiles(R4, Sp);
+      __syncthreads();
+      rc(acc, -c3p_inv_fact[6], c3p_inv_fact[8], -c3p_inv_fact[10], 0.0);
+      rc(acs, -c3p_inv_fact[7], c3p_inv_fact[9], -c3p_inv_fact[11], 0.0);
+      mm_real<NIGR, NJ, W, WV, 1>(R3, R3, R0, R4, cm, acc, acs);
+      store_tiles(R1, acc);
+      store_tiles(R2, acs);
+      __syncthreads();
+      rc(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], 0.0);
+      rc(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], 0.0);
+      mm_real<NIGR, NJ, W, WV, 1>(R3, R3, R1, R2, cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
+      store_tiles(R0, Sp);
+      store_tiles(R4, Y);
+      __syncthreads();
+      mm_real<NIGR, NJ, W, WV, 0>(R4, R4, R0, R0, cm, Sn, dummy);  // sin Y
+    }
     // ---- squarings in real form: cos 2Y = 2 C^2 - I, sin 2Y = 2 S C (image pairs alternate: no extra barrier) ----
     for (int it = 0; it < cm.ps; ++it) {
-      double* Ra = (it & 1) ? R3 : R1;
-      double* Rb = (it & 1) ? R4 : R2;
+      // the pair not read by the previous product
+      const bool hi = ((it & 1) != 0) != DEG16;
+      double* Ra = hi ? R3 : R1;
+      double* Rb = hi ? R4 : R2;
       store_tiles(Ra, Cm);
       store_tiles(Rb, Sn);
       __syncthreads();
@@ -460,6 +507,11 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       mus_i = c3p_phase_add(mus_i, mu_i);
     }
   }
+  };
+  if (cm.t18)  // (reused as the variant flag on the real path)
+    real_loop(std::true_type{});
+  else
+    real_loop(std::false_type{});
   // ---- segment result: e^{sum mu} (Ur + i Ui), optional row phases ----
   double sn, cs;
   sincos(mus_i, &sn, &cs);
@@ -550,6 +602,8 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
   auto slice_loop = [&](auto t18_tag) {
   constexpr bool T18 = decltype(t18_tag)::value;
   for (int t = 0; t < cm.len; ++t) {
+    if constexpr (!GIVEN && !XG)
+      if ((t & (SGC - 1)) == 0) md_stage_signals<WV>(A, cm, t);
     Regs P;
     zero(P);
     double mu_r = 0.0, mu_i = 0.0;
@@ -586,7 +640,7 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
 #pragma unroll
       for (int e = 0; e < NE; ++e) X.set(e, cm.scale * tabs[eoff(e)]);
       for (int k = 0; k < K; ++k) {
-        const double c0 = cm.sg[k * A.Lmax + t];
+        const double c0 = cm.sg[k * SGC + (t & (SGC - 1))];
         const double ck = cm.scale * c0;
         const double* tk = tabs + (long)(k + 1) * (IMG + 4);
         mu_r = fma(c0, tk[IMG + 0], mu_r);
@@ -761,7 +815,7 @@ __global__ void __launch_bounds__(256, (MidOcc<NIG, W>::WGS)) midd_chain_kernel(
   cm.buf0 = c3p_md_lds;
   cm.buf1 = cm.buf0 + IMG;
   cm.buf2 = cm.buf1 + IMG;
-  cm.sg = cm.buf0 + AREA;  // K x Lmax control amplitudes of the segment
+  cm.sg = cm.buf0 + AREA;  // K x SGC control amplitudes (a chunk of the segment)
   __shared__ double red[NW];
 
   const long chain = blockIdx.x;
@@ -808,7 +862,6 @@ __global__ void __launch_bounds__(256, (MidOcc<NIG, W>::WGS)) midd_chain_kernel(
       double cmax = 0.0;
       for (int t = tid; t < cm.len; t += 256) {
         const double v = s[t];
-        cm.sg[k * A.Lmax + t] = v;
         cmax = fmax(cmax, fabs(v));
       }
       for (int o = 32; o >= 1; o >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, o));
@@ -842,6 +895,7 @@ __global__ void __launch_bounds__(256, (MidOcc<NIG, W>::WGS)) midd_chain_kernel(
           ++s18;
         }
         cm.ps = __builtin_amdgcn_readfirstlane(s18);
+        cm.t18 = __builtin_amdgcn_readfirstlane((int)(ldexp(nrm, -s18) <= 8.16e-1));  // real path: degree-16 variant
       }
     }
     cm.scale = ldexp(1.0, -cm.ps);
@@ -967,7 +1021,7 @@ __global__ void __launch_bounds__(256) midd_prep_kernel(MidPrepArgs P) {
 template <int NIG, int NJ, int W>
 hipError_t launch_t(const MidArgs& A, hipStream_t st) {
   constexpr int IMG = MD<NIG, NJ>::ROWS * W;
-  const size_t lds = (size_t)(MDR<NIG>::AREA_ROWS * W + (A.mode == C3P_MODE_GIVEN ? 0 : A.K * A.Lmax)) * sizeof(double);
+  const size_t lds = (size_t)(MDR<NIG>::AREA_ROWS * W + (A.mode == C3P_MODE_GIVEN ? 0 : A.K * SGC)) * sizeof(double);
   const unsigned grid = (unsigned)((long)A.B * A.S);
   auto go = [&](auto kern) -> hipError_t {
     if (lds > 64 * 1024) {
@@ -1321,7 +1375,8 @@ size_t c3p_midd_lds_bytes(int Dm, int K, int Lmax) {
   if (!c3p_midd_geometry(Dm, &nig, &nj, &w)) return 0;
   const int nigr = (nig + 1) / 2;
   const int rows = 3 * 16 * nig > 5 * 16 * nigr ? 3 * 16 * nig : 5 * 16 * nigr;  // MDR<NIG>::AREA_ROWS
-  return ((size_t)rows * w + (size_t)K * Lmax) * sizeof(double);
+  (void)Lmax;  // the chain kernel stages the control amplitudes in chunks of SGC slices
+  return ((size_t)rows * w + (size_t)K * SGC) * sizeof(double);
 }
 
 hipError_t c3p_launch_midd_chain(const MidArgs& A, hipStream_t st) {

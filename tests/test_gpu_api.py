@@ -224,7 +224,7 @@ def test_mixed_real_and_complex_samples_in_one_launch(prop):
         assert np.linalg.norm(np.asarray(r["U"][b]) - ref) < 1e-10 * max(1.0, np.linalg.norm(ref))
 
 
-@pytest.mark.parametrize("D", [3, 5, 9, 12])
+@pytest.mark.parametrize("D", [3, 5, 9, 12, 14, 19, 27, 36, 40])
 @pytest.mark.parametrize("nrm", [0.5, 0.80, 0.83, 1.0, 1.12, 1.2, 1.7, 2.4])
 def test_real_path_polynomial_variants(prop, D, nrm):
     """both evaluations of the real path (degree 16 below ||Y|| = 0.816, degree 18 up to 1.13, squarings beyond) at
