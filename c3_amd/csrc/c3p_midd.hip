@@ -211,6 +211,10 @@ __device__ __forceinline__ void mm_tiles(const double* imgA, const double* imgB,
   }
 }
 
+// Workgroup barrier that waits for the LDS traffic only (__syncthreads also drains the vector-memory counter,
+// i.e. stalls on outstanding global stores of partial propagators).
+__device__ __forceinline__ void md_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Stage the control amplitudes of slices [t0, t0 + SGC) of the chain's segment in LDS (all four waves call this
 // at the same t0).  Readers of the previous chunk are at least one barrier behind its last use.
 template <int WV>
@@ -352,6 +356,23 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
   Regs Ur, Ui;
   double mus_r = 0.0, mus_i = 0.0;
   Regs dummy;
+  // the lane's table elements do not depend on the slice: kept in registers for the whole segment (the first
+  // KP control lines; any further ones are re-read per slice)
+  constexpr int KP = 4;
+  Regs Tab[KP + 1];
+#pragma unroll
+  for (int k = 0; k <= KP; ++k)
+    if (k <= K) {
+      const double* tk = tabs + (long)k * (IMG + 4);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) Tab[k].set(e, -cm.scale * ymask[e] * tk[yoff[e]]);
+    }
+  double tmu_r[KP + 1], tmu_i[KP + 1];
+#pragma unroll
+  for (int k = 0; k <= KP; ++k) {
+    tmu_r[k] = (k <= K) ? tabs[(long)k * (IMG + 4) + IMG + 0] : 0.0;
+    tmu_i[k] = (k <= K) ? tabs[(long)k * (IMG + 4) + IMG + 1] : 0.0;
+  }
 
   // instantiated per polynomial variant with the branch outside the loop (as in the small-D kernel): below
   // theta_16 = 0.816 the degree-16 / 17 polynomials are exact to roundoff and W^3, W^4 are one paired product
@@ -359,11 +380,18 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
   constexpr bool DEG16 = decltype(deg16_tag)::value;
   for (int t = 0; t < cm.len; ++t) {
     if ((t & (SGC - 1)) == 0) md_stage_signals<WV>(A, cm, t);
-    double mu_r = tabs[IMG + 0], mu_i = tabs[IMG + 1];
-    Regs Y;
+    double mu_r = tmu_r[0], mu_i = tmu_i[0];
+    Regs Y = Tab[0];
 #pragma unroll
-    for (int e = 0; e < NE; ++e) Y.set(e, -cm.scale * ymask[e] * tabs[yoff[e]]);
-    for (int k = 0; k < K; ++k) {
+    for (int k = 0; k < KP; ++k)
+      if (k < K) {
+        const double c0 = cm.sg[k * SGC + (t & (SGC - 1))];
+        mu_r = fma(c0, tmu_r[k + 1], mu_r);
+        mu_i = fma(c0, tmu_i[k + 1], mu_i);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) Y.set(e, fma(c0, Tab[k + 1].get(e), Y.get(e)));
+      }
+    for (int k = KP; k < K; ++k) {
       const double c0 = cm.sg[k * SGC + (t & (SGC - 1))];
       const double ck = -cm.scale * c0;
       const double* tk = tabs + (long)(k + 1) * (IMG + 4);
@@ -373,16 +401,16 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       for (int e = 0; e < NE; ++e) Y.set(e, fma(ck * ymask[e], tk[yoff[e]], Y.get(e)));
     }
     store_tiles(R0, Y);
-    __syncthreads();
+    md_bar();
     Regs W1, W2, W3, Cm, Sp, acc, acs;
     zero(W1);
     mm_real<NIGR, NJ, W, WV, 0>(R0, R0, R0, R0, cm, W1, dummy);  // W = Y^2
     store_tiles(R1, W1);
-    __syncthreads();
+    md_bar();
     zero(W2);
     mm_real<NIGR, NJ, W, WV, 0>(R1, R1, R1, R1, cm, W2, dummy);  // W^2
     store_tiles(R2, W2);
-    __syncthreads();
+    md_bar();
     zero(W3);
     auto rc = [&](Regs& out, double c0, double c1, double c2, double c3) {
 #pragma unroll
@@ -411,13 +439,13 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       store_tiles(R3, W4);
       store_tiles(R0, acc);
       store_tiles(R4, acs);
-      __syncthreads();
+      md_bar();
       rc(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], -c3p_inv_fact[6]);
       rc(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7]);
       mm_real<NIGR, NJ, W, WV, 1>(R3, R3, R0, R4, cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
       store_tiles(R1, Sp);
       store_tiles(R2, Y);
-      __syncthreads();
+      md_bar();
       mm_real<NIGR, NJ, W, WV, 0>(R2, R2, R1, R1, cm, Sn, dummy);  // sin Y
     } else {
       // degree 18 / 17: two paired Horner steps in W^3
@@ -427,19 +455,19 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       store_tiles(R3, W3);
       store_tiles(R0, Cm);
       store_tiles(R4, Sp);
-      __syncthreads();
+      md_bar();
       rc(acc, -c3p_inv_fact[6], c3p_inv_fact[8], -c3p_inv_fact[10], 0.0);
       rc(acs, -c3p_inv_fact[7], c3p_inv_fact[9], -c3p_inv_fact[11], 0.0);
       mm_real<NIGR, NJ, W, WV, 1>(R3, R3, R0, R4, cm, acc, acs);
       store_tiles(R1, acc);
       store_tiles(R2, acs);
-      __syncthreads();
+      md_bar();
       rc(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], 0.0);
       rc(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], 0.0);
       mm_real<NIGR, NJ, W, WV, 1>(R3, R3, R1, R2, cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
       store_tiles(R0, Sp);
       store_tiles(R4, Y);
-      __syncthreads();
+      md_bar();
       mm_real<NIGR, NJ, W, WV, 0>(R4, R4, R0, R0, cm, Sn, dummy);  // sin Y
     }
     // ---- squarings in real form: cos 2Y = 2 C^2 - I, sin 2Y = 2 S C (image pairs alternate: no extra barrier) ----
@@ -450,7 +478,7 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       double* Rb = hi ? R4 : R2;
       store_tiles(Ra, Cm);
       store_tiles(Rb, Sn);
-      __syncthreads();
+      md_bar();
       Regs C2, SC;
       zero(C2);
       zero(SC);
@@ -486,14 +514,14 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       }
       mus_r = mu_r;
       mus_i = c3p_phase_add(0.0, mu_i);
-      __syncthreads();  // R0 is rewritten by the next slice
+      md_bar();  // R0 is rewritten by the next slice
     } else {
-      __syncthreads();  // the last product's operands are no longer read
+      md_bar();  // the last product's operands are no longer read
       store_tiles(R1, Cm);
       store_tiles(R2, Sn);
       store_tiles(R3, Ur);
       store_tiles(R4, Ui);
-      __syncthreads();
+      md_bar();
       Regs Vr, Vi;
       zero(Vr);
       zero(Vi);
