@@ -415,6 +415,10 @@ int run_vjp_midd(DeviceWs* w, GradArgs& G, hipStream_t st) {
 // `slots` resident workgroups, each N / S slices long (+ a few slices' worth of prologue): take the S that
 // minimises rounds x segment length, so that the last round is not a mostly idle tail.
 static long pick_segments(long B, long N, long slots, long smax) {
+  if (const char* e = getenv("C3P_SEGMENTS")) {  // tuning override
+    const long S = atol(e);
+    if (S >= 1 && S <= (N > 1 ? N : 1)) return S;
+  }
   long best = 1;
   double best_cost = 1e300;
   if (smax > 96) smax = 96;

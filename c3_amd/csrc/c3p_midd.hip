@@ -305,17 +305,18 @@ __device__ __forceinline__ void mm_real(const double* A1, const double* A2, cons
   }
 }
 
-template <int NIG>
+template <int NIG, int W>
 struct MDR {
   static constexpr int NIGR = (NIG + 1) / 2;
-  static constexpr int NIMG = 5;  // real images of the slice pipeline
-  // LDS rows of the image area: three complex images or NIMG real ones
-  static constexpr int AREA_ROWS = 3 * 16 * NIG > NIMG * 16 * NIGR ? 3 * 16 * NIG : NIMG * 16 * NIGR;
+  static constexpr int NIMG = 5;                       // real images of the slice pipeline
+  static constexpr int AREA = NIMG * 16 * NIGR * W;    // doubles
+  static constexpr int KP = 3;                         // control lines whose tables stay in registers (K <= KP)
+  static constexpr int WGS = (AREA * 8 + 6144) * 3 <= 160 * 1024 ? 3 : 2;
 };
 
 template <int NIG, int NJ, int W, bool DUS, int WV>
 __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon& cm, long chain) {
-  constexpr int NIGR = MDR<NIG>::NIGR;
+  constexpr int NIGR = MDR<NIG, W>::NIGR;
   using T = WaveTiles<NIGR, NJ, W, WV>;
   constexpr int IMG = MD<NIG, NJ>::ROWS * W;  // complex table image
   constexpr int IMGR = 16 * NIGR * W, NE = T::NE;
@@ -341,39 +342,36 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
 #pragma unroll
     for (int e = 0; e < NE; ++e) v.set(e, 0.0);
   };
-  // Im rows of the half-image tables hold -Y; positions outside the matrix are clamped and masked
-  constexpr int NE1 = NE > 0 ? NE : 1;
-  int yoff[NE1];
-  double ymask[NE1], dmask[NE1];
+  // bit e: element e of the lane's tile set lies on the diagonal (inside the matrix)
+  unsigned dbits = 0;
 #pragma unroll
   for (int e = 0; e < NE; ++e) {
     const int row = erow(e), col = ecol(e);
-    const bool in = row < D && col < D;
-    yoff[e] = in ? (2 * row + 1) * W + col : 0;
-    ymask[e] = in ? 1.0 : 0.0;
-    dmask[e] = (in && row == col) ? 1.0 : 0.0;
+    dbits |= (row == col && col < D) ? (1u << e) : 0u;
   }
+  auto dmask = [&](int e) -> double { return (dbits >> e) & 1u ? 1.0 : 0.0; };
   Regs Ur, Ui;
   double mus_r = 0.0, mus_i = 0.0;
   Regs dummy;
-  // the lane's table elements do not depend on the slice: kept in registers for the whole segment (the first
-  // KP control lines; any further ones are re-read per slice)
-  constexpr int KP = 4;
+  // The lane's table elements do not depend on the slice: -scale Im(table) at the lane's positions stays in
+  // registers for the whole segment (the kernel requires K <= KP).  Im rows of the half-image tables hold -Y;
+  // positions outside the matrix are clamped and masked.
+  constexpr int KP = MDR<NIG, W>::KP;
   Regs Tab[KP + 1];
-#pragma unroll
-  for (int k = 0; k <= KP; ++k)
-    if (k <= K) {
-      const double* tk = tabs + (long)k * (IMG + 4);
-#pragma unroll
-      for (int e = 0; e < NE; ++e) Tab[k].set(e, -cm.scale * ymask[e] * tk[yoff[e]]);
-    }
   double tmu_r[KP + 1], tmu_i[KP + 1];
 #pragma unroll
   for (int k = 0; k <= KP; ++k) {
-    tmu_r[k] = (k <= K) ? tabs[(long)k * (IMG + 4) + IMG + 0] : 0.0;
-    tmu_i[k] = (k <= K) ? tabs[(long)k * (IMG + 4) + IMG + 1] : 0.0;
+    const double* tk = tabs + (long)(k <= K ? k : 0) * (IMG + 4);
+    const double on = k <= K ? -cm.scale : 0.0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int row = erow(e), col = ecol(e);
+      const bool in = row < D && col < D;
+      Tab[k].set(e, in ? on * tk[(2 * row + 1) * W + col] : 0.0);
+    }
+    tmu_r[k] = md_rfl(k <= K ? tk[IMG + 0] : 0.0);
+    tmu_i[k] = md_rfl(k <= K ? tk[IMG + 1] : 0.0);
   }
-
   // instantiated per polynomial variant with the branch outside the loop (as in the small-D kernel): below
   // theta_16 = 0.816 the degree-16 / 17 polynomials are exact to roundoff and W^3, W^4 are one paired product
   auto real_loop = [&](auto deg16_tag) {
@@ -383,22 +381,12 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
     double mu_r = tmu_r[0], mu_i = tmu_i[0];
     Regs Y = Tab[0];
 #pragma unroll
-    for (int k = 0; k < KP; ++k)
-      if (k < K) {
-        const double c0 = cm.sg[k * SGC + (t & (SGC - 1))];
-        mu_r = fma(c0, tmu_r[k + 1], mu_r);
-        mu_i = fma(c0, tmu_i[k + 1], mu_i);
+    for (int k = 0; k < KP; ++k) {
+      const double c0 = k < K ? cm.sg[k * SGC + (t & (SGC - 1))] : 0.0;  // Tab[k + 1] = 0 beyond K
+      mu_r = fma(c0, tmu_r[k + 1], mu_r);
+      mu_i = fma(c0, tmu_i[k + 1], mu_i);
 #pragma unroll
-        for (int e = 0; e < NE; ++e) Y.set(e, fma(c0, Tab[k + 1].get(e), Y.get(e)));
-      }
-    for (int k = KP; k < K; ++k) {
-      const double c0 = cm.sg[k * SGC + (t & (SGC - 1))];
-      const double ck = -cm.scale * c0;
-      const double* tk = tabs + (long)(k + 1) * (IMG + 4);
-      mu_r = fma(c0, tk[IMG + 0], mu_r);
-      mu_i = fma(c0, tk[IMG + 1], mu_i);
-#pragma unroll
-      for (int e = 0; e < NE; ++e) Y.set(e, fma(ck * ymask[e], tk[yoff[e]], Y.get(e)));
+      for (int e = 0; e < NE; ++e) Y.set(e, fma(c0, Tab[k + 1].get(e), Y.get(e)));
     }
     store_tiles(R0, Y);
     md_bar();
@@ -418,7 +406,7 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
         double v = c1 * W1.get(e);
         v = fma(c2, W2.get(e), v);
         v = fma(c3, W3.get(e), v);
-        out.set(e, fma(c0, dmask[e], v));
+        out.set(e, fma(c0, dmask(e), v));
       }
     };
     Regs Sn;
@@ -485,7 +473,7 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       mm_real<NIGR, NJ, W, WV, 2>(Ra, Rb, Ra, Ra, cm, C2, SC);
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
-        Cm.set(e, fma(2.0, C2.get(e), -dmask[e]));
+        Cm.set(e, fma(2.0, C2.get(e), -dmask(e)));
         Sn.set(e, 2.0 * SC.get(e));
       }
     }
@@ -578,12 +566,6 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
   const int cbig = 4 * cm.b + cm.c, csmall = cm.c;   // column inside the unit
   double mus_r = 0.0, mus_i = 0.0;
   const double* tabs = cm.tabs;
-  if constexpr (!GIVEN && !XG) {
-    if (cm.realH) {
-      midd_real_body<NIG, NJ, W, DUS, WV>(A, cm, chain);
-      return;
-    }
-  }
   Regs U;
 
   auto eoff = [&](int e) -> int { return T::off0(e) + (T::is_big(e) ? lbig : lsmall); };
@@ -818,12 +800,14 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
 
 template <int NIG, int W>
 struct MidOcc {
-  static constexpr int AREA_BYTES = MDR<NIG>::AREA_ROWS * W * 8;
-  static constexpr int WGS = (AREA_BYTES + 6144) * 3 <= 160 * 1024 ? 3 : 2;
+  static constexpr int IMG_BYTES = 16 * NIG * W * 8;
+  static constexpr int WGS = (3 * IMG_BYTES + 6144) * 3 <= 160 * 1024 ? 3 : 2;
 };
 
-template <int NIG, int NJ, int W, bool GIVEN, bool DUS, bool XG = false>
-__global__ void __launch_bounds__(256, (MidOcc<NIG, W>::WGS)) midd_chain_kernel(MidArgs A) {
+// REAL = true: the real-Hamiltonian kernel (own LDS layout, register budget and occupancy).  For unitary-mode
+// calls both kernels are launched; a workgroup whose sample is (not) real leaves the (real) complex one at once.
+template <int NIG, int NJ, int W, bool GIVEN, bool DUS, bool XG = false, bool REAL = false>
+__global__ void __launch_bounds__(256, (REAL ? MDR<NIG, W>::WGS : MidOcc<NIG, W>::WGS)) midd_chain_kernel(MidArgs A) {
   using C = MD<NIG, NJ>;
   constexpr int IMG = C::ROWS * W;
   const int tid = threadIdx.x;
@@ -838,7 +822,7 @@ __global__ void __launch_bounds__(256, (MidOcc<NIG, W>::WGS)) midd_chain_kernel(
   cm.nbkR = (cm.D + 3) / 4;
   cm.K = A.K;
   const int K = A.K;
-  constexpr int AREA = MDR<NIG>::AREA_ROWS * W;  // image area: 3 complex images or 5 real ones
+  constexpr int AREA = REAL ? MDR<NIG, W>::AREA : 3 * IMG;  // image area: 3 complex images or the real pipeline's
 
   cm.buf0 = c3p_md_lds;
   cm.buf1 = cm.buf0 + IMG;
@@ -848,6 +832,15 @@ __global__ void __launch_bounds__(256, (MidOcc<NIG, W>::WGS)) midd_chain_kernel(
 
   const long chain = blockIdx.x;
   cm.sample = (int)(chain / A.S);
+  cm.tabs = XG ? nullptr : A.tables + (long)(A.tab_per_sample ? cm.sample : 0) * (1 + K) * (IMG + 4);
+  cm.realH = 0;
+  if constexpr (!GIVEN && !XG) {
+    // every table purely imaginary (real Hamiltonian, unitary mode, K <= KP): real cos / sin kernel
+    bool realH = A.mode == C3P_MODE_UNITARY && !A.no_real && K <= MDR<NIG, W>::KP;
+    for (int k = 0; k <= K; ++k) realH = realH && (cm.tabs[(long)k * (IMG + 4) + IMG + 3] == 0.0);
+    cm.realH = __builtin_amdgcn_readfirstlane((int)realH);
+    if ((cm.realH != 0) != REAL) return;
+  }
   const int seg = (int)(chain - (long)cm.sample * A.S);
   cm.n0 = (int)(((long)seg * A.N) / A.S);
   const int n1 = (int)(((long)(seg + 1) * A.N) / A.S);
@@ -865,12 +858,10 @@ __global__ void __launch_bounds__(256, (MidOcc<NIG, W>::WGS)) midd_chain_kernel(
   for (int e = tid; e < AREA; e += 256) c3p_md_lds[e] = 0.0;
   __syncthreads();
 
-  cm.tabs = XG ? nullptr : A.tables + (long)(A.tab_per_sample ? cm.sample : 0) * (1 + K) * (IMG + 4);
   cm.pr = 1;
   cm.ps = 0;
   cm.t18 = 0;
   cm.scale = 1.0;
-  cm.realH = 0;
   if constexpr (!GIVEN) {
     // segment-wide plan from ||G0|| + sum_k max_t |c_k(t)| ||G_k||  (XG: max of the per-slice norms)
     double nrm = 0.0;
@@ -910,30 +901,34 @@ __global__ void __launch_bounds__(256, (MidOcc<NIG, W>::WGS)) midd_chain_kernel(
       cm.pr = __builtin_amdgcn_readfirstlane(q.r);
       cm.ps = __builtin_amdgcn_readfirstlane(q.s);
     }
-    if constexpr (!XG) {
-      // every table purely imaginary (real Hamiltonian, unitary mode): real cos / sin path, T18 scaling rule
-      bool realH = A.mode == C3P_MODE_UNITARY && !A.no_real;
-      for (int k = 0; k <= K; ++k) realH = realH && (cm.tabs[(long)k * (IMG + 4) + IMG + 3] == 0.0);
-      cm.realH = __builtin_amdgcn_readfirstlane((int)realH);
-      if (cm.realH) {
-        int s18 = 0;
-        double p = C3P_T18_THETA;
-        while (p < nrm && s18 < 40) {
-          p *= 2.0;
-          ++s18;
-        }
-        cm.ps = __builtin_amdgcn_readfirstlane(s18);
-        cm.t18 = __builtin_amdgcn_readfirstlane((int)(ldexp(nrm, -s18) <= 8.16e-1));  // real path: degree-16 variant
+    if constexpr (REAL) {
+      // T18 scaling rule; below theta_16 the degree-16 variant (flag kept in t18)
+      int s18 = 0;
+      double p = C3P_T18_THETA;
+      while (p < nrm && s18 < 40) {
+        p *= 2.0;
+        ++s18;
       }
+      cm.ps = __builtin_amdgcn_readfirstlane(s18);
+      cm.t18 = __builtin_amdgcn_readfirstlane((int)(ldexp(nrm, -s18) <= 8.16e-1));
     }
     cm.scale = ldexp(1.0, -cm.ps);
     __syncthreads();
   }
-  switch (wave) {
-    case 0: midd_body<NIG, NJ, W, GIVEN, DUS, XG, 0>(A, cm, chain); break;
-    case 1: midd_body<NIG, NJ, W, GIVEN, DUS, XG, 1>(A, cm, chain); break;
-    case 2: midd_body<NIG, NJ, W, GIVEN, DUS, XG, 2>(A, cm, chain); break;
-    default: midd_body<NIG, NJ, W, GIVEN, DUS, XG, 3>(A, cm, chain); break;
+  if constexpr (REAL) {
+    switch (wave) {
+      case 0: midd_real_body<NIG, NJ, W, DUS, 0>(A, cm, chain); break;
+      case 1: midd_real_body<NIG, NJ, W, DUS, 1>(A, cm, chain); break;
+      case 2: midd_real_body<NIG, NJ, W, DUS, 2>(A, cm, chain); break;
+      default: midd_real_body<NIG, NJ, W, DUS, 3>(A, cm, chain); break;
+    }
+  } else {
+    switch (wave) {
+      case 0: midd_body<NIG, NJ, W, GIVEN, DUS, XG, 0>(A, cm, chain); break;
+      case 1: midd_body<NIG, NJ, W, GIVEN, DUS, XG, 1>(A, cm, chain); break;
+      case 2: midd_body<NIG, NJ, W, GIVEN, DUS, XG, 2>(A, cm, chain); break;
+      default: midd_body<NIG, NJ, W, GIVEN, DUS, XG, 3>(A, cm, chain); break;
+    }
   }
 }
 
@@ -1049,22 +1044,30 @@ __global__ void __launch_bounds__(256) midd_prep_kernel(MidPrepArgs P) {
 template <int NIG, int NJ, int W>
 hipError_t launch_t(const MidArgs& A, hipStream_t st) {
   constexpr int IMG = MD<NIG, NJ>::ROWS * W;
-  const size_t lds = (size_t)(MDR<NIG>::AREA_ROWS * W + (A.mode == C3P_MODE_GIVEN ? 0 : A.K * SGC)) * sizeof(double);
+  const size_t lds = (size_t)(3 * IMG + (A.mode == C3P_MODE_GIVEN ? 0 : A.K * SGC)) * sizeof(double);
   const unsigned grid = (unsigned)((long)A.B * A.S);
-  auto go = [&](auto kern) -> hipError_t {
-    if (lds > 64 * 1024) {
+  auto go = [&](auto kern, size_t bytes) -> hipError_t {
+    if (bytes > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, A);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, st, A);
     return hipGetLastError();
   };
-  if (A.mode == C3P_MODE_GIVEN) return go(midd_chain_kernel<NIG, NJ, W, true, false>);
+  if (A.mode == C3P_MODE_GIVEN) return go(midd_chain_kernel<NIG, NJ, W, true, false>, lds);
   if (A.mode == C3P_MODE_EXPM)
-    return A.dUs_out ? go(midd_chain_kernel<NIG, NJ, W, false, true, true>) : go(midd_chain_kernel<NIG, NJ, W, false, false, true>);
-  if (A.dUs_out) return go(midd_chain_kernel<NIG, NJ, W, false, true>);
-  return go(midd_chain_kernel<NIG, NJ, W, false, false>);
+    return A.dUs_out ? go(midd_chain_kernel<NIG, NJ, W, false, true, true>, lds)
+                     : go(midd_chain_kernel<NIG, NJ, W, false, false, true>, lds);
+  if (A.mode == C3P_MODE_UNITARY && !A.no_real && A.K <= MDR<NIG, W>::KP) {
+    // samples with real Hamiltonians are taken by the real kernel, the others by the complex one
+    const size_t ldsr = (size_t)(MDR<NIG, W>::AREA + A.K * SGC) * sizeof(double);
+    hipError_t e = A.dUs_out ? go(midd_chain_kernel<NIG, NJ, W, false, true, false, true>, ldsr)
+                             : go(midd_chain_kernel<NIG, NJ, W, false, false, false, true>, ldsr);
+    if (e != hipSuccess) return e;
+  }
+  if (A.dUs_out) return go(midd_chain_kernel<NIG, NJ, W, false, true>, lds);
+  return go(midd_chain_kernel<NIG, NJ, W, false, false>, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1401,10 +1404,8 @@ size_t c3p_midd_table_doubles(int Dm, int K) {
 size_t c3p_midd_lds_bytes(int Dm, int K, int Lmax) {
   int nig, nj, w;
   if (!c3p_midd_geometry(Dm, &nig, &nj, &w)) return 0;
-  const int nigr = (nig + 1) / 2;
-  const int rows = 3 * 16 * nig > 5 * 16 * nigr ? 3 * 16 * nig : 5 * 16 * nigr;  // MDR<NIG>::AREA_ROWS
   (void)Lmax;  // the chain kernel stages the control amplitudes in chunks of SGC slices
-  return ((size_t)rows * w + (size_t)K * SGC) * sizeof(double);
+  return ((size_t)3 * 16 * nig * w + (size_t)K * SGC) * sizeof(double);
 }
 
 hipError_t c3p_launch_midd_chain(const MidArgs& A, hipStream_t st) {
