@@ -211,6 +211,18 @@ __device__ __forceinline__ void mm_tiles(const double* imgA, const double* imgB,
   }
 }
 
+template <int I>
+using IC = std::integral_constant<int, I>;
+
+// compile-time loop: f(integral_constant<int, I>) for I in [B, E)
+template <int B, int E, typename F>
+__device__ __forceinline__ void md_unroll(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    md_unroll<B + 1, E>(f);
+  }
+}
+
 // Workgroup barrier that waits for the LDS traffic only (__syncthreads also drains the vector-memory counter,
 // i.e. stalls on outstanding global stores of partial propagators).
 __device__ __forceinline__ void md_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -238,9 +250,8 @@ __device__ __forceinline__ void md_stage_signals(const MidArgs& A, const MidComm
 // (5 + s + 1) complex = 24 + 4 s real-equivalent ones.  Products that share an operand are issued
 // together (MODE 1: shared left operand, MODE 2: shared right operand) and share its LDS reads.
 // ---------------------------------------------------------------------------------------------
-template <int NIGR, int NJ, int W, int WV, int MODE>
-__device__ __forceinline__ void mm_real(const double* A1, const double* A2, const double* B1, const double* B2,
-                                        const MidCommon& cm,
+template <int NIGR, int NJ, int W, int WV, int MODE, int IA1, int IA2, int IB1, int IB2>
+__device__ __forceinline__ void mm_real(const MidCommon& cm,
                                         TileRegs<WaveTiles<NIGR, NJ, W, WV>::NBW, WaveTiles<NIGR, NJ, W, WV>::NSW>& acc1,
                                         TileRegs<WaveTiles<NIGR, NJ, W, WV>::NBW, WaveTiles<NIGR, NJ, W, WV>::NSW>& acc2) {
   using T = WaveTiles<NIGR, NJ, W, WV>;
@@ -248,61 +259,63 @@ __device__ __forceinline__ void mm_real(const double* A1, const double* A2, cons
   constexpr int NB16 = S::NB16 > 0 ? S::NB16 : 1;
   constexpr int JR = S::JR > 0 ? S::JR : 1;
   constexpr bool TWOA = MODE == 2, TWOB = MODE == 1;
-  double a0[NIGR], a1[NIGR], g0[NB16], g1[NB16], s0[JR], s1[JR];
-  double x0[NIGR], x1[NIGR], h0[NB16], h1[NB16], u0[JR], u1[JR];  // second left / right operand
-  const double* pa = A1 + cm.aoffR;
-  const double* px = A2 + cm.aoffR;
-  const double* pg = B1 + cm.lbig;
-  const double* ph = B2 + cm.lbig;
-  const double* ps4 = B1 + cm.boff;
-  const double* pu4 = B2 + cm.boff;
-  auto load = [&](double (&a)[NIGR], double (&x)[NIGR], double (&g)[NB16], double (&h)[NB16], double (&sb)[JR],
-                  double (&ub)[JR], int K) {
-#pragma unroll
-    for (int Ig = 0; Ig < NIGR; ++Ig) {
-      a[Ig] = T::uses_ig(Ig) ? pa[Ig * 16 * W + 4 * K] : 0.0;
-      x[Ig] = (TWOA && T::uses_ig(Ig)) ? px[Ig * 16 * W + 4 * K] : 0.0;
-    }
-#pragma unroll
-    for (int Jg = 0; Jg < S::NB16; ++Jg) {
-      g[Jg] = T::uses_jg(Jg) ? pg[K * 4 * W + 16 * Jg] : 0.0;
-      h[Jg] = (TWOB && T::uses_jg(Jg)) ? ph[K * 4 * W + 16 * Jg] : 0.0;
-    }
-#pragma unroll
-    for (int js = 0; js < S::JR; ++js) {
-      sb[js] = T::uses_j(4 * S::NB16 + js) ? ps4[K * 4 * W + 4 * (4 * S::NB16 + js)] : 0.0;
-      ub[js] = (TWOB && T::uses_j(4 * S::NB16 + js)) ? pu4[K * 4 * W + 4 * (4 * S::NB16 + js)] : 0.0;
-    }
-  };
-  auto fmas = [&](const double (&a)[NIGR], const double (&x)[NIGR], const double (&g)[NB16], const double (&h)[NB16],
-                  const double (&sb)[JR], const double (&ub)[JR]) {
-#pragma unroll
-    for (int i = 0; i < T::NBW; ++i) {
-      acc1.big[i] = md_mfma16(a[T::bIg(i)], g[T::bJg(i)], acc1.big[i]);
-      if constexpr (TWOB) acc2.big[i] = md_mfma16(a[T::bIg(i)], h[T::bJg(i)], acc2.big[i]);
-      if constexpr (TWOA) acc2.big[i] = md_mfma16(x[T::bIg(i)], g[T::bJg(i)], acc2.big[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < T::NSW; ++i) {
-      acc1.sm[i] = md_mfma4(a[T::sIg(i)], sb[T::sJ(i) - 4 * S::NB16], acc1.sm[i]);
-      if constexpr (TWOB) acc2.sm[i] = md_mfma4(a[T::sIg(i)], ub[T::sJ(i) - 4 * S::NB16], acc2.sm[i]);
-      if constexpr (TWOA) acc2.sm[i] = md_mfma4(x[T::sIg(i)], sb[T::sJ(i) - 4 * S::NB16], acc2.sm[i]);
-    }
-  };
-  const int nbk = cm.nbkR;
-  load(a0, x0, g0, h0, s0, u0, 0);
-  for (int K = 0; K < nbk; K += 2) {
-    const int K1 = (K + 1 < nbk) ? K + 1 : K;
-    load(a1, x1, g1, h1, s1, u1, K1);
-    __builtin_amdgcn_sched_barrier(0);
-    fmas(a0, x0, g0, h0, s0, u0);
-    __builtin_amdgcn_sched_barrier(0);
-    const int K2 = (K + 2 < nbk) ? K + 2 : K;
-    load(a0, x0, g0, h0, s0, u0, K2);
-    __builtin_amdgcn_sched_barrier(0);
-    if (K + 1 < nbk) fmas(a1, x1, g1, h1, s1, u1);
-    __builtin_amdgcn_sched_barrier(0);
+  // D is in (4 NJ - 4, 4 NJ]: a real product has exactly NJ K-steps.  The loop is fully unrolled with the operands
+  // fetched PF steps ahead in a ring of PF + 1 register stages: the LDS round trip (~150 cycles) is more than two
+  // K-steps of a single 16x16x4 instruction, and a one-step prefetch left the matrix pipe waiting on every step.
+  constexpr int PF = NJ < 3 ? NJ : 3;
+  constexpr int NS = PF + 1;
+  double a[NS][NIGR], x[NS][NIGR], g[NS][NB16], h[NS][NB16], sb[NS][JR], ub[NS][JR];
+  // one base register per lane-offset kind; the image (a compile-time index) goes into the instruction offset
+  constexpr int IMGR = 16 * NIGR * W;
+  const double* qa = c3p_md_lds + cm.aoffR;
+  const double* qg = c3p_md_lds + cm.lbig;
+  const double* qs = c3p_md_lds + cm.boff;
+  const double* pa = qa + IA1 * IMGR;
+  const double* px = qa + IA2 * IMGR;
+  const double* pg = qg + IB1 * IMGR;
+  const double* ph = qg + IB2 * IMGR;
+  const double* ps4 = qs + IB1 * IMGR;
+  const double* pu4 = qs + IB2 * IMGR;
+#define C3P_MMR_LOAD(K)                                                                                          \
+  {                                                                                                              \
+    constexpr int st_ = (K) % NS;                                                                                \
+    _Pragma("unroll") for (int Ig = 0; Ig < NIGR; ++Ig) {                                                        \
+      a[st_][Ig] = T::uses_ig(Ig) ? pa[Ig * 16 * W + 4 * (K)] : 0.0;                                             \
+      x[st_][Ig] = (TWOA && T::uses_ig(Ig)) ? px[Ig * 16 * W + 4 * (K)] : 0.0;                                   \
+    }                                                                                                            \
+    _Pragma("unroll") for (int Jg = 0; Jg < S::NB16; ++Jg) {                                                     \
+      g[st_][Jg] = T::uses_jg(Jg) ? pg[(K) * 4 * W + 16 * Jg] : 0.0;                                             \
+      h[st_][Jg] = (TWOB && T::uses_jg(Jg)) ? ph[(K) * 4 * W + 16 * Jg] : 0.0;                                   \
+    }                                                                                                            \
+    _Pragma("unroll") for (int js = 0; js < S::JR; ++js) {                                                       \
+      sb[st_][js] = T::uses_j(4 * S::NB16 + js) ? ps4[(K) * 4 * W + 4 * (4 * S::NB16 + js)] : 0.0;               \
+      ub[st_][js] = (TWOB && T::uses_j(4 * S::NB16 + js)) ? pu4[(K) * 4 * W + 4 * (4 * S::NB16 + js)] : 0.0;     \
+    }                                                                                                            \
   }
+#define C3P_MMR_FMAS(K)                                                                                          \
+  {                                                                                                              \
+    constexpr int st_ = (K) % NS;                                                                                \
+    _Pragma("unroll") for (int i = 0; i < T::NBW; ++i) {                                                         \
+      acc1.big[i] = md_mfma16(a[st_][T::bIg(i)], g[st_][T::bJg(i)], acc1.big[i]);                                \
+      if constexpr (TWOB) acc2.big[i] = md_mfma16(a[st_][T::bIg(i)], h[st_][T::bJg(i)], acc2.big[i]);            \
+      if constexpr (TWOA) acc2.big[i] = md_mfma16(x[st_][T::bIg(i)], g[st_][T::bJg(i)], acc2.big[i]);            \
+    }                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < T::NSW; ++i) {                                                         \
+      acc1.sm[i] = md_mfma4(a[st_][T::sIg(i)], sb[st_][T::sJ(i) - 4 * S::NB16], acc1.sm[i]);                     \
+      if constexpr (TWOB) acc2.sm[i] = md_mfma4(a[st_][T::sIg(i)], ub[st_][T::sJ(i) - 4 * S::NB16], acc2.sm[i]); \
+      if constexpr (TWOA) acc2.sm[i] = md_mfma4(x[st_][T::sIg(i)], sb[st_][T::sJ(i) - 4 * S::NB16], acc2.sm[i]); \
+    }                                                                                                            \
+  }
+  md_unroll<0, PF>([&](auto Kc) { constexpr int K = decltype(Kc)::value; C3P_MMR_LOAD(K) });
+  md_unroll<0, NJ>([&](auto Kc) {
+    constexpr int K = decltype(Kc)::value;
+    if constexpr (K + PF < NJ) C3P_MMR_LOAD(K + PF)
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA group
+    C3P_MMR_FMAS(K)
+    __builtin_amdgcn_sched_barrier(0);
+  });
+#undef C3P_MMR_LOAD
+#undef C3P_MMR_FMAS
 }
 
 template <int NIG, int W>
@@ -326,17 +339,14 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
   const int rbig = cm.r, rsmall = 4 * cm.b + cm.r;
   const int cbig = 4 * cm.b + cm.c, csmall = cm.c;
   const double* tabs = cm.tabs;
-  double* R0 = c3p_md_lds;
-  double* R1 = R0 + IMGR;
-  double* R2 = R1 + IMGR;
-  double* R3 = R2 + IMGR;
-  double* R4 = R3 + IMGR;
-  auto eoff = [&](int e) -> int { return T::off0(e) + (T::is_big(e) ? lbig : lsmall); };
+  double* const qbig = c3p_md_lds + lbig;      // image i adds i * IMGR: a compile-time instruction offset
+  double* const qsmall = c3p_md_lds + lsmall;
   auto erow = [&](int e) -> int { return T::row0(e) + (T::is_big(e) ? rbig : rsmall); };
   auto ecol = [&](int e) -> int { return T::col0(e) + (T::is_big(e) ? cbig : csmall); };
-  auto store_tiles = [&](double* img, const Regs& v) {
+  auto store_tiles = [&](auto img, const Regs& v) {
+    constexpr int I = decltype(img)::value;
 #pragma unroll
-    for (int e = 0; e < NE; ++e) img[eoff(e)] = v.get(e);
+    for (int e = 0; e < NE; ++e) (T::is_big(e) ? qbig : qsmall)[I * IMGR + T::off0(e)] = v.get(e);
   };
   auto zero = [&](Regs& v) {
 #pragma unroll
@@ -388,16 +398,16 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
 #pragma unroll
       for (int e = 0; e < NE; ++e) Y.set(e, fma(c0, Tab[k + 1].get(e), Y.get(e)));
     }
-    store_tiles(R0, Y);
+    store_tiles(IC<0>{}, Y);
     md_bar();
     Regs W1, W2, W3, Cm, Sp, acc, acs;
     zero(W1);
-    mm_real<NIGR, NJ, W, WV, 0>(R0, R0, R0, R0, cm, W1, dummy);  // W = Y^2
-    store_tiles(R1, W1);
+    mm_real<NIGR, NJ, W, WV, 0, 0, 0, 0, 0>(cm, W1, dummy);  // W = Y^2
+    store_tiles(IC<1>{}, W1);
     md_bar();
     zero(W2);
-    mm_real<NIGR, NJ, W, WV, 0>(R1, R1, R1, R1, cm, W2, dummy);  // W^2
-    store_tiles(R2, W2);
+    mm_real<NIGR, NJ, W, WV, 0, 1, 1, 1, 1>(cm, W2, dummy);  // W^2
+    store_tiles(IC<2>{}, W2);
     md_bar();
     zero(W3);
     auto rc = [&](Regs& out, double c0, double c1, double c2, double c3) {
@@ -416,7 +426,7 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       // q = 4: {W^3, W^4} = {W, W^2} W^2 as one paired product, then ONE paired Horner step in W^4
       Regs W4;
       zero(W4);
-      mm_real<NIGR, NJ, W, WV, 2>(R1, R2, R2, R2, cm, W3, W4);
+      mm_real<NIGR, NJ, W, WV, 2, 1, 2, 2, 2>(cm, W3, W4);
       rc(acc, c3p_inv_fact[8], -c3p_inv_fact[10], c3p_inv_fact[12], -c3p_inv_fact[14]);
       rc(acs, c3p_inv_fact[9], -c3p_inv_fact[11], c3p_inv_fact[13], -c3p_inv_fact[15]);
 #pragma unroll
@@ -424,58 +434,62 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
         acc.set(e, fma(c3p_inv_fact[16], W4.get(e), acc.get(e)));
         acs.set(e, fma(c3p_inv_fact[17], W4.get(e), acs.get(e)));
       }
-      store_tiles(R3, W4);
-      store_tiles(R0, acc);
-      store_tiles(R4, acs);
+      store_tiles(IC<3>{}, W4);
+      store_tiles(IC<0>{}, acc);
+      store_tiles(IC<4>{}, acs);
       md_bar();
       rc(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], -c3p_inv_fact[6]);
       rc(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7]);
-      mm_real<NIGR, NJ, W, WV, 1>(R3, R3, R0, R4, cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
-      store_tiles(R1, Sp);
-      store_tiles(R2, Y);
+      mm_real<NIGR, NJ, W, WV, 1, 3, 3, 0, 4>(cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
+      store_tiles(IC<1>{}, Sp);
+      store_tiles(IC<2>{}, Y);
       md_bar();
-      mm_real<NIGR, NJ, W, WV, 0>(R2, R2, R1, R1, cm, Sn, dummy);  // sin Y
+      mm_real<NIGR, NJ, W, WV, 0, 2, 2, 1, 1>(cm, Sn, dummy);  // sin Y
     } else {
       // degree 18 / 17: two paired Horner steps in W^3
-      mm_real<NIGR, NJ, W, WV, 0>(R1, R1, R2, R2, cm, W3, dummy);  // W^3
+      mm_real<NIGR, NJ, W, WV, 0, 1, 1, 2, 2>(cm, W3, dummy);  // W^3
       rc(Cm, c3p_inv_fact[12], -c3p_inv_fact[14], c3p_inv_fact[16], -c3p_inv_fact[18]);
       rc(Sp, c3p_inv_fact[13], -c3p_inv_fact[15], c3p_inv_fact[17], 0.0);
-      store_tiles(R3, W3);
-      store_tiles(R0, Cm);
-      store_tiles(R4, Sp);
+      store_tiles(IC<3>{}, W3);
+      store_tiles(IC<0>{}, Cm);
+      store_tiles(IC<4>{}, Sp);
       md_bar();
       rc(acc, -c3p_inv_fact[6], c3p_inv_fact[8], -c3p_inv_fact[10], 0.0);
       rc(acs, -c3p_inv_fact[7], c3p_inv_fact[9], -c3p_inv_fact[11], 0.0);
-      mm_real<NIGR, NJ, W, WV, 1>(R3, R3, R0, R4, cm, acc, acs);
-      store_tiles(R1, acc);
-      store_tiles(R2, acs);
+      mm_real<NIGR, NJ, W, WV, 1, 3, 3, 0, 4>(cm, acc, acs);
+      store_tiles(IC<1>{}, acc);
+      store_tiles(IC<2>{}, acs);
       md_bar();
       rc(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], 0.0);
       rc(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], 0.0);
-      mm_real<NIGR, NJ, W, WV, 1>(R3, R3, R1, R2, cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
-      store_tiles(R0, Sp);
-      store_tiles(R4, Y);
+      mm_real<NIGR, NJ, W, WV, 1, 3, 3, 1, 2>(cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
+      store_tiles(IC<0>{}, Sp);
+      store_tiles(IC<4>{}, Y);
       md_bar();
-      mm_real<NIGR, NJ, W, WV, 0>(R4, R4, R0, R0, cm, Sn, dummy);  // sin Y
+      mm_real<NIGR, NJ, W, WV, 0, 4, 4, 0, 0>(cm, Sn, dummy);  // sin Y
     }
     // ---- squarings in real form: cos 2Y = 2 C^2 - I, sin 2Y = 2 S C (image pairs alternate: no extra barrier) ----
-    for (int it = 0; it < cm.ps; ++it) {
-      // the pair not read by the previous product
-      const bool hi = ((it & 1) != 0) != DEG16;
-      double* Ra = hi ? R3 : R1;
-      double* Rb = hi ? R4 : R2;
-      store_tiles(Ra, Cm);
-      store_tiles(Rb, Sn);
+    auto square = [&](auto ia, auto ib) {
+      constexpr int IA = decltype(ia)::value, IB = decltype(ib)::value;
+      store_tiles(ia, Cm);
+      store_tiles(ib, Sn);
       md_bar();
       Regs C2, SC;
       zero(C2);
       zero(SC);
-      mm_real<NIGR, NJ, W, WV, 2>(Ra, Rb, Ra, Ra, cm, C2, SC);
+      mm_real<NIGR, NJ, W, WV, 2, IA, IB, IA, IA>(cm, C2, SC);
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
         Cm.set(e, fma(2.0, C2.get(e), -dmask(e)));
         Sn.set(e, 2.0 * SC.get(e));
       }
+    };
+    for (int it = 0; it < cm.ps; ++it) {
+      // the image pair not read by the previous product
+      if (((it & 1) != 0) != DEG16)
+        square(IC<3>{}, IC<4>{});
+      else
+        square(IC<1>{}, IC<2>{});
     }
     if constexpr (DUS) {
       // dU = e^{mu} (C - iS)
@@ -502,21 +516,21 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       }
       mus_r = mu_r;
       mus_i = c3p_phase_add(0.0, mu_i);
-      md_bar();  // R0 is rewritten by the next slice
+      md_bar();  // image 0 is rewritten by the next slice
     } else {
       md_bar();  // the last product's operands are no longer read
-      store_tiles(R1, Cm);
-      store_tiles(R2, Sn);
-      store_tiles(R3, Ur);
-      store_tiles(R4, Ui);
+      store_tiles(IC<1>{}, Cm);
+      store_tiles(IC<2>{}, Sn);
+      store_tiles(IC<3>{}, Ur);
+      store_tiles(IC<4>{}, Ui);
       md_bar();
       Regs Vr, Vi;
       zero(Vr);
       zero(Vi);
-      mm_real<NIGR, NJ, W, WV, 1>(R2, R2, R4, R3, cm, Vr, Vi);  // S Ui, S Ur
+      mm_real<NIGR, NJ, W, WV, 1, 2, 2, 4, 3>(cm, Vr, Vi);  // S Ui, S Ur
 #pragma unroll
       for (int e = 0; e < NE; ++e) Vi.set(e, -Vi.get(e));
-      mm_real<NIGR, NJ, W, WV, 1>(R1, R1, R3, R4, cm, Vr, Vi);  // + C Ur, + C Ui
+      mm_real<NIGR, NJ, W, WV, 1, 1, 1, 3, 4>(cm, Vr, Vi);  // + C Ur, + C Ui
       Ur = Vr;
       Ui = Vi;
       mus_r += mu_r;
