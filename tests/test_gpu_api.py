@@ -198,13 +198,16 @@ def test_supplied_generators_every_kernel(prop, D):
         assert np.abs(got - want).max() < 1e-12 * np.exp(6.0)
 
 
-def test_mixed_real_and_complex_samples_in_one_launch(prop):
+@pytest.mark.parametrize("D,K", [(9, 2), (14, 2), (27, 3), (27, 4), (36, 1)])
+def test_mixed_real_and_complex_samples_in_one_launch(prop, D, K):
     """per-sample operators: real symmetric, complex Hermitian and real non-symmetric drifts in ONE batch -- every
-    wave picks its path from its own sample's flag"""
+    wave (small-D) / workgroup (mid-D: the real and the complex kernel instance share the launch; K = 4 control
+    lines exceed the real kernel's register-resident tables and stay on the complex one) picks its path from its
+    own sample's flag"""
     import scipy.linalg as sla
 
-    rng = np.random.default_rng(77)
-    D, B, K, N = 9, 6, 2, 41
+    rng = np.random.default_rng(77 + D + K)
+    B, N = 6, 41
     a = rng.normal(size=(B, D, D))
     h0 = (a + np.swapaxes(a, -1, -2)).astype(np.complex128) * 2e10
     im = rng.normal(size=(D, D))
@@ -214,7 +217,7 @@ def test_mixed_real_and_complex_samples_in_one_launch(prop):
     hk = rng.normal(size=(K, D, D))
     hks = (hk + np.swapaxes(hk, -1, -2)).astype(np.complex128)
     sig = rng.normal(size=(B, K, N)) * 1e9
-    dt = 1e-11
+    dt = 1e-11 / max(1.0, D / 8)
     r = prop.propagate_batch(h0, hks, sig, dt, want_dUs=True)
     for b in range(B):
         Xs = -1j * dt * (h0[b][None] + np.einsum("kn,kij->nij", sig[b], hks))
