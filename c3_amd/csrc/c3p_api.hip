@@ -1,5 +1,6 @@
 // C ABI of libc3prop.so (see include/c3prop.h for the contract and the reference
 // functions each entry point stands in for).
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -241,20 +242,34 @@ int combine_smalld(DeviceWs* w, const cplx* cur, int B, int count, int Dm, int r
 }
 
 int pick_segments(int B, int N, int K, int Dm, bool need_mult4) {
-  // two waves per SIMD (the D = 9 kernel fits 256 registers): 256 CUs x 4 SIMDs x 2 x 4 chains
-  const long target = 8192;
-  long S = (target + B - 1) / B;
-  if (S > N) S = N;
-  if (S < 1) S = 1;
+  // two waves per SIMD (the D = 9 kernel fits 256 registers): 256 CUs x 4 SIMDs x 2 x 4 chains are resident at once.
+  // B S chains run in ceil(B S / slots) rounds of N / S slices (+ the table build and plan of the prologue):
+  // take the S that minimises rounds x segment length, so that the last round is not a mostly idle tail
+  // (B = 300 with the old "fill the machine twice" rule ran a second round at 2 % occupancy).
+  const long slots = 8192;
   // the segment's control amplitudes live in LDS: 4 chains x K x Lmax doubles
   const long lds_budget = 20 * 1024 - (long)(c3p_smalld_table_doubles(Dm, K) + 4 * c3p_smalld_img_doubles(Dm)) * 8;
   const long lmax_cap = K > 0 ? lds_budget / (32L * K) : (1L << 30);
-  while ((N + S - 1) / S > lmax_cap && S < N) ++S;
-  // a multiple of four lets every wave fold its four segments in registers (fused combine)
-  if (S > 1 && ((S + 3) / 4) * 4 <= N) S = ((S + 3) / 4) * 4;
-  if (need_mult4) S = ((S + 3) / 4) * 4;
-  if (S > N) return -1;
-  return (int)S;
+  long best = -1;
+  double best_cost = 1e300;
+  const long smax = N < 4096 ? N : 4096;
+  for (long S = 1; S <= smax; ++S) {
+    // a multiple of four lets every wave fold its four segments in registers (fused combine)
+    if (S > 1 && (S % 4) != 0 && S + 3 <= N) continue;
+    if (need_mult4 && (S % 4) != 0) continue;
+    if ((N + S - 1) / S > lmax_cap) continue;
+    const long rounds = ((long)B * S + slots - 1) / slots;
+    const double cost = (double)rounds * (double)((N + S - 1) / S + 8);
+    if (cost < best_cost * (1.0 - 1e-9)) {
+      best_cost = cost;
+      best = S;
+    }
+  }
+  if (best < 0 && need_mult4) {
+    const long S = ((std::min<long>(N, 4) + 3) / 4) * 4;
+    if (S <= N && (N + S - 1) / S <= lmax_cap) best = S;
+  }
+  return (int)best;
 }
 
 int run_pwc_smalld(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs,
@@ -414,7 +429,7 @@ int run_vjp_midd(DeviceWs* w, GradArgs& G, hipStream_t st) {
 // Time segments per sample for the workgroup-per-chain kernels.  B S chains run in ceil(B S / slots) rounds of
 // `slots` resident workgroups, each N / S slices long (+ a few slices' worth of prologue): take the S that
 // minimises rounds x segment length, so that the last round is not a mostly idle tail.
-static long pick_segments(long B, long N, long slots, long smax) {
+static long pick_segments_rounds(long B, long N, long slots, long smax) {
   if (const char* e = getenv("C3P_SEGMENTS")) {  // tuning override
     const long S = atol(e);
     if (S >= 1 && S <= (N > 1 ? N : 1)) return S;
@@ -443,7 +458,7 @@ int run_xg_midd(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, dou
   if (wg_per_cu > 3) wg_per_cu = 3;
   if (wg_per_cu < 1) wg_per_cu = 1;
   const long smax = N / 8 > 1 ? N / 8 : 1;
-  const long S = pick_segments(B, N, 256L * wg_per_cu, smax);
+  const long S = pick_segments_rounds(B, N, 256L * wg_per_cu, smax);
   void* mv;
   if (ws_get(w, SL_TABLES, (size_t)B * N * 4 * sizeof(double), &mv)) return -1;
   HIP_TRY(c3p_launch_hmeta(hs, hs_bstride, (long)B * N, N, D, coef_r, coef_i, (double*)mv, st));
@@ -632,7 +647,7 @@ int run_pwc_midd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   if (wg_per_cu > 3) wg_per_cu = 3;
   if (wg_per_cu < 1) wg_per_cu = 1;
   const long smax = N / 8 > 1 ? N / 8 : 1;
-  const long S = pick_segments(B, N, 256L * wg_per_cu, smax);
+  const long S = pick_segments_rounds(B, N, 256L * wg_per_cu, smax);
   if (lds0 > 158 * 1024) return 1;
   const int nsamp = per_sample ? B : 1;
   void* v;
