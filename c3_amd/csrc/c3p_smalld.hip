@@ -485,7 +485,12 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
   double* sg = img + 4 * IMG;  // 4 chains x K x Lmax signals, odd chain stride (bank spread)
   const int SG = (K * A.Lmax) | 1;
 
-  const long chain = (long)blockIdx.x * 4 + lp.b;
+  // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Logical block
+  // (bid % 8) * (nb / 8) + bid / 8 keeps consecutive logical blocks -- the waves of one sample, which exchange their
+  // segment partials in the fused combine -- on ONE XCD.
+  long lblock = blockIdx.x;
+  if ((gridDim.x & 7) == 0) lblock = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const long chain = lblock * 4 + lp.b;
   const long nchains = (long)A.B * A.S;
   const bool valid = chain < nchains;
   const long cc = valid ? chain : nchains - 1;
@@ -1026,10 +1031,12 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
       const int cnt = hi - lo;
       const int cmax = (nW + 3) >> 2;
       const double* base = reinterpret_cast<const double*>(A.seg_out) + ((long)sample * nW + lo) * D * D * 2;
-      for (int t = 0; t < cmax; ++t) {
+      // the next partial of the slot is always in flight while the current product runs, and the first two are
+      // fetched together: ONE cross-CU memory round trip for S <= 32
+      double Pn[NBI][NJ];
+      auto fetch = [&](double (&P)[NBI][NJ], int t) {
         const bool act = t < cnt;
         const double* src = base + (long)(act ? t : 0) * D * D * 2;
-        double P[NBI][NJ];
 #pragma unroll
         for (int I = 0; I < NBI; ++I)
 #pragma unroll
@@ -1039,12 +1046,17 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
             const double idv = (in && row == col && (lp.r & 1) == 0) ? 1.0 : 0.0;  // identity when idle
             P[I][J] = (act && in) ? src[(row * D + col) * 2 + (lp.r & 1)] : idv;
           }
-        if (t == 0) {
+      };
+      fetch(U, 0);
+      if (cmax > 1) fetch(Pn, 1);
+      for (int t = 1; t < cmax; ++t) {
+        double P[NBI][NJ];
 #pragma unroll
-          for (int I = 0; I < NBI; ++I)
+        for (int I = 0; I < NBI; ++I)
 #pragma unroll
-            for (int J = 0; J < NJ; ++J) U[I][J] = P[I][J];
-        } else {
+          for (int J = 0; J < NJ; ++J) P[I][J] = Pn[I][J];
+        if (t + 1 < cmax) fetch(Pn, t + 1);
+        {
           double acc[NBI][NJ];
 #pragma unroll
           for (int I = 0; I < NBI; ++I)
