@@ -223,6 +223,51 @@ __device__ __forceinline__ void md_unroll(F&& f) {
   }
 }
 
+// mm_tiles with the K loop fully unrolled (2 NJ K-steps; the last one is skipped when 2 D <= 8 NJ - 4) and the operands
+// fetched PF steps ahead in a ring of register stages -- for kernels that run ONE wave per SIMD (the gradient
+// sweep), where nothing else hides the LDS round trip behind a one-step prefetch.
+template <int NIG, int NJ, int W, int WV, int PF>
+__device__ __forceinline__ void mm_tiles_pf(const double* imgA, const double* imgB, const MidCommon& cm,
+                                            TileRegs<WaveTiles<NIG, NJ, W, WV>::NBW, WaveTiles<NIG, NJ, W, WV>::NSW>& acc) {
+  using T = WaveTiles<NIG, NJ, W, WV>;
+  using S = Sched<NIG, NJ>;
+  constexpr int NB16 = S::NB16 > 0 ? S::NB16 : 1;
+  constexpr int JR = S::JR > 0 ? S::JR : 1;
+  constexpr int NK = 2 * NJ, NS = PF + 1;
+  double a[NS][NIG], g[NS][NB16], sb[NS][JR];
+  const double* pa = imgA + cm.aoff;
+  const double* pg = imgB + cm.lbig;
+  const double* ps4 = imgB + cm.boff;
+  const bool tail = NK - 1 < cm.nbk;  // is the last K-step inside the matrix?
+#define C3P_MMT_LOAD(K)                                                                                             \
+  {                                                                                                                 \
+    constexpr int st_ = (K) % NS;                                                                                   \
+    _Pragma("unroll") for (int Ig = 0; Ig < NIG; ++Ig)                                                              \
+        a[st_][Ig] = T::uses_ig(Ig) ? md_flip(pa[Ig * 16 * W + 2 * (K)], cm.negmask) : 0.0;                         \
+    _Pragma("unroll") for (int Jg = 0; Jg < S::NB16; ++Jg) g[st_][Jg] = T::uses_jg(Jg) ? pg[(K) * 4 * W + 16 * Jg] : 0.0; \
+    _Pragma("unroll") for (int js = 0; js < S::JR; ++js)                                                            \
+        sb[st_][js] = T::uses_j(4 * S::NB16 + js) ? ps4[(K) * 4 * W + 4 * (4 * S::NB16 + js)] : 0.0;                \
+  }
+#define C3P_MMT_FMAS(K)                                                                                             \
+  {                                                                                                                 \
+    constexpr int st_ = (K) % NS;                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < T::NBW; ++i)                                                              \
+        acc.big[i] = md_mfma16(a[st_][T::bIg(i)], g[st_][T::bJg(i)], acc.big[i]);                                   \
+    _Pragma("unroll") for (int i = 0; i < T::NSW; ++i)                                                              \
+        acc.sm[i] = md_mfma4(a[st_][T::sIg(i)], sb[st_][T::sJ(i) - 4 * S::NB16], acc.sm[i]);                        \
+  }
+  md_unroll<0, PF>([&](auto Kc) { constexpr int K = decltype(Kc)::value; C3P_MMT_LOAD(K) });
+  md_unroll<0, NK>([&](auto Kc) {
+    constexpr int K = decltype(Kc)::value;
+    if constexpr (K + PF < NK) C3P_MMT_LOAD(K + PF)
+    __builtin_amdgcn_sched_barrier(0);
+    if (K < NK - 1 || tail) C3P_MMT_FMAS(K)
+    __builtin_amdgcn_sched_barrier(0);
+  });
+#undef C3P_MMT_LOAD
+#undef C3P_MMT_FMAS
+}
+
 // Workgroup barrier that waits for the LDS traffic only (__syncthreads also drains the vector-memory counter,
 // i.e. stalls on outstanding global stores of partial propagators).
 __device__ __forceinline__ void md_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -1121,7 +1166,7 @@ __device__ __forceinline__ void midd_grad_body(const MidGradArgs& A, const MidCo
 #pragma unroll
     for (int e = 0; e < NE; ++e) v.set(e, 0.0);
   };
-  auto product = [&](const double* imgA, const double* imgB, Regs& acc) { mm_tiles<NIG, NJ, W, WV>(imgA, imgB, cm, acc); };
+  auto product = [&](const double* imgA, const double* imgB, Regs& acc) { mm_tiles_pf<NIG, NJ, W, WV, 3>(imgA, imgB, cm, acc); };
   auto is_diag = [&](int e) -> bool {
     const int row = erow(e), col = ecol(e);
     return ((row & 1) == 0) && ((row >> 1) == col) && (col < D);
