@@ -639,7 +639,7 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
     for (int e = 0; e < NE; ++e) v.set(e, 0.0);
   };
   auto product = [&](const double* imgA, const double* imgB, Regs& acc) {
-    mm_tiles<NIG, NJ, W, WV>(imgA, imgB, cm, acc);
+    mm_tiles_pf<NIG, NJ, W, WV, 2>(imgA, imgB, cm, acc);
   };
   auto is_diag = [&](int e) -> bool {
     const int row = erow(e), col = ecol(e);
