@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config index (2 = headline)")
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default: config's B, capped at 256/GPU for cfg3/5)")
     ap.add_argument("--slices", type=int, default=None)
-    ap.add_argument("--gather-every", type=int, default=8, help="batches exchanged per all-gather (multi-GPU)")
+    ap.add_argument("--gather-every", type=int, default=32, help="batches exchanged per all-gather (multi-GPU)")
     ap.add_argument("--ramp-ms", type=float, default=60.0, help="untimed device clock ramp before the W warmup steps (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the generic LDS kernel")
@@ -119,7 +119,7 @@ def main():
     )
     # The only data-path collective is the all-gather of the U slabs (RCCL over xGMI), in stream order.
     # xGMI all-gathers of 0.33 MB per rank are latency-bound (tens of microseconds against a 0.25 ms
-    # batch), so the slabs of `--gather-every` consecutive batches (default 8) are exchanged by ONE
+    # batch), so the slabs of `--gather-every` consecutive batches (default 32) are exchanged by ONE
     # collective: fewer, larger messages; every batch's propagators still reach every rank inside the
     # timed region.  (An asynchronous gather beside the chain kernel was measured SLOWER: the RCCL kernel
     # takes CUs away from a grid sized to fill the chip exactly and creates a partial second round.)
