@@ -50,5 +50,6 @@ bool c3p_midd_geometry(int Dm, int* nig, int* nj, int* w);
 size_t c3p_midd_table_doubles(int Dm, int K);
 size_t c3p_midd_lds_bytes(int Dm, int K, int Lmax);
 hipError_t c3p_launch_midd_chain(const MidArgs& A, hipStream_t st);
+hipError_t c3p_launch_midd_real(const MidArgs& A, hipStream_t st);  // real-Hamiltonian instance only (c3p_launch_midd_chain calls it)
 hipError_t c3p_launch_midd_grad(const MidGradArgs& A, hipStream_t st);
 hipError_t c3p_launch_midd_prep(const MidPrepArgs& P, int nsamp, hipStream_t st);

@@ -27,6 +27,15 @@
 #include "c3p_kernels.h"
 #include "c3p_midd.h"
 
+// The file is compiled as up to three translation units (__graft_entry__.build passes -DC3P_MIDD_PART=1|2|3: complex
+// chain kernels + tables, real-Hamiltonian instance, gradient sweep) so that they build concurrently; without the
+// macro everything lands in one unit.
+#ifdef C3P_MIDD_PART
+#define C3P_MIDD_HAS(p) (C3P_MIDD_PART == (p))
+#else
+#define C3P_MIDD_HAS(p) 1
+#endif
+
 extern __shared__ __attribute__((aligned(16))) double c3p_md_lds[];
 
 namespace {
@@ -1100,34 +1109,44 @@ __global__ void __launch_bounds__(256) midd_prep_kernel(MidPrepArgs P) {
   }
 }
 
+template <typename Kern>
+hipError_t md_go(Kern kern, const MidArgs& A, size_t bytes, hipStream_t st) {
+  if (bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)bytes);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((long)A.B * A.S)), dim3(256), bytes, st, A);
+  return hipGetLastError();
+}
+
+#if C3P_MIDD_HAS(1)
 template <int NIG, int NJ, int W>
 hipError_t launch_t(const MidArgs& A, hipStream_t st) {
   constexpr int IMG = MD<NIG, NJ>::ROWS * W;
   const size_t lds = (size_t)(3 * IMG + (A.mode == C3P_MODE_GIVEN ? 0 : A.K * SGC)) * sizeof(double);
-  const unsigned grid = (unsigned)((long)A.B * A.S);
-  auto go = [&](auto kern, size_t bytes) -> hipError_t {
-    if (bytes > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-      if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, st, A);
-    return hipGetLastError();
-  };
-  if (A.mode == C3P_MODE_GIVEN) return go(midd_chain_kernel<NIG, NJ, W, true, false>, lds);
+  if (A.mode == C3P_MODE_GIVEN) return md_go(midd_chain_kernel<NIG, NJ, W, true, false>, A, lds, st);
   if (A.mode == C3P_MODE_EXPM)
-    return A.dUs_out ? go(midd_chain_kernel<NIG, NJ, W, false, true, true>, lds)
-                     : go(midd_chain_kernel<NIG, NJ, W, false, false, true>, lds);
+    return A.dUs_out ? md_go(midd_chain_kernel<NIG, NJ, W, false, true, true>, A, lds, st)
+                     : md_go(midd_chain_kernel<NIG, NJ, W, false, false, true>, A, lds, st);
   if (A.mode == C3P_MODE_UNITARY && !A.no_real && A.K <= MDR<NIG, W>::KP) {
     // samples with real Hamiltonians are taken by the real kernel, the others by the complex one
-    const size_t ldsr = (size_t)(MDR<NIG, W>::AREA + A.K * SGC) * sizeof(double);
-    hipError_t e = A.dUs_out ? go(midd_chain_kernel<NIG, NJ, W, false, true, false, true>, ldsr)
-                             : go(midd_chain_kernel<NIG, NJ, W, false, false, false, true>, ldsr);
+    hipError_t e = c3p_launch_midd_real(A, st);
     if (e != hipSuccess) return e;
   }
-  if (A.dUs_out) return go(midd_chain_kernel<NIG, NJ, W, false, true>, lds);
-  return go(midd_chain_kernel<NIG, NJ, W, false, false>, lds);
+  if (A.dUs_out) return md_go(midd_chain_kernel<NIG, NJ, W, false, true>, A, lds, st);
+  return md_go(midd_chain_kernel<NIG, NJ, W, false, false>, A, lds, st);
 }
+#endif
+
+#if C3P_MIDD_HAS(2)
+template <int NIG, int NJ, int W>
+hipError_t launch_real_t(const MidArgs& A, hipStream_t st) {
+  const size_t ldsr = (size_t)(MDR<NIG, W>::AREA + A.K * SGC) * sizeof(double);
+  return A.dUs_out ? md_go(midd_chain_kernel<NIG, NJ, W, false, true, false, true>, A, ldsr, st)
+                   : md_go(midd_chain_kernel<NIG, NJ, W, false, false, false, true>, A, ldsr, st);
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Backward sweep of the control gradient (method in c3p_grad.hip) in the mid-D layout.
@@ -1420,6 +1439,7 @@ __global__ void __launch_bounds__(256, 1) midd_grad_kernel(MidGradArgs A) {
   }
 }
 
+#if C3P_MIDD_HAS(3)
 template <int NIG, int NJ, int W>
 hipError_t launch_grad_t(const MidGradArgs& A, hipStream_t st) {
   constexpr int IMG = MD<NIG, NJ>::ROWS * W;
@@ -1434,8 +1454,11 @@ hipError_t launch_grad_t(const MidGradArgs& A, hipStream_t st) {
   return hipGetLastError();
 }
 
+#endif
+
 }  // namespace
 
+#if C3P_MIDD_HAS(1)
 // geometry classes: Dm -> (NIG, NJ, W)
 bool c3p_midd_geometry(int Dm, int* nig, int* nj, int* w) {
   if (Dm < 13 || Dm > 40) return false;
@@ -1484,7 +1507,24 @@ hipError_t c3p_launch_midd_prep(const MidPrepArgs& P, int nsamp, hipStream_t st)
   hipLaunchKernelGGL(midd_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K))), dim3(256), 0, st, P);
   return hipGetLastError();
 }
+#endif
 
+#if C3P_MIDD_HAS(2)
+hipError_t c3p_launch_midd_real(const MidArgs& A, hipStream_t st) {
+  int nig, nj, w;
+  if (!c3p_midd_geometry(A.Dm, &nig, &nj, &w)) return hipErrorInvalidValue;
+  if (nig == 2 && nj == 4) return launch_real_t<2, 4, 18>(A, st);
+  if (nig == 3 && nj == 5) return launch_real_t<3, 5, 22>(A, st);
+  if (nig == 3 && nj == 6) return launch_real_t<3, 6, 26>(A, st);
+  if (nig == 4 && nj == 7) return launch_real_t<4, 7, 30>(A, st);
+  if (nig == 4 && nj == 8) return launch_real_t<4, 8, 34>(A, st);
+  if (nig == 5 && nj == 9) return launch_real_t<5, 9, 38>(A, st);
+  if (nig == 5 && nj == 10) return launch_real_t<5, 10, 42>(A, st);
+  return hipErrorInvalidValue;
+}
+#endif
+
+#if C3P_MIDD_HAS(3)
 hipError_t c3p_launch_midd_grad(const MidGradArgs& A, hipStream_t st) {
   int nig, nj, w;
   if (!c3p_midd_geometry(A.Dm, &nig, &nj, &w)) return hipErrorInvalidValue;
@@ -1497,3 +1537,4 @@ hipError_t c3p_launch_midd_grad(const MidGradArgs& A, hipStream_t st) {
   if (nig == 5 && nj == 10) return launch_grad_t<5, 10, 42>(A, st);
   return hipErrorInvalidValue;
 }
+#endif
