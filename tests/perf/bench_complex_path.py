@@ -1,6 +1,6 @@
 """cfg2-sized batch with a complex Hermitian control operator: times the COMPLEX path of the small-D kernel."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from c3_amd import propagation as prop, _lib
 from c3_amd.workloads import make_workload

@@ -1,6 +1,6 @@
 """ODE-solver variant: RK steps/s, final-state error vs the oracle's RK and vs the PWC propagator."""
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from c3_amd import propagation as prop

@@ -1,7 +1,7 @@
 """The CPU column of SURVEY 8d at full host width: the numpy oracle (Higham Pade expm per slice + pairwise
 tree product, i.e. tf_propagation_vectorized + tf_matmul_n semantics) process-parallel over samples."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("OMP_NUM_THREADS", "1"); os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 import multiprocessing as mp
 import numpy as np
