@@ -316,7 +316,7 @@ __device__ __forceinline__ void mm_real(const MidCommon& cm,
   // D is in (4 NJ - 4, 4 NJ]: a real product has exactly NJ K-steps.  The loop is fully unrolled with the operands
   // fetched PF steps ahead in a ring of PF + 1 register stages: the LDS round trip (~150 cycles) is more than two
   // K-steps of a single 16x16x4 instruction, and a one-step prefetch left the matrix pipe waiting on every step.
-  constexpr int PF = NJ < 3 ? NJ : 3;
+  constexpr int PF = NIGR >= 3 ? 2 : (NJ < 3 ? NJ : 3);  // the 48-row classes are register-bound: one stage less
   constexpr int NS = PF + 1;
   double a[NS][NIGR], x[NS][NIGR], g[NS][NB16], h[NS][NB16], sb[NS][JR], ub[NS][JR];
   // one base register per lane-offset kind; the image (a compile-time index) goes into the instruction offset
