@@ -170,6 +170,9 @@ struct MidCommon {
   int sample, n0, len;
   int aoff, boff, lbig, lsmall;
   int aoffR, nbkR, realH;  // real-Hamiltonian path: A-slab offset of a REAL image, its K-steps, the flag
+  // real images: lane offsets of a 16x16 unit element / a 16x4 unit element / a 4x4 B block; index 0 for columns
+  // 0..15, 1 for columns 16..31 (they differ only in the swizzled layout)
+  int rbig[2], rsm[2], rblk[2];
   unsigned negmask;
   int pr, ps, t18;
   double scale;
@@ -308,7 +311,9 @@ template <int NIGR, int NJ, int W, int WV, int MODE, int IA1, int IA2, int IB1, 
 __device__ __forceinline__ void mm_real(const MidCommon& cm,
                                         TileRegs<WaveTiles<NIGR, NJ, W, WV>::NBW, WaveTiles<NIGR, NJ, W, WV>::NSW>& acc1,
                                         TileRegs<WaveTiles<NIGR, NJ, W, WV>::NBW, WaveTiles<NIGR, NJ, W, WV>::NSW>& acc2) {
-  using T = WaveTiles<NIGR, NJ, W, WV>;
+  constexpr bool SWZ = NIGR <= 2;  // MDR::SWZ
+  constexpr int WI = SWZ ? 32 : W;
+  using T = WaveTiles<NIGR, NJ, WI, WV>;
   using S = Sched<NIGR, NJ>;
   constexpr int NB16 = S::NB16 > 0 ? S::NB16 : 1;
   constexpr int JR = S::JR > 0 ? S::JR : 1;
@@ -320,30 +325,35 @@ __device__ __forceinline__ void mm_real(const MidCommon& cm,
   constexpr int NS = PF + 1;
   double a[NS][NIGR], x[NS][NIGR], g[NS][NB16], h[NS][NB16], sb[NS][JR], ub[NS][JR];
   // one base register per lane-offset kind; the image (a compile-time index) goes into the instruction offset
-  constexpr int IMGR = 16 * NIGR * W;
-  const double* qa = c3p_md_lds + cm.aoffR;
-  const double* qg = c3p_md_lds + cm.lbig;
-  const double* qs = c3p_md_lds + cm.boff;
-  const double* pa = qa + IA1 * IMGR;
-  const double* px = qa + IA2 * IMGR;
-  const double* pg = qg + IB1 * IMGR;
-  const double* ph = qg + IB2 * IMGR;
-  const double* ps4 = qs + IB1 * IMGR;
-  const double* pu4 = qs + IB2 * IMGR;
+  constexpr int IMGR = 16 * NIGR * WI;
+  const double* qa = c3p_md_lds + cm.aoffR;  // plain layout: 16 rows x 4 columns of the left operand
+  const double* qg0 = c3p_md_lds + cm.rbig[0];
+  const double* qg1 = c3p_md_lds + cm.rbig[1];
+  const double* qs0 = c3p_md_lds + cm.rblk[0];
+  const double* qs1 = c3p_md_lds + cm.rblk[1];
 #define C3P_MMR_LOAD(K)                                                                                          \
   {                                                                                                              \
     constexpr int st_ = (K) % NS;                                                                                \
     _Pragma("unroll") for (int Ig = 0; Ig < NIGR; ++Ig) {                                                        \
-      a[st_][Ig] = T::uses_ig(Ig) ? pa[Ig * 16 * W + 4 * (K)] : 0.0;                                             \
-      x[st_][Ig] = (TWOA && T::uses_ig(Ig)) ? px[Ig * 16 * W + 4 * (K)] : 0.0;                                   \
+      if constexpr (SWZ) {                                                                                       \
+        const double* q_ = Ig == 0 ? qg0 : qg1;                                                                  \
+        a[st_][Ig] = T::uses_ig(Ig) ? q_[IA1 * IMGR + (K) * 4 * WI + 16 * Ig] : 0.0;                             \
+        x[st_][Ig] = (TWOA && T::uses_ig(Ig)) ? q_[IA2 * IMGR + (K) * 4 * WI + 16 * Ig] : 0.0;                   \
+      } else {                                                                                                   \
+        a[st_][Ig] = T::uses_ig(Ig) ? qa[IA1 * IMGR + Ig * 16 * WI + 4 * (K)] : 0.0;                             \
+        x[st_][Ig] = (TWOA && T::uses_ig(Ig)) ? qa[IA2 * IMGR + Ig * 16 * WI + 4 * (K)] : 0.0;                   \
+      }                                                                                                          \
     }                                                                                                            \
     _Pragma("unroll") for (int Jg = 0; Jg < S::NB16; ++Jg) {                                                     \
-      g[st_][Jg] = T::uses_jg(Jg) ? pg[(K) * 4 * W + 16 * Jg] : 0.0;                                             \
-      h[st_][Jg] = (TWOB && T::uses_jg(Jg)) ? ph[(K) * 4 * W + 16 * Jg] : 0.0;                                   \
+      const double* q_ = Jg == 0 ? qg0 : qg1;                                                                    \
+      g[st_][Jg] = T::uses_jg(Jg) ? q_[IB1 * IMGR + (K) * 4 * WI + 16 * Jg] : 0.0;                               \
+      h[st_][Jg] = (TWOB && T::uses_jg(Jg)) ? q_[IB2 * IMGR + (K) * 4 * WI + 16 * Jg] : 0.0;                     \
     }                                                                                                            \
     _Pragma("unroll") for (int js = 0; js < S::JR; ++js) {                                                       \
-      sb[st_][js] = T::uses_j(4 * S::NB16 + js) ? ps4[(K) * 4 * W + 4 * (4 * S::NB16 + js)] : 0.0;               \
-      ub[st_][js] = (TWOB && T::uses_j(4 * S::NB16 + js)) ? pu4[(K) * 4 * W + 4 * (4 * S::NB16 + js)] : 0.0;     \
+      constexpr int J_ = 4 * S::NB16;                                                                            \
+      const double* q_ = (J_ + js) < 4 ? qs0 : qs1;                                                              \
+      sb[st_][js] = T::uses_j(J_ + js) ? q_[IB1 * IMGR + (K) * 4 * WI + 4 * (J_ + js)] : 0.0;                    \
+      ub[st_][js] = (TWOB && T::uses_j(J_ + js)) ? q_[IB2 * IMGR + (K) * 4 * WI + 4 * (J_ + js)] : 0.0;          \
     }                                                                                                            \
   }
 #define C3P_MMR_FMAS(K)                                                                                          \
@@ -376,7 +386,13 @@ template <int NIG, int W>
 struct MDR {
   static constexpr int NIGR = (NIG + 1) / 2;
   static constexpr int NIMG = 5;                       // real images of the slice pipeline
-  static constexpr int AREA = NIMG * 16 * NIGR * W;    // doubles
+  // D <= 32: 32-wide images with the column index XOR 16 on odd rows, and EVERY operand read in the B pattern
+  // (row 4K + r, 16 consecutive columns) -- the left operands of the real path are all symmetric, so the A
+  // fragment A[i][4K + r] is read as M[4K + r][i].  Rows 4K and 4K + 1 then sit in different bank halves: no
+  // bank conflicts on any operand read (a W = 30 image had 2-way conflicts on every B read).
+  static constexpr bool SWZ = NIGR <= 2;
+  static constexpr int WI = SWZ ? 32 : W;              // image row stride
+  static constexpr int AREA = NIMG * 16 * NIGR * WI;   // doubles
   static constexpr int KP = 3;                         // control lines whose tables stay in registers (K <= KP)
   static constexpr int WGS = (AREA * 8 + 6144) * 3 <= 160 * 1024 ? 3 : 2;
 };
@@ -384,23 +400,28 @@ struct MDR {
 template <int NIG, int NJ, int W, bool DUS, int WV>
 __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon& cm, long chain) {
   constexpr int NIGR = MDR<NIG, W>::NIGR;
-  using T = WaveTiles<NIGR, NJ, W, WV>;
+  constexpr int WI = MDR<NIG, W>::WI;         // image row stride (32, swizzled, for D <= 32)
+  using T = WaveTiles<NIGR, NJ, WI, WV>;
   constexpr int IMG = MD<NIG, NJ>::ROWS * W;  // complex table image
-  constexpr int IMGR = 16 * NIGR * W, NE = T::NE;
+  constexpr int IMGR = 16 * NIGR * WI, NE = T::NE;
   typedef TileRegs<T::NBW, T::NSW> Regs;
   const int D = cm.D, K = cm.K;
   const int lbig = cm.lbig, lsmall = cm.lsmall;
   const int rbig = cm.r, rsmall = 4 * cm.b + cm.r;
   const int cbig = 4 * cm.b + cm.c, csmall = cm.c;
   const double* tabs = cm.tabs;
-  double* const qbig = c3p_md_lds + lbig;      // image i adds i * IMGR: a compile-time instruction offset
-  double* const qsmall = c3p_md_lds + lsmall;
+  // image i adds i * IMGR: a compile-time instruction offset; [1] = units in columns 16..31 (swizzled layout)
+  double* const qbig0 = c3p_md_lds + cm.rbig[0];
+  double* const qbig1 = c3p_md_lds + cm.rbig[1];
+  double* const qsm0 = c3p_md_lds + cm.rsm[0];
+  double* const qsm1 = c3p_md_lds + cm.rsm[1];
   auto erow = [&](int e) -> int { return T::row0(e) + (T::is_big(e) ? rbig : rsmall); };
   auto ecol = [&](int e) -> int { return T::col0(e) + (T::is_big(e) ? cbig : csmall); };
   auto store_tiles = [&](auto img, const Regs& v) {
     constexpr int I = decltype(img)::value;
 #pragma unroll
-    for (int e = 0; e < NE; ++e) (T::is_big(e) ? qbig : qsmall)[I * IMGR + T::off0(e)] = v.get(e);
+    for (int e = 0; e < NE; ++e)
+      (T::is_big(e) ? (T::col0(e) < 16 ? qbig0 : qbig1) : (T::col0(e) < 16 ? qsm0 : qsm1))[I * IMGR + T::off0(e)] = v.get(e);
   };
   auto zero = [&](Regs& v) {
 #pragma unroll
@@ -921,6 +942,19 @@ __global__ void __launch_bounds__(256, (REAL ? MDR<NIG, W>::WGS : MidOcc<NIG, W>
   cm.lsmall = (4 * cm.b + cm.r) * W + cm.c;  // element of a 16x4 unit: row 4b + r, column c
   cm.lbig = cm.r * W + 4 * cm.b + cm.c;      // element of a 16x16 unit (register q adds 4q rows): row r, column 4b + c
   cm.negmask = (((cm.c & 1) == 0) && ((cm.r & 1) == 1)) ? 0x80000000u : 0u;
+  if constexpr (REAL) {
+    constexpr int WI = MDR<NIG, W>::WI;
+    // swizzled layout: element (row, col) lives at row * 32 + (col ^ 16 (row & 1)); every unit's rows have the
+    // parity of the lane's r, so the XOR is +16 for columns 0..15 and -16 for columns 16..31 on odd-r lanes
+    const int sw = MDR<NIG, W>::SWZ ? 16 * (cm.r & 1) : 0;
+    cm.aoffR = (4 * cm.b + cm.c) * WI + cm.r;
+    cm.rbig[0] = cm.r * WI + 4 * cm.b + cm.c + sw;
+    cm.rbig[1] = cm.r * WI + 4 * cm.b + cm.c - sw;
+    cm.rsm[0] = (4 * cm.b + cm.r) * WI + cm.c + sw;
+    cm.rsm[1] = (4 * cm.b + cm.r) * WI + cm.c - sw;
+    cm.rblk[0] = cm.r * WI + cm.c + sw;
+    cm.rblk[1] = cm.r * WI + cm.c - sw;
+  }
 
   // zero all images once (padding rows/columns must stay zero)
   for (int e = tid; e < AREA; e += 256) c3p_md_lds[e] = 0.0;
@@ -1004,7 +1038,7 @@ __global__ void __launch_bounds__(256, (REAL ? MDR<NIG, W>::WGS : MidOcc<NIG, W>
 // G - mu I (G = -i dt h, or the Lindblad generator pieces), ROWS x W doubles zero padded,
 // followed by {Re mu, Im mu, ||G - mu I||_1, 0}.
 __global__ void __launch_bounds__(256) midd_prep_kernel(MidPrepArgs P) {
-  __shared__ double redr[256], redi[256];
+  __shared__ double redr[256], redi[256], reda[256];
   __shared__ double mu[2];
   const int tid = threadIdx.x;
   const int ti = blockIdx.x % (1 + P.K);
@@ -1053,7 +1087,7 @@ __global__ void __launch_bounds__(256) midd_prep_kernel(MidPrepArgs P) {
     mu[1] = bq / D;
   }
   __syncthreads();
-  double cs = 0, remax = 0;
+  double cs = 0, remax = 0, asym = 0;
   for (int j = tid; j < D; j += 256) {
     double s = 0;
     for (int i = 0; i < D; ++i) {
@@ -1064,11 +1098,13 @@ __global__ void __launch_bounds__(256) midd_prep_kernel(MidPrepArgs P) {
       }
       s += hypot(v.x, v.y);
       remax = fmax(remax, fabs(v.x));
+      if (i < j) asym = fmax(asym, fabs(v.y - gelem(j, i).y));
     }
     cs = fmax(cs, s);
   }
   redr[tid] = cs;
   redi[tid] = remax;
+  reda[tid] = asym;
   __syncthreads();
   const int IMG = P.tile_nig ? P.tile_nig * P.tile_nj * 64 : P.rows * P.W;
   double* out = P.tables + ((long)sample * (1 + P.K) + ti) * (IMG + 4);
@@ -1102,6 +1138,11 @@ __global__ void __launch_bounds__(256) midd_prep_kernel(MidPrepArgs P) {
       nrm = fmax(nrm, redr[i]);
       re = fmax(re, redi[i]);
     }
+    // the real path reads its left operands through their transposes: the flag also demands a symmetric Im part
+    // (to rounding -- dressed operators V^T H V are symmetric to ~5e-16 relative, as in the small-D kernel)
+    double as = 0;
+    for (int i = 0; i < 256; ++i) as = fmax(as, reda[i]);
+    if (as > 1e-14 * nrm) re = fmax(re, as);
     out[IMG + 0] = mu[0];
     out[IMG + 1] = mu[1];
     out[IMG + 2] = nrm;
