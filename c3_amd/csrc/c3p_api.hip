@@ -15,6 +15,7 @@
 #include "c3p_smalld.h"
 #include "c3p_midd.h"
 #include "c3p_bigd.h"
+#include "c3p_regd.h"
 #include "c3p_signal.h"
 #include "c3p_grad.h"
 
@@ -779,6 +780,82 @@ int run_pwc_bigd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Register-resident MFMA path (Dm = 49, 65, 81; the 81 x 81 Lindblad superoperators of cfg4): 4-wave workgroup
+// per chain, right operands / accumulators in registers, three-real-product complex arithmetic (c3p_regd.hip)
+// ---------------------------------------------------------------------------
+int run_pwc_regd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs,
+                 const double* signals, const cplx* clp, double dt, int B, int K, int N, int D, int Dm,
+                 const double* fr_phase, cplx* U_out, cplx* dUs_out, hipStream_t st) {
+  if (!c3p_regd_supported(Dm) || K > 16) return 1;
+  const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
+  long S = (C3P_REGD_MAX_WGS + B - 1) / B;
+  const long smax = N / 8 > 1 ? N / 8 : 1;
+  if (S > smax) S = smax;
+  if (S < 1) S = 1;
+  const int nsamp = per_sample ? B : 1;
+  void* v;
+  if (ws_get(w, SL_TABLES, (size_t)nsamp * c3p_regd_table_doubles(Dm, K) * sizeof(double), &v)) return -1;
+  RegdPrepArgs p = {};
+  p.h0 = h0;
+  p.h0_bstride = h0_bs;
+  p.hks = hks;
+  p.hks_bstride = hk_bs;
+  p.clp = clp;
+  p.dt = dt;
+  p.K = K;
+  p.Dh = D;
+  p.Dm = Dm;
+  p.lindblad = lindblad;
+  p.tables = (double*)v;
+  HIP_TRY(c3p_launch_regd_prep(p, nsamp, st));
+  void* av;
+  if (ws_get(w, SL_SCRATCH, c3p_regd_arena_bytes(Dm), &av)) return -1;
+  MidArgs a = {};
+  a.tables = (const double*)v;
+  a.tab_per_sample = per_sample ? 1 : 0;
+  a.signals = signals;
+  a.B = B;
+  a.K = K;
+  a.N = N;
+  a.Dm = Dm;
+  a.S = (int)S;
+  a.Lmax = (int)((N + S - 1) / S);
+  a.mode = lindblad ? C3P_MODE_LINDBLAD : C3P_MODE_UNITARY;
+  a.dUs_out = dUs_out;
+  cplx* seg = U_out;
+  if (S > 1) {
+    void* sv;
+    if (ws_get(w, SL_SEG_A, (size_t)B * S * Dm * Dm * sizeof(cplx), &sv)) return -1;
+    seg = (cplx*)sv;
+  }
+  a.seg_out = seg;
+  g_last_kernel = C3P_KERNEL_MFMA;
+  if (record_start(w, st)) return -1;
+  HIP_TRY(c3p_launch_regd_chain(a, av, st));
+  if (record_stop(w, st)) return -1;
+  if (S == 1 && fr_phase) HIP_TRY(c3p_launch_rowphase(U_out, fr_phase, B, Dm, st));
+  if (S > 1) {
+    // ordered combine of the few segment products with the generic kernel (GIVEN mode)
+    ChainArgs c = {};
+    c.mode = C3P_MODE_GIVEN;
+    c.mats = seg;
+    c.B = B;
+    c.N = (int)S;
+    c.D = D;
+    c.Dm = Dm;
+    c.fr_phase = fr_phase;
+    const int keep = g_last_kernel;
+    const int prof = g_profiling;
+    g_profiling = 0;  // keep the event pair on the main kernel
+    const int rc = run_chain_generic(w, c, U_out, st);
+    g_profiling = prof;
+    g_last_kernel = keep;
+    if (rc) return -1;
+  }
+  return 0;
+}
+
 // Host-pointer staging helpers --------------------------------------------------
 struct Stage {
   DeviceWs* w;
@@ -895,6 +972,12 @@ int pwc_common(int lindblad, const void* h0, int64_t h0_bstride, const void* hks
   }
   if (!done && !(flags & C3P_FORCE_GENERIC) && !per_slice && Dm >= 13 && Dm <= 40 && K <= 16) {
     const int rc = run_pwc_midd(w, lindblad, a.h0, a.h0_bstride, a.hks, a.hks_bstride, a.signals, a.clp, dt, B,
+                                K, N, D, Dm, a.fr_phase, (cplx*)d_U, a.dUs_out, st);
+    if (rc < 0) return -1;
+    done = (rc == 0);
+  }
+  if (!done && !(flags & C3P_FORCE_GENERIC) && !per_slice && c3p_regd_supported(Dm) && K <= 16 && !getenv("C3P_NO_REGD")) {
+    const int rc = run_pwc_regd(w, lindblad, a.h0, a.h0_bstride, a.hks, a.hks_bstride, a.signals, a.clp, dt, B,
                                 K, N, D, Dm, a.fr_phase, (cplx*)d_U, a.dUs_out, st);
     if (rc < 0) return -1;
     done = (rc == 0);
