@@ -1,15 +1,24 @@
 #!/usr/bin/env python
 """Headline benchmark: full-gate propagators/s (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config C] [--scaling weak|strong] [--batch B] [--check]
 
-One "step" = one pass of the hot path over one batch of synthetic pulse-parameter
-samples: U[b] = FR_b * prod_n exp(-i H_b[n] dt) for all b (config cfg2 of BASELINE.json:
-two-qubit CR gate, D=9, 1000 PWC slices, B=256 samples per GPU; weak scaling: every rank
-propagates its own 256 samples, then one RCCL all-gather of the U slabs).
-Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path over one batch of synthetic pulse-parameter samples:
+U[b] = FR_b * prod_n exp(-i H_b[n] dt) for all b (Lindblad configs: the D^2 x D^2 superoperator).  Default = the
+configuration BASELINE.json's metric is quoted on: cfg2, two-qubit CR gate, D=9, 1000 PWC slices, B=256 on one GPU.
+
+Batch and scaling:
+  weak   (default) every rank propagates `--batch` samples of its own (default: the config's batch divided by the
+         number of GPUs BASELINE.json quotes it on -- cfg2 256, cfg3 4096/8 = 512, cfg4 512, cfg5 8192/8 = 1024);
+  strong the GLOBAL batch (`--batch`, default the config's: cfg3 4096, cfg5 8192) is split over the ranks with
+         c3_amd.dist.shard_bounds (contiguous shards, sizes differ by at most one).
+The only data-path collective is the all-gather of the U slabs over RCCL (c3_amd.dist.SlabRing: the slabs of
+`--gather-every` consecutive steps travel in ONE collective).  Inputs are resident in HBM before the timed region.
+The value is SUSTAINED throughput: an untimed clock ramp (`--ramp-ms`, default 60 ms) precedes the W warmup steps.
+Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -19,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP64_TFLOPS = 78.6  # MI355X dense fp64 (vector = matrix; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
-
+PROFILE_ROUND = "r02"
 
 # thresholds of the reference's expm (tf.linalg.expm, Higham 2005 Pade 3/5/7/9/13 chosen from ||A||_1)
 _PADE_THETA = (1.495585217958292e-2, 2.539398330063230e-1, 9.504178996162932e-1, 2.097847961257068, 5.371920351148152)
@@ -63,32 +72,59 @@ def algorithmic_flops_per_prop(wl):
     return float(tot)
 
 
+def kernel_sources_digest():
+    """sha1 over the kernel sources: PMC numbers in profiles/ are only quoted for the build they were taken on."""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "c3_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def plan_batch(cfg, scaling, batch, world, rank):
+    """(global batch, [lo, hi) of this rank, padded slab rows).  See the module docstring."""
+    from c3_amd import dist as c3dist
+
+    if scaling == "strong":
+        B_glob = int(batch) if batch is not None else int(cfg["B"])
+        lo, hi = c3dist.shard_bounds(B_glob, world, rank)
+        return B_glob, lo, hi, c3dist.max_shard(B_glob, world)
+    per = int(batch) if batch is not None else max(1, int(cfg["B"]) // int(cfg.get("gpus", 1)))
+    if batch is None and cfg["B"] == 1:
+        per = 256  # cfg1 is the reference's single-sample plumbing case; batched here like cfg2
+    return per * world, rank * per, (rank + 1) * per, per
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config index (2 = headline)")
-    ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default: config's B, capped at 256/GPU for cfg3/5)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--batch", type=int, default=None, help="weak: samples per GPU; strong: GLOBAL batch")
     ap.add_argument("--slices", type=int, default=None)
-    ap.add_argument("--gather-every", type=int, default=32, help="batches exchanged per all-gather (multi-GPU)")
+    ap.add_argument("--gather-every", type=int, default=32, help="steps exchanged per all-gather (multi-GPU)")
     ap.add_argument("--ramp-ms", type=float, default=60.0, help="untimed device clock ramp before the W warmup steps (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive side measurement")
     ap.add_argument("--generic", action="store_true", help="force the generic LDS kernel")
-    ap.add_argument("--check", action="store_true", help="verify a few samples against the oracle")
+    ap.add_argument("--check", action="store_true", help="verify samples against the oracle (and the gathered slabs)")
     args = ap.parse_args()
 
     import numpy as np
     import torch
 
     from c3_amd import _lib, propagation, workloads
+    from c3_amd import dist as c3dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dist = None
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
     if use_dist:
@@ -98,136 +134,128 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rank == 0:
+            print(f"[bench] RCCL world size {dist.get_world_size()} (backend {dist.get_backend()})", file=sys.stderr, flush=True)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
     cfg = workloads.CONFIGS[args.config]
-    B = args.batch if args.batch is not None else min(cfg["B"], 256)
-    wl = workloads.make_workload(args.config, B=B, N=args.slices, b_offset=rank * B)
+    B_glob, lo, hi, b_pad = plan_batch(cfg, args.scaling, args.batch, world, rank)
+    B = hi - lo  # this rank's samples
+    wl = workloads.make_workload(args.config, B=max(B, 1), N=args.slices, b_offset=lo)
     Dm = wl.D * wl.D if wl.lindblad else wl.D
     fr = wl.fr_phase
     if wl.lindblad:
         fr = np.stack([(p[:, None] - p[None, :]).ravel() for p in wl.fr_phase])
-    bp = propagation.BatchPropagator(
-        torch.as_tensor(wl.h0, device=dev),
-        torch.as_tensor(wl.hks, device=dev),
-        torch.as_tensor(wl.signals, device=dev),
-        wl.dt,
-        col_ops=torch.as_tensor(wl.col_ops, device=dev) if wl.lindblad else None,
-        fr_phase=torch.as_tensor(fr, device=dev),
-        force_generic=args.generic,
-    )
-    # The only data-path collective is the all-gather of the U slabs (RCCL over xGMI), in stream order.
-    # xGMI all-gathers of 0.33 MB per rank are latency-bound (tens of microseconds against a 0.25 ms
-    # batch), so the slabs of `--gather-every` consecutive batches (default 32) are exchanged by ONE
-    # collective: fewer, larger messages; every batch's propagators still reach every rank inside the
-    # timed region.  (An asynchronous gather beside the chain kernel was measured SLOWER: the RCCL kernel
-    # takes CUs away from a grid sized to fill the chip exactly and creates a partial second round.)
-    G = max(1, int(args.gather_every))
-    Ubuf = torch.empty((G, B, Dm, Dm), dtype=torch.complex128, device=dev)
-    gathered = torch.empty((world * G * B * Dm * Dm,), dtype=torch.complex128, device=dev) if use_dist else None
-    counter = [0]
-    pending = [0]
+    bp = None
+    if B > 0:
+        bp = propagation.BatchPropagator(
+            torch.as_tensor(wl.h0, device=dev),
+            torch.as_tensor(wl.hks, device=dev),
+            torch.as_tensor(wl.signals, device=dev),
+            wl.dt,
+            col_ops=torch.as_tensor(wl.col_ops, device=dev) if wl.lindblad else None,
+            fr_phase=torch.as_tensor(fr, device=dev),
+            force_generic=args.generic,
+        )
+    # The only data-path collective is the all-gather of the U slabs (RCCL over xGMI), in stream order, G steps per
+    # collective.  (An asynchronous gather beside the chain kernel was measured SLOWER: the RCCL kernel takes CUs away
+    # from a grid sized to fill the chip exactly and creates a partial second round.)
+    ring = c3dist.SlabRing(B, b_pad, (Dm, Dm), args.gather_every, device=dev, use_dist=use_dist)
+    G = ring.G
 
-    def flush():
-        g = pending[0]
-        if use_dist and g > 0:
-            n = g * B * Dm * Dm
-            dist.all_gather_into_tensor(torch.view_as_real(gathered[: world * n]), torch.view_as_real(Ubuf[:g].reshape(-1)))
-        pending[0] = 0
-
-    def step():
-        i = counter[0] % G
-        counter[0] += 1
-        U = bp.run(out=Ubuf[i])
-        pending[0] += 1
-        if pending[0] == G:
-            flush()
-        return U
-
-    def drain():
-        flush()
-        counter[0] = 0
+    def compute(out):
+        if bp is not None:
+            bp.run(out=out[:B])
 
     lib = _lib.load()
-    if use_dist:
-        # the communicator and every message size of the run are set up before anything is timed
-        for g in sorted({min(G, max(1, args.steps)), args.steps % G, args.warmup % G, min(G, max(1, args.warmup))} - {0}):
-            pending[0] = g
-            flush()
-        torch.cuda.synchronize()
+    # the communicator and every message size of the run are set up before anything is timed
+    ring.warm({min(G, max(1, args.steps)), args.steps % G, args.warmup % G, min(G, max(1, args.warmup))})
+    torch.cuda.synchronize()
     # Untimed clock ramp: the MI355X needs tens of milliseconds of sustained work to reach its steady clocks
-    # (measured: 0.210 ms per batch after 5 warmup batches, 0.194 ms after 300).  The metric is sustained
+    # (measured: 0.210 ms per cfg2 batch after 5 warmup batches, 0.194 ms after 300).  The metric is sustained
     # throughput, so the device is brought to steady state before the W warmup steps and the K timed steps.
-    if args.ramp_ms > 0:
+    if args.ramp_ms > 0 and bp is not None:
         t_r = time.perf_counter()
         while (time.perf_counter() - t_r) * 1e3 < args.ramp_ms:
             for _ in range(16):
-                bp.run(out=Ubuf[0])
+                bp.run(out=ring.buf[0][:B])
             torch.cuda.synchronize()
     for _ in range(args.warmup):
-        step()
-    drain()
+        ring.step(compute)
+    ring.drain()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()  # HIP events on the stream the kernels are launched on (torch's current stream), over the timed region
     for _ in range(args.steps):
-        step()
-    drain()
+        ring.step(compute)
+    ev1.record()
+    ring.drain()
     torch.cuda.synchronize()
     # The K steps end here on this rank (the last all-gather inside drain() has already waited for every rank's
     # slabs); the closing barrier follows and the MAX over ranks of the per-rank times is reported, so the
-    # barrier's own latency (~0.3 ms, 6 % of a 30-step run) is not booked as step time.
+    # barrier's own latency is not booked as step time.
     elapsed = time.perf_counter() - t0
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    device_ms_per_step = ev0.elapsed_time(ev1) / max(1, args.steps)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_name = _lib.last_kernel()
 
-    # ---- dominant-kernel duration: HIP events on the launch stream, outside the timed region ----
-    lib.c3p_set_profiling(1)
-    kms = []
-    for _ in range(min(10, max(3, args.steps))):
-        bp.run()
-        torch.cuda.synchronize()
-        kms.append(lib.c3p_last_kernel_ms())
-    lib.c3p_set_profiling(0)
-    kernel_ms = float(np.mean(kms))
-
     err = None
-    if args.check and rank == 0:
+    nchk = 0
+    if args.check and bp is not None:
         from oracle import c3_oracle
 
-        nchk = min(4, B)
+        # a spread of samples of this rank's shard against the oracle (bounded by the oracle's cost)
+        cost = wl.N * (Dm / 9.0) ** 3
+        nchk = int(min(B, max(2, min(32, 2.5e5 / cost))))
+        idx = np.unique(np.linspace(0, B - 1, nchk).astype(int))
         U = bp.run()
         torch.cuda.synchronize()
-        ref = c3_oracle.propagate_batch(
-            wl.h0, wl.hks, wl.signals[:nchk], wl.dt, col_ops=wl.col_ops, lindbladian=wl.lindblad, fr_phase=wl.fr_phase[:nchk]
-        )
-        Uh = U[:nchk].cpu().numpy()
-        err = float(max(np.linalg.norm(Uh[b] - ref[b]) for b in range(nchk)))
+        ref = c3_oracle.propagate_batch(wl.h0, wl.hks, wl.signals[idx], wl.dt, col_ops=wl.col_ops, lindbladian=wl.lindblad, fr_phase=wl.fr_phase[idx])
+        Uh = U[torch.as_tensor(idx, device=dev)].cpu().numpy()
+        err = float(max(np.linalg.norm(Uh[i] - ref[i]) for i in range(len(idx))))
+        nchk = len(idx)
+        if use_dist:
+            # the slab every rank received from this rank must equal this rank's own result
+            ring.step(compute)
+            ring.drain()
+            torch.cuda.synchronize()
+            mine = ring.gathered_slab(rank, 0)[:B]
+            assert torch.equal(mine, ring.buf[0][:B]), "all-gather mismatch"
+            e = torch.tensor([err], dtype=torch.float64, device=dev)
+            dist.all_reduce(e, op=dist.ReduceOp.MAX)
+            err = float(e.item())
 
     if rank == 0:
-        total_props = world * B * args.steps
+        total_props = B_glob * args.steps
         value = total_props / elapsed
         f_prop = algorithmic_flops_per_prop(wl)
-        achieved = f_prop * B / (kernel_ms * 1e-3) / 1e12
-        traffic = None
-        issued = None
-        tfile = os.path.join(ROOT, "profiles", "r01", "traffic.json")
-        if os.path.exists(tfile) and args.batch is None and args.slices is None and not args.generic:
+        achieved = f_prop * B / (device_ms_per_step * 1e-3) / 1e12
+        traffic = issued = issued_frac = None
+        pfile = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc.json")
+        digest = kernel_sources_digest()
+        if os.path.exists(pfile) and args.slices is None and not args.generic:
             try:
-                prof = json.load(open(tfile)).get(f"cfg{args.config}", {})
-                traffic = prof.get("bytes_per_launch")
-                issued = prof.get("issued_mfma_flop_per_launch")
+                prof = json.load(open(pfile))
+                ent = prof.get(f"cfg{args.config}", {})
+                # only for the kernel build and the batch the counters were taken on
+                if ent.get("kernel_sources_digest") == digest and ent.get("batch") == B:
+                    traffic = ent.get("hbm_bytes_per_launch")
+                    issued = ent.get("issued_flop_per_launch")
+                    if issued:
+                        issued_frac = issued / (device_ms_per_step * 1e-3) / 1e12 / PEAK_FP64_TFLOPS
             except Exception:
-                traffic = None
+                traffic = issued = issued_frac = None
         out = {
             "metric": "full-gate propagators/s",
             "value": value,
@@ -237,20 +265,22 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "c128",
             "data": "synthetic",
             "config": {
-                "workload": wl.name,
+                "workload": wl.name if world == 1 else f"{wl.name} per rank 0 shard; global batch {B_glob}",
                 "D": wl.D,
                 "matrix_dim": Dm,
                 "slices": wl.N,
                 "controls": wl.K,
                 "batch_per_gpu": B,
-                "global_batch": world * B,
+                "global_batch": B_glob,
+                "baseline_batch": f"{cfg['B']} on {cfg.get('gpus', 1)} GPU(s)",
                 "clock_ramp_ms": args.ramp_ms,
-                "parallelism": f"dp{world} (batch sharded; one RCCL all-gather of U per {G} batches)" if world > 1 else "single GPU",
+                "throughput": f"sustained: after a {args.ramp_ms:g} ms untimed clock ramp and {args.warmup} warmup steps",
+                "parallelism": (f"dp{world} ({args.scaling}: batch sharded; one RCCL all-gather of U per {G} steps)" if world > 1 else "single GPU"),
                 "kernel": kernel_name,
             },
             "roofline": {
@@ -261,52 +291,71 @@ def main():
                 "frac": achieved / PEAK_FP64_TFLOPS,
                 "traffic": traffic,
                 "issued_flop_per_launch": issued,
+                "issued_frac": issued_frac,
                 "algorithmic_flop_per_launch": f_prop * B,
                 "kernel": f"chain kernel ({kernel_name})",
-                "kernel_ms": kernel_ms,
+                "kernel_ms": device_ms_per_step,
                 "algorithmic_flop_per_propagator": f_prop,
-                "note": "fp64 compute-bound path: algorithmic flops (SURVEY 8d, reference Pade order per slice) / hipEvent kernel time; peak = dense fp64 (MFMA = vector on MI355X); traffic = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/traffic.json), null when not profiled for this configuration",
+                "note": "fp64 compute-bound path. achieved/frac: ALGORITHMIC flops (SURVEY 8d: the reference's complex Pade order per slice + product tree) / device time per step by HIP events over the timed region; a method that needs fewer flops than the reference's can exceed 1. issued_frac: flops the kernel actually issues (PMC: SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 + fp64 VALU) / same time / peak -- quoted only for the kernel build and batch profiled in profiles/" + PROFILE_ROUND + "/pmc.json, else null; traffic = HBM bytes per launch from the same PMC passes, else null",
             },
         }
         if err is not None:
             out["max_fro_err_vs_oracle"] = err
+            out["oracle_samples_checked"] = nchk
+        if world == 1 and not args.no_e2e and bp is not None:
+            out["e2e"] = e2e_rates(wl, fr, propagation, torch, dev)
         if world == 1 and not args.no_cpu_baseline:
             from oracle import c3_oracle  # the CPU restatement, timed beside the GPU path (checker only)
 
             out["cpu_baseline"] = cpu_baseline(wl, c3_oracle)
+            out["cpu_baseline_allcores"] = cpu_baseline_allcores(args.config, wl)
         print(json.dumps(out), flush=True)
     if use_dist:
-        if args.check and gathered is not None:
-            # the gathered slab of this rank must equal its own result
-            last = (counter[0] - 1) % nbuf
-            assert torch.equal(gathered[last][rank * B : (rank + 1) * B], Ubuf[last]), "all-gather mismatch"
         dist.destroy_process_group()
+
+
+def e2e_rates(wl, fr, propagation, torch, dev, reps=5):
+    """PCIe-inclusive rates (never the reported `value`): host numpy in / out through C3P_HOST_PTRS
+    (control samples in, U out, synchronous)."""
+    def host():
+        propagation.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt, col_ops=wl.col_ops, lindbladian=wl.lindblad, fr_phase=fr)
+
+    host()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        host()
+    t = (time.perf_counter() - t0) / reps
+    Dm = wl.D * wl.D if wl.lindblad else wl.D
+    return {
+        "host_in_out_props_per_s": wl.B / t,
+        "host_in_out_ms_per_batch": t * 1e3,
+        "bytes_in": int(wl.signals.nbytes),
+        "bytes_out": int(wl.B * Dm * Dm * 16),
+        "note": "numpy arrays in host memory -> C ABI (C3P_HOST_PTRS: H2D of the control samples, kernel, D2H of U, synchronous); parameter-row input (signals synthesised on the device): tools/bench_pcie.py",
+    }
+
+
+def _oracle_run(wl, oracle, nb):
+    t0 = time.perf_counter()
+    oracle.propagate_batch(wl.h0, wl.hks, wl.signals[:nb], wl.dt, col_ops=wl.col_ops, lindbladian=wl.lindblad, fr_phase=wl.fr_phase[:nb])
+    return time.perf_counter() - t0
 
 
 def cpu_baseline(wl, oracle):
     """The numpy oracle (reference algorithm: batched per-slice Pade expm + pairwise tree
     product) timed single-threaded on a bounded sample of the same workload."""
-    import numpy as np
-
     try:
         from threadpoolctl import threadpool_limits
     except Exception:  # pragma: no cover
         threadpool_limits = None
 
-    def run(nb):
-        t0 = time.perf_counter()
-        oracle.propagate_batch(
-            wl.h0, wl.hks, wl.signals[:nb], wl.dt, col_ops=wl.col_ops, lindbladian=wl.lindblad, fr_phase=wl.fr_phase[:nb]
-        )
-        return time.perf_counter() - t0
-
     ctx = threadpool_limits(limits=1) if threadpool_limits else None
     try:
         if ctx is not None:
             ctx.__enter__()
-        t1 = run(1)
-        nb = int(max(1, min(wl.B, round(12.0 / max(t1, 1e-3)))))
-        t = run(nb)
+        t1 = _oracle_run(wl, oracle, 1)
+        nb = int(max(1, min(wl.B, round(10.0 / max(t1, 1e-3)))))
+        t = _oracle_run(wl, oracle, nb)
     finally:
         if ctx is not None:
             ctx.__exit__(None, None, None)
@@ -316,6 +365,59 @@ def cpu_baseline(wl, oracle):
         "cores": 1,
         "kind": "port",
         "sample": f"{nb} of {wl.B} samples of {wl.name}, numpy oracle (Higham Pade expm per slice + tf_matmul_n tree), 1 thread, {os.cpu_count()} host cores present",
+    }
+
+
+def _pool_init():
+    os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = os.environ["MKL_NUM_THREADS"] = "1"
+    import numpy  # noqa: F401
+
+    from oracle import c3_oracle  # noqa: F401
+    from c3_amd import workloads  # noqa: F401
+
+
+def _pool_work(job):
+    cfg, N, b0, nb = job
+    from c3_amd.workloads import make_workload
+    from oracle import c3_oracle as o
+
+    if nb == 0:
+        return 0.0
+    w = make_workload(cfg, B=nb, N=N, b_offset=b0)
+    t0 = time.perf_counter()
+    o.propagate_batch(w.h0, w.hks, w.signals, w.dt, col_ops=w.col_ops, lindbladian=w.lindblad, fr_phase=w.fr_phase)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_allcores(cfg_index, wl, budget_s=12.0):
+    """The same oracle process-parallel over samples on ALL host cores, with a persistent worker pool: workers are
+    started and warmed (imports, one sample each) BEFORE the timed map, so pool start-up is excluded."""
+    import multiprocessing as mp
+
+    cores = os.cpu_count() or 1
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    ctx = mp.get_context("spawn")  # the parent holds a HIP context: no fork
+    with ctx.Pool(cores, initializer=_pool_init) as pool:
+        warm = pool.map(_pool_work, [(cfg_index, wl.N, 0, 1)] * cores)  # untimed: start-up + one sample per worker
+        t1 = sorted(warm)[len(warm) // 2]
+        per = int(max(1, min(64, round(budget_s / max(t1, 1e-3)))))
+        t0 = time.perf_counter()
+        pool.map(_pool_work, [(cfg_index, wl.N, i * per, per) for i in range(cores)], chunksize=1)
+        wall = time.perf_counter() - t0
+    return {
+        "value": cores * per / wall,
+        "unit": "propagators/s",
+        "cores": cores,
+        "kind": "port",
+        "cpu_model": model,
+        "sample": f"{cores * per} samples of {wl.name.rsplit(' B=', 1)[0]} ({per} per worker), numpy oracle, one single-threaded process per hardware thread, persistent pool (start-up and a warm-up sample excluded)",
     }
 
 

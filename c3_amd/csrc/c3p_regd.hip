@@ -7,20 +7,26 @@
 //   * Core matrices live in REGISTERS: wave w owns the 4n columns [4n w, 4n w + 4n) -- n column blocks of 4 --
 //     and all 16n rows, as n x n tiles in the C/D layout of v_mfma_f64_4x4x4_4b_f64 (lane (q,b,p) of tile
 //     (Ig,jj) holds row 16 Ig + 4 b + q, column 4 (n w + jj) + p), real and imaginary parts in separate registers.
-//   * A product C = L R streams the LEFT operand from one LDS image (complex, row stride Dm + 1: the 16 x 4
-//     A fragments are conflict-free ds_read_b128) and takes the RIGHT operand from the registers of the wave that
-//     owns those columns: the B operand of K-step 4 Ig' + b' is block b' of tile (Ig',jj), broadcast to the four
-//     blocks with ds_swizzle -- no global or LDS traffic for it, and the result lands in the layout the next
-//     product needs.
+//   * A product C = L R streams the LEFT operand from one LDS image (complex, row stride Dm + 1, 16 x 4 A fragments by
+//     ds_read_b128) and takes the RIGHT operand from the registers of the wave that owns those columns: in the four
+//     K-steps of a row group of R, MFMA block b multiplies by block (b - s) mod 4 of the tile -- the tile rotated by s
+//     4-lane groups with DPP row_ror moves -- and reads its A fragment at the k of that block.  No global or LDS traffic
+//     for the right operand, and the result lands in the layout the next product needs.
 //   * Complex products use three real products (P = Lr Rr, Q = Li Ri, R = (Lr + Li)(Rr + Ri); Re C = P - Q,
 //     Im C = R - P - Q): 3 n^2 MFMAs per K-step and wave instead of 4 n^2, zero padding (the core is a multiple of
 //     the tile in every direction).
-//   * The border (last row / column / k = Dm - 1) is exact vector work: a rank-1 update of the core, a
-//     matrix-vector product from the LDS image, a vector-matrix product against the register tiles with a lane
-//     reduction; border elements of every live matrix stay in small LDS slots, one element per lane.
-//   * exp: T18 (Bader-Blanes-Casas, 5 products) + s squarings + 1 chain product per slice.  Only three tile sets
-//     per slice visit the per-workgroup global arena (A2, B2 and the running product U): 0.6 MB per slice instead of
-//     the 2.5 MB of the arena kernel in c3p_bigd.hip; the polynomial combinations are formed in registers.
+//   * The border (last row / column / k = Dm - 1): the last column of C is one more B column on a quarter of the K-steps
+//     of each wave, the last row uses the tiles of R block by block (partial sums per wave / per MFMA block, summed
+//     through LDS), the k = Dm - 1 term is a rank-1 update on the vector unit; border elements of every live matrix stay
+//     in small LDS slots, one element per lane.
+//   * exp: T18 (Bader-Blanes-Casas, 5 products) + s squarings + 1 chain product per slice.  Five tile sets per slice
+//     visit the per-workgroup global arena (X, A2, B2, B3 and the running product U, each written once and read back once
+//     by the thread that wrote it): 1.0 MB per slice instead of the 2.5 MB of the arena kernel in c3p_bigd.hip; the
+//     polynomial combinations are formed in registers.
+//   * The main loop is ROLLED over the row groups of R (its tiles move up one row per pass): a fifth of the code and a
+//     register allocation the compiler solves without spilling the right operand; inside a K-step the source order
+//     (three MFMAs, one piece of the next step's operand preparation) is pinned with sched_barrier.
+#include <cstdio>
 #include <utility>
 
 #include "c3p_common.h"
@@ -51,11 +57,10 @@ struct RG {
   static constexpr int LD = DM + 1;      // image row stride (complex elements), = 2 mod 16
   static constexpr int BS = 2 * DM;      // border slot: row DM-1 (DM elements, corner last), column DM-1 (DM elements, corner last)
   static constexpr int DMP = DM + 1;
-  static constexpr int KP = (DM + 2) / 3;  // k range of one matrix-vector part
   static constexpr int IMG_C = DM * LD;
   static constexpr int TSET_C = NT * RG_THREADS;  // complex elements of a tile set: element (tile, thread) at tile * 256 + thread
   static constexpr int TAB_D = 2 * (TSET_C + BS) + 4;  // doubles per generator table: tile set, border slot, {mu_r, mu_i, norm1, 0}
-  static constexpr int LDS_C = IMG_C + S_NSLOT * BS + 3 * DMP;
+  static constexpr int LDS_C = IMG_C + S_NSLOT * BS + 8 * DMP;
   static constexpr int LDS_D = 2 * LDS_C + RG_KMAX * RG_CH + 2 * RG_WAVES;
 };
 
@@ -68,13 +73,19 @@ __device__ __forceinline__ void rg_static_for(F&& f) {
   rg_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// value of lane (q, BP, p) for every lane (q, b, p): block BP of a C/D-layout register as the B operand of all four blocks
-template <int BP>
-__device__ __forceinline__ double rg_bcast(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_ds_swizzle(lo, 0x13 | (BP << 7));  // bit mode: lane' = (lane & 0b10011) | (BP << 2)
-  hi = __builtin_amdgcn_ds_swizzle(hi, 0x13 | (BP << 7));
-  return __hiloint2double(hi, lo);
+// The four 4-lane groups of every 16-lane row rotated by S groups (DPP row_ror: lane l takes lane (l - 4 S) mod 16 of its
+// row): MFMA block b then holds what block (b - S) mod 4 held.  A VALU move -- it issues in the shadow of the MFMAs,
+// where a ds_swizzle broadcast held up the matrix pipe (measured: 20 swizzles per 75 MFMAs cost 3.8 cycles per MFMA).
+template <int S>
+__device__ __forceinline__ double rg_rot(double v) {
+  if constexpr (S == 0) {
+    return v;
+  } else {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x120 + 4 * S, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x120 + 4 * S, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+  }
 }
 
 // Global accesses are (uniform base in SGPRs, opaque so the address arithmetic is not hoisted out of the slice loop and
@@ -87,12 +98,29 @@ template <typename T>
 __device__ __forceinline__ T* rg_ubase(T* p) {
   return p + rg_opq(0);
 }
+// arena traffic is streamed once per slice (written, read back by the same thread, dead): non-temporal, so that it does not
+// push the generator tables (shared by every workgroup, re-read every slice) out of the L2
+typedef double rg_v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cplx rg_ld_nt(const cplx* ubase, unsigned voff) {
+  const rg_v2d v = __builtin_nontemporal_load(reinterpret_cast<const rg_v2d*>(reinterpret_cast<const char*>(ubase) + voff));
+  return cmake(v.x, v.y);
+}
+__device__ __forceinline__ void rg_st_nt(cplx* ubase, unsigned voff, cplx v) {
+  rg_v2d w;
+  w.x = v.x;
+  w.y = v.y;
+  __builtin_nontemporal_store(w, reinterpret_cast<rg_v2d*>(reinterpret_cast<char*>(ubase) + voff));
+}
 __device__ __forceinline__ cplx rg_ld(const cplx* ubase, unsigned voff) {
   return *reinterpret_cast<const cplx*>(reinterpret_cast<const char*>(ubase) + voff);
 }
 __device__ __forceinline__ void rg_st(cplx* ubase, unsigned voff, cplx v) {
   *reinterpret_cast<cplx*>(reinterpret_cast<char*>(ubase) + voff) = v;
 }
+
+// Workgroup barrier that waits for the LDS traffic only (__syncthreads also drains the vector-memory counter, i.e. stalls
+// on the outstanding arena stores; those are only ever read back by the thread that wrote them)
+__device__ __forceinline__ void rg_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ double rg_rfl(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -102,9 +130,9 @@ __device__ __forceinline__ double rg_rfl(double v) {
 }
 
 template <int NRG, bool DUS>
-__global__ void __launch_bounds__(RG_THREADS, 1) regd_chain_kernel(MidArgs A, cplx* arena_base) {
+__global__ void __launch_bounds__(RG_THREADS, 1) regd_chain_kernel(MidArgs A, cplx* arena_base, long long* dbg) {
   using G = RG<NRG>;
-  constexpr int DM = G::DM, NJ = G::NJ, NKS = G::NKS, LD = G::LD, BS = G::BS, DMP = G::DMP, KP = G::KP;
+  constexpr int DM = G::DM, NJ = G::NJ, LD = G::LD, BS = G::BS, DMP = G::DMP;
   constexpr int TSET = G::TSET_C;
   // lane indices are re-derived from an opaque copy of the thread id at the start of every phase (refresh): otherwise
   // the compiler hoists every address / mask that depends on them out of the slice loop and spills them
@@ -115,7 +143,8 @@ __global__ void __launch_bounds__(RG_THREADS, 1) regd_chain_kernel(MidArgs A, cp
   cplx* img = reinterpret_cast<cplx*>(c3p_rg_lds);
   cplx* brd = img + G::IMG_C;
   cplx* cpart = brd + S_NSLOT * BS;
-  double* sg = reinterpret_cast<double*>(cpart + 3 * DMP);
+  cplx* rpart = cpart + 4 * DMP;
+  double* sg = reinterpret_cast<double*>(rpart + 4 * DMP);
   double* red = sg + RG_KMAX * RG_CH;
   const int col0 = 4 * NJ * wave;  // first column of this wave
   int rowC = 4 * b + q;            // row of a C/D-layout element inside its row group
@@ -134,6 +163,18 @@ __global__ void __launch_bounds__(RG_THREADS, 1) regd_chain_kernel(MidArgs A, cp
     voff = (unsigned)tid * (unsigned)sizeof(cplx);
   };
 
+#ifdef C3P_REGD_TIMING
+  long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tq = 0;
+#define RG_TICK(i)                  \
+  {                                 \
+    const long long tn = clock64(); \
+    tacc[i] += tn - tq;             \
+    tq = tn;                        \
+  }
+#else
+#define RG_TICK(i)
+#endif
   double Rr[NRG][NJ], Ri[NRG][NJ];                // right operand of the next product
   double aP[NRG][NJ], aQ[NRG][NJ], aR[NRG][NJ];   // accumulators; after a product aP = Re C, aR = Im C
 
@@ -151,45 +192,150 @@ __global__ void __launch_bounds__(RG_THREADS, 1) regd_chain_kernel(MidArgs A, cp
   };
 
   // C = (init) + L R: L = the LDS image, R = (Rr, Ri) with borders in slot sr; the accumulators carry the initial
-  // value (aP = Re, aQ = 0, aR = Re + Im); border of the initial value in slot si (or si < 0); border of C -> slot sd.
-  // Ends before the workgroup barrier that publishes the border partials.
+  // value (aP = Re, aQ = 0, aR = Re + Im); border of the initial value in slot si (or si < 0); border of C -> slot sd
+  // (by finalize, after the workgroup barrier that publishes the border partials).
+  // The borders ride on the matrix cores as well: column DM-1 of C is one more B column (the border column of R, read
+  // from its LDS slot) on the K-steps with kk mod 4 == wave -- four partial sums, one per wave; row DM-1 of C uses the
+  // tiles of R block by block (A operand = row DM-1 of L in the i = 0 row of every block): four partial sums, one per
+  // MFMA block.  The k = DM-1 terms are added by finalize / the rank-1 update of the core.
+  cplx cornerA = cmake(0.0, 0.0), cornerR = cmake(0.0, 0.0);
   auto product = [&](int sr, int si, int sd) {
     const cplx* rb = brd + sr * BS;
+    // new live ranges for the right operand inside the product (whatever the phases around it did to the old ones)
+#pragma unroll
+    for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) {
+        asm volatile("" : "+v"(Rr[Ig][jj]));
+        asm volatile("" : "+v"(Ri[Ig][jj]));
+      }
+    double cP[NRG], cQ[NRG], cR[NRG];
+    double rP[NJ + 1], rQ[NJ + 1], rR[NJ + 1];
+#pragma unroll
+    for (int Ig = 0; Ig < NRG; ++Ig) cP[Ig] = cQ[Ig] = cR[Ig] = 0.0;
+#pragma unroll
+    for (int jj = 0; jj <= NJ; ++jj) rP[jj] = rQ[jj] = rR[jj] = 0.0;
     {
-      const cplx* pa = img + rowA * LD + q;
+      // One pass of this loop = the four K-steps of one row group of R (its tiles are row 0 of (Rr, Ri); the rows move
+      // up at the end of the pass) + that row group's share of row DM-1 of C.  A rolled loop: a fifth of the code, and
+      // a register allocation problem the compiler solves without spilling the right operand.
+      // K-step s of a pass: MFMA block b multiplies by block (b - s) mod 4 of the tile (the tile rotated by s groups), so
+      // its A fragment is taken at the k of that block: every block meets every k of the row group in the four steps.
+      const cplx* pa = img + rowA * LD;
+      const cplx* pr = img + (DM - 1) * LD + rowC;  // row DM-1 of L at this lane's k
+      const cplx* pc = rb + DM;                     // column DM-1 of R
+      int ko[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) ko[s] = 4 * ((b - s) & 3) + q;
       cplx aC[NRG], aN[NRG];
+      double br[NJ], bi[NJ], bs[NJ];  // B operands of the current K-step (prepared during the previous one)
 #pragma unroll
-      for (int Ig = 0; Ig < NRG; ++Ig) aC[Ig] = pa[16 * Ig * LD];
-      rg_static_for<NKS>([&](auto kk_) {
-        constexpr int kk = decltype(kk_)::value;
-        constexpr int Igp = kk >> 2, bp = kk & 3;
-        if constexpr (kk + 1 < NKS) {
+      for (int Ig = 0; Ig < NRG; ++Ig) aC[Ig] = pa[16 * Ig * LD + ko[0]];
 #pragma unroll
-          for (int Ig = 0; Ig < NRG; ++Ig) aN[Ig] = pa[16 * Ig * LD + 4 * (kk + 1)];
-        }
-        double br[NJ], bi[NJ], bs[NJ];
+      for (int jj = 0; jj < NJ; ++jj) {
+        br[jj] = Rr[0][jj];
+        bi[jj] = Ri[0][jj];
+        bs[jj] = br[jj] + bi[jj];
+      }
+      RG_TICK(10)
+#pragma unroll 1
+      for (int it = 0; it < NRG; ++it) {
+        rg_static_for<4>([&](auto s_) {
+          constexpr int sx = decltype(s_)::value;
+          constexpr int sn = (sx + 1) & 3, rn = (sx == 3) ? 1 : 0;  // next step: rotation, row of (Rr, Ri)
+          // Source order = issue order (sched_barrier pins it): three MFMAs, then one piece of the next step's operand
+          // preparation -- an A-fragment load, a tile rotation (two DPP moves) or a sum -- so that the preparation issues
+          // in the shadow of the matrix pipe instead of stalling it at the top of the step.
+          double as[NRG];
+          double brN[NJ], biN[NJ], bsN[NJ];
+          rg_static_for<NRG>([&](auto Ig_) {
+            constexpr int Ig = decltype(Ig_)::value;
+            as[Ig] = aC[Ig].x + aC[Ig].y;
+            rg_static_for<NJ>([&](auto jj_) {
+              constexpr int jj = decltype(jj_)::value;
+              constexpr int u = Ig * NJ + jj;  // preparation slot
+              aP[Ig][jj] = mfma(aC[Ig].x, br[jj], aP[Ig][jj]);
+              aQ[Ig][jj] = mfma(aC[Ig].y, bi[jj], aQ[Ig][jj]);
+              aR[Ig][jj] = mfma(as[Ig], bs[jj], aR[Ig][jj]);
+              constexpr int OPS = (4 * NRG + NRG * NJ - 1) / (NRG * NJ);  // preparation pieces per slot (4 NRG in all)
+              rg_static_for<OPS>([&](auto o_) {
+                constexpr int op = u * OPS + decltype(o_)::value;
+                if constexpr (op < NRG) {
+                  aN[op] = pa[16 * op * LD + (sx == 3 ? 16 : 0) + ko[sn]];  // (the very last prefetch is unused)
+                } else if constexpr (op < NRG + 2 * NJ) {
+                  constexpr int j2 = (op - NRG) >> 1;
+                  if constexpr (((op - NRG) & 1) == 0) brN[j2] = rg_rot<sn>(Rr[rn][j2]);
+                  else biN[j2] = rg_rot<sn>(Ri[rn][j2]);
+                } else if constexpr (op < NRG + 3 * NJ) {
+                  constexpr int j2 = op - NRG - 2 * NJ;
+                  bsN[j2] = brN[j2] + biN[j2];
+                }
+              });
+              __builtin_amdgcn_sched_barrier(0);
+            });
+          });
+          if (sx == wave) {  // this wave's share of column DM-1
+            const cplx vb = pc[ko[sx]];
+            const double cbr = (p == 0) ? vb.x : 0.0, cbi = (p == 0) ? vb.y : 0.0, cbs = cbr + cbi;
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) {
-          br[jj] = rg_bcast<bp>(Rr[Igp][jj]);
-          bi[jj] = rg_bcast<bp>(Ri[Igp][jj]);
-          bs[jj] = br[jj] + bi[jj];
-        }
-#pragma unroll
-        for (int Ig = 0; Ig < NRG; ++Ig) {
-          const double as = aC[Ig].x + aC[Ig].y;
-#pragma unroll
-          for (int jj = 0; jj < NJ; ++jj) {
-            aP[Ig][jj] = mfma(aC[Ig].x, br[jj], aP[Ig][jj]);
-            aQ[Ig][jj] = mfma(aC[Ig].y, bi[jj], aQ[Ig][jj]);
-            aR[Ig][jj] = mfma(as, bs[jj], aR[Ig][jj]);
+            for (int Ig = 0; Ig < NRG; ++Ig) {
+              cP[Ig] = mfma(aC[Ig].x, cbr, cP[Ig]);
+              cQ[Ig] = mfma(aC[Ig].y, cbi, cQ[Ig]);
+              cR[Ig] = mfma(as[Ig], cbs, cR[Ig]);
+            }
           }
-        }
-        if constexpr (kk + 1 < NKS) {
 #pragma unroll
           for (int Ig = 0; Ig < NRG; ++Ig) aC[Ig] = aN[Ig];
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) {
+            br[jj] = brN[jj];
+            bi[jj] = biN[jj];
+            bs[jj] = bsN[jj];
+          }
+        });
+        // row DM-1 (and, on wave 0, the corner): partial sums over the k of each MFMA block
+        {
+          const cplx va = pr[0];
+          const double ar = (p == 0) ? va.x : 0.0, ai = (p == 0) ? va.y : 0.0, as = ar + ai;
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) {
+            rP[jj] = mfma(ar, Rr[0][jj], rP[jj]);
+            rQ[jj] = mfma(ai, Ri[0][jj], rQ[jj]);
+            rR[jj] = mfma(as, Rr[0][jj] + Ri[0][jj], rR[jj]);
+          }
+          if (wave == 0) {
+            const cplx vb = rb[DM + 16 * it + rowC];
+            const double cbr = (p == 0) ? vb.x : 0.0, cbi = (p == 0) ? vb.y : 0.0;
+            rP[NJ] = mfma(ar, cbr, rP[NJ]);
+            rQ[NJ] = mfma(ai, cbi, rQ[NJ]);
+            rR[NJ] = mfma(as, cbr + cbi, rR[NJ]);
+          }
         }
-      });
+#pragma unroll
+        for (int Ig = 0; Ig + 1 < NRG; ++Ig)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) {
+            Rr[Ig][jj] = Rr[Ig + 1][jj];
+            Ri[Ig][jj] = Ri[Ig + 1][jj];
+          }
+        pa += 16;
+        pr += 16;
+        pc += 16;
+      }
     }
+    RG_TICK(0)
+    if (q == 0) {
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+        rpart[b * DMP + col0 + 4 * jj + p] = cmake(rP[jj] - rQ[jj], rR[jj] - rP[jj] - rQ[jj]);
+      if (wave == 0 && p == 0) rpart[b * DMP + DM - 1] = cmake(rP[NJ] - rQ[NJ], rR[NJ] - rP[NJ] - rQ[NJ]);
+    }
+    if (p == 0) {
+#pragma unroll
+      for (int Ig = 0; Ig < NRG; ++Ig) cpart[wave * DMP + 16 * Ig + rowC] = cmake(cP[Ig] - cQ[Ig], cR[Ig] - cP[Ig] - cQ[Ig]);
+    }
+    cornerA = img[(DM - 1) * LD + DM - 1];
+    cornerR = rb[BS - 1];
 #pragma unroll
     for (int Ig = 0; Ig < NRG; ++Ig)
 #pragma unroll
@@ -213,62 +359,28 @@ __global__ void __launch_bounds__(RG_THREADS, 1) regd_chain_kernel(MidArgs A, cp
           aR[Ig][jj] = fma(a80[Ig].x, b80[jj].y, fma(a80[Ig].y, b80[jj].x, aR[Ig][jj]));
         }
     }
-    // column DM-1 of C (and the corner): L . (column DM-1 of R), three k ranges per row
-    if (tid < 3 * DM) {
-      const int part = tid / DM, i = tid - part * DM;
-      const int k0 = part * KP, k1 = (k0 + KP < DM) ? k0 + KP : DM;
-      const cplx* ar = img + i * LD;
-      const cplx* cb = rb + DM;
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      for (int k = k0; k < k1; ++k) {
-        const cplx a = ar[k], v = cb[k];
-        s0 = fma(a.x, v.x, s0);
-        s1 = fma(a.y, v.y, s1);
-        s2 = fma(a.x, v.y, s2);
-        s3 = fma(a.y, v.x, s3);
-      }
-      cpart[part * DMP + i] = cmake(s0 - s1, s2 + s3);
-    }
-    // row DM-1 of C, columns of this wave: (row DM-1 of L) . R, partial over the lane's rows, reduced over (q, b)
-    {
-      cplx a8[NRG];
-#pragma unroll
-      for (int Ig = 0; Ig < NRG; ++Ig) a8[Ig] = img[(DM - 1) * LD + 16 * Ig + rowC];
-      const cplx corner = img[(DM - 1) * LD + DM - 1];
-#pragma unroll
-      for (int jj = 0; jj < NJ; ++jj) {
-        double vr = 0.0, vi = 0.0;
-#pragma unroll
-        for (int Ig = 0; Ig < NRG; ++Ig) {
-          vr = fma(a8[Ig].x, Rr[Ig][jj], fma(-a8[Ig].y, Ri[Ig][jj], vr));
-          vi = fma(a8[Ig].x, Ri[Ig][jj], fma(a8[Ig].y, Rr[Ig][jj], vi));
-        }
-#pragma unroll
-        for (int m = 4; m <= 32; m <<= 1) {
-          vr += __shfl_xor(vr, m);
-          vi += __shfl_xor(vi, m);
-        }
-        if (lane < 4) {
-          const int j = col0 + 4 * jj + p;
-          const cplx rbj = rb[j];
-          vr = fma(corner.x, rbj.x, fma(-corner.y, rbj.y, vr));
-          vi = fma(corner.x, rbj.y, fma(corner.y, rbj.x, vi));
-          if (si >= 0) {
-            const cplx ini = brd[si * BS + j];
-            vr += ini.x;
-            vi += ini.y;
-          }
-          brd[sd * BS + j] = cmake(vr, vi);
-        }
-      }
-    }
   };
-  // after the barrier: column DM-1 (and both copies of the corner) of the product
-  auto finalize = [&](int si, int sd) {
-    if (tid >= DM - 1 && tid < BS) {
-      const int i = (tid == DM - 1) ? DM - 1 : tid - DM;
-      const cplx v0 = cpart[i], v1 = cpart[DMP + i], v2 = cpart[2 * DMP + i];
-      double vr = (v0.x + v1.x) + v2.x, vi = (v0.y + v1.y) + v2.y;
+  // after the barrier: the border of the product, one element per lane (own slot entries only; the corners of L and R
+  // were read before the barrier, so nothing here races with the image / slot writes of the phase that follows)
+  auto finalize = [&](int sr, int si, int sd) {
+    if (tid < BS) {
+      double vr, vi;
+      cplx f;  // the k = DM-1 factor of the other operand
+      if (tid < DM || tid == BS - 1) {
+        const int j = tid < DM ? tid : DM - 1;
+        const cplx v0 = rpart[j], v1 = rpart[DMP + j], v2 = rpart[2 * DMP + j], v3 = rpart[3 * DMP + j];
+        vr = (v0.x + v1.x) + (v2.x + v3.x), vi = (v0.y + v1.y) + (v2.y + v3.y);
+        f = brd[sr * BS + tid];
+        vr = fma(cornerA.x, f.x, fma(-cornerA.y, f.y, vr));
+        vi = fma(cornerA.x, f.y, fma(cornerA.y, f.x, vi));
+      } else {
+        const int i = tid - DM;
+        const cplx v0 = cpart[i], v1 = cpart[DMP + i], v2 = cpart[2 * DMP + i], v3 = cpart[3 * DMP + i];
+        vr = (v0.x + v1.x) + (v2.x + v3.x), vi = (v0.y + v1.y) + (v2.y + v3.y);
+        f = img[i * LD + DM - 1];
+        vr = fma(f.x, cornerR.x, fma(-f.y, cornerR.y, vr));
+        vi = fma(f.x, cornerR.y, fma(f.y, cornerR.x, vi));
+      }
       if (si >= 0) {
         const cplx ini = brd[si * BS + tid];
         vr += ini.x;
@@ -299,15 +411,25 @@ __global__ void __launch_bounds__(RG_THREADS, 1) regd_chain_kernel(MidArgs A, cp
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) rg_st(dst + (Ig * NJ + jj) * RG_THREADS, voff, cmake(aP[Ig][jj], aR[Ig][jj]));
   };
+  // all loads of a tile set are issued before the first use (the scheduler otherwise serialises load -> use -> load
+  // to save registers: 25 dependent memory round trips)
+  auto load_set = [&](const cplx* base, cplx (&v)[NRG][NJ]) {
+    const cplx* src = rg_ubase(base);
+#pragma unroll
+    for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) v[Ig][jj] = rg_ld(src + (Ig * NJ + jj) * RG_THREADS, voff);
+    __builtin_amdgcn_sched_barrier(0);
+  };
   auto unpark_R = [&](int set) {
-    const cplx* src = rg_ubase(arena + set * TSET);
+    cplx v[NRG][NJ];
+    load_set(arena + set * TSET, v);
 #pragma unroll
     for (int Ig = 0; Ig < NRG; ++Ig)
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) {
-        const cplx v = rg_ld(src + (Ig * NJ + jj) * RG_THREADS, voff);
-        Rr[Ig][jj] = v.x;
-        Ri[Ig][jj] = v.y;
+        Rr[Ig][jj] = v[Ig][jj].x;
+        Ri[Ig][jj] = v[Ig][jj].y;
       }
   };
   auto park_R = [&](int set) {
@@ -377,19 +499,30 @@ __global__ void __launch_bounds__(RG_THREADS, 1) regd_chain_kernel(MidArgs A, cp
         sg[e] = (t + tt < len) ? A.signals[((long)sample * K + k) * A.N + n0 + t + tt] : 0.0;
       }
     };
-    // X = 2^-s (G0 + sum_k c_k G_k): tiles -> (Rr, Ri), borders -> slot M0, everything -> image
+    // tiles of X = 2^-s (G0 + sum_k c_k G_k) for slice tt of the staged chunk (tables: L2 resident, shared by all workgroups)
+    auto assemble_tiles = [&](int tt, double (&xr)[NRG][NJ], double (&xi)[NRG][NJ]) {
+      auto table = [&](int k1) -> const cplx* { return reinterpret_cast<const cplx*>(tabs + (long)k1 * G::TAB_D); };
+      auto accumulate = [&](const cplx (&v)[NRG][NJ], int k1) {
+        const double w = k1 ? scale * sg[(k1 - 1) * RG_CH + tt] : scale;
+#pragma unroll
+        for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) {
+            xr[Ig][jj] = k1 ? fma(w, v[Ig][jj].x, xr[Ig][jj]) : w * v[Ig][jj].x;
+            xi[Ig][jj] = k1 ? fma(w, v[Ig][jj].y, xi[Ig][jj]) : w * v[Ig][jj].y;
+          }
+      };
+      for (int k1 = 0; k1 <= K; ++k1) {
+        cplx v[NRG][NJ];
+        load_set(table(k1), v);
+        accumulate(v, k1);
+      }
+    };
+    // X: tiles -> (Rr, Ri), borders -> slot M0, everything -> image; trace shift of the slice -> (mu_r, mu_i)
     auto assemble = [&](int tt) {
-      const cplx* T0 = rg_ubase(reinterpret_cast<const cplx*>(tabs));
+      const cplx* T0 = reinterpret_cast<const cplx*>(tabs);
       mu_r = meta(0)[0];
       mu_i = meta(0)[1];
-#pragma unroll
-      for (int Ig = 0; Ig < NRG; ++Ig)
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) {
-          const cplx v = rg_ld(T0 + (Ig * NJ + jj) * RG_THREADS, voff);
-          Rr[Ig][jj] = scale * v.x;
-          Ri[Ig][jj] = scale * v.y;
-        }
       cplx bv = cmake(0.0, 0.0);
       if (tid < BS) {
         bv = T0[TSET + tid];
@@ -397,19 +530,11 @@ __global__ void __launch_bounds__(RG_THREADS, 1) regd_chain_kernel(MidArgs A, cp
         bv.y *= scale;
       }
       for (int k = 0; k < K; ++k) {
-        const cplx* Tk = rg_ubase(reinterpret_cast<const cplx*>(tabs + (long)(k + 1) * G::TAB_D));
+        const cplx* Tk = reinterpret_cast<const cplx*>(tabs + (long)(k + 1) * G::TAB_D);
         const double c = sg[k * RG_CH + tt];
         const double w = scale * c;
         mu_r = fma(c, meta(k + 1)[0], mu_r);
         mu_i = fma(c, meta(k + 1)[1], mu_i);
-#pragma unroll
-        for (int Ig = 0; Ig < NRG; ++Ig)
-#pragma unroll
-          for (int jj = 0; jj < NJ; ++jj) {
-            const cplx v = rg_ld(Tk + (Ig * NJ + jj) * RG_THREADS, voff);
-            Rr[Ig][jj] = fma(w, v.x, Rr[Ig][jj]);
-            Ri[Ig][jj] = fma(w, v.y, Ri[Ig][jj]);
-          }
         if (tid < BS) {
           const cplx v = Tk[TSET + tid];
           bv.x = fma(w, v.x, bv.x);
@@ -420,6 +545,7 @@ __global__ void __launch_bounds__(RG_THREADS, 1) regd_chain_kernel(MidArgs A, cp
         brd[S_M0 * BS + tid] = bv;
         border_to_image(bv);
       }
+      assemble_tiles(tt, Rr, Ri);
 #pragma unroll
       for (int Ig = 0; Ig < NRG; ++Ig)
 #pragma unroll
@@ -436,45 +562,45 @@ __global__ void __launch_bounds__(RG_THREADS, 1) regd_chain_kernel(MidArgs A, cp
     zero_acc();
     int op = OP_P1, sr = S_M0, si = -1, sd = S_M1, sq_left = 0;
     __syncthreads();
+#ifdef C3P_REGD_TIMING
+    tq = clock64();
+#endif
     for (;;) {
       refresh();
       product(sr, si, sd);
-      __syncthreads();  // A: everyone is done with the image; border partials are visible
+      RG_TICK(1)
+      rg_bar();  // A: everyone is done with the image; border partials are visible
+      RG_TICK(2)
       refresh();
-      finalize(si, sd);
+      finalize(sr, si, sd);
+      const int op_in = op;
       bool next_slice = false;
-      if (op == OP_P1) {  // C = A2: it becomes the right operand (the image still holds X)
+      if (op == OP_P1) {  // C = A2: parked, and the right operand of the next product (the image still holds X)
+        park_C(AR_A2);
         R_from_C();
         zero_acc();
         op = OP_P2, sr = S_M1, si = -1, sd = S_M2;
-      } else if (op == OP_P2) {  // C = A3 = X A2: park A2, A3 becomes both operands
-        park_R(AR_A2);
+      } else if (op == OP_P2) {  // C = A3 = X A2: A3 becomes both operands
         image_from_C();
         if (tid < BS) border_to_image(brd[S_M2 * BS + tid]);
         R_from_C();
         zero_acc();
         op = OP_P3, sr = S_M2, si = -1, sd = S_M3;
-      } else if (op == OP_P3) {  // C = A6: the T18 combinations of X, A2 (arena), A3 (R), A6 (C)
+      } else if (op == OP_P3) {  // C = A6: the T18 combinations of X, A2 (arena), A3 (image), A6 (C)
         {
-          const cplx* srcx = rg_ubase(arena + AR_X * TSET);
-          const cplx* src = rg_ubase(arena + AR_A2 * TSET);
           cplx* dst = rg_ubase(arena + AR_B2 * TSET);
           cplx* dst3 = rg_ubase(arena + AR_B3 * TSET);
           cplx a2[NRG][NJ], xx[NRG][NJ];
-#pragma unroll
-          for (int Ig = 0; Ig < NRG; ++Ig)
-#pragma unroll
-            for (int jj = 0; jj < NJ; ++jj) {
-              xx[Ig][jj] = rg_ld(srcx + (Ig * NJ + jj) * RG_THREADS, voff);
-              a2[Ig][jj] = rg_ld(src + (Ig * NJ + jj) * RG_THREADS, voff);
-            }
+          load_set(arena + AR_X * TSET, xx);
+          load_set(arena + AR_A2 * TSET, a2);
 #pragma unroll
           for (int Ig = 0; Ig < NRG; ++Ig)
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) {
               const double dg = (16 * Ig + rowC == col0 + 4 * jj + p) ? 1.0 : 0.0;
               const double xr = xx[Ig][jj].x, xi = xx[Ig][jj].y, a2r = a2[Ig][jj].x, a2i = a2[Ig][jj].y;
-              const double a3r = Rr[Ig][jj], a3i = Ri[Ig][jj], a6r = aP[Ig][jj], a6i = aR[Ig][jj];
+              const cplx a3 = img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p];  // the left operand of A6 = A3 A3
+              const double a3r = a3.x, a3i = a3.y, a6r = aP[Ig][jj], a6i = aR[Ig][jj];
               // B1 -> image (left operand of A9 = B1 B5 + B4)
               img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p] =
                   cmake(fma(C3P_T18_A31, a3r, fma(C3P_T18_A21, a2r, C3P_T18_A11 * xr)),
@@ -515,30 +641,26 @@ __global__ void __launch_bounds__(RG_THREADS, 1) regd_chain_kernel(MidArgs A, cp
         op = OP_P4, sr = S_M1, si = S_M2, sd = S_R0;
       } else if (op == OP_P4) {  // C = A9: left operand B3 + A9, right operand A9, initial value B2
         {
-          const cplx* src3 = rg_ubase(arena + AR_B3 * TSET);
+          cplx v3[NRG][NJ], v2[NRG][NJ];
+          load_set(arena + AR_B3 * TSET, v3);
+          load_set(arena + AR_B2 * TSET, v2);
+#pragma unroll
+          for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+              img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p] = cmake(v3[Ig][jj].x + aP[Ig][jj], v3[Ig][jj].y + aR[Ig][jj]);
+          if (tid < BS) {
+            const cplx b3 = brd[S_M0 * BS + tid], a9 = brd[S_R0 * BS + tid];
+            border_to_image(cmake(b3.x + a9.x, b3.y + a9.y));
+          }
+          R_from_C();
 #pragma unroll
           for (int Ig = 0; Ig < NRG; ++Ig)
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) {
-              const cplx v = rg_ld(src3 + (Ig * NJ + jj) * RG_THREADS, voff);
-              img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p] = cmake(v.x + aP[Ig][jj], v.y + aR[Ig][jj]);
-            }
-        }
-        if (tid < BS) {
-          const cplx b3 = brd[S_M0 * BS + tid], a9 = brd[S_R0 * BS + tid];
-          border_to_image(cmake(b3.x + a9.x, b3.y + a9.y));
-        }
-        R_from_C();
-        {
-          const cplx* src = rg_ubase(arena + AR_B2 * TSET);
-#pragma unroll
-          for (int Ig = 0; Ig < NRG; ++Ig)
-#pragma unroll
-            for (int jj = 0; jj < NJ; ++jj) {
-              const cplx v = rg_ld(src + (Ig * NJ + jj) * RG_THREADS, voff);
-              aP[Ig][jj] = v.x;
+              aP[Ig][jj] = v2[Ig][jj].x;
               aQ[Ig][jj] = 0.0;
-              aR[Ig][jj] = v.x + v.y;
+              aR[Ig][jj] = v2[Ig][jj].x + v2[Ig][jj].y;
             }
         }
         op = OP_EX, sr = S_R0, si = S_M3, sd = S_R1, sq_left = ps;
@@ -591,8 +713,14 @@ __global__ void __launch_bounds__(RG_THREADS, 1) regd_chain_kernel(MidArgs A, cp
         zero_acc();
         op = OP_P1, sr = S_M0, si = -1, sd = S_M1;
       }
-      __syncthreads();  // B: image, border slots and arena writes of this phase are visible
+      RG_TICK(4 + op_in)
+      rg_bar();  // B: image and border slots of this phase are visible
+      RG_TICK(3)
     }
+#ifdef C3P_REGD_TIMING
+    if (blockIdx.x == 0 && tid == 0 && dbg)
+      for (int i = 0; i < 12; ++i) dbg[i] = tacc[i];
+#endif
     // segment product (the frame-rotation row phases are a separate epilogue)
     double sn, cs;
     sincos(mus_i, &sn, &cs);
@@ -712,7 +840,22 @@ hipError_t launch_r(const MidArgs& A, void* arena, hipStream_t st) {
   auto go = [&](auto kern) -> hipError_t {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(RG_THREADS), lds, st, A, reinterpret_cast<cplx*>(arena));
+    long long* dbg = nullptr;
+#ifdef C3P_REGD_TIMING
+    static long long* dbg_dev = nullptr;
+    if (!dbg_dev) (void)hipMalloc(&dbg_dev, 12 * sizeof(long long));
+    dbg = dbg_dev;
+#endif
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(RG_THREADS), lds, st, A, reinterpret_cast<cplx*>(arena), dbg);
+#ifdef C3P_REGD_TIMING
+    {
+      long long h[12];
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[regd timing, cycles of wave 0 / block 0, last chain] mfma %lld  borders %lld  barA %lld  barB %lld | post P1 %lld P2 %lld P3 %lld P4 %lld EX %lld CH %lld | product entry %lld\n",
+              h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10]);
+    }
+#endif
     return hipGetLastError();
   };
   if (A.dUs_out) return go(regd_chain_kernel<NRG, true>);

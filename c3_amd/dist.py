@@ -136,3 +136,73 @@ def robust_goal_sharded(goal_and_grad: Callable, B: int, *, group=None):
     mean = part[0] / B
     var = torch.clamp(part[1] / B - mean * mean, min=0.0)
     return {"goal": mean, "goal_std": torch.sqrt(var), "grad": (part[2:] / B).reshape(tuple(grads.shape[1:])), "bounds": (lo, hi)}
+
+
+class SlabRing:
+    """The exchange schedule of `bench.py --gpus N`: every rank computes its slab of a step into one of G
+    buffers; after G steps (or at `drain()`) ONE all-gather moves the G slabs of every rank (fewer, larger
+    collectives: an xGMI all-gather of a single 0.3 MB slab is latency-bound against a 0.15 ms batch).
+
+    `compute(out)` fills `out` [b_pad, ...] (rows past the rank's own `b_local` samples are padding so that uneven
+    shards -- strong scaling of a batch that does not divide by the world size -- use one equal-size collective).
+    Works on any backend / device (RCCL on the GPU box, gloo on CPU in tests/test_dist_gloo.py).
+    """
+
+    def __init__(self, b_local: int, b_pad: int, tail: tuple, G: int, *, dtype=None, device=None, group=None, use_dist=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.use_dist = (dist.is_available() and dist.is_initialized()) if use_dist is None else use_dist
+        self.world = dist.get_world_size(group) if self.use_dist else 1
+        self.rank = dist.get_rank(group) if self.use_dist else 0
+        self.b_local, self.b_pad, self.G = int(b_local), int(b_pad), max(1, int(G))
+        if self.b_local > self.b_pad:
+            raise ValueError("b_local exceeds the padded slab")
+        dtype = torch.complex128 if dtype is None else dtype
+        self.buf = torch.zeros((self.G, self.b_pad) + tuple(tail), dtype=dtype, device=device)
+        self.slab = int(np.prod((self.b_pad,) + tuple(tail)))
+        self.gathered = torch.empty((self.world * self.G * self.slab,), dtype=dtype, device=device) if self.use_dist else None
+        self.counter = 0
+        self.pending = 0
+        self.last_flushed = 0  # slabs moved by the most recent collective
+        self.collectives = 0
+
+    def _real(self, t):
+        return self.torch.view_as_real(t) if t.is_complex() else t
+
+    def flush(self):
+        g = self.pending
+        if self.use_dist and g > 0:
+            n = g * self.slab
+            self.dist.all_gather_into_tensor(self._real(self.gathered[: self.world * n]), self._real(self.buf[:g].reshape(-1)), group=self.group)
+            self.collectives += 1
+            self.last_flushed = g
+        self.pending = 0
+
+    def step(self, compute):
+        out = self.buf[self.counter % self.G]
+        self.counter += 1
+        res = compute(out)
+        self.pending += 1
+        if self.pending == self.G:
+            self.flush()
+        return out if res is None else res
+
+    def drain(self):
+        self.flush()
+        self.counter = 0
+
+    def warm(self, sizes):
+        """Run every message size in `sizes` once (communicator set-up before anything is timed)."""
+        if not self.use_dist:
+            return
+        for g in sorted({int(s) for s in sizes if 0 < int(s) <= self.G}):
+            self.pending = g
+            self.flush()
+
+    def gathered_slab(self, r: int, i: int):
+        """Slab i (of the most recent collective) as sent by rank r: [b_pad, ...]."""
+        g = self.last_flushed
+        flat = self.gathered[r * g * self.slab : (r + 1) * g * self.slab]
+        return flat.reshape((g,) + tuple(self.buf.shape[1:]))[i]

@@ -557,8 +557,15 @@ def ode_solve_batch(h0, hks, signals, dt, init_state, solver="rk4", step_functio
     h0 = call.c128(h0)
     hks = call.c128(hks)
     sig = call.f64(signals)
+    if sig.ndim != 3:
+        raise C3PropError(f"C3:Error: signals must be [B,K,N], got {tuple(sig.shape)}")
     B, K, N = (int(s) for s in sig.shape)
     D = int(h0.shape[-1])
+    # c3p_ode_solve takes ONE set of operators for the whole batch (no per-sample strides in the ABI)
+    if h0.ndim != 2 or tuple(h0.shape) != (D, D):
+        raise C3PropError(f"C3:Error: ode solvers take one drift Hamiltonian [D,D], got {tuple(h0.shape)}")
+    if hks.ndim != 3 or tuple(hks.shape) != (K, D, D):
+        raise C3PropError(f"C3:Error: {K} signal channels need control Hamiltonians [{K},{D},{D}], got {tuple(hks.shape)}")
     M = 1 if step_function == "schrodinger" else D
     init = call.c128(init_state)
     if tuple(init.shape[-2:]) != (D, M):

@@ -296,11 +296,12 @@ _T1 = (27e-6, 23e-6, 25e-6)
 _T2S = (39e-6, 31e-6, 35e-6)
 
 CONFIGS = {
-    1: dict(name="cfg1 X90 D=3 N=200", dims=(3,), N=200, B=1, lindblad=False),
-    2: dict(name="cfg2 CR D=9 N=1000 B=256", dims=(3, 3), N=1000, B=256, lindblad=False),
-    3: dict(name="cfg3 coupler D=27 N=2000 B=4096", dims=(3, 3, 3), N=2000, B=4096, lindblad=False),
-    4: dict(name="cfg4 Lindblad D=9 (81x81) N=1000 B=512", dims=(3, 3), N=1000, B=512, lindblad=True),
-    5: dict(name="cfg5 3 qubits D=36 N=5000 B=8192", dims=(3, 3, 4), N=5000, B=8192, lindblad=False),
+    # `gpus` = the number of GPUs BASELINE.json quotes the batch on (cfg3 / cfg5: B sharded over 8 GPUs)
+    1: dict(name="cfg1 X90 D=3", dims=(3,), N=200, B=1, gpus=1, lindblad=False),
+    2: dict(name="cfg2 CR D=9", dims=(3, 3), N=1000, B=256, gpus=1, lindblad=False),
+    3: dict(name="cfg3 coupler D=27", dims=(3, 3, 3), N=2000, B=4096, gpus=8, lindblad=False),
+    4: dict(name="cfg4 Lindblad D=9 (81x81)", dims=(3, 3), N=1000, B=512, gpus=1, lindblad=True),
+    5: dict(name="cfg5 3 qubits D=36", dims=(3, 3, 4), N=5000, B=8192, gpus=8, lindblad=False),
 }
 
 
@@ -363,7 +364,7 @@ def make_workload(cfg: int, B: Optional[int] = None, N: Optional[int] = None, se
     if c["lindblad"]:
         col = np.stack([dress(qubit_collapse_op(a[q], _T1[q], _T2S[q]), T) for q in range(nq)])
     return Workload(
-        name=c["name"],
+        name=f"{c['name']} N={N} B={B}",  # the sizes actually built (B = this rank's samples)
         dims=tuple(dims),
         D=h0.shape[0],
         K=nq,

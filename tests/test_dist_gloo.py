@@ -83,3 +83,75 @@ def test_robust_goal_all_reduce(tmp_path, B):
     for r in range(world):
         got = np.load(tmp_path / f"g_rank{r}.npy")
         assert np.abs(got - want).max() < 1e-12
+
+
+# --------------------------------------------------------------------------
+# bench.py's multi-GPU schedule (plan_batch + SlabRing: step / flush / drain) with an injected compute
+# --------------------------------------------------------------------------
+
+
+def _ring_worker(rank, world, port, B_glob, G, steps, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+
+        cfg = dict(B=B_glob, gpus=world)
+        Bg, lo, hi, b_pad = bench.plan_batch(cfg, "strong", None, world, rank)
+        assert (lo, hi) == c3dist.shard_bounds(B_glob, world, rank) and Bg == B_glob and b_pad == c3dist.max_shard(B_glob, world)
+        B = hi - lo
+        ring = c3dist.SlabRing(B, b_pad, (2, 2), G, use_dist=True)
+        ring.warm({min(G, steps), steps % G})
+        calls = [0]
+
+        def compute(out):
+            # sample b of step k on this rank: a recognisable value in every element
+            k = calls[0]
+            calls[0] += 1
+            for b in range(B):
+                out[b] = complex(1000 * (lo + b) + k, -k)
+
+        for _ in range(steps):
+            ring.step(compute)
+        ring.drain()
+        assert ring.counter == 0 and ring.pending == 0
+        # collectives: the warm-up sizes + ceil(steps / G)
+        g_last = steps % G or G
+        assert ring.last_flushed == g_last
+        got = np.stack([np.stack([ring.gathered_slab(r, i).numpy() for i in range(g_last)]) for r in range(world)])
+        np.save(os.path.join(out_dir, f"ring_rank{rank}.npy"), got)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B_glob,G,steps", [(5, 3, 7), (4, 2, 4)])
+def test_bench_slab_ring_two_ranks(tmp_path, B_glob, G, steps):
+    world = 2
+    port = _free_port()
+    mp.spawn(_ring_worker, args=(world, port, B_glob, G, steps, str(tmp_path)), nprocs=world, join=True)
+    g_last = steps % G or G
+    first = steps - g_last  # step index of slab 0 of the last collective
+    b_pad = c3dist.max_shard(B_glob, world)
+    outs = [np.load(tmp_path / f"ring_rank{r}.npy") for r in range(world)]
+    assert np.array_equal(outs[0], outs[1])  # every rank holds every rank's slabs
+    for r in range(world):
+        lo, hi = c3dist.shard_bounds(B_glob, world, r)
+        for i in range(g_last):
+            for b in range(hi - lo):
+                assert np.all(outs[0][r, i, b] == complex(1000 * (lo + b) + first + i, -(first + i)))
+            assert outs[0].shape[2] == b_pad
+
+
+def test_bench_plan_batch_defaults():
+    import bench
+
+    C = workloads.CONFIGS
+    # weak: BASELINE's batch divided by the GPUs it is quoted on; strong: the whole batch, sharded
+    assert bench.plan_batch(C[2], "weak", None, 1, 0) == (256, 0, 256, 256)
+    assert bench.plan_batch(C[4], "weak", None, 1, 0) == (512, 0, 512, 512)
+    assert bench.plan_batch(C[3], "weak", None, 8, 3) == (4096, 3 * 512, 4 * 512, 512)
+    assert bench.plan_batch(C[5], "weak", None, 2, 1) == (2048, 1024, 2048, 1024)
+    assert bench.plan_batch(C[3], "strong", None, 8, 7) == (4096, 7 * 512, 4096, 512)
+    assert bench.plan_batch(C[5], "strong", 10, 4, 3) == (10, 8, 10, 3)
+    assert bench.plan_batch(C[2], "weak", 64, 4, 2) == (256, 128, 192, 64)

@@ -1,0 +1,323 @@
+"""Round-2 GPU parity tests (through the C ABI): the register-resident kernel of c3p_regd.hip, the remaining
+entry points of SURVEY 8a rows a10 / a15, the reference's fidelity known answers and ODE invariants, and wider
+full-size spot parity."""
+import os
+
+import numpy as np
+import pytest
+
+from c3_amd import workloads
+from oracle import c3_oracle as o
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def prop(lib):
+    from c3_amd import _lib, propagation
+
+    _lib.require_gpu()
+    return propagation
+
+
+def fro_max(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return max(np.linalg.norm(a[i] - b[i]) for i in range(a.shape[0]))
+
+
+def _rand_herm(rng, D, scale):
+    a = rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))
+    return scale * (a + a.conj().T) / 2
+
+
+# --------------------------------------------------------------------------
+# c3p_regd.hip: Dm = 49, 65, 81
+# --------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("B,N", [(1, 1), (2, 2), (3, 5), (2, 41), (5, 70), (300, 9)])
+def test_regd_lindblad_81_vs_oracle(prop, B, N):
+    """propagation.py:551-585 at cfg4's operators: one slice, first-slice / chain paths, several time segments
+    (B < 256), more chains than workgroups (B = 300)."""
+    from c3_amd import _lib
+
+    wl = workloads.make_workload(4, B=B, N=N)
+    ph = np.stack([(p[:, None] - p[None, :]).ravel() for p in wl.fr_phase])
+    r = prop.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt, col_ops=wl.col_ops, lindbladian=True, fr_phase=ph)
+    assert _lib.last_kernel() == "mfma"
+    ref = o.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt, col_ops=wl.col_ops, lindbladian=True, fr_phase=wl.fr_phase)
+    assert fro_max(r["U"], ref) < TOL
+
+
+def test_regd_lindblad_partials_and_old_kernel(prop):
+    """dUs of the new kernel vs the oracle's per-slice superoperators, and U vs the arena kernel it replaces."""
+    wl = workloads.make_workload(4, B=2, N=6)
+    r = prop.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt, col_ops=wl.col_ops, lindbladian=True, want_dUs=True)
+    d = o.tf_propagation_lind(wl.h0, wl.hks, wl.col_ops, wl.signals[1], wl.dt)
+    assert np.abs(np.asarray(r["dUs"][1]) - d).max() < 1e-13
+    os.environ["C3P_NO_REGD"] = "1"
+    try:
+        old = prop.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt, col_ops=wl.col_ops, lindbladian=True)
+    finally:
+        os.environ.pop("C3P_NO_REGD")
+    assert fro_max(r["U"], old["U"]) < 1e-12
+
+
+def test_regd_lindblad_49(prop):
+    """D = 7 -> 49 x 49 superoperators (n = 3 instance): a 7-level system with one collapse operator."""
+    rng = np.random.default_rng(11)
+    D, B, N, K = 7, 3, 21, 2
+    h0 = _rand_herm(rng, D, 0.05)
+    hks = np.stack([_rand_herm(rng, D, 0.02) for _ in range(K)])
+    col = np.stack([0.03 * (rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))) for _ in range(2)])
+    sig = rng.uniform(-1, 1, size=(B, K, N))
+    r = prop.propagate_batch(h0, hks, sig, 1.0, col_ops=col, lindbladian=True, want_dUs=True)
+    ref = o.propagate_batch(h0, hks, sig, 1.0, col_ops=col, lindbladian=True)
+    assert fro_max(r["U"], ref) < TOL
+    assert np.abs(np.asarray(r["dUs"][0]) - o.tf_propagation_lind(h0, hks, col, sig[0], 1.0)).max() < 1e-13
+
+
+@pytest.mark.parametrize("D", [49, 65, 81])
+@pytest.mark.parametrize("scale", [0.02, 0.2])
+def test_regd_unitary_dimensions(prop, D, scale):
+    """Unitary mode of the same kernel, complex Hermitian operators, norms with 0 .. 3 squarings, per-sample operators."""
+    rng = np.random.default_rng(D)
+    B, N, K = 3, 17, 2
+    h0 = np.stack([_rand_herm(rng, D, scale) for _ in range(B)])  # per-sample drift
+    hks = np.stack([_rand_herm(rng, D, scale / 2) for _ in range(K)])
+    sig = rng.uniform(-1, 1, size=(B, K, N))
+    r = prop.propagate_batch(h0, hks, sig, 1.0, want_dUs=True)
+    for b in range(B):
+        ref = o.pwc_arrays(h0[b], hks, sig[b], 1.0)
+        assert np.linalg.norm(np.asarray(r["U"][b]) - ref["U"]) < TOL
+        assert np.abs(np.asarray(r["dUs"][b]) - ref["dUs"]).max() < 1e-12
+    U = np.asarray(r["U"])
+    assert np.abs(U @ U.conj().transpose(0, 2, 1) - np.eye(D)).max() < 1e-11
+
+
+def test_regd_full_size_cfg4_properties(prop):
+    """BASELINE cfg4 at full size (B = 512, N = 1000): trace preservation of every superoperator, split / repeat
+    invariance, spot parity on 4 samples."""
+    import torch
+
+    wl = workloads.make_workload(4)
+    assert wl.B == 512 and wl.N == 1000
+    dev = "cuda:0"
+    a = [torch.as_tensor(x, device=dev) for x in (wl.h0, wl.hks, wl.signals, wl.col_ops)]
+    U = prop.propagate_batch(a[0], a[1], a[2], wl.dt, col_ops=a[3], lindbladian=True)["U"]
+    Uh = U.cpu().numpy()
+    D = wl.D
+    # trace preservation: vec(I)^T S = vec(I)^T for a trace-preserving map in the row-major vec convention
+    vI = np.eye(D).ravel()
+    assert np.abs(np.einsum("i,bij->bj", vI, Uh) - vI).max() < 1e-10
+    again = prop.propagate_batch(a[0], a[1], a[2], wl.dt, col_ops=a[3], lindbladian=True)["U"].cpu().numpy()
+    assert np.array_equal(again, Uh)
+    idx = [0, 171, 340, 511]
+    ref = o.propagate_batch(wl.h0, wl.hks, wl.signals[idx], wl.dt, col_ops=wl.col_ops, lindbladian=True)
+    assert fro_max(Uh[idx], ref) < TOL
+    # time split: U = U2 U1 over the two halves of the slices (8 samples)
+    s = wl.signals[:8]
+    U1 = np.asarray(prop.propagate_batch(wl.h0, wl.hks, s[:, :, :500], wl.dt, col_ops=wl.col_ops, lindbladian=True)["U"])
+    U2 = np.asarray(prop.propagate_batch(wl.h0, wl.hks, s[:, :, 500:], wl.dt, col_ops=wl.col_ops, lindbladian=True)["U"])
+    assert fro_max(U2 @ U1, Uh[:8]) < 1e-11
+
+
+# --------------------------------------------------------------------------
+# the legacy / variant entry points, on the device
+# --------------------------------------------------------------------------
+
+
+def test_a15_single_slice_and_legacy_loop(prop):
+    """tf_dU_of_t (propagation.py:349-379), tf_dU_of_t_lind (:382-423), tf_propagation (:518-548)."""
+    wl = workloads.make_workload(2, B=1, N=12)
+    c = wl.signals[0][:, 3]
+    got = prop.tf_dU_of_t(wl.h0, wl.hks, c, wl.dt)
+    assert np.abs(np.asarray(got) - o.tf_dU_of_t(wl.h0, wl.hks, c, wl.dt)).max() < 1e-13
+    wl4 = workloads.make_workload(4, B=1, N=4)
+    c4 = wl4.signals[0][:, 1]
+    gotl = prop.tf_dU_of_t_lind(wl4.h0, wl4.hks, wl4.col_ops, c4, wl4.dt)
+    assert np.abs(np.asarray(gotl) - o.tf_dU_of_t_lind(wl4.h0, wl4.hks, wl4.col_ops, c4, wl4.dt)).max() < 1e-13
+    lst = prop.tf_propagation(wl.h0, wl.hks, wl.signals[0], wl.dt)
+    ref = o.tf_propagation(wl.h0, wl.hks, wl.signals[0], wl.dt)
+    assert isinstance(lst, list) and len(lst) == len(ref) == 12
+    assert max(np.abs(np.asarray(a) - b).max() for a, b in zip(lst, ref)) < 1e-13
+    assert "tf_propagation" in prop.unitary_provider
+
+
+def test_a15_pwc_trott_drift(prop):
+    """propagation.py:443-457: dU0 expm(-i Ht dt) (dU0 + [H0,Ht] dt^2 / 2) with the reference's eigh / v.T form."""
+    wl = workloads.make_workload(2, B=1, N=4)
+    c = wl.signals[0][:, 2].reshape(-1, 1, 1)
+    got = np.asarray(prop.pwc_trott_drift(wl.h0, wl.hks, c, wl.dt))
+    ref = o.pwc_trott_drift(wl.h0, wl.hks, c, wl.dt)
+    assert np.abs(got - ref).max() < 1e-12
+
+
+def test_a15_evaluate_sequences(prop):
+    """propagation.py:588-627: left-multiplied gate sequences, the empty sequence, repeated gates."""
+    wl = workloads.make_workload(2, B=3, N=30)
+    U = np.asarray(prop.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt)["U"])
+    gates = {"a": U[0], "b": U[1], "c": U[2]}
+    seqs = [["a"], ["a", "b"], ["c", "a", "b", "a"], [], ["b"] * 7]
+    got = prop.evaluate_sequences(gates, seqs)
+    ref = o.evaluate_sequences(gates, seqs)
+    assert len(got) == len(ref)
+    for g, r in zip(got, ref):
+        assert np.abs(np.asarray(g) - np.asarray(r)).max() < 1e-12
+    assert np.abs(np.asarray(got[1]) - U[1] @ U[0]).max() < 1e-12  # later gate on the left
+
+
+# --------------------------------------------------------------------------
+# dephasing channel, positive path (experiment.py:510-522, model.py:597-639)
+# --------------------------------------------------------------------------
+
+
+class _Awg:
+    def __init__(self, amp):
+        self.amp = amp
+
+    def get_average_amp(self):
+        return self.amp, self.amp * 10
+
+
+class _PMap:
+    def __init__(self, model, generator, instructions):
+        self.model, self.generator, self.instructions = model, generator, instructions
+
+
+def test_dephasing_channel_positive_path(prop):
+    from c3_amd.experiment import Experiment
+
+    N = 40
+    T = N * 1e-11
+    m = workloads.ChipModel((3, 3), (5e9, 5.6e9), (-210e6, -240e6), {(0, 1): 20e6}, {"d1": 0, "d2": 1}, t1=(27e-6, 23e-6), t2star=(39e-6, 31e-6))
+    m.set_lindbladian(True)
+    m.set_FR(True)
+    wl = workloads.make_workload(2, B=1, N=N)
+    ts = (np.arange(N) + 0.5) * 1e-11
+    sig = {"g": {"d1": {"values": wl.signals[0, 0], "ts": ts}, "d2": {"values": wl.signals[0, 1], "ts": ts}}}
+    gen = workloads.SignalSource(sig)
+    gen.devices = {"awg": _Awg(0.37)}
+    g = workloads.Gate("g", 0.0, T, ["d1", "d2"], carrier_freqs={"d1": 2 * np.pi * 5.05e9, "d2": 2 * np.pi * 5.65e9}, framechanges={"d1": 0.3, "d2": -0.2})
+    exp = Experiment(_PMap(m, gen, {"g": g}), sim_res=100e9)
+    plain = exp.compute_propagators()["g"]
+    m.dephasing_strength = 1.1e9  # p = T * amp * strength = 0.16 per line
+    out = exp.compute_propagators()["g"]
+    assert out.shape == (81, 81) and np.linalg.norm(out - plain) > 1e-3
+    # independent restatement: oracle pwc + frame rotation + the oracle's dephasing channel
+    ref = o.pwc(m, gen, g, None, None)["U"]
+    ph = np.exp(1j * m.frame_rotation_phases(T, g.carrier_freqs, g.framechanges))
+    ref = np.kron(ph, ph.conj())[:, None] * ref
+    nums = [m.number_operator("d1"), m.number_operator("d2")]
+    ch = o.dephasing_channel(nums, [0.37, 0.37], T, 1.1e9, 9)
+    assert np.linalg.norm(out - ch @ ref) < TOL
+    m.dephasing_strength = 1e12  # p > 1 -> the reference's ValueError (model.py:631-636)
+    with pytest.raises(ValueError, match="outside"):
+        exp.compute_propagators()
+
+
+def test_experiment_batch_with_excitation_cut(prop):
+    """compute_propagators_batch returns full-dimension propagators when max_excitations is set, like pwc."""
+    from c3_amd.experiment import Experiment
+
+    N = 32
+    T = N * 1e-11
+    m = workloads.ChipModel((3, 3), (5e9, 5.6e9), (-210e6, -240e6), {(0, 1): 20e6}, {"d1": 0, "d2": 1})
+    m.set_max_excitations(2)
+    m.set_FR(True)
+    wl = workloads.make_workload(2, B=4, N=N)
+    ts = (np.arange(N) + 0.5) * 1e-11
+    gen = workloads.SignalSource({"g": {"d1": {"values": wl.signals[0, 0], "ts": ts}, "d2": {"values": wl.signals[0, 1], "ts": ts}}})
+    g = workloads.Gate("g", 0.0, T, ["d1", "d2"], carrier_freqs={"d1": 2 * np.pi * 5.05e9, "d2": 2 * np.pi * 5.65e9}, framechanges={"d1": 0.1, "d2": 0.2})
+    exp = Experiment(_PMap(m, gen, {"g": g}), sim_res=100e9)
+    U = exp.compute_propagators_batch("g", wl.signals)
+    assert U.shape == (4, 9, 9)
+    one = exp.compute_propagators()["g"]  # serial route: pwc blows up, the adapter applies FR on the full space
+    assert np.linalg.norm(U[0] - one) < TOL
+
+
+# --------------------------------------------------------------------------
+# Fidelity known answers held by the reference (test/test_fidelities.py:23-140) on c3p_gate_overlap
+# --------------------------------------------------------------------------
+
+X = np.array([[0, -1j], [-1j, 0]], dtype=np.complex128)  # GATES["rxp"] (c3/libraries/constants.py:54)
+Y = np.array([[0, -1], [1, 0]], dtype=np.complex128)     # GATES["ryp"] (:57)
+Id = np.eye(2, dtype=np.complex128)
+_LEAK0 = np.array([[0 + 0j, 1, 0], [1, 0, 0], [0, 0, 0]])
+_LEAK = np.array([[0 + 0j, 1, 0], [1, 0, 0], [0, 0, 34345j]])
+
+
+def test_reference_fidelity_known_answers(prop):
+    from c3_amd import fidelities as F
+
+    assert abs(F.unitary_infid(X, X, dims=[2])) < 1e-12                                        # test_unitary_infid_1
+    assert F.unitary_infid(X, Y, dims=[2]) == 1                                               # _2 (exact in the reference)
+    XI = np.kron(X, Id)
+    assert abs(F.unitary_infid(XI, XI, index=[0, 1], dims=[2, 2])) < 1e-12                     # _3
+    assert abs(F.unitary_infid(X, XI, index=[0], dims=[2, 2])) < 1e-12                         # projection
+    assert abs(F.unitary_infid(X, np.kron(Id, X), index=[1], dims=[2, 2])) < 1e-12             # projection_2
+    assert abs(F.unitary_infid(ideal=X, actual=_LEAK0, index=[0], dims=[3])) < 1e-12           # projection_3
+    assert abs(F.unitary_infid(ideal=X, actual=_LEAK, index=[0], dims=[3])) < 1e-12            # projection_4
+    assert abs(F.unitary_infid(ideal=X, actual=np.kron(_LEAK, Id), index=[0], dims=[3, 2])) < 1e-12   # projection_5
+    assert abs(F.average_infid(X, X)) < 1e-12                                                  # test_average_infid_1
+    assert abs(F.average_infid(X, Y) - 2.0 / 3) < 1e-12                                        # _2
+    assert abs(F.average_infid(X, XI, index=[0], dims=[2, 2])) < 1e-12
+    assert abs(F.average_infid(X, np.kron(Id, X), index=[1], dims=[2, 2])) < 1e-12
+    assert abs(F.average_infid(ideal=X, actual=_LEAK0, index=[0], dims=[3])) < 1e-12
+    assert abs(F.average_infid(ideal=X, actual=_LEAK, index=[0], dims=[3])) < 1e-12
+    assert abs(F.average_infid(ideal=X, actual=np.kron(_LEAK, Id), index=[0], dims=[3, 2])) < 1e-12
+    # a batch mixes them all in one device call
+    batch = np.stack([np.kron(_LEAK, Id), np.kron(_LEAK0, Id)])
+    assert np.abs(np.asarray(F.unitary_infid(X, batch, index=[0], dims=[3, 2]))).max() < 1e-12
+
+
+# --------------------------------------------------------------------------
+# The reference's ODE invariant checks (test/test_two_qubits.py:228-251) through c3p_ode_solve, on the inputs
+# the reference's own fixture stores (tests/golden/two_qubit.npz)
+# --------------------------------------------------------------------------
+
+
+def test_ode_invariants_on_reference_inputs(prop, golden_dir):
+    g = np.load(golden_dir + "/two_qubit.npz")
+    sig = np.stack([g["sig_d1"], g["sig_d2"]])[None]
+    hks = np.stack([g["hk_d1"], g["hk_d2"]])
+    dt = float(g["ts"][1] - g["ts"][0])
+    psi = np.zeros((4, 1), dtype=np.complex128)
+    psi[0, 0] = 1.0
+    st = np.asarray(prop.ode_solve_batch(g["hdrift"], hks, sig, dt, psi, "rk4", "schrodinger"))[0]
+    assert st.shape == (700, 4, 1)
+    assert abs(np.linalg.norm(st[-1]) - 1) < 0.5e-2                      # decimal=2 in the reference
+    rho = np.asarray(prop.ode_solve_batch(g["hdrift"], hks, sig, dt, psi @ psi.conj().T, "rk4", "von_neumann"))[0]
+    assert abs(np.trace(rho[-1]) - 1) < 0.5e-6                           # decimal=6
+    m = workloads.ChipModel((2, 2), (5e9, 5.6e9), (0, 0), {(0, 1): 20e6}, {"d1": 0, "d2": 1}, t1=(20e-6, 20e-6), t2star=(40e-6, 40e-6))
+    rl = np.asarray(prop.ode_solve_batch(g["hdrift"], hks, sig, dt, psi @ psi.conj().T, "rk4", "lindblad", col_ops=np.asarray(m.col_ops)))[0]
+    assert abs(np.trace(rl[-1]) - 1) < 0.5e-6
+    # and the values themselves against the oracle's solver (same tableau)
+    ref = o.ode_solver_arrays(g["hdrift"], hks, sig[0], g["ts"], psi, "rk4", "schrodinger")["states"]
+    assert np.abs(st - ref).max() < 1e-11
+    # bad operator shapes are refused (one operator set per call)
+    from c3_amd._lib import C3PropError
+
+    with pytest.raises(C3PropError, match="C3:Error"):
+        prop.ode_solve_batch(np.stack([g["hdrift"]] * 2), hks, sig, dt, psi)
+    with pytest.raises(C3PropError, match="C3:Error"):
+        prop.ode_solve_batch(g["hdrift"], hks[:1], sig, dt, psi)
+
+
+# --------------------------------------------------------------------------
+# Full-size spot parity on >= 32 samples (cfg1-3)
+# --------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("cfg,B", [(1, 256), (2, 256), (3, 512)])
+def test_full_size_spot_parity_32_samples(prop, cfg, B):
+    import torch
+
+    wl = workloads.make_workload(cfg, B=B)
+    dev = "cuda:0"
+    U = prop.propagate_batch(torch.as_tensor(wl.h0, device=dev), torch.as_tensor(wl.hks, device=dev), torch.as_tensor(wl.signals, device=dev),
+                             wl.dt, fr_phase=torch.as_tensor(wl.fr_phase, device=dev))["U"].cpu().numpy()
+    idx = np.unique(np.linspace(0, B - 1, 32).astype(int))
+    ref = o.propagate_batch(wl.h0, wl.hks, wl.signals[idx], wl.dt, fr_phase=wl.fr_phase[idx])
+    assert len(idx) >= 32 and fro_max(U[idx], ref) < TOL
