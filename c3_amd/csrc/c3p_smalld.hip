@@ -186,14 +186,13 @@ struct RD {
 // compute the tiles on and above the diagonal (6 of 9 at D = 9) and sym_fill mirrors them.
 // lane (r, c) of tile (I, J) holds M[4I + r][4J + c]; its mirror element M[4J + c][4I + r] is held by lane
 // (c, r) of tile (J, I): one in-chain lane swap per lower tile (ds_bpermute).
+// Only the tile rows a product reads as operands need their lower tiles: operand tiles are za[K][.] / zb[K][.] with
+// K < KM, and with the rank-1 tail (D = 1 mod 4) the last row of tiles is never an operand -- at D = 9 ONE lower tile,
+// (1,0), instead of three.  FULL mirrors everything (matrices that leave the symmetric stage: dU output, U <- E).
 template <int D>
-__device__ __forceinline__ void sym_fill(double (&m)[RD<D>::NB][RD<D>::NB], int swap_lane) {
-  constexpr int NB = RD<D>::NB;
-#pragma unroll
-  for (int I = 1; I < NB; ++I)
-#pragma unroll
-    for (int J = 0; J < I; ++J) m[I][J] = __shfl(m[J][I], swap_lane);
-}
+struct SymTail;
+template <int D, bool FULL = false>
+__device__ __forceinline__ void sym_fill(double (&m)[RD<D>::NB][RD<D>::NB], int swap_lane);
 
 // The left operand of every real product is SYMMETRIC, and for a symmetric M the A-layout fragment of tile
 // (I, K) -- lane (r, c) <- M[4I + c][4K + r] -- equals M[4K + r][4I + c], the D-layout register of tile (K, I)
@@ -217,6 +216,30 @@ struct SymTail {
   static constexpr bool ON = (D % 4 == 1) && (RD<D>::NB > 1);
   static constexpr int KM = ON ? RD<D>::NB - 1 : RD<D>::NB;
 };
+
+// first tile column of row I among the tiles kept for a symmetric matrix (operand rows in full, else upper tiles)
+template <int D>
+__device__ __forceinline__ constexpr int sym_j0(int I) {
+  return I >= SymTail<D>::KM ? I : 0;
+}
+template <int D, bool FULL>
+__device__ __forceinline__ void sym_fill(double (&m)[RD<D>::NB][RD<D>::NB], int swap_lane) {
+  constexpr int NB = RD<D>::NB;
+  constexpr int ROWS = FULL ? NB : SymTail<D>::KM;
+#pragma unroll
+  for (int I = 1; I < ROWS; ++I)
+#pragma unroll
+    for (int J = 0; J < I; ++J) m[I][J] = __shfl(m[J][I], swap_lane);
+}
+// the lower tiles sym_fill<D, false> left out
+template <int D>
+__device__ __forceinline__ void sym_fill_rest(double (&m)[RD<D>::NB][RD<D>::NB], int swap_lane) {
+  constexpr int NB = RD<D>::NB;
+#pragma unroll
+  for (int I = SymTail<D>::KM; I < NB; ++I)
+#pragma unroll
+    for (int J = 0; J < I; ++J) m[I][J] = __shfl(m[J][I], swap_lane);
+}
 
 template <int D>
 __device__ __forceinline__ void mm_sym(const double (&za)[RD<D>::NB][RD<D>::NB], const double (&zb)[RD<D>::NB][RD<D>::NB],
@@ -300,7 +323,8 @@ __device__ __forceinline__ void mm_symA(const double (&za)[RD<D>::NB][RD<D>::NB]
   }
 }
 
-// out = c0 I + c1 W + c2 W2 (+ c3 W3)
+// out = c0 I + c1 W + c2 W2 (+ c3 W3); UPPER: tiles J >= I only (accumulators of a symmetric product, mirrored
+// afterwards); otherwise the tiles a product reads as operands (rows I < KM in full, upper tiles of the other rows)
 template <int D, bool WITH3, bool UPPER = false>
 __device__ __forceinline__ void rcomb(double (&out)[RD<D>::NB][RD<D>::NB], double c0, double c1, double c2, double c3,
                                       const double (&W1)[RD<D>::NB][RD<D>::NB], const double (&W2)[RD<D>::NB][RD<D>::NB],
@@ -309,7 +333,7 @@ __device__ __forceinline__ void rcomb(double (&out)[RD<D>::NB][RD<D>::NB], doubl
 #pragma unroll
   for (int I = 0; I < NB; ++I)
 #pragma unroll
-    for (int J = UPPER ? I : 0; J < NB; ++J) {  // UPPER: accumulators of a symmetric product (mirrored afterwards)
+    for (int J = (UPPER || I >= SymTail<D>::KM) ? I : 0; J < NB; ++J) {
       double v = c1 * W1[I][J];
       v = fma(c2, W2[I][J], v);
       if constexpr (WITH3) v = fma(c3, W3[I][J], v);
@@ -686,7 +710,7 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
 #pragma unroll
           for (int I = 0; I < NB; ++I)
 #pragma unroll
-            for (int J = 0; J < NB; ++J) {
+            for (int J = sym_j0<D>(I); J < NB; ++J) {
               acc[I][J] = fma(c3p_inv_fact[16], W4[I][J], acc[I][J]);
               acs[I][J] = fma(c3p_inv_fact[17], W4[I][J], acs[I][J]);
             }
@@ -716,25 +740,33 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
           for (int J = 0; J < NB; ++J) acc[I][J] = 0.0;
         mm_sym<D>(Y, Sp, acc, tail_lane);  // acc = sin Y
         sym_fill<D>(acc, swap_lane);
-        // ---- E = cos Y - i sin Y (Cm, acc) ; squarings in real form: cos 2Y = C^2 - S^2, sin 2Y = 2 S C ----
+        // ---- E = cos Y - i sin Y (Cm, acc) ; squarings in real form.  C and S are polynomials in Y and commute:
+        //      cos 2Y = C^2 - S^2 = (C - S)(C + S) (ONE product, symmetric result), sin 2Y = 2 S C ----
         for (int it = 0; it < ps18; ++it) {
-          RMat C2, S2, SC;
+          RMat Dm, Sm, C2, SC;
 #pragma unroll
           for (int I = 0; I < NB; ++I)
 #pragma unroll
-            for (int J = 0; J < NB; ++J) C2[I][J] = S2[I][J] = SC[I][J] = 0.0;
-          mm_sym<D>(Cm, Cm, C2, tail_lane);
-          mm_sym<D>(acc, acc, S2, tail_lane);
+            for (int J = sym_j0<D>(I); J < NB; ++J) {
+              Dm[I][J] = Cm[I][J] - acc[I][J];
+              Sm[I][J] = Cm[I][J] + acc[I][J];
+              C2[I][J] = SC[I][J] = 0.0;
+            }
+          mm_sym<D>(Dm, Sm, C2, tail_lane);
           mm_sym<D>(acc, Cm, SC, tail_lane);
 #pragma unroll
           for (int I = 0; I < NB; ++I)
 #pragma unroll
             for (int J = I; J < NB; ++J) {
-              Cm[I][J] = C2[I][J] - S2[I][J];
+              Cm[I][J] = C2[I][J];
               acc[I][J] = 2.0 * SC[I][J];
             }
           sym_fill<D>(Cm, swap_lane);
           sym_fill<D>(acc, swap_lane);
+        }
+        if (DUS || t == 0) {  // the whole matrices leave the symmetric stage: dU output / U <- E
+          sym_fill_rest<D>(Cm, swap_lane);
+          sym_fill_rest<D>(acc, swap_lane);
         }
         if constexpr (DUS) {
           // dU = e^{mu} (C - iS)
@@ -766,24 +798,26 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
           mus_r = mu_r;
           mus_i = c3p_phase_add(0.0, mu_i);
         } else {
-          RMat nS, Vr, Vi;
+          // (C - iS)(Ur + i Ui) with three real products: T1 = C Ur, T2 = S Ui, T3 = (C - S)(Ur + Ui);
+          // Re = T1 + T2, Im = T3 - T1 + T2  (C - S is symmetric: its A fragments are registers, as for C and S)
+          RMat Dm, Us, T1, T2, T3;
 #pragma unroll
           for (int I = 0; I < NB; ++I)
 #pragma unroll
             for (int J = 0; J < NB; ++J) {
-              nS[I][J] = -acc[I][J];
-              Vr[I][J] = Vi[I][J] = 0.0;
+              if (J >= sym_j0<D>(I)) Dm[I][J] = Cm[I][J] - acc[I][J];
+              Us[I][J] = Ur[I][J] + Ui[I][J];
+              T1[I][J] = T2[I][J] = T3[I][J] = 0.0;
             }
-          mm_symA<D>(Cm, Ur, Vr, row0_lane, 1.0);
-          mm_symA<D>(Cm, Ui, Vi, row0_lane, 1.0);
-          mm_symA<D>(acc, Ui, Vr, row0_lane, 1.0);
-          mm_symA<D>(nS, Ur, Vi, row0_lane, 1.0);
+          mm_symA<D>(Cm, Ur, T1, row0_lane, 1.0);
+          mm_symA<D>(acc, Ui, T2, row0_lane, 1.0);
+          mm_symA<D>(Dm, Us, T3, row0_lane, 1.0);
 #pragma unroll
           for (int I = 0; I < NB; ++I)
 #pragma unroll
             for (int J = 0; J < NB; ++J) {
-              Ur[I][J] = Vr[I][J];
-              Ui[I][J] = Vi[I][J];
+              Ur[I][J] = T1[I][J] + T2[I][J];
+              Ui[I][J] = (T3[I][J] - T1[I][J]) + T2[I][J];
             }
           mus_r += mu_r;
           mus_i = c3p_phase_add(mus_i, mu_i);

@@ -1,0 +1,72 @@
+"""Fold the rocprofv3 passes of tools/profile_r02.sh into one JSON entry for profiles/r02/pmc.json: per-launch
+averages of the DOMINANT kernel (largest total time in the kernel trace), HBM bytes with the gfx950 FETCH_SIZE correction
+of MI355X_MICROARCH.md (FETCH_SIZE counts half the bytes of wide reads: x2), issued flops from the instruction counters.
+
+    python tools/pmc_to_json.py <cfg> <dirs...>
+"""
+import collections, csv, glob, json, os, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    cfg = int(sys.argv[1])
+    dirs = sys.argv[2:]
+    dur = collections.defaultdict(list)
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            break
+        if dur:
+            break
+    dom = max(dur, key=lambda k: sum(dur[k]))
+    counters = collections.defaultdict(list)
+    meta = {}
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Kernel_Name"] == dom:
+                    counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    meta = {"vgpr": int(r["VGPR_Count"]), "agpr": int(r["Accum_VGPR_Count"]), "lds_bytes": int(r["LDS_Block_Size"]),
+                            "scratch_bytes_per_lane": int(r["Scratch_Size"]), "grid": int(r["Grid_Size"]), "workgroup": int(r["Workgroup_Size"])}
+    avg = {k: sum(v) / len(v) for k, v in counters.items()}
+    import bench
+    from c3_amd import workloads
+
+    c = workloads.CONFIGS[cfg]
+    _, lo, hi, _ = bench.plan_batch(c, "weak", None, 1, 0)
+    out = {
+        "kernel": dom[:160],
+        "launches_in_trace": len(dur[dom]),
+        "avg_launch_us": sum(dur[dom]) / len(dur[dom]) / 1e3,
+        "batch": hi - lo,
+        "kernel_sources_digest": bench.kernel_sources_digest(),
+        "resources": meta,
+        "counters_per_launch": avg,
+    }
+    if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
+        out["hbm_bytes_per_launch"] = (2.0 * avg["FETCH_SIZE"] + avg["WRITE_SIZE"]) * 1024.0
+        out["hbm_note"] = "(2 x FETCH_SIZE + WRITE_SIZE) KiB: gfx950 FETCH_SIZE counts half the bytes of wide (16 B / lane) reads (MI355X_MICROARCH.md); WRITE_SIZE uncalibrated"
+    mfma = avg.get("SQ_INSTS_MFMA")
+    if mfma is not None:
+        # wave-level v_mfma_f64_4x4x4_4b (4 blocks x 4x4x4 MAC) and v_mfma_f64_16x16x4 differ 4x in flops; MOPS_F64 counts
+        # 512-flop units when available
+        mops = avg.get("SQ_INSTS_VALU_MFMA_MOPS_F64")
+        mfma_flop = (mops * 512.0) if mops else mfma * 512.0
+        valu_flop = 64.0 * (2.0 * avg.get("SQ_INSTS_VALU_FMA_F64", 0.0) + avg.get("SQ_INSTS_VALU_ADD_F64", 0.0) + avg.get("SQ_INSTS_VALU_MUL_F64", 0.0))
+        out["issued_mfma_flop_per_launch"] = mfma_flop
+        out["issued_valu_f64_flop_per_launch"] = valu_flop
+        out["issued_flop_per_launch"] = mfma_flop + valu_flop
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "SQ_BUSY_CYCLES" in avg:
+        out["mfma_busy_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch cycles); launch cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs: it reproduces launch time x 2.4 GHz)"
+        if avg.get("GRBM_GUI_ACTIVE"):
+            cyc = avg["GRBM_GUI_ACTIVE"] / 8.0
+            out["launch_cycles"] = cyc
+            out["mfma_busy_frac"] = avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0)
+            out["issued_frac_of_fp64_peak"] = out.get("issued_flop_per_launch", 0.0) / (cyc * 1024.0 * 32.0)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
