@@ -1,6 +1,7 @@
 // C ABI of libc3prop.so (see include/c3prop.h for the contract and the reference
 // functions each entry point stands in for).
 #include <algorithm>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -45,21 +46,61 @@ int fail(const char* fmt, ...) {
 enum Slot { SL_SEG_A = 0, SL_SEG_B, SL_SCRATCH, SL_CLP, SL_TABLES, SL_COUNTERS, SL_IN0, SL_IN1, SL_IN2, SL_IN3, SL_IN4, SL_OUT0, SL_OUT1, SL_COUNT };
 
 struct DeviceWs {
+  std::mutex mu;  // one lock per device: calls on different GPUs of one process do not serialise
   void* ptr[SL_COUNT] = {};
   size_t cap[SL_COUNT] = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_valid = false;
+  // The workspace (segment products, tables, arrival counters, arena) is ONE set per device and calls are asynchronous:
+  // a call on another stream than the previous one first makes its stream wait for the event recorded at the end of that
+  // call, so two streams never run kernels on the shared workspace at the same time (calls on one stream are ordered
+  // by the stream itself).
+  hipEvent_t done = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool has_last = false;
 };
 
-std::mutex g_mu;
-std::vector<DeviceWs> g_ws;
+std::mutex g_mu;  // guards the table of per-device workspaces only
+std::vector<std::unique_ptr<DeviceWs>> g_ws;
 
 DeviceWs* ws_for_current_device() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_mu);
   if ((int)g_ws.size() <= dev) g_ws.resize(dev + 1);
-  return &g_ws[dev];
+  if (!g_ws[dev]) g_ws[dev].reset(new DeviceWs());
+  return g_ws[dev].get();
 }
+
+// RAII: the current device's workspace, locked for this call and ordered after the previous call's stream
+struct WsLock {
+  DeviceWs* w = nullptr;
+  hipStream_t st = nullptr;
+  bool locked = false;
+  bool ok = true;
+  WsLock(hipStream_t stream, bool order = true) : st(stream) {
+    w = ws_for_current_device();
+    if (!w) return;
+    w->mu.lock();
+    locked = true;
+    if (order && w->has_last && w->last_stream != st) {
+      if (hipStreamWaitEvent(st, w->done, 0) != hipSuccess) ok = false;
+    }
+    ordered = order;
+  }
+  ~WsLock() {
+    if (!locked) return;
+    if (ordered) {
+      if (!w->done) (void)hipEventCreateWithFlags(&w->done, hipEventDisableTiming);
+      if (w->done && hipEventRecord(w->done, st) == hipSuccess) {
+        w->last_stream = st;
+        w->has_last = true;
+      }
+    }
+    w->mu.unlock();
+  }
+  bool ordered = true;
+};
 
 int ws_get(DeviceWs* w, Slot s, size_t bytes, void** out) {
   if (bytes == 0) bytes = 16;
@@ -911,9 +952,10 @@ int pwc_common(int lindblad, const void* h0, int64_t h0_bstride, const void* hks
   const int Dm = lindblad ? D * D : D;
   const size_t cs = sizeof(cplx);
   hipStream_t st = (hipStream_t)stream;
-  std::lock_guard<std::mutex> lk(g_mu);
-  DeviceWs* w = ws_for_current_device();
+  WsLock lk(st);
+  DeviceWs* w = lk.w;
   if (!w) return fail("no HIP device");
+  if (!lk.ok) return fail("hipStreamWaitEvent on the previous call's stream failed");
   Stage sg{w, st};
   const void *d_h0 = h0, *d_hks = hks, *d_sig = signals, *d_col = col_ops, *d_ph = fr_phase;
   void *d_U = U_out, *d_dUs = dUs_out;
@@ -1017,8 +1059,8 @@ int c3p_set_profiling(int enable) {
 }
 
 double c3p_last_kernel_ms(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  DeviceWs* w = ws_for_current_device();
+  WsLock lk(nullptr, false);
+  DeviceWs* w = lk.w;
   if (!w || !w->ev_valid) return -1.0;
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, w->ev0, w->ev1) != hipSuccess) {
@@ -1029,25 +1071,37 @@ double c3p_last_kernel_ms(void) {
 }
 
 void c3p_shutdown(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::vector<DeviceWs*> all;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& p : g_ws) all.push_back(p.get());
+  }
   int cur = 0;
   (void)hipGetDevice(&cur);
-  for (size_t d = 0; d < g_ws.size(); ++d) {
-    bool any = g_ws[d].ev0 != nullptr;
-    for (int s = 0; s < SL_COUNT; ++s) any = any || g_ws[d].ptr[s];
+  for (size_t d = 0; d < all.size(); ++d) {
+    DeviceWs* w = all[d];
+    if (!w) continue;
+    std::lock_guard<std::mutex> lk(w->mu);
+    bool any = w->ev0 != nullptr || w->done != nullptr;
+    for (int s = 0; s < SL_COUNT; ++s) any = any || w->ptr[s];
     if (!any) continue;
     (void)hipSetDevice((int)d);
     (void)hipDeviceSynchronize();
     for (int s = 0; s < SL_COUNT; ++s) {
-      if (g_ws[d].ptr[s]) (void)hipFree(g_ws[d].ptr[s]);
-      g_ws[d].ptr[s] = nullptr;
-      g_ws[d].cap[s] = 0;
+      if (w->ptr[s]) (void)hipFree(w->ptr[s]);
+      w->ptr[s] = nullptr;
+      w->cap[s] = 0;
     }
-    if (g_ws[d].ev0) {
-      (void)hipEventDestroy(g_ws[d].ev0);
-      (void)hipEventDestroy(g_ws[d].ev1);
-      g_ws[d].ev0 = g_ws[d].ev1 = nullptr;
-      g_ws[d].ev_valid = false;
+    if (w->ev0) {
+      (void)hipEventDestroy(w->ev0);
+      (void)hipEventDestroy(w->ev1);
+      w->ev0 = w->ev1 = nullptr;
+      w->ev_valid = false;
+    }
+    if (w->done) {
+      (void)hipEventDestroy(w->done);
+      w->done = nullptr;
+      w->has_last = false;
     }
   }
   (void)hipSetDevice(cur);
@@ -1073,9 +1127,10 @@ int c3p_expm(const void* A, int n, int D, int flags, void* out, void* stream) {
   if (n == 0) return 0;
   if (!A || !out) return fail("NULL matrix pointer");
   hipStream_t st = (hipStream_t)stream;
-  std::lock_guard<std::mutex> lk(g_mu);
-  DeviceWs* w = ws_for_current_device();
+  WsLock lk(st);
+  DeviceWs* w = lk.w;
   if (!w) return fail("no HIP device");
+  if (!lk.ok) return fail("hipStreamWaitEvent on the previous call's stream failed");
   Stage sg{w, st};
   const void* d_A = A;
   void* d_out = out;
@@ -1113,9 +1168,10 @@ int c3p_matmul_chain(const void* M, int B, int N, int D, int flags, void* out, v
   if (N == 0) return fail("empty matrix list (N == 0)");
   if (!M || !out) return fail("NULL matrix pointer");
   hipStream_t st = (hipStream_t)stream;
-  std::lock_guard<std::mutex> lk(g_mu);
-  DeviceWs* w = ws_for_current_device();
+  WsLock lk(st);
+  DeviceWs* w = lk.w;
   if (!w) return fail("no HIP device");
+  if (!lk.ok) return fail("hipStreamWaitEvent on the previous call's stream failed");
   Stage sg{w, st};
   const void* d_M = M;
   void* d_out = out;
@@ -1150,9 +1206,10 @@ static int kron_common(const void* A, const void* Bm, int n, int Da, int Db, int
   if (n == 0) return 0;
   if (!A || !out || (which == 0 && !Bm)) return fail("NULL matrix pointer");
   hipStream_t st = (hipStream_t)stream;
-  std::lock_guard<std::mutex> lk(g_mu);
-  DeviceWs* w = ws_for_current_device();
+  WsLock lk(st);
+  DeviceWs* w = lk.w;
   if (!w) return fail("no HIP device");
+  if (!lk.ok) return fail("hipStreamWaitEvent on the previous call's stream failed");
   Stage sg{w, st};
   const void *d_A = A, *d_B = Bm;
   void* d_out = out;
@@ -1192,9 +1249,10 @@ int c3p_ode_solve(const void* h0, const void* hks, const double* signals, const 
   const int M = (step == C3P_STEP_SCHRODINGER) ? 1 : D;
   const size_t cs = sizeof(cplx);
   hipStream_t st = (hipStream_t)stream;
-  std::lock_guard<std::mutex> lk(g_mu);
-  DeviceWs* w = ws_for_current_device();
+  WsLock lk(st);
+  DeviceWs* w = lk.w;
   if (!w) return fail("no HIP device");
+  if (!lk.ok) return fail("hipStreamWaitEvent on the previous call's stream failed");
   Stage sg{w, st};
   const void *d_h0 = h0, *d_hks = hks, *d_sig = signals, *d_col = col_ops, *d_init = init;
   void* d_states = states;
@@ -1252,9 +1310,10 @@ int c3p_rk4_unitary(const void* h0, const void* hks, const double* signals, cons
   const int n_steps = (Ns - 1) / 2;  // range(0, len(h) - 2, 2), propagation.py:79,251
   const size_t cs = sizeof(cplx);
   hipStream_t st = (hipStream_t)stream;
-  std::lock_guard<std::mutex> lk(g_mu);
-  DeviceWs* w = ws_for_current_device();
+  WsLock lk(st);
+  DeviceWs* w = lk.w;
   if (!w) return fail("no HIP device");
+  if (!lk.ok) return fail("hipStreamWaitEvent on the previous call's stream failed");
   Stage sg{w, st};
   const void *d_h0 = h0, *d_hks = hks, *d_sig = signals, *d_hs = hs;
   void *d_U = U_out, *d_dUs = dUs_out;
@@ -1327,9 +1386,10 @@ int c3p_gate_overlap(const void* U, int B, int D, const int32_t* comp_rows, int 
   if (!U || !comp_rows || !ideal || !overlap_out) return fail("NULL pointer argument");
   const size_t cs = sizeof(cplx);
   hipStream_t st = (hipStream_t)stream;
-  std::lock_guard<std::mutex> lk(g_mu);
-  DeviceWs* w = ws_for_current_device();
+  WsLock lk(st);
+  DeviceWs* w = lk.w;
   if (!w) return fail("no HIP device");
+  if (!lk.ok) return fail("hipStreamWaitEvent on the previous call's stream failed");
   Stage sg{w, st};
   const void *d_U = U, *d_rows = comp_rows, *d_G = ideal;
   void* d_out = overlap_out;
@@ -1357,9 +1417,10 @@ int c3p_synth_signals(const double* env_params, const int32_t* env_shapes, const
   if (B == 0) return 0;
   if (!env_params || !env_shapes || !carrier || !signals_out) return fail("NULL pointer argument");
   hipStream_t st = (hipStream_t)stream;
-  std::lock_guard<std::mutex> lk(g_mu);
-  DeviceWs* w = ws_for_current_device();
+  WsLock lk(st);
+  DeviceWs* w = lk.w;
   if (!w) return fail("no HIP device");
+  if (!lk.ok) return fail("hipStreamWaitEvent on the previous call's stream failed");
   Stage sg{w, st};
   const void *d_env = env_params, *d_shape = env_shapes, *d_car = carrier;
   void *d_iq = awg_iq_out, *d_sig = signals_out;
@@ -1407,9 +1468,10 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
   if (!h0 || !hks || !signals || !U_bar || !grad_signals) return fail("NULL pointer argument");
   const size_t cs = sizeof(cplx);
   hipStream_t st = (hipStream_t)stream;
-  std::lock_guard<std::mutex> lk(g_mu);
-  DeviceWs* w = ws_for_current_device();
+  WsLock lk(st);
+  DeviceWs* w = lk.w;
   if (!w) return fail("no HIP device");
+  if (!lk.ok) return fail("hipStreamWaitEvent on the previous call's stream failed");
   Stage sg{w, st};
   const void *d_h0 = h0, *d_hks = hks, *d_sig = signals, *d_ph = fr_phase, *d_ub = U_bar;
   void* d_grad = grad_signals;
@@ -1506,9 +1568,10 @@ int c3p_synth_signals_vjp(const double* env_params, const int32_t* env_shapes, c
   if (!env_params || !env_shapes || !carrier || !grad_signals || !grad_env || !grad_carrier)
     return fail("NULL pointer argument");
   hipStream_t st = (hipStream_t)stream;
-  std::lock_guard<std::mutex> lk(g_mu);
-  DeviceWs* w = ws_for_current_device();
+  WsLock lk(st);
+  DeviceWs* w = lk.w;
   if (!w) return fail("no HIP device");
+  if (!lk.ok) return fail("hipStreamWaitEvent on the previous call's stream failed");
   Stage sg{w, st};
   const void *d_env = env_params, *d_shape = env_shapes, *d_car = carrier, *d_gs = grad_signals;
   void *d_ge = grad_env, *d_gc = grad_carrier;

@@ -476,13 +476,10 @@ hipError_t c3p_launch_chain_generic(const ChainArgs& A, bool global_scratch, hip
     hipLaunchKernelGGL(chain_kernel<true>, grid, dim3(threads), 0, st, A);
   } else {
     const size_t lds = c3p_generic_lds_bytes(A.Dm);
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-      if (e != hipSuccess) return e;
-      attr_set = true;
-    }
+    // per launch: the attribute is per DEVICE, and one process may drive several GPUs
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(chain_kernel<false>, grid, dim3(threads), lds, st, A);
   }
   return hipGetLastError();

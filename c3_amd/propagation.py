@@ -202,7 +202,21 @@ def propagate_batch(
     return {"U": U, "dUs": dUs}
 
 
-def propagate_batch_vjp(h0, hks, signals, dt: float, U_bar, *, fr_phase=None, force_generic: bool = False, want_model_grads: bool = False):
+def _require_hermitian(call, name, h):
+    """The adjoint sweep assumes unitary slices, i.e. Hermitian Hamiltonians; the library only checks host-pointer
+    inputs, so device tensors are checked here (one reduction + a host sync per operator set)."""
+    if call.device:
+        t = call.torch
+        dev = float((h - h.conj().transpose(-1, -2)).abs().max().item())
+        scale = float(h.abs().max().item())
+    else:
+        dev = float(np.abs(h - np.conj(np.swapaxes(h, -1, -2))).max())
+        scale = float(np.abs(h).max())
+    if dev > 1e-12 * max(scale, 1e-300):
+        raise C3PropError(f"C3:Error: {name} must be Hermitian for the gradient (|h - h^+| = {dev:.3e})")
+
+
+def propagate_batch_vjp(h0, hks, signals, dt: float, U_bar, *, fr_phase=None, force_generic: bool = False, want_model_grads: bool = False, check_hermitian: bool = True):
     """Vector-Jacobian product of `propagate_batch` (unitary, branch A) w.r.t. the control samples.
 
     The reference tapes the goal function (optimizers/optimizer.py:206-216) and lets TensorFlow
@@ -226,6 +240,9 @@ def propagate_batch_vjp(h0, hks, signals, dt: float, U_bar, *, fr_phase=None, fo
     hk_bs = _bstride(hks, 3, B, "hks")
     if int(hks.shape[-3]) != K:
         raise C3PropError(f"C3:Error: {K} signal channels but {int(hks.shape[-3])} control Hamiltonians")
+    if check_hermitian:
+        _require_hermitian(call, "h0", h0)
+        _require_hermitian(call, "hks", hks)
     U_bar = call.c128(U_bar)
     if tuple(U_bar.shape) != (B, D, D):
         raise C3PropError(f"C3:Error: U_bar must be [{B},{D},{D}], got {tuple(U_bar.shape)}")

@@ -29,8 +29,13 @@
  *    like the reference (c3/experiment.py:465-468).
  *  - The caller owns every buffer it passes.  The library owns only a lazily
  *    grown per-device workspace, released by c3p_shutdown().
- *  - Re-entrant per (device, stream); the workspace is per device and guarded
- *    by a mutex, so concurrent calls on one device serialise their launches.
+ *  - Thread-safe.  The workspace is ONE set per device, guarded by a per-device
+ *    mutex at enqueue time (different devices do not serialise each other).  Calls
+ *    on one stream are ordered by the stream; a call on ANOTHER stream of the same
+ *    device first makes its stream wait (hipStreamWaitEvent) for the end of the
+ *    previous call, so two streams never run kernels on the shared workspace at
+ *    once -- results are correct from any number of streams, but calls on one
+ *    device do not overlap each other.
  */
 #ifndef C3PROP_H
 #define C3PROP_H

@@ -321,3 +321,32 @@ def test_full_size_spot_parity_32_samples(prop, cfg, B):
     idx = np.unique(np.linspace(0, B - 1, 32).astype(int))
     ref = o.propagate_batch(wl.h0, wl.hks, wl.signals[idx], wl.dt, fr_phase=wl.fr_phase[idx])
     assert len(idx) >= 32 and fro_max(U[idx], ref) < TOL
+
+
+# --------------------------------------------------------------------------
+# Calls from several streams of one device share the per-device workspace: they must be ordered, not racing
+# --------------------------------------------------------------------------
+
+
+def test_two_streams_share_the_workspace_safely(prop):
+    import torch
+
+    dev = torch.device("cuda:0")
+    wa = workloads.make_workload(2, B=64, N=400)           # small-D kernel, fused combine (arrival counters, partials)
+    wb = workloads.make_workload(3, B=24, N=120)           # mid-D kernel (tables, segment products)
+    ta = [torch.as_tensor(x, device=dev) for x in (wa.h0, wa.hks, wa.signals)]
+    tb = [torch.as_tensor(x, device=dev) for x in (wb.h0, wb.hks, wb.signals)]
+    ref_a = prop.propagate_batch(ta[0], ta[1], ta[2], wa.dt)["U"].clone()
+    ref_b = prop.propagate_batch(tb[0], tb[1], tb[2], wb.dt)["U"].clone()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    outs = []
+    for rep in range(6):  # interleaved enqueues, no host synchronisation in between
+        with torch.cuda.stream(s1):
+            ua = prop.propagate_batch(ta[0], ta[1], ta[2], wa.dt)["U"]
+        with torch.cuda.stream(s2):
+            ub = prop.propagate_batch(tb[0], tb[1], tb[2], wb.dt)["U"]
+        outs.append((ua, ub))
+    torch.cuda.synchronize()
+    for ua, ub in outs:
+        assert torch.equal(ua, ref_a) and torch.equal(ub, ref_b)
