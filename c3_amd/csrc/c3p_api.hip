@@ -17,6 +17,7 @@
 #include "c3p_midd.h"
 #include "c3p_bigd.h"
 #include "c3p_regd.h"
+#include "c3p_tiled.h"
 #include "c3p_signal.h"
 #include "c3p_grad.h"
 
@@ -897,6 +898,40 @@ int run_pwc_regd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Tiled large-matrix path (c3p_tiled.hip): matrices in HBM, one batched MFMA GEMM launch per product
+// ---------------------------------------------------------------------------
+int run_pwc_tiled(DeviceWs* w, const ChainArgs& a, bool per_slice, cplx* U_out, hipStream_t st) {
+  const bool lindblad = a.mode == C3P_MODE_LINDBLAD;
+  const bool per_sample = !per_slice && (a.h0_bstride != 0 || a.hks_bstride != 0);
+  const int K = per_slice ? 0 : a.K;
+  const int Bc = c3p_tiled_chunk(a.Dm, K, a.B, per_sample, (size_t)24 << 30);
+  void* v;
+  if (ws_get(w, SL_SCRATCH, c3p_tiled_ws_bytes(a.Dm, K, Bc, per_sample), &v)) return -1;
+  TiledArgs t = {};
+  t.lindblad = lindblad ? 1 : 0;
+  t.per_slice = per_slice ? 1 : 0;
+  t.h0 = a.h0;
+  t.h0_bstride = a.h0_bstride;
+  t.hks = a.hks;
+  t.hks_bstride = a.hks_bstride;
+  t.signals = a.signals;
+  t.clp = a.clp;
+  t.dt = a.dt;
+  t.B = a.B;
+  t.K = K;
+  t.N = a.N;
+  t.D = a.D;
+  t.Dm = a.Dm;
+  t.fr_phase = a.fr_phase;
+  t.U_out = U_out;
+  t.dUs_out = a.dUs_out;
+  g_last_kernel = C3P_KERNEL_MFMA;
+  std::string err;
+  if (c3p_tiled_run(t, v, Bc, st, err)) return fail("%s", err.c_str());
+  return 0;
+}
+
 // Host-pointer staging helpers --------------------------------------------------
 struct Stage {
   DeviceWs* w;
@@ -1029,6 +1064,13 @@ int pwc_common(int lindblad, const void* h0, int64_t h0_bstride, const void* hks
                                 K, N, D, Dm, a.fr_phase, (cplx*)d_U, a.dUs_out, st);
     if (rc < 0) return -1;
     done = (rc == 0);
+  }
+  // beyond the on-chip kernels: Dm >= 93, and supplied / per-slice generators at Dm >= 41 (the generic kernel would run
+  // those from global scratch at a few percent of the roofline, and stops at Dm = 256)
+  if (!done && !(flags & C3P_FORCE_GENERIC) && !getenv("C3P_NO_TILED") && (Dm >= 93 || (per_slice && Dm >= 41)) &&
+      (per_slice ? K == 0 : true)) {
+    if (run_pwc_tiled(w, a, per_slice, (cplx*)d_U, st)) return -1;
+    done = true;
   }
   if (!done && run_chain_generic(w, a, (cplx*)d_U, st)) return -1;
   if (flags & C3P_HOST_PTRS) return sg.finish();

@@ -1,0 +1,545 @@
+// Tiled large-matrix propagator path: U[b] = prod_n exp(X_b[n]) for matrix dimensions beyond what a workgroup can
+// keep on chip (Dm >= 93; the 729 x 729 Lindblad superoperator of three qutrits is the reference's own "takes way too
+// long" case, test/test_tunable_coupler.py:406-418).  Matrices live in HBM (288 GB: ten 9 MB matrices per sample at
+// Dm = 729 is nothing), every product is ONE batched launch of a tiled f64 MFMA GEMM, and the slice loop runs on the
+// host: assemble X, T18 (5 products, Bader-Blanes-Casas) + s squarings, chain product.  The reference computes the
+// same thing with tf.linalg.expm + tf.matmul (propagation.py:426-440, 551-585; tf_utils.py:144-193).
+//
+// Layout: every matrix is a HALF IMAGE of the real 2x2 representation, rows 2i / 2i+1 = Re / Im of row i, zero
+// padded to [2 DPR][DPC] doubles (DPR = Dm rounded up to 32, DPC to 64) so that no tile needs a bounds check.
+// C_h = R(A) B_h is then a plain real GEMM; R(A) (2M x 2K) is expanded from A_h while its panel is staged in LDS
+// ([[a,-b],[b,a]] per element), B_h and C_h are used as stored.  64 x 64 output tile per workgroup of four waves,
+// each wave 2 x 2 tiles of v_mfma_f64_16x16x4_f64, K panels of 16 double-buffered through registers and LDS.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "c3p_tiled.h"
+#include "c3p_kernels.h"
+
+namespace {
+
+typedef double tg_d4 __attribute__((ext_vector_type(4)));
+
+constexpr int TG_BM = 64, TG_BN = 64, TG_KP = 16;
+constexpr int TG_SA = 17;  // LDS row stride of the expanded A panel (doubles)
+constexpr int TG_SB = 80;  // LDS row stride of the B panel: = 16 mod 32, the two k rows of a half-wave hit disjoint banks
+enum { M_X = 0, M_A2, M_A3, M_A6, M_T1, M_T2, M_T3, M_T4, M_U0, M_U1, M_COUNT };
+
+struct TG {
+  int Dm, DPR, DPC;
+  long MS;  // doubles per matrix
+  __host__ __device__ TG(int dm) : Dm(dm), DPR((dm + 31) / 32 * 32), DPC((dm + 63) / 64 * 64), MS(2L * ((dm + 31) / 32 * 32) * ((dm + 63) / 64 * 64)) {}
+};
+
+// ---- C = A B (+ Add), batched over blockIdx.z ------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) tg_gemm_kernel(const double* __restrict__ A, const double* __restrict__ Bm,
+                                                      const double* __restrict__ Add, double* __restrict__ C, int rows2, int DPC,
+                                                      long mstride) {
+  __shared__ double As[2][TG_BM * TG_SA];
+  __shared__ double Bs[2][TG_KP * TG_SB];
+  const long boff = (long)blockIdx.z * mstride;
+  A += boff;
+  Bm += boff;
+  C += boff;
+  if (Add) Add += boff;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r0 = blockIdx.y * TG_BM, c0 = blockIdx.x * TG_BN;
+  // loaders: A_h panel 64 rows x 8 complex columns (2 doubles per thread), B_h panel 16 rows x 64 columns (4 per thread)
+  const int a_row = tid >> 2, a_j = (tid & 3) * 2;
+  const int b_row = tid >> 4, b_c = (tid & 15) * 4;
+  const double* ap = A + (long)(r0 + a_row) * DPC + a_j;
+  const double* bp = Bm + (long)b_row * DPC + c0 + b_c;
+  const int a_rb = a_row & ~1, a_p = a_row & 1;
+  tg_d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (tg_d4){0.0, 0.0, 0.0, 0.0};
+  const int npanel = rows2 / TG_KP;
+  double2 av = *reinterpret_cast<const double2*>(ap);
+  double2 bv0 = *reinterpret_cast<const double2*>(bp), bv1 = *reinterpret_cast<const double2*>(bp + 2);
+  for (int pn = 0; pn < npanel; ++pn) {
+    double* as = As[pn & 1];
+    double* bs = Bs[pn & 1];
+    // expand R(A): a value of a Re row feeds (row, 2j) and (row + 1, 2j + 1); of an Im row (row - 1, 2j + 1) negated and (row, 2j)
+    if (a_p == 0) {
+      as[a_rb * TG_SA + 2 * a_j] = av.x;
+      as[(a_rb + 1) * TG_SA + 2 * a_j + 1] = av.x;
+      as[a_rb * TG_SA + 2 * a_j + 2] = av.y;
+      as[(a_rb + 1) * TG_SA + 2 * a_j + 3] = av.y;
+    } else {
+      as[a_rb * TG_SA + 2 * a_j + 1] = -av.x;
+      as[(a_rb + 1) * TG_SA + 2 * a_j] = av.x;
+      as[a_rb * TG_SA + 2 * a_j + 3] = -av.y;
+      as[(a_rb + 1) * TG_SA + 2 * a_j + 2] = av.y;
+    }
+    bs[b_row * TG_SB + b_c + 0] = bv0.x;
+    bs[b_row * TG_SB + b_c + 1] = bv0.y;
+    bs[b_row * TG_SB + b_c + 2] = bv1.x;
+    bs[b_row * TG_SB + b_c + 3] = bv1.y;
+    __syncthreads();  // (double buffered: the next iteration writes the other buffer, one barrier per panel)
+    if (pn + 1 < npanel) {
+      av = *reinterpret_cast<const double2*>(ap + (long)(pn + 1) * (TG_KP / 2));
+      const double* bn = bp + (long)(pn + 1) * TG_KP * DPC;
+      bv0 = *reinterpret_cast<const double2*>(bn);
+      bv1 = *reinterpret_cast<const double2*>(bn + 2);
+    }
+#pragma unroll
+    for (int ks = 0; ks < TG_KP / 4; ++ks) {
+      double af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = as[(32 * wr + 16 * i + (lane & 15)) * TG_SA + 4 * ks + (lane >> 4)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = bs[(4 * ks + (lane >> 4)) * TG_SB + 32 * wc + 16 * j + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // D layout of 16x16x4: register v of lane l = element (4 v + l / 16, l % 16)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const long e = (long)(r0 + 32 * wr + 16 * i + 4 * v + (lane >> 4)) * DPC + c0 + 32 * wc + 16 * j + (lane & 15);
+        C[e] = acc[i][j][v] + (Add ? Add[e] : 0.0);
+      }
+}
+
+// ---- generator elements ------------------------------------------------------------------------------------------------
+// G = -i dt h (unitary) or the Lindblad generator dt (clp - i (h (x) I - I (x) h^T)) (propagation.py:565-582); with_clp only
+// for the drift table / per-slice generators
+__device__ __forceinline__ cplx tg_gelem(const cplx* h, const cplx* clp, int lindblad, int Dh, int Dm, double dt, bool with_clp,
+                                         int row, int col) {
+  if (!lindblad) {
+    const cplx x = h[(long)row * Dm + col];
+    return cmake(x.y * dt, -x.x * dt);
+  }
+  const int i = row / Dh, j = row - i * Dh, k = col / Dh, l = col - k * Dh;
+  cplx v = with_clp ? clp[(long)row * Dm + col] : cmake(0.0, 0.0);
+  if (j == l) {
+    const cplx x = h[i * Dh + k];
+    v.x += x.y;
+    v.y -= x.x;
+  }
+  if (i == k) {
+    const cplx x = h[l * Dh + j];
+    v.x -= x.y;
+    v.y += x.x;
+  }
+  return cscale(v, dt);
+}
+
+struct TabArgs {
+  const cplx* h0;
+  long h0_bstride;
+  const cplx* hks;
+  long hks_bstride;
+  const cplx* clp;
+  double dt;
+  int K, Dh, Dm, lindblad;
+  int b0;          // first sample of the chunk (per-sample tables)
+  double* tables;  // [nsamp][1+K][MS]
+  double* meta;    // [nsamp][1+K][4] = {mu_r, mu_i, ||G - mu||_1, 0}
+};
+
+__device__ __forceinline__ const cplx* tg_table_src(const TabArgs& P, int ti, int s) {
+  return ti == 0 ? P.h0 + (long)(P.b0 + s) * P.h0_bstride : P.hks + (long)(P.b0 + s) * P.hks_bstride + (long)(ti - 1) * P.Dh * P.Dh;
+}
+
+// one block per (table, sample): trace shift and 1-norm
+__global__ void __launch_bounds__(256) tg_meta_kernel(TabArgs P) {
+  __shared__ double r1[256], r2[256];
+  const int ti = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+  const cplx* h = tg_table_src(P, ti, s);
+  double tr = 0.0, tim = 0.0;
+  for (int i = tid; i < P.Dm; i += 256) {
+    const cplx v = tg_gelem(h, P.clp, P.lindblad, P.Dh, P.Dm, P.dt, ti == 0, i, i);
+    tr += v.x;
+    tim += v.y;
+  }
+  r1[tid] = tr;
+  r2[tid] = tim;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) {
+      r1[tid] += r1[tid + o];
+      r2[tid] += r2[tid + o];
+    }
+    __syncthreads();
+  }
+  const double mur = r1[0] / P.Dm, mui = r2[0] / P.Dm;
+  __syncthreads();
+  double cs = 0.0;
+  for (int j = tid; j < P.Dm; j += 256) {
+    double sum = 0.0;
+    for (int i = 0; i < P.Dm; ++i) {
+      cplx v = tg_gelem(h, P.clp, P.lindblad, P.Dh, P.Dm, P.dt, ti == 0, i, j);
+      if (i == j) {
+        v.x -= mur;
+        v.y -= mui;
+      }
+      sum += hypot(v.x, v.y);
+    }
+    cs = fmax(cs, sum);
+  }
+  r1[tid] = cs;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) r1[tid] = fmax(r1[tid], r1[tid + o]);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    double* m = P.meta + ((long)s * (1 + P.K) + ti) * 4;
+    m[0] = mur;
+    m[1] = mui;
+    m[2] = r1[0];
+    m[3] = 0.0;
+  }
+}
+
+__global__ void __launch_bounds__(256) tg_table_kernel(TabArgs P, int DPR, int DPC) {
+  const int ti = blockIdx.y, s = blockIdx.z;
+  const long MS = 2L * DPR * DPC;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= MS) return;
+  const int r = (int)(e / DPC), c = (int)(e - (long)r * DPC);
+  const int i = r >> 1, p = r & 1;
+  double out = 0.0;
+  if (i < P.Dm && c < P.Dm) {
+    const cplx* h = tg_table_src(P, ti, s);
+    cplx g = tg_gelem(h, P.clp, P.lindblad, P.Dh, P.Dm, P.dt, ti == 0, i, c);
+    if (i == c) {
+      const double* m = P.meta + ((long)s * (1 + P.K) + ti) * 4;
+      g.x -= m[0];
+      g.y -= m[1];
+    }
+    out = p ? g.y : g.x;
+  }
+  P.tables[((long)s * (1 + P.K) + ti) * MS + e] = out;
+}
+
+// max_n,b |c_k|: one block per control line, result as the bit pattern of a non-negative double (atomicMax on u64)
+__global__ void __launch_bounds__(256) tg_sigmax_kernel(const double* sig, int B, int K, int N, unsigned long long* out) {
+  __shared__ double r1[256];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  double m = 0.0;
+  for (long e = tid; e < (long)B * N; e += 256) {
+    const long b = e / N, n = e - b * N;
+    m = fmax(m, fabs(sig[(b * K + k) * N + n]));
+  }
+  r1[tid] = m;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) r1[tid] = fmax(r1[tid], r1[tid + o]);
+    __syncthreads();
+  }
+  if (tid == 0) out[k] = (unsigned long long)__double_as_longlong(r1[0]);
+}
+
+// per-slice Hamiltonians: max over matrices of ||H||_1 (out[0]) and ||H||_inf (out[1]); ||clp||_1 with nmat = 1 -> out[0]
+__global__ void __launch_bounds__(64) tg_hnorm_kernel(const cplx* hs, long bstride, int N, int D, unsigned long long* out) {
+  const long m = blockIdx.x;
+  const long b = m / N, n = m - b * N;
+  const cplx* h = hs + b * bstride + n * (long)D * D;
+  const int tid = threadIdx.x;
+  double c1 = 0.0, ci = 0.0;
+  for (int j = tid; j < D; j += 64) {
+    double sc = 0.0, sr = 0.0;
+    for (int i = 0; i < D; ++i) {
+      sc += hypot(h[(long)i * D + j].x, h[(long)i * D + j].y);
+      sr += hypot(h[(long)j * D + i].x, h[(long)j * D + i].y);
+    }
+    c1 = fmax(c1, sc);
+    ci = fmax(ci, sr);
+  }
+  for (int o = 32; o >= 1; o >>= 1) {
+    c1 = fmax(c1, __shfl_xor(c1, o));
+    ci = fmax(ci, __shfl_xor(ci, o));
+  }
+  if (tid == 0) {
+    atomicMax(out + 0, (unsigned long long)__double_as_longlong(c1));
+    atomicMax(out + 1, (unsigned long long)__double_as_longlong(ci));
+  }
+}
+
+struct AsmArgs {
+  const double* tables;  // mode A
+  const double* meta;
+  int tab_per_sample;
+  const double* signals;  // [B,K,N]
+  int b0, n, K, N;
+  // mode B: per-slice Hamiltonians
+  const cplx* hs;
+  long hs_bstride;
+  const cplx* clp;
+  int lindblad, Dh, Dm;
+  double dt;
+  double scale;
+  double* X;     // [Bc][M_COUNT][MS] (slot M_X)
+  double* mus;   // [Bc][2] running trace-shift sum
+  double* mun;   // [Bc][2] this slice's trace shift
+};
+
+// X = 2^-s (G0 + sum_k c_k G_k)  (propagation.py:426-439), or 2^-s G(H_n) for per-slice Hamiltonians (:295-308)
+__global__ void __launch_bounds__(256) tg_assemble_kernel(AsmArgs P, int DPR, int DPC) {
+  const int b = blockIdx.y;
+  const long MS = 2L * DPR * DPC;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  double* X = P.X + (long)b * M_COUNT * MS + (long)M_X * MS;
+  if (P.hs) {
+    if (e < MS) {
+      const int r = (int)(e / DPC), c = (int)(e - (long)r * DPC);
+      const int i = r >> 1, p = r & 1;
+      double out = 0.0;
+      if (i < P.Dm && c < P.Dm) {
+        const cplx* h = P.hs + (long)(P.b0 + b) * P.hs_bstride + (long)P.n * P.Dh * P.Dh;
+        const cplx g = tg_gelem(h, P.clp, P.lindblad, P.Dh, P.Dm, P.dt, true, i, c);
+        out = P.scale * (p ? g.y : g.x);
+      }
+      X[e] = out;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) P.mun[2 * b] = P.mun[2 * b + 1] = 0.0;
+    return;
+  }
+  const int ts = P.tab_per_sample ? b : 0;
+  const double* T = P.tables + (long)ts * (1 + P.K) * MS;
+  const double* sg = P.signals + ((long)(P.b0 + b) * P.K) * P.N + P.n;
+  if (e < MS) {
+    double v = T[e];
+    for (int k = 0; k < P.K; ++k) v = fma(sg[(long)k * P.N], T[(long)(k + 1) * MS + e], v);
+    X[e] = P.scale * v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const double* m = P.meta + (long)ts * (1 + P.K) * 4;
+    double mr = m[0], mi = m[1];
+    for (int k = 0; k < P.K; ++k) {
+      mr = fma(sg[(long)k * P.N], m[4 * (k + 1)], mr);
+      mi = fma(sg[(long)k * P.N], m[4 * (k + 1) + 1], mi);
+    }
+    P.mun[2 * b] = mr;
+    P.mun[2 * b + 1] = mi;
+    P.mus[2 * b] += mr;
+    P.mus[2 * b + 1] = c3p_phase_add(P.mus[2 * b + 1], mi);
+  }
+}
+
+// T18 combinations (c3p_common.h): from X, A2, A3, A6 -> T1 = B1, T2 = B5, T3 = B4, T4 = B3, X <- B2
+__global__ void __launch_bounds__(256) tg_combo_kernel(double* mats, int Dm, int DPR, int DPC) {
+  const int b = blockIdx.y;
+  const long MS = 2L * DPR * DPC;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= MS) return;
+  double* M = mats + (long)b * M_COUNT * MS;
+  const int r = (int)(e / DPC), c = (int)(e - (long)r * DPC);
+  const double dg = ((r & 1) == 0 && (r >> 1) == c && c < Dm) ? 1.0 : 0.0;
+  const double x = M[M_X * MS + e], a2 = M[M_A2 * MS + e], a3 = M[M_A3 * MS + e], a6 = M[M_A6 * MS + e];
+  M[M_T1 * MS + e] = fma(C3P_T18_A31, a3, fma(C3P_T18_A21, a2, C3P_T18_A11 * x));
+  M[M_T2 * MS + e] = fma(C3P_T18_B64, a6, fma(C3P_T18_B34, a3, C3P_T18_B24 * a2));
+  M[M_T3 * MS + e] = fma(C3P_T18_B63, a6, fma(C3P_T18_B33, a3, fma(C3P_T18_B23, a2, fma(C3P_T18_B13, x, C3P_T18_B03 * dg))));
+  M[M_T4 * MS + e] = fma(C3P_T18_B62, a6, fma(C3P_T18_B32, a3, fma(C3P_T18_B22, a2, fma(C3P_T18_B12, x, C3P_T18_B02 * dg))));
+  M[M_X * MS + e] = fma(C3P_T18_B61, a6, fma(C3P_T18_B31, a3, fma(C3P_T18_B21, a2, C3P_T18_B11 * x)));
+}
+
+// dst = a + b (slots of the same sample)
+__global__ void __launch_bounds__(256) tg_add_kernel(double* mats, int sa, int sb, int sd, long MS) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= MS) return;
+  double* M = mats + (long)blockIdx.y * M_COUNT * MS;
+  M[sd * MS + e] = M[sa * MS + e] + M[sb * MS + e];
+}
+
+// out[b][i][j] = e^{mu} e^{i phase_i} (M[2i][j] + i M[2i+1][j]) as interleaved complex [Dm][Dm]
+__global__ void __launch_bounds__(256) tg_out_kernel(const double* mats, int slot, const double* mu, const double* phase, cplx* out,
+                                                     long out_bstride, int Dm, int DPR, int DPC) {
+  const int b = blockIdx.y;
+  const long MS = 2L * DPR * DPC;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)Dm * Dm) return;
+  const int i = (int)(e / Dm), j = (int)(e - (long)i * Dm);
+  const double* M = mats + (long)b * M_COUNT * MS + (long)slot * MS;
+  const double re = M[(long)(2 * i) * DPC + j], im = M[(long)(2 * i + 1) * DPC + j];
+  double ang = mu ? mu[2 * b + 1] : 0.0;
+  if (phase) ang += phase[(long)b * Dm + i];
+  double sn, cs;
+  sincos(ang, &sn, &cs);
+  const double er = mu ? exp(mu[2 * b]) : 1.0;
+  out[(long)b * out_bstride + e] = cmake(er * (cs * re - sn * im), er * (cs * im + sn * re));
+}
+
+#define TG_TRY(expr)                                                                  \
+  do {                                                                                \
+    hipError_t e__ = (expr);                                                          \
+    if (e__ != hipSuccess) {                                                          \
+      err = std::string(#expr) + " failed: " + hipGetErrorString(e__);                \
+      return -1;                                                                      \
+    }                                                                                 \
+  } while (0)
+
+}  // namespace
+
+size_t c3p_tiled_ws_bytes(int Dm, int K, int Bc, bool per_sample_tables) {
+  const TG g(Dm);
+  const size_t nt = per_sample_tables ? (size_t)Bc : 1;
+  return ((size_t)Bc * M_COUNT * g.MS + nt * (1 + K) * (g.MS + 4) + 4 * (size_t)Bc + 64) * sizeof(double);
+}
+
+int c3p_tiled_chunk(int Dm, int K, int B, bool per_sample_tables, size_t budget_bytes) {
+  int bc = B;
+  while (bc > 1 && c3p_tiled_ws_bytes(Dm, K, bc, per_sample_tables) > budget_bytes) bc = (bc + 1) / 2;
+  return bc;
+}
+
+int c3p_tiled_run(const TiledArgs& A, void* ws, int Bc, hipStream_t st, std::string& err) {
+  const TG g(A.Dm);
+  const long MS = g.MS;
+  const bool per_sample = !A.per_slice && (A.h0_bstride != 0 || A.hks_bstride != 0);
+  const int K = A.per_slice ? 0 : A.K;
+  const size_t nt = per_sample ? (size_t)Bc : 1;
+  double* mats = reinterpret_cast<double*>(ws);
+  double* tables = mats + (size_t)Bc * M_COUNT * MS;
+  double* meta = tables + nt * (1 + K) * MS;
+  double* mus = meta + nt * (1 + K) * 4;
+  double* mun = mus + 2 * (size_t)Bc;
+  unsigned long long* red = reinterpret_cast<unsigned long long*>(mun + 2 * (size_t)Bc);  // 64 words
+  const unsigned ebl = (unsigned)((MS + 255) / 256);
+  const dim3 ggrid((unsigned)(g.DPC / TG_BN), (unsigned)(2 * g.DPR / TG_BM), 1);
+
+  for (int b0 = 0; b0 < A.B; b0 += Bc) {
+    const int nb = A.B - b0 < Bc ? A.B - b0 : Bc;
+    const int nts = per_sample ? nb : 1;
+    // ---- tables (mode A) and the norm bound that fixes the squaring count ----
+    double bound = 0.0;
+    TG_TRY(hipMemsetAsync(red, 0, 64 * sizeof(unsigned long long), st));
+    TabArgs T = {};
+    if (!A.per_slice) {
+      T.h0 = A.h0;
+      T.h0_bstride = A.h0_bstride;
+      T.hks = A.hks;
+      T.hks_bstride = A.hks_bstride;
+      T.clp = A.clp;
+      T.dt = A.dt;
+      T.K = K;
+      T.Dh = A.D;
+      T.Dm = A.Dm;
+      T.lindblad = A.lindblad;
+      T.b0 = per_sample ? b0 : 0;
+      T.tables = tables;
+      T.meta = meta;
+      if (b0 == 0 || per_sample) {
+        hipLaunchKernelGGL(tg_meta_kernel, dim3(1 + K, nts), dim3(256), 0, st, T);
+        hipLaunchKernelGGL(tg_table_kernel, dim3(ebl, 1 + K, nts), dim3(256), 0, st, T, g.DPR, g.DPC);
+      }
+      if (K > 0)
+        hipLaunchKernelGGL(tg_sigmax_kernel, dim3(K), dim3(256), 0, st, A.signals + (long)b0 * K * A.N, nb, K, A.N, red);
+      TG_TRY(hipGetLastError());
+      std::vector<double> hm((size_t)nts * (1 + K) * 4);
+      std::vector<unsigned long long> hr(64);
+      TG_TRY(hipMemcpyAsync(hm.data(), meta, hm.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      TG_TRY(hipMemcpyAsync(hr.data(), red, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+      TG_TRY(hipStreamSynchronize(st));
+      for (int ti = 0; ti <= K; ++ti) {
+        double nk = 0.0;
+        for (int s = 0; s < nts; ++s) nk = std::max(nk, hm[((size_t)s * (1 + K) + ti) * 4 + 2]);
+        double cm = 1.0;
+        if (ti > 0) memcpy(&cm, &hr[ti - 1], 8);
+        bound += cm * nk;
+      }
+    } else {
+      const long nmat = (long)nb * A.N;
+      hipLaunchKernelGGL(tg_hnorm_kernel, dim3((unsigned)nmat), dim3(64), 0, st, A.h0 + (long)b0 * A.h0_bstride, A.h0_bstride, A.N,
+                         A.D, red);
+      if (A.lindblad) hipLaunchKernelGGL(tg_hnorm_kernel, dim3(1), dim3(64), 0, st, A.clp, 0L, 1, A.Dm, red + 2);
+      TG_TRY(hipGetLastError());
+      std::vector<unsigned long long> hr(64);
+      TG_TRY(hipMemcpyAsync(hr.data(), red, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+      TG_TRY(hipStreamSynchronize(st));
+      double h1, hi, c1;
+      memcpy(&h1, &hr[0], 8);
+      memcpy(&hi, &hr[1], 8);
+      memcpy(&c1, &hr[2], 8);
+      bound = A.lindblad ? A.dt * (h1 + hi + c1) : A.dt * h1;
+    }
+    int s18 = 0;
+    {
+      double p = C3P_T18_THETA;
+      while (p < bound && s18 < 60) {
+        p *= 2.0;
+        ++s18;
+      }
+    }
+    TG_TRY(hipMemsetAsync(mus, 0, 4 * (size_t)Bc * sizeof(double), st));
+    const dim3 eg(ebl, (unsigned)nb);
+    dim3 gg = ggrid;
+    gg.z = (unsigned)nb;
+    auto M = [&](int slot) -> double* { return mats + (long)slot * MS; };
+    auto gemm = [&](int a, int b, int add, int c) {
+      hipLaunchKernelGGL(tg_gemm_kernel, gg, dim3(256), 0, st, M(a), M(b), add >= 0 ? M(add) : nullptr, M(c), 2 * g.DPR, g.DPC,
+                         (long)M_COUNT * MS);
+    };
+    int ucur = M_U0;
+    for (int n = 0; n < A.N; ++n) {
+      AsmArgs P = {};
+      P.tables = tables;
+      P.meta = meta;
+      P.tab_per_sample = per_sample ? 1 : 0;
+      P.signals = A.signals;
+      P.b0 = b0;
+      P.n = n;
+      P.K = K;
+      P.N = A.N;
+      if (A.per_slice) {
+        P.hs = A.h0;
+        P.hs_bstride = A.h0_bstride;
+      }
+      P.clp = A.clp;
+      P.lindblad = A.lindblad;
+      P.Dh = A.D;
+      P.Dm = A.Dm;
+      P.dt = A.dt;
+      P.scale = ldexp(1.0, -s18);
+      P.X = mats;
+      P.mus = mus;
+      P.mun = mun;
+      hipLaunchKernelGGL(tg_assemble_kernel, eg, dim3(256), 0, st, P, g.DPR, g.DPC);
+      gemm(M_X, M_X, -1, M_A2);
+      gemm(M_X, M_A2, -1, M_A3);
+      gemm(M_A3, M_A3, -1, M_A6);
+      hipLaunchKernelGGL(tg_combo_kernel, eg, dim3(256), 0, st, mats, A.Dm, g.DPR, g.DPC);
+      gemm(M_T1, M_T2, M_T3, M_A2);                                                   // A9 = B1 B5 + B4
+      hipLaunchKernelGGL(tg_add_kernel, eg, dim3(256), 0, st, mats, M_T4, M_A2, M_A3, MS);  // B3 + A9
+      gemm(M_A3, M_A2, M_X, M_A6);                                                    // T18 = (B3 + A9) A9 + B2
+      int e = M_A6, o = M_T1;
+      for (int it = 0; it < s18; ++it) {
+        gemm(e, e, -1, o);
+        std::swap(e, o);
+      }
+      if (A.dUs_out)
+        hipLaunchKernelGGL(tg_out_kernel, dim3((unsigned)(((long)A.Dm * A.Dm + 255) / 256), (unsigned)nb), dim3(256), 0, st, mats, e,
+                           mun, (const double*)nullptr, A.dUs_out + ((long)b0 * A.N + n) * A.Dm * A.Dm, (long)A.N * A.Dm * A.Dm, A.Dm,
+                           g.DPR, g.DPC);
+      if (n == 0) {
+        // U <- E: a product with the identity would cost a launch too; copy instead
+        for (int b = 0; b < nb; ++b)
+          TG_TRY(hipMemcpyAsync(mats + ((long)b * M_COUNT + ucur) * MS, mats + ((long)b * M_COUNT + e) * MS, MS * sizeof(double),
+                                hipMemcpyDeviceToDevice, st));
+      } else {
+        const int unew = ucur == M_U0 ? M_U1 : M_U0;
+        gemm(e, ucur, -1, unew);
+        ucur = unew;
+      }
+      TG_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(tg_out_kernel, dim3((unsigned)(((long)A.Dm * A.Dm + 255) / 256), (unsigned)nb), dim3(256), 0, st, mats, ucur, mus,
+                       A.fr_phase ? A.fr_phase + (long)b0 * A.Dm : nullptr, A.U_out + (long)b0 * A.Dm * A.Dm, (long)A.Dm * A.Dm, A.Dm,
+                       g.DPR, g.DPC);
+    TG_TRY(hipGetLastError());
+  }
+  return 0;
+}

@@ -350,3 +350,80 @@ def test_two_streams_share_the_workspace_safely(prop):
     torch.cuda.synchronize()
     for ua, ub in outs:
         assert torch.equal(ua, ref_a) and torch.equal(ub, ref_b)
+
+
+# --------------------------------------------------------------------------
+# c3p_tiled.hip: matrices in HBM, one batched MFMA GEMM per product (Dm >= 93; supplied generators at Dm >= 41)
+# --------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("D,B,N,K,scale", [(93, 2, 4, 2, 0.01), (100, 3, 7, 2, 0.02), (128, 2, 5, 1, 0.05), (200, 2, 3, 2, 0.01), (257, 1, 2, 1, 0.004)])
+def test_tiled_unitary_dimensions(prop, D, B, N, K, scale):
+    """Beyond the on-chip kernels (and beyond the old Dm <= 256 cap): padded / unpadded tile edges, frame phases, dUs."""
+    from c3_amd import _lib
+
+    rng = np.random.default_rng(D)
+    h0 = _rand_herm(rng, D, scale)
+    hks = np.stack([_rand_herm(rng, D, scale / 2) for _ in range(K)])
+    sig = rng.uniform(-1, 1, size=(B, K, N))
+    ph = rng.uniform(0, 6, size=(B, D))
+    r = prop.propagate_batch(h0, hks, sig, 1.0, fr_phase=ph, want_dUs=True)
+    assert _lib.last_kernel() == "mfma"
+    ref = o.propagate_batch(h0, hks, sig, 1.0, fr_phase=ph)
+    assert fro_max(r["U"], ref) < TOL
+    assert np.abs(np.asarray(r["dUs"][B - 1]) - o.tf_propagation_vectorized(h0, hks, sig[B - 1], 1.0)).max() < 1e-12
+
+
+def test_tiled_per_sample_operators_and_chunks(prop):
+    """Per-sample drift Hamiltonians (one table set per sample)."""
+    rng = np.random.default_rng(3)
+    D, B, N, K = 96, 3, 4, 1
+    h0 = np.stack([_rand_herm(rng, D, 0.03) for _ in range(B)])
+    hks = np.stack([_rand_herm(rng, D, 0.01) for _ in range(K)])
+    sig = rng.uniform(-1, 1, size=(B, K, N))
+    r = prop.propagate_batch(h0, hks, sig, 1.0)
+    for b in range(B):
+        assert np.linalg.norm(np.asarray(r["U"][b]) - o.pwc_arrays(h0[b], hks, sig[b], 1.0)["U"]) < TOL
+
+
+@pytest.mark.parametrize("D", [45, 120])
+def test_tiled_supplied_generators(prop, D):
+    """Branch B of pwc (propagation.py:295-308) above the mid-D kernel."""
+    rng = np.random.default_rng(D)
+    H = np.stack([np.stack([_rand_herm(rng, D, 0.03) for _ in range(5)]) for _ in range(2)])
+    r = prop.propagate_batch(H, None, None, 1.0, want_dUs=True)
+    for b in range(2):
+        U = np.eye(D, dtype=complex)
+        for n in range(5):
+            E = o.expm(-1j * H[b, n])
+            assert np.abs(np.asarray(r["dUs"][b][n]) - E).max() < 1e-12
+            U = E @ U
+        assert np.linalg.norm(np.asarray(r["U"][b]) - U) < TOL
+
+
+def test_tiled_lindblad_three_qutrits_729(prop):
+    """The reference's own 'takes way too long' case (test/test_tunable_coupler.py:406-418): three qutrits with
+    collapse operators, 729 x 729 superoperators -- two slices against the oracle, trace preservation."""
+    B, N, K = 2, 2, 2
+    wl = workloads.make_workload(3, B=B, N=N)
+    a = workloads.annihilators((3, 3, 3))
+    T = workloads.dressing_transform(workloads.bare_drift((3, 3, 3), (5.0e9, 5.6e9, 6.2e9), (-210e6, -240e6, -235e6), {(0, 1): 20e6, (0, 2): 20e6, (1, 2): 20e6}))
+    col = np.stack([workloads.dress(workloads.qubit_collapse_op(a[q], (27e-6, 23e-6, 25e-6)[q], (39e-6, 31e-6, 35e-6)[q]), T) for q in range(3)])
+    r = prop.propagate_batch(wl.h0, wl.hks[:K], wl.signals[:, :K], wl.dt, col_ops=col, lindbladian=True)
+    U = np.asarray(r["U"])
+    assert U.shape == (B, 729, 729)
+    ref = o.propagate_batch(wl.h0, wl.hks[:K], wl.signals[:, :K], wl.dt, col_ops=col, lindbladian=True)
+    assert fro_max(U, ref) < TOL
+    vI = np.eye(27).ravel()
+    assert np.abs(np.einsum("i,bij->bj", vI, U) - vI).max() < 1e-11
+
+
+def test_tiled_lindblad_per_slice_hamiltonians(prop):
+    """Lindblad propagation with supplied per-slice Hamiltonians (controllability off + lindbladian) at D = 7."""
+    rng = np.random.default_rng(2)
+    D, N = 7, 6
+    H = np.stack([_rand_herm(rng, D, 0.05) for _ in range(N)])
+    col = np.stack([0.04 * (rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))])
+    r = prop.propagate_batch(H, None, None, 1.0, col_ops=col, lindbladian=True)
+    ref = o.pwc_arrays(H, None, None, 1.0, col_ops=col, lindbladian=True)["U"]
+    assert np.linalg.norm(np.asarray(r["U"][0]) - ref) < TOL
