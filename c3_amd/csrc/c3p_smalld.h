@@ -46,6 +46,8 @@ struct SmallGradArgs {
   double* grad;           // [B,K,N]
   cplx* zout;             // [B,N,Dm,Dm] or null: Z_n, the cotangent of G_n = -i dt H_n
   int B, K, N, Dm, S, Lmax;
+  // the real-Hamiltonian sweep (smalld_grad_real_kernel) has taken the samples it can: this launch skips them
+  int skip_real;
 };
 
 struct PrepArgs {

@@ -24,6 +24,7 @@
 //   U <- E U ;  the scalar factors e^{mu_n} are summed and applied once per segment.
 #include <type_traits>
 
+#include <cstdlib>
 #include "c3p_common.h"
 #include "c3p_kernels.h"
 #include "c3p_smalld.h"
@@ -1270,6 +1271,20 @@ __device__ __forceinline__ void mat_zero(double (&m)[SD<D>::NBI][SD<D>::NJ]) {
     for (int J = 0; J < SD<D>::NJ; ++J) m[I][J] = 0.0;
 }
 
+// squarings of the real-Hamiltonian backward sweep (smalld_grad_real_kernel below): degree 16 / 17, theta_16 = 0.816
+constexpr int SDG_MAXS = 3;
+
+template <int D>
+__device__ __forceinline__ int sdg_real_squarings(double nrm) {
+  int ps = 0;
+  double p = 8.16e-1;
+  while (p < nrm && ps < 40) {
+    p *= 2.0;
+    ++ps;
+  }
+  return ps;
+}
+
 template <int D>
 __global__ void __launch_bounds__(64, 1) smalld_grad_kernel(SmallGradArgs A) {
   using C = SD<D>;
@@ -1334,6 +1349,12 @@ __global__ void __launch_bounds__(64, 1) smalld_grad_kernel(SmallGradArgs A) {
     }
   }
   ps = __builtin_amdgcn_readfirstlane(ps);
+  if (A.skip_real) {  // the real-Hamiltonian sweep has taken this wave's chains (same tables, same norm bound: same decision)
+    bool realH = true;
+    for (int k = 0; k <= K; ++k) realH = realH && (tab[k * (MAT + 4) + MAT + 3] == 0.0);
+    if (__builtin_amdgcn_readfirstlane((int)realH) != 0 && __builtin_amdgcn_readfirstlane(sdg_real_squarings<D>(nrm)) <= SDG_MAXS)
+      return;
+  }
   const double scale = ldexp(1.0, -ps);
   __syncthreads();
 
@@ -1487,6 +1508,393 @@ __global__ void __launch_bounds__(64, 1) smalld_grad_kernel(SmallGradArgs A) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward sweep for REAL Hamiltonians (the case of every dressed lab-frame transmon model): reverse mode through the
+// real cos / sin evaluation of the forward kernel instead of the forward-mode pair evaluation of complex T18 above.
+// With X = -iY (Y real symmetric), dU = C - iS, and the adjoint state carried TRANSPOSED, N = M^T:
+//   R = dU N = (M dU)^T  ->  the cotangents of C and S are REAL and may be symmetrised:  C_bar = sym Re R, S_bar = -sym Im R;
+//   every adjoint of the symmetric stage is a symmetrised product of symmetric matrices, 2 sym(A_bar B) = A_bar B + B A_bar
+//   (two upper-triangle products whose left operands come from registers, as in the forward kernel);
+//   grad[k, n] = scale <Y_bar, Y_k> + Re(mu_k conj(tr N));   N <- R conj(dU)  (the only product with a general LEFT operand:
+//   R goes through a real LDS image).
+// ~600 MFMAs per slice at D = 9 against ~1500 of the complex pair evaluation.  Always the degree-16 / 17 polynomials
+// (theta_16 = 0.816) with up to SDG_MAXS squarings; samples that are not real, or need more squarings, are left to the
+// complex kernel (same norm bound, same decision).
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(64, 1) smalld_grad_real_kernel(SmallGradArgs A) {
+  using C = SD<D>;
+  constexpr int W = C::W, MAT = C::MAT;
+  constexpr int NB = RD<D>::NB, WR = 4 * NB + 1, RIMG = 4 * NB * WR;
+  typedef double RMat[NB][NB];
+  const int lane = threadIdx.x;
+  LanePos lp;
+  lp.r = lane >> 4;
+  lp.b = (lane >> 2) & 3;
+  lp.c = lane & 3;
+  lp.idx16 = lp.r * 4 + lp.c;
+  const int K = A.K;
+  double* tab = c3p_sd_lds;
+  double* rimg = tab + (1 + K) * (MAT + 4);  // per chain: Re R, Im R as real row-major images (row stride WR)
+  double* sg = rimg + 4 * 2 * RIMG;
+
+  const long chain = (long)blockIdx.x * 4 + lp.b;
+  const long nchains = (long)A.B * A.S;
+  const bool valid = chain < nchains;
+  const long cc = valid ? chain : nchains - 1;
+  const int sample = (int)(cc / A.S);
+  const int seg = (int)(cc - (long)sample * A.S);
+  const int n0 = (int)(((long)seg * A.N) / A.S);
+  const int n1 = (int)(((long)(seg + 1) * A.N) / A.S);
+  const int len = n1 - n0;
+
+  const double* gt0 = A.tables + (long)(A.tab_per_sample ? sample : 0) * (1 + K) * (MAT + 4);
+  for (int e = lane; e < (1 + K) * (MAT + 4); e += 64) tab[e] = gt0[e];
+  __syncthreads();
+  double nrm = tab[MAT + 2];
+  for (int k = 0; k < K; ++k) {
+    const double* s = A.signals + ((long)sample * K + k) * A.N + n0;
+    double cmax = 0.0;
+    for (int t = lp.idx16; t < A.Lmax; t += 16) {
+      const double v = (valid && t < len) ? s[t] : 0.0;
+      sg[(lp.b * K + k) * A.Lmax + t] = v;
+      cmax = fmax(cmax, fabs(v));
+    }
+    cmax = fmax(cmax, __shfl_xor(cmax, 1));
+    cmax = fmax(cmax, __shfl_xor(cmax, 2));
+    cmax = fmax(cmax, __shfl_xor(cmax, 16));
+    cmax = fmax(cmax, __shfl_xor(cmax, 32));
+    nrm = fma(cmax, tab[(k + 1) * (MAT + 4) + MAT + 2], nrm);
+  }
+  nrm = fmax(nrm, __shfl_xor(nrm, 4));
+  nrm = fmax(nrm, __shfl_xor(nrm, 8));
+  nrm = readfirstlane_f64(nrm);
+  bool realH = true;
+  for (int k = 0; k <= K; ++k) realH = realH && (tab[k * (MAT + 4) + MAT + 3] == 0.0);
+  // (without per-sample tables the four chains of a wave may belong to different samples, but then all samples share
+  // the tables; with per-sample tables S % 4 == 0 and the wave has one sample)
+  const int ps = __builtin_amdgcn_readfirstlane(sdg_real_squarings<D>(nrm));
+  if (!(__builtin_amdgcn_readfirstlane((int)realH) != 0) || ps > SDG_MAXS) return;
+  const double scale = ldexp(1.0, -ps);
+  __syncthreads();
+
+  const int swap_lane = 16 * lp.c + 4 * lp.b + lp.r;
+  const int tail_lane = 16 * lp.c + 4 * lp.b;
+  const int row0_lane = 4 * lp.b + lp.c;
+  int yo[NB];
+  double ymask[NB];
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+    const bool ok = 4 * I + lp.r < D;
+    yo[I] = (2 * (ok ? 4 * I + lp.r : 0) + 1) * W + lp.c;
+    ymask[I] = ok ? 1.0 : 0.0;
+  }
+  auto zero = [&](RMat& m) {
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) m[I][J] = 0.0;
+  };
+  // acc(upper) += f (A B + B A) for symmetric A, B (operand tiles filled)
+  auto sym2 = [&](const RMat& Am, const RMat& Bm, RMat& acc) {
+    mm_sym<D>(Am, Bm, acc, tail_lane);
+    mm_sym<D>(Bm, Am, acc, tail_lane);
+  };
+  auto scale_fill = [&](RMat& m, double f) {  // upper tiles *= f, then mirror the operand tiles
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = I; J < NB; ++J) m[I][J] *= f;
+    sym_fill<D>(m, swap_lane);
+  };
+
+  // N = M^T at the end of this segment
+  RMat Nr, Ni;
+  {
+    const double* src = reinterpret_cast<const double*>(A.Mb) + cc * D * D * 2;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) {
+        const int row = 4 * I + lp.r, col = 4 * J + lp.c;
+        const bool ok = valid && row < D && col < D;
+        Nr[I][J] = ok ? src[(col * D + row) * 2 + 0] : 0.0;
+        Ni[I][J] = ok ? src[(col * D + row) * 2 + 1] : 0.0;
+      }
+  }
+
+  for (int t = A.Lmax - 1; t >= 0; --t) {
+    const bool act = valid && t < len;
+    const double sc = act ? scale : 0.0;
+    // ---- forward: Y, W = Y^2, ..., cos Y, sin Y (as in smalld_chain_kernel, degree 16 / 17) ----
+    RMat Y;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      const double f = -sc * ymask[I];
+#pragma unroll
+      for (int J = sym_j0<D>(I); J < NB; ++J) Y[I][J] = f * lds_ld(tab + yo[I] + J * 4);
+    }
+    for (int k = 0; k < K; ++k) {
+      const double ck = sc * sg[(lp.b * K + k) * A.Lmax + t];
+      const double* tk = tab + (k + 1) * (MAT + 4);
+#pragma unroll
+      for (int I = 0; I < NB; ++I) {
+        const double f = -ck * ymask[I];
+#pragma unroll
+        for (int J = sym_j0<D>(I); J < NB; ++J) Y[I][J] = fma(f, lds_ld(tk + yo[I] + J * 4), Y[I][J]);
+      }
+    }
+    RMat W1, W2, W3, W4, acc, acs, Cm, Sp, S0;
+    zero(W1), zero(W2), zero(W3), zero(W4), zero(S0);
+    mm_sym<D>(Y, Y, W1, tail_lane);
+    sym_fill<D>(W1, swap_lane);
+    mm_sym<D>(W1, W1, W2, tail_lane);
+    sym_fill<D>(W2, swap_lane);
+    mm_sym<D>(W1, W2, W3, tail_lane);
+    mm_sym<D>(W2, W2, W4, tail_lane);
+    sym_fill<D>(W3, swap_lane);
+    sym_fill<D>(W4, swap_lane);
+    rcomb<D, true>(acc, c3p_inv_fact[8], -c3p_inv_fact[10], c3p_inv_fact[12], -c3p_inv_fact[14], W1, W2, W3, lp);
+    rcomb<D, true>(acs, c3p_inv_fact[9], -c3p_inv_fact[11], c3p_inv_fact[13], -c3p_inv_fact[15], W1, W2, W3, lp);
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = sym_j0<D>(I); J < NB; ++J) {
+        acc[I][J] = fma(c3p_inv_fact[16], W4[I][J], acc[I][J]);
+        acs[I][J] = fma(c3p_inv_fact[17], W4[I][J], acs[I][J]);
+      }
+    rcomb<D, true, true>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], -c3p_inv_fact[6], W1, W2, W3, lp);
+    rcomb<D, true, true>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7], W1, W2, W3, lp);
+    mm_sym2<D>(W4, acc, Cm, acs, Sp, tail_lane);
+    sym_fill<D>(Cm, swap_lane);
+    sym_fill<D>(Sp, swap_lane);
+    mm_sym<D>(Y, Sp, S0, tail_lane);
+    sym_fill<D>(S0, swap_lane);
+    // squarings, every level kept for the way back: C' = (C - S)(C + S), S' = 2 S C
+    RMat Cl[SDG_MAXS], Sl[SDG_MAXS], Cf, Sf;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = sym_j0<D>(I); J < NB; ++J) {
+        Cf[I][J] = Cm[I][J];
+        Sf[I][J] = S0[I][J];
+      }
+#pragma unroll
+    for (int j = 0; j < SDG_MAXS; ++j)
+      if (j < ps) {
+        RMat Dm, Sm, C2, SC;
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+          for (int J = sym_j0<D>(I); J < NB; ++J) {
+            Cl[j][I][J] = Cf[I][J];
+            Sl[j][I][J] = Sf[I][J];
+            Dm[I][J] = Cf[I][J] - Sf[I][J];
+            Sm[I][J] = Cf[I][J] + Sf[I][J];
+            C2[I][J] = SC[I][J] = 0.0;
+          }
+        mm_sym<D>(Dm, Sm, C2, tail_lane);
+        mm_sym<D>(Sf, Cf, SC, tail_lane);
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+          for (int J = I; J < NB; ++J) {
+            Cf[I][J] = C2[I][J];
+            Sf[I][J] = 2.0 * SC[I][J];
+          }
+        sym_fill<D>(Cf, swap_lane);
+        sym_fill<D>(Sf, swap_lane);
+      }
+    sym_fill_rest<D>(Cf, swap_lane);  // the whole matrices: right operands of the update of N
+    sym_fill_rest<D>(Sf, swap_lane);
+    // ---- R = dU N = (C - iS)(Nr + i Ni) with three real products ----
+    RMat Rr, Ri;
+    {
+      RMat Ps, Nd, P1, P2, P3;
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) {
+          if (J >= sym_j0<D>(I)) Ps[I][J] = Cf[I][J] + Sf[I][J];
+          Nd[I][J] = Ni[I][J] - Nr[I][J];
+          P1[I][J] = P2[I][J] = P3[I][J] = 0.0;
+        }
+      mm_symA<D>(Cf, Nr, P1, row0_lane, 1.0);
+      mm_symA<D>(Sf, Ni, P2, row0_lane, 1.0);
+      mm_symA<D>(Ps, Nd, P3, row0_lane, 1.0);
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) {
+          Rr[I][J] = P1[I][J] + P2[I][J];
+          Ri[I][J] = (P3[I][J] + P1[I][J]) - P2[I][J];
+        }
+    }
+    // tr N (= tr M): the trace-shift part of the gradient
+    double trr = 0.0, tri = 0.0;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      const bool on = (lp.r == lp.c) && (4 * I + lp.r < D);
+      trr += on ? Nr[I][I] : 0.0;
+      tri += on ? Ni[I][I] : 0.0;
+    }
+    // the images of R for the update of N (written now, read at the end of the slice)
+    wave_sync();
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) {
+        rimg[(lp.b * 2 + 0) * RIMG + (4 * I + lp.r) * WR + 4 * J + lp.c] = Rr[I][J];
+        rimg[(lp.b * 2 + 1) * RIMG + (4 * I + lp.r) * WR + 4 * J + lp.c] = Ri[I][J];
+      }
+    wave_sync();
+    // ---- cotangents of cos / sin: C_bar = sym Re R, S_bar = -sym Im R (upper tiles, then the operand tiles) ----
+    RMat Cb, Sb;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = I; J < NB; ++J) {
+        Cb[I][J] = 0.5 * (Rr[I][J] + __shfl(Rr[J][I], swap_lane));
+        Sb[I][J] = -0.5 * (Ri[I][J] + __shfl(Ri[J][I], swap_lane));
+      }
+    sym_fill<D>(Cb, swap_lane);
+    sym_fill<D>(Sb, swap_lane);
+    // ---- back through the squarings ----
+#pragma unroll
+    for (int j = SDG_MAXS - 1; j >= 0; --j)
+      if (j < ps) {
+        RMat nC, nS, tmp;
+        zero(nC), zero(nS), zero(tmp);
+        sym2(Cb, Cl[j], nC);
+        sym2(Sb, Sl[j], nC);
+        sym2(Sb, Cl[j], nS);
+        sym2(Cb, Sl[j], tmp);
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+          for (int J = I; J < NB; ++J) {
+            Cb[I][J] = nC[I][J];
+            Sb[I][J] = nS[I][J] - tmp[I][J];
+          }
+        sym_fill<D>(Cb, swap_lane);
+        sym_fill<D>(Sb, swap_lane);
+      }
+    // ---- back through S = Y Sp, Cm = Cm0 + W4 acc, Sp = Sp0 + W4 acs and the powers ----
+    RMat Yb, Spb, W4b, accb, acsb;
+    zero(Yb), zero(Spb), zero(W4b), zero(accb), zero(acsb);
+    sym2(Sb, Sp, Yb);      // 2 x sym(S_bar Sp)
+    sym2(Sb, Y, Spb);      // 2 x sym(S_bar Y)
+    scale_fill(Spb, 0.5);
+    sym2(Cb, acc, W4b);
+    sym2(Spb, acs, W4b);   // 2 x
+    sym2(W4, Cb, accb);
+    sym2(W4, Spb, acsb);
+    RMat W1b, W2b, W3b;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = I; J < NB; ++J) {
+        const double ab = 0.5 * accb[I][J], sb = 0.5 * acsb[I][J], cb = Cb[I][J], pb = Spb[I][J];
+        W1b[I][J] = -(c3p_inv_fact[2] * cb + c3p_inv_fact[3] * pb + c3p_inv_fact[10] * ab + c3p_inv_fact[11] * sb);
+        W2b[I][J] = c3p_inv_fact[4] * cb + c3p_inv_fact[5] * pb + c3p_inv_fact[12] * ab + c3p_inv_fact[13] * sb;
+        W3b[I][J] = -(c3p_inv_fact[6] * cb + c3p_inv_fact[7] * pb + c3p_inv_fact[14] * ab + c3p_inv_fact[15] * sb);
+        W4b[I][J] = 0.5 * W4b[I][J] + c3p_inv_fact[16] * ab + c3p_inv_fact[17] * sb;
+      }
+    sym_fill<D>(W4b, swap_lane);
+    sym_fill<D>(W3b, swap_lane);
+    {
+      RMat t2, t1;
+      zero(t2), zero(t1);
+      sym2(W4b, W2, W2b);  // W4 = W2^2
+      sym2(W3b, W1, t2);   // W3 = W1 W2: 2 x sym(W3_bar W1) -> W2_bar, 2 x sym(W3_bar W2) -> W1_bar
+      sym2(W3b, W2, t1);
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = I; J < NB; ++J) {
+          W2b[I][J] = fma(0.5, t2[I][J], W2b[I][J]);
+          W1b[I][J] = fma(0.5, t1[I][J], W1b[I][J]);
+        }
+    }
+    sym_fill<D>(W2b, swap_lane);
+    sym2(W2b, W1, W1b);  // W2 = W1^2
+    sym_fill<D>(W1b, swap_lane);
+    {
+      RMat t0;
+      zero(t0);
+      sym2(W1b, Y, t0);  // W1 = Y^2
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = I; J < NB; ++J) Yb[I][J] = fma(0.5, Yb[I][J], t0[I][J]);
+    }
+    // ---- grad[k] = scale <Y_bar, Y_k> (full-matrix inner product of symmetric matrices) + Re(mu_k conj(tr N)) ----
+    for (int k = 0; k < K; ++k) {
+      const double* tk = tab + (k + 1) * (MAT + 4);
+      double part = 0.0;
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = I; J < NB; ++J) {
+          const double yk = -ymask[I] * lds_ld(tk + yo[I] + J * 4);
+          part = fma((I == J ? sc : 2.0 * sc) * Yb[I][J], yk, part);
+        }
+      part = fma(tk[MAT + 0], trr, fma(tk[MAT + 1], tri, part));
+      part += __shfl_xor(part, 1);
+      part += __shfl_xor(part, 2);
+      part += __shfl_xor(part, 16);
+      part += __shfl_xor(part, 32);
+      if (act && lp.idx16 == 0) A.grad[((long)sample * K + k) * A.N + n0 + t] = part;
+    }
+    // ---- N <- R conj(dU) = (Rr + i Ri)(C + iS): general left operand from its LDS image, three real products ----
+    {
+      RMat Ps, Q1, Q2, Q3;
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) {
+          Ps[I][J] = Cf[I][J] + Sf[I][J];
+          Q1[I][J] = Q2[I][J] = Q3[I][J] = 0.0;
+        }
+      const double* ir = rimg + (lp.b * 2 + 0) * RIMG;
+      const double* ii = rimg + (lp.b * 2 + 1) * RIMG;
+#pragma unroll
+      for (int Kk = 0; Kk < NB; ++Kk)
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+          const double fr = lds_ld(ir + (4 * I + lp.c) * WR + 4 * Kk + lp.r);  // A layout: lane (r, c) <- R[4I + c][4K + r]
+          const double fi = lds_ld(ii + (4 * I + lp.c) * WR + 4 * Kk + lp.r);
+          const double fs = fr + fi;
+#pragma unroll
+          for (int J = 0; J < NB; ++J) {
+            Q1[I][J] = mfma4(fr, Cf[Kk][J], Q1[I][J]);
+            Q2[I][J] = mfma4(fi, Sf[Kk][J], Q2[I][J]);
+            Q3[I][J] = mfma4(fs, Ps[Kk][J], Q3[I][J]);
+          }
+        }
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) {
+          Nr[I][J] = Q1[I][J] - Q2[I][J];
+          Ni[I][J] = (Q3[I][J] - Q1[I][J]) - Q2[I][J];
+        }
+    }
+  }
+}
+
+template <int D>
+hipError_t launch_grad_real_t(const SmallGradArgs& A, hipStream_t st) {
+  using C = SD<D>;
+  constexpr int NB = RD<D>::NB, RIMG = 4 * NB * (4 * NB + 1);
+  const long nchains = (long)A.B * A.S;
+  const unsigned grid = (unsigned)((nchains + 3) / 4);
+  const size_t lds = (size_t)((1 + A.K) * (C::MAT + 4) + 8 * RIMG + 4 * A.K * A.Lmax) * sizeof(double);
+  if (lds > 60 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(smalld_grad_real_kernel<D>, dim3(grid), dim3(64), lds, st, A);
+  return hipGetLastError();
+}
+
 template <int D>
 hipError_t launch_grad_t(const SmallGradArgs& A, hipStream_t st) {
   using C = SD<D>;
@@ -1542,8 +1950,21 @@ hipError_t c3p_launch_smalld_chain(const SmallArgs& A, hipStream_t st) {
   SD_DISPATCH(launch_chain_t, A, st)
 }
 
-hipError_t c3p_launch_smalld_grad(const SmallGradArgs& A, hipStream_t st) {
-  const int Dm = A.Dm;
+hipError_t c3p_launch_smalld_grad(const SmallGradArgs& A_, hipStream_t st) {
+  const int Dm = A_.Dm;
+  SmallGradArgs A = A_;
+  A.skip_real = 0;
+  // real Hamiltonians first (reverse mode through the cos / sin evaluation), then the general sweep for the rest; the
+  // per-slice generator cotangents (zout) only exist in the general sweep
+  if (A.zout == nullptr && !getenv("C3P_NO_REAL_GRAD")) {
+    hipError_t e = hipSuccess;
+    {
+      auto go = [&]() -> hipError_t { SD_DISPATCH(launch_grad_real_t, A, st) };
+      e = go();
+    }
+    if (e != hipSuccess) return e;
+    A.skip_real = 1;
+  }
   SD_DISPATCH(launch_grad_t, A, st)
 }
 

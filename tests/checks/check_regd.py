@@ -1,6 +1,6 @@
 """GPU check + timing of the register-resident kernel (c3p_regd.hip) against the oracle and the arena kernel.
 
-    python tools/check_regd.py [--time]
+    python tests/checks/check_regd.py [--time]
 """
 import os
 import sys
@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 
 from c3_amd import propagation, workloads, _lib  # noqa: E402

@@ -1,7 +1,7 @@
 """GPU check + timing of the tiled large-matrix path (c3p_tiled.hip) against the oracle."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from c3_amd import propagation, workloads, _lib
 from oracle import c3_oracle as o

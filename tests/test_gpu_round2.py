@@ -427,3 +427,33 @@ def test_tiled_lindblad_per_slice_hamiltonians(prop):
     r = prop.propagate_batch(H, None, None, 1.0, col_ops=col, lindbladian=True)
     ref = o.pwc_arrays(H, None, None, 1.0, col_ops=col, lindbladian=True)["U"]
     assert np.linalg.norm(np.asarray(r["U"][0]) - ref) < TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# real-Hamiltonian backward sweep (smalld_grad_real_kernel): reverse mode through cos Y / sin Y
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("amp", [3e9, 3e10, 2e11, 8e11])
+@pytest.mark.parametrize("D", list(range(2, 13)))
+def test_vjp_real_hamiltonian_small_dims(prop, D, amp, monkeypatch):
+    """every template instance, 0 .. 3 squarings and the hand-over to the general sweep above that; against the
+    FD-pinned oracle gradient and against the general (complex T18 pair) sweep on the same inputs"""
+    rng = np.random.default_rng(100 * D + int(np.log10(amp)))
+    B, K, N = 3, 2, 29
+
+    def sym():
+        a = rng.normal(size=(D, D))
+        return (a + a.T) / 2
+
+    h0 = np.stack([sym() * amp for _ in range(B)]).astype(np.complex128)
+    hks = np.stack([sym() for _ in range(K)]).astype(np.complex128)
+    sig = rng.normal(size=(B, K, N)) * 2e9
+    Ubar = rng.normal(size=(B, D, D)) + 1j * rng.normal(size=(B, D, D))
+    g = np.asarray(prop.propagate_batch_vjp(h0, hks, sig, 1e-11, Ubar))
+    monkeypatch.setenv("C3P_NO_REAL_GRAD", "1")
+    g0 = np.asarray(prop.propagate_batch_vjp(h0, hks, sig, 1e-11, Ubar))
+    monkeypatch.delenv("C3P_NO_REAL_GRAD")
+    for b in range(B):
+        want = o.pwc_signal_gradient(h0[b], hks, sig[b], 1e-11, Ubar[b])
+        assert np.abs(g[b] - want).max() < 1e-10 * np.abs(want).max()
+    assert np.abs(g - g0).max() < 1e-10 * np.abs(g0).max()
