@@ -403,7 +403,8 @@ int run_vjp_midd(DeviceWs* w, GradArgs& G, hipStream_t st) {
   const long smax = N / 8 > 1 ? N / 8 : 1;
   if (S > smax) S = smax;
   if (S < 1) S = 1;
-  auto lds_need = [&](long s) { return 4 * img_bytes + (size_t)K * ((N + s - 1) / s) * sizeof(double); };
+  (void)img_bytes;
+  auto lds_need = [&](long s) { return c3p_midd_grad_image_bytes(D) + (size_t)K * ((N + s - 1) / s) * sizeof(double); };
   while (lds_need(S) > (size_t)150 * 1024 && S < N) ++S;
   if (lds_need(S) > (size_t)150 * 1024) return 1;
   const bool per_sample = (G.h0_bstride != 0) || (G.hks_bstride != 0);

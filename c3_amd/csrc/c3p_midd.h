@@ -31,6 +31,8 @@ struct MidGradArgs {
   double* grad;           // [B,K,N]
   cplx* zout;             // [B,N,Dm,Dm] or null: Z_n, the cotangent of G_n = -i dt H_n
   int B, K, N, Dm, S, Lmax;
+  // the real-Hamiltonian sweep (midd_grad_real_kernel) has taken the chains it can: this launch skips them
+  int skip_real;
 };
 
 struct MidPrepArgs {
@@ -49,6 +51,8 @@ struct MidPrepArgs {
 bool c3p_midd_geometry(int Dm, int* nig, int* nj, int* w);
 size_t c3p_midd_table_doubles(int Dm, int K);
 size_t c3p_midd_lds_bytes(int Dm, int K, int Lmax);
+// LDS bytes of the images of the backward sweeps (the larger of the general and the real-Hamiltonian kernel)
+size_t c3p_midd_grad_image_bytes(int Dm);
 hipError_t c3p_launch_midd_chain(const MidArgs& A, hipStream_t st);
 hipError_t c3p_launch_midd_real(const MidArgs& A, hipStream_t st);  // real-Hamiltonian instance only (c3p_launch_midd_chain calls it)
 hipError_t c3p_launch_midd_grad(const MidGradArgs& A, hipStream_t st);

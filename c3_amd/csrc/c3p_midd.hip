@@ -21,6 +21,7 @@
 // (the block polynomials B_j are lane-local), so only three LDS images are live at any time:
 // buf0 = X then P/E, buf1 = X^2 then X^3 then U, buf2 = X^4  (73 KB at D = 36 -> two
 // workgroups = two waves per SIMD per CU).  Same plan logic as the small-D kernel.
+#include <cstdlib>
 #include <type_traits>
 
 #include "c3p_common.h"
@@ -1403,6 +1404,20 @@ __device__ __forceinline__ void midd_grad_body(const MidGradArgs& A, const MidCo
   }
 }
 
+// real-Hamiltonian backward sweep (midd_grad_real_kernel below): squarings kept, image slots, scaling rule (theta_16)
+constexpr int MGR_MAXS = 2;
+constexpr int MGR_SLOTS = 8;
+
+__device__ __forceinline__ int mgr_squarings(double nrm) {
+  int ps = 0;
+  double p = 8.16e-1;
+  while (p < nrm && ps < 40) {
+    p *= 2.0;
+    ++ps;
+  }
+  return ps;
+}
+
 template <int NIG, int NJ, int W>
 __global__ void __launch_bounds__(256, 1) midd_grad_kernel(MidGradArgs A) {
   using C = MD<NIG, NJ>;
@@ -1465,6 +1480,11 @@ __global__ void __launch_bounds__(256, 1) midd_grad_kernel(MidGradArgs A) {
     }
   }
   cm.ps = __builtin_amdgcn_readfirstlane(ps);
+  if (A.skip_real) {  // the real-Hamiltonian sweep has taken this chain (same tables, same norm bound: same decision)
+    bool realH = K <= MDR<NIG, W>::KP;
+    for (int k = 0; k <= K; ++k) realH = realH && (cm.tabs[(long)k * (IMG + 4) + IMG + 3] == 0.0);
+    if (__builtin_amdgcn_readfirstlane((int)realH) != 0 && __builtin_amdgcn_readfirstlane(mgr_squarings(nrm)) <= MGR_MAXS) return;
+  }
   cm.pr = 0;
   cm.t18 = 1;
   cm.scale = ldexp(1.0, -cm.ps);
@@ -1480,6 +1500,447 @@ __global__ void __launch_bounds__(256, 1) midd_grad_kernel(MidGradArgs A) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward sweep for REAL Hamiltonians in the mid-D layout: reverse mode through the real cos / sin evaluation of
+// midd_real_body (method and derivation: smalld_grad_real_kernel in c3p_smalld.hip).  The adjoint state is carried
+// transposed, N = M^T; every cotangent of the symmetric stage is  A_bar B + B A_bar = P + P^T  with ONE real product
+// P = A_bar B: the product goes through an LDS image and each lane adds the mirror element (linear combinations are
+// formed BEFORE the transposition where two products feed the same cotangent).  Per slice 7 + 4 + 11 + 4 real products
+// (+ 2 forward and 3 backward per squaring) against 18 + 3 s COMPLEX ones of the pair evaluation above.
+// Eight real images: slots 0..3 hold the operands of the running product, 4 / 5 the products to be transposed,
+// 6 / 7 the product R = dU N for the update N <- R conj(dU) (stored transposed in the swizzled layout, whose left
+// operands are read in the B pattern).  Always the degree-16 / 17 polynomials, up to MGR_MAXS squarings; other chains
+// are left to midd_grad_kernel (same tables, same norm bound: same decision).
+// ---------------------------------------------------------------------------------------------
+template <int NIG, int NJ, int W, int WV>
+__device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const MidCommon& cm, long chain, double* red) {
+  constexpr int NIGR = MDR<NIG, W>::NIGR;
+  constexpr int WI = MDR<NIG, W>::WI;
+  constexpr bool SWZ = MDR<NIG, W>::SWZ;
+  using T = WaveTiles<NIGR, NJ, WI, WV>;
+  constexpr int IMG = MD<NIG, NJ>::ROWS * W;  // complex table image
+  constexpr int IMGR = 16 * NIGR * WI, NE = T::NE;
+  constexpr int KP = MDR<NIG, W>::KP;
+  typedef TileRegs<T::NBW, T::NSW> Regs;
+  const int D = cm.D, K = cm.K;
+  const int rbig = cm.r, rsmall = 4 * cm.b + cm.r;
+  const int cbig = 4 * cm.b + cm.c, csmall = cm.c;
+  const double* tabs = cm.tabs;
+  double* const qbig0 = c3p_md_lds + cm.rbig[0];
+  double* const qbig1 = c3p_md_lds + cm.rbig[1];
+  double* const qsm0 = c3p_md_lds + cm.rsm[0];
+  double* const qsm1 = c3p_md_lds + cm.rsm[1];
+  auto erow = [&](int e) -> int { return T::row0(e) + (T::is_big(e) ? rbig : rsmall); };
+  auto ecol = [&](int e) -> int { return T::col0(e) + (T::is_big(e) ? cbig : csmall); };
+  auto st = [&](auto img, const Regs& v) {
+    constexpr int I = decltype(img)::value;
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+      (T::is_big(e) ? (T::col0(e) < 16 ? qbig0 : qbig1) : (T::col0(e) < 16 ? qsm0 : qsm1))[I * IMGR + T::off0(e)] = v.get(e);
+  };
+  // the mirror position of every element of the lane: offset of (col, row) in an image, 0 / 1 mask (inside the matrix)
+  int toff[NE > 0 ? NE : 1];
+  double tmask[NE > 0 ? NE : 1];
+  unsigned dbits = 0;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int row = erow(e), col = ecol(e);
+    const bool in = row < D && col < D;
+    const int rr = in ? row : 0, cc = in ? col : 0;
+    toff[e] = SWZ ? cc * 32 + (rr ^ (16 * (cc & 1))) : cc * WI + rr;
+    tmask[e] = in ? 1.0 : 0.0;
+    dbits |= (row == col && col < D) ? (1u << e) : 0u;
+  }
+  auto dmask = [&](int e) -> double { return (dbits >> e) & 1u ? 1.0 : 0.0; };
+  // out = f (P + P^T) for the product P the workgroup has just stored in image I
+  auto mirror = [&](auto img, const Regs& P, double f, Regs& out) {
+    constexpr int I = decltype(img)::value;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) out.set(e, f * (P.get(e) + tmask[e] * c3p_md_lds[I * IMGR + toff[e]]));
+  };
+  // image of the transpose (swizzled layout: general LEFT operands are read in the B pattern)
+  auto st_left = [&](auto img, const Regs& v) {
+    constexpr int I = decltype(img)::value;
+    if constexpr (SWZ) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int row = erow(e), col = ecol(e);  // always inside the 32 x 32 image
+        c3p_md_lds[I * IMGR + col * 32 + (row ^ (16 * (col & 1)))] = v.get(e);
+      }
+    } else {
+      st(img, v);
+    }
+  };
+  auto zero = [&](Regs& v) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v.set(e, 0.0);
+  };
+  Regs dummy;
+  Regs Tab[KP + 1];
+  double tmu_r[KP + 1], tmu_i[KP + 1];
+#pragma unroll
+  for (int k = 0; k <= KP; ++k) {
+    const double* tk = tabs + (long)(k <= K ? k : 0) * (IMG + 4);
+    const double on = k <= K ? -cm.scale : 0.0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int row = erow(e), col = ecol(e);
+      const bool in = row < D && col < D;
+      Tab[k].set(e, in ? on * tk[(2 * row + 1) * W + col] : 0.0);
+    }
+    tmu_r[k] = md_rfl(k <= K ? tk[IMG + 0] : 0.0);
+    tmu_i[k] = md_rfl(k <= K ? tk[IMG + 1] : 0.0);
+  }
+  // N = M^T at the end of the segment
+  Regs Nr, Ni;
+  {
+    const double* src = reinterpret_cast<const double*>(A.Mb) + chain * D * D * 2;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int row = erow(e), col = ecol(e);
+      const bool in = row < D && col < D;
+      Nr.set(e, in ? src[(col * D + row) * 2 + 0] : 0.0);
+      Ni.set(e, in ? src[(col * D + row) * 2 + 1] : 0.0);
+    }
+  }
+  const int ps = cm.ps;
+  for (int t = cm.len - 1; t >= 0; --t) {
+    // ---- forward: Y, W = Y^2, W^2, {W^3, W^4}, cos Y, sin(Y)/Y, sin Y (midd_real_body, degree 16 / 17) ----
+    Regs Y = Tab[0];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      const double c0 = k < K ? cm.sg[k * A.Lmax + t] : 0.0;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) Y.set(e, fma(c0, Tab[k + 1].get(e), Y.get(e)));
+    }
+    md_bar();  // the previous slice's last products have left the images
+    st(IC<0>{}, Y);
+    md_bar();
+    Regs W1, W2, W3, W4, Cm, Sp, acc, acs, Sn;
+    zero(W1);
+    mm_real<NIGR, NJ, W, WV, 0, 0, 0, 0, 0>(cm, W1, dummy);
+    st(IC<1>{}, W1);
+    md_bar();
+    zero(W2);
+    mm_real<NIGR, NJ, W, WV, 0, 1, 1, 1, 1>(cm, W2, dummy);
+    st(IC<2>{}, W2);
+    md_bar();
+    zero(W3);
+    zero(W4);
+    mm_real<NIGR, NJ, W, WV, 2, 1, 2, 2, 2>(cm, W3, W4);
+    auto rc = [&](Regs& out, double c0, double c1, double c2, double c3) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        double v = c1 * W1.get(e);
+        v = fma(c2, W2.get(e), v);
+        v = fma(c3, W3.get(e), v);
+        out.set(e, fma(c0, dmask(e), v));
+      }
+    };
+    rc(acc, c3p_inv_fact[8], -c3p_inv_fact[10], c3p_inv_fact[12], -c3p_inv_fact[14]);
+    rc(acs, c3p_inv_fact[9], -c3p_inv_fact[11], c3p_inv_fact[13], -c3p_inv_fact[15]);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      acc.set(e, fma(c3p_inv_fact[16], W4.get(e), acc.get(e)));
+      acs.set(e, fma(c3p_inv_fact[17], W4.get(e), acs.get(e)));
+    }
+    st(IC<3>{}, W4);
+    st(IC<4>{}, acc);
+    st(IC<5>{}, acs);
+    md_bar();
+    rc(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], -c3p_inv_fact[6]);
+    rc(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7]);
+    mm_real<NIGR, NJ, W, WV, 1, 3, 3, 4, 5>(cm, Cm, Sp);
+    st(IC<6>{}, Sp);
+    md_bar();
+    zero(Sn);
+    mm_real<NIGR, NJ, W, WV, 0, 0, 0, 6, 6>(cm, Sn, dummy);
+    // squarings, every level kept: C' = 2 C^2 - I, S' = 2 S C
+    Regs Cl[MGR_MAXS], Sl[MGR_MAXS];
+    auto square = [&](auto ia, auto ib, int lvl) {
+      constexpr int IA = decltype(ia)::value, IB = decltype(ib)::value;
+      Cl[lvl] = Cm;
+      Sl[lvl] = Sn;
+      st(ia, Cm);
+      st(ib, Sn);
+      md_bar();
+      Regs C2, SC;
+      zero(C2);
+      zero(SC);
+      mm_real<NIGR, NJ, W, WV, 2, IA, IB, IA, IA>(cm, C2, SC);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        Cm.set(e, fma(2.0, C2.get(e), -dmask(e)));
+        Sn.set(e, 2.0 * SC.get(e));
+      }
+    };
+    if (ps > 0) square(IC<1>{}, IC<2>{}, 0);
+    if (ps > 1) square(IC<3>{}, IC<4>{}, 1);
+    // ---- R = dU N = (C - iS)(Nr + i Ni):  Rr = C Nr + S Ni,  Ri = C Ni - S Nr ----
+    md_bar();
+    st(IC<0>{}, Cm);
+    st(IC<1>{}, Sn);
+    st(IC<2>{}, Nr);
+    st(IC<3>{}, Ni);
+    md_bar();
+    Regs Rr, Ri;
+    zero(Rr);
+    zero(Ri);
+    mm_real<NIGR, NJ, W, WV, 1, 1, 1, 3, 2>(cm, Rr, Ri);  // S Ni, S Nr
+#pragma unroll
+    for (int e = 0; e < NE; ++e) Ri.set(e, -Ri.get(e));
+    mm_real<NIGR, NJ, W, WV, 1, 0, 0, 2, 3>(cm, Rr, Ri);  // + C Nr, + C Ni
+    // tr N (= tr M), this wave's share
+    double trr = 0.0, tri = 0.0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      trr = fma(dmask(e), Nr.get(e), trr);
+      tri = fma(dmask(e), Ni.get(e), tri);
+    }
+    st(IC<4>{}, Rr);
+    st(IC<5>{}, Ri);
+    st_left(IC<6>{}, Rr);
+    st_left(IC<7>{}, Ri);
+    md_bar();
+    // ---- cotangents of cos / sin: C_bar = sym Re R, S_bar = -sym Im R ----
+    Regs Cb, Sb;
+    mirror(IC<4>{}, Rr, 0.5, Cb);
+    mirror(IC<5>{}, Ri, -0.5, Sb);
+    // ---- back through the squarings: C_bar = 2 {C_bar', C} + {S_bar', S},  S_bar = {S_bar', C}  ({A, B} = AB + BA) ----
+    auto unsquare = [&](int lvl) {
+      st(IC<0>{}, Cb);
+      st(IC<1>{}, Sb);
+      st(IC<2>{}, Cl[lvl]);
+      st(IC<3>{}, Sl[lvl]);
+      md_bar();
+      Regs P1, P2;
+      zero(P1);
+      zero(P2);
+      mm_real<NIGR, NJ, W, WV, 2, 0, 1, 2, 2>(cm, P1, P2);  // C_bar' C, S_bar' C
+#pragma unroll
+      for (int e = 0; e < NE; ++e) P1.set(e, 2.0 * P1.get(e));
+      mm_real<NIGR, NJ, W, WV, 0, 1, 1, 3, 3>(cm, P1, dummy);  // + S_bar' S
+      st(IC<4>{}, P1);
+      st(IC<5>{}, P2);
+      md_bar();
+      mirror(IC<4>{}, P1, 1.0, Cb);
+      mirror(IC<5>{}, P2, 1.0, Sb);
+    };
+    if (ps > 1) unsquare(1);
+    if (ps > 0) unsquare(0);
+    // ---- S = Y Sp:  Y_bar = sym(S_bar Sp) (kept doubled),  Sp_bar = sym(S_bar Y) ----
+    Regs Yb2, Spb;
+    {
+      st(IC<0>{}, Sb);
+      st(IC<1>{}, Sp);
+      st(IC<2>{}, Y);
+      md_bar();
+      Regs Pa, Pb;
+      zero(Pa);
+      zero(Pb);
+      mm_real<NIGR, NJ, W, WV, 1, 0, 0, 1, 2>(cm, Pa, Pb);
+      st(IC<4>{}, Pa);
+      st(IC<5>{}, Pb);
+      md_bar();
+      mirror(IC<4>{}, Pa, 1.0, Yb2);
+      mirror(IC<5>{}, Pb, 0.5, Spb);
+    }
+    // ---- Cm = Cm0 + W4 acc, Sp = Sp0 + W4 acs ----
+    Regs W4b2, accb, acsb;
+    {
+      st(IC<0>{}, Cb);
+      st(IC<1>{}, acc);
+      st(IC<2>{}, W4);
+      md_bar();
+      Regs Pc, Pd;
+      zero(Pc);
+      zero(Pd);
+      mm_real<NIGR, NJ, W, WV, 1, 0, 0, 1, 2>(cm, Pc, Pd);  // C_bar acc, C_bar W4
+      st(IC<4>{}, Pc);
+      st(IC<5>{}, Pd);
+      md_bar();
+      mirror(IC<4>{}, Pc, 1.0, W4b2);
+      mirror(IC<5>{}, Pd, 0.5, accb);
+      st(IC<0>{}, Spb);
+      st(IC<1>{}, acs);  // (image 2 still holds W4)
+      md_bar();
+      Regs Pe, Pf;
+      zero(Pe);
+      zero(Pf);
+      mm_real<NIGR, NJ, W, WV, 1, 0, 0, 1, 2>(cm, Pe, Pf);  // Sp_bar acs, Sp_bar W4
+      st(IC<4>{}, Pe);
+      st(IC<5>{}, Pf);
+      md_bar();
+      Regs tmp;
+      mirror(IC<4>{}, Pe, 1.0, tmp);
+      mirror(IC<5>{}, Pf, 0.5, acsb);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) W4b2.set(e, W4b2.get(e) + tmp.get(e));
+    }
+    Regs W1b, W2b, W3b, W4b;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const double ab = accb.get(e), sb = acsb.get(e), cb = Cb.get(e), pb = Spb.get(e);
+      W1b.set(e, -(c3p_inv_fact[2] * cb + c3p_inv_fact[3] * pb + c3p_inv_fact[10] * ab + c3p_inv_fact[11] * sb));
+      W2b.set(e, c3p_inv_fact[4] * cb + c3p_inv_fact[5] * pb + c3p_inv_fact[12] * ab + c3p_inv_fact[13] * sb);
+      W3b.set(e, -(c3p_inv_fact[6] * cb + c3p_inv_fact[7] * pb + c3p_inv_fact[14] * ab + c3p_inv_fact[15] * sb));
+      W4b.set(e, 0.5 * W4b2.get(e) + c3p_inv_fact[16] * ab + c3p_inv_fact[17] * sb);
+    }
+    // ---- W4 = W2^2, W3 = W W2:  W2_bar += {W4_bar, W2} + sym(W3_bar W),  W_bar += sym(W3_bar W2) ----
+    {
+      st(IC<0>{}, W3b);
+      st(IC<1>{}, W1);
+      st(IC<2>{}, W2);
+      st(IC<3>{}, W4b);
+      md_bar();
+      Regs Pg, Ph, Pi;
+      zero(Pg);
+      zero(Ph);
+      zero(Pi);
+      mm_real<NIGR, NJ, W, WV, 1, 0, 0, 1, 2>(cm, Pg, Ph);   // W3_bar W, W3_bar W2
+      mm_real<NIGR, NJ, W, WV, 0, 3, 3, 2, 2>(cm, Pi, dummy);  // W4_bar W2
+#pragma unroll
+      for (int e = 0; e < NE; ++e) Pi.set(e, fma(0.5, Pg.get(e), Pi.get(e)));
+      st(IC<4>{}, Pi);
+      st(IC<5>{}, Ph);
+      md_bar();
+      Regs q, h;
+      mirror(IC<4>{}, Pi, 1.0, q);
+      mirror(IC<5>{}, Ph, 0.5, h);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        W2b.set(e, W2b.get(e) + q.get(e));
+        W1b.set(e, W1b.get(e) + h.get(e));
+      }
+    }
+    // ---- W2 = W^2:  W_bar += {W2_bar, W} ----
+    {
+      st(IC<0>{}, W2b);  // (image 1 still holds W)
+      md_bar();
+      Regs Pj;
+      zero(Pj);
+      mm_real<NIGR, NJ, W, WV, 0, 0, 0, 1, 1>(cm, Pj, dummy);
+      st(IC<4>{}, Pj);
+      md_bar();
+      Regs q;
+      mirror(IC<4>{}, Pj, 1.0, q);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) W1b.set(e, W1b.get(e) + q.get(e));
+    }
+    // ---- W = Y^2:  Y_bar = sym(S_bar Sp) + {W_bar, Y} ----
+    Regs Yb;
+    {
+      st(IC<0>{}, W1b);
+      st(IC<2>{}, Y);
+      md_bar();
+      Regs Pk;
+      zero(Pk);
+      mm_real<NIGR, NJ, W, WV, 0, 0, 0, 2, 2>(cm, Pk, dummy);
+      st(IC<4>{}, Pk);
+      md_bar();
+      mirror(IC<4>{}, Pk, 1.0, Yb);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) Yb.set(e, fma(0.5, Yb2.get(e), Yb.get(e)));
+    }
+    // ---- grad[k] = <Y_bar, dY/dc_k> + Re(mu_k conj(tr N)) ----
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      double part = fma(tmu_r[k + 1], trr, tmu_i[k + 1] * tri);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) part = fma(Yb.get(e), Tab[k + 1].get(e), part);
+      for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+      if (cm.lane == 0) red[WV * 16 + k] = part;
+    }
+    // ---- N <- R conj(dU):  Nr = Rr C - Ri S,  Ni = Rr S + Ri C  (R: images 6 / 7) ----
+    st(IC<0>{}, Cm);
+    st(IC<1>{}, Sn);
+    md_bar();  // (also: partial sums visible)
+    if (WV == 0 && cm.lane < K)
+      A.grad[((long)cm.sample * K + cm.lane) * A.N + cm.n0 + t] =
+          red[cm.lane] + red[16 + cm.lane] + red[32 + cm.lane] + red[48 + cm.lane];
+    if (t > 0) {
+      zero(Nr);
+      zero(Ni);
+      mm_real<NIGR, NJ, W, WV, 2, 7, 6, 1, 1>(cm, Nr, Ni);  // Ri S, Rr S
+#pragma unroll
+      for (int e = 0; e < NE; ++e) Nr.set(e, -Nr.get(e));
+      mm_real<NIGR, NJ, W, WV, 2, 6, 7, 0, 0>(cm, Nr, Ni);  // + Rr C, + Ri C
+    }
+  }
+}
+
+template <int NIG, int NJ, int W>
+__global__ void __launch_bounds__(256, 1) midd_grad_real_kernel(MidGradArgs A) {
+  using C = MD<NIG, NJ>;
+  constexpr int IMG = C::ROWS * W;
+  constexpr int WI = MDR<NIG, W>::WI, IMGR = 16 * MDR<NIG, W>::NIGR * WI;
+  const int tid = threadIdx.x;
+  MidCommon cm;
+  cm.lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  cm.r = cm.lane >> 4;
+  cm.b = (cm.lane >> 2) & 3;
+  cm.c = cm.lane & 3;
+  cm.D = A.Dm;
+  cm.nbk = (2 * cm.D + 3) / 4;
+  cm.nbkR = (cm.D + 3) / 4;
+  cm.K = A.K;
+  const int K = A.K;
+  cm.sg = c3p_md_lds + MGR_SLOTS * IMGR;
+  __shared__ double red[64];
+  __shared__ double redn[NW];
+  const long chain = blockIdx.x;
+  cm.sample = (int)(chain / A.S);
+  cm.tabs = A.tables + (long)(A.tab_per_sample ? cm.sample : 0) * (1 + K) * (IMG + 4);
+  bool realH = K <= MDR<NIG, W>::KP;
+  for (int k = 0; k <= K; ++k) realH = realH && (cm.tabs[(long)k * (IMG + 4) + IMG + 3] == 0.0);
+  if (__builtin_amdgcn_readfirstlane((int)realH) == 0) return;
+  const int seg = (int)(chain - (long)cm.sample * A.S);
+  cm.n0 = (int)(((long)seg * A.N) / A.S);
+  const int n1 = (int)(((long)(seg + 1) * A.N) / A.S);
+  cm.len = n1 - cm.n0;
+  {
+    const int sw = MDR<NIG, W>::SWZ ? 16 * (cm.r & 1) : 0;
+    cm.aoffR = (4 * cm.b + cm.c) * WI + cm.r;
+    cm.rbig[0] = cm.r * WI + 4 * cm.b + cm.c + sw;
+    cm.rbig[1] = cm.r * WI + 4 * cm.b + cm.c - sw;
+    cm.rsm[0] = (4 * cm.b + cm.r) * WI + cm.c + sw;
+    cm.rsm[1] = (4 * cm.b + cm.r) * WI + cm.c - sw;
+    cm.rblk[0] = cm.r * WI + cm.c + sw;
+    cm.rblk[1] = cm.r * WI + cm.c - sw;
+  }
+  double nrm = cm.tabs[IMG + 2];
+  for (int k = 0; k < K; ++k) {
+    const double* s = A.signals + ((long)cm.sample * K + k) * A.N + cm.n0;
+    double cmax = 0.0;
+    for (int t = tid; t < cm.len; t += 256) cmax = fmax(cmax, fabs(s[t]));
+    for (int o = 32; o >= 1; o >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, o));
+    if (cm.lane == 0) redn[wave] = cmax;
+    __syncthreads();
+    cmax = fmax(fmax(redn[0], redn[1]), fmax(redn[2], redn[3]));
+    __syncthreads();
+    nrm = fma(cmax, cm.tabs[(long)(k + 1) * (IMG + 4) + IMG + 2], nrm);
+  }
+  nrm = md_rfl(nrm);
+  cm.ps = __builtin_amdgcn_readfirstlane(mgr_squarings(nrm));
+  if (cm.ps > MGR_MAXS) return;
+  for (int e = tid; e < MGR_SLOTS * IMGR; e += 256) c3p_md_lds[e] = 0.0;
+  for (int k = 0; k < K; ++k) {
+    const double* s = A.signals + ((long)cm.sample * K + k) * A.N + cm.n0;
+    for (int t = tid; t < cm.len; t += 256) cm.sg[k * A.Lmax + t] = s[t];
+  }
+  cm.pr = 0;
+  cm.t18 = 1;
+  cm.scale = ldexp(1.0, -cm.ps);
+  __syncthreads();
+  switch (wave) {
+    case 0: midd_grad_real_body<NIG, NJ, W, 0>(A, cm, chain, red); break;
+    case 1: midd_grad_real_body<NIG, NJ, W, 1>(A, cm, chain, red); break;
+    case 2: midd_grad_real_body<NIG, NJ, W, 2>(A, cm, chain, red); break;
+    default: midd_grad_real_body<NIG, NJ, W, 3>(A, cm, chain, red); break;
+  }
+}
+
 #if C3P_MIDD_HAS(3)
 template <int NIG, int NJ, int W>
 hipError_t launch_grad_t(const MidGradArgs& A, hipStream_t st) {
@@ -1492,6 +1953,24 @@ hipError_t launch_grad_t(const MidGradArgs& A, hipStream_t st) {
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)((long)A.B * A.S)), dim3(256), lds, st, A);
+  return hipGetLastError();
+}
+
+// *launched = false (and hipSuccess) when the real sweep does not apply: more control lines than the kernel keeps in
+// registers, or the eight real images and the segment's control amplitudes do not fit the LDS
+template <int NIG, int NJ, int W>
+hipError_t launch_grad_real_t(const MidGradArgs& A, hipStream_t st, bool* launched) {
+  constexpr int IMGR = 16 * MDR<NIG, W>::NIGR * MDR<NIG, W>::WI;
+  const size_t lds = (size_t)(MGR_SLOTS * IMGR + A.K * A.Lmax) * sizeof(double);
+  *launched = false;
+  if (A.K > MDR<NIG, W>::KP || lds > 158 * 1024) return hipSuccess;
+  auto kern = midd_grad_real_kernel<NIG, NJ, W>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((long)A.B * A.S)), dim3(256), lds, st, A);
+  *launched = true;
   return hipGetLastError();
 }
 
@@ -1531,6 +2010,14 @@ size_t c3p_midd_lds_bytes(int Dm, int K, int Lmax) {
   return ((size_t)3 * 16 * nig * w + (size_t)K * SGC) * sizeof(double);
 }
 
+size_t c3p_midd_grad_image_bytes(int Dm) {
+  int nig, nj, w;
+  if (!c3p_midd_geometry(Dm, &nig, &nj, &w)) return 0;
+  const int nigr = (nig + 1) / 2;
+  const size_t general = (size_t)4 * 16 * nig * w, real = (size_t)8 * 16 * nigr * (nigr <= 2 ? 32 : w);
+  return (general > real ? general : real) * sizeof(double);
+}
+
 hipError_t c3p_launch_midd_chain(const MidArgs& A, hipStream_t st) {
   int nig, nj, w;
   if (!c3p_midd_geometry(A.Dm, &nig, &nj, &w)) return hipErrorInvalidValue;
@@ -1566,9 +2053,32 @@ hipError_t c3p_launch_midd_real(const MidArgs& A, hipStream_t st) {
 #endif
 
 #if C3P_MIDD_HAS(3)
-hipError_t c3p_launch_midd_grad(const MidGradArgs& A, hipStream_t st) {
+namespace {
+hipError_t launch_grad_real(const MidGradArgs& A, int nig, int nj, hipStream_t st, bool* launched) {
+  if (nig == 2 && nj == 4) return launch_grad_real_t<2, 4, 18>(A, st, launched);
+  if (nig == 3 && nj == 5) return launch_grad_real_t<3, 5, 22>(A, st, launched);
+  if (nig == 3 && nj == 6) return launch_grad_real_t<3, 6, 26>(A, st, launched);
+  if (nig == 4 && nj == 7) return launch_grad_real_t<4, 7, 30>(A, st, launched);
+  if (nig == 4 && nj == 8) return launch_grad_real_t<4, 8, 34>(A, st, launched);
+  if (nig == 5 && nj == 9) return launch_grad_real_t<5, 9, 38>(A, st, launched);
+  if (nig == 5 && nj == 10) return launch_grad_real_t<5, 10, 42>(A, st, launched);
+  return hipErrorInvalidValue;
+}
+}  // namespace
+
+hipError_t c3p_launch_midd_grad(const MidGradArgs& A_, hipStream_t st) {
   int nig, nj, w;
-  if (!c3p_midd_geometry(A.Dm, &nig, &nj, &w)) return hipErrorInvalidValue;
+  if (!c3p_midd_geometry(A_.Dm, &nig, &nj, &w)) return hipErrorInvalidValue;
+  MidGradArgs A = A_;
+  A.skip_real = 0;
+  // real Hamiltonians first (reverse mode through the cos / sin evaluation), then the general sweep for the rest; the
+  // per-slice generator cotangents (zout) only exist in the general sweep
+  if (A.zout == nullptr && !getenv("C3P_NO_REAL_GRAD")) {
+    bool launched = false;
+    hipError_t e = launch_grad_real(A, nig, nj, st, &launched);
+    if (e != hipSuccess) return e;
+    if (launched) A.skip_real = 1;
+  }
   if (nig == 2 && nj == 4) return launch_grad_t<2, 4, 18>(A, st);
   if (nig == 3 && nj == 5) return launch_grad_t<3, 5, 22>(A, st);
   if (nig == 3 && nj == 6) return launch_grad_t<3, 6, 26>(A, st);
