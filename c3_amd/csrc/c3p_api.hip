@@ -398,8 +398,9 @@ int run_vjp_midd(DeviceWs* w, GradArgs& G, hipStream_t st) {
   int nig, nj, wd;
   if (!c3p_midd_geometry(D, &nig, &nj, &wd) || K > 16) return 1;
   const size_t img_bytes = (size_t)16 * nig * wd * sizeof(double);
-  // one workgroup per CU in the backward sweep (four images); aim at two rounds
-  long S = (512 + B - 1) / B;
+  // backward sweep: one workgroup per CU (two for the real-Hamiltonian kernel at D <= 32); aim at two rounds
+  const long target = D <= 32 ? 1024 : 512;
+  long S = (target + B - 1) / B;
   const long smax = N / 8 > 1 ? N / 8 : 1;
   if (S > smax) S = smax;
   if (S < 1) S = 1;

@@ -1405,8 +1405,12 @@ __device__ __forceinline__ void midd_grad_body(const MidGradArgs& A, const MidCo
 }
 
 // real-Hamiltonian backward sweep (midd_grad_real_kernel below): squarings kept, image slots, scaling rule (theta_16)
-constexpr int MGR_MAXS = 2;
 constexpr int MGR_SLOTS = 8;
+// squaring levels kept in registers: two, one for the 48-row classes (D >= 33, register-bound)
+template <int NIG>
+struct MGR {
+  static constexpr int MAXS = (NIG + 1) / 2 >= 3 ? 1 : 2;
+};
 
 __device__ __forceinline__ int mgr_squarings(double nrm) {
   int ps = 0;
@@ -1483,7 +1487,7 @@ __global__ void __launch_bounds__(256, 1) midd_grad_kernel(MidGradArgs A) {
   if (A.skip_real) {  // the real-Hamiltonian sweep has taken this chain (same tables, same norm bound: same decision)
     bool realH = K <= MDR<NIG, W>::KP;
     for (int k = 0; k <= K; ++k) realH = realH && (cm.tabs[(long)k * (IMG + 4) + IMG + 3] == 0.0);
-    if (__builtin_amdgcn_readfirstlane((int)realH) != 0 && __builtin_amdgcn_readfirstlane(mgr_squarings(nrm)) <= MGR_MAXS) return;
+    if (__builtin_amdgcn_readfirstlane((int)realH) != 0 && __builtin_amdgcn_readfirstlane(mgr_squarings(nrm)) <= MGR<NIG>::MAXS) return;
   }
   cm.pr = 0;
   cm.t18 = 1;
@@ -1509,7 +1513,7 @@ __global__ void __launch_bounds__(256, 1) midd_grad_kernel(MidGradArgs A) {
 // (+ 2 forward and 3 backward per squaring) against 18 + 3 s COMPLEX ones of the pair evaluation above.
 // Eight real images: slots 0..3 hold the operands of the running product, 4 / 5 the products to be transposed,
 // 6 / 7 the product R = dU N for the update N <- R conj(dU) (stored transposed in the swizzled layout, whose left
-// operands are read in the B pattern).  Always the degree-16 / 17 polynomials, up to MGR_MAXS squarings; other chains
+// operands are read in the B pattern).  Always the degree-16 / 17 polynomials, up to MGR<NIG>::MAXS squarings; other chains
 // are left to midd_grad_kernel (same tables, same norm bound: same decision).
 // ---------------------------------------------------------------------------------------------
 template <int NIG, int NJ, int W, int WV>
@@ -1540,15 +1544,14 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
   };
   // the mirror position of every element of the lane: offset of (col, row) in an image, 0 / 1 mask (inside the matrix)
   int toff[NE > 0 ? NE : 1];
-  double tmask[NE > 0 ? NE : 1];
-  unsigned dbits = 0;
+  unsigned inbits = 0, dbits = 0;
 #pragma unroll
   for (int e = 0; e < NE; ++e) {
     const int row = erow(e), col = ecol(e);
     const bool in = row < D && col < D;
     const int rr = in ? row : 0, cc = in ? col : 0;
     toff[e] = SWZ ? cc * 32 + (rr ^ (16 * (cc & 1))) : cc * WI + rr;
-    tmask[e] = in ? 1.0 : 0.0;
+    inbits |= in ? (1u << e) : 0u;
     dbits |= (row == col && col < D) ? (1u << e) : 0u;
   }
   auto dmask = [&](int e) -> double { return (dbits >> e) & 1u ? 1.0 : 0.0; };
@@ -1556,7 +1559,10 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
   auto mirror = [&](auto img, const Regs& P, double f, Regs& out) {
     constexpr int I = decltype(img)::value;
 #pragma unroll
-    for (int e = 0; e < NE; ++e) out.set(e, f * (P.get(e) + tmask[e] * c3p_md_lds[I * IMGR + toff[e]]));
+    for (int e = 0; e < NE; ++e) {
+      const double m = c3p_md_lds[I * IMGR + toff[e]];
+      out.set(e, f * (P.get(e) + ((inbits >> e) & 1u ? m : 0.0)));
+    }
   };
   // image of the transpose (swizzled layout: general LEFT operands are read in the B pattern)
   auto st_left = [&](auto img, const Regs& v) {
@@ -1576,21 +1582,38 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
     for (int e = 0; e < NE; ++e) v.set(e, 0.0);
   };
   Regs dummy;
-  Regs Tab[KP + 1];
+  // dY/dc_k at the lane's positions (-scale Im(table k); k = 0: the drift): in registers for the whole segment
+  // (TABREG = false reads them from the tables (L2) at every use: measured 18% slower at D = 36, although it spills less)
+  constexpr bool TABREG = true;
+  Regs Tab[TABREG ? KP + 1 : 1];
+  int tix[NE > 0 ? NE : 1];
   double tmu_r[KP + 1], tmu_i[KP + 1];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int row = erow(e), col = ecol(e);
+    tix[e] = (row < D && col < D) ? (2 * row + 1) * W + col : W;
+  }
 #pragma unroll
   for (int k = 0; k <= KP; ++k) {
     const double* tk = tabs + (long)(k <= K ? k : 0) * (IMG + 4);
     const double on = k <= K ? -cm.scale : 0.0;
+    if constexpr (TABREG) {
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      const int row = erow(e), col = ecol(e);
-      const bool in = row < D && col < D;
-      Tab[k].set(e, in ? on * tk[(2 * row + 1) * W + col] : 0.0);
+      for (int e = 0; e < NE; ++e) Tab[k].set(e, (inbits >> e) & 1u ? on * tk[tix[e]] : 0.0);
     }
     tmu_r[k] = md_rfl(k <= K ? tk[IMG + 0] : 0.0);
     tmu_i[k] = md_rfl(k <= K ? tk[IMG + 1] : 0.0);
   }
+  auto tab_get = [&](int k, Regs& out) {  // k <= KP, compile-time after unrolling
+    if constexpr (TABREG) {
+      out = Tab[k];
+    } else {
+      const double* tk = tabs + (long)(k <= K ? k : 0) * (IMG + 4);
+      const double on = k <= K ? -cm.scale : 0.0;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) out.set(e, (inbits >> e) & 1u ? on * tk[tix[e]] : 0.0);
+    }
+  };
   // N = M^T at the end of the segment
   Regs Nr, Ni;
   {
@@ -1606,12 +1629,15 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
   const int ps = cm.ps;
   for (int t = cm.len - 1; t >= 0; --t) {
     // ---- forward: Y, W = Y^2, W^2, {W^3, W^4}, cos Y, sin(Y)/Y, sin Y (midd_real_body, degree 16 / 17) ----
-    Regs Y = Tab[0];
+    Regs Y;
+    tab_get(0, Y);
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
       const double c0 = k < K ? cm.sg[k * A.Lmax + t] : 0.0;
+      Regs Tk;
+      tab_get(k + 1, Tk);
 #pragma unroll
-      for (int e = 0; e < NE; ++e) Y.set(e, fma(c0, Tab[k + 1].get(e), Y.get(e)));
+      for (int e = 0; e < NE; ++e) Y.set(e, fma(c0, Tk.get(e), Y.get(e)));
     }
     md_bar();  // the previous slice's last products have left the images
     st(IC<0>{}, Y);
@@ -1656,7 +1682,8 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
     zero(Sn);
     mm_real<NIGR, NJ, W, WV, 0, 0, 0, 6, 6>(cm, Sn, dummy);
     // squarings, every level kept: C' = 2 C^2 - I, S' = 2 S C
-    Regs Cl[MGR_MAXS], Sl[MGR_MAXS];
+    constexpr int MAXS = MGR<NIG>::MAXS;
+    Regs Cl[MAXS], Sl[MAXS];
     auto square = [&](auto ia, auto ib, int lvl) {
       constexpr int IA = decltype(ia)::value, IB = decltype(ib)::value;
       Cl[lvl] = Cm;
@@ -1675,7 +1702,8 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
       }
     };
     if (ps > 0) square(IC<1>{}, IC<2>{}, 0);
-    if (ps > 1) square(IC<3>{}, IC<4>{}, 1);
+    if constexpr (MAXS > 1)
+      if (ps > 1) square(IC<3>{}, IC<4>{}, 1);
     // ---- R = dU N = (C - iS)(Nr + i Ni):  Rr = C Nr + S Ni,  Ri = C Ni - S Nr ----
     md_bar();
     st(IC<0>{}, Cm);
@@ -1726,7 +1754,8 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
       mirror(IC<4>{}, P1, 1.0, Cb);
       mirror(IC<5>{}, P2, 1.0, Sb);
     };
-    if (ps > 1) unsquare(1);
+    if constexpr (MAXS > 1)
+      if (ps > 1) unsquare(1);
     if (ps > 0) unsquare(0);
     // ---- S = Y Sp:  Y_bar = sym(S_bar Sp) (kept doubled),  Sp_bar = sym(S_bar Y) ----
     Regs Yb2, Spb;
@@ -1846,8 +1875,10 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
       double part = fma(tmu_r[k + 1], trr, tmu_i[k + 1] * tri);
+      Regs Tk;
+      tab_get(k + 1, Tk);
 #pragma unroll
-      for (int e = 0; e < NE; ++e) part = fma(Yb.get(e), Tab[k + 1].get(e), part);
+      for (int e = 0; e < NE; ++e) part = fma(Yb.get(e), Tk.get(e), part);
       for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
       if (cm.lane == 0) red[WV * 16 + k] = part;
     }
@@ -1870,7 +1901,7 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
 }
 
 template <int NIG, int NJ, int W>
-__global__ void __launch_bounds__(256, 1) midd_grad_real_kernel(MidGradArgs A) {
+__global__ void __launch_bounds__(256, (MDR<NIG, W>::SWZ ? 2 : 1)) midd_grad_real_kernel(MidGradArgs A) {
   using C = MD<NIG, NJ>;
   constexpr int IMG = C::ROWS * W;
   constexpr int WI = MDR<NIG, W>::WI, IMGR = 16 * MDR<NIG, W>::NIGR * WI;
@@ -1923,7 +1954,7 @@ __global__ void __launch_bounds__(256, 1) midd_grad_real_kernel(MidGradArgs A) {
   }
   nrm = md_rfl(nrm);
   cm.ps = __builtin_amdgcn_readfirstlane(mgr_squarings(nrm));
-  if (cm.ps > MGR_MAXS) return;
+  if (cm.ps > MGR<NIG>::MAXS) return;
   for (int e = tid; e < MGR_SLOTS * IMGR; e += 256) c3p_md_lds[e] = 0.0;
   for (int k = 0; k < K; ++k) {
     const double* s = A.signals + ((long)cm.sample * K + k) * A.N + cm.n0;

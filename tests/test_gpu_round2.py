@@ -495,3 +495,22 @@ def test_vjp_real_hamiltonian_mid_dims(prop, D, amp, monkeypatch):
         want = o.pwc_signal_gradient(h0[b] if per_sample else h0, hks, sig[b], 1e-11, Ubar[b], ph[b])
         assert np.abs(g[b] - want).max() < tol * np.abs(want).max()
     assert np.abs(g - g0).max() < tol * np.abs(g0).max()
+
+
+@pytest.mark.gpu
+def test_vjp_hermitian_check_is_cached_per_tensor_version(prop):
+    """device operators are reduced once; an in-place write invalidates the pass"""
+    import torch
+    from c3_amd.propagation import C3PropError
+
+    w = workloads.make_workload(2, B=2, N=16)
+    dev = "cuda:0"
+    h0, hks = torch.as_tensor(w.h0, device=dev), torch.as_tensor(w.hks, device=dev)
+    sig = torch.as_tensor(w.signals, device=dev)
+    Ubar = torch.randn(2, w.D, w.D, dtype=torch.complex128, device=dev)
+    g1 = prop.propagate_batch_vjp(h0, hks, sig, w.dt, Ubar)
+    g2 = prop.propagate_batch_vjp(h0, hks, sig, w.dt, Ubar)
+    assert torch.equal(g1, g2)
+    h0[0, 1] += 1e9j  # no longer Hermitian
+    with pytest.raises(C3PropError, match="Hermitian"):
+        prop.propagate_batch_vjp(h0, hks, sig, w.dt, Ubar)
