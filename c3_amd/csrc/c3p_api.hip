@@ -284,12 +284,12 @@ int combine_smalld(DeviceWs* w, const cplx* cur, int B, int count, int Dm, int r
   return 0;
 }
 
-int pick_segments(int B, int N, int K, int Dm, bool need_mult4) {
+int pick_segments(int B, int N, int K, int Dm, bool need_mult4, long slots = 8192) {
   // two waves per SIMD (the D = 9 kernel fits 256 registers): 256 CUs x 4 SIMDs x 2 x 4 chains are resident at once.
   // B S chains run in ceil(B S / slots) rounds of N / S slices (+ the table build and plan of the prologue):
   // take the S that minimises rounds x segment length, so that the last round is not a mostly idle tail
   // (B = 300 with the old "fill the machine twice" rule ran a second round at 2 % occupancy).
-  const long slots = 8192;
+  // (the backward sweep runs one wave per SIMD: 4096 slots)
   // the segment's control amplitudes live in LDS: 4 chains x K x Lmax doubles
   const long lds_budget = 20 * 1024 - (long)(c3p_smalld_table_doubles(Dm, K) + 4 * c3p_smalld_img_doubles(Dm)) * 8;
   const long lmax_cap = K > 0 ? lds_budget / (32L * K) : (1L << 30);
@@ -592,7 +592,7 @@ int run_xg_smalld(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, d
 int run_vjp_smalld(DeviceWs* w, GradArgs& G, hipStream_t st) {
   const int D = G.D, B = G.B, K = G.K, N = G.N;
   const bool per_sample = (G.h0_bstride != 0) || (G.hks_bstride != 0);
-  const int S = pick_segments(B, N, K, D, per_sample);
+  const int S = pick_segments(B, N, K, D, per_sample, getenv("C3P_GRAD_SLOTS") ? atol(getenv("C3P_GRAD_SLOTS")) : 4096);
   if (S < 0) return 1;
   const int nsamp = per_sample ? B : 1;
   void* v;
