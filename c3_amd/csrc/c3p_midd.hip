@@ -394,7 +394,7 @@ struct MDR {
   static constexpr bool SWZ = NIGR <= 2;
   static constexpr int WI = SWZ ? 32 : W;              // image row stride
   static constexpr int AREA = NIMG * 16 * NIGR * WI;   // doubles
-  static constexpr int KP = 3;                         // control lines whose tables stay in registers (K <= KP)
+  static constexpr int KP = 3;                         // control lines whose tables stay in registers
   static constexpr int WGS = (AREA * 8 + 6144) * 3 <= 160 * 1024 ? 3 : 2;
 };
 
@@ -440,7 +440,8 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
   double mus_r = 0.0, mus_i = 0.0;
   Regs dummy;
   // The lane's table elements do not depend on the slice: -scale Im(table) at the lane's positions stays in
-  // registers for the whole segment (the kernel requires K <= KP).  Im rows of the half-image tables hold -Y;
+  // registers for the whole segment (the first KP control lines; further ones are read per slice).  Im rows of the
+  // half-image tables hold -Y;
   // positions outside the matrix are clamped and masked.
   constexpr int KP = MDR<NIG, W>::KP;
   Regs Tab[KP + 1];
@@ -473,6 +474,19 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       mu_i = fma(c0, tmu_i[k + 1], mu_i);
 #pragma unroll
       for (int e = 0; e < NE; ++e) Y.set(e, fma(c0, Tab[k + 1].get(e), Y.get(e)));
+    }
+    for (int k = KP; k < K; ++k) {  // control lines beyond the register budget: their tables come from L2 every slice
+      const double c0 = cm.sg[k * SGC + (t & (SGC - 1))];
+      const double* tk = tabs + (long)(k + 1) * (IMG + 4);
+      mu_r = fma(c0, md_rfl(tk[IMG + 0]), mu_r);
+      mu_i = fma(c0, md_rfl(tk[IMG + 1]), mu_i);
+      const double f = -cm.scale * c0;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int row = erow(e), col = ecol(e);
+        const bool in = row < D && col < D;
+        Y.set(e, fma(f, in ? tk[(2 * row + 1) * W + col] : 0.0, Y.get(e)));
+      }
     }
     store_tiles(IC<0>{}, Y);
     md_bar();
@@ -925,8 +939,8 @@ __global__ void __launch_bounds__(256, (REAL ? MDR<NIG, W>::WGS : MidOcc<NIG, W>
   cm.tabs = XG ? nullptr : A.tables + (long)(A.tab_per_sample ? cm.sample : 0) * (1 + K) * (IMG + 4);
   cm.realH = 0;
   if constexpr (!GIVEN && !XG) {
-    // every table purely imaginary (real Hamiltonian, unitary mode, K <= KP): real cos / sin kernel
-    bool realH = A.mode == C3P_MODE_UNITARY && !A.no_real && K <= MDR<NIG, W>::KP;
+    // every table purely imaginary (real Hamiltonian, unitary mode): real cos / sin kernel
+    bool realH = A.mode == C3P_MODE_UNITARY && !A.no_real;
     for (int k = 0; k <= K; ++k) realH = realH && (cm.tabs[(long)k * (IMG + 4) + IMG + 3] == 0.0);
     cm.realH = __builtin_amdgcn_readfirstlane((int)realH);
     if ((cm.realH != 0) != REAL) return;
@@ -1171,7 +1185,7 @@ hipError_t launch_t(const MidArgs& A, hipStream_t st) {
   if (A.mode == C3P_MODE_EXPM)
     return A.dUs_out ? md_go(midd_chain_kernel<NIG, NJ, W, false, true, true>, A, lds, st)
                      : md_go(midd_chain_kernel<NIG, NJ, W, false, false, true>, A, lds, st);
-  if (A.mode == C3P_MODE_UNITARY && !A.no_real && A.K <= MDR<NIG, W>::KP) {
+  if (A.mode == C3P_MODE_UNITARY && !A.no_real) {
     // samples with real Hamiltonians are taken by the real kernel, the others by the complex one
     hipError_t e = c3p_launch_midd_real(A, st);
     if (e != hipSuccess) return e;

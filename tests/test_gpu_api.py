@@ -168,7 +168,7 @@ def test_real_hamiltonian_fast_path(prop, D, strength):
 @pytest.mark.parametrize("D", [2, 3, 5, 8, 9, 12, 13, 14, 24, 27, 36, 40, 45])
 def test_supplied_generators_every_kernel(prop, D):
     """Branch B of pwc (per-slice Hamiltonians, propagation.py:295-308) and c3p_expm on the MFMA kernels
-    (small-D <= 12, mid-D 13..40; the generic kernel beyond and under FORCE_GENERIC): general complex,
+    (small-D <= 12, mid-D 13..40, the tiled path beyond; the generic kernel under FORCE_GENERIC): general complex,
     non-Hermitian generators, shared and per-sample stacks, partial propagators, frame phases."""
     import scipy.linalg as sla
     from c3_amd import _lib
@@ -184,7 +184,8 @@ def test_supplied_generators_every_kernel(prop, D):
     for gen in (False, True):
         r = prop.propagate_batch(H, None, None, dt, want_dUs=True, fr_phase=ph, force_generic=gen)
         kern = _lib.last_kernel()
-        assert kern == (("generic_lds" if D <= 37 else "generic_global") if (gen or D > 40) else ("smalld" if D <= 12 else "mfma"))
+        # (D > 40 with per-slice Hamiltonians: the tiled large-matrix path, also reported as "mfma")
+        assert kern == (("generic_lds" if D <= 37 else "generic_global") if gen else ("smalld" if D <= 12 else "mfma"))
         assert np.abs(np.asarray(r["dUs"]) - want_d).max() < 1e-12
         assert max(np.linalg.norm(np.asarray(r["U"][b]) - want_U[b]) for b in range(B)) < 1e-10
     r1 = prop.propagate_batch(H[1], None, None, dt)  # one shared stack [N,D,D]

@@ -514,3 +514,33 @@ def test_vjp_hermitian_check_is_cached_per_tensor_version(prop):
     h0[0, 1] += 1e9j  # no longer Hermitian
     with pytest.raises(C3PropError, match="Hermitian"):
         prop.propagate_batch_vjp(h0, hks, sig, w.dt, Ubar)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,K", [(14, 4), (27, 5), (36, 6)])
+def test_mid_dims_real_path_more_than_three_control_lines(prop, D, K):
+    """the real cos / sin instance keeps three control tables in registers and reads further ones per slice"""
+    rng = np.random.default_rng(77 * D + K)
+    B, N = 3, 23
+
+    def sym():
+        a = rng.normal(size=(D, D))
+        return (a + a.T) / 2
+
+    h0 = sym().astype(np.complex128) * (2e11 / np.sqrt(D))
+    hks = np.stack([sym() for _ in range(K)]).astype(np.complex128)
+    sig = rng.normal(size=(B, K, N)) * 2e9
+    ph = rng.uniform(0, 6, size=(B, D))
+    out = prop.propagate_batch(h0, hks, sig, 1e-11, fr_phase=ph, want_dUs=True)
+    U, dUs = np.asarray(out["U"]), np.asarray(out["dUs"])
+    ref = o.propagate_batch(h0, hks, sig, 1e-11, fr_phase=ph)
+    assert np.abs(U - ref).max() < 1e-10
+    for b in range(B):
+        d = o.tf_propagation_vectorized(h0, hks, sig[b], 1e-11)
+        assert np.abs(dUs[b] - d).max() < 1e-11
+    # and its gradient (general sweep: the real sweep keeps K <= 3)
+    Ubar = rng.normal(size=(B, D, D)) + 1j * rng.normal(size=(B, D, D))
+    g = np.asarray(prop.propagate_batch_vjp(h0, hks, sig, 1e-11, Ubar, fr_phase=ph))
+    for b in range(B):
+        want = o.pwc_signal_gradient(h0, hks, sig[b], 1e-11, Ubar[b], ph[b])
+        assert np.abs(g[b] - want).max() < 1e-10 * np.abs(want).max()
