@@ -1557,14 +1557,18 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
       (T::is_big(e) ? (T::col0(e) < 16 ? qbig0 : qbig1) : (T::col0(e) < 16 ? qsm0 : qsm1))[I * IMGR + T::off0(e)] = v.get(e);
   };
   // the mirror position of every element of the lane: offset of (col, row) in an image, 0 / 1 mask (inside the matrix)
-  int toff[NE > 0 ? NE : 1];
+  int toff[NE > 0 ? NE : 1], soff[NE > 0 ? NE : 1];
   unsigned inbits = 0, dbits = 0;
 #pragma unroll
   for (int e = 0; e < NE; ++e) {
     const int row = erow(e), col = ecol(e);
     const bool in = row < D && col < D;
     const int rr = in ? row : 0, cc = in ? col : 0;
-    toff[e] = SWZ ? cc * 32 + (rr ^ (16 * (cc & 1))) : cc * WI + rr;
+    // images 4 / 5 only pass products to their mirror reads: in the 32-wide classes they have their own swizzle,
+    // element (row, col) at row * 32 + (col ^ 4 (row & 7)), which spreads the 64 lanes of a MIRROR read (16 rows x 4
+    // columns of the image) over all bank pairs (the operand swizzle gave 8-way conflicts there)
+    toff[e] = SWZ ? cc * 32 + (rr ^ (4 * (cc & 7))) : cc * WI + rr;
+    soff[e] = SWZ ? row * 32 + (col ^ (4 * (row & 7))) : 0;
     inbits |= in ? (1u << e) : 0u;
     dbits |= (row == col && col < D) ? (1u << e) : 0u;
   }
@@ -1576,6 +1580,16 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
     for (int e = 0; e < NE; ++e) {
       const double m = c3p_md_lds[I * IMGR + toff[e]];
       out.set(e, f * (P.get(e) + ((inbits >> e) & 1u ? m : 0.0)));
+    }
+  };
+  // store into a mirror image (4 / 5)
+  auto st_T = [&](auto img, const Regs& v) {
+    constexpr int I = decltype(img)::value;
+    if constexpr (SWZ) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) c3p_md_lds[I * IMGR + soff[e]] = v.get(e);
+    } else {
+      st(img, v);
     }
   };
   // image of the transpose (swizzled layout: general LEFT operands are read in the B pattern)
@@ -1739,8 +1753,8 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
       trr = fma(dmask(e), Nr.get(e), trr);
       tri = fma(dmask(e), Ni.get(e), tri);
     }
-    st(IC<4>{}, Rr);
-    st(IC<5>{}, Ri);
+    st_T(IC<4>{}, Rr);
+    st_T(IC<5>{}, Ri);
     st_left(IC<6>{}, Rr);
     st_left(IC<7>{}, Ri);
     md_bar();
@@ -1762,8 +1776,8 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
 #pragma unroll
       for (int e = 0; e < NE; ++e) P1.set(e, 2.0 * P1.get(e));
       mm_real<NIGR, NJ, W, WV, 0, 1, 1, 3, 3>(cm, P1, dummy);  // + S_bar' S
-      st(IC<4>{}, P1);
-      st(IC<5>{}, P2);
+      st_T(IC<4>{}, P1);
+      st_T(IC<5>{}, P2);
       md_bar();
       mirror(IC<4>{}, P1, 1.0, Cb);
       mirror(IC<5>{}, P2, 1.0, Sb);
@@ -1782,8 +1796,8 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
       zero(Pa);
       zero(Pb);
       mm_real<NIGR, NJ, W, WV, 1, 0, 0, 1, 2>(cm, Pa, Pb);
-      st(IC<4>{}, Pa);
-      st(IC<5>{}, Pb);
+      st_T(IC<4>{}, Pa);
+      st_T(IC<5>{}, Pb);
       md_bar();
       mirror(IC<4>{}, Pa, 1.0, Yb2);
       mirror(IC<5>{}, Pb, 0.5, Spb);
@@ -1799,8 +1813,8 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
       zero(Pc);
       zero(Pd);
       mm_real<NIGR, NJ, W, WV, 1, 0, 0, 1, 2>(cm, Pc, Pd);  // C_bar acc, C_bar W4
-      st(IC<4>{}, Pc);
-      st(IC<5>{}, Pd);
+      st_T(IC<4>{}, Pc);
+      st_T(IC<5>{}, Pd);
       md_bar();
       mirror(IC<4>{}, Pc, 1.0, W4b2);
       mirror(IC<5>{}, Pd, 0.5, accb);
@@ -1811,8 +1825,8 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
       zero(Pe);
       zero(Pf);
       mm_real<NIGR, NJ, W, WV, 1, 0, 0, 1, 2>(cm, Pe, Pf);  // Sp_bar acs, Sp_bar W4
-      st(IC<4>{}, Pe);
-      st(IC<5>{}, Pf);
+      st_T(IC<4>{}, Pe);
+      st_T(IC<5>{}, Pf);
       md_bar();
       Regs tmp;
       mirror(IC<4>{}, Pe, 1.0, tmp);
@@ -1844,8 +1858,8 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
       mm_real<NIGR, NJ, W, WV, 0, 3, 3, 2, 2>(cm, Pi, dummy);  // W4_bar W2
 #pragma unroll
       for (int e = 0; e < NE; ++e) Pi.set(e, fma(0.5, Pg.get(e), Pi.get(e)));
-      st(IC<4>{}, Pi);
-      st(IC<5>{}, Ph);
+      st_T(IC<4>{}, Pi);
+      st_T(IC<5>{}, Ph);
       md_bar();
       Regs q, h;
       mirror(IC<4>{}, Pi, 1.0, q);
@@ -1863,7 +1877,7 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
       Regs Pj;
       zero(Pj);
       mm_real<NIGR, NJ, W, WV, 0, 0, 0, 1, 1>(cm, Pj, dummy);
-      st(IC<4>{}, Pj);
+      st_T(IC<4>{}, Pj);
       md_bar();
       Regs q;
       mirror(IC<4>{}, Pj, 1.0, q);
@@ -1879,7 +1893,7 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
       Regs Pk;
       zero(Pk);
       mm_real<NIGR, NJ, W, WV, 0, 0, 0, 2, 2>(cm, Pk, dummy);
-      st(IC<4>{}, Pk);
+      st_T(IC<4>{}, Pk);
       md_bar();
       mirror(IC<4>{}, Pk, 1.0, Yb);
 #pragma unroll
