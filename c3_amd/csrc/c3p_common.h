@@ -174,8 +174,8 @@ __host__ __device__ __forceinline__ MfmaPlan c3p_pick_plan_mfma(double nrm) {
   return m;
 }
 
-// 1/k!, k = 0..20
-__constant__ double c3p_inv_fact[21] = {
+// 1/k!, k = 0..21
+__constant__ double c3p_inv_fact[22] = {
     1.0,
     1.0,
     0.5,
@@ -197,4 +197,5 @@ __constant__ double c3p_inv_fact[21] = {
     1.0 / 6402373705728000.0,
     1.0 / 121645100408832000.0,
     1.0 / 2432902008176640000.0,
+    1.0 / 51090942171709440000.0,
 };

@@ -461,8 +461,9 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
   }
   // instantiated per polynomial variant with the branch outside the loop (as in the small-D kernel): below
   // theta_16 = 0.816 the degree-16 / 17 polynomials are exact to roundoff and W^3, W^4 are one paired product
-  auto real_loop = [&](auto deg16_tag) {
-  constexpr bool DEG16 = decltype(deg16_tag)::value;
+  auto real_loop = [&](auto var_tag) {
+  constexpr int VAR = decltype(var_tag)::value;  // Taylor degree of cos: 16, 18 or 20
+  constexpr bool DEG16 = VAR == 16, DEG20 = VAR == 20;
   for (int t = 0; t < cm.len; ++t) {
     if ((t & (SGC - 1)) == 0) md_stage_signals<WV>(A, cm, t);
     double mu_r = tmu_r[0], mu_i = tmu_i[0];
@@ -512,7 +513,43 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
     Regs Sn;
     zero(Sn);
     // cos: c_j = (-1)^j / (2j)!;  sin / Y: s_j = (-1)^j / (2j+1)!
-    if constexpr (DEG16) {
+    if constexpr (DEG20) {
+      // q = 5 (theta_20 = 1.49: cfg3 / cfg5 need no squaring): {W^3, W^4} as in the degree-16 variant, W^5 = W^2 W^3,
+      // then ONE paired Horner step in W^5:  p = B0(W..W^4) + W^5 (B1(W..W^4) + c10 W^5)
+      Regs W4, W5;
+      zero(W4);
+      zero(W5);
+      mm_real<NIGR, NJ, W, WV, 2, 1, 2, 2, 2>(cm, W3, W4);
+      store_tiles(IC<3>{}, W3);
+      md_bar();
+      mm_real<NIGR, NJ, W, WV, 0, 2, 2, 3, 3>(cm, W5, dummy);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        double a = -c3p_inv_fact[10] * dmask(e), s = -c3p_inv_fact[11] * dmask(e);
+        a = fma(c3p_inv_fact[12], W1.get(e), a), s = fma(c3p_inv_fact[13], W1.get(e), s);
+        a = fma(-c3p_inv_fact[14], W2.get(e), a), s = fma(-c3p_inv_fact[15], W2.get(e), s);
+        a = fma(c3p_inv_fact[16], W3.get(e), a), s = fma(c3p_inv_fact[17], W3.get(e), s);
+        a = fma(-c3p_inv_fact[18], W4.get(e), a), s = fma(-c3p_inv_fact[19], W4.get(e), s);
+        acc.set(e, fma(c3p_inv_fact[20], W5.get(e), a));
+        acs.set(e, fma(c3p_inv_fact[21], W5.get(e), s));
+      }
+      store_tiles(IC<0>{}, W5);
+      store_tiles(IC<1>{}, acc);
+      store_tiles(IC<4>{}, acs);
+      md_bar();
+      rc(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], -c3p_inv_fact[6]);
+      rc(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7]);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        Cm.set(e, fma(c3p_inv_fact[8], W4.get(e), Cm.get(e)));
+        Sp.set(e, fma(c3p_inv_fact[9], W4.get(e), Sp.get(e)));
+      }
+      mm_real<NIGR, NJ, W, WV, 1, 0, 0, 1, 4>(cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
+      store_tiles(IC<2>{}, Sp);
+      store_tiles(IC<3>{}, Y);
+      md_bar();
+      mm_real<NIGR, NJ, W, WV, 0, 3, 3, 2, 2>(cm, Sn, dummy);  // sin Y
+    } else if constexpr (DEG16) {
       // q = 4: {W^3, W^4} = {W, W^2} W^2 as one paired product, then ONE paired Horner step in W^4
       Regs W4;
       zero(W4);
@@ -575,11 +612,13 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       }
     };
     for (int it = 0; it < cm.ps; ++it) {
-      // the image pair not read by the previous product
-      if (((it & 1) != 0) != DEG16)
-        square(IC<3>{}, IC<4>{});
+      // the image pair not read by the previous product (sin Y reads images 2, 1 / 4, 0 / 3, 2 at degree 16 / 18 / 20)
+      if ((it & 1) != 0)
+        DEG16 ? square(IC<1>{}, IC<2>{}) : square(IC<3>{}, IC<4>{});
+      else if constexpr (DEG20)
+        square(IC<0>{}, IC<1>{});
       else
-        square(IC<1>{}, IC<2>{});
+        DEG16 ? square(IC<3>{}, IC<4>{}) : square(IC<1>{}, IC<2>{});
     }
     if constexpr (DUS) {
       // dU = e^{mu} (C - iS)
@@ -628,10 +667,12 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
     }
   }
   };
-  if (cm.t18)  // (reused as the variant flag on the real path)
-    real_loop(std::true_type{});
+  if (cm.t18 == 2)  // (reused as the variant flag on the real path: 1 = degree 16, 0 = degree 18, 2 = degree 20)
+    real_loop(IC<20>{});
+  else if (cm.t18 == 1)
+    real_loop(IC<16>{});
   else
-    real_loop(std::false_type{});
+    real_loop(IC<18>{});
   // ---- segment result: e^{sum mu} (Ur + i Ui), optional row phases ----
   double sn, cs;
   sincos(mus_i, &sn, &cs);
@@ -1019,15 +1060,24 @@ __global__ void __launch_bounds__(256, (REAL ? MDR<NIG, W>::WGS : MidOcc<NIG, W>
       cm.ps = __builtin_amdgcn_readfirstlane(q.s);
     }
     if constexpr (REAL) {
-      // T18 scaling rule; below theta_16 the degree-16 variant (flag kept in t18)
-      int s18 = 0;
-      double p = C3P_T18_THETA;
-      while (p < nrm && s18 < 40) {
-        p *= 2.0;
-        ++s18;
-      }
-      cm.ps = __builtin_amdgcn_readfirstlane(s18);
-      cm.t18 = __builtin_amdgcn_readfirstlane((int)(ldexp(nrm, -s18) <= 8.16e-1));
+      // Taylor degree 16 / 18 / 20 of cos (theta = 0.816 / 1.13 / 1.49: backward error below 2^-53) with s squarings:
+      // 7 / 8 / 8 + 2 s real products; the cheapest, the lower degree on ties (variant kept in t18: 1 / 0 / 2)
+      auto squarings = [&](double theta) {
+        int s = 0;
+        while (theta < nrm && s < 40) {
+          theta *= 2.0;
+          ++s;
+        }
+        return s;
+      };
+      const int s16 = squarings(8.16e-1), s18 = squarings(C3P_T18_THETA), s20 = squarings(1.49);
+      int var = 1, s = s16, cost = 7 + 2 * s16;
+      if (8 + 2 * s18 < cost) var = 0, s = s18, cost = 8 + 2 * s18;
+      // (degree 20 only in the 16- and 32-row classes: at D >= 33 its extra dependent product and two more live tile sets
+      // cost more than the squaring they save -- cfg5 measured 3 % slower with it, cfg3 3.6 % faster)
+      if (MDR<NIG, W>::NIGR <= 2 && 8 + 2 * s20 < cost) var = 2, s = s20, cost = 8 + 2 * s20;
+      cm.ps = __builtin_amdgcn_readfirstlane(s);
+      cm.t18 = __builtin_amdgcn_readfirstlane(var);
     }
     cm.scale = ldexp(1.0, -cm.ps);
     __syncthreads();
@@ -1530,7 +1580,7 @@ __global__ void __launch_bounds__(256, 1) midd_grad_kernel(MidGradArgs A) {
 // operands are read in the B pattern).  Always the degree-16 / 17 polynomials, up to MGR<NIG>::MAXS squarings; other chains
 // are left to midd_grad_kernel (same tables, same norm bound: same decision).
 // ---------------------------------------------------------------------------------------------
-template <int NIG, int NJ, int W, int WV>
+template <int NIG, int NJ, int W, int WV, bool DEG20>
 __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const MidCommon& cm, long chain, double* red) {
   constexpr int NIGR = MDR<NIG, W>::NIGR;
   constexpr int WI = MDR<NIG, W>::WI;
@@ -1691,20 +1741,48 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
         out.set(e, fma(c0, dmask(e), v));
       }
     };
-    rc(acc, c3p_inv_fact[8], -c3p_inv_fact[10], c3p_inv_fact[12], -c3p_inv_fact[14]);
-    rc(acs, c3p_inv_fact[9], -c3p_inv_fact[11], c3p_inv_fact[13], -c3p_inv_fact[15]);
+    // the power the Horner step runs in: W^4 (degree 16), W^5 = W^2 W^3 (degree 20, theta_20 = 1.49: one squaring less)
+    Regs H;
+    if constexpr (DEG20) {
+      st(IC<3>{}, W3);
+      md_bar();
+      zero(H);
+      mm_real<NIGR, NJ, W, WV, 0, 2, 2, 3, 3>(cm, H, dummy);
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      acc.set(e, fma(c3p_inv_fact[16], W4.get(e), acc.get(e)));
-      acs.set(e, fma(c3p_inv_fact[17], W4.get(e), acs.get(e)));
+      for (int e = 0; e < NE; ++e) {
+        double a = -c3p_inv_fact[10] * dmask(e), s = -c3p_inv_fact[11] * dmask(e);
+        a = fma(c3p_inv_fact[12], W1.get(e), a), s = fma(c3p_inv_fact[13], W1.get(e), s);
+        a = fma(-c3p_inv_fact[14], W2.get(e), a), s = fma(-c3p_inv_fact[15], W2.get(e), s);
+        a = fma(c3p_inv_fact[16], W3.get(e), a), s = fma(c3p_inv_fact[17], W3.get(e), s);
+        a = fma(-c3p_inv_fact[18], W4.get(e), a), s = fma(-c3p_inv_fact[19], W4.get(e), s);
+        acc.set(e, fma(c3p_inv_fact[20], H.get(e), a));
+        acs.set(e, fma(c3p_inv_fact[21], H.get(e), s));
+      }
+      st(IC<7>{}, H);
+    } else {
+      H = W4;
+      rc(acc, c3p_inv_fact[8], -c3p_inv_fact[10], c3p_inv_fact[12], -c3p_inv_fact[14]);
+      rc(acs, c3p_inv_fact[9], -c3p_inv_fact[11], c3p_inv_fact[13], -c3p_inv_fact[15]);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        acc.set(e, fma(c3p_inv_fact[16], W4.get(e), acc.get(e)));
+        acs.set(e, fma(c3p_inv_fact[17], W4.get(e), acs.get(e)));
+      }
+      st(IC<7>{}, H);
     }
-    st(IC<3>{}, W4);
     st(IC<4>{}, acc);
     st(IC<5>{}, acs);
     md_bar();
     rc(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], -c3p_inv_fact[6]);
     rc(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7]);
-    mm_real<NIGR, NJ, W, WV, 1, 3, 3, 4, 5>(cm, Cm, Sp);
+    if constexpr (DEG20) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        Cm.set(e, fma(c3p_inv_fact[8], W4.get(e), Cm.get(e)));
+        Sp.set(e, fma(c3p_inv_fact[9], W4.get(e), Sp.get(e)));
+      }
+    }
+    mm_real<NIGR, NJ, W, WV, 1, 7, 7, 4, 5>(cm, Cm, Sp);
     st(IC<6>{}, Sp);
     md_bar();
     zero(Sn);
@@ -1802,29 +1880,29 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
       mirror(IC<4>{}, Pa, 1.0, Yb2);
       mirror(IC<5>{}, Pb, 0.5, Spb);
     }
-    // ---- Cm = Cm0 + W4 acc, Sp = Sp0 + W4 acs ----
+    // ---- Cm = Cm0 + H acc, Sp = Sp0 + H acs (W4b2: twice the cotangent of H from these two) ----
     Regs W4b2, accb, acsb;
     {
       st(IC<0>{}, Cb);
       st(IC<1>{}, acc);
-      st(IC<2>{}, W4);
+      st(IC<2>{}, H);
       md_bar();
       Regs Pc, Pd;
       zero(Pc);
       zero(Pd);
-      mm_real<NIGR, NJ, W, WV, 1, 0, 0, 1, 2>(cm, Pc, Pd);  // C_bar acc, C_bar W4
+      mm_real<NIGR, NJ, W, WV, 1, 0, 0, 1, 2>(cm, Pc, Pd);  // C_bar acc, C_bar H
       st_T(IC<4>{}, Pc);
       st_T(IC<5>{}, Pd);
       md_bar();
       mirror(IC<4>{}, Pc, 1.0, W4b2);
       mirror(IC<5>{}, Pd, 0.5, accb);
       st(IC<0>{}, Spb);
-      st(IC<1>{}, acs);  // (image 2 still holds W4)
+      st(IC<1>{}, acs);  // (image 2 still holds H)
       md_bar();
       Regs Pe, Pf;
       zero(Pe);
       zero(Pf);
-      mm_real<NIGR, NJ, W, WV, 1, 0, 0, 1, 2>(cm, Pe, Pf);  // Sp_bar acs, Sp_bar W4
+      mm_real<NIGR, NJ, W, WV, 1, 0, 0, 1, 2>(cm, Pe, Pf);  // Sp_bar acs, Sp_bar H
       st_T(IC<4>{}, Pe);
       st_T(IC<5>{}, Pf);
       md_bar();
@@ -1835,13 +1913,46 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
       for (int e = 0; e < NE; ++e) W4b2.set(e, W4b2.get(e) + tmp.get(e));
     }
     Regs W1b, W2b, W3b, W4b;
+    if constexpr (DEG20) {
+      Regs W5b;
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      const double ab = accb.get(e), sb = acsb.get(e), cb = Cb.get(e), pb = Spb.get(e);
-      W1b.set(e, -(c3p_inv_fact[2] * cb + c3p_inv_fact[3] * pb + c3p_inv_fact[10] * ab + c3p_inv_fact[11] * sb));
-      W2b.set(e, c3p_inv_fact[4] * cb + c3p_inv_fact[5] * pb + c3p_inv_fact[12] * ab + c3p_inv_fact[13] * sb);
-      W3b.set(e, -(c3p_inv_fact[6] * cb + c3p_inv_fact[7] * pb + c3p_inv_fact[14] * ab + c3p_inv_fact[15] * sb));
-      W4b.set(e, 0.5 * W4b2.get(e) + c3p_inv_fact[16] * ab + c3p_inv_fact[17] * sb);
+      for (int e = 0; e < NE; ++e) {
+        const double ab = accb.get(e), sb = acsb.get(e), cb = Cb.get(e), pb = Spb.get(e);
+        W1b.set(e, -(c3p_inv_fact[2] * cb + c3p_inv_fact[3] * pb) + (c3p_inv_fact[12] * ab + c3p_inv_fact[13] * sb));
+        W2b.set(e, (c3p_inv_fact[4] * cb + c3p_inv_fact[5] * pb) - (c3p_inv_fact[14] * ab + c3p_inv_fact[15] * sb));
+        W3b.set(e, -(c3p_inv_fact[6] * cb + c3p_inv_fact[7] * pb) + (c3p_inv_fact[16] * ab + c3p_inv_fact[17] * sb));
+        W4b.set(e, (c3p_inv_fact[8] * cb + c3p_inv_fact[9] * pb) - (c3p_inv_fact[18] * ab + c3p_inv_fact[19] * sb));
+        W5b.set(e, 0.5 * W4b2.get(e) + c3p_inv_fact[20] * ab + c3p_inv_fact[21] * sb);
+      }
+      // ---- W5 = W2 W3:  W2_bar += sym(W5_bar W3),  W3_bar += sym(W5_bar W2) ----
+      st(IC<0>{}, W5b);
+      st(IC<1>{}, W2);
+      st(IC<2>{}, W3);
+      md_bar();
+      Regs Pm, Pn;
+      zero(Pm);
+      zero(Pn);
+      mm_real<NIGR, NJ, W, WV, 1, 0, 0, 1, 2>(cm, Pm, Pn);  // W5_bar W2, W5_bar W3
+      st_T(IC<4>{}, Pm);
+      st_T(IC<5>{}, Pn);
+      md_bar();
+      Regs q, h;
+      mirror(IC<4>{}, Pm, 0.5, q);
+      mirror(IC<5>{}, Pn, 0.5, h);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        W3b.set(e, W3b.get(e) + q.get(e));
+        W2b.set(e, W2b.get(e) + h.get(e));
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const double ab = accb.get(e), sb = acsb.get(e), cb = Cb.get(e), pb = Spb.get(e);
+        W1b.set(e, -(c3p_inv_fact[2] * cb + c3p_inv_fact[3] * pb + c3p_inv_fact[10] * ab + c3p_inv_fact[11] * sb));
+        W2b.set(e, c3p_inv_fact[4] * cb + c3p_inv_fact[5] * pb + c3p_inv_fact[12] * ab + c3p_inv_fact[13] * sb);
+        W3b.set(e, -(c3p_inv_fact[6] * cb + c3p_inv_fact[7] * pb + c3p_inv_fact[14] * ab + c3p_inv_fact[15] * sb));
+        W4b.set(e, 0.5 * W4b2.get(e) + c3p_inv_fact[16] * ab + c3p_inv_fact[17] * sb);
+      }
     }
     // ---- W4 = W2^2, W3 = W W2:  W2_bar += {W4_bar, W2} + sym(W3_bar W),  W_bar += sym(W3_bar W2) ----
     {
@@ -1983,6 +2094,9 @@ __global__ void __launch_bounds__(256, (MDR<NIG, W>::SWZ ? 2 : 1)) midd_grad_rea
   nrm = md_rfl(nrm);
   cm.ps = __builtin_amdgcn_readfirstlane(mgr_squarings(nrm));
   if (cm.ps > MGR<NIG>::MAXS) return;
+  // degree 20 (theta_20 = 1.49) where it saves a squaring: 8 + 13 products against 7 + 11 + 5 per squaring
+  const int deg20 = __builtin_amdgcn_readfirstlane((int)(cm.ps > 0 && ldexp(nrm, 1 - cm.ps) <= 1.49));
+  cm.ps -= deg20;
   for (int e = tid; e < MGR_SLOTS * IMGR; e += 256) c3p_md_lds[e] = 0.0;
   for (int k = 0; k < K; ++k) {
     const double* s = A.signals + ((long)cm.sample * K + k) * A.N + cm.n0;
@@ -1992,11 +2106,20 @@ __global__ void __launch_bounds__(256, (MDR<NIG, W>::SWZ ? 2 : 1)) midd_grad_rea
   cm.t18 = 1;
   cm.scale = ldexp(1.0, -cm.ps);
   __syncthreads();
-  switch (wave) {
-    case 0: midd_grad_real_body<NIG, NJ, W, 0>(A, cm, chain, red); break;
-    case 1: midd_grad_real_body<NIG, NJ, W, 1>(A, cm, chain, red); break;
-    case 2: midd_grad_real_body<NIG, NJ, W, 2>(A, cm, chain, red); break;
-    default: midd_grad_real_body<NIG, NJ, W, 3>(A, cm, chain, red); break;
+  if (deg20) {
+    switch (wave) {
+      case 0: midd_grad_real_body<NIG, NJ, W, 0, true>(A, cm, chain, red); break;
+      case 1: midd_grad_real_body<NIG, NJ, W, 1, true>(A, cm, chain, red); break;
+      case 2: midd_grad_real_body<NIG, NJ, W, 2, true>(A, cm, chain, red); break;
+      default: midd_grad_real_body<NIG, NJ, W, 3, true>(A, cm, chain, red); break;
+    }
+  } else {
+    switch (wave) {
+      case 0: midd_grad_real_body<NIG, NJ, W, 0, false>(A, cm, chain, red); break;
+      case 1: midd_grad_real_body<NIG, NJ, W, 1, false>(A, cm, chain, red); break;
+      case 2: midd_grad_real_body<NIG, NJ, W, 2, false>(A, cm, chain, red); break;
+      default: midd_grad_real_body<NIG, NJ, W, 3, false>(A, cm, chain, red); break;
+    }
   }
 }
 
