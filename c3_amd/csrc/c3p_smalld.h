@@ -69,4 +69,5 @@ size_t c3p_smalld_table_doubles(int Dm, int K);
 bool c3p_smalld_supported(int Dm);
 hipError_t c3p_launch_smalld_chain(const SmallArgs& A, hipStream_t st);
 hipError_t c3p_launch_smalld_grad(const SmallGradArgs& A, hipStream_t st);
+hipError_t c3p_launch_smalld_grad_real(const SmallGradArgs& A, hipStream_t st);  // real-Hamiltonian sweep only (c3p_launch_smalld_grad calls it)
 hipError_t c3p_launch_smalld_prep(const PrepArgs& P, int Dm, int nsamp, hipStream_t st);

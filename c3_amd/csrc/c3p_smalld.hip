@@ -29,6 +29,15 @@
 #include "c3p_kernels.h"
 #include "c3p_smalld.h"
 
+// Built as two translation units (__graft_entry__.build: -DC3P_SMALLD_PART=1 | 2): everything but the real-Hamiltonian
+// backward sweep, and that sweep alone -- it is compiled with -mllvm -amdgpu-mfma-vgpr-form (see smalld_grad_real_kernel).
+// Without the macro everything lands in one unit.
+#ifdef C3P_SMALLD_PART
+#define C3P_SMALLD_HAS(p) (C3P_SMALLD_PART == (p))
+#else
+#define C3P_SMALLD_HAS(p) 1
+#endif
+
 extern __shared__ __attribute__((aligned(16))) double c3p_sd_lds[];
 
 namespace {
@@ -1914,21 +1923,6 @@ hipError_t launch_prep_t(const PrepArgs& P, int nsamp, hipStream_t st) {
 
 }  // namespace
 
-int c3p_smalld_mat_doubles(int Dm) {
-  const int NBI = (Dm + 1) / 2, NJ = (Dm + 3) / 4;
-  return 4 * NBI * (4 * NJ + 1);
-}
-
-int c3p_smalld_img_doubles(int Dm) {
-  const int NBI = (Dm + 1) / 2, NJ = (Dm + 3) / 4;
-  const int mat = 4 * NBI * (4 * NJ + 1);
-  return ((mat - 12 + 31) / 32) * 32 + 12;
-}
-
-size_t c3p_smalld_table_doubles(int Dm, int K) { return (size_t)(1 + K) * (c3p_smalld_mat_doubles(Dm) + 4); }
-
-bool c3p_smalld_supported(int Dm) { return Dm >= 2 && Dm <= C3P_SMALLD_MAX; }
-
 #define SD_DISPATCH(FN, ...)                                   \
   switch (Dm) {                                                \
     case 2: return FN<2>(__VA_ARGS__);                         \
@@ -1945,6 +1939,29 @@ bool c3p_smalld_supported(int Dm) { return Dm >= 2 && Dm <= C3P_SMALLD_MAX; }
     default: return hipErrorInvalidValue;                      \
   }
 
+#if C3P_SMALLD_HAS(2)
+hipError_t c3p_launch_smalld_grad_real(const SmallGradArgs& A, hipStream_t st) {
+  const int Dm = A.Dm;
+  SD_DISPATCH(launch_grad_real_t, A, st)
+}
+#endif
+
+#if C3P_SMALLD_HAS(1)
+int c3p_smalld_mat_doubles(int Dm) {
+  const int NBI = (Dm + 1) / 2, NJ = (Dm + 3) / 4;
+  return 4 * NBI * (4 * NJ + 1);
+}
+
+int c3p_smalld_img_doubles(int Dm) {
+  const int NBI = (Dm + 1) / 2, NJ = (Dm + 3) / 4;
+  const int mat = 4 * NBI * (4 * NJ + 1);
+  return ((mat - 12 + 31) / 32) * 32 + 12;
+}
+
+size_t c3p_smalld_table_doubles(int Dm, int K) { return (size_t)(1 + K) * (c3p_smalld_mat_doubles(Dm) + 4); }
+
+bool c3p_smalld_supported(int Dm) { return Dm >= 2 && Dm <= C3P_SMALLD_MAX; }
+
 hipError_t c3p_launch_smalld_chain(const SmallArgs& A, hipStream_t st) {
   const int Dm = A.Dm;
   SD_DISPATCH(launch_chain_t, A, st)
@@ -1957,11 +1974,7 @@ hipError_t c3p_launch_smalld_grad(const SmallGradArgs& A_, hipStream_t st) {
   // real Hamiltonians first (reverse mode through the cos / sin evaluation), then the general sweep for the rest; the
   // per-slice generator cotangents (zout) only exist in the general sweep
   if (A.zout == nullptr && !getenv("C3P_NO_REAL_GRAD")) {
-    hipError_t e = hipSuccess;
-    {
-      auto go = [&]() -> hipError_t { SD_DISPATCH(launch_grad_real_t, A, st) };
-      e = go();
-    }
+    const hipError_t e = c3p_launch_smalld_grad_real(A, st);
     if (e != hipSuccess) return e;
     A.skip_real = 1;
   }
@@ -1971,3 +1984,4 @@ hipError_t c3p_launch_smalld_grad(const SmallGradArgs& A_, hipStream_t st) {
 hipError_t c3p_launch_smalld_prep(const PrepArgs& P, int Dm, int nsamp, hipStream_t st) {
   SD_DISPATCH(launch_prep_t, P, nsamp, st)
 }
+#endif
