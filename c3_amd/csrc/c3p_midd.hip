@@ -1580,6 +1580,8 @@ __global__ void __launch_bounds__(256, 1) midd_grad_kernel(MidGradArgs A) {
 // operands are read in the B pattern).  Always the degree-16 / 17 polynomials, up to MGR<NIG>::MAXS squarings; other chains
 // are left to midd_grad_kernel (same tables, same norm bound: same decision).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int mgr_tswz(int x) { return (16 * (x & 1)) ^ (4 * ((x >> 1) & 7)); }
+
 template <int NIG, int NJ, int W, int WV, bool DEG20>
 __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const MidCommon& cm, long chain, double* red) {
   constexpr int NIGR = MDR<NIG, W>::NIGR;
@@ -1615,10 +1617,11 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
     const bool in = row < D && col < D;
     const int rr = in ? row : 0, cc = in ? col : 0;
     // images 4 / 5 only pass products to their mirror reads: in the 32-wide classes they have their own swizzle,
-    // element (row, col) at row * 32 + (col ^ 4 (row & 7)), which spreads the 64 lanes of a MIRROR read (16 rows x 4
-    // columns of the image) over all bank pairs (the operand swizzle gave 8-way conflicts there)
-    toff[e] = SWZ ? cc * 32 + (rr ^ (4 * (cc & 7))) : cc * WI + rr;
-    soff[e] = SWZ ? row * 32 + (col ^ (4 * (row & 7))) : 0;
+    // element (row, col) at row * 32 + (col ^ f(row)), f(x) = 16 (x & 1) ^ 4 ((x >> 1) & 7), which spreads the 64 lanes
+    // of the store (4 rows x 16 columns) AND of the mirror read (16 rows x 4 columns) over all 32 bank pairs (the operand
+    // swizzle gave 8-way conflicts on the mirror read)
+    toff[e] = SWZ ? cc * 32 + (rr ^ mgr_tswz(cc)) : cc * WI + rr;
+    soff[e] = SWZ ? row * 32 + (col ^ mgr_tswz(row)) : 0;
     inbits |= in ? (1u << e) : 0u;
     dbits |= (row == col && col < D) ? (1u << e) : 0u;
   }
