@@ -333,6 +333,32 @@ __device__ __forceinline__ void mm_symA(const double (&za)[RD<D>::NB][RD<D>::NB]
   }
 }
 
+// acc (ALL tiles) += A B for symmetric A and B (operand tiles filled): the full product whose mirror gives
+// A B + B A (backward sweep).  The single-k tail takes column D-1 of both from their last tile column.
+template <int D>
+__device__ __forceinline__ void mm_symfull(const double (&za)[RD<D>::NB][RD<D>::NB], const double (&zb)[RD<D>::NB][RD<D>::NB],
+                                           double (&acc)[RD<D>::NB][RD<D>::NB], int tail_lane) {
+  constexpr int NB = RD<D>::NB;
+#pragma unroll
+  for (int K = 0; K < SymTail<D>::KM; ++K)
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) acc[I][J] = mfma4(za[K][I], zb[K][J], acc[I][J]);
+  if constexpr (SymTail<D>::ON) {
+    double av[NB], bv[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      av[I] = quad_bcast0(za[I][NB - 1]);
+      bv[I] = __shfl(zb[I][NB - 1], tail_lane);
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) acc[I][J] = fma(av[I], bv[J], acc[I][J]);
+  }
+}
+
 // out = c0 I + c1 W + c2 W2 (+ c3 W3); UPPER: tiles J >= I only (accumulators of a symmetric product, mirrored
 // afterwards); otherwise the tiles a product reads as operands (rows I < KM in full, upper tiles of the other rows)
 template <int D, bool WITH3, bool UPPER = false>
@@ -1604,17 +1630,15 @@ __global__ void __launch_bounds__(64, 1) smalld_grad_real_kernel(SmallGradArgs A
 #pragma unroll
       for (int J = 0; J < NB; ++J) m[I][J] = 0.0;
   };
-  // acc(upper) += f (A B + B A) for symmetric A, B (operand tiles filled)
-  auto sym2 = [&](const RMat& Am, const RMat& Bm, RMat& acc) {
-    mm_sym<D>(Am, Bm, acc, tail_lane);
-    mm_sym<D>(Bm, Am, acc, tail_lane);
-  };
-  auto scale_fill = [&](RMat& m, double f) {  // upper tiles *= f, then mirror the operand tiles
+  // acc (all tiles) += A B for symmetric A, B (operand tiles filled)
+  auto prod = [&](const RMat& Am, const RMat& Bm, RMat& acc) { mm_symfull<D>(Am, Bm, acc, tail_lane); };
+  // out = f (P + P^T) on the tiles a product reads as operands (rows I < KM in full, upper tiles of the others): element
+  // (4J + c, 4I + r) of P sits in lane (c, r) of tile (J, I).  One round of lane swaps, no separate mirror fill.
+  auto mirror = [&](const RMat& P, double f, RMat& out) {
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
-      for (int J = I; J < NB; ++J) m[I][J] *= f;
-    sym_fill<D>(m, swap_lane);
+      for (int J = sym_j0<D>(I); J < NB; ++J) out[I][J] = f * (P[I][J] + __shfl(P[J][I], swap_lane));
   };
 
   // N = M^T at the end of this segment
@@ -1759,83 +1783,101 @@ __global__ void __launch_bounds__(64, 1) smalld_grad_real_kernel(SmallGradArgs A
     wave_sync();
     // ---- cotangents of cos / sin: C_bar = sym Re R, S_bar = -sym Im R (upper tiles, then the operand tiles) ----
     RMat Cb, Sb;
-#pragma unroll
-    for (int I = 0; I < NB; ++I)
-#pragma unroll
-      for (int J = I; J < NB; ++J) {
-        Cb[I][J] = 0.5 * (Rr[I][J] + __shfl(Rr[J][I], swap_lane));
-        Sb[I][J] = -0.5 * (Ri[I][J] + __shfl(Ri[J][I], swap_lane));
-      }
-    sym_fill<D>(Cb, swap_lane);
-    sym_fill<D>(Sb, swap_lane);
-    // ---- back through the squarings ----
+    mirror(Rr, 0.5, Cb);
+    mirror(Ri, -0.5, Sb);
+    // Every cotangent below is A_bar B + B A_bar = P + P^T with ONE full product P = A_bar B (18 MFMAs + a 9-FMA tail
+    // at D = 9) and the mirror by lane swaps -- against two upper-triangle products (24 + 12); products that feed the same
+    // cotangent are summed (in the accumulators, or by one FMA per element) BEFORE the mirror.
+    // ---- back through the squarings: C_bar = {C_bar', C} + {S_bar', S},  S_bar = {S_bar', C} - {C_bar', S} ----
 #pragma unroll
     for (int j = SDG_MAXS - 1; j >= 0; --j)
       if (j < ps) {
-        RMat nC, nS, tmp;
-        zero(nC), zero(nS), zero(tmp);
-        sym2(Cb, Cl[j], nC);
-        sym2(Sb, Sl[j], nC);
-        sym2(Sb, Cl[j], nS);
-        sym2(Cb, Sl[j], tmp);
+        RMat Pc, Ps, Pt;
+        zero(Pc), zero(Ps), zero(Pt);
+        prod(Cb, Cl[j], Pc);
+        prod(Sb, Sl[j], Pc);
+        prod(Sb, Cl[j], Ps);
+        prod(Cb, Sl[j], Pt);
 #pragma unroll
         for (int I = 0; I < NB; ++I)
 #pragma unroll
-          for (int J = I; J < NB; ++J) {
-            Cb[I][J] = nC[I][J];
-            Sb[I][J] = nS[I][J] - tmp[I][J];
-          }
-        sym_fill<D>(Cb, swap_lane);
-        sym_fill<D>(Sb, swap_lane);
+          for (int J = 0; J < NB; ++J) Ps[I][J] -= Pt[I][J];
+        mirror(Pc, 1.0, Cb);
+        mirror(Ps, 1.0, Sb);
       }
     // ---- back through S = Y Sp, Cm = Cm0 + W4 acc, Sp = Sp0 + W4 acs and the powers ----
-    RMat Yb, Spb, W4b, accb, acsb;
-    zero(Yb), zero(Spb), zero(W4b), zero(accb), zero(acsb);
-    sym2(Sb, Sp, Yb);      // 2 x sym(S_bar Sp)
-    sym2(Sb, Y, Spb);      // 2 x sym(S_bar Y)
-    scale_fill(Spb, 0.5);
-    sym2(Cb, acc, W4b);
-    sym2(Spb, acs, W4b);   // 2 x
-    sym2(W4, Cb, accb);
-    sym2(W4, Spb, acsb);
+    RMat Yb2, Spb, W4b, accb, acsb;
+    {
+      RMat Pa, Pb;
+      zero(Pa), zero(Pb);
+      prod(Sb, Sp, Pa);
+      prod(Sb, Y, Pb);
+      mirror(Pa, 1.0, Yb2);  // 2 x sym(S_bar Sp)
+      mirror(Pb, 0.5, Spb);  // sym(S_bar Y)
+    }
+    {
+      RMat Pw, Pd, Pf;
+      zero(Pw), zero(Pd), zero(Pf);
+      prod(Cb, acc, Pw);
+      prod(Spb, acs, Pw);
+      prod(Cb, W4, Pd);
+      prod(Spb, W4, Pf);
+      mirror(Pw, 0.5, W4b);   // sym(C_bar acc) + sym(Sp_bar acs)
+      mirror(Pd, 0.5, accb);  // sym(W4 C_bar)
+      mirror(Pf, 0.5, acsb);  // sym(W4 Sp_bar)
+    }
     RMat W1b, W2b, W3b;
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
-      for (int J = I; J < NB; ++J) {
-        const double ab = 0.5 * accb[I][J], sb = 0.5 * acsb[I][J], cb = Cb[I][J], pb = Spb[I][J];
+      for (int J = sym_j0<D>(I); J < NB; ++J) {
+        const double ab = accb[I][J], sb = acsb[I][J], cb = Cb[I][J], pb = Spb[I][J];
         W1b[I][J] = -(c3p_inv_fact[2] * cb + c3p_inv_fact[3] * pb + c3p_inv_fact[10] * ab + c3p_inv_fact[11] * sb);
         W2b[I][J] = c3p_inv_fact[4] * cb + c3p_inv_fact[5] * pb + c3p_inv_fact[12] * ab + c3p_inv_fact[13] * sb;
         W3b[I][J] = -(c3p_inv_fact[6] * cb + c3p_inv_fact[7] * pb + c3p_inv_fact[14] * ab + c3p_inv_fact[15] * sb);
-        W4b[I][J] = 0.5 * W4b[I][J] + c3p_inv_fact[16] * ab + c3p_inv_fact[17] * sb;
+        W4b[I][J] = W4b[I][J] + c3p_inv_fact[16] * ab + c3p_inv_fact[17] * sb;
       }
-    sym_fill<D>(W4b, swap_lane);
-    sym_fill<D>(W3b, swap_lane);
     {
-      RMat t2, t1;
-      zero(t2), zero(t1);
-      sym2(W4b, W2, W2b);  // W4 = W2^2
-      sym2(W3b, W1, t2);   // W3 = W1 W2: 2 x sym(W3_bar W1) -> W2_bar, 2 x sym(W3_bar W2) -> W1_bar
-      sym2(W3b, W2, t1);
+      // W4 = W2^2, W3 = W W2:  W2_bar += {W4_bar, W2} + sym(W3_bar W),  W_bar += sym(W3_bar W2)
+      RMat Pi, Pg, Ph, q, h;
+      zero(Pi), zero(Pg), zero(Ph);
+      prod(W4b, W2, Pi);
+      prod(W3b, W1, Pg);
+      prod(W3b, W2, Ph);
 #pragma unroll
       for (int I = 0; I < NB; ++I)
 #pragma unroll
-        for (int J = I; J < NB; ++J) {
-          W2b[I][J] = fma(0.5, t2[I][J], W2b[I][J]);
-          W1b[I][J] = fma(0.5, t1[I][J], W1b[I][J]);
+        for (int J = 0; J < NB; ++J) Pi[I][J] = fma(0.5, Pg[I][J], Pi[I][J]);
+      mirror(Pi, 1.0, q);
+      mirror(Ph, 0.5, h);
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = sym_j0<D>(I); J < NB; ++J) {
+          W2b[I][J] += q[I][J];
+          W1b[I][J] += h[I][J];
         }
     }
-    sym_fill<D>(W2b, swap_lane);
-    sym2(W2b, W1, W1b);  // W2 = W1^2
-    sym_fill<D>(W1b, swap_lane);
     {
-      RMat t0;
-      zero(t0);
-      sym2(W1b, Y, t0);  // W1 = Y^2
+      RMat Pj, q;  // W2 = W^2:  W_bar += {W2_bar, W}
+      zero(Pj);
+      prod(W2b, W1, Pj);
+      mirror(Pj, 1.0, q);
 #pragma unroll
       for (int I = 0; I < NB; ++I)
 #pragma unroll
-        for (int J = I; J < NB; ++J) Yb[I][J] = fma(0.5, Yb[I][J], t0[I][J]);
+        for (int J = sym_j0<D>(I); J < NB; ++J) W1b[I][J] += q[I][J];
+    }
+    RMat Yb;
+    {
+      RMat Pk;  // W = Y^2:  Y_bar = sym(S_bar Sp) + {W_bar, Y}
+      zero(Pk);
+      prod(W1b, Y, Pk);
+      mirror(Pk, 1.0, Yb);
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = I; J < NB; ++J) Yb[I][J] = fma(0.5, Yb2[I][J], Yb[I][J]);
     }
     // ---- grad[k] = scale <Y_bar, Y_k> (full-matrix inner product of symmetric matrices) + Re(mu_k conj(tr N)) ----
     for (int k = 0; k < K; ++k) {
