@@ -529,27 +529,37 @@ __device__ __forceinline__ void build_tables(const SmallArgs& A, int sample, dou
 
 // XG: the generators are supplied per slice (branch B of pwc, propagation.py:295-308, and c3p_expm):
 // X_n = coef * hs[b,n] - mu_n with (mu_n, ||X_n - mu_n||_1) from the hmeta pre-pass; no tables, no signals.
-template <int D, bool GIVEN, bool DUS, bool XG = false>
-__global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
+// MW (table modes, fused combine): ONE WORKGROUP PER SAMPLE, S / 4 waves of four chains each (cfg2: 8 waves = two per SIMD
+// of one CU).  The tables are built once per workgroup and the waves' partial products meet in LDS behind a barrier,
+// instead of once per wave and through global memory behind a ticket: the fixed cost of a cfg2 batch (29 us of 149:
+// combine 12, table build 4, launch and prologue 13) is what this mode attacks.
+template <int D, bool GIVEN, bool DUS, bool XG = false, bool MW = false>
+__global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallArgs A) {
   using C = SD<D>;
   constexpr int NBI = C::NBI, NJ = C::NJ, W = C::W, MAT = C::MAT, IMG = C::IMG;
-  const int lane = threadIdx.x;
+  const int lane = MW ? (threadIdx.x & 63) : threadIdx.x;
+  const int wv = MW ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+  const int nwv = MW ? (int)(blockDim.x >> 6) : 1;
   LanePos lp;
   lp.r = lane >> 4;
   lp.b = (lane >> 2) & 3;
   lp.c = lane & 3;
   lp.idx16 = lp.r * 4 + lp.c;
   const int K = A.K;
-  double* tab = c3p_sd_lds;  // (1+K) images + scalars (table modes only)
-  double* img = tab + ((GIVEN || XG) ? 0 : (1 + K) * (MAT + 4));  // 4 chain images
-  double* sg = img + 4 * IMG;  // 4 chains x K x Lmax signals, odd chain stride (bank spread)
+  double* tab = c3p_sd_lds;  // (1+K) images + scalars (table modes only; shared by the waves of a workgroup)
   const int SG = (K * A.Lmax) | 1;
+  double* img = tab + ((GIVEN || XG) ? 0 : (1 + K) * (MAT + 4)) + wv * (4 * IMG + 4 * SG);  // this wave's 4 chain images
+  double* sg = img + 4 * IMG;  // 4 chains x K x Lmax signals, odd chain stride (bank spread)
+  double* part = tab + (1 + K) * (MAT + 4) + nwv * (4 * IMG + 4 * SG);  // MW: the waves' partial products [nwv][D][D][2]
 
   // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Logical block
   // (bid % 8) * (nb / 8) + bid / 8 keeps consecutive logical blocks -- the waves of one sample, which exchange their
   // segment partials in the fused combine -- on ONE XCD.
   long lblock = blockIdx.x;
-  if ((gridDim.x & 7) == 0) lblock = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if constexpr (MW)
+    lblock = (long)blockIdx.x * nwv + wv;  // workgroup = sample, wave = four consecutive segments
+  else if ((gridDim.x & 7) == 0)
+    lblock = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const long chain = lblock * 4 + lp.b;
   const long nchains = (long)A.B * A.S;
   const bool valid = chain < nchains;
@@ -622,29 +632,42 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
       nrm = fmax(nrm, __shfl_xor(nrm, 16));
       nrm = fmax(nrm, __shfl_xor(nrm, 32));
     } else {
-    if (A.inline_tables) {
-      build_tables<D>(A, __builtin_amdgcn_readfirstlane(sample), tab, lane);
-    } else {
-      const double* gt0 = A.tables + (long)(A.tab_per_sample ? sample : 0) * (1 + K) * (MAT + 4);
-      for (int e = lane; e < (1 + K) * (MAT + 4); e += 64) tab[e] = gt0[e];
+    if (!MW || wv == 0) {  // (MW: wave 0 builds for the workgroup, the others go on to their control amplitudes)
+      if (A.inline_tables) {
+        build_tables<D>(A, __builtin_amdgcn_readfirstlane(sample), tab, lane);
+      } else {
+        const double* gt0 = A.tables + (long)(A.tab_per_sample ? sample : 0) * (1 + K) * (MAT + 4);
+        for (int e = lane; e < (1 + K) * (MAT + 4); e += 64) tab[e] = gt0[e];
+      }
     }
-    __syncthreads();
+    if constexpr (!MW) __syncthreads();
     // segment-wide bound on ||X||_1 <= ||G0|| + sum_k max_t |c_k(t)| ||G_k||  -> one plan per segment
-    nrm = tab[MAT + 2];
-    for (int k = 0; k < K; ++k) {
+    // (MW: the amplitudes are fetched while wave 0 builds the tables, their maxima taken from LDS after the barrier)
+    auto seg_max = [&](int k, bool from_lds) {
       const double* s = A.signals + ((long)sample * K + k) * A.N + n0;
       double cmax = 0.0;
       for (int t = lp.idx16; t < A.Lmax; t += 16) {
-        const double v = (valid && t < len) ? s[t] : 0.0;
-        sg[lp.b * SG + k * A.Lmax + t] = v;
+        double v;
+        if (from_lds) {
+          v = sg[lp.b * SG + k * A.Lmax + t];
+        } else {
+          v = (valid && t < len) ? s[t] : 0.0;
+          sg[lp.b * SG + k * A.Lmax + t] = v;
+        }
         cmax = fmax(cmax, fabs(v));
       }
       cmax = fmax(cmax, __shfl_xor(cmax, 1));
       cmax = fmax(cmax, __shfl_xor(cmax, 2));
       cmax = fmax(cmax, __shfl_xor(cmax, 16));
       cmax = fmax(cmax, __shfl_xor(cmax, 32));
-      nrm = fma(cmax, tab[(k + 1) * (MAT + 4) + MAT + 2], nrm);
+      return cmax;
+    };
+    if constexpr (MW) {
+      for (int k = 0; k < K; ++k) (void)seg_max(k, false);
+      __syncthreads();  // the tables of wave 0 are in place
     }
+    nrm = tab[MAT + 2];
+    for (int k = 0; k < K; ++k) nrm = fma(seg_max(k, MW), tab[(k + 1) * (MAT + 4) + MAT + 2], nrm);
     }
     nrm = fmax(nrm, __shfl_xor(nrm, 4));
     nrm = fmax(nrm, __shfl_xor(nrm, 8));
@@ -1083,24 +1106,33 @@ __global__ void __launch_bounds__(64, 2) smalld_chain_kernel(SmallArgs A) {
         store_plain<D>(Wt, dst, er * cs, er * sn, ph, lp, valid && lp.b == 0);
         return;
       }
-      {
-        double* dst = reinterpret_cast<double*>(A.seg_out) + ((long)sample * nW + wq) * D * D * 2;
-        store_plain<D, true>(Wt, dst, er * cs, er * sn, nullptr, lp, valid && lp.b == 0);
-      }
-      // (2) publish and arrive (cdna guide G16, form R1: write-through payload, drain, relaxed ticket)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      int old = 0;
-      if (lane == 0)
-        old = __hip_atomic_fetch_add(A.counters + sample, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      old = __builtin_amdgcn_readfirstlane(old);
-      if (old != nW - 1) return;
-      if (lane == 0) A.counters[sample] = 0;  // self-resetting: the next launch finds it zero
-      // (3) last arriver of this sample: fold the nW partials (slot b takes a contiguous quarter)
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       const int lo = (lp.b * nW) >> 2, hi = ((lp.b + 1) * nW) >> 2;
       const int cnt = hi - lo;
       const int cmax = (nW + 3) >> 2;
-      const double* base = reinterpret_cast<const double*>(A.seg_out) + ((long)sample * nW + lo) * D * D * 2;
+      const double* base;
+      if constexpr (MW) {
+        // (2) the waves of the sample are the waves of this workgroup: partials through LDS, wave 0 folds them
+        store_plain<D>(Wt, part + (long)wq * D * D * 2, er * cs, er * sn, nullptr, lp, lp.b == 0);
+        __syncthreads();
+        if (wv != 0) return;
+        base = part + (long)lo * D * D * 2;
+      } else {
+        {
+          double* dst = reinterpret_cast<double*>(A.seg_out) + ((long)sample * nW + wq) * D * D * 2;
+          store_plain<D, true>(Wt, dst, er * cs, er * sn, nullptr, lp, valid && lp.b == 0);
+        }
+        // (2) publish and arrive (cdna guide G16, form R1: write-through payload, drain, relaxed ticket)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int old = 0;
+        if (lane == 0)
+          old = __hip_atomic_fetch_add(A.counters + sample, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old != nW - 1) return;
+        if (lane == 0) A.counters[sample] = 0;  // self-resetting: the next launch finds it zero
+        // (3) last arriver of this sample: fold the nW partials (slot b takes a contiguous quarter)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        base = reinterpret_cast<const double*>(A.seg_out) + ((long)sample * nW + lo) * D * D * 2;
+      }
       // the next partial of the slot is always in flight while the current product runs, and the first two are
       // fetched together: ONE cross-CU memory round trip for S <= 32
       double Pn[NBI][NJ];
@@ -1269,8 +1301,25 @@ hipError_t launch_chain_t(const SmallArgs& A, hipStream_t st) {
     hipLaunchKernelGGL((smalld_chain_kernel<D, true, false>), dim3(grid), dim3(64), lds, st, A);
   else if (A.dUs_out)
     hipLaunchKernelGGL((smalld_chain_kernel<D, false, true>), dim3(grid), dim3(64), lds, st, A);
-  else
-    hipLaunchKernelGGL((smalld_chain_kernel<D, false, false>), dim3(grid), dim3(64), lds, st, A);
+  else {
+    // one workgroup per sample (MW) when the S / 4 waves of a sample fit a CU together with enough other samples for all
+    // B workgroups to be resident at once (8 waves per CU at two per SIMD): B = 256, S = 32 -> 256 workgroups of 8 waves
+    const int nW = A.S >> 2;
+    const size_t wstride = (size_t)(4 * C::IMG + 4 * ((A.K * A.Lmax) | 1));
+    const size_t lds_mw = (size_t)((1 + A.K) * (C::MAT + 4) + nW * wstride + (size_t)nW * D * D * 2) * sizeof(double);
+    const bool mw = A.fuse && (A.S & 3) == 0 && (nW == 2 || nW == 4 || nW == 8) && (long)A.B * nW <= 2048 &&
+                    lds_mw * (8 / nW) <= (size_t)156 * 1024 && !getenv("C3P_NO_MW");
+    if (mw) {
+      auto kern = smalld_chain_kernel<D, false, false, false, true>;
+      if (lds_mw > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mw);
+        if (e != hipSuccess) return e;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)A.B), dim3(64 * nW), lds_mw, st, A);
+    } else {
+      hipLaunchKernelGGL((smalld_chain_kernel<D, false, false>), dim3(grid), dim3(64), lds, st, A);
+    }
+  }
   return hipGetLastError();
 }
 
