@@ -455,11 +455,11 @@ __device__ __forceinline__ double wave_max64(double v) {
 // {Re mu, Im mu, ||G||_1, max |Re G|} -- what smalld_prep_kernel writes, without a dependent launch in
 // front of the chain kernel (~12 us of a 250 us batch).
 template <int D>
-__device__ __forceinline__ void build_tables(const SmallArgs& A, int sample, double* tab, int lane) {
+__device__ __forceinline__ void build_tables(const SmallArgs& A, int sample, double* tab, int lane, int first = 0, int step = 1) {
   using C = SD<D>;
   constexpr int MAT = C::MAT, W = C::W;
   constexpr int NE = (D * D + 63) / 64;
-  for (int ti = 0; ti <= A.K; ++ti) {
+  for (int ti = first; ti <= A.K; ti += step) {  // (a workgroup of several waves deals the tables to its waves)
     double* out = tab + ti * (MAT + 4);
     const cplx* h = (ti == 0) ? A.h0 + (long)sample * A.h0_bstride
                               : A.hks + (long)sample * A.hks_bstride + (long)(ti - 1) * D * D;
@@ -632,13 +632,12 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
       nrm = fmax(nrm, __shfl_xor(nrm, 16));
       nrm = fmax(nrm, __shfl_xor(nrm, 32));
     } else {
-    if (!MW || wv == 0) {  // (MW: wave 0 builds for the workgroup, the others go on to their control amplitudes)
-      if (A.inline_tables) {
-        build_tables<D>(A, __builtin_amdgcn_readfirstlane(sample), tab, lane);
-      } else {
-        const double* gt0 = A.tables + (long)(A.tab_per_sample ? sample : 0) * (1 + K) * (MAT + 4);
-        for (int e = lane; e < (1 + K) * (MAT + 4); e += 64) tab[e] = gt0[e];
-      }
+    // (MW: table k is built by wave k mod nwv; the barrier comes after the waves have fetched their control amplitudes)
+    if (A.inline_tables) {
+      build_tables<D>(A, __builtin_amdgcn_readfirstlane(sample), tab, lane, wv, nwv);
+    } else {
+      const double* gt0 = A.tables + (long)(A.tab_per_sample ? sample : 0) * (1 + K) * (MAT + 4);
+      for (int e = (MW ? (int)threadIdx.x : lane); e < (1 + K) * (MAT + 4); e += 64 * nwv) tab[e] = gt0[e];
     }
     if constexpr (!MW) __syncthreads();
     // segment-wide bound on ||X||_1 <= ||G0|| + sum_k max_t |c_k(t)| ||G_k||  -> one plan per segment
