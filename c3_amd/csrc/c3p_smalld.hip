@@ -540,6 +540,12 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
   const int lane = MW ? (threadIdx.x & 63) : threadIdx.x;
   const int wv = MW ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
   const int nwv = MW ? (int)(blockDim.x >> 6) : 1;
+#ifdef C3P_SD_TIMING
+  long long tk0 = wall_clock64(), tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0;
+#define SD_TICK(v) v = wall_clock64()
+#else
+#define SD_TICK(v)
+#endif
   LanePos lp;
   lp.r = lane >> 4;
   lp.b = (lane >> 2) & 3;
@@ -677,6 +683,7 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
     const int t18 = __builtin_amdgcn_readfirstlane(plan.t18);
     const double scale = ldexp(1.0, -ps);
     __syncthreads();
+    SD_TICK(tk1);
 
     // every table of this sample purely imaginary (real Hamiltonians) -> real fast path
     bool realH = !XG && (A.mode == C3P_MODE_UNITARY);
@@ -715,6 +722,9 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
       auto real_loop = [&](auto deg16_tag) {
       constexpr bool DEG16 = decltype(deg16_tag)::value;
       for (int t = 0; t < A.Lmax; ++t) {
+        // (Two waves share a SIMD and the arbiter serves the OLDER one first: wave w finishes its segment at ~64 % of the
+        // kernel time and wave w + 4 then runs alone -- wall_clock64 probes, -DC3P_SD_TIMING.  Alternating s_setprio per
+        // slice makes them finish together and changes nothing in the total: measured, not kept.)
         const bool act = valid && t < len;
         const double sc = act ? rscale : 0.0;
         const double muw = act ? 1.0 : 0.0;
@@ -1074,6 +1084,7 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
     }  // complex path
   }
   // ---- segment result ----
+  SD_TICK(tk2);
   if constexpr (!GIVEN) {
     if (A.fuse) {
       // (1) fold the wave's four consecutive segments: W = U3 U2 U1 U0 (later segment on the left)
@@ -1112,6 +1123,7 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
       if constexpr (MW) {
         // (2) the waves of the sample are the waves of this workgroup: partials through LDS, wave 0 folds them
         store_plain<D>(Wt, part + (long)wq * D * D * 2, er * cs, er * sn, nullptr, lp, lp.b == 0);
+        SD_TICK(tk3);
         __syncthreads();
         if (wv != 0) return;
         base = part + (long)lo * D * D * 2;
@@ -1181,6 +1193,11 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
       mm_img<D>(img, roff2, negmask, V, Wt);
       double* dst = reinterpret_cast<double*>(A.final_out) + (long)sample * D * D * 2;
       store_plain<D>(Wt, dst, 1.0, 0.0, ph, lp, lp.b == 0);
+#ifdef C3P_SD_TIMING
+      SD_TICK(tk4);
+      if (MW && blockIdx.x == 0 && threadIdx.x == 0)
+        printf("sd timing (100 MHz ticks): prologue %lld loop %lld fold4+store %lld combine %lld total %lld\n", tk1 - tk0, tk2 - tk1, tk3 - tk2, tk4 - tk3, tk4 - tk0);
+#endif
       return;
     }
   }
