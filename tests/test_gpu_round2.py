@@ -544,3 +544,57 @@ def test_mid_dims_real_path_more_than_three_control_lines(prop, D, K):
     for b in range(B):
         want = o.pwc_signal_gradient(h0, hks, sig[b], 1e-11, Ubar[b], ph[b])
         assert np.abs(g[b] - want).max() < 1e-10 * np.abs(want).max()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# small-D kernel: one workgroup per sample (S / 4 waves, combine through LDS) against one-wave workgroups (ticket)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,B,N", [(2, 256, 1000), (2, 512, 640), (2, 1024, 256), (2, 300, 500), (2, 2, 257), (1, 256, 200)])
+def test_smalld_workgroup_per_sample_mode(prop, cfg, B, N, monkeypatch):
+    """same arithmetic in the same order: bit-identical to the one-wave-workgroup mode; spot parity against the oracle"""
+    w = workloads.make_workload(cfg, B=B, N=N)
+    U = np.asarray(prop.propagate_batch(w.h0, w.hks, w.signals, w.dt, fr_phase=w.fr_phase)["U"])
+    monkeypatch.setenv("C3P_NO_MW", "1")
+    U0 = np.asarray(prop.propagate_batch(w.h0, w.hks, w.signals, w.dt, fr_phase=w.fr_phase)["U"])
+    monkeypatch.delenv("C3P_NO_MW")
+    assert np.array_equal(U, U0)
+    idx = np.unique(np.linspace(0, B - 1, 4).astype(int))
+    ref = o.propagate_batch(w.h0, w.hks, w.signals[idx], w.dt, fr_phase=w.fr_phase[idx])
+    assert np.abs(U[idx] - ref).max() < 1e-11
+
+
+@pytest.mark.gpu
+def test_smalld_workgroup_per_sample_mode_per_sample_and_lindblad(prop, monkeypatch):
+    """per-sample Hamiltonians (tables per workgroup) and a 9 x 9 Lindblad superoperator batch through the same mode"""
+    rng = np.random.default_rng(5)
+    D, B, K, N = 7, 256, 2, 320
+
+    def sym():
+        a = rng.normal(size=(D, D))
+        return (a + a.T) / 2
+
+    h0 = np.stack([sym() * 4e10 for _ in range(B)]).astype(np.complex128)
+    hks = np.stack([sym() for _ in range(K)]).astype(np.complex128)
+    sig = rng.normal(size=(B, K, N)) * 2e9
+    U = np.asarray(prop.propagate_batch(h0, hks, sig, 1e-11)["U"])
+    monkeypatch.setenv("C3P_NO_MW", "1")
+    U0 = np.asarray(prop.propagate_batch(h0, hks, sig, 1e-11)["U"])
+    monkeypatch.delenv("C3P_NO_MW")
+    assert np.array_equal(U, U0)
+    for b in (0, 100, 255):
+        assert np.abs(U[b] - o.propagate_batch(h0[b], hks, sig[b : b + 1], 1e-11)[0]).max() < 1e-11
+    # Lindblad, D = 3 (Dm = 9)
+    D = 3
+    a = rng.normal(size=(D, D))
+    h0 = ((a + a.T) / 2 * 3e10).astype(np.complex128)
+    hks = np.stack([sym()[:D, :D] for _ in range(K)]).astype(np.complex128)
+    col = (rng.normal(size=(2, D, D)) + 1j * rng.normal(size=(2, D, D))) * 3e3
+    sig = rng.normal(size=(B, K, N)) * 2e9
+    U = np.asarray(prop.propagate_batch(h0, hks, sig, 1e-11, col_ops=col, lindbladian=True)["U"])
+    monkeypatch.setenv("C3P_NO_MW", "1")
+    U0 = np.asarray(prop.propagate_batch(h0, hks, sig, 1e-11, col_ops=col, lindbladian=True)["U"])
+    monkeypatch.delenv("C3P_NO_MW")
+    assert np.array_equal(U, U0)
+    ref = o.propagate_batch(h0, hks, sig[:2], 1e-11, col_ops=col, lindbladian=True)
+    assert np.abs(U[:2] - ref).max() < 1e-11
