@@ -84,19 +84,24 @@ struct WsLock {
     if (!w) return;
     w->mu.lock();
     locked = true;
+    // The workspace is shared by the calls of a device: a call on ANOTHER stream than the previous one first waits for
+    // everything enqueued on that stream so far.  The event is recorded lazily, here, on the previous stream (enqueue order
+    // is fixed by the mutex), so the common one-stream caller pays no event per call (a marker packet between every two
+    // kernels: ~3 us of a 140 us cfg2 batch).  A previous stream that has been destroyed meanwhile: device-wide sync.
     if (order && w->has_last && w->last_stream != st) {
-      if (hipStreamWaitEvent(st, w->done, 0) != hipSuccess) ok = false;
+      if (!w->done) (void)hipEventCreateWithFlags(&w->done, hipEventDisableTiming);
+      if (!w->done || hipEventRecord(w->done, w->last_stream) != hipSuccess || hipStreamWaitEvent(st, w->done, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipDeviceSynchronize() != hipSuccess) ok = false;
+      }
     }
     ordered = order;
   }
   ~WsLock() {
     if (!locked) return;
     if (ordered) {
-      if (!w->done) (void)hipEventCreateWithFlags(&w->done, hipEventDisableTiming);
-      if (w->done && hipEventRecord(w->done, st) == hipSuccess) {
-        w->last_stream = st;
-        w->has_last = true;
-      }
+      w->last_stream = st;
+      w->has_last = true;
     }
     w->mu.unlock();
   }
