@@ -32,8 +32,9 @@
  *  - Thread-safe.  The workspace is ONE set per device, guarded by a per-device
  *    mutex at enqueue time (different devices do not serialise each other).  Calls
  *    on one stream are ordered by the stream; a call on ANOTHER stream of the same
- *    device first makes its stream wait (hipStreamWaitEvent) for the end of the
- *    previous call, so two streams never run kernels on the shared workspace at
+ *    device first makes its stream wait (hipStreamWaitEvent) for an event recorded,
+ *    at that moment, on the stream of the previous call (a one-stream caller pays no
+ *    event per call), so two streams never run kernels on the shared workspace at
  *    once -- results are correct from any number of streams, but calls on one
  *    device do not overlap each other.
  */
