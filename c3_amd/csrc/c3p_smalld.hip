@@ -404,16 +404,32 @@ __device__ __forceinline__ void plan_q4(double nrm, int& r, int& s) {
 
 // Write a D-layout matrix times the complex scalar (sr + i si), with optional row phases,
 // to a plain complex [D][D] array.
+// cos / sin of the row phases of the lane's rows (store_plain takes them instead of evaluating sincos in the store)
+template <int D>
+__device__ __forceinline__ void row_phase_factors(const double* row_phase, const LanePos& lp, double (&pc)[SD<D>::NBI],
+                                                  double (&ps)[SD<D>::NBI]) {
+#pragma unroll
+  for (int I = 0; I < SD<D>::NBI; ++I) {
+    const int row = 2 * I + (lp.r >> 1);
+    pc[I] = 1.0, ps[I] = 0.0;
+    if (row_phase != nullptr && row < D) sincos(row_phase[row], &ps[I], &pc[I]);
+  }
+}
+
 template <int D, bool WRITE_THROUGH = false>
 __device__ __forceinline__ void store_plain(const double (&zh)[SD<D>::NBI][SD<D>::NJ], double* dst,
                                             double sr, double si, const double* row_phase,
-                                            const LanePos& lp, bool active) {
+                                            const LanePos& lp, bool active, const double* pre_c = nullptr,
+                                            const double* pre_s = nullptr) {
   using C = SD<D>;
 #pragma unroll
   for (int I = 0; I < C::NBI; ++I) {
     const int row = 2 * I + (lp.r >> 1);
     double pr = sr, pi = si;
-    if (row_phase != nullptr && row < D) {
+    if (pre_c != nullptr) {
+      pr = sr * pre_c[I] - si * pre_s[I];
+      pi = sr * pre_s[I] + si * pre_c[I];
+    } else if (row_phase != nullptr && row < D) {
       double sn, cs;
       sincos(row_phase[row], &sn, &cs);
       pr = sr * cs - si * sn;
@@ -541,7 +557,7 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
   const int wv = MW ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
   const int nwv = MW ? (int)(blockDim.x >> 6) : 1;
 #ifdef C3P_SD_TIMING
-  long long tk0 = wall_clock64(), tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0;
+  long long tk0 = wall_clock64(), tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0, tk5 = 0, tk6 = 0, tk7 = 0, tk8 = 0, tk9 = 0;
 #define SD_TICK(v) v = wall_clock64()
 #else
 #define SD_TICK(v)
@@ -667,8 +683,10 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
       cmax = fmax(cmax, __shfl_xor(cmax, 32));
       return cmax;
     };
+    SD_TICK(tk8);
     if constexpr (MW) {
       for (int k = 0; k < K; ++k) (void)seg_max(k, false);
+      SD_TICK(tk9);
       __syncthreads();  // the tables of wave 0 are in place
     }
     nrm = tab[MAT + 2];
@@ -1120,12 +1138,17 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
       const int cnt = hi - lo;
       const int cmax = (nW + 3) >> 2;
       const double* base;
+      double phc[NBI], phs[NBI];
       if constexpr (MW) {
         // (2) the waves of the sample are the waves of this workgroup: partials through LDS, wave 0 folds them
         store_plain<D>(Wt, part + (long)wq * D * D * 2, er * cs, er * sn, nullptr, lp, lp.b == 0);
         SD_TICK(tk3);
+        // (wave 0 -- the older wave of its SIMD, through its loop first -- evaluates the row phases of the final store
+        // while it waits for the others: five double-precision sincos, 1.5 us otherwise spent after the barrier)
+        if (wv == 0) row_phase_factors<D>(ph, lp, phc, phs);
         __syncthreads();
         if (wv != 0) return;
+        SD_TICK(tk5);
         base = part + (long)lo * D * D * 2;
       } else {
         {
@@ -1183,6 +1206,7 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
             for (int J = 0; J < NJ; ++J) U[I][J] = acc[I][J];
         }
       }
+      SD_TICK(tk6);
 #pragma unroll
       for (int I = 0; I < NBI; ++I)
 #pragma unroll
@@ -1191,12 +1215,16 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
       mm_img<D>(img, roff1, negmask, U, V);
       write_image<D>(V, img, woff);
       mm_img<D>(img, roff2, negmask, V, Wt);
+      SD_TICK(tk7);
       double* dst = reinterpret_cast<double*>(A.final_out) + (long)sample * D * D * 2;
-      store_plain<D>(Wt, dst, 1.0, 0.0, ph, lp, lp.b == 0);
+      if constexpr (MW)
+        store_plain<D>(Wt, dst, 1.0, 0.0, ph, lp, lp.b == 0, phc, phs);
+      else
+        store_plain<D>(Wt, dst, 1.0, 0.0, ph, lp, lp.b == 0);
 #ifdef C3P_SD_TIMING
       SD_TICK(tk4);
       if (MW && blockIdx.x == 0 && threadIdx.x == 0)
-        printf("sd timing (100 MHz ticks): prologue %lld loop %lld fold4+store %lld combine %lld total %lld\n", tk1 - tk0, tk2 - tk1, tk3 - tk2, tk4 - tk3, tk4 - tk0);
+        printf("sd timing (100 MHz ticks): tables %lld signals %lld prologue %lld loop %lld fold4+store %lld barrier %lld level1 %lld fold2 %lld store %lld total %lld\n", tk8 - tk0, tk9 - tk8, tk1 - tk0, tk2 - tk1, tk3 - tk2, tk5 - tk3, tk6 - tk5, tk7 - tk6, tk4 - tk7, tk4 - tk0);
 #endif
       return;
     }
