@@ -78,8 +78,15 @@ struct MD {
 // Bigs are dealt round-robin (cost 4 each), smalls greedily to the least loaded wave.
 template <int NIG, int NJ>
 struct Sched {
-  static constexpr int NB16 = NJ / 4;
-  static constexpr int JR = NJ % 4;
+  // The 32-row real class with 7 column blocks (D = 25..28, cfg3: only the real instance has NIG = 2 there) pads the three
+  // leftover column blocks to a second 16-column unit (the 32-wide image has the zero columns): FOUR 16 x 16 units, one per
+  // wave, instead of two plus six small ones -- the small units cost two waves five LDS reads per K-step for 48 matrix-pipe
+  // cycles and their 16 x 4 stores are 8-way bank-conflicted; the kernel shares the LDS pipe of a CU between three
+  // workgroups and was as LDS-bound (63 % busy) as MFMA-bound (62 %).  cfg3 +9 %; with 6 column blocks (D = 21..24) the
+  // padding costs more matrix-pipe time than it saves LDS time (-4 %).
+  static constexpr bool PAD = NIG == 2 && NJ == 7;
+  static constexpr int NB16 = PAD ? 2 : NJ / 4;
+  static constexpr int JR = PAD ? 0 : NJ % 4;
   static constexpr int NBIG = NIG * NB16;
   static constexpr int NSMALL = NIG * JR;
   static constexpr int nbig(int w) { return w < NBIG ? (NBIG - w + NW - 1) / NW : 0; }
