@@ -1587,7 +1587,7 @@ __global__ void __launch_bounds__(256, 1) midd_grad_kernel(MidGradArgs A) {
 // operands are read in the B pattern).  Always the degree-16 / 17 polynomials, up to MGR<NIG>::MAXS squarings; other chains
 // are left to midd_grad_kernel (same tables, same norm bound: same decision).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int mgr_tswz(int x) { return (16 * (x & 1)) ^ (4 * ((x >> 1) & 7)); }
+__device__ __forceinline__ int mgr_tswz(int x) { return x & 15; }
 
 template <int NIG, int NJ, int W, int WV, bool DEG20>
 __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const MidCommon& cm, long chain, double* red) {
@@ -1624,9 +1624,10 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
     const bool in = row < D && col < D;
     const int rr = in ? row : 0, cc = in ? col : 0;
     // images 4 / 5 only pass products to their mirror reads: in the 32-wide classes they have their own swizzle,
-    // element (row, col) at row * 32 + (col ^ f(row)), f(x) = 16 (x & 1) ^ 4 ((x >> 1) & 7), which spreads the 64 lanes
-    // of the store (4 rows x 16 columns) AND of the mirror read (16 rows x 4 columns) over all 32 bank pairs (the operand
-    // swizzle gave 8-way conflicts on the mirror read)
+    // element (row, col) at row * 32 + (col ^ (row & 15)).  A 64-bit LDS access is served 16 lanes per cycle (32 banks x 4 B);
+    // the 16 lanes of a group hold ONE row and 16 columns in a store (any XOR keeps them distinct mod 16) and ONE column and
+    // 16 rows in a mirror read: (row' ^ (col' & 15)) mod 16 is distinct over the 16 col' -- conflict-free both ways (the
+    // operand swizzle put the 16 lanes of a mirror read on one bank pair)
     toff[e] = SWZ ? cc * 32 + (rr ^ mgr_tswz(cc)) : cc * WI + rr;
     soff[e] = SWZ ? row * 32 + (col ^ mgr_tswz(row)) : 0;
     inbits |= in ? (1u << e) : 0u;
@@ -1648,19 +1649,6 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
     if constexpr (SWZ) {
 #pragma unroll
       for (int e = 0; e < NE; ++e) c3p_md_lds[I * IMGR + soff[e]] = v.get(e);
-    } else {
-      st(img, v);
-    }
-  };
-  // image of the transpose (swizzled layout: general LEFT operands are read in the B pattern)
-  auto st_left = [&](auto img, const Regs& v) {
-    constexpr int I = decltype(img)::value;
-    if constexpr (SWZ) {
-#pragma unroll
-      for (int e = 0; e < NE; ++e) {
-        const int row = erow(e), col = ecol(e);  // always inside the 32 x 32 image
-        c3p_md_lds[I * IMGR + col * 32 + (row ^ (16 * (col & 1)))] = v.get(e);
-      }
     } else {
       st(img, v);
     }
@@ -1843,13 +1831,31 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
     }
     st_T(IC<4>{}, Rr);
     st_T(IC<5>{}, Ri);
-    st_left(IC<6>{}, Rr);
-    st_left(IC<7>{}, Ri);
+    if constexpr (!SWZ) {
+      st(IC<6>{}, Rr);
+      st(IC<7>{}, Ri);
+    }
     md_bar();
     // ---- cotangents of cos / sin: C_bar = sym Re R, S_bar = -sym Im R ----
+    // (swizzled classes: the mirror elements are also R^T at this lane's positions -- the image of the LEFT operand of
+    // the update of N, which those classes read in the B pattern -- stored with the ordinary conflict-free tile store;
+    // a transposed store into the operand layout puts the 16 lanes of a group on one bank pair)
     Regs Cb, Sb;
-    mirror(IC<4>{}, Rr, 0.5, Cb);
-    mirror(IC<5>{}, Ri, -0.5, Sb);
+    {
+      Regs tRr, tRi;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const double mr = c3p_md_lds[4 * IMGR + toff[e]], mi = c3p_md_lds[5 * IMGR + toff[e]];
+        tRr.set(e, (inbits >> e) & 1u ? mr : 0.0);
+        tRi.set(e, (inbits >> e) & 1u ? mi : 0.0);
+        Cb.set(e, 0.5 * (Rr.get(e) + tRr.get(e)));
+        Sb.set(e, -0.5 * (Ri.get(e) + tRi.get(e)));
+      }
+      if constexpr (SWZ) {
+        st(IC<6>{}, tRr);
+        st(IC<7>{}, tRi);
+      }
+    }
     // ---- back through the squarings: C_bar = 2 {C_bar', C} + {S_bar', S},  S_bar = {S_bar', C}  ({A, B} = AB + BA) ----
     auto unsquare = [&](int lvl) {
       st(IC<0>{}, Cb);
