@@ -13,8 +13,9 @@
 // The NIG x NJ output tiles are dealt to the 4 waves as contiguous runs of the flat index
 // t = J*NIG + Ig, compile-time per wave, so each wave loads every A slab it needs once per
 // K step and at most 3-4 B blocks: ~0.6 LDS reads per MFMA.
-// Row stride W (doubles) is chosen with 2W mod 64 in {12,...,52} step 8 or +-4 so that the
-// 16 rows of an A-slab read fall on distinct bank pairs.
+// Row stride W (doubles) = 4 NJ + 1, ODD: a 64-bit LDS access is served 16 lanes per cycle (32 banks x 4 B), and the 16
+// lanes of a group of an A-slab read hold 16 different rows of one column -- i W mod 16 must be distinct over 16 rows
+// (round 2: the even strides 4 NJ + 2 of round 1, chosen for a 64-bank model, made every A-slab read 2-way conflicted).
 //
 // Per slice: X (registers, from pre-shifted global tables) -> image; X^2, X^3, X^4; Horner in
 // X^4; squarings; U <- E U.  Every wave keeps ITS tiles of X, X^2, X^3, P and U in registers
@@ -2184,13 +2185,13 @@ bool c3p_midd_geometry(int Dm, int* nig, int* nj, int* w) {
   *nig = (NBI + 3) / 4;
   *nj = (Dm + 3) / 4;
   switch (*nj) {
-    case 4: *w = 18; break;   // D 13..16
-    case 5: *w = 22; break;   // D 17..20
-    case 6: *w = 26; break;   // D 21..24
-    case 7: *w = 30; break;   // D 25..28
-    case 8: *w = 34; break;   // D 29..32
-    case 9: *w = 38; break;   // D 33..36
-    default: *w = 42; break;  // D 37..40
+    case 4: *w = 17; break;   // D 13..16
+    case 5: *w = 21; break;   // D 17..20
+    case 6: *w = 25; break;   // D 21..24
+    case 7: *w = 29; break;   // D 25..28
+    case 8: *w = 33; break;   // D 29..32
+    case 9: *w = 37; break;   // D 33..36
+    default: *w = 41; break;  // D 37..40
   }
   return true;
 }
@@ -2219,13 +2220,13 @@ size_t c3p_midd_grad_image_bytes(int Dm) {
 hipError_t c3p_launch_midd_chain(const MidArgs& A, hipStream_t st) {
   int nig, nj, w;
   if (!c3p_midd_geometry(A.Dm, &nig, &nj, &w)) return hipErrorInvalidValue;
-  if (nig == 2 && nj == 4) return launch_t<2, 4, 18>(A, st);
-  if (nig == 3 && nj == 5) return launch_t<3, 5, 22>(A, st);
-  if (nig == 3 && nj == 6) return launch_t<3, 6, 26>(A, st);
-  if (nig == 4 && nj == 7) return launch_t<4, 7, 30>(A, st);
-  if (nig == 4 && nj == 8) return launch_t<4, 8, 34>(A, st);
-  if (nig == 5 && nj == 9) return launch_t<5, 9, 38>(A, st);
-  if (nig == 5 && nj == 10) return launch_t<5, 10, 42>(A, st);
+  if (nig == 2 && nj == 4) return launch_t<2, 4, 17>(A, st);
+  if (nig == 3 && nj == 5) return launch_t<3, 5, 21>(A, st);
+  if (nig == 3 && nj == 6) return launch_t<3, 6, 25>(A, st);
+  if (nig == 4 && nj == 7) return launch_t<4, 7, 29>(A, st);
+  if (nig == 4 && nj == 8) return launch_t<4, 8, 33>(A, st);
+  if (nig == 5 && nj == 9) return launch_t<5, 9, 37>(A, st);
+  if (nig == 5 && nj == 10) return launch_t<5, 10, 41>(A, st);
   return hipErrorInvalidValue;
 }
 
@@ -2239,13 +2240,13 @@ hipError_t c3p_launch_midd_prep(const MidPrepArgs& P, int nsamp, hipStream_t st)
 hipError_t c3p_launch_midd_real(const MidArgs& A, hipStream_t st) {
   int nig, nj, w;
   if (!c3p_midd_geometry(A.Dm, &nig, &nj, &w)) return hipErrorInvalidValue;
-  if (nig == 2 && nj == 4) return launch_real_t<2, 4, 18>(A, st);
-  if (nig == 3 && nj == 5) return launch_real_t<3, 5, 22>(A, st);
-  if (nig == 3 && nj == 6) return launch_real_t<3, 6, 26>(A, st);
-  if (nig == 4 && nj == 7) return launch_real_t<4, 7, 30>(A, st);
-  if (nig == 4 && nj == 8) return launch_real_t<4, 8, 34>(A, st);
-  if (nig == 5 && nj == 9) return launch_real_t<5, 9, 38>(A, st);
-  if (nig == 5 && nj == 10) return launch_real_t<5, 10, 42>(A, st);
+  if (nig == 2 && nj == 4) return launch_real_t<2, 4, 17>(A, st);
+  if (nig == 3 && nj == 5) return launch_real_t<3, 5, 21>(A, st);
+  if (nig == 3 && nj == 6) return launch_real_t<3, 6, 25>(A, st);
+  if (nig == 4 && nj == 7) return launch_real_t<4, 7, 29>(A, st);
+  if (nig == 4 && nj == 8) return launch_real_t<4, 8, 33>(A, st);
+  if (nig == 5 && nj == 9) return launch_real_t<5, 9, 37>(A, st);
+  if (nig == 5 && nj == 10) return launch_real_t<5, 10, 41>(A, st);
   return hipErrorInvalidValue;
 }
 #endif
@@ -2253,13 +2254,13 @@ hipError_t c3p_launch_midd_real(const MidArgs& A, hipStream_t st) {
 #if C3P_MIDD_HAS(3)
 namespace {
 hipError_t launch_grad_real(const MidGradArgs& A, int nig, int nj, hipStream_t st, bool* launched) {
-  if (nig == 2 && nj == 4) return launch_grad_real_t<2, 4, 18>(A, st, launched);
-  if (nig == 3 && nj == 5) return launch_grad_real_t<3, 5, 22>(A, st, launched);
-  if (nig == 3 && nj == 6) return launch_grad_real_t<3, 6, 26>(A, st, launched);
-  if (nig == 4 && nj == 7) return launch_grad_real_t<4, 7, 30>(A, st, launched);
-  if (nig == 4 && nj == 8) return launch_grad_real_t<4, 8, 34>(A, st, launched);
-  if (nig == 5 && nj == 9) return launch_grad_real_t<5, 9, 38>(A, st, launched);
-  if (nig == 5 && nj == 10) return launch_grad_real_t<5, 10, 42>(A, st, launched);
+  if (nig == 2 && nj == 4) return launch_grad_real_t<2, 4, 17>(A, st, launched);
+  if (nig == 3 && nj == 5) return launch_grad_real_t<3, 5, 21>(A, st, launched);
+  if (nig == 3 && nj == 6) return launch_grad_real_t<3, 6, 25>(A, st, launched);
+  if (nig == 4 && nj == 7) return launch_grad_real_t<4, 7, 29>(A, st, launched);
+  if (nig == 4 && nj == 8) return launch_grad_real_t<4, 8, 33>(A, st, launched);
+  if (nig == 5 && nj == 9) return launch_grad_real_t<5, 9, 37>(A, st, launched);
+  if (nig == 5 && nj == 10) return launch_grad_real_t<5, 10, 41>(A, st, launched);
   return hipErrorInvalidValue;
 }
 }  // namespace
@@ -2277,13 +2278,13 @@ hipError_t c3p_launch_midd_grad(const MidGradArgs& A_, hipStream_t st) {
     if (e != hipSuccess) return e;
     if (launched) A.skip_real = 1;
   }
-  if (nig == 2 && nj == 4) return launch_grad_t<2, 4, 18>(A, st);
-  if (nig == 3 && nj == 5) return launch_grad_t<3, 5, 22>(A, st);
-  if (nig == 3 && nj == 6) return launch_grad_t<3, 6, 26>(A, st);
-  if (nig == 4 && nj == 7) return launch_grad_t<4, 7, 30>(A, st);
-  if (nig == 4 && nj == 8) return launch_grad_t<4, 8, 34>(A, st);
-  if (nig == 5 && nj == 9) return launch_grad_t<5, 9, 38>(A, st);
-  if (nig == 5 && nj == 10) return launch_grad_t<5, 10, 42>(A, st);
+  if (nig == 2 && nj == 4) return launch_grad_t<2, 4, 17>(A, st);
+  if (nig == 3 && nj == 5) return launch_grad_t<3, 5, 21>(A, st);
+  if (nig == 3 && nj == 6) return launch_grad_t<3, 6, 25>(A, st);
+  if (nig == 4 && nj == 7) return launch_grad_t<4, 7, 29>(A, st);
+  if (nig == 4 && nj == 8) return launch_grad_t<4, 8, 33>(A, st);
+  if (nig == 5 && nj == 9) return launch_grad_t<5, 9, 37>(A, st);
+  if (nig == 5 && nj == 10) return launch_grad_t<5, 10, 41>(A, st);
   return hipErrorInvalidValue;
 }
 #endif
