@@ -88,9 +88,24 @@ struct Sched {
   static constexpr bool PAD = NIG == 2 && NJ == 7;
   static constexpr int NB16 = PAD ? 2 : NJ / 4;
   static constexpr int JR = PAD ? 0 : NJ % 4;
-  static constexpr int NBIG = NIG * NB16;
-  static constexpr int NSMALL = NIG * JR;
+  // The 48-row real class with 9 column blocks (D = 33..36, cfg5; real instance only): six 16 x 16 units and three 16 x 4
+  // ones deal out as 128 / 128 / 96 / 80 matrix-pipe cycles per K-step; with the last NSPLIT = 2 big units dealt as four
+  // small ones each it is 112 / 112 / 112 / 96.  (Splitting wherever it lowers the maximum was measured: +2 - 3 % here,
+  // 20 - 27 % SLOWER at D <= 24, where small units mean four broadcast B reads and four instructions instead of one.)
+  static constexpr int NSPLIT = (NIG == 3 && NJ == 9) ? 2 : 0;
+  static constexpr int NBIG = NIG * NB16 - NSPLIT;
+  static constexpr int NSMALL = NIG * JR + 4 * NSPLIT;
   static constexpr int nbig(int w) { return w < NBIG ? (NBIG - w + NW - 1) / NW : 0; }
+  // small unit us -> (column block J, row group Ig): first the leftover column blocks, then the split big units
+  static constexpr int small_j(int us) {
+    if (us < NIG * JR) return 4 * NB16 + us / NIG;
+    const int k = us - NIG * JR;
+    return 4 * ((NBIG + k / 4) / NIG) + k % 4;
+  }
+  static constexpr int small_ig(int us) {
+    if (us < NIG * JR) return us % NIG;
+    return (NBIG + (us - NIG * JR) / 4) % NIG;
+  }
   static constexpr int small_owner(int us) {
     int load[NW] = {4 * nbig(0), 4 * nbig(1), 4 * nbig(2), 4 * nbig(3)};
     int owner = 0;
@@ -131,8 +146,8 @@ struct WaveTiles {
   static constexpr int bIg(int i) { return (WV + NW * i) % NIG; }
   static constexpr int bJg(int i) { return (WV + NW * i) / NIG; }
   // small unit i: us -> (J, Ig)
-  static constexpr int sIg(int i) { return S::small_us(WV, i) % NIG; }
-  static constexpr int sJ(int i) { return 4 * S::NB16 + S::small_us(WV, i) / NIG; }
+  static constexpr int sIg(int i) { return S::small_ig(S::small_us(WV, i)); }
+  static constexpr int sJ(int i) { return S::small_j(S::small_us(WV, i)); }
   // element e: big tile i = e/4, accumulator register q = e%4 (rows 4q + r of the 16-row group),
   //            or small tile e - 4 NBW
   static constexpr bool is_big(int e) { return e < 4 * NBW; }
@@ -196,7 +211,7 @@ __device__ __forceinline__ void mm_tiles(const double* imgA, const double* imgB,
   using T = WaveTiles<NIG, NJ, W, WV>;
   using S = Sched<NIG, NJ>;
   constexpr int NB16 = S::NB16 > 0 ? S::NB16 : 1;
-  constexpr int JR = S::JR > 0 ? S::JR : 1;
+  constexpr int JR = NJ;  // small B blocks are indexed by their column block J (only the ones the wave uses are loaded)
   // software pipelined over K: operands of step K+1 are in flight while step K's MFMAs issue
   double a0[NIG], a1[NIG], g0[NB16], g1[NB16], s0[JR], s1[JR];
   const double* pa = imgA + cm.aoff;
@@ -208,13 +223,13 @@ __device__ __forceinline__ void mm_tiles(const double* imgA, const double* imgB,
 #pragma unroll
     for (int Jg = 0; Jg < S::NB16; ++Jg) g[Jg] = T::uses_jg(Jg) ? pg[K * 4 * W + 16 * Jg] : 0.0;
 #pragma unroll
-    for (int js = 0; js < S::JR; ++js) sb[js] = T::uses_j(4 * S::NB16 + js) ? ps4[K * 4 * W + 4 * (4 * S::NB16 + js)] : 0.0;
+    for (int J = 0; J < NJ; ++J) sb[J] = T::uses_j(J) ? ps4[K * 4 * W + 4 * J] : 0.0;
   };
   auto fmas = [&](const double (&a)[NIG], const double (&g)[NB16], const double (&sb)[JR]) {
 #pragma unroll
     for (int i = 0; i < T::NBW; ++i) acc.big[i] = md_mfma16(a[T::bIg(i)], g[T::bJg(i)], acc.big[i]);
 #pragma unroll
-    for (int i = 0; i < T::NSW; ++i) acc.sm[i] = md_mfma4(a[T::sIg(i)], sb[T::sJ(i) - 4 * S::NB16], acc.sm[i]);
+    for (int i = 0; i < T::NSW; ++i) acc.sm[i] = md_mfma4(a[T::sIg(i)], sb[T::sJ(i)], acc.sm[i]);
   };
   const int nbk = cm.nbk;
   load(a0, g0, s0, 0);
@@ -253,7 +268,7 @@ __device__ __forceinline__ void mm_tiles_pf(const double* imgA, const double* im
   using T = WaveTiles<NIG, NJ, W, WV>;
   using S = Sched<NIG, NJ>;
   constexpr int NB16 = S::NB16 > 0 ? S::NB16 : 1;
-  constexpr int JR = S::JR > 0 ? S::JR : 1;
+  constexpr int JR = NJ;  // small B blocks by column block J
   constexpr int NK = 2 * NJ, NS = PF + 1;
   double a[NS][NIG], g[NS][NB16], sb[NS][JR];
   const double* pa = imgA + cm.aoff;
@@ -266,8 +281,8 @@ __device__ __forceinline__ void mm_tiles_pf(const double* imgA, const double* im
     _Pragma("unroll") for (int Ig = 0; Ig < NIG; ++Ig)                                                              \
         a[st_][Ig] = T::uses_ig(Ig) ? md_flip(pa[Ig * 16 * W + 2 * (K)], cm.negmask) : 0.0;                         \
     _Pragma("unroll") for (int Jg = 0; Jg < S::NB16; ++Jg) g[st_][Jg] = T::uses_jg(Jg) ? pg[(K) * 4 * W + 16 * Jg] : 0.0; \
-    _Pragma("unroll") for (int js = 0; js < S::JR; ++js)                                                            \
-        sb[st_][js] = T::uses_j(4 * S::NB16 + js) ? ps4[(K) * 4 * W + 4 * (4 * S::NB16 + js)] : 0.0;                \
+    _Pragma("unroll") for (int J = 0; J < NJ; ++J)                                                                  \
+        sb[st_][J] = T::uses_j(J) ? ps4[(K) * 4 * W + 4 * J] : 0.0;                                                 \
   }
 #define C3P_MMT_FMAS(K)                                                                                             \
   {                                                                                                                 \
@@ -275,7 +290,7 @@ __device__ __forceinline__ void mm_tiles_pf(const double* imgA, const double* im
     _Pragma("unroll") for (int i = 0; i < T::NBW; ++i)                                                              \
         acc.big[i] = md_mfma16(a[st_][T::bIg(i)], g[st_][T::bJg(i)], acc.big[i]);                                   \
     _Pragma("unroll") for (int i = 0; i < T::NSW; ++i)                                                              \
-        acc.sm[i] = md_mfma4(a[st_][T::sIg(i)], sb[st_][T::sJ(i) - 4 * S::NB16], acc.sm[i]);                        \
+        acc.sm[i] = md_mfma4(a[st_][T::sIg(i)], sb[st_][T::sJ(i)], acc.sm[i]);                                      \
   }
   md_unroll<0, PF>([&](auto Kc) { constexpr int K = decltype(Kc)::value; C3P_MMT_LOAD(K) });
   md_unroll<0, NK>([&](auto Kc) {
@@ -325,7 +340,7 @@ __device__ __forceinline__ void mm_real(const MidCommon& cm,
   using T = WaveTiles<NIGR, NJ, WI, WV>;
   using S = Sched<NIGR, NJ>;
   constexpr int NB16 = S::NB16 > 0 ? S::NB16 : 1;
-  constexpr int JR = S::JR > 0 ? S::JR : 1;
+  constexpr int JR = NJ;  // small B blocks by column block J
   constexpr bool TWOA = MODE == 2, TWOB = MODE == 1;
   // D is in (4 NJ - 4, 4 NJ]: a real product has exactly NJ K-steps.  The loop is fully unrolled with the operands
   // fetched PF steps ahead in a ring of PF + 1 register stages: the LDS round trip (~150 cycles) is more than two
@@ -358,11 +373,10 @@ __device__ __forceinline__ void mm_real(const MidCommon& cm,
       g[st_][Jg] = T::uses_jg(Jg) ? q_[IB1 * IMGR + (K) * 4 * WI + 16 * Jg] : 0.0;                               \
       h[st_][Jg] = (TWOB && T::uses_jg(Jg)) ? q_[IB2 * IMGR + (K) * 4 * WI + 16 * Jg] : 0.0;                     \
     }                                                                                                            \
-    _Pragma("unroll") for (int js = 0; js < S::JR; ++js) {                                                       \
-      constexpr int J_ = 4 * S::NB16;                                                                            \
-      const double* q_ = (J_ + js) < 4 ? qs0 : qs1;                                                              \
-      sb[st_][js] = T::uses_j(J_ + js) ? q_[IB1 * IMGR + (K) * 4 * WI + 4 * (J_ + js)] : 0.0;                    \
-      ub[st_][js] = (TWOB && T::uses_j(J_ + js)) ? q_[IB2 * IMGR + (K) * 4 * WI + 4 * (J_ + js)] : 0.0;          \
+    _Pragma("unroll") for (int J = 0; J < NJ; ++J) {                                                             \
+      const double* q_ = J < 4 ? qs0 : qs1;                                                                      \
+      sb[st_][J] = T::uses_j(J) ? q_[IB1 * IMGR + (K) * 4 * WI + 4 * J] : 0.0;                                   \
+      ub[st_][J] = (TWOB && T::uses_j(J)) ? q_[IB2 * IMGR + (K) * 4 * WI + 4 * J] : 0.0;                         \
     }                                                                                                            \
   }
 #define C3P_MMR_FMAS(K)                                                                                          \
@@ -374,9 +388,9 @@ __device__ __forceinline__ void mm_real(const MidCommon& cm,
       if constexpr (TWOA) acc2.big[i] = md_mfma16(x[st_][T::bIg(i)], g[st_][T::bJg(i)], acc2.big[i]);            \
     }                                                                                                            \
     _Pragma("unroll") for (int i = 0; i < T::NSW; ++i) {                                                         \
-      acc1.sm[i] = md_mfma4(a[st_][T::sIg(i)], sb[st_][T::sJ(i) - 4 * S::NB16], acc1.sm[i]);                     \
-      if constexpr (TWOB) acc2.sm[i] = md_mfma4(a[st_][T::sIg(i)], ub[st_][T::sJ(i) - 4 * S::NB16], acc2.sm[i]); \
-      if constexpr (TWOA) acc2.sm[i] = md_mfma4(x[st_][T::sIg(i)], sb[st_][T::sJ(i) - 4 * S::NB16], acc2.sm[i]); \
+      acc1.sm[i] = md_mfma4(a[st_][T::sIg(i)], sb[st_][T::sJ(i)], acc1.sm[i]);                                   \
+      if constexpr (TWOB) acc2.sm[i] = md_mfma4(a[st_][T::sIg(i)], ub[st_][T::sJ(i)], acc2.sm[i]);               \
+      if constexpr (TWOA) acc2.sm[i] = md_mfma4(x[st_][T::sIg(i)], sb[st_][T::sJ(i)], acc2.sm[i]);               \
     }                                                                                                            \
   }
   md_unroll<0, PF>([&](auto Kc) { constexpr int K = decltype(Kc)::value; C3P_MMR_LOAD(K) });
