@@ -33,6 +33,9 @@ struct SmallArgs {
   // segments in registers, publishes one partial product, and the last wave to arrive for a
   // sample (per-sample counter, agent-scope release/acquire) folds the S/4 partials into U.
   int fuse;
+  // MW mode with two waves per SIMD: slices of the segments of the first half of a sample's chains (the OLDER waves of
+  // their SIMDs, which the arbiter serves first); 0 = equal segments.  Set by the launcher.
+  int seg_long;
   int* counters;   // [B], zeroed by the prep kernel of the same call
   cplx* final_out;  // [B,Dm,Dm]
 };

@@ -588,9 +588,25 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
   const long cc = valid ? chain : nchains - 1;
   const int sample = (int)(cc / A.S);
   const int seg = (int)(cc - (long)sample * A.S);
-  const int n0 = (int)(((long)seg * A.N) / A.S);
-  const int n1 = (int)(((long)(seg + 1) * A.N) / A.S);
+  int n0 = (int)(((long)seg * A.N) / A.S);
+  int n1 = (int)(((long)(seg + 1) * A.N) / A.S);
+  if (MW && A.seg_long > 0) {
+    // uneven segments: the first S / 2 chains (waves 0 .. 3, the older wave of each SIMD) take seg_long slices each, the
+    // others share the rest
+    const int h = A.S >> 1;
+    const long rest = (long)A.N - (long)h * A.seg_long;
+    n0 = seg < h ? seg * A.seg_long : h * A.seg_long + (int)(((long)(seg - h) * rest) / h);
+    n1 = seg + 1 <= h ? (seg + 1) * A.seg_long : h * A.seg_long + (int)(((long)(seg + 1 - h) * rest) / h);
+  }
   const int len = n1 - n0;
+  // slices the wave iterates over: the longest of its four chains (MW with uneven segments), else the common maximum
+  int tmax = A.Lmax;
+  if (MW && A.seg_long > 0) {
+    int m = len;
+    m = max(m, __shfl_xor(m, 4));
+    m = max(m, __shfl_xor(m, 8));
+    tmax = __builtin_amdgcn_readfirstlane(m);
+  }
 
   // per-lane LDS offsets (doubles)
   const int woff = lp.b * IMG + lp.r * W + lp.c;
@@ -606,7 +622,7 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
   if constexpr (GIVEN) {
     // ---- ordered product of supplied matrices ----
     const double* base = reinterpret_cast<const double*>(A.mats) + ((long)sample * A.N + n0) * D * D * 2;
-    for (int t = 0; t < A.Lmax; ++t) {
+    for (int t = 0; t < tmax; ++t) {
       const bool act = valid && t < len;
       double P[NBI][NJ];
       const double* src = base + (long)(act ? t : 0) * D * D * 2;
@@ -739,7 +755,7 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
       const bool deg16 = __builtin_amdgcn_readfirstlane((int)(nrm * rscale <= 8.16e-1)) != 0;
       auto real_loop = [&](auto deg16_tag) {
       constexpr bool DEG16 = decltype(deg16_tag)::value;
-      for (int t = 0; t < A.Lmax; ++t) {
+      for (int t = 0; t < tmax; ++t) {
         // (Two waves share a SIMD and the arbiter serves the OLDER one first: wave w finishes its segment at ~64 % of the
         // kernel time and wave w + 4 then runs alone -- wall_clock64 probes, -DC3P_SD_TIMING.  Alternating s_setprio per
         // slice makes them finish together and changes nothing in the total: measured, not kept.)
@@ -936,7 +952,7 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
     // the slice loop is instantiated per plan (T18 / Paterson-Stockmeyer) with the branch outside, as on the real path
     auto complex_loop = [&](auto t18_tag) {
     constexpr bool T18 = decltype(t18_tag)::value;
-    for (int t = 0; t < A.Lmax; ++t) {
+    for (int t = 0; t < tmax; ++t) {
       const bool act = valid && t < len;
       // ---- X = scale (G0 + sum_k c_k G_k) in D-layout; trace shift mu ----
       // chains past their segment end (lengths differ by at most one slice) take X = 0, E = I
@@ -1354,12 +1370,35 @@ hipError_t launch_chain_t(const SmallArgs& A, hipStream_t st) {
     const bool mw = A.fuse && (A.S & 3) == 0 && (nW == 2 || nW == 4 || nW == 8) && (long)A.B * nW <= 2048 &&
                     lds_mw * (8 / nW) <= (size_t)156 * 1024 && !getenv("C3P_NO_MW");
     if (mw) {
+      // Two waves share a SIMD (nW = 8) and the arbiter serves the older one first: with equal segments wave w leaves its
+      // loop at 64 % of the kernel time and wave w + 4 runs the rest alone, at the (slower) one-wave rate.  Give the older
+      // waves the longer segments so that both finish together: measured optimum near 2 : 1 (C3P_MW_SKEW = long share of
+      // a pair's slices in per mille, default 640; 500 = equal segments).
+      SmallArgs A2 = A;
+      if (nW == 8 && A.N >= 4 * A.S) {
+        int skew = 640;
+        if (const char* e = getenv("C3P_MW_SKEW")) skew = atoi(e);
+        if (skew > 500 && skew < 900) {
+          const int h = A.S / 2;
+          int La = (int)(((long)A.N * skew) / (500L * A.S));  // = skew / 1000 of the 2 N / S slices of a pair of chains
+          if (La < 1) La = 1;
+          if ((long)h * La > A.N - h) La = (A.N - h) / h;  // at least one slice for every short chain
+          const long rest = (long)A.N - (long)h * La;
+          const int Lb = (int)((rest + h - 1) / h);
+          A2.seg_long = La;
+          A2.Lmax = La > Lb ? La : Lb;
+        }
+      }
+      const size_t wstride2 = (size_t)(4 * C::IMG + 4 * ((A2.K * A2.Lmax) | 1));
+      const size_t lds_mw2 = (size_t)((1 + A2.K) * (C::MAT + 4) + nW * wstride2 + (size_t)nW * D * D * 2) * sizeof(double);
+      if (lds_mw2 > (size_t)156 * 1024) A2 = A;  // (the longer segments need more LDS for their control amplitudes)
+      const size_t lds_use = A2.seg_long > 0 ? lds_mw2 : lds_mw;
       auto kern = smalld_chain_kernel<D, false, false, false, true>;
-      if (lds_mw > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mw);
+      if (lds_use > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_use);
         if (e != hipSuccess) return e;
       }
-      hipLaunchKernelGGL(kern, dim3((unsigned)A.B), dim3(64 * nW), lds_mw, st, A);
+      hipLaunchKernelGGL(kern, dim3((unsigned)A.B), dim3(64 * nW), lds_use, st, A2);
     } else {
       hipLaunchKernelGGL((smalld_chain_kernel<D, false, false>), dim3(grid), dim3(64), lds, st, A);
     }
