@@ -294,6 +294,10 @@ int pick_segments(int B, int N, int K, int Dm, bool need_mult4, long slots = 819
   // B S chains run in ceil(B S / slots) rounds of N / S slices (+ the table build and plan of the prologue):
   // take the S that minimises rounds x segment length, so that the last round is not a mostly idle tail
   // (B = 300 with the old "fill the machine twice" rule ran a second round at 2 % occupancy).
+  if (const char* e = getenv("C3P_SMALLD_SEGMENTS")) {  // tuning override
+    const long S = atol(e);
+    if (S >= 1 && S <= N && (!need_mult4 || S % 4 == 0)) return (int)S;
+  }
   // (the backward sweep runs one wave per SIMD: 4096 slots)
   // the segment's control amplitudes live in LDS: 4 chains x K x Lmax doubles
   const long lds_budget = 20 * 1024 - (long)(c3p_smalld_table_doubles(Dm, K) + 4 * c3p_smalld_img_doubles(Dm)) * 8;
