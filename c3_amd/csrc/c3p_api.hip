@@ -407,8 +407,9 @@ int run_vjp_midd(DeviceWs* w, GradArgs& G, hipStream_t st) {
   int nig, nj, wd;
   if (!c3p_midd_geometry(D, &nig, &nj, &wd) || K > 16) return 1;
   const size_t img_bytes = (size_t)16 * nig * wd * sizeof(double);
-  // backward sweep: one workgroup per CU (two for the real-Hamiltonian kernel at D <= 32); aim at two rounds
-  const long target = D <= 32 ? 1024 : 512;
+  // backward sweep: one workgroup per CU (two for the real-Hamiltonian kernel at D <= 32); two to four rounds
+  long target = D <= 32 ? 2048 : 512;  // (D <= 32: four rounds of the two-per-CU sweep; 1024 -> 2048 measured -2 % at cfg3)
+  if (const char* e = getenv("C3P_GRAD_TARGET")) target = atol(e) > 0 ? atol(e) : target;  // tuning override
   long S = (target + B - 1) / B;
   const long smax = N / 8 > 1 ? N / 8 : 1;
   if (S > smax) S = smax;
@@ -483,7 +484,7 @@ int run_vjp_midd(DeviceWs* w, GradArgs& G, hipStream_t st) {
 // Time segments per sample for the workgroup-per-chain kernels.  B S chains run in ceil(B S / slots) rounds of
 // `slots` resident workgroups, each N / S slices long (+ a few slices' worth of prologue): take the S that
 // minimises rounds x segment length, so that the last round is not a mostly idle tail.
-static long pick_segments_rounds(long B, long N, long slots, long smax) {
+static long pick_segments_rounds(long B, long N, long slots, long smax, long min_len = 100) {
   if (const char* e = getenv("C3P_SEGMENTS")) {  // tuning override
     const long S = atol(e);
     if (S >= 1 && S <= (N > 1 ? N : 1)) return S;
@@ -499,6 +500,19 @@ static long pick_segments_rounds(long B, long N, long slots, long smax) {
       best = S;
     }
   }
+  // The workgroups that share a SIMD do not advance at the same rate (the arbiter serves the older wave first), so a
+  // round does not end for all of them at once: with MANY more workgroups than slots the SIMDs stay shared until the
+  // very end, with one or two rounds the last workgroup of every CU runs a good part of its segment alone.  Measured
+  // (cfg5, B = 1024): S = 1 (2 rounds) 6.13e3, S = 4 6.28e3, S = 12 6.33e3 propagators/s; cfg3 (B = 512): 3 -> 12 segments
+  // +1 %.  At least 12 rounds, segments of at least min_len slices (100; 400 in the 16-row class, whose slices are short
+  // against the per-segment prologue: D = 13 measured 20 % slower with 100).
+  if (!getenv("C3P_NO_MANY_ROUNDS")) {
+    long want = (12 * slots + B - 1) / B;
+    const long cap = N / min_len > 1 ? N / min_len : 1;
+    if (want > cap) want = cap;
+    if (want > smax) want = smax;
+    if (want > best) best = want;
+  }
   return best;
 }
 
@@ -512,7 +526,7 @@ int run_xg_midd(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, dou
   if (wg_per_cu > 3) wg_per_cu = 3;
   if (wg_per_cu < 1) wg_per_cu = 1;
   const long smax = N / 8 > 1 ? N / 8 : 1;
-  const long S = pick_segments_rounds(B, N, 256L * wg_per_cu, smax);
+  const long S = pick_segments_rounds(B, N, 256L * wg_per_cu, smax, D <= 16 ? 400 : 100);
   void* mv;
   if (ws_get(w, SL_TABLES, (size_t)B * N * 4 * sizeof(double), &mv)) return -1;
   HIP_TRY(c3p_launch_hmeta(hs, hs_bstride, (long)B * N, N, D, coef_r, coef_i, (double*)mv, st));
@@ -701,7 +715,7 @@ int run_pwc_midd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   if (wg_per_cu > 3) wg_per_cu = 3;
   if (wg_per_cu < 1) wg_per_cu = 1;
   const long smax = N / 8 > 1 ? N / 8 : 1;
-  const long S = pick_segments_rounds(B, N, 256L * wg_per_cu, smax);
+  const long S = pick_segments_rounds(B, N, 256L * wg_per_cu, smax, Dm <= 16 ? 400 : 100);
   if (lds0 > 158 * 1024) return 1;
   const int nsamp = per_sample ? B : 1;
   void* v;
