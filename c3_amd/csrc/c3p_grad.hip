@@ -43,16 +43,50 @@ struct GMem {
 };
 
 // C (= | +=) op(A) op(B); op = identity or conjugate transpose.  C must not alias A or B.
-template <bool GLOBAL, bool ACC, bool AH, bool BH>
-__device__ void gmm(const GMem<GLOBAL>& M, int c, int a, int b, int n, int ld, int tid, int nt) {
+// NF != 0: the dimension is the compile-time NF (the k loop fully unrolled, its loads issued together, no integer
+// division by a run-time tile count) -- the per-sample scan is a chain of dependent small products whose every cycle of
+// latency is exposed.
+template <bool GLOBAL, bool ACC, bool AH, bool BH, int NF = 0>
+__device__ void gmm(const GMem<GLOBAL>& M, int c, int a, int b, int n_, int ld, int tid, int nt) {
+  const int n = NF ? NF : n_;
   const int tn = (n + 1) >> 1;
+  if constexpr (NF != 0 && !ACC) {
+    // 1 x 2 tiles: NF (NF + 1) / 2 of them (45 at D = 9) keep most of the wave's lanes busy with half the multiply-adds
+    // per lane of the 2 x 2 tiling (25 lanes busy)
+    for (int t = tid; t < NF * tn; t += nt) {
+      const int i0 = t / tn, tj = t - i0 * tn;
+      const int j0 = 2 * tj, j1 = min(j0 + 1, NF - 1);
+      cplx c00 = cmake(0, 0), c01 = c00;
+#pragma unroll
+      for (int k = 0; k < NF; ++k) {
+        cplx a0, b0, b1;
+        if constexpr (AH)
+          a0 = cconj(M.ld(a + k * ld + i0));
+        else
+          a0 = M.ld(a + i0 * ld + k);
+        if constexpr (BH) {
+          b0 = cconj(M.ld(b + j0 * ld + k));
+          b1 = cconj(M.ld(b + j1 * ld + k));
+        } else {
+          b0 = M.ld(b + k * ld + j0);
+          b1 = M.ld(b + k * ld + j1);
+        }
+        cfma(c00, a0, b0);
+        cfma(c01, a0, b1);
+      }
+      M.st(c + i0 * ld + j0, c00);
+      if (j0 + 1 < NF) M.st(c + i0 * ld + j1, c01);
+    }
+    __syncthreads();
+    return;
+  }
   const int ntiles = tn * tn;
   for (int t = tid; t < ntiles; t += nt) {
     const int ti = t / tn, tj = t - ti * tn;
     const int i0 = 2 * ti, j0 = 2 * tj;
     const int i1 = min(i0 + 1, n - 1), j1 = min(j0 + 1, n - 1);
     cplx c00 = cmake(0, 0), c01 = c00, c10 = c00, c11 = c00;
-#pragma unroll 2
+#pragma unroll(NF ? NF : 2)
     for (int k = 0; k < n; ++k) {
       cplx a0, a1, b0, b1;
       if constexpr (AH) {
@@ -321,7 +355,7 @@ __global__ void __launch_bounds__(256) grad_seg_kernel(GradArgs A) {
 }
 
 // ---- kernel 2: per sample, adjoint state M at the end of every segment ----
-template <bool GLOBAL>
+template <bool GLOBAL, int NF = 0>
 __global__ void __launch_bounds__(256) grad_scan_kernel(GradArgs A) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int b = blockIdx.x;
@@ -330,16 +364,29 @@ __global__ void __launch_bounds__(256) grad_scan_kernel(GradArgs A) {
   M.g = GLOBAL ? A.scratch + (long)b * A.S * A.scratch_stride : nullptr;  // the scratch of this sample's first chain
   int bU = 0, bV = msz, bS = 2 * msz, bM = 3 * msz;
   const cplx* segb = A.seg + (long)b * A.S * D * D;
+  // The scan is a chain of dependent small products: every global round trip in it is exposed.  With the matrices in LDS
+  // the segment products 1 .. npre are fetched ONCE, in one pass of independent loads, into the slots the backward
+  // kernel uses for its T18 intermediates (the scan needs four of the C3P_GRAD_NMAT); the rest are read when needed.
+  const int npre = GLOBAL ? 0 : min(A.S - 1, C3P_GRAD_NMAT - 4);
+  auto slot = [&](int j) -> int { return (3 + j) * msz; };  // 1 <= j <= npre
+  for (int e = tid; e < npre * D * D; e += nt) {
+    const int j = e / (D * D), r = e - j * D * D;
+    M.st(slot(j + 1) + (r / D) * ld + (r % D), segb[(long)(j + 1) * D * D + r]);
+  }
+  // Ubar' = FR^H Ubar (row i times e^{-i phi_i}) goes to registers now as well
+  const cplx* ub = A.Ubar + (long)b * D * D;
   copy_in(M, bU, segb, D, ld, tid, nt);
   for (int j = 1; j < A.S; ++j) {
-    copy_in(M, bS, segb + (long)j * D * D, D, ld, tid, nt);
-    mm(M, bV, bS, bU, D, ld, tid, nt);
+    int src = bS;
+    if (j <= npre)
+      src = slot(j);
+    else
+      copy_in(M, bS, segb + (long)j * D * D, D, ld, tid, nt);
+    gmm<GLOBAL, false, false, false, NF>(M, bV, src, bU, D, ld, tid, nt);
     const int t = bU;
     bU = bV;
     bV = t;
   }
-  // Ubar' = FR^H Ubar (row i times e^{-i phi_i}); M_N = Ubar' P_N^H
-  const cplx* ub = A.Ubar + (long)b * D * D;
   for (int e = tid; e < D * D; e += nt) {
     const int i = e / D, j = e - i * D;
     cplx v = ub[e];
@@ -351,14 +398,18 @@ __global__ void __launch_bounds__(256) grad_scan_kernel(GradArgs A) {
     M.st(bS + i * ld + j, v);
   }
   __syncthreads();
-  gmm<GLOBAL, false, false, true>(M, bM, bS, bU, D, ld, tid, nt);
+  gmm<GLOBAL, false, false, true, NF>(M, bM, bS, bU, D, ld, tid, nt);
   cplx* mb = A.Mb + (long)b * A.S * D * D;
   for (int j = A.S - 1; j >= 0; --j) {
     copy_out(M, mb + (long)j * D * D, bM, D, ld, tid, nt);
     if (j == 0) break;
-    copy_in(M, bS, segb + (long)j * D * D, D, ld, tid, nt);  // also orders the copy_out reads before M is rewritten
-    mm(M, bV, bM, bS, D, ld, tid, nt);                        // V = M S_j
-    gmm<GLOBAL, false, true, false>(M, bM, bS, bV, D, ld, tid, nt);  // M = S_j^H V
+    int src = bS;
+    if (j <= npre)
+      src = slot(j), __syncthreads();  // (orders the copy_out reads before M is rewritten)
+    else
+      copy_in(M, bS, segb + (long)j * D * D, D, ld, tid, nt);  // (its barrier does the same)
+    gmm<GLOBAL, false, false, false, NF>(M, bV, bM, src, D, ld, tid, nt);                           // V = M S_j
+    gmm<GLOBAL, false, true, false, NF>(M, bM, src, bV, D, ld, tid, nt);  // M = S_j^H V
   }
 }
 
@@ -443,8 +494,21 @@ hipError_t c3p_launch_grad_seg(const GradArgs& A, bool global_scratch, hipStream
                         : launch_one(grad_seg_kernel<false>, (unsigned)(A.B * A.S), A, false, st);
 }
 hipError_t c3p_launch_grad_scan(const GradArgs& A, bool global_scratch, hipStream_t st) {
-  return global_scratch ? launch_one(grad_scan_kernel<true>, (unsigned)A.B, A, true, st)
-                        : launch_one(grad_scan_kernel<false>, (unsigned)A.B, A, false, st);
+  if (global_scratch) return launch_one(grad_scan_kernel<true>, (unsigned)A.B, A, true, st);
+  switch (A.D) {  // small matrices: the scan with compile-time dimension
+    case 2: return launch_one(grad_scan_kernel<false, 2>, (unsigned)A.B, A, false, st);
+    case 3: return launch_one(grad_scan_kernel<false, 3>, (unsigned)A.B, A, false, st);
+    case 4: return launch_one(grad_scan_kernel<false, 4>, (unsigned)A.B, A, false, st);
+    case 5: return launch_one(grad_scan_kernel<false, 5>, (unsigned)A.B, A, false, st);
+    case 6: return launch_one(grad_scan_kernel<false, 6>, (unsigned)A.B, A, false, st);
+    case 7: return launch_one(grad_scan_kernel<false, 7>, (unsigned)A.B, A, false, st);
+    case 8: return launch_one(grad_scan_kernel<false, 8>, (unsigned)A.B, A, false, st);
+    case 9: return launch_one(grad_scan_kernel<false, 9>, (unsigned)A.B, A, false, st);
+    case 10: return launch_one(grad_scan_kernel<false, 10>, (unsigned)A.B, A, false, st);
+    case 11: return launch_one(grad_scan_kernel<false, 11>, (unsigned)A.B, A, false, st);
+    case 12: return launch_one(grad_scan_kernel<false, 12>, (unsigned)A.B, A, false, st);
+    default: return launch_one(grad_scan_kernel<false>, (unsigned)A.B, A, false, st);
+  }
 }
 hipError_t c3p_launch_grad_bwd(const GradArgs& A, bool global_scratch, hipStream_t st) {
   return global_scratch ? launch_one(grad_bwd_kernel<true>, (unsigned)(A.B * A.S), A, true, st)
