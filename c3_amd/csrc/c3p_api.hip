@@ -17,6 +17,7 @@
 #include "c3p_midd.h"
 #include "c3p_bigd.h"
 #include "c3p_regd.h"
+#include <atomic>
 #include "c3p_tiled.h"
 #include "c3p_signal.h"
 #include "c3p_grad.h"
@@ -25,7 +26,7 @@ namespace {
 
 thread_local std::string g_err;
 thread_local int g_last_kernel = C3P_KERNEL_NONE;
-int g_profiling = 0;
+std::atomic<int> g_profiling{0};  // process-wide switch; the event pairs it arms are per device
 
 int fail(const char* fmt, ...) {
   char buf[512];
@@ -93,6 +94,8 @@ struct WsLock {
       if (!w->done || hipEventRecord(w->done, w->last_stream) != hipSuccess || hipStreamWaitEvent(st, w->done, 0) != hipSuccess) {
         (void)hipGetLastError();
         if (hipDeviceSynchronize() != hipSuccess) ok = false;
+        w->has_last = false;  // everything enqueued so far is done: forget the (possibly destroyed) stream
+        w->last_stream = nullptr;
       }
     }
     ordered = order;
@@ -156,8 +159,15 @@ ChainPlan plan_generic(int B, int N, int Dm) {
 
 // Runs one chained propagation (all modes) with the generic kernel, including the
 // ordered combine of segment products.  All pointers are device pointers.
-int run_chain_generic(DeviceWs* w, ChainArgs base, cplx* U_out, hipStream_t st) {
+// `profile` = false keeps the timing event pair (and c3p_last_kernel) on the caller's main kernel.
+int run_chain_generic(DeviceWs* w, ChainArgs base, cplx* U_out, hipStream_t st, bool profile = true) {
   const int Dm = base.Dm;
+  profile = profile && g_profiling;
+  // GIVEN mode callers may hand over matrices that live in one of the two segment slots (the segment products of the
+  // big-D kernels): this launch must not write its own segment products into the buffer it is reading (and ws_get
+  // must not re-allocate it), so it starts on the OTHER slot.
+  const bool mats_in_a = base.mats && w->ptr[SL_SEG_A] && (const void*)base.mats == w->ptr[SL_SEG_A];
+  const Slot first_slot = mats_in_a ? SL_SEG_B : SL_SEG_A;
   if (Dm > kMaxGenericDm) return fail("matrix dimension %d exceeds the generic kernel limit %d", Dm, kMaxGenericDm);
   const size_t msz = (size_t)Dm * Dm * sizeof(cplx);
   ChainPlan p = plan_generic(base.B, base.N, Dm);
@@ -168,7 +178,7 @@ int run_chain_generic(DeviceWs* w, ChainArgs base, cplx* U_out, hipStream_t st) 
   cplx* seg = U_out;
   if (p.S > 1) {
     void* v;
-    if (ws_get(w, SL_SEG_A, (size_t)base.B * p.S * msz, &v)) return -1;
+    if (ws_get(w, first_slot, (size_t)base.B * p.S * msz, &v)) return -1;
     seg = (cplx*)v;
     base.fr_phase = nullptr;
   }
@@ -180,7 +190,7 @@ int run_chain_generic(DeviceWs* w, ChainArgs base, cplx* U_out, hipStream_t st) 
     base.scratch = (cplx*)v;
   }
   g_last_kernel = p.global_scratch ? C3P_KERNEL_GENERIC_GLOBAL : C3P_KERNEL_GENERIC_LDS;
-  if (g_profiling) {
+  if (profile) {
     if (!w->ev0) {
       HIP_TRY(hipEventCreate(&w->ev0));
       HIP_TRY(hipEventCreate(&w->ev1));
@@ -188,14 +198,14 @@ int run_chain_generic(DeviceWs* w, ChainArgs base, cplx* U_out, hipStream_t st) 
     HIP_TRY(hipEventRecord(w->ev0, st));
   }
   HIP_TRY(c3p_launch_chain_generic(base, p.global_scratch, st));
-  if (g_profiling) {
+  if (profile) {
     HIP_TRY(hipEventRecord(w->ev1, st));
     w->ev_valid = true;
   }
   // ordered combine of the S segment products: groups of 8 until <= 16 remain
   int count = p.S;
   cplx* cur = seg;
-  Slot next_slot = SL_SEG_B;
+  Slot next_slot = (first_slot == SL_SEG_A) ? SL_SEG_B : SL_SEG_A;
   while (count > 1) {
     ChainArgs c = {};
     c.mode = C3P_MODE_GIVEN;
@@ -837,10 +847,7 @@ int run_pwc_bigd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
     c.Dm = Dm;
     c.fr_phase = fr_phase;
     const int keep = g_last_kernel;
-    const int prof = g_profiling;
-    g_profiling = 0;  // keep the event pair on the main kernel
-    const int rc = run_chain_generic(w, c, U_out, st);
-    g_profiling = prof;
+    const int rc = run_chain_generic(w, c, U_out, st, /*profile=*/false);  // the event pair stays on the main kernel
     g_last_kernel = keep;
     if (rc) return -1;
   }
@@ -913,10 +920,7 @@ int run_pwc_regd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
     c.Dm = Dm;
     c.fr_phase = fr_phase;
     const int keep = g_last_kernel;
-    const int prof = g_profiling;
-    g_profiling = 0;  // keep the event pair on the main kernel
-    const int rc = run_chain_generic(w, c, U_out, st);
-    g_profiling = prof;
+    const int rc = run_chain_generic(w, c, U_out, st, /*profile=*/false);  // the event pair stays on the main kernel
     g_last_kernel = keep;
     if (rc) return -1;
   }
@@ -953,7 +957,10 @@ int run_pwc_tiled(DeviceWs* w, const ChainArgs& a, bool per_slice, cplx* U_out, 
   t.dUs_out = a.dUs_out;
   g_last_kernel = C3P_KERNEL_MFMA;
   std::string err;
+  // many launches per call: the timing pair brackets the whole host-driven slice loop
+  if (record_start(w, st)) return -1;
   if (c3p_tiled_run(t, v, Bc, st, err)) return fail("%s", err.c_str());
+  if (record_stop(w, st)) return -1;
   return 0;
 }
 
@@ -1168,9 +1175,15 @@ void c3p_shutdown(void) {
     if (w->done) {
       (void)hipEventDestroy(w->done);
       w->done = nullptr;
-      w->has_last = false;
     }
   }
+  // the remembered stream may be destroyed by the caller after a shutdown: never touch it again
+  for (DeviceWs* w : all)
+    if (w) {
+      std::lock_guard<std::mutex> lk(w->mu);
+      w->has_last = false;
+      w->last_stream = nullptr;
+    }
   (void)hipSetDevice(cur);
 }
 
@@ -1353,6 +1366,18 @@ int c3p_ode_solve(const void* h0, const void* hks, const double* signals, const 
   a.n_steps = N;
   a.u_stride = 1;
   a.states = (cplx*)d_states;
+  if (c3p_ode_row_supported(a)) {
+    // lane-row kernels (c3p_ode_row.hip): one sample per 16-lane row, state and operator rows in registers
+    void* aux = nullptr;
+    if (C > 0 && ws_get(w, SL_TABLES, c3p_ode_row_aux_bytes(D, C), &aux)) return -1;
+    g_last_kernel = C3P_KERNEL_ODE_ROW;
+    if (record_start(w, st)) return -1;
+    HIP_TRY(c3p_launch_ode_row(a, aux, st));
+    if (record_stop(w, st)) return -1;
+    if (flags & C3P_HOST_PTRS) return sg.finish();
+    return 0;
+  }
+  g_last_kernel = C3P_KERNEL_ODE_WG;
   const size_t elems = c3p_ode_elems(D, M, C);
   const bool global = elems * cs > (size_t)(150 * 1024);
   if (global) {
@@ -1424,6 +1449,23 @@ int c3p_rk4_unitary(const void* h0, const void* hks, const double* signals, cons
   a.step = C3P_STEP_PROPAGATOR_ID;
   a.n_steps = n_steps;
   a.u_stride = 2;
+  if (c3p_ode_row_supported(a)) {
+    // every column of the propagator is an independent Schroedinger problem: B x D vector states on the lane-row kernel
+    g_last_kernel = C3P_KERNEL_ODE_ROW;
+    a.want_all = 0;
+    a.states = (cplx*)d_U;
+    HIP_TRY(c3p_launch_ode_row(a, nullptr, st));
+    if (d_dUs) {
+      a.want_all = 1;
+      a.reset_each_step = 1;
+      a.transpose_out = 1;
+      a.states = (cplx*)d_dUs;
+      HIP_TRY(c3p_launch_ode_row(a, nullptr, st));
+    }
+    if (flags & C3P_HOST_PTRS) return sg.finish();
+    return 0;
+  }
+  g_last_kernel = C3P_KERNEL_ODE_WG;
   const size_t elems = c3p_ode_elems(D, D, 0);
   const bool global = elems * cs > (size_t)(150 * 1024);
   if (global) {

@@ -28,5 +28,17 @@ struct OdeArgs {
   long scratch_stride;
 };
 
+// padded copies of the collapse operators for the lane-row rho kernel (c3p_ode_row.hip), written by its prep kernel
+struct OdeRowAux {
+  const cplx* colpad;  // [C][DP][DP]
+  const cplx* coladj;  // [C][DP][DP]: [m][j][c] = conj(C_m[c][j])
+  const cplx* gpad;    // [DP][DP]: sum_m C_m^+ C_m
+};
+
 size_t c3p_ode_elems(int D, int M, int C);
 hipError_t c3p_launch_ode(const OdeArgs& A, bool global_scratch, hipStream_t st);
+
+// Lane-row kernels (c3p_ode_row.hip): D <= 16, K <= 4, operators + signals (no supplied per-sample Hamiltonians)
+bool c3p_ode_row_supported(const OdeArgs& A);
+size_t c3p_ode_row_aux_bytes(int D, int C);
+hipError_t c3p_launch_ode_row(const OdeArgs& A, void* aux, hipStream_t st);

@@ -10,54 +10,16 @@
 #include "c3p_common.h"
 #include "c3p_kernels.h"
 #include "c3p_ode.h"
+#include "c3p_ode_tab.h"
 
 extern __shared__ __attribute__((aligned(16))) unsigned char c3p_ode_smem[];
 
 namespace {
 
-struct Tableau {
-  int stages;
-  double a[7][6];   // a[s][j], j < s
-  double b[7];
-  double node[7];   // stage time as a fraction of dt (which `Hs` window entry the stage uses)
-};
+typedef OdeTableau Tableau;
 
-// Coefficients exactly as the reference writes them.
-__constant__ Tableau c3p_tab[4] = {
-    // rk4 (propagation.py:755-762): h[0], h[1], h[1], h[2] = t, t+dt/2, t+dt/2, t+dt
-    {4,
-     {{0}, {0.5}, {0, 0.5}, {0, 0, 1.0}},
-     {1.0 / 6.0, 2.0 / 6.0, 2.0 / 6.0, 1.0 / 6.0},
-     {0.0, 0.5, 0.5, 1.0}},
-    // rk38 (:765-772)
-    {4,
-     {{0}, {1.0 / 3.0}, {-1.0 / 3.0, 1.0}, {1.0, -1.0, 1.0}},
-     {1.0 / 8.0, 3.0 / 8.0, 3.0 / 8.0, 1.0 / 8.0},
-     {0.0, 1.0 / 3.0, 2.0 / 3.0, 1.0}},
-    // rk5 (:775-823), nodes from interpolate_signal (tf_utils.py:523-537); k7 re-uses h[5]
-    {7,
-     {{0},
-      {1.0 / 5},
-      {3.0 / 40, 9.0 / 40},
-      {44.0 / 45, -56.0 / 15, 32.0 / 9},
-      {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729},
-      {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656},
-      {35.0 / 384, 0.0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84}},
-     {5179.0 / 57600, 0.0, 7571.0 / 16695, 393.0 / 640, -92097.0 / 339200, 187.0 / 2100, 1.0 / 40},
-     {0.0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0}},
-    // tsit5 (:826-883), nodes tf_utils.py:538-552
-    {7,
-     {{0},
-      {0.161},
-      {-0.008480655492356989, 0.335480655492357},
-      {2.8971530571054935, -6.359448489975075, 4.3622954328695815},
-      {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525},
-      {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383},
-      {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774}},
-     {0.09468075576583945, 0.009183565540343254, 0.4877705284247616, 1.234297566930479,
-      -2.7077123499835256, 1.866628418170587, 1.0 / 66},
-     {0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0}},
-};
+// Coefficients exactly as the reference writes them (c3p_ode_tab.h).
+__constant__ Tableau c3p_tab[4] = C3P_ODE_TABLEAUX;
 
 template <bool GLOBAL>
 struct OMem {

@@ -1,0 +1,588 @@
+// Lane-row ODE state solvers for D <= 16 (round 3): explicit Runge-Kutta integration of psi (Schroedinger), of the
+// columns of a propagator (rk4_unitary) and of rho (von Neumann / Lindblad), register resident, no barriers.
+//
+// Stands in for ode_solver / ode_solver_final_state (c3/libraries/propagation.py:687-752), the tableaux rk4 / rk38 /
+// rk5 / tsit5 (:755-883), the step functions schrodinger / von_neumann / lindblad (:886-904), Model.Hs_of_t
+// (c3/model.py:641-697) with interpolate_signal (c3/utils/tf_utils.py:521-559) and the rk4_unitary family
+// (propagation.py:71-101,221-255) -- same arithmetic as the workgroup-per-sample kernel of c3p_ode.hip (which stays the
+// path for D > 16, more than four control lines and supplied per-sample Hamiltonians), mapped to the machine differently:
+//
+//  * ONE SAMPLE PER 16-LANE DPP ROW, four samples per wavefront: lane i of the row owns ROW i of the Hamiltonian
+//    (the rows of h0 and of every hk stay in registers for the whole integration; H(t) = h0 + sum_k c_k(t) hk is
+//    assembled per stage node, 2 K D FMAs per lane) and element i of the state vector / row i of rho.
+//  * The matrix-vector product needs every lane to see all of y: `v_fmac_f64_dpp ... row_newbcast:j` multiplies the own
+//    H_ij by lane j's y_j in ONE instruction at the plain fp64 FMA rate -- no LDS round trip, no lane moves, no barrier
+//    (c3p_ode_dpp.inc; measured in tools/ubench_dpp.hip).  4 D FMAs per lane and stage (2 D for real operators).
+//  * rho-valued steps: (H rho)_i,: = sum_j H_ij rho_j,: (own scalar x broadcast row) and (rho H)_i,: = sum_j rho_ij H_j,:
+//    (own scalar x broadcast row of H): the same primitive; the anticommutator of the Lindblad step is folded into
+//    L = H - (i/2) G and R = H + (i/2) G (G = sum C^+ C), -i (L rho - rho R) = -i [H, rho] - {G, rho} / 2; the jump terms
+//    C rho C^+ use the broadcast primitive for C rho and wave-uniform scalar operands (SGPR) for (.) C^+.
+//  * Control amplitudes: 16 samples per row are fetched one chunk ahead (one coalesced 128-byte read per control line and
+//    chunk) and parked in LDS; a stage reads its two neighbours from there.  `Hs` is never materialised.
+//  * RK stages of the vector kernels live in registers (tableau = template parameter, zero coefficients vanish at compile
+//    time); the rho kernels keep them in lane-private LDS slots (stage loop rolled: the code of one stage is large).
+//  * The Hamiltonian of the last stage node (t + dt) IS the one of the next step's first node: carried, not rebuilt.
+#include <type_traits>
+#include <utility>
+
+#include "c3p_common.h"
+#include "c3p_ode.h"
+#include "c3p_ode_tab.h"
+#include "c3p_ode_dpp.inc"
+
+extern __shared__ __attribute__((aligned(16))) unsigned char c3p_ode_row_smem[];
+
+namespace {
+
+__constant__ OdeTableau c3p_row_tab[4] = C3P_ODE_TABLEAUX;
+
+__host__ __device__ constexpr OdeTableau tab_of(int solver) {
+  constexpr OdeTableau t[4] = C3P_ODE_TABLEAUX;
+  return t[solver];
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// values of one chunk: indices [base, base + 15] of a control line, 14 / u_stride steps per chunk (a stage reads
+// index lo and lo + 1 with lo <= base + u_stride * steps)
+__device__ __forceinline__ int chunk_steps(int us) { return 14 / us; }
+__device__ __forceinline__ int chunk_base(int n0, int us, int N) {
+  int b = us * n0;
+  if (b > N - 2) b = N - 2;
+  return b < 0 ? 0 : b;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// vector state: Schroedinger psi (M = 1) or one column of a propagator (M = D virtual samples per sample)
+// ---------------------------------------------------------------------------------------------------------------
+template <int DP, int KT, int SOLVER, bool REALH>
+__global__ void __launch_bounds__(64) ode_vec_kernel(OdeArgs A) {
+  using P = OdeDpp<DP>;
+  constexpr int S = tab_of(SOLVER).stages;
+  __shared__ double sig[4 * KT * 16];
+  const int lane = threadIdx.x, r = lane >> 4, i = lane & 15;
+  const int D = A.D, K = A.K, N = A.N, M = A.M, us = A.u_stride;
+  const long nv = (long)A.B * M;
+  long v = (long)blockIdx.x * 4 + r;
+  const bool live = v < nv;
+  if (!live) v = nv - 1;
+  const int b = (int)(v / M), col = (int)(v - (long)b * M);
+  const bool row = i < D;
+
+  // rows of the operators (zero padded to DP columns; lanes i >= D hold zero rows)
+  double h0r[DP], h0i[REALH ? 1 : DP], hkr[KT][DP], hki[KT][REALH ? 1 : DP];
+  bool im0 = true;
+#pragma unroll
+  for (int j = 0; j < DP; ++j) {
+    cplx z = cmake(0, 0);
+    if (row && j < D) z = A.h0[i * D + j];
+    h0r[j] = z.x;
+    if constexpr (!REALH) h0i[j] = z.y;
+    im0 = im0 && (z.y == 0.0);
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      cplx zk = cmake(0, 0);
+      if (row && j < D && k < K) zk = A.hks[((long)k * D + i) * D + j];
+      hkr[k][j] = zk.x;
+      if constexpr (!REALH) hki[k][j] = zk.y;
+      im0 = im0 && (zk.y == 0.0);
+    }
+  }
+  // real operators take the REALH instance, everything else the complex one (both are launched; wave-uniform exit)
+  if ((__all(im0) != 0) != REALH) return;
+
+  const cplx* init = A.init + (long)b * A.init_bstride;
+  double pr = 0.0, pi = 0.0;
+  if (row) {
+    const cplx z = init[(long)i * M + col];
+    pr = z.x;
+    pi = z.y;
+  }
+  const double ir = pr, ii = pi;
+  const double dt = A.dt;
+  const double* sg = A.signals + (long)b * K * N;
+  const int SPC = chunk_steps(us);
+  double pre[KT];
+  {
+    const int base = chunk_base(0, us, N);
+    int idx = base + i;
+    if (idx > N - 1) idx = N - 1;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) pre[k] = (k < K) ? sg[(long)k * N + idx] : 0.0;
+  }
+  double Hr[DP], Hi[REALH ? 1 : DP];
+  const long ssz = (long)D * M;
+  const long eo = A.transpose_out ? (long)col * D + i : (long)i * M + col;
+  cplx* outp = A.states + (long)b * (A.want_all ? (long)A.n_steps : 1) * ssz + eo;
+
+  for (int n0 = 0; n0 < A.n_steps; n0 += SPC) {
+    const int base = chunk_base(n0, us, N);
+#pragma unroll
+    for (int k = 0; k < KT; ++k) sig[(r * KT + k) * 16 + i] = pre[k];
+    {
+      const int nb = chunk_base(n0 + SPC, us, N);
+      int idx = nb + i;
+      if (idx > N - 1) idx = N - 1;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) pre[k] = (k < K) ? sg[(long)k * N + idx] : 0.0;
+    }
+    auto assemble = [&](double theta, int n) {
+      // linear interpolation of the control amplitudes, linear extrapolation past the last sample (tf_utils.py:557-559)
+      const double u = ((double)n + theta) * (double)us;
+      int lo = (int)floor(u);
+      if (lo > N - 2) lo = N - 2;
+      if (lo < 0) lo = 0;
+      const double f = u - (double)lo;
+      const double* sp = &sig[r * KT * 16 + (lo - base)];
+      double c[KT];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        const double y0 = sp[k * 16], y1 = sp[k * 16 + 1];
+        c[k] = fma(f, y1 - y0, y0);
+      }
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        double hr = h0r[j];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) hr = fma(c[k], hkr[k][j], hr);
+        Hr[j] = hr;
+        if constexpr (!REALH) {
+          double hi = h0i[j];
+#pragma unroll
+          for (int k = 0; k < KT; ++k) hi = fma(c[k], hki[k][j], hi);
+          Hi[j] = hi;
+        }
+      }
+    };
+    const int n1 = (n0 + SPC < A.n_steps) ? n0 + SPC : A.n_steps;
+    for (int n = n0; n < n1; ++n) {
+      double kr[S], ki[S];
+      static_for<0, S>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (s == 0) {
+          if (n == 0) assemble(tab_of(SOLVER).node[0], n);  // later steps: carried over from the previous step's last node
+        } else if constexpr (tab_of(SOLVER).node[s] != tab_of(SOLVER).node[s - 1]) {
+          assemble(tab_of(SOLVER).node[s], n);
+        }
+        double yr = pr, yi = pi;
+        static_for<0, s>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          constexpr double a = tab_of(SOLVER).a[s][j];
+          if constexpr (a != 0.0) {
+            yr = fma(a, kr[j], yr);
+            yi = fma(a, ki[j], yi);
+          }
+        });
+        double w[4] = {0.0, 0.0, 0.0, 0.0};
+        if constexpr (REALH) {
+          P::matvec_r(w, yr, yi, Hr);
+          kr[s] = dt * (w[1] + w[3]);
+          ki[s] = -dt * (w[0] + w[2]);
+        } else {
+          P::matvec_c(w, yr, yi, Hr, Hi);
+          kr[s] = dt * (w[1] + w[3]);  // -i dt (wr + i wi) = dt wi - i dt wr
+          ki[s] = -dt * (w[0] + w[2]);
+        }
+      });
+      static_for<0, S>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr double bj = tab_of(SOLVER).b[j];
+        if constexpr (bj != 0.0) {
+          pr = fma(bj, kr[j], pr);
+          pi = fma(bj, ki[j], pi);
+        }
+      });
+      if (A.want_all && live && row) outp[(long)n * ssz] = cmake(pr, pi);
+      if (A.reset_each_step) {
+        pr = ir;
+        pi = ii;
+      }
+    }
+  }
+  if (!A.want_all && live && row) outp[0] = cmake(pr, pi);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// matrix state rho: von Neumann (C = 0) and Lindblad steps; lane i owns row i of rho
+// ---------------------------------------------------------------------------------------------------------------
+struct MatLds {
+  int sig_off, k_off, col_off;
+  size_t bytes;
+};
+__host__ __device__ inline MatLds mat_lds(int DP, int KT, int stages, int C) {
+  MatLds m;
+  m.sig_off = 0;
+  m.k_off = 4 * KT * 16 * 8;
+  m.col_off = m.k_off + stages * DP * 64 * 16;
+  m.bytes = (size_t)m.col_off + (size_t)C * DP * DP * 16;
+  return m;
+}
+
+template <int DP, int KT, bool REALH>
+__global__ void __launch_bounds__(64, 1) ode_mat_kernel(OdeArgs A, OdeRowAux X) {
+  using P = OdeDpp<DP>;
+  const OdeTableau& T = c3p_row_tab[A.solver];
+  const int S = T.stages;
+  const int lane = threadIdx.x, r = lane >> 4, i = lane & 15;
+  const int D = A.D, K = A.K, N = A.N, C = A.C, us = A.u_stride;
+  const MatLds L = mat_lds(DP, KT, S, C);
+  double* sig = reinterpret_cast<double*>(c3p_ode_row_smem + L.sig_off);
+  cplx* kst = reinterpret_cast<cplx*>(c3p_ode_row_smem + L.k_off);       // [stage][c][lane]
+  cplx* colrow = reinterpret_cast<cplx*>(c3p_ode_row_smem + L.col_off);  // [m][i][j], zero padded to DP
+  long v = (long)blockIdx.x * 4 + r;
+  const bool live = v < A.B;
+  if (!live) v = A.B - 1;
+  const int b = (int)v;
+  const bool row = i < D;
+
+  double h0r[DP], h0i[REALH ? 1 : DP], hkr[KT][DP], hki[KT][REALH ? 1 : DP];
+  bool im0 = true;
+#pragma unroll
+  for (int j = 0; j < DP; ++j) {
+    cplx z = cmake(0, 0);
+    if (row && j < D) z = A.h0[i * D + j];
+    h0r[j] = z.x;
+    if constexpr (!REALH) h0i[j] = z.y;
+    im0 = im0 && (z.y == 0.0);
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      cplx zk = cmake(0, 0);
+      if (row && j < D && k < K) zk = A.hks[((long)k * D + i) * D + j];
+      hkr[k][j] = zk.x;
+      if constexpr (!REALH) hki[k][j] = zk.y;
+      im0 = im0 && (zk.y == 0.0);
+    }
+  }
+  // the real instance takes real Hamiltonians without collapse operators, the complex one everything else
+  const bool real_case = (__all(im0) != 0) && C == 0;
+  if (real_case != REALH) return;
+
+  // G = sum_m C_m^+ C_m (row i, from the padded copy the prep kernel wrote), own rows of the collapse operators -> LDS
+  double Gr[REALH ? 1 : DP], Gi[REALH ? 1 : DP];
+  if constexpr (!REALH) {
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+      cplx g = cmake(0, 0);
+      if (C > 0) g = X.gpad[i * DP + j];
+      Gr[j] = g.x;
+      Gi[j] = g.y;
+    }
+    for (int e = lane; e < C * DP * DP; e += 64) colrow[e] = X.colpad[e];
+  }
+
+  double Sr[DP], Si[DP];
+  const cplx* init = A.init + (long)b * A.init_bstride;
+#pragma unroll
+  for (int c = 0; c < DP; ++c) {
+    cplx z = cmake(0, 0);
+    if (row && c < D) z = init[(long)i * D + c];
+    Sr[c] = z.x;
+    Si[c] = z.y;
+  }
+  const double dt = A.dt;
+  const double* sg = A.signals + (long)b * K * N;
+  const int SPC = chunk_steps(us);
+  double pre[KT];
+  {
+    const int base = chunk_base(0, us, N);
+    int idx = base + i;
+    if (idx > N - 1) idx = N - 1;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) pre[k] = (k < K) ? sg[(long)k * N + idx] : 0.0;
+  }
+  const long ssz = (long)D * D;
+  cplx* outp = A.states + (long)b * (A.want_all ? (long)A.n_steps : 1) * ssz + (long)i * D;
+
+  for (int n0 = 0; n0 < A.n_steps; n0 += SPC) {
+    const int base = chunk_base(n0, us, N);
+#pragma unroll
+    for (int k = 0; k < KT; ++k) sig[(r * KT + k) * 16 + i] = pre[k];
+    {
+      const int nb = chunk_base(n0 + SPC, us, N);
+      int idx = nb + i;
+      if (idx > N - 1) idx = N - 1;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) pre[k] = (k < K) ? sg[(long)k * N + idx] : 0.0;
+    }
+    const int n1 = (n0 + SPC < A.n_steps) ? n0 + SPC : A.n_steps;
+    for (int n = n0; n < n1; ++n) {
+      for (int s = 0; s < S; ++s) {
+        // H(t_stage): rows L = H - (i/2) G (left factor) and R = H + (i/2) G (right factor, read by the other lanes)
+        double Lr[DP], Li[REALH ? 1 : DP], Rr[REALH ? 1 : DP], Ri[REALH ? 1 : DP];
+        {
+          const double u = ((double)n + T.node[s]) * (double)us;
+          int lo = (int)floor(u);
+          if (lo > N - 2) lo = N - 2;
+          if (lo < 0) lo = 0;
+          const double f = u - (double)lo;
+          const double* sp = &sig[r * KT * 16 + (lo - base)];
+          double c[KT];
+#pragma unroll
+          for (int k = 0; k < KT; ++k) {
+            const double y0 = sp[k * 16], y1 = sp[k * 16 + 1];
+            c[k] = fma(f, y1 - y0, y0);
+          }
+#pragma unroll
+          for (int j = 0; j < DP; ++j) {
+            double hr = h0r[j];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) hr = fma(c[k], hkr[k][j], hr);
+            if constexpr (REALH) {
+              Lr[j] = hr;
+            } else {
+              double hi = h0i[j];
+#pragma unroll
+              for (int k = 0; k < KT; ++k) hi = fma(c[k], hki[k][j], hi);
+              // -(i/2) (gr + i gi) = gi/2 - i gr/2
+              Lr[j] = fma(0.5, Gi[j], hr);
+              Li[j] = fma(-0.5, Gr[j], hi);
+              Rr[j] = fma(-0.5, Gi[j], hr);
+              Ri[j] = fma(0.5, Gr[j], hi);
+            }
+          }
+        }
+        // stage argument Y = rho + sum_j a[s][j] k_j
+        double Yr[DP], Yi[DP];
+#pragma unroll
+        for (int c = 0; c < DP; ++c) {
+          Yr[c] = Sr[c];
+          Yi[c] = Si[c];
+        }
+        for (int j = 0; j < s; ++j) {
+          const double a = T.a[s][j];
+          if (a != 0.0) {
+#pragma unroll
+            for (int c = 0; c < DP; ++c) {
+              const cplx kk = kst[(j * DP + c) * 64 + lane];
+              Yr[c] = fma(a, kk.x, Yr[c]);
+              Yi[c] = fma(a, kk.y, Yi[c]);
+            }
+          }
+        }
+        // W = L Y - Y R
+        double Wr[DP], Wi[DP];
+#pragma unroll
+        for (int c = 0; c < DP; ++c) Wr[c] = Wi[c] = 0.0;
+        static_for<0, DP>([&](auto jc) {
+          constexpr int J = decltype(jc)::value;
+          if constexpr (REALH) {
+            P::template bmac_rs<J, false>(Wr, Wi, Lr[J], Yr, Yi);
+          } else {
+            P::template bmac_cc<J, false>(Wr, Wi, Lr[J], Li[J], Yr, Yi);
+          }
+        });
+        static_for<0, DP>([&](auto jc) {
+          constexpr int J = decltype(jc)::value;
+          if constexpr (REALH) {
+            P::template bmac_rv<J, true>(Wr, Wi, Yr[J], Yi[J], Lr);
+          } else {
+            P::template bmac_cc<J, true>(Wr, Wi, Yr[J], Yi[J], Rr, Ri);
+          }
+        });
+        // k = -i dt W
+        double kr[DP], ki[DP];
+#pragma unroll
+        for (int c = 0; c < DP; ++c) {
+          kr[c] = dt * Wi[c];
+          ki[c] = -dt * Wr[c];
+        }
+        if constexpr (!REALH) {
+          // jump terms: k += dt sum_m (C_m Y) C_m^+
+          for (int m = 0; m < C; ++m) {
+            double Tr[DP], Ti[DP];
+#pragma unroll
+            for (int c = 0; c < DP; ++c) Tr[c] = Ti[c] = 0.0;
+            const cplx* cr = colrow + ((long)m * DP + i) * DP;
+            static_for<0, DP>([&](auto jc) {
+              constexpr int J = decltype(jc)::value;
+              const cplx cij = cr[J];
+              P::template bmac_cc<J, false>(Tr, Ti, cij.x, cij.y, Yr, Yi);
+            });
+#pragma unroll
+            for (int c = 0; c < DP; ++c) {
+              Tr[c] *= dt;
+              Ti[c] *= dt;
+            }
+            // (T C^+)_ic = sum_j T_ij conj(C_cj): the right factor is the same for every lane -> scalar operands
+            const cplx* __restrict__ ca = X.coladj + (long)m * DP * DP;  // [j][c] = conj(C_m[c][j])
+#pragma unroll
+            for (int j = 0; j < DP; ++j) {
+#pragma unroll
+              for (int c = 0; c < DP; ++c) {
+                const cplx z = ca[j * DP + c];
+                kr[c] = fma(Tr[j], z.x, kr[c]);
+                kr[c] = fma(-Ti[j], z.y, kr[c]);
+                ki[c] = fma(Tr[j], z.y, ki[c]);
+                ki[c] = fma(Ti[j], z.x, ki[c]);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < DP; ++c) kst[(s * DP + c) * 64 + lane] = cmake(kr[c], ki[c]);
+      }
+      // rho += sum_j b_j k_j
+      for (int j = 0; j < S; ++j) {
+        const double bj = T.b[j];
+        if (bj != 0.0) {
+#pragma unroll
+          for (int c = 0; c < DP; ++c) {
+            const cplx kk = kst[(j * DP + c) * 64 + lane];
+            Sr[c] = fma(bj, kk.x, Sr[c]);
+            Si[c] = fma(bj, kk.y, Si[c]);
+          }
+        }
+      }
+      if (A.want_all && live && row) {
+        cplx* o = outp + (long)n * ssz;
+#pragma unroll
+        for (int c = 0; c < DP; ++c)
+          if (c < D) o[c] = cmake(Sr[c], Si[c]);
+      }
+    }
+  }
+  if (!A.want_all && live && row) {
+#pragma unroll
+    for (int c = 0; c < DP; ++c)
+      if (c < D) outp[c] = cmake(Sr[c], Si[c]);
+  }
+}
+
+// padded copies of the collapse operators for ode_mat_kernel: colpad [C][DP][DP], coladj[m][j][c] = conj(C_m[c][j]),
+// gpad = sum_m C_m^+ C_m [DP][DP]
+__global__ void ode_colprep_kernel(const cplx* col, int C, int D, int DP, cplx* colpad, cplx* coladj, cplx* gpad) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int e = tid; e < C * DP * DP; e += nt) {
+    const int m = e / (DP * DP), rr = (e / DP) % DP, cc = e % DP;
+    cplx z = cmake(0, 0), za = cmake(0, 0);
+    if (rr < D && cc < D) {
+      z = col[((long)m * D + rr) * D + cc];
+      za = cconj(col[((long)m * D + cc) * D + rr]);
+    }
+    colpad[e] = z;
+    coladj[e] = za;
+  }
+  for (int e = tid; e < DP * DP; e += nt) {
+    const int ii = e / DP, jj = e % DP;
+    cplx s = cmake(0, 0);
+    if (ii < D && jj < D)
+      for (int m = 0; m < C; ++m)
+        for (int k = 0; k < D; ++k) cfma(s, cconj(col[((long)m * D + k) * D + ii]), col[((long)m * D + k) * D + jj]);
+    gpad[e] = s;
+  }
+}
+
+int pad_dim(int D) {
+  const int dps[] = {2, 3, 4, 6, 9, 12, 16};
+  for (int d : dps)
+    if (D <= d) return d;
+  return 0;
+}
+
+template <int DP, int KT, int SOLVER>
+hipError_t launch_vec3(const OdeArgs& A, dim3 grid, hipStream_t st) {
+  hipLaunchKernelGGL((ode_vec_kernel<DP, KT, SOLVER, true>), grid, dim3(64), 0, st, A);
+  hipLaunchKernelGGL((ode_vec_kernel<DP, KT, SOLVER, false>), grid, dim3(64), 0, st, A);
+  return hipGetLastError();
+}
+template <int DP, int KT>
+hipError_t launch_vec2(const OdeArgs& A, dim3 grid, hipStream_t st) {
+  switch (A.solver) {
+    case 0: return launch_vec3<DP, KT, 0>(A, grid, st);
+    case 1: return launch_vec3<DP, KT, 1>(A, grid, st);
+    case 2: return launch_vec3<DP, KT, 2>(A, grid, st);
+    default: return launch_vec3<DP, KT, 3>(A, grid, st);
+  }
+}
+template <int DP>
+hipError_t launch_vec1(const OdeArgs& A, dim3 grid, hipStream_t st) {
+  return A.K <= 2 ? launch_vec2<DP, 2>(A, grid, st) : launch_vec2<DP, 4>(A, grid, st);
+}
+
+template <int DP, int KT, bool REALH>
+hipError_t launch_mat3(const OdeArgs& A, const OdeRowAux& X, dim3 grid, size_t lds, hipStream_t st) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ode_mat_kernel<DP, KT, REALH>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((ode_mat_kernel<DP, KT, REALH>), grid, dim3(64), lds, st, A, X);
+  return hipGetLastError();
+}
+template <int DP>
+hipError_t launch_mat1(const OdeArgs& A, const OdeRowAux& X, dim3 grid, hipStream_t st) {
+  const int stages = (A.solver >= 2) ? 7 : 4;
+  hipError_t e = hipSuccess;
+  if (A.K <= 2) {
+    const size_t lds = mat_lds(DP, 2, stages, A.C).bytes;
+    if (A.C == 0) e = launch_mat3<DP, 2, true>(A, X, grid, lds, st);
+    if (e == hipSuccess) e = launch_mat3<DP, 2, false>(A, X, grid, lds, st);
+  } else {
+    const size_t lds = mat_lds(DP, 4, stages, A.C).bytes;
+    if (A.C == 0) e = launch_mat3<DP, 4, true>(A, X, grid, lds, st);
+    if (e == hipSuccess) e = launch_mat3<DP, 4, false>(A, X, grid, lds, st);
+  }
+  return e;
+}
+
+}  // namespace
+
+bool c3p_ode_row_supported(const OdeArgs& A) {
+  if (getenv("C3P_ODE_WG")) return false;  // A/B switch: the workgroup-per-sample kernel of c3p_ode.hip
+  if (A.D > 16 || A.K > 4 || A.hs || A.N < 2) return false;
+  if (A.u_stride != 1 && A.u_stride != 2) return false;
+  if (A.step == C3P_STEP_SCHRODINGER_ID || A.step == C3P_STEP_PROPAGATOR_ID) return true;
+  // rho-valued steps
+  if (A.reset_each_step || A.transpose_out) return false;
+  const int DP = pad_dim(A.D);
+  const int stages = (A.solver >= 2) ? 7 : 4;
+  return mat_lds(DP, A.K <= 2 ? 2 : 4, stages, A.C).bytes <= (size_t)(150 * 1024);
+}
+
+size_t c3p_ode_row_aux_bytes(int D, int C) {
+  const int DP = pad_dim(D);
+  return (size_t)(2 * C + 1) * DP * DP * sizeof(cplx);
+}
+
+hipError_t c3p_launch_ode_row(const OdeArgs& A, void* aux, hipStream_t st) {
+  const int DP = pad_dim(A.D);
+  const bool vec = (A.step == C3P_STEP_SCHRODINGER_ID || A.step == C3P_STEP_PROPAGATOR_ID);
+  const long nv = vec ? (long)A.B * A.M : (long)A.B;
+  const dim3 grid((unsigned)((nv + 3) / 4));
+  if (vec) {
+    switch (DP) {
+      case 2: return launch_vec1<2>(A, grid, st);
+      case 3: return launch_vec1<3>(A, grid, st);
+      case 4: return launch_vec1<4>(A, grid, st);
+      case 6: return launch_vec1<6>(A, grid, st);
+      case 9: return launch_vec1<9>(A, grid, st);
+      case 12: return launch_vec1<12>(A, grid, st);
+      default: return launch_vec1<16>(A, grid, st);
+    }
+  }
+  OdeRowAux X = {};
+  if (A.C > 0) {
+    cplx* base = static_cast<cplx*>(aux);
+    const size_t one = (size_t)DP * DP;
+    cplx* colpad = base;
+    cplx* coladj = base + (size_t)A.C * one;
+    cplx* gpad = base + (size_t)2 * A.C * one;
+    hipLaunchKernelGGL(ode_colprep_kernel, dim3(1), dim3(256), 0, st, A.col_ops, A.C, A.D, DP, colpad, coladj, gpad);
+    X.colpad = colpad;
+    X.coladj = coladj;
+    X.gpad = gpad;
+  }
+  switch (DP) {
+    case 2: return launch_mat1<2>(A, X, grid, st);
+    case 3: return launch_mat1<3>(A, X, grid, st);
+    case 4: return launch_mat1<4>(A, X, grid, st);
+    case 6: return launch_mat1<6>(A, X, grid, st);
+    case 9: return launch_mat1<9>(A, X, grid, st);
+    case 12: return launch_mat1<12>(A, X, grid, st);
+    default: return launch_mat1<16>(A, X, grid, st);
+  }
+}

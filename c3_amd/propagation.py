@@ -202,24 +202,29 @@ def propagate_batch(
     return {"U": U, "dUs": dUs}
 
 
-_hermitian_ok = set()
+_hermitian_ok = {}  # id(tensor) -> (weakref to the tensor, _version it passed at)
 
 
 def _require_hermitian(call, name, h):
     """The adjoint sweep assumes unitary slices, i.e. Hermitian Hamiltonians; the library only checks host-pointer
     inputs, so device tensors are checked here (one reduction + a host sync per operator set)."""
     if call.device:
-        # an optimizer calls with the same operator tensors every iteration: a tensor that passed is not reduced again
-        # until it is written to (`_version`) or its storage is reused for another shape
-        key = (h.data_ptr(), h._version, tuple(h.shape), str(h.device))
-        if key in _hermitian_ok:
+        # an optimizer calls with the same operator tensors every iteration: a tensor OBJECT that passed is not reduced
+        # again until it is written to (`_version`).  Keyed on the object (weak reference, entry dropped when it dies),
+        # not on its address: the caching allocator hands a freed address to the next operator tensor of that shape.
+        import weakref
+
+        ent = _hermitian_ok.get(id(h))
+        if ent is not None and ent[0]() is h and ent[1] == h._version:
             return
         dev = float((h - h.conj().transpose(-1, -2)).abs().max().item())
         scale = float(h.abs().max().item())
         if dev <= 1e-12 * max(scale, 1e-300):
-            if len(_hermitian_ok) >= 32:
-                _hermitian_ok.clear()
-            _hermitian_ok.add(key)
+            key = id(h)
+            try:
+                _hermitian_ok[key] = (weakref.ref(h, lambda _r, k=key: _hermitian_ok.pop(k, None)), h._version)
+            except TypeError:
+                pass
     else:
         dev = float(np.abs(h - np.conj(np.swapaxes(h, -1, -2))).max())
         scale = float(np.abs(h).max())

@@ -60,6 +60,8 @@ extern "C" {
 #define C3P_KERNEL_GENERIC_GLOBAL 2
 #define C3P_KERNEL_SMALLD 3
 #define C3P_KERNEL_MFMA 4
+#define C3P_KERNEL_ODE_WG 5  /* workgroup-per-sample ODE kernel (c3p_ode.hip)            */
+#define C3P_KERNEL_ODE_ROW 6 /* lane-row ODE kernels, D <= 16 (c3p_ode_row.hip)          */
 
 /* ODE solver / step ids (propagation.py:27-32 solver_slicing; :886-904 steps) */
 #define C3P_SOLVER_RK4 0
