@@ -41,6 +41,8 @@ __host__ __device__ constexpr OdeTableau tab_of(int solver) {
   return t[solver];
 }
 
+typedef const double __attribute__((address_space(4)))* cdouble_ptr;  // constant address space: uniform loads become s_load
+
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
@@ -215,11 +217,14 @@ struct MatLds {
   int sig_off, k_off, col_off;
   size_t bytes;
 };
-__host__ __device__ inline MatLds mat_lds(int DP, int KT, int stages, int C) {
+// stage slots hold the LIVE lanes only (4 rows x D lanes): 7 stages at D = 9 are 36 KB instead of 64 KB per wavefront
+// (rk4: a[s][j] = 0 but for j = s - 1, the previous stage is still in registers: no slots at all)
+__host__ __device__ inline MatLds mat_lds(int D, int DP, int KT, int solver, int C) {
+  const int stages = solver == 0 ? 0 : (solver == 1 ? 4 : 7);
   MatLds m;
   m.sig_off = 0;
   m.k_off = 4 * KT * 16 * 8;
-  m.col_off = m.k_off + stages * DP * 64 * 16;
+  m.col_off = m.k_off + stages * DP * 4 * D * 16;
   m.bytes = (size_t)m.col_off + (size_t)C * DP * DP * 16;
   return m;
 }
@@ -231,15 +236,18 @@ __global__ void __launch_bounds__(64, 1) ode_mat_kernel(OdeArgs A, OdeRowAux X) 
   const int S = T.stages;
   const int lane = threadIdx.x, r = lane >> 4, i = lane & 15;
   const int D = A.D, K = A.K, N = A.N, C = A.C, us = A.u_stride;
-  const MatLds L = mat_lds(DP, KT, S, C);
+  const MatLds L = mat_lds(D, DP, KT, A.solver, C);
+  const bool subdiag = A.solver == 0;  // rk4
   double* sig = reinterpret_cast<double*>(c3p_ode_row_smem + L.sig_off);
-  cplx* kst = reinterpret_cast<cplx*>(c3p_ode_row_smem + L.k_off);       // [stage][c][lane]
+  cplx* kst = reinterpret_cast<cplx*>(c3p_ode_row_smem + L.k_off);       // [stage][c][live lane]
   cplx* colrow = reinterpret_cast<cplx*>(c3p_ode_row_smem + L.col_off);  // [m][i][j], zero padded to DP
   long v = (long)blockIdx.x * 4 + r;
   const bool live = v < A.B;
   if (!live) v = A.B - 1;
   const int b = (int)v;
   const bool row = i < D;
+  const int NL = 4 * D;                                // live lanes of the wavefront
+  const int lidx = r * D + (row ? i : D - 1);          // stage-slot index (padding lanes alias a live one, reads masked)
 
   double h0r[DP], h0i[REALH ? 1 : DP], hkr[KT][DP], hki[KT][REALH ? 1 : DP];
   bool im0 = true;
@@ -312,6 +320,9 @@ __global__ void __launch_bounds__(64, 1) ode_mat_kernel(OdeArgs A, OdeRowAux X) 
     }
     const int n1 = (n0 + SPC < A.n_steps) ? n0 + SPC : A.n_steps;
     for (int n = n0; n < n1; ++n) {
+      double kr[DP], ki[DP], Br[DP], Bi[DP];  // current stage, running sum_j b_j k_j
+#pragma unroll
+      for (int c = 0; c < DP; ++c) kr[c] = ki[c] = Br[c] = Bi[c] = 0.0;
       for (int s = 0; s < S; ++s) {
         // H(t_stage): rows L = H - (i/2) G (left factor) and R = H + (i/2) G (right factor, read by the other lanes)
         double Lr[DP], Li[REALH ? 1 : DP], Rr[REALH ? 1 : DP], Ri[REALH ? 1 : DP];
@@ -354,14 +365,25 @@ __global__ void __launch_bounds__(64, 1) ode_mat_kernel(OdeArgs A, OdeRowAux X) 
           Yr[c] = Sr[c];
           Yi[c] = Si[c];
         }
-        for (int j = 0; j < s; ++j) {
-          const double a = T.a[s][j];
-          if (a != 0.0) {
+        if (s > 0) {
+          const double a = T.a[s][s - 1];  // the previous stage is still in registers
 #pragma unroll
-            for (int c = 0; c < DP; ++c) {
-              const cplx kk = kst[(j * DP + c) * 64 + lane];
-              Yr[c] = fma(a, kk.x, Yr[c]);
-              Yi[c] = fma(a, kk.y, Yi[c]);
+          for (int c = 0; c < DP; ++c) {
+            Yr[c] = fma(a, kr[c], Yr[c]);
+            Yi[c] = fma(a, ki[c], Yi[c]);
+          }
+        }
+        if (!subdiag) {
+          for (int j = 0; j + 1 < s; ++j) {
+            const double a0 = T.a[s][j];
+            if (a0 != 0.0) {
+              const double a = row ? a0 : 0.0;  // padding lanes keep their zero rows
+#pragma unroll
+              for (int c = 0; c < DP; ++c) {
+                const cplx kk = kst[(j * DP + c) * NL + lidx];
+                Yr[c] = fma(a, kk.x, Yr[c]);
+                Yi[c] = fma(a, kk.y, Yi[c]);
+              }
             }
           }
         }
@@ -386,7 +408,6 @@ __global__ void __launch_bounds__(64, 1) ode_mat_kernel(OdeArgs A, OdeRowAux X) 
           }
         });
         // k = -i dt W
-        double kr[DP], ki[DP];
 #pragma unroll
         for (int c = 0; c < DP; ++c) {
           kr[c] = dt * Wi[c];
@@ -410,34 +431,39 @@ __global__ void __launch_bounds__(64, 1) ode_mat_kernel(OdeArgs A, OdeRowAux X) 
               Ti[c] *= dt;
             }
             // (T C^+)_ic = sum_j T_ij conj(C_cj): the right factor is the same for every lane -> scalar operands
-            const cplx* __restrict__ ca = X.coladj + (long)m * DP * DP;  // [j][c] = conj(C_m[c][j])
+            // (read through the constant address space: s_load + SGPR operands; the buffer is written by the prep kernel only)
+            const cdouble_ptr ca = (cdouble_ptr)(const double*)(X.coladj + (long)m * DP * DP);  // [j][c] = conj(C_m[c][j])
 #pragma unroll
             for (int j = 0; j < DP; ++j) {
 #pragma unroll
               for (int c = 0; c < DP; ++c) {
-                const cplx z = ca[j * DP + c];
-                kr[c] = fma(Tr[j], z.x, kr[c]);
-                kr[c] = fma(-Ti[j], z.y, kr[c]);
-                ki[c] = fma(Tr[j], z.y, ki[c]);
-                ki[c] = fma(Ti[j], z.x, ki[c]);
+                const double zx = ca[2 * (j * DP + c)], zy = ca[2 * (j * DP + c) + 1];
+                kr[c] = fma(Tr[j], zx, kr[c]);
+                kr[c] = fma(-Ti[j], zy, kr[c]);
+                ki[c] = fma(Tr[j], zy, ki[c]);
+                ki[c] = fma(Ti[j], zx, ki[c]);
               }
             }
           }
         }
-#pragma unroll
-        for (int c = 0; c < DP; ++c) kst[(s * DP + c) * 64 + lane] = cmake(kr[c], ki[c]);
-      }
-      // rho += sum_j b_j k_j
-      for (int j = 0; j < S; ++j) {
-        const double bj = T.b[j];
-        if (bj != 0.0) {
+        {
+          const double bs = T.b[s];
 #pragma unroll
           for (int c = 0; c < DP; ++c) {
-            const cplx kk = kst[(j * DP + c) * 64 + lane];
-            Sr[c] = fma(bj, kk.x, Sr[c]);
-            Si[c] = fma(bj, kk.y, Si[c]);
+            Br[c] = fma(bs, kr[c], Br[c]);
+            Bi[c] = fma(bs, ki[c], Bi[c]);
           }
         }
+        if (!subdiag && row && s + 2 < S) {  // later stages than the next one read it back
+#pragma unroll
+          for (int c = 0; c < DP; ++c) kst[(s * DP + c) * NL + lidx] = cmake(kr[c], ki[c]);
+        }
+      }
+      // rho += sum_j b_j k_j
+#pragma unroll
+      for (int c = 0; c < DP; ++c) {
+        Sr[c] += Br[c];
+        Si[c] += Bi[c];
       }
       if (A.want_all && live && row) {
         cplx* o = outp + (long)n * ssz;
@@ -515,14 +541,13 @@ hipError_t launch_mat3(const OdeArgs& A, const OdeRowAux& X, dim3 grid, size_t l
 }
 template <int DP>
 hipError_t launch_mat1(const OdeArgs& A, const OdeRowAux& X, dim3 grid, hipStream_t st) {
-  const int stages = (A.solver >= 2) ? 7 : 4;
   hipError_t e = hipSuccess;
   if (A.K <= 2) {
-    const size_t lds = mat_lds(DP, 2, stages, A.C).bytes;
+    const size_t lds = mat_lds(A.D, DP, 2, A.solver, A.C).bytes;
     if (A.C == 0) e = launch_mat3<DP, 2, true>(A, X, grid, lds, st);
     if (e == hipSuccess) e = launch_mat3<DP, 2, false>(A, X, grid, lds, st);
   } else {
-    const size_t lds = mat_lds(DP, 4, stages, A.C).bytes;
+    const size_t lds = mat_lds(A.D, DP, 4, A.solver, A.C).bytes;
     if (A.C == 0) e = launch_mat3<DP, 4, true>(A, X, grid, lds, st);
     if (e == hipSuccess) e = launch_mat3<DP, 4, false>(A, X, grid, lds, st);
   }
@@ -539,8 +564,7 @@ bool c3p_ode_row_supported(const OdeArgs& A) {
   // rho-valued steps
   if (A.reset_each_step || A.transpose_out) return false;
   const int DP = pad_dim(A.D);
-  const int stages = (A.solver >= 2) ? 7 : 4;
-  return mat_lds(DP, A.K <= 2 ? 2 : 4, stages, A.C).bytes <= (size_t)(150 * 1024);
+  return mat_lds(A.D, DP, A.K <= 2 ? 2 : 4, A.solver, A.C).bytes <= (size_t)(150 * 1024);
 }
 
 size_t c3p_ode_row_aux_bytes(int D, int C) {

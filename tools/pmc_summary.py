@@ -7,7 +7,7 @@ def main(dirs):
             agg = collections.defaultdict(lambda: collections.defaultdict(list))
             meta = {}
             for r in rows:
-                k = (r['Kernel_Name'].split('(')[1][:40] if 'anonymous' in r['Kernel_Name'] else r['Kernel_Name'][:40], r['Grid_Size'])
+                k = (r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '')[:64], r['Grid_Size'])
                 agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
                 meta[k] = (r['VGPR_Count'], r['Accum_VGPR_Count'], r['LDS_Block_Size'], r['Scratch_Size'])
             for k, v in agg.items():
