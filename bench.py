@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP64_TFLOPS = 78.6  # MI355X dense fp64 (vector = matrix; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 # thresholds of the reference's expm (tf.linalg.expm, Higham 2005 Pade 3/5/7/9/13 chosen from ||A||_1)
 _PADE_THETA = (1.495585217958292e-2, 2.539398330063230e-1, 9.504178996162932e-1, 2.097847961257068, 5.371920351148152)
@@ -112,6 +112,10 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive side measurement")
     ap.add_argument("--generic", action="store_true", help="force the generic LDS kernel")
     ap.add_argument("--check", action="store_true", help="verify samples against the oracle (and the gathered slabs)")
+    ap.add_argument("--complex", action="store_true", dest="complex_ops",
+                    help="give the second control operator an imaginary (Hermitian) part: the general complex-Hamiltonian instances instead of the real fast path")
+    ap.add_argument("--exchange", choices=("gather", "goal"), default="gather",
+                    help="multi-GPU exchange: all-gather of the U slabs (default) or the gather-free optimiser loop: fused fidelity per sample + ONE all-reduce of the goal per step")
     args = ap.parse_args()
 
     import numpy as np
@@ -143,6 +147,12 @@ def main():
     B_glob, lo, hi, b_pad = plan_batch(cfg, args.scaling, args.batch, world, rank)
     B = hi - lo  # this rank's samples
     wl = workloads.make_workload(args.config, B=max(B, 1), N=args.slices, b_offset=lo)
+    if args.complex_ops:
+        k = min(1, wl.K - 1)
+        up = np.triu(wl.hks[k].real, 1)
+        wl.hks = wl.hks.copy()
+        wl.hks[k] = wl.hks[k] + 0.3j * (up - up.T)  # Hermitian, complex (a Y-type drive / rotating-frame operator)
+        wl.name += " complex-Hamiltonian"
     Dm = wl.D * wl.D if wl.lindblad else wl.D
     fr = wl.fr_phase
     if wl.lindblad:
@@ -161,12 +171,36 @@ def main():
     # The only data-path collective is the all-gather of the U slabs (RCCL over xGMI), in stream order, G steps per
     # collective.  (An asynchronous gather beside the chain kernel was measured SLOWER: the RCCL kernel takes CUs away
     # from a grid sized to fill the chip exactly and creates a partial second round.)
-    ring = c3dist.SlabRing(B, b_pad, (Dm, Dm), args.gather_every, device=dev, use_dist=use_dist)
+    ring = c3dist.SlabRing(B, b_pad, (Dm, Dm), args.gather_every, device=dev, use_dist=use_dist and args.exchange == "gather")
     G = ring.G
+
+    goal_mode = args.exchange == "goal"
+    if goal_mode and wl.lindblad:
+        raise SystemExit("--exchange goal: unitary configurations only")
+    if goal_mode:
+        from c3_amd import fidelities
+
+        comp_index = list(range(len(wl.dims)))
+        L = 2 ** len(wl.dims)
+        ideal = torch.eye(L, dtype=torch.complex128, device=dev)
+        goal_buf = torch.zeros(2, dtype=torch.float64, device=dev)  # {sum of infidelities, samples}
+        goal_last = [None]
 
     def compute(out):
         if bp is not None:
             bp.run(out=out[:B])
+        if goal_mode:
+            # the optimiser loop of SURVEY 8e/8f-1: B infidelities per rank instead of B propagators, one all-reduce
+            # of the goal per step (optimalcontrol_robust.py:49-70 averages them) -- no gather at all
+            if bp is not None:
+                infid = fidelities.unitary_infid(ideal, out[:B], comp_index, list(wl.dims))
+                goal_buf[0] = infid.sum()
+                goal_buf[1] = float(B)
+            else:
+                goal_buf.zero_()
+            if use_dist:
+                dist.all_reduce(goal_buf, op=dist.ReduceOp.SUM)
+            goal_last[0] = goal_buf
 
     lib = _lib.load()
     # the communicator and every message size of the run are set up before anything is timed
@@ -212,50 +246,71 @@ def main():
 
     err = None
     nchk = 0
-    if args.check and bp is not None:
+    if args.check:
         from oracle import c3_oracle
 
-        # a spread of samples of this rank's shard against the oracle (bounded by the oracle's cost)
-        cost = wl.N * (Dm / 9.0) ** 3
-        nchk = int(min(B, max(2, min(32, 2.5e5 / cost))))
-        idx = np.unique(np.linspace(0, B - 1, nchk).astype(int))
-        U = bp.run()
-        torch.cuda.synchronize()
-        ref = c3_oracle.propagate_batch(wl.h0, wl.hks, wl.signals[idx], wl.dt, col_ops=wl.col_ops, lindbladian=wl.lindblad, fr_phase=wl.fr_phase[idx])
-        Uh = U[torch.as_tensor(idx, device=dev)].cpu().numpy()
-        err = float(max(np.linalg.norm(Uh[i] - ref[i]) for i in range(len(idx))))
-        nchk = len(idx)
-        if use_dist:
-            # the slab every rank received from this rank must equal this rank's own result
-            ring.step(compute)
-            ring.drain()
+        # a spread of samples of this rank's shard against the oracle (bounded by the oracle's cost); a rank with an
+        # empty shard (strong scaling of a batch smaller than the world) still takes part in every collective below
+        err = 0.0
+        if bp is not None:
+            cost = wl.N * (Dm / 9.0) ** 3
+            nchk = int(min(B, max(2, min(32, 2.5e5 / cost))))
+            idx = np.unique(np.linspace(0, B - 1, nchk).astype(int))
+            U = bp.run()
             torch.cuda.synchronize()
-            mine = ring.gathered_slab(rank, 0)[:B]
-            assert torch.equal(mine, ring.buf[0][:B]), "all-gather mismatch"
+            ref = c3_oracle.propagate_batch(wl.h0, wl.hks, wl.signals[idx], wl.dt, col_ops=wl.col_ops, lindbladian=wl.lindblad, fr_phase=wl.fr_phase[idx])
+            Uh = U[torch.as_tensor(idx, device=dev)].cpu().numpy()
+            err = float(max(np.linalg.norm(Uh[i] - ref[i]) for i in range(len(idx))))
+            nchk = len(idx)
+        if use_dist:
+            if args.exchange == "gather":
+                # the slab every rank received from this rank must equal this rank's own result
+                ring.step(compute)
+                ring.drain()
+                torch.cuda.synchronize()
+                if bp is not None:
+                    mine = ring.gathered_slab(rank, 0)[:B]
+                    assert torch.equal(mine, ring.buf[0][:B]), "all-gather mismatch"
             e = torch.tensor([err], dtype=torch.float64, device=dev)
             dist.all_reduce(e, op=dist.ReduceOp.MAX)
             err = float(e.item())
+            n_ = torch.tensor([float(nchk)], dtype=torch.float64, device=dev)
+            dist.all_reduce(n_, op=dist.ReduceOp.SUM)
+            nchk = int(n_.item())
 
     if rank == 0:
         total_props = B_glob * args.steps
         value = total_props / elapsed
         f_prop = algorithmic_flops_per_prop(wl)
-        achieved = f_prop * B / (device_ms_per_step * 1e-3) / 1e12
-        traffic = issued = issued_frac = None
+        t_step = device_ms_per_step * 1e-3
+        achieved_alg = f_prop * B / t_step / 1e12
+        # What the hardware did (PMC, profiles/<round>/pmc.json, taken on this bench command by tools/profile_r03.sh):
+        #   issued  = MFMA flops (SQ_INSTS_VALU_MFMA_MOPS_F64 x 512) + fp64 VALU flops, all lanes, padding included
+        #   useful  = MFMA flops x the fraction of each MFMA tile that holds matrix data (zero padding excluded) + VALU flops
+        # per sample and slice, so other batch sizes / slice counts of the same configuration are scaled, flagged inexact.
+        traffic = issued = useful = None
+        pmc_exact = False
         pfile = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc.json")
         digest = kernel_sources_digest()
-        if os.path.exists(pfile) and args.slices is None and not args.generic:
+        ent = {}
+        if os.path.exists(pfile) and not args.generic:
             try:
-                prof = json.load(open(pfile))
-                ent = prof.get(f"cfg{args.config}", {})
-                # only for the kernel build and the batch the counters were taken on
-                if ent.get("kernel_sources_digest") == digest and ent.get("batch") == B:
-                    traffic = ent.get("hbm_bytes_per_launch")
-                    issued = ent.get("issued_flop_per_launch")
-                    if issued:
-                        issued_frac = issued / (device_ms_per_step * 1e-3) / 1e12 / PEAK_FP64_TFLOPS
+                ent = json.load(open(pfile)).get(f"cfg{args.config}{'_complex' if args.complex_ops else ''}", {})
             except Exception:
-                traffic = issued = issued_frac = None
+                ent = {}
+        if ent.get("issued_flop_per_launch") and ent.get("batch") and ent.get("slices"):
+            per = 1.0 / (ent["batch"] * ent["slices"]) * (B * wl.N)
+            issued = ent["issued_flop_per_launch"] * per
+            useful = ent.get("useful_flop_per_launch", ent["issued_flop_per_launch"]) * per
+            pmc_exact = ent.get("kernel_sources_digest") == digest and ent["batch"] == B and ent["slices"] == wl.N
+            if pmc_exact:
+                traffic = ent.get("hbm_bytes_per_launch")
+        if useful is not None:
+            achieved = useful / t_step / 1e12
+            frac_source = "useful issued flops (PMC: MFMA flops x tile utilisation + fp64 VALU flops)"
+        else:
+            achieved = min(achieved_alg, PEAK_FP64_TFLOPS)
+            frac_source = "algorithmic flops (no PMC profile for this configuration)"
         out = {
             "metric": "full-gate propagators/s",
             "value": value,
@@ -280,7 +335,8 @@ def main():
                 "baseline_batch": f"{cfg['B']} on {cfg.get('gpus', 1)} GPU(s)",
                 "clock_ramp_ms": args.ramp_ms,
                 "throughput": f"sustained: after a {args.ramp_ms:g} ms untimed clock ramp and {args.warmup} warmup steps",
-                "parallelism": (f"dp{world} ({args.scaling}: batch sharded; one RCCL all-gather of U per {G} steps)" if world > 1 else "single GPU"),
+                "parallelism": ((f"dp{world} ({args.scaling}: batch sharded; one RCCL all-gather of U per {G} steps)" if args.exchange == "gather" else f"dp{world} ({args.scaling}: batch sharded; fused fidelity, one RCCL all-reduce of the goal per step, no gather)") if world > 1 else ("single GPU" if args.exchange == "gather" else "single GPU, fused fidelity per step")),
+                "exchange": args.exchange,
                 "kernel": kernel_name,
             },
             "roofline": {
@@ -289,16 +345,27 @@ def main():
                 "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_TFLOPS,
+                "frac_source": frac_source,
                 "traffic": traffic,
-                "issued_flop_per_launch": issued,
-                "issued_frac": issued_frac,
+                "achieved_algorithmic": achieved_alg,
+                "frac_algorithmic": achieved_alg / PEAK_FP64_TFLOPS,
                 "algorithmic_flop_per_launch": f_prop * B,
-                "kernel": f"chain kernel ({kernel_name})",
-                "kernel_ms": device_ms_per_step,
                 "algorithmic_flop_per_propagator": f_prop,
-                "note": "fp64 compute-bound path. achieved/frac: ALGORITHMIC flops (SURVEY 8d: the reference's complex Pade order per slice + product tree) / device time per step by HIP events over the timed region; a method that needs fewer flops than the reference's can exceed 1. issued_frac: flops the kernel actually issues (PMC: SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 + fp64 VALU) / same time / peak -- quoted only for the kernel build and batch profiled in profiles/" + PROFILE_ROUND + "/pmc.json, else null; traffic = HBM bytes per launch from the same PMC passes, else null",
+                "issued_flop_per_launch": issued,
+                "issued_frac": None if issued is None else issued / t_step / 1e12 / PEAK_FP64_TFLOPS,
+                "useful_flop_per_launch": useful,
+                "mfma_tile_utilisation": ent.get("mfma_tile_utilisation"),
+                "pmc_profile": f"profiles/{PROFILE_ROUND}/pmc.json" if issued is not None else None,
+                "pmc_exact_match": pmc_exact,
+                "pmc_avg_launch_us": ent.get("avg_launch_us") if pmc_exact else None,
+                "kernel": f"chain kernel ({kernel_name})",
+                "device_ms_per_step": device_ms_per_step,
+                "note": "fp64 compute-bound path. frac = USEFUL issued flops / device time per step (HIP events over the timed region, launch gaps included) / dense fp64 peak: flops the kernel really issues (PMC) with the zero padding of its MFMA tiles taken out -- at most 1 by construction. frac_algorithmic = SURVEY 8d's figure (the reference's complex Pade order per slice + product tree) over the same time: a method that needs fewer flops than the reference's (real cos / sin evaluation of real Hamiltonians) can exceed 1 there; it is an algorithm credit, not a hardware one. traffic = HBM-side bytes per launch from the same PMC passes (only for the exact build / batch profiled). pmc_exact_match false: the per-sample-and-slice PMC figures of another build / batch of this configuration were scaled",
             },
         }
+        if goal_mode and goal_last[0] is not None:
+            g = goal_last[0].cpu().numpy()
+            out["goal"] = {"mean_unitary_infidelity_vs_identity": float(g[0] / max(g[1], 1.0)), "samples": int(g[1])}
         if err is not None:
             out["max_fro_err_vs_oracle"] = err
             out["oracle_samples_checked"] = nchk
@@ -389,12 +456,48 @@ def _pool_work(job):
     return time.perf_counter() - t0
 
 
-def cpu_baseline_allcores(cfg_index, wl, budget_s=12.0):
-    """The same oracle process-parallel over samples on ALL host cores, with a persistent worker pool: workers are
-    started and warmed (imports, one sample each) BEFORE the timed map, so pool start-up is excluded."""
+def effective_cores():
+    """(usable hardware threads, how that was determined): the scheduler affinity mask and the cgroup CPU quota of the
+    lease, not os.cpu_count() (a container may see 256 threads and be allowed a handful)."""
+    n = os.cpu_count() or 1
+    how = [f"os.cpu_count()={n}"]
+    try:
+        aff = len(os.sched_getaffinity(0))
+        how.append(f"sched_getaffinity={aff}")
+        n = min(n, aff)
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    q = float(txt[0]) / float(txt[1])
+                    how.append(f"cgroup cpu.max={q:.1f}")
+                    n = max(1, min(n, int(q + 0.999)))
+                else:
+                    how.append("cgroup cpu.max=max")
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    how.append(f"cgroup cfs quota={q / per:.1f}")
+                    n = max(1, min(n, int(q / per + 0.999)))
+            break
+        except Exception:
+            continue
+    return n, ", ".join(how)
+
+
+def cpu_baseline_allcores(cfg_index, wl, budget_s=2.0):
+    """The same oracle process-parallel over samples, with a persistent worker pool (workers started and warmed --
+    imports, one sample each -- BEFORE anything is timed).  The worker count is swept in powers of two up to the usable
+    hardware threads and every rate is reported: `value` is the best of the sweep and `cores` the worker count that gave
+    it, so a box whose lease cannot feed all its threads (memory bandwidth, SMT, cgroup limits) does not quote a
+    nominal core count it does not scale to."""
     import multiprocessing as mp
 
-    cores = os.cpu_count() or 1
+    cores, how = effective_cores()
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -404,20 +507,33 @@ def cpu_baseline_allcores(cfg_index, wl, budget_s=12.0):
     except Exception:
         pass
     ctx = mp.get_context("spawn")  # the parent holds a HIP context: no fork
+    sweep = {}
     with ctx.Pool(cores, initializer=_pool_init) as pool:
         warm = pool.map(_pool_work, [(cfg_index, wl.N, 0, 1)] * cores)  # untimed: start-up + one sample per worker
-        t1 = sorted(warm)[len(warm) // 2]
+        t1 = min(warm)
         per = int(max(1, min(64, round(budget_s / max(t1, 1e-3)))))
-        t0 = time.perf_counter()
-        pool.map(_pool_work, [(cfg_index, wl.N, i * per, per) for i in range(cores)], chunksize=1)
-        wall = time.perf_counter() - t0
+        w = 1
+        counts = []
+        while w < cores:
+            counts.append(w)
+            w *= 2
+        counts.append(cores)
+        for w in counts:
+            t0 = time.perf_counter()
+            pool.map(_pool_work, [(cfg_index, wl.N, i * per, per) for i in range(w)], chunksize=1)
+            sweep[w] = w * per / (time.perf_counter() - t0)
+    best = max(sweep, key=sweep.get)
     return {
-        "value": cores * per / wall,
+        "value": sweep[best],
         "unit": "propagators/s",
-        "cores": cores,
+        "cores": best,
+        "usable_hardware_threads": cores,
+        "how_counted": how,
         "kind": "port",
         "cpu_model": model,
-        "sample": f"{cores * per} samples of {wl.name.rsplit(' B=', 1)[0]} ({per} per worker), numpy oracle, one single-threaded process per hardware thread, persistent pool (start-up and a warm-up sample excluded)",
+        "rate_by_workers": {str(k): v for k, v in sweep.items()},
+        "scaling_1_to_8_workers": (sweep.get(8, 0.0) / sweep[1]) if 8 in sweep else None,
+        "sample": f"{per} samples of {wl.name.rsplit(' B=', 1)[0]} per worker, numpy oracle, one single-threaded process per worker, persistent pool (start-up and a warm-up sample excluded), worker counts {counts}; value = the best rate of the sweep",
     }
 
 

@@ -35,6 +35,8 @@ SIGNATURES = {
     "c3p_last_error": (C.c_char_p, []),
     "c3p_last_kernel": (_i, []),
     "c3p_set_profiling": (_i, [_i]),
+    "c3p_reserve": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "c3p_workspace_generation": (C.c_long, []),
     "c3p_last_kernel_ms": (_d, []),
     "c3p_shutdown": (None, []),
     "c3p_pwc_unitary": (_i, [_vp, _i64, _vp, _i64, _vp, _d, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -26,7 +26,8 @@ namespace {
 
 thread_local std::string g_err;
 thread_local int g_last_kernel = C3P_KERNEL_NONE;
-std::atomic<int> g_profiling{0};  // process-wide switch; the event pairs it arms are per device
+thread_local hipStream_t g_call_stream = nullptr;  // stream of the call in flight (capture check on workspace growth)
+thread_local bool g_dry = false;  // c3p_reserve: run the planning and size the workspace, launch nothing
 
 int fail(const char* fmt, ...) {
   char buf[512];
@@ -44,6 +45,11 @@ int fail(const char* fmt, ...) {
     if (e__ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e__)); \
   } while (0)
 
+#define LAUNCH_TRY(expr) \
+  do {                   \
+    if (!g_dry) HIP_TRY(expr); \
+  } while (0)
+
 // Per-device workspace slots, grown lazily, freed by c3p_shutdown().
 enum Slot { SL_SEG_A = 0, SL_SEG_B, SL_SCRATCH, SL_CLP, SL_TABLES, SL_COUNTERS, SL_IN0, SL_IN1, SL_IN2, SL_IN3, SL_IN4, SL_OUT0, SL_OUT1, SL_COUNT };
 
@@ -53,6 +59,8 @@ struct DeviceWs {
   size_t cap[SL_COUNT] = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_valid = false;
+  std::atomic<int> profiling{0};  // per device, like the event pair it arms (c3p_set_profiling acts on the current device)
+  std::atomic<long> generation{0};  // bumped whenever a slot is (re)allocated: steady state = constant
   // The workspace (segment products, tables, arrival counters, arena) is ONE set per device and calls are asynchronous:
   // a call on another stream than the previous one first makes its stream wait for the event recorded at the end of that
   // call, so two streams never run kernels on the shared workspace at the same time (calls on one stream are ordered
@@ -85,6 +93,11 @@ struct WsLock {
     if (!w) return;
     w->mu.lock();
     locked = true;
+    g_call_stream = stream;
+    // a capturing stream takes no dependency on work outside its graph: the caller orders other streams before the capture
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) order = false;
+    (void)hipGetLastError();
     // The workspace is shared by the calls of a device: a call on ANOTHER stream than the previous one first waits for
     // everything enqueued on that stream so far.  The event is recorded lazily, here, on the previous stream (enqueue order
     // is fixed by the mutex), so the common one-stream caller pays no event per call (a marker packet between every two
@@ -114,6 +127,11 @@ struct WsLock {
 int ws_get(DeviceWs* w, Slot s, size_t bytes, void** out) {
   if (bytes == 0) bytes = 16;
   if (w->cap[s] < bytes) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (g_call_stream && hipStreamIsCapturing(g_call_stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+      return fail("workspace growth during stream capture: run the call once outside the capture, or c3p_reserve() its shape first");
+    (void)hipGetLastError();
+    ++w->generation;
     if (w->ptr[s]) {
       HIP_TRY(hipDeviceSynchronize());
       HIP_TRY(hipFree(w->ptr[s]));
@@ -162,7 +180,7 @@ ChainPlan plan_generic(int B, int N, int Dm) {
 // `profile` = false keeps the timing event pair (and c3p_last_kernel) on the caller's main kernel.
 int run_chain_generic(DeviceWs* w, ChainArgs base, cplx* U_out, hipStream_t st, bool profile = true) {
   const int Dm = base.Dm;
-  profile = profile && g_profiling;
+  profile = profile && w->profiling && !g_dry;
   // GIVEN mode callers may hand over matrices that live in one of the two segment slots (the segment products of the
   // big-D kernels): this launch must not write its own segment products into the buffer it is reading (and ws_get
   // must not re-allocate it), so it starts on the OTHER slot.
@@ -197,7 +215,7 @@ int run_chain_generic(DeviceWs* w, ChainArgs base, cplx* U_out, hipStream_t st, 
     }
     HIP_TRY(hipEventRecord(w->ev0, st));
   }
-  HIP_TRY(c3p_launch_chain_generic(base, p.global_scratch, st));
+  LAUNCH_TRY(c3p_launch_chain_generic(base, p.global_scratch, st));
   if (profile) {
     HIP_TRY(hipEventRecord(w->ev1, st));
     w->ev_valid = true;
@@ -236,7 +254,7 @@ int run_chain_generic(DeviceWs* w, ChainArgs base, cplx* U_out, hipStream_t st, 
       if (ws_get(w, SL_SCRATCH, (size_t)c.B * c.S * c.scratch_stride * sizeof(cplx), &v)) return -1;
       c.scratch = (cplx*)v;
     }
-    HIP_TRY(c3p_launch_chain_generic(c, global, st));
+    LAUNCH_TRY(c3p_launch_chain_generic(c, global, st));
     cur = c.seg_out;
     count = c.S;
     next_slot = (next_slot == SL_SEG_B) ? SL_SEG_A : SL_SEG_B;
@@ -251,7 +269,7 @@ int run_chain_generic(DeviceWs* w, ChainArgs base, cplx* U_out, hipStream_t st, 
 const int kSmallDLimit = 12;  // D = 11, 12 spill ~100 registers but still beat the generic kernel
 
 int record_start(DeviceWs* w, hipStream_t st) {
-  if (!g_profiling) return 0;
+  if (!w->profiling || g_dry) return 0;
   if (!w->ev0) {
     HIP_TRY(hipEventCreate(&w->ev0));
     HIP_TRY(hipEventCreate(&w->ev1));
@@ -260,7 +278,7 @@ int record_start(DeviceWs* w, hipStream_t st) {
   return 0;
 }
 int record_stop(DeviceWs* w, hipStream_t st) {
-  if (!g_profiling) return 0;
+  if (!w->profiling || g_dry) return 0;
   HIP_TRY(hipEventRecord(w->ev1, st));
   w->ev_valid = true;
   return 0;
@@ -290,7 +308,7 @@ int combine_smalld(DeviceWs* w, const cplx* cur, int B, int count, int Dm, int r
       c.seg_out = (cplx*)v;
     }
     c.Lmax = (count + c.S - 1) / c.S;
-    HIP_TRY(c3p_launch_smalld_chain(c, st));
+    LAUNCH_TRY(c3p_launch_smalld_chain(c, st));
     if (c.seg_out == U_out) break;
     cur = c.seg_out;
     count = c.S;
@@ -372,7 +390,7 @@ int run_pwc_smalld(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const 
     p.Dh = D;
     p.lindblad = lindblad;
     p.tables = (double*)v;
-    HIP_TRY(c3p_launch_smalld_prep(p, Dm, nsamp, st));
+    LAUNCH_TRY(c3p_launch_smalld_prep(p, Dm, nsamp, st));
     a.tables = (const double*)v;
   }
   a.tab_per_sample = per_sample ? 1 : 0;
@@ -401,7 +419,7 @@ int run_pwc_smalld(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const 
   }
   g_last_kernel = C3P_KERNEL_SMALLD;
   if (record_start(w, st)) return -1;
-  HIP_TRY(c3p_launch_smalld_chain(a, st));
+  LAUNCH_TRY(c3p_launch_smalld_chain(a, st));
   if (record_stop(w, st)) return -1;
   if (S > 1 && !fuse) return combine_smalld(w, a.seg_out, B, S, Dm, 0, fr_phase, U_out, st);
   return 0;
@@ -444,7 +462,7 @@ int run_vjp_midd(DeviceWs* w, GradArgs& G, hipStream_t st) {
   p.rows = 16 * nig;
   p.W = wd;
   p.tables = (double*)v;
-  HIP_TRY(c3p_launch_midd_prep(p, nsamp, st));
+  LAUNCH_TRY(c3p_launch_midd_prep(p, nsamp, st));
   const size_t segb = (size_t)B * S * D * D * sizeof(cplx);
   void *sv, *mv;
   if (ws_get(w, SL_SEG_A, segb, &sv)) return -1;
@@ -461,7 +479,7 @@ int run_vjp_midd(DeviceWs* w, GradArgs& G, hipStream_t st) {
   a.Lmax = (int)((N + S - 1) / S);
   a.mode = C3P_MODE_UNITARY;
   a.seg_out = (cplx*)sv;
-  HIP_TRY(c3p_launch_midd_chain(a, st));
+  LAUNCH_TRY(c3p_launch_midd_chain(a, st));
   G.S = (int)S;
   G.seg = (cplx*)sv;
   G.Mb = (cplx*)mv;
@@ -473,7 +491,7 @@ int run_vjp_midd(DeviceWs* w, GradArgs& G, hipStream_t st) {
     if (ws_get(w, SL_SCRATCH, (size_t)B * G.S * G.scratch_stride * sizeof(cplx), &gv)) return -1;
     G.scratch = (cplx*)gv;
   }
-  HIP_TRY(c3p_launch_grad_scan(G, scan_global, st));
+  LAUNCH_TRY(c3p_launch_grad_scan(G, scan_global, st));
   MidGradArgs g = {};
   g.tables = p.tables;
   g.tab_per_sample = a.tab_per_sample;
@@ -487,7 +505,7 @@ int run_vjp_midd(DeviceWs* w, GradArgs& G, hipStream_t st) {
   g.Dm = D;
   g.S = (int)S;
   g.Lmax = a.Lmax;
-  HIP_TRY(c3p_launch_midd_grad(g, st));
+  LAUNCH_TRY(c3p_launch_midd_grad(g, st));
   return 0;
 }
 
@@ -539,7 +557,7 @@ int run_xg_midd(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, dou
   const long S = pick_segments_rounds(B, N, 256L * wg_per_cu, smax, D <= 16 ? 400 : 100);
   void* mv;
   if (ws_get(w, SL_TABLES, (size_t)B * N * 4 * sizeof(double), &mv)) return -1;
-  HIP_TRY(c3p_launch_hmeta(hs, hs_bstride, (long)B * N, N, D, coef_r, coef_i, (double*)mv, st));
+  LAUNCH_TRY(c3p_launch_hmeta(hs, hs_bstride, (long)B * N, N, D, coef_r, coef_i, (double*)mv, st));
   MidArgs a = {};
   a.hs = hs;
   a.hs_bstride = hs_bstride;
@@ -566,7 +584,7 @@ int run_xg_midd(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, dou
   }
   g_last_kernel = C3P_KERNEL_MFMA;
   if (record_start(w, st)) return -1;
-  HIP_TRY(c3p_launch_midd_chain(a, st));
+  LAUNCH_TRY(c3p_launch_midd_chain(a, st));
   if (record_stop(w, st)) return -1;
   if (S > 1) return combine_midd(w, a.seg_out, B, (int)S, D, 0, fr_phase, U_out, st);
   return 0;
@@ -580,7 +598,7 @@ int run_xg_smalld(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, d
   if (S < 0) return 1;
   void* mv;
   if (ws_get(w, SL_TABLES, (size_t)B * N * 4 * sizeof(double), &mv)) return -1;
-  HIP_TRY(c3p_launch_hmeta(hs, hs_bstride, (long)B * N, N, D, coef_r, coef_i, (double*)mv, st));
+  LAUNCH_TRY(c3p_launch_hmeta(hs, hs_bstride, (long)B * N, N, D, coef_r, coef_i, (double*)mv, st));
   SmallArgs a = {};
   a.hs = hs;
   a.hs_bstride = hs_bstride;
@@ -614,7 +632,7 @@ int run_xg_smalld(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, d
   }
   g_last_kernel = C3P_KERNEL_SMALLD;
   if (record_start(w, st)) return -1;
-  HIP_TRY(c3p_launch_smalld_chain(a, st));
+  LAUNCH_TRY(c3p_launch_smalld_chain(a, st));
   if (record_stop(w, st)) return -1;
   if (S > 1 && !fuse) return combine_smalld(w, a.seg_out, B, S, D, 0, fr_phase, U_out, st);
   return 0;
@@ -639,7 +657,7 @@ int run_vjp_smalld(DeviceWs* w, GradArgs& G, hipStream_t st) {
   p.K = K;
   p.Dh = D;
   p.tables = (double*)v;
-  HIP_TRY(c3p_launch_smalld_prep(p, D, nsamp, st));
+  LAUNCH_TRY(c3p_launch_smalld_prep(p, D, nsamp, st));
   const size_t segb = (size_t)B * S * D * D * sizeof(cplx);
   void *sv, *mv;
   if (ws_get(w, SL_SEG_A, segb, &sv)) return -1;
@@ -656,11 +674,11 @@ int run_vjp_smalld(DeviceWs* w, GradArgs& G, hipStream_t st) {
   a.Lmax = (N + S - 1) / S;
   a.mode = C3P_MODE_UNITARY;
   a.seg_out = (cplx*)sv;
-  HIP_TRY(c3p_launch_smalld_chain(a, st));
+  LAUNCH_TRY(c3p_launch_smalld_chain(a, st));
   G.S = S;
   G.seg = (cplx*)sv;
   G.Mb = (cplx*)mv;
-  HIP_TRY(c3p_launch_grad_scan(G, false, st));
+  LAUNCH_TRY(c3p_launch_grad_scan(G, false, st));
   SmallGradArgs g = {};
   g.tables = p.tables;
   g.tab_per_sample = a.tab_per_sample;
@@ -674,7 +692,7 @@ int run_vjp_smalld(DeviceWs* w, GradArgs& G, hipStream_t st) {
   g.Dm = D;
   g.S = S;
   g.Lmax = a.Lmax;
-  HIP_TRY(c3p_launch_smalld_grad(g, st));
+  LAUNCH_TRY(c3p_launch_smalld_grad(g, st));
   return 0;
 }
 
@@ -704,7 +722,7 @@ int combine_midd(DeviceWs* w, const cplx* cur, int B, int count, int Dm, int rig
       c.seg_out = (cplx*)v;
     }
     c.Lmax = (count + c.S - 1) / c.S;
-    HIP_TRY(c3p_launch_midd_chain(c, st));
+    LAUNCH_TRY(c3p_launch_midd_chain(c, st));
     if (c.seg_out == U_out) break;
     cur = c.seg_out;
     count = c.S;
@@ -744,7 +762,7 @@ int run_pwc_midd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   p.rows = 16 * nig;
   p.W = wd;
   p.tables = (double*)v;
-  HIP_TRY(c3p_launch_midd_prep(p, nsamp, st));
+  LAUNCH_TRY(c3p_launch_midd_prep(p, nsamp, st));
   MidArgs a = {};
   a.tables = (const double*)v;
   a.tab_per_sample = per_sample ? 1 : 0;
@@ -769,7 +787,7 @@ int run_pwc_midd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   }
   g_last_kernel = C3P_KERNEL_MFMA;
   if (record_start(w, st)) return -1;
-  HIP_TRY(c3p_launch_midd_chain(a, st));
+  LAUNCH_TRY(c3p_launch_midd_chain(a, st));
   if (record_stop(w, st)) return -1;
   if (S > 1) return combine_midd(w, a.seg_out, B, (int)S, Dm, 0, fr_phase, U_out, st);
   return 0;
@@ -809,7 +827,7 @@ int run_pwc_bigd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   p.tile_nig = nig;
   p.tile_nj = nj;
   p.tables = (double*)v;
-  HIP_TRY(c3p_launch_midd_prep(p, nsamp, st));
+  LAUNCH_TRY(c3p_launch_midd_prep(p, nsamp, st));
   void* av;
   if (ws_get(w, SL_SCRATCH, c3p_bigd_arena_doubles(Dm) * sizeof(double), &av)) return -1;
   MidArgs a = {};
@@ -833,9 +851,9 @@ int run_pwc_bigd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   a.seg_out = seg;
   g_last_kernel = C3P_KERNEL_MFMA;
   if (record_start(w, st)) return -1;
-  HIP_TRY(c3p_launch_bigd_chain(a, (double*)av, st));
+  LAUNCH_TRY(c3p_launch_bigd_chain(a, (double*)av, st));
   if (record_stop(w, st)) return -1;
-  if (S == 1 && fr_phase) HIP_TRY(c3p_launch_rowphase(U_out, fr_phase, B, Dm, st));
+  if (S == 1 && fr_phase) LAUNCH_TRY(c3p_launch_rowphase(U_out, fr_phase, B, Dm, st));
   if (S > 1) {
     // ordered combine of the few segment products with the generic kernel (GIVEN mode)
     ChainArgs c = {};
@@ -882,7 +900,7 @@ int run_pwc_regd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   p.Dm = Dm;
   p.lindblad = lindblad;
   p.tables = (double*)v;
-  HIP_TRY(c3p_launch_regd_prep(p, nsamp, st));
+  LAUNCH_TRY(c3p_launch_regd_prep(p, nsamp, st));
   void* av;
   if (ws_get(w, SL_SCRATCH, c3p_regd_arena_bytes(Dm), &av)) return -1;
   MidArgs a = {};
@@ -906,9 +924,9 @@ int run_pwc_regd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   a.seg_out = seg;
   g_last_kernel = C3P_KERNEL_MFMA;
   if (record_start(w, st)) return -1;
-  HIP_TRY(c3p_launch_regd_chain(a, av, st));
+  LAUNCH_TRY(c3p_launch_regd_chain(a, av, st));
   if (record_stop(w, st)) return -1;
-  if (S == 1 && fr_phase) HIP_TRY(c3p_launch_rowphase(U_out, fr_phase, B, Dm, st));
+  if (S == 1 && fr_phase) LAUNCH_TRY(c3p_launch_rowphase(U_out, fr_phase, B, Dm, st));
   if (S > 1) {
     // ordered combine of the few segment products with the generic kernel (GIVEN mode)
     ChainArgs c = {};
@@ -956,6 +974,7 @@ int run_pwc_tiled(DeviceWs* w, const ChainArgs& a, bool per_slice, cplx* U_out, 
   t.U_out = U_out;
   t.dUs_out = a.dUs_out;
   g_last_kernel = C3P_KERNEL_MFMA;
+  if (g_dry) return 0;  // c3p_reserve: the arena above is all this path owns
   std::string err;
   // many launches per call: the timing pair brackets the whole host-driven slice loop
   if (record_start(w, st)) return -1;
@@ -1058,7 +1077,7 @@ int pwc_common(int lindblad, const void* h0, int64_t h0_bstride, const void* hks
   if (lindblad) {
     void* v;
     if (ws_get(w, SL_CLP, (size_t)Dm * Dm * cs, &v)) return -1;
-    HIP_TRY(c3p_launch_clp((const cplx*)d_col, C, D, (cplx*)v, st));
+    LAUNCH_TRY(c3p_launch_clp((const cplx*)d_col, C, D, (cplx*)v, st));
     a.clp = (const cplx*)v;
   }
   bool done = false;
@@ -1128,8 +1147,28 @@ const char* c3p_last_error(void) { return g_err.c_str(); }
 int c3p_last_kernel(void) { return g_last_kernel; }
 
 int c3p_set_profiling(int enable) {
-  g_profiling = enable ? 1 : 0;
+  DeviceWs* w = ws_for_current_device();
+  if (!w) return fail("no HIP device");
+  w->profiling = enable ? 1 : 0;
   return 0;
+}
+
+long c3p_workspace_generation(void) {
+  DeviceWs* w = ws_for_current_device();
+  return w ? w->generation.load() : -1;
+}
+
+int c3p_reserve(int lindblad, int B, int K, int N, int D, int C, int flags) {
+  if (flags & C3P_HOST_PTRS) return fail("c3p_reserve sizes the device workspace: not for C3P_HOST_PTRS calls");
+  // the planning code of the real call with launches switched off: every slot it would touch is allocated at the size
+  // it would need, so later calls of this shape (and smaller ones) never allocate, free or synchronise
+  static double dummy[4];
+  void* p = dummy;  // never dereferenced: device pointers are only handed to kernels
+  g_dry = true;
+  const int rc = pwc_common(lindblad ? 1 : 0, p, 0, p, 0, (const double*)p, lindblad ? p : nullptr, lindblad ? C : 0, 1.0, B, K, N, D,
+                            flags, nullptr, p, nullptr, nullptr);
+  g_dry = false;
+  return rc;
 }
 
 double c3p_last_kernel_ms(void) {
@@ -1299,7 +1338,7 @@ static int kron_common(const void* A, const void* Bm, int n, int Da, int Db, int
     if (sg.in(which == 0 ? Bm : nullptr, (size_t)n * Db * Db * sizeof(cplx), &d_B)) return -1;
     if (sg.out(out, (size_t)n * Dm * Dm * sizeof(cplx), &d_out)) return -1;
   }
-  HIP_TRY(c3p_launch_kron((const cplx*)d_A, (const cplx*)d_B, n, Da, Db, which, (cplx*)d_out, st));
+  LAUNCH_TRY(c3p_launch_kron((const cplx*)d_A, (const cplx*)d_B, n, Da, Db, which, (cplx*)d_out, st));
   if (flags & C3P_HOST_PTRS) return sg.finish();
   return 0;
 }
@@ -1372,7 +1411,7 @@ int c3p_ode_solve(const void* h0, const void* hks, const double* signals, const 
     if (C > 0 && ws_get(w, SL_TABLES, c3p_ode_row_aux_bytes(D, C), &aux)) return -1;
     g_last_kernel = C3P_KERNEL_ODE_ROW;
     if (record_start(w, st)) return -1;
-    HIP_TRY(c3p_launch_ode_row(a, aux, st));
+    LAUNCH_TRY(c3p_launch_ode_row(a, aux, st));
     if (record_stop(w, st)) return -1;
     if (flags & C3P_HOST_PTRS) return sg.finish();
     return 0;
@@ -1386,7 +1425,7 @@ int c3p_ode_solve(const void* h0, const void* hks, const double* signals, const 
     a.scratch = (cplx*)v;
     a.scratch_stride = (long)elems;
   }
-  HIP_TRY(c3p_launch_ode(a, global, st));
+  LAUNCH_TRY(c3p_launch_ode(a, global, st));
   if (flags & C3P_HOST_PTRS) return sg.finish();
   return 0;
 }
@@ -1454,13 +1493,13 @@ int c3p_rk4_unitary(const void* h0, const void* hks, const double* signals, cons
     g_last_kernel = C3P_KERNEL_ODE_ROW;
     a.want_all = 0;
     a.states = (cplx*)d_U;
-    HIP_TRY(c3p_launch_ode_row(a, nullptr, st));
+    LAUNCH_TRY(c3p_launch_ode_row(a, nullptr, st));
     if (d_dUs) {
       a.want_all = 1;
       a.reset_each_step = 1;
       a.transpose_out = 1;
       a.states = (cplx*)d_dUs;
-      HIP_TRY(c3p_launch_ode_row(a, nullptr, st));
+      LAUNCH_TRY(c3p_launch_ode_row(a, nullptr, st));
     }
     if (flags & C3P_HOST_PTRS) return sg.finish();
     return 0;
@@ -1476,13 +1515,13 @@ int c3p_rk4_unitary(const void* h0, const void* hks, const double* signals, cons
   }
   a.want_all = 0;
   a.states = (cplx*)d_U;
-  HIP_TRY(c3p_launch_ode(a, global, st));
+  LAUNCH_TRY(c3p_launch_ode(a, global, st));
   if (d_dUs) {
     a.want_all = 1;
     a.reset_each_step = 1;
     a.transpose_out = 1;
     a.states = (cplx*)d_dUs;
-    HIP_TRY(c3p_launch_ode(a, global, st));
+    LAUNCH_TRY(c3p_launch_ode(a, global, st));
   }
   if (flags & C3P_HOST_PTRS) return sg.finish();
   return 0;
@@ -1510,7 +1549,7 @@ int c3p_gate_overlap(const void* U, int B, int D, const int32_t* comp_rows, int 
     if (sg.in(ideal, (size_t)L * L * cs, &d_G)) return -1;
     if (sg.out(overlap_out, (size_t)B * cs, &d_out)) return -1;
   }
-  HIP_TRY(c3p_launch_overlap((const cplx*)d_U, B, D, (const int*)d_rows, L, (const cplx*)d_G, (cplx*)d_out, st));
+  LAUNCH_TRY(c3p_launch_overlap((const cplx*)d_U, B, D, (const int*)d_rows, L, (const cplx*)d_G, (cplx*)d_out, st));
   if (flags & C3P_HOST_PTRS) return sg.finish();
   return 0;
 }
@@ -1561,7 +1600,7 @@ int c3p_synth_signals(const double* env_params, const int32_t* env_shapes, const
   A.N = N;
   A.iq = (double*)d_iq;
   A.signals = (double*)d_sig;
-  HIP_TRY(c3p_launch_synth(A, st));
+  LAUNCH_TRY(c3p_launch_synth(A, st));
   if (flags & C3P_HOST_PTRS) return sg.finish();
   return 0;
 }
@@ -1655,9 +1694,9 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
       A.scratch = (cplx*)v;
     }
     g_last_kernel = global ? C3P_KERNEL_GENERIC_GLOBAL : C3P_KERNEL_GENERIC_LDS;
-    HIP_TRY(c3p_launch_grad_seg(A, global, st));
-    HIP_TRY(c3p_launch_grad_scan(A, global, st));
-    HIP_TRY(c3p_launch_grad_bwd(A, global, st));
+    LAUNCH_TRY(c3p_launch_grad_seg(A, global, st));
+    LAUNCH_TRY(c3p_launch_grad_scan(A, global, st));
+    LAUNCH_TRY(c3p_launch_grad_bwd(A, global, st));
   }
   if (record_stop(w, st)) return -1;
   if (flags & C3P_HOST_PTRS) return sg.finish();
@@ -1713,7 +1752,7 @@ int c3p_synth_signals_vjp(const double* env_params, const int32_t* env_shapes, c
   A.N = N;
   A.iq = (double*)v;
   A.signals = nullptr;
-  HIP_TRY(c3p_launch_synth_vjp(A, (const double*)d_gs, A.iq + part, A.iq + 2 * part, (double*)d_ge, (double*)d_gc, st));
+  LAUNCH_TRY(c3p_launch_synth_vjp(A, (const double*)d_gs, A.iq + part, A.iq + 2 * part, (double*)d_ge, (double*)d_gc, st));
   if (flags & C3P_HOST_PTRS) return sg.finish();
   return 0;
 }

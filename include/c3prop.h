@@ -80,9 +80,20 @@ int c3p_last_kernel(void);
  * with hipEvents on the stream it was launched on; valid after that stream has
  * been synchronised.  Only recorded when profiling was enabled with
  * c3p_set_profiling(1).  Returns < 0 if nothing was recorded. */
-int c3p_set_profiling(int enable);
+int c3p_set_profiling(int enable); /* per device: acts on the current device's workspace */
 double c3p_last_kernel_ms(void);
 void c3p_shutdown(void);
+
+/* Workspace management.  The library owns one workspace per device (segment products, generator tables, arenas), grown
+ * lazily by the first call that needs more -- which synchronises the device, frees and allocates (not legal inside a
+ * stream capture, and a latency cliff in a serving loop).  c3p_reserve sizes it for one call shape ahead of time
+ * (arguments as c3p_pwc_unitary / c3p_pwc_lindblad; device-pointer calls only): afterwards calls of that shape, or of
+ * any shape that needs no more, neither allocate nor synchronise, and ONE c3p_pwc_* call can be captured into a hipGraph
+ * (a call whose workspace would have to grow during a capture fails with an error instead).
+ * c3p_workspace_generation counts (re)allocations of the current device's workspace: constant = steady state.
+ * Reference analogue: none (TensorFlow owns its allocator; nothing on this path is retained between calls). */
+int c3p_reserve(int lindblad, int B, int K, int N, int D, int C, int flags);
+long c3p_workspace_generation(void);
 
 /* U[b] = diag(exp(i fr_phase[b])) * prod_n exp(-i (h0 + sum_k signals[b,k,n] hks[k]) dt)
  *

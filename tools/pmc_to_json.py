@@ -1,4 +1,4 @@
-"""Fold the rocprofv3 passes of tools/profile_r02.sh into one JSON entry for profiles/r02/pmc.json: per-launch
+"""Fold the rocprofv3 passes of tools/profile_r03.sh into one JSON entry for profiles/r03/pmc.json: per-launch
 averages of the DOMINANT kernel (largest total time in the kernel trace), HBM bytes with the gfx950 FETCH_SIZE correction
 of MI355X_MICROARCH.md (FETCH_SIZE counts half the bytes of wide reads: x2), issued flops from the instruction counters.
 
@@ -7,6 +7,28 @@ of MI355X_MICROARCH.md (FETCH_SIZE counts half the bytes of wide reads: x2), iss
 import collections, csv, glob, json, os, sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def tile_utilisation(Dm, kernel):
+    """Fraction of every issued MFMA tile that multiplies matrix data (the rest is zero padding), from the tile geometry
+    of the kernel class that ran:
+      smalld (Dm <= 12): 4 x 4 blocks, rows and columns padded to 4 ceil(Dm / 4); the K dimension is exact when
+                         Dm = 1 (mod 4) (rank-1 tail on the vector unit), otherwise padded as well;
+      midd (13..40):     16-row units and 4-column blocks, K in steps of 4 (real instance, Dm = 25..28: columns padded to 32);
+      regd (49/65/81):   the 16 n x 16 n core tiles exactly, the border runs on the vector unit: 1.0;
+      others:            1.0 (not corrected)."""
+    if Dm <= 12:
+        p = 4 * ((Dm + 3) // 4)
+        kk = 1.0 if Dm % 4 == 1 else Dm / p
+        return (Dm / p) ** 2 * kk, f"small-D kernel: ({Dm}/{p})^2 rows x columns" + ("" if Dm % 4 == 1 else f" x {Dm}/{p} in K")
+    if Dm <= 40:
+        rows = 16 * ((Dm + 15) // 16)
+        cols = 4 * ((Dm + 3) // 4)
+        if "true" in kernel.split("midd_chain_kernel")[-1][:40] and 25 <= Dm <= 28:
+            cols = 32
+        kp = 4 * ((Dm + 3) // 4)
+        return (Dm / rows) * (Dm / cols) * (Dm / kp), f"mid-D kernel: {Dm}/{rows} rows x {Dm}/{cols} columns x {Dm}/{kp} in K"
+    return 1.0, "no padded MFMA work (register-resident core / not corrected)"
 
 
 def main():
@@ -36,11 +58,16 @@ def main():
 
     c = workloads.CONFIGS[cfg]
     _, lo, hi, _ = bench.plan_batch(c, "weak", None, 1, 0)
+    D = 1
+    for d in c["dims"]:
+        D *= d
+    Dm = D * D if c["lindblad"] else D
     out = {
         "kernel": dom[:160],
         "launches_in_trace": len(dur[dom]),
         "avg_launch_us": sum(dur[dom]) / len(dur[dom]) / 1e3,
         "batch": hi - lo,
+        "slices": c["N"],
         "kernel_sources_digest": bench.kernel_sources_digest(),
         "resources": meta,
         "counters_per_launch": avg,
@@ -58,6 +85,10 @@ def main():
         out["issued_mfma_flop_per_launch"] = mfma_flop
         out["issued_valu_f64_flop_per_launch"] = valu_flop
         out["issued_flop_per_launch"] = mfma_flop + valu_flop
+        util, why = tile_utilisation(Dm, dom)
+        out["mfma_tile_utilisation"] = util
+        out["mfma_tile_utilisation_note"] = why
+        out["useful_flop_per_launch"] = mfma_flop * util + valu_flop
     if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "SQ_BUSY_CYCLES" in avg:
         out["mfma_busy_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch cycles); launch cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs: it reproduces launch time x 2.4 GHz)"
         if avg.get("GRBM_GUI_ACTIVE"):
