@@ -1416,6 +1416,15 @@ int c3p_ode_solve(const void* h0, const void* hks, const double* signals, const 
     if (flags & C3P_HOST_PTRS) return sg.finish();
     return 0;
   }
+  if (c3p_ode_rowq_supported(a)) {
+    // 17 <= D <= 48 vector states: several DPP rows per sample, operators in LDS (c3p_ode_rowq.hip)
+    g_last_kernel = C3P_KERNEL_ODE_ROW;
+    if (record_start(w, st)) return -1;
+    LAUNCH_TRY(c3p_launch_ode_rowq(a, st));
+    if (record_stop(w, st)) return -1;
+    if (flags & C3P_HOST_PTRS) return sg.finish();
+    return 0;
+  }
   g_last_kernel = C3P_KERNEL_ODE_WG;
   const size_t elems = c3p_ode_elems(D, M, C);
   const bool global = elems * cs > (size_t)(150 * 1024);
@@ -1500,6 +1509,21 @@ int c3p_rk4_unitary(const void* h0, const void* hks, const double* signals, cons
       a.transpose_out = 1;
       a.states = (cplx*)d_dUs;
       LAUNCH_TRY(c3p_launch_ode_row(a, nullptr, st));
+    }
+    if (flags & C3P_HOST_PTRS) return sg.finish();
+    return 0;
+  }
+  if (c3p_ode_rowq_supported(a)) {
+    g_last_kernel = C3P_KERNEL_ODE_ROW;
+    a.want_all = 0;
+    a.states = (cplx*)d_U;
+    LAUNCH_TRY(c3p_launch_ode_rowq(a, st));
+    if (d_dUs) {
+      a.want_all = 1;
+      a.reset_each_step = 1;
+      a.transpose_out = 1;
+      a.states = (cplx*)d_dUs;
+      LAUNCH_TRY(c3p_launch_ode_rowq(a, st));
     }
     if (flags & C3P_HOST_PTRS) return sg.finish();
     return 0;

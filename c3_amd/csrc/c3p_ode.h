@@ -42,3 +42,8 @@ hipError_t c3p_launch_ode(const OdeArgs& A, bool global_scratch, hipStream_t st)
 bool c3p_ode_row_supported(const OdeArgs& A);
 size_t c3p_ode_row_aux_bytes(int D, int C);
 hipError_t c3p_launch_ode_row(const OdeArgs& A, void* aux, hipStream_t st);
+
+// Lane-row vector-state kernel for 17 <= D <= 48 (c3p_ode_rowq.hip): operators in LDS, H(t) advanced along the linear
+// pieces of the control amplitudes
+bool c3p_ode_rowq_supported(const OdeArgs& A);
+hipError_t c3p_launch_ode_rowq(const OdeArgs& A, hipStream_t st);

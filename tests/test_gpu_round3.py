@@ -320,3 +320,57 @@ def test_reserve_lindblad_and_profiling_switch(prop):
     assert lib.c3p_workspace_generation() == gen
     ref = o.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt, col_ops=wl.col_ops, lindbladian=True)
     assert fro_max(r["U"].cpu().numpy(), ref) < TOL
+
+
+@pytest.mark.parametrize("D,K", [(17, 1), (20, 2), (24, 3), (27, 3), (28, 2), (32, 4), (33, 1), (36, 3), (41, 2), (48, 2)])
+@pytest.mark.parametrize("real", [False, True])
+def test_ode_rowq_mid_dimensions(prop, D, K, real):
+    """Schroedinger steps at 17 <= D <= 48 (c3p_ode_rowq.hip: several DPP rows per sample, H advanced along the linear
+    pieces of the control amplitudes): every column-group class, all four solvers, trajectory and final state."""
+    from c3_amd import _lib
+
+    B, N = 5, 31
+    h0, hks, sig, ts = _ode_problem(D, K, B, N, real, 31 * D + K)
+    rng = np.random.default_rng(D)
+    psi = rng.normal(size=(B, D, 1)) + 1j * rng.normal(size=(B, D, 1))
+    psi /= np.linalg.norm(psi, axis=1, keepdims=True)
+    for solver in ("rk4", "rk38", "rk5", "tsit5"):
+        out = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], psi, solver, "schrodinger"))
+        assert _lib.last_kernel() == "ode_row"
+        for b in range(B):
+            ref = o.ode_solver_arrays(h0, hks, sig[b], ts, psi[b], solver, "schrodinger")["states"]
+            assert np.abs(out[b] - ref).max() < 1e-11
+    fin = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], psi, "rk4", "schrodinger", final_only=True))
+    ref = np.stack([o.ode_solver_arrays(h0, hks, sig[b], ts, psi[b], "rk4", "schrodinger", final_only=True)["states"] for b in range(B)])
+    assert np.abs(fin - ref).max() < 1e-11
+
+
+def test_ode_rowq_cfg3_long_and_rk4_unitary(prop):
+    """cfg3's operators (D = 27, K = 3) over 300 steps (re-anchoring of H every 14 steps, chunk boundaries), and the
+    rk4_unitary columns (stride-2 sample windows: two linear pieces per step) at D = 20."""
+    import ctypes
+
+    from c3_amd import _lib
+
+    wl = workloads.make_workload(3, B=6, N=300)
+    psi = np.zeros((wl.D, 1), complex)
+    psi[2, 0] = 1.0
+    out = np.asarray(prop.ode_solve_batch(wl.h0, wl.hks, wl.signals, wl.dt, psi, "rk4", "schrodinger"))
+    assert _lib.last_kernel() == "ode_row"
+    for b in (0, 5):
+        ref = o.ode_solver_arrays(wl.h0, wl.hks, wl.signals[b], wl.ts, psi, "rk4", "schrodinger")["states"]
+        assert np.abs(out[b] - ref).max() < 1e-11
+    D, K, B, Ns = 20, 2, 2, 33
+    h0, hks, sig, _ = _ode_problem(D, K, B, Ns, False, 77)
+    lib = _lib.load()
+    U = np.zeros((B, D, D), complex)
+    dUs = np.zeros((B, (Ns - 1) // 2, D, D), complex)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    h0c, hkc, sgc = np.ascontiguousarray(h0), np.ascontiguousarray(hks), np.ascontiguousarray(sig)
+    rc = lib.c3p_rk4_unitary(p(h0c), p(hkc), p(sgc), None, 0, 0.1, B, K, Ns, D, 1, p(U), p(dUs), None)
+    assert rc == 0 and _lib.last_kernel() == "ode_row"
+    for b in range(B):
+        Hs = h0[None] + np.einsum("kn,kij->nij", sig[b], hks)
+        ref = o.rk4_unitary_arrays(Hs, 0.1, D)
+        assert np.abs(U[b] - ref["U"]).max() < 1e-12
+        assert np.abs(dUs[b] - ref["dUs"]).max() < 1e-12

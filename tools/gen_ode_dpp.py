@@ -12,7 +12,7 @@ not look into inline asm, so every block opens with `s_nop 1`.
 """
 import sys
 
-DPS = [2, 3, 4, 6, 9, 12, 16]
+DPS = [2, 3, 4, 6, 8, 9, 12, 16]
 TAIL = "row_mask:0xf bank_mask:0xf"
 
 
