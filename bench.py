@@ -192,15 +192,14 @@ def main():
         if goal_mode:
             # the optimiser loop of SURVEY 8e/8f-1: B infidelities per rank instead of B propagators, one all-reduce
             # of the goal per step (optimalcontrol_robust.py:49-70 averages them) -- no gather at all
+            g = goal_buf
             if bp is not None:
-                infid = fidelities.unitary_infid(ideal, out[:B], comp_index, list(wl.dims))
-                goal_buf[0] = infid.sum()
-                goal_buf[1] = float(B)
+                g = fidelities.infid_sum(ideal, out[:B], comp_index, list(wl.dims), kind="unitary")["sum"]  # {sum, B}: one launch
             else:
                 goal_buf.zero_()
             if use_dist:
-                dist.all_reduce(goal_buf, op=dist.ReduceOp.SUM)
-            goal_last[0] = goal_buf
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            goal_last[0] = g
 
     lib = _lib.load()
     # the communicator and every message size of the run are set up before anything is timed

@@ -51,7 +51,7 @@ int fail(const char* fmt, ...) {
   } while (0)
 
 // Per-device workspace slots, grown lazily, freed by c3p_shutdown().
-enum Slot { SL_SEG_A = 0, SL_SEG_B, SL_SCRATCH, SL_CLP, SL_TABLES, SL_COUNTERS, SL_IN0, SL_IN1, SL_IN2, SL_IN3, SL_IN4, SL_OUT0, SL_OUT1, SL_COUNT };
+enum Slot { SL_SEG_A = 0, SL_SEG_B, SL_SCRATCH, SL_CLP, SL_TABLES, SL_COUNTERS, SL_COUNTERS2, SL_IN0, SL_IN1, SL_IN2, SL_IN3, SL_IN4, SL_IN5, SL_OUT0, SL_OUT1, SL_COUNT };
 
 struct DeviceWs {
   std::mutex mu;  // one lock per device: calls on different GPUs of one process do not serialise
@@ -983,6 +983,35 @@ int run_pwc_tiled(DeviceWs* w, const ChainArgs& a, bool per_slice, cplx* U_out, 
   return 0;
 }
 
+// Tiled backward sweep (c3p_tiled.hip): any matrix dimension, unitary and Lindblad generators
+int run_vjp_tiled(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals,
+                  const cplx* clp, double dt, int B, int K, int N, int D, int Dm, const double* fr_phase, const cplx* U_bar,
+                  double* grad, hipStream_t st) {
+  const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
+  const int Bc = c3p_tiled_vjp_chunk(Dm, K, N, B, per_sample, (size_t)24 << 30);
+  void* v;
+  if (ws_get(w, SL_SCRATCH, c3p_tiled_vjp_ws_bytes(Dm, K, N, Bc, per_sample), &v)) return -1;
+  if (g_dry) return 0;
+  TiledArgs t = {};
+  t.lindblad = lindblad;
+  t.h0 = h0;
+  t.h0_bstride = h0_bs;
+  t.hks = hks;
+  t.hks_bstride = hk_bs;
+  t.signals = signals;
+  t.clp = clp;
+  t.dt = dt;
+  t.B = B;
+  t.K = K;
+  t.N = N;
+  t.D = D;
+  t.Dm = Dm;
+  t.fr_phase = fr_phase;
+  std::string err;
+  if (c3p_tiled_vjp_run(t, U_bar, grad, v, Bc, st, err)) return fail("%s", err.c_str());
+  return 0;
+}
+
 // Host-pointer staging helpers --------------------------------------------------
 struct Stage {
   DeviceWs* w;
@@ -1578,6 +1607,80 @@ int c3p_gate_overlap(const void* U, int B, int D, const int32_t* comp_rows, int 
   return 0;
 }
 
+int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride, const double* signals,
+                         const void* col_ops, int C, double dt, int B, int K, int N, int D, int flags, const double* fr_phase,
+                         const void* U_bar, double* grad_signals, void* stream) {
+  if (B < 0 || K <= 0 || N <= 0 || D <= 0 || C <= 0) return fail("bad sizes B=%d K=%d N=%d D=%d C=%d", B, K, N, D, C);
+  if (flags & (C3P_PER_SLICE_H | C3P_ORDER_RIGHT)) return fail("c3p_pwc_lindblad_vjp: unsupported flag");
+  if (B == 0) return 0;
+  if (!h0 || !hks || !signals || !col_ops || !U_bar || !grad_signals) return fail("NULL pointer argument");
+  const size_t cs = sizeof(cplx);
+  const int Dm = D * D;
+  hipStream_t st = (hipStream_t)stream;
+  WsLock lk(st);
+  DeviceWs* w = lk.w;
+  if (!w) return fail("no HIP device");
+  if (!lk.ok) return fail("hipStreamWaitEvent on the previous call's stream failed");
+  Stage sg{w, st};
+  const void *d_h0 = h0, *d_hks = hks, *d_sig = signals, *d_ph = fr_phase, *d_ub = U_bar, *d_col = col_ops;
+  void* d_grad = grad_signals;
+  if (flags & C3P_HOST_PTRS) {
+    if (sg.in(h0, (size_t)(h0_bstride ? B : 1) * D * D * cs, &d_h0)) return -1;
+    if (sg.in(hks, (size_t)(hks_bstride ? B : 1) * K * D * D * cs, &d_hks)) return -1;
+    if (sg.in(signals, (size_t)B * K * N * sizeof(double), &d_sig)) return -1;
+    if (sg.in(col_ops, (size_t)C * D * D * cs, &d_col)) return -1;
+    if (sg.in(U_bar, (size_t)B * Dm * Dm * cs, &d_ub)) return -1;
+    if (fr_phase && sg.in(fr_phase, (size_t)B * Dm * sizeof(double), &d_ph)) return -1;
+    if (sg.out(grad_signals, (size_t)B * K * N * sizeof(double), &d_grad)) return -1;
+  }
+  void* clp;
+  if (ws_get(w, SL_CLP, (size_t)Dm * Dm * cs, &clp)) return -1;
+  LAUNCH_TRY(c3p_launch_clp((const cplx*)d_col, C, D, (cplx*)clp, st));
+  g_last_kernel = C3P_KERNEL_MFMA;
+  if (record_start(w, st)) return -1;
+  if (run_vjp_tiled(w, 1, (const cplx*)d_h0, h0_bstride, (const cplx*)d_hks, hks_bstride, (const double*)d_sig, (const cplx*)clp, dt, B,
+                    K, N, D, Dm, (const double*)d_ph, (const cplx*)d_ub, (double*)d_grad, st))
+    return -1;
+  if (record_stop(w, st)) return -1;
+  if (flags & C3P_HOST_PTRS) return sg.finish();
+  return 0;
+}
+
+int c3p_gate_infid(const void* U, int B, int D, const int32_t* comp_rows, int L, const void* ideal, int kind, int flags,
+                   double* infid_out, double* sum_out, void* stream) {
+  if (B < 0 || D <= 0 || L <= 0 || L > D) return fail("bad sizes B=%d D=%d L=%d", B, D, L);
+  if (kind != 0 && kind != 1) return fail("unknown infidelity kind %d (0 = unitary_infid, 1 = average_infid)", kind);
+  if (!U || !comp_rows || !ideal || (!infid_out && !sum_out)) return fail("NULL pointer argument");
+  hipStream_t st = (hipStream_t)stream;
+  WsLock lk(st);
+  DeviceWs* w = lk.w;
+  if (!w) return fail("no HIP device");
+  if (!lk.ok) return fail("hipStreamWaitEvent on the previous call's stream failed");
+  const size_t cs = sizeof(cplx);
+  Stage sg{w, st};
+  const void *d_U = U, *d_rows = comp_rows, *d_G = ideal;
+  void *d_inf = infid_out, *d_sum = sum_out;
+  if (flags & C3P_HOST_PTRS) {
+    for (int a = 0; a < L; ++a)
+      if (comp_rows[a] < 0 || comp_rows[a] >= D) return fail("comp_rows[%d]=%d outside [0,%d)", a, comp_rows[a], D);
+    if (sg.in(U, (size_t)B * D * D * cs, &d_U)) return -1;
+    if (sg.in(comp_rows, (size_t)L * sizeof(int32_t), &d_rows)) return -1;
+    if (sg.in(ideal, (size_t)L * L * cs, &d_G)) return -1;
+    if (sg.out(infid_out, infid_out ? (size_t)B * sizeof(double) : 0, &d_inf)) return -1;
+    if (sg.out(sum_out, sum_out ? 2 * sizeof(double) : 0, &d_sum)) return -1;
+  }
+  void* part;
+  if (ws_get(w, SL_COUNTERS2, 256 * sizeof(double), &part)) return -1;
+  if (B == 0) {
+    if (d_sum) HIP_TRY(hipMemsetAsync(d_sum, 0, 2 * sizeof(double), st));
+  } else {
+    LAUNCH_TRY(c3p_launch_infid((const cplx*)d_U, B, D, (const int*)d_rows, L, (const cplx*)d_G, kind, (double*)d_inf,
+                                (double*)part, (double*)d_sum, st));
+  }
+  if (flags & C3P_HOST_PTRS) return sg.finish();
+  return 0;
+}
+
 int c3p_synth_signals(const double* env_params, const int32_t* env_shapes, const double* carrier,
                       double t_start, double t_end, double awg_res, double sim_res, int B, int K,
                       int E, int flags, double* awg_iq_out, double* signals_out, void* stream) {
@@ -1634,7 +1737,7 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
                         const double* fr_phase, const void* U_bar, double* grad_signals, void* gen_bar_out,
                         void* stream) {
   if (B < 0 || K <= 0 || N <= 0 || D <= 0) return fail("bad sizes B=%d K=%d N=%d D=%d", B, K, N, D);
-  if (D > 64) return fail("gradient kernels support D <= 64, got %d", D);
+  if (D > 40 && gen_bar_out) return fail("gen_bar_out (per-slice generator cotangents) is available for D <= 40, got %d", D);
   if (flags & (C3P_PER_SLICE_H | C3P_ORDER_RIGHT)) return fail("c3p_pwc_unitary_vjp: unsupported flag");
   if (B == 0) return 0;
   if (!h0 || !hks || !signals || !U_bar || !grad_signals) return fail("NULL pointer argument");
@@ -1701,6 +1804,14 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
     done = (rc == 0);
     if (done) g_last_kernel = C3P_KERNEL_MFMA;
   }
+  if (!done && !(flags & C3P_FORCE_GENERIC) && D > 40 && !gen_bar_out) {
+    // beyond the on-chip sweeps: forward partials in HBM, one pair evaluation of T18 per slice on the tiled MFMA GEMM
+    if (run_vjp_tiled(w, 0, A.h0, h0_bstride, A.hks, hks_bstride, A.signals, nullptr, dt, B, K, N, D, D, A.fr_phase, A.Ubar, A.grad, st))
+      return -1;
+    done = true;
+    g_last_kernel = C3P_KERNEL_MFMA;
+  }
+  if (!done && D > 64) return fail("the VALU gradient kernels support D <= 64, got %d", D);
   if (!done) {
     long S = 4096 / B;
     if (S > N / 8) S = N / 8;

@@ -346,6 +346,48 @@ __global__ void __launch_bounds__(64) overlap_kernel(const cplx* U, int D, const
   if (lane == 0) out[b] = cmake(sr, si);
 }
 
+// Fused goal epilogue: infid[b] from the overlap (kind 0: unitary_infid = 1 - |s / L|^2, fidelities.py:154-184; kind 1:
+// average_infid = 1 - (|s|^2 / L + 1) / (L + 1), fidelities.py:290-313) and the partial sum of the block's samples --
+// what an optimiser (or the all-reduce of a sharded batch, optimalcontrol_robust.py:49-70) needs instead of B matrices.
+// One wavefront per sample slot, 4 per block; partial[blockIdx] = sum over the block's samples in a fixed order.
+__global__ void __launch_bounds__(256) infid_kernel(const cplx* U, int B, int D, const int* rows, int L, const cplx* ideal,
+                                                    int kind, double* infid, double* partial) {
+  __shared__ double wsum[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double acc = 0.0;
+  for (long b = (long)blockIdx.x * 4 + wave; b < B; b += (long)gridDim.x * 4) {
+    const cplx* Ub = U + b * D * D;
+    double sr = 0.0, si = 0.0;
+    for (int e = lane; e < L * L; e += 64) {
+      const int a = e / L, c = e - a * L;
+      const cplx u = Ub[rows[a] * D + rows[c]];
+      const cplx g = ideal[e];
+      sr += u.x * g.x + u.y * g.y;
+      si += u.y * g.x - u.x * g.y;
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+      sr += __shfl_xor(sr, o);
+      si += __shfl_xor(si, o);
+    }
+    const double s2 = sr * sr + si * si;
+    const double f = kind == 0 ? 1.0 - s2 / ((double)L * L) : 1.0 - (s2 / L + 1.0) / (L + 1.0);
+    if (lane == 0 && infid) infid[b] = f;
+    acc += f;
+  }
+  if (lane == 0) wsum[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+__global__ void __launch_bounds__(64) infid_sum_kernel(const double* partial, int n, int B, double* out) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  if (threadIdx.x == 0) {
+    out[0] = s;
+    out[1] = (double)B;
+  }
+}
+
 // Pre-pass of the supplied-generator modes (branch B of pwc, c3p_expm): one workgroup per matrix,
 // X = coef * H;  meta = {Re mu, Im mu, ||X - mu I||_1, 0},  mu = tr X / D.
 __global__ void __launch_bounds__(64) hmeta_kernel(const cplx* hs, long bstride, int N, int D, double cr, double ci,
@@ -499,6 +541,18 @@ hipError_t c3p_launch_kron(const cplx* A, const cplx* Bm, int n, int Da, int Db,
   if (total == 0) return hipSuccess;
   hipLaunchKernelGGL(kron_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, A, Bm, Da,
                      Db, which, total, out);
+  return hipGetLastError();
+}
+
+int c3p_infid_blocks(int B) {
+  const int nb = (B + 3) / 4;
+  return nb < 256 ? nb : 256;
+}
+hipError_t c3p_launch_infid(const cplx* U, int B, int D, const int* rows, int L, const cplx* ideal, int kind, double* infid,
+                            double* partial, double* sum_out, hipStream_t st) {
+  const int nb = c3p_infid_blocks(B);
+  hipLaunchKernelGGL(infid_kernel, dim3((unsigned)nb), dim3(256), 0, st, U, B, D, rows, L, ideal, kind, infid, partial);
+  if (sum_out) hipLaunchKernelGGL(infid_sum_kernel, dim3(1), dim3(64), 0, st, partial, nb, B, sum_out);
   return hipGetLastError();
 }
 

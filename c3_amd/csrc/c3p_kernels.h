@@ -34,6 +34,9 @@ hipError_t c3p_launch_chain_generic(const ChainArgs& A, bool global_scratch, hip
 hipError_t c3p_launch_clp(const cplx* col, int C, int D, cplx* clp, hipStream_t st);
 hipError_t c3p_launch_kron(const cplx* A, const cplx* Bm, int n, int Da, int Db, int which, cplx* out,
                            hipStream_t st);
+int c3p_infid_blocks(int B);
+hipError_t c3p_launch_infid(const cplx* U, int B, int D, const int* rows, int L, const cplx* ideal, int kind, double* infid,
+                            double* partial, double* sum_out, hipStream_t st);
 hipError_t c3p_launch_overlap(const cplx* U, int B, int D, const int* rows, int L, const cplx* ideal,
                               cplx* out, hipStream_t st);
 // pre-pass of the supplied-generator modes: meta[m] = {Re mu, Im mu, ||coef H_m - mu||_1, 0}, m = b * N + n

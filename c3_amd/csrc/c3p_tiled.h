@@ -29,3 +29,11 @@ size_t c3p_tiled_ws_bytes(int Dm, int K, int Bc, bool per_sample_tables);
 // Runs the whole propagation (synchronises the stream once, to read the norm bound that fixes the number of
 // squarings).  Returns 0 or -1 with `err` set.
 int c3p_tiled_run(const TiledArgs& A, void* ws, int Bc, hipStream_t st, std::string& err);
+
+// Vector-Jacobian product of the same path with respect to the control samples (table mode): forward sweep storing the
+// adjoints of the partial products in HBM, backward sweep with one pair evaluation of T18 per slice (value + Frechet
+// derivative, 15 + 3 s batched GEMMs).  No unitarity assumed: unitary AND Lindblad generators, any matrix dimension.
+//   U_bar [B,Dm,Dm]: d loss = Re sum conj(U_bar) dU;   grad f64 [B,K,N]
+int c3p_tiled_vjp_chunk(int Dm, int K, int N, int B, bool per_sample_tables, size_t budget_bytes);
+size_t c3p_tiled_vjp_ws_bytes(int Dm, int K, int N, int Bc, bool per_sample_tables);
+int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, void* ws, int Bc, hipStream_t st, std::string& err);

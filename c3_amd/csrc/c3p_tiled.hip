@@ -34,16 +34,15 @@ struct TG {
 };
 
 // ---- C = A B (+ Add), batched over blockIdx.z ------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) tg_gemm_kernel(const double* __restrict__ A, const double* __restrict__ Bm,
-                                                      const double* __restrict__ Add, double* __restrict__ C, int rows2, int DPC,
-                                                      long mstride) {
+// (Add may alias C: every element is read and written by the same thread; C must not alias A or B)
+__global__ void __launch_bounds__(256) tg_gemm_kernel(const double* A, const double* Bm, const double* Add, double* C, int rows2,
+                                                      int DPC, long strideA, long strideB, long strideC) {
   __shared__ double As[2][TG_BM * TG_SA];
   __shared__ double Bs[2][TG_KP * TG_SB];
-  const long boff = (long)blockIdx.z * mstride;
-  A += boff;
-  Bm += boff;
-  C += boff;
-  if (Add) Add += boff;
+  A += (long)blockIdx.z * strideA;
+  Bm += (long)blockIdx.z * strideB;
+  C += (long)blockIdx.z * strideC;
+  if (Add) Add += (long)blockIdx.z * strideC;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int r0 = blockIdx.y * TG_BM, c0 = blockIdx.x * TG_BN;
@@ -330,6 +329,34 @@ __global__ void __launch_bounds__(256) tg_assemble_kernel(AsmArgs P, int DPR, in
   }
 }
 
+// the same for a sample block of `nslots` matrices (backward sweep); table mode only
+__global__ void __launch_bounds__(256) tg_assemble_slots_kernel(AsmArgs P, int nslots, int DPR, int DPC) {
+  const int b = blockIdx.y;
+  const long MS = 2L * DPR * DPC;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  double* X = P.X + (long)b * nslots * MS;
+  const int ts = P.tab_per_sample ? b : 0;
+  const double* T = P.tables + (long)ts * (1 + P.K) * MS;
+  const double* sg = P.signals + ((long)(P.b0 + b) * P.K) * P.N + P.n;
+  if (e < MS) {
+    double v = T[e];
+    for (int k = 0; k < P.K; ++k) v = fma(sg[(long)k * P.N], T[(long)(k + 1) * MS + e], v);
+    X[e] = P.scale * v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const double* m = P.meta + (long)ts * (1 + P.K) * 4;
+    double mr = m[0], mi = m[1];
+    for (int k = 0; k < P.K; ++k) {
+      mr = fma(sg[(long)k * P.N], m[4 * (k + 1)], mr);
+      mi = fma(sg[(long)k * P.N], m[4 * (k + 1) + 1], mi);
+    }
+    P.mun[2 * b] = mr;
+    P.mun[2 * b + 1] = mi;
+    P.mus[2 * b] += mr;
+    P.mus[2 * b + 1] = c3p_phase_add(P.mus[2 * b + 1], mi);
+  }
+}
+
 // T18 combinations (c3p_common.h): from X, A2, A3, A6 -> T1 = B1, T2 = B5, T3 = B4, T4 = B3, X <- B2
 __global__ void __launch_bounds__(256) tg_combo_kernel(double* mats, int Dm, int DPR, int DPC) {
   const int b = blockIdx.y;
@@ -371,6 +398,121 @@ __global__ void __launch_bounds__(256) tg_out_kernel(const double* mats, int slo
   sincos(ang, &sn, &cs);
   const double er = mu ? exp(mu[2 * b]) : 1.0;
   out[(long)b * out_bstride + e] = cmake(er * (cs * re - sn * im), er * (cs * im + sn * re));
+}
+
+
+// ---- backward sweep (c3p_tiled_vjp_run) ---------------------------------------------------------------------------------
+enum {
+  V_Y = 0, V_A2, V_A3, V_A6, V_T1, V_T2, V_T3, V_T4,      // value side of the pair evaluation (slot layout as the forward pass)
+  V_V, V_DA2, V_DA3, V_DA6, V_DT1, V_DT2, V_DT3, V_DT4,   // derivative side
+  V_P0, V_P1, V_L0, V_L1, V_COUNT
+};
+
+// dst = src^H in the half-image layout: dst[2i][j] = src[2j][i], dst[2i+1][j] = -src[2j+1][i]
+__global__ void __launch_bounds__(256) tg_adjoint_kernel(const double* src, long sstride, double* dst, long dstride, int Dm, int DPR,
+                                                         int DPC) {
+  const long MS = 2L * DPR * DPC;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= MS) return;
+  const double* S = src + (long)blockIdx.y * sstride;
+  double* Dd = dst + (long)blockIdx.y * dstride;
+  const int r = (int)(e / DPC), c = (int)(e - (long)r * DPC);
+  const int i = r >> 1, p = r & 1;
+  double v = 0.0;
+  if (i < Dm && c < Dm) {
+    const double x = S[(long)(2 * c + p) * DPC + i];
+    v = p ? -x : x;
+  }
+  Dd[e] = v;
+}
+
+// T18 combinations with explicit slots; the derivative side drops the identity terms
+__global__ void __launch_bounds__(256) tg_combo_slots_kernel(double* mats, int nslots, int sx, int s2, int s3, int s6, int t1, int t2,
+                                                             int t3, int t4, int with_identity, int Dm, int DPR, int DPC) {
+  const int b = blockIdx.y;
+  const long MS = 2L * DPR * DPC;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= MS) return;
+  double* M = mats + (long)b * nslots * MS;
+  const int r = (int)(e / DPC), c = (int)(e - (long)r * DPC);
+  const double dg = (with_identity && (r & 1) == 0 && (r >> 1) == c && c < Dm) ? 1.0 : 0.0;
+  const double x = M[sx * MS + e], a2 = M[s2 * MS + e], a3 = M[s3 * MS + e], a6 = M[s6 * MS + e];
+  M[t1 * MS + e] = fma(C3P_T18_A31, a3, fma(C3P_T18_A21, a2, C3P_T18_A11 * x));
+  M[t2 * MS + e] = fma(C3P_T18_B64, a6, fma(C3P_T18_B34, a3, C3P_T18_B24 * a2));
+  M[t3 * MS + e] = fma(C3P_T18_B63, a6, fma(C3P_T18_B33, a3, fma(C3P_T18_B23, a2, fma(C3P_T18_B13, x, C3P_T18_B03 * dg))));
+  M[t4 * MS + e] = fma(C3P_T18_B62, a6, fma(C3P_T18_B32, a3, fma(C3P_T18_B22, a2, fma(C3P_T18_B12, x, C3P_T18_B02 * dg))));
+  M[sx * MS + e] = fma(C3P_T18_B61, a6, fma(C3P_T18_B31, a3, fma(C3P_T18_B21, a2, C3P_T18_B11 * x)));
+}
+
+__global__ void __launch_bounds__(256) tg_add_slots_kernel(double* mats, int nslots, int sa, int sb, int sd, long MS) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= MS) return;
+  double* M = mats + (long)blockIdx.y * nslots * MS;
+  M[sd * MS + e] = M[sa * MS + e] + M[sb * MS + e];
+}
+
+// Lambda = conj(e^{M}) diag(e^{-i phase}) U_bar as a half image; tau = <Lambda, P> (complex) for the trace-shift term
+__global__ void __launch_bounds__(256) tg_ubar_kernel(const cplx* ubar, const double* mus, const double* phase, const double* P,
+                                                      long pstride, double* lam, long lstride, double* tau, int Dm, int DPR, int DPC) {
+  __shared__ double r1[256], r2[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const long MS = 2L * DPR * DPC;
+  double* Lm = lam + (long)b * lstride;
+  const double* Pm = P + (long)b * pstride;
+  for (long e = tid; e < MS; e += 256) Lm[e] = 0.0;
+  __syncthreads();
+  const double er = exp(mus[2 * b]), mi = mus[2 * b + 1];
+  double tr = 0.0, ti = 0.0;
+  for (long e = tid; e < (long)Dm * Dm; e += 256) {
+    const int i = (int)(e / Dm), j = (int)(e - (long)i * Dm);
+    const double ang = -(mi + (phase ? phase[(long)b * Dm + i] : 0.0));  // conj(e^{M}) e^{-i phase_i}
+    double sn, cs;
+    sincos(ang, &sn, &cs);
+    const cplx u = ubar[(long)b * Dm * Dm + e];
+    const double lr = er * (cs * u.x - sn * u.y), li = er * (cs * u.y + sn * u.x);
+    Lm[(long)(2 * i) * DPC + j] = lr;
+    Lm[(long)(2 * i + 1) * DPC + j] = li;
+    const double pr = Pm[(long)(2 * i) * DPC + j], pi = Pm[(long)(2 * i + 1) * DPC + j];
+    tr += lr * pr + li * pi;  // conj(lambda) p
+    ti += lr * pi - li * pr;
+  }
+  r1[tid] = tr;
+  r2[tid] = ti;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) {
+      r1[tid] += r1[tid + o];
+      r2[tid] += r2[tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    tau[2 * b] = r1[0];
+    tau[2 * b + 1] = r2[0];
+  }
+}
+
+// grad[b][k][n] = scale <Xbar, G_k> + Re(mu_k tau): one block per (k, sample)
+__global__ void __launch_bounds__(256) tg_graddot_kernel(const double* mats, int nslots, int slot, const double* tables, const double* meta,
+                                                         int tab_per_sample, int K, const double* tau, double scale, double* grad, int b0,
+                                                         int n, int N, long MS) {
+  __shared__ double r1[256];
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const double* X = mats + ((long)b * nslots + slot) * MS;
+  const int ts = tab_per_sample ? b : 0;
+  const double* G = tables + ((long)ts * (1 + K) + (k + 1)) * MS;
+  double acc = 0.0;
+  for (long e = tid; e < MS; e += 256) acc = fma(X[e], G[e], acc);
+  r1[tid] = acc;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) r1[tid] += r1[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double* m = meta + ((long)ts * (1 + K) + (k + 1)) * 4;
+    grad[((long)(b0 + b) * K + k) * N + n] = scale * r1[0] + (m[0] * tau[2 * b] - m[1] * tau[2 * b + 1]);
+  }
 }
 
 #define TG_TRY(expr)                                                                  \
@@ -481,7 +623,7 @@ int c3p_tiled_run(const TiledArgs& A, void* ws, int Bc, hipStream_t st, std::str
     auto M = [&](int slot) -> double* { return mats + (long)slot * MS; };
     auto gemm = [&](int a, int b, int add, int c) {
       hipLaunchKernelGGL(tg_gemm_kernel, gg, dim3(256), 0, st, M(a), M(b), add >= 0 ? M(add) : nullptr, M(c), 2 * g.DPR, g.DPC,
-                         (long)M_COUNT * MS);
+                         (long)M_COUNT * MS, (long)M_COUNT * MS, (long)M_COUNT * MS);
     };
     int ucur = M_U0;
     for (int n = 0; n < A.N; ++n) {
@@ -540,6 +682,213 @@ int c3p_tiled_run(const TiledArgs& A, void* ws, int Bc, hipStream_t st, std::str
                        A.fr_phase ? A.fr_phase + (long)b0 * A.Dm : nullptr, A.U_out + (long)b0 * A.Dm * A.Dm, (long)A.Dm * A.Dm, A.Dm,
                        g.DPR, g.DPC);
     TG_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
+// ---- vector-Jacobian product of the whole tiled path -------------------------------------------------------------------
+size_t c3p_tiled_vjp_ws_bytes(int Dm, int K, int N, int Bc, bool per_sample_tables) {
+  const TG g(Dm);
+  const size_t nt = per_sample_tables ? (size_t)Bc : 1;
+  return ((size_t)Bc * V_COUNT * g.MS + (size_t)Bc * N * g.MS + 2 * nt * (1 + K) * (g.MS + 4) + 12 * (size_t)Bc + 64) * sizeof(double);
+}
+
+int c3p_tiled_vjp_chunk(int Dm, int K, int N, int B, bool per_sample_tables, size_t budget_bytes) {
+  int bc = B;
+  while (bc > 1 && c3p_tiled_vjp_ws_bytes(Dm, K, N, bc, per_sample_tables) > budget_bytes) bc = (bc + 1) / 2;
+  return bc;
+}
+
+int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, void* ws, int Bc, hipStream_t st, std::string& err) {
+  const TG g(A.Dm);
+  const long MS = g.MS;
+  const bool per_sample = (A.h0_bstride != 0 || A.hks_bstride != 0);
+  const int K = A.K, N = A.N;
+  const size_t nt = per_sample ? (size_t)Bc : 1;
+  double* mats = reinterpret_cast<double*>(ws);
+  double* store = mats + (size_t)Bc * V_COUNT * MS;          // [Bc][N][MS]: adjoints of the forward partial products
+  double* tables = store + (size_t)Bc * N * MS;              // G_k - mu_k
+  double* tables_adj = tables + nt * (1 + K) * MS;           // their adjoints
+  double* meta = tables_adj + nt * (1 + K) * MS;
+  double* meta_adj = meta + nt * (1 + K) * 4;
+  double* mus = meta_adj + nt * (1 + K) * 4;
+  double* mun = mus + 2 * (size_t)Bc;
+  double* junk = mun + 2 * (size_t)Bc;  // trace-shift outputs of the backward assemblies (unused)
+  double* tau = junk + 4 * (size_t)Bc;
+  unsigned long long* red = reinterpret_cast<unsigned long long*>(tau + 2 * (size_t)Bc);
+  const unsigned ebl = (unsigned)((MS + 255) / 256);
+  const dim3 ggrid((unsigned)(g.DPC / TG_BN), (unsigned)(2 * g.DPR / TG_BM), 1);
+  const long VS = (long)V_COUNT * MS, SS = (long)N * MS;
+
+  for (int b0 = 0; b0 < A.B; b0 += Bc) {
+    const int nb = A.B - b0 < Bc ? A.B - b0 : Bc;
+    const int nts = per_sample ? nb : 1;
+    TG_TRY(hipMemsetAsync(red, 0, 64 * sizeof(unsigned long long), st));
+    TabArgs T = {};
+    T.h0 = A.h0;
+    T.h0_bstride = A.h0_bstride;
+    T.hks = A.hks;
+    T.hks_bstride = A.hks_bstride;
+    T.clp = A.clp;
+    T.dt = A.dt;
+    T.K = K;
+    T.Dh = A.D;
+    T.Dm = A.Dm;
+    T.lindblad = A.lindblad;
+    T.b0 = per_sample ? b0 : 0;
+    T.tables = tables;
+    T.meta = meta;
+    if (b0 == 0 || per_sample) {
+      hipLaunchKernelGGL(tg_meta_kernel, dim3(1 + K, nts), dim3(256), 0, st, T);
+      hipLaunchKernelGGL(tg_table_kernel, dim3(ebl, 1 + K, nts), dim3(256), 0, st, T, g.DPR, g.DPC);
+      hipLaunchKernelGGL(tg_adjoint_kernel, dim3(ebl, (unsigned)(nts * (1 + K))), dim3(256), 0, st, tables, MS, tables_adj, MS, A.Dm,
+                         g.DPR, g.DPC);
+    }
+    hipLaunchKernelGGL(tg_sigmax_kernel, dim3(K), dim3(256), 0, st, A.signals + (long)b0 * K * N, nb, K, N, red);
+    TG_TRY(hipGetLastError());
+    std::vector<double> hm((size_t)nts * (1 + K) * 4);
+    std::vector<unsigned long long> hr(64);
+    TG_TRY(hipMemcpyAsync(hm.data(), meta, hm.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    TG_TRY(hipMemcpyAsync(hr.data(), red, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    TG_TRY(hipStreamSynchronize(st));
+    double bound = 0.0;
+    for (int ti = 0; ti <= K; ++ti) {
+      double nk = 0.0;
+      for (int sidx = 0; sidx < nts; ++sidx) nk = std::max(nk, hm[((size_t)sidx * (1 + K) + ti) * 4 + 2]);
+      double cm = 1.0;
+      if (ti > 0) memcpy(&cm, &hr[ti - 1], 8);
+      bound += cm * nk;
+    }
+    int s18 = 0;
+    {
+      double p = C3P_T18_THETA;
+      while (p < bound && s18 < 60) {
+        p *= 2.0;
+        ++s18;
+      }
+    }
+    const double scale = ldexp(1.0, -s18);
+    // the adjoint generators' trace shifts are the conjugates (only the assemblies of the backward sweep read them; unused)
+    TG_TRY(hipMemcpyAsync(meta_adj, meta, nt * (1 + K) * 4 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    TG_TRY(hipMemsetAsync(mus, 0, 2 * (size_t)Bc * sizeof(double), st));
+    const dim3 eg(ebl, (unsigned)nb);
+    dim3 gg = ggrid;
+    gg.z = (unsigned)nb;
+    auto M = [&](int slot) -> double* { return mats + (long)slot * MS; };
+    auto gemm = [&](int a, int b, int add, int c) {
+      hipLaunchKernelGGL(tg_gemm_kernel, gg, dim3(256), 0, st, M(a), M(b), add >= 0 ? M(add) : nullptr, M(c), 2 * g.DPR, g.DPC, VS, VS,
+                         VS);
+    };
+    auto assemble = [&](const double* tabs, const double* mt, int n, double* ms, double* mn) {
+      AsmArgs P = {};
+      P.tables = tabs;
+      P.meta = mt;
+      P.tab_per_sample = per_sample ? 1 : 0;
+      P.signals = A.signals;
+      P.b0 = b0;
+      P.n = n;
+      P.K = K;
+      P.N = N;
+      P.clp = A.clp;
+      P.lindblad = A.lindblad;
+      P.Dh = A.D;
+      P.Dm = A.Dm;
+      P.dt = A.dt;
+      P.scale = scale;
+      P.X = mats;  // slot V_Y == M_X == 0 of a V_COUNT-slot sample block
+      P.mus = ms;
+      P.mun = mn;
+      hipLaunchKernelGGL(tg_assemble_slots_kernel, eg, dim3(256), 0, st, P, V_COUNT, g.DPR, g.DPC);
+    };
+    // value side of T18 + squarings from the generator in slot V_Y; returns the slot of exp
+    auto t18_value = [&]() -> int {
+      gemm(V_Y, V_Y, -1, V_A2);
+      gemm(V_Y, V_A2, -1, V_A3);
+      gemm(V_A3, V_A3, -1, V_A6);
+      hipLaunchKernelGGL(tg_combo_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_Y, V_A2, V_A3, V_A6, V_T1, V_T2, V_T3, V_T4, 1,
+                         A.Dm, g.DPR, g.DPC);
+      gemm(V_T1, V_T2, V_T3, V_A2);
+      hipLaunchKernelGGL(tg_add_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_T4, V_A2, V_A3, MS);
+      gemm(V_A3, V_A2, V_Y, V_A6);
+      int e = V_A6, o = V_T1;
+      for (int it = 0; it < s18; ++it) {
+        gemm(e, e, -1, o);
+        std::swap(e, o);
+      }
+      return e;
+    };
+    // ---- forward: partial products P_n = E_n ... E_0 (trace-shifted), their adjoints stored ----
+    int pcur = V_P0;
+    for (int n = 0; n < N; ++n) {
+      assemble(tables, meta, n, mus, mun);
+      const int e = t18_value();
+      if (n == 0) {
+        for (int b = 0; b < nb; ++b)
+          TG_TRY(hipMemcpyAsync(mats + (long)b * VS + (long)pcur * MS, mats + (long)b * VS + (long)e * MS, MS * sizeof(double),
+                                hipMemcpyDeviceToDevice, st));
+      } else {
+        const int pn = pcur == V_P0 ? V_P1 : V_P0;
+        gemm(e, pcur, -1, pn);
+        pcur = pn;
+      }
+      if (n + 1 < N)  // B_{n+1}^H = P_n^H
+        hipLaunchKernelGGL(tg_adjoint_kernel, eg, dim3(256), 0, st, M(pcur), VS, store + (long)(n + 1) * MS, SS, A.Dm, g.DPR, g.DPC);
+      TG_TRY(hipGetLastError());
+    }
+    // ---- cotangent of the trace-shifted product and the trace-shift term ----
+    int lcur = V_L0;
+    hipLaunchKernelGGL(tg_ubar_kernel, dim3((unsigned)nb), dim3(256), 0, st, U_bar + (long)b0 * A.Dm * A.Dm, mus,
+                       A.fr_phase ? A.fr_phase + (long)b0 * A.Dm : nullptr, M(pcur), VS, M(lcur), VS, tau, A.Dm, g.DPR, g.DPC);
+    // ---- backward: Ebar_n = Lambda_n B_n^H, Xbar_n = L(X_n^H)[Ebar_n] by the pair evaluation of T18, Lambda_{n-1} = E_n^H Lambda_n ----
+    for (int n = N - 1; n >= 0; --n) {
+      if (n > 0) {
+        hipLaunchKernelGGL(tg_gemm_kernel, gg, dim3(256), 0, st, M(lcur), store + (long)n * MS, (const double*)nullptr, M(V_V), 2 * g.DPR,
+                           g.DPC, VS, SS, VS);
+      } else {
+        for (int b = 0; b < nb; ++b)
+          TG_TRY(hipMemcpyAsync(mats + (long)b * VS + (long)V_V * MS, mats + (long)b * VS + (long)lcur * MS, MS * sizeof(double),
+                                hipMemcpyDeviceToDevice, st));
+      }
+      assemble(tables_adj, meta_adj, n, junk, junk + 2 * (size_t)Bc);  // Y = X_n^H (scaled)
+      // derivative side first where it needs the un-overwritten values
+      gemm(V_Y, V_Y, -1, V_A2);
+      gemm(V_V, V_Y, -1, V_DA2);
+      gemm(V_Y, V_V, V_DA2, V_DA2);
+      gemm(V_Y, V_A2, -1, V_A3);
+      gemm(V_V, V_A2, -1, V_DA3);
+      gemm(V_Y, V_DA2, V_DA3, V_DA3);
+      gemm(V_A3, V_A3, -1, V_A6);
+      gemm(V_DA3, V_A3, -1, V_DA6);
+      gemm(V_A3, V_DA3, V_DA6, V_DA6);
+      hipLaunchKernelGGL(tg_combo_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_Y, V_A2, V_A3, V_A6, V_T1, V_T2, V_T3, V_T4, 1,
+                         A.Dm, g.DPR, g.DPC);
+      hipLaunchKernelGGL(tg_combo_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_V, V_DA2, V_DA3, V_DA6, V_DT1, V_DT2, V_DT3,
+                         V_DT4, 0, A.Dm, g.DPR, g.DPC);
+      gemm(V_T1, V_T2, V_T3, V_A2);       // A9 = B1 B5 + B4
+      gemm(V_DT1, V_T2, V_DT3, V_DA2);    // dA9 = dB1 B5 + dB4
+      gemm(V_T1, V_DT2, V_DA2, V_DA2);    //      + B1 dB5
+      hipLaunchKernelGGL(tg_add_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_T4, V_A2, V_A3, MS);     // L = B3 + A9
+      hipLaunchKernelGGL(tg_add_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_DT4, V_DA2, V_DA3, MS);  // dL
+      gemm(V_A3, V_A2, V_Y, V_A6);        // F = L A9 + B2
+      gemm(V_DA3, V_A2, V_V, V_DA6);      // dF = dL A9 + dB2
+      gemm(V_A3, V_DA2, V_DA6, V_DA6);    //     + L dA9
+      int e = V_A6, o = V_T1, de = V_DA6, dq = V_DT1;
+      for (int it = 0; it < s18; ++it) {
+        gemm(de, e, -1, dq);
+        gemm(e, de, dq, dq);
+        gemm(e, e, -1, o);
+        std::swap(e, o);
+        std::swap(de, dq);
+      }
+      hipLaunchKernelGGL(tg_graddot_kernel, dim3((unsigned)K, (unsigned)nb), dim3(256), 0, st, mats, V_COUNT, de, tables, meta,
+                         per_sample ? 1 : 0, K, tau, scale, grad, b0, n, N, MS);
+      if (n > 0) {
+        const int ln = lcur == V_L0 ? V_L1 : V_L0;
+        gemm(e, lcur, -1, ln);  // Lambda_{n-1} = E_n^H Lambda_n
+        lcur = ln;
+      }
+      TG_TRY(hipGetLastError());
+    }
   }
   return 0;
 }

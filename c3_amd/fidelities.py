@@ -67,6 +67,37 @@ def gate_overlaps(ideal, actual, index=None, dims=None):
     return (out[0] if squeeze else out), L
 
 
+def infid_sum(ideal, actual, index=None, dims=None, kind: str = "unitary", want_each: bool = False):
+    """Fused goal epilogue (c3p_gate_infid): returns `{"sum": [sum_b infid[b], B], "each": [B] or None}` for a batch of
+    propagators on the device -- one small launch instead of the overlap kernel plus element-wise host-framework ops;
+    the quantity a sharded batch all-reduces (optimalcontrol_robust.py:49-70)."""
+    call = _Call(actual, ideal)
+    U = call.c128(actual)
+    if U.ndim == 2:
+        U = U[None]
+    B, D = int(U.shape[0]), int(U.shape[-1])
+    if dims is None or int(np.prod(dims)) != D:
+        raise C3PropError(f"C3:Error: dims {dims} do not match the propagator dimension {D}")
+    if kind not in ("unitary", "average"):
+        raise C3PropError(f"C3:Error: unknown infidelity kind '{kind}'")
+    rows = computational_rows(dims, index)
+    L = int(rows.shape[0])
+    G = call.c128(ideal)
+    if tuple(G.shape) != (L, L):
+        raise C3PropError(f"C3:Error: ideal gate must be [{L},{L}] for index {index}, got {tuple(G.shape)}")
+    if call.device:
+        rows_d = call.torch.as_tensor(rows, device=call.dev)
+        out = call.torch.empty((2,), dtype=call.torch.float64, device=call.dev)
+        each = call.torch.empty((B,), dtype=call.torch.float64, device=call.dev) if want_each else None
+    else:
+        rows_d = rows
+        out = np.empty((2,), dtype=np.float64)
+        each = np.empty((B,), dtype=np.float64) if want_each else None
+    _lib.check(_lib.load().c3p_gate_infid(_ptr(U), B, D, _ptr(rows_d), L, _ptr(G), 0 if kind == "unitary" else 1, call.flags,
+                                          _ptr(each), _ptr(out), call.stream))
+    return {"sum": out, "each": each}
+
+
 @fid_reg_deco
 def unitary_infid(ideal, actual, index: List[int] = None, dims=None):
     """fidelities.py:154-184; `actual` may be a batch [B,D,D] (returns [B])."""

@@ -289,6 +289,46 @@ def propagate_batch_vjp(h0, hks, signals, dt: float, U_bar, *, fr_phase=None, fo
     return grad, g0, gk
 
 
+def propagate_batch_lindblad_vjp(h0, hks, signals, dt: float, col_ops, U_bar, *, fr_phase=None):
+    """Vector-Jacobian product of `propagate_batch(..., lindbladian=True)` w.r.t. the control samples: the reference
+    tapes tf_propagation_lind (propagation.py:551-585) under the same GradientTape (optimizers/optimizer.py:206-216).
+    `U_bar` [B,D^2,D^2] is the cotangent of the superoperators (d loss = Re sum conj(U_bar) dU); returns f64 [B,K,N]."""
+    call = _Call(h0, hks, signals, U_bar, fr_phase, col_ops)
+    h0 = call.c128(h0)
+    hks = call.c128(hks)
+    signals = call.f64(signals)
+    if signals.ndim != 3:
+        raise C3PropError(f"C3:Error: signals must be [B,K,N], got {tuple(signals.shape)}")
+    B, K, N = (int(s) for s in signals.shape)
+    D = int(h0.shape[-1])
+    Dm = D * D
+    h0_bs = _bstride(h0, 2, B, "h0")
+    hk_bs = _bstride(hks, 3, B, "hks")
+    if int(hks.shape[-3]) != K:
+        raise C3PropError(f"C3:Error: {K} signal channels but {int(hks.shape[-3])} control Hamiltonians")
+    if col_ops is None:
+        raise C3PropError("C3:Error: lindbladian propagation needs collapse operators")
+    col = call.c128(col_ops if _is_torch(col_ops) else np.asarray(col_ops))
+    U_bar = call.c128(U_bar)
+    if tuple(U_bar.shape) != (B, Dm, Dm):
+        raise C3PropError(f"C3:Error: U_bar must be [{B},{Dm},{Dm}], got {tuple(U_bar.shape)}")
+    if fr_phase is not None:
+        fr_phase = call.f64(fr_phase)
+        if tuple(fr_phase.shape) != (B, Dm):
+            raise C3PropError(f"C3:Error: fr_phase must be [{B},{Dm}], got {tuple(fr_phase.shape)}")
+    if call.device:
+        grad = call.torch.empty((B, K, N), dtype=call.torch.float64, device=call.dev)
+    else:
+        grad = np.empty((B, K, N), dtype=np.float64)
+    _lib.check(
+        _lib.load().c3p_pwc_lindblad_vjp(
+            _ptr(h0), h0_bs, _ptr(hks), hk_bs, _ptr(signals), _ptr(col), int(col.shape[0]), float(dt), B, K, N, D, call.flags,
+            _ptr(fr_phase), _ptr(U_bar), _ptr(grad), call.stream
+        )
+    )
+    return grad
+
+
 # --------------------------------------------------------------------------
 # tf_utils counterparts on the device (tf_utils.py:120-193, 240-289)
 # --------------------------------------------------------------------------

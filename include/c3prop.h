@@ -185,6 +185,18 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
                         const double* fr_phase, const void* U_bar, double* grad_signals, void* gen_bar_out,
                         void* stream);
 
+/* The same vector-Jacobian product through the LINDBLAD path (c3p_pwc_lindblad; the reference tapes
+ * tf_propagation_lind just as well, c3/libraries/propagation.py:551-585 under c3/optimizers/optimizer.py:206-216):
+ *   U_bar c128 [B,D^2,D^2] (d loss = Re sum conj(U_bar) dU of the superoperators), grad_signals f64 [B,K,N],
+ *   fr_phase f64 [B,D^2] or NULL (the row phases c3p_pwc_lindblad applies).
+ * The slices are not unitary, so the adjoint state cannot be propagated backwards through inverses: the forward partial
+ * products are kept in HBM (N matrices of D^4 complex per sample, processed in chunks of samples that fit 24 GB) and the
+ * backward sweep evaluates value and Frechet derivative of every slice's exponential together on the tiled MFMA GEMM
+ * (c3p_tiled.hip).  c3p_pwc_unitary_vjp uses the same sweep above D = 40 (any dimension; gen_bar_out only up to D = 40). */
+int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride,
+                         const double* signals, const void* col_ops, int C, double dt, int B, int K, int N, int D,
+                         int flags, const double* fr_phase, const void* U_bar, double* grad_signals, void* stream);
+
 /* Control-signal synthesis for the standard drive line LO + AWG -> DAC -> Mixer -> VoltsToHertz
  * (Instruction.get_awg_signal c3/signal/gates.py:341-370, Envelope/EnvelopeDrag
  * c3/signal/pulse.py:88-180, Device.create_ts c3/generator/devices.py:72-122, DigitalToAnalog :306-351,
@@ -253,6 +265,16 @@ int c3p_synth_signals_vjp(const double* env_params, const int32_t* env_shapes, c
  */
 int c3p_gate_overlap(const void* U, int B, int D, const int32_t* comp_rows, int L, const void* ideal,
                      int flags, void* overlap_out, void* stream);
+
+/* The goal itself, fused: infid[b] = unitary_infid (kind 0: 1 - |overlap / L|^2, fidelities.py:154-184)
+ * or average_infid (kind 1: 1 - (|overlap|^2 / L + 1) / (L + 1), fidelities.py:290-313) of every propagator and their sum
+ * over the batch -- B scalars (or two) leave the device instead of B matrices, and a batch sharded over GPUs exchanges
+ * ONE all-reduce of sum_out instead of an all-gather of U (the mean over noise / parameter instances is what
+ * OptimalControlRobust.goal_run_with_grad forms, c3/optimizers/optimalcontrol_robust.py:49-70).
+ *   infid_out f64 [B] or NULL; sum_out f64 [2] = {sum_b infid[b], B} or NULL (deterministic summation order)
+ */
+int c3p_gate_infid(const void* U, int B, int D, const int32_t* comp_rows, int L, const void* ideal, int kind,
+                   int flags, double* infid_out, double* sum_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1242,6 +1242,40 @@ def pwc_signal_gradient(h0, hks, signals, dt, Ubar, fr_phase=None) -> np.ndarray
     return g
 
 
+def pwc_lindblad_signal_gradient(h0, hks, col_ops, signals, dt, Ubar, fr_phase=None) -> np.ndarray:
+    """d loss / d signals[k, n] for loss with d loss = Re sum conj(Ubar) dU, U the Lindblad superoperator of
+    propagation.py:551-585 (what the reference obtains by taping tf_propagation_lind, optimizer.py:206-216): one
+    Frechet derivative of the slice exponential per (k, n), no unitarity assumed.  `fr_phase` [D^2]: row phases applied
+    to U.  Pinned by central finite differences of the pinned propagator oracle (tests/test_gradient.py)."""
+    h0 = np.asarray(h0, dtype=np.complex128)
+    hks = np.asarray(hks, dtype=np.complex128)
+    signals = np.asarray(signals, dtype=np.float64)
+    K, N = signals.shape
+    D = h0.shape[-1]
+    I = np.eye(D)
+    clp = lindblad_dissipator(col_ops)
+    sup = lambda h: -1j * (np.kron(h, I) - np.kron(I, h.T))
+    Gk = [sup(hks[k]) * dt for k in range(K)]
+    Xs = [(sup(h0 + sum(signals[k, n] * hks[k] for k in range(K))) + clp) * dt for n in range(N)]
+    Es = [expm(X) for X in Xs]
+    Dm = D * D
+    pre = [np.eye(Dm, dtype=np.complex128)]  # pre[n] = E_{n-1} ... E_0
+    for n in range(N):
+        pre.append(Es[n] @ pre[-1])
+    post = [None] * N  # post[n] = E_{N-1} ... E_{n+1}
+    acc = np.eye(Dm, dtype=np.complex128)
+    for n in range(N - 1, -1, -1):
+        post[n] = acc
+        acc = acc @ Es[n]
+    ph = np.exp(1j * np.asarray(fr_phase)) if fr_phase is not None else np.ones(Dm)
+    grad = np.zeros((K, N))
+    for n in range(N):
+        W = (post[n].conj().T * np.conj(ph)[None, :]) @ np.asarray(Ubar) @ pre[n].conj().T  # cotangent of E_n
+        for k in range(K):
+            grad[k, n] = np.real(np.sum(np.conj(W) * expm_frechet(Xs[n], Gk[k])))
+    return grad
+
+
 def unitary_infid_cotangent(ideal, U, index, dims):
     """Ubar for loss = unitary_infid (fidelities.py:154-184): 1 - |tr(G^+ P^T U P) / L|^2."""
     Pm = projector(dims, index)

@@ -97,7 +97,7 @@ def main():
                 row = {"step": step, "solver": solver, "B": B, "N": N, "D": D, "K": K, "C": C, "kernel": kern, "complex_ops": bool(a.complex_ops),
                        "ms": best * 1e3, "rk_steps_per_s": steps / best, "final_states_per_s": B / best,
                        "algorithmic_flop_per_step": fl, "algorithmic_tflops": steps * fl / best * 1e-12, "frac": steps * fl / best / PEAK,
-                       "err_vs_oracle_rk": float(np.abs(got - ref).max())}
+                       "err_vs_oracle_rk": float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max())), "max_abs_state": float(np.abs(ref).max())}
                 if step == "schrodinger" and not a.complex_ops:
                     U = o.propagate_batch(wl.h0, wl.hks, wl.signals[:2], wl.dt)
                     row["err_vs_pwc"] = float(np.abs(got - np.stack([U[b] @ psi0 for b in range(2)])).max())

@@ -374,3 +374,30 @@ def test_ode_rowq_cfg3_long_and_rk4_unitary(prop):
         ref = o.rk4_unitary_arrays(Hs, 0.1, D)
         assert np.abs(U[b] - ref["U"]).max() < 1e-12
         assert np.abs(dUs[b] - ref["dUs"]).max() < 1e-12
+
+
+def test_fused_infidelity_sum(prop):
+    """c3p_gate_infid: per-sample unitary_infid / average_infid and their batch sum in one launch, against the oracle
+    (fidelities.py:154-184,290-313) and the unfused device path."""
+    import torch
+
+    from c3_amd import fidelities as fid
+
+    wl = workloads.make_workload(2, B=37, N=20)
+    U = o.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt, fr_phase=wl.fr_phase)
+    rng = np.random.default_rng(3)
+    a = rng.normal(size=(4, 4)) + 1j * rng.normal(size=(4, 4))
+    ideal, _ = np.linalg.qr(a)
+    Ud = torch.as_tensor(U, device="cuda:0")
+    for kind, ref_fn, dev_fn in (("unitary", o.unitary_infid, fid.unitary_infid), ("average", o.average_infid, fid.average_infid)):
+        r = fid.infid_sum(torch.as_tensor(ideal, device="cuda:0"), Ud, [0, 1], [3, 3], kind=kind, want_each=True)
+        each = r["each"].cpu().numpy()
+        ref = np.array([ref_fn(ideal, U[b], index=[0, 1], dims=[3, 3]) for b in range(wl.B)]).real
+        assert np.abs(each - ref).max() < 1e-13
+        s = r["sum"].cpu().numpy()
+        assert abs(s[0] - ref.sum()) < 1e-11 and s[1] == wl.B
+        unfused = np.asarray(dev_fn(ideal, U, index=[0, 1], dims=[3, 3])).real
+        assert np.abs(each - unfused).max() < 1e-13
+    # host-pointer route
+    r = fid.infid_sum(ideal, U, [0, 1], [3, 3], kind="unitary", want_each=True)
+    assert np.abs(r["each"] - np.array([o.unitary_infid(ideal, U[b], index=[0, 1], dims=[3, 3]) for b in range(wl.B)]).real).max() < 1e-13

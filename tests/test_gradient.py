@@ -238,3 +238,88 @@ def test_vjp_model_gradients(prop, cfg, N, generic):
         fd = (loss(w.h0, hp, b) - loss(w.h0, hm, b)) / (2 * epk)
         an = np.real(np.vdot(gk[b, k], Ek))
         assert abs(fd - an) < 2e-6 * abs(an) + 1e-18
+
+
+def test_oracle_lindblad_gradient_matches_finite_differences():
+    """The Lindblad gradient oracle (one Frechet derivative per (k, n), no unitarity assumed) against central finite
+    differences of the PINNED Lindblad propagator oracle (propagation.py:551-585)."""
+    w = make_workload(4, B=1, N=4)
+    rng = np.random.default_rng(5)
+    Dm = w.D * w.D
+    Ubar = rng.normal(size=(Dm, Dm)) + 1j * rng.normal(size=(Dm, Dm))
+    ph = rng.uniform(0, 2 * np.pi, size=Dm)
+    g = o.pwc_lindblad_signal_gradient(w.h0, w.hks, w.col_ops, w.signals[0], w.dt, Ubar, ph)
+
+    def loss(sig):
+        U = o.propagate_batch(w.h0, w.hks, sig[None], w.dt, col_ops=w.col_ops, lindbladian=True)[0]
+        return np.real(np.vdot(Ubar, np.exp(1j * ph)[:, None] * U))
+
+    for k in range(w.K):
+        for n in range(4):
+            h = 2e3
+            sp, sm = w.signals[0].copy(), w.signals[0].copy()
+            sp[k, n] += h
+            sm[k, n] -= h
+            fd = (loss(sp) - loss(sm)) / (2 * h)
+            assert abs(fd - g[k, n]) < 1e-6 * np.abs(g).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,N,B,C", [((2,), 9, 3, 1), ((3,), 14, 2, 1), ((2, 2), 7, 2, 2), ((3, 3), 6, 2, 2)])
+def test_lindblad_vjp_vs_oracle(prop, dims, N, B, C):
+    """c3p_pwc_lindblad_vjp (forward partials in HBM + pair evaluation of T18 on the tiled GEMM) against the FD-pinned
+    oracle gradient: D^2 = 4, 9, 16, 81 superoperators, frame-rotation row phases, per-sample cotangents."""
+    rng = np.random.default_rng(len(dims) * 10 + N)
+    D = int(np.prod(dims))
+    herm = lambda s: (lambda a: s * (a + a.conj().T) / 2)(rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))
+    K = 2
+    h0, hks = herm(0.8), np.stack([herm(0.5) for _ in range(K)])
+    col = np.stack([0.3 * (rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))) for _ in range(C)])
+    sig = rng.uniform(-1, 1, size=(B, K, N))
+    Dm = D * D
+    Ubar = rng.normal(size=(B, Dm, Dm)) + 1j * rng.normal(size=(B, Dm, Dm))
+    ph = rng.uniform(0, 2 * np.pi, size=(B, Dm))
+    dt = 0.7  # |L| dt ~ 2 - 5: squarings in the pair evaluation
+    g = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar, fr_phase=ph))
+    for b in range(B):
+        want = o.pwc_lindblad_signal_gradient(h0, hks, col, sig[b], dt, Ubar[b], ph[b])
+        assert np.abs(g[b] - want).max() < 1e-10 * np.abs(want).max()
+
+
+@pytest.mark.gpu
+def test_lindblad_vjp_cfg4_operators_on_device(prop):
+    """cfg4's operators (81 x 81 superoperators), device-resident tensors, against the oracle on both samples."""
+    import torch
+
+    w = make_workload(4, B=2, N=10)
+    rng = np.random.default_rng(8)
+    Dm = w.D * w.D
+    Ubar = rng.normal(size=(2, Dm, Dm)) + 1j * rng.normal(size=(2, Dm, Dm))
+    t = lambda x: torch.as_tensor(x, device="cuda:0")
+    g = prop.propagate_batch_lindblad_vjp(t(w.h0), t(w.hks), t(w.signals), w.dt, t(w.col_ops), t(Ubar))
+    assert g.is_cuda
+    g = g.cpu().numpy()
+    for b in range(2):
+        want = o.pwc_lindblad_signal_gradient(w.h0, w.hks, w.col_ops, w.signals[b], w.dt, Ubar[b])
+        assert np.abs(g[b] - want).max() < 1e-10 * np.abs(want).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,N", [(41, 9), (48, 12), (64, 6), (81, 5)])
+def test_unitary_vjp_above_40_on_the_tiled_sweep(prop, D, N):
+    """c3p_pwc_unitary_vjp beyond the on-chip sweeps (D > 40, no cap any more): the tiled backward sweep, complex
+    Hermitian operators, frame rotation, norms that need squarings."""
+    from c3_amd import _lib
+
+    rng = np.random.default_rng(D)
+    herm = lambda s: (lambda a: s * (a + a.conj().T) / 2)(rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))
+    B, K = 2, 2
+    h0, hks = herm(0.25), np.stack([herm(0.15) for _ in range(K)])
+    sig = rng.uniform(-1, 1, size=(B, K, N))
+    Ubar = rng.normal(size=(B, D, D)) + 1j * rng.normal(size=(B, D, D))
+    ph = rng.uniform(0, 2 * np.pi, size=(B, D))
+    g = np.asarray(prop.propagate_batch_vjp(h0, hks, sig, 1.0, Ubar, fr_phase=ph))
+    assert _lib.last_kernel() == "mfma"
+    for b in range(B):
+        want = o.pwc_signal_gradient(h0, hks, sig[b], 1.0, Ubar[b], ph[b])
+        assert np.abs(g[b] - want).max() < 1e-10 * np.abs(want).max()

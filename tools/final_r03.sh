@@ -1,0 +1,58 @@
+# Round-3 closing measurements on one MI355X (everything lands under gpurun_out/final/; copy what is to be judged into
+# profiles/r03/): PMC passes of the bench command for cfg2..5 and the complex-Hamiltonian variant of cfg2 (-> pmc.json, so
+# that the bench lines that follow quote issued / useful flops and traffic for THIS build), the bench lines (all
+# configs, --complex, one gather per batch and the gather-free goal mode under torch.distributed.run with one rank), the
+# ODE benches and their rocprof passes, gradient timings.      bash tools/final_r03.sh
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/final
+mkdir -p $O $R/gpurun_out/r03
+cd $R
+for spec in "2 30" "3 4" "5 3" "4 3"; do
+  set -- $spec
+  bash tools/profile_r03.sh $1 $2
+  cp gpurun_out/pmc_cfg$1.json gpurun_out/cfg$1_pmc_summary.txt gpurun_out/cfg$1_kernel_stats.csv gpurun_out/cfg$1_bench_under_rocprof.json $O/ 2>/dev/null
+done
+bash tools/profile_r03.sh 2 30 --complex
+cp gpurun_out/pmc_cfg2_complex.json gpurun_out/cfg2_complex_pmc_summary.txt gpurun_out/cfg2_complex_kernel_stats.csv gpurun_out/cfg2_complex_bench_under_rocprof.json $O/ 2>/dev/null
+python - <<'PY'
+import json, os
+R = os.environ["GRAFT_REPO_ROOT"]
+out = {"_comment": "per-launch PMC figures of the dominant kernel of each bench configuration (tools/profile_r03.sh on the bench command WITH its clock ramp, tools/pmc_to_json.py); bench.py quotes issued / useful flops per sample and slice from here, traffic only when kernel_sources_digest, batch and slices match"}
+for tag in ("cfg2", "cfg3", "cfg4", "cfg5", "cfg2_complex"):
+    f = os.path.join(R, "gpurun_out", f"pmc_{tag}.json")
+    try:
+        out[tag] = json.load(open(f))
+    except Exception as e:
+        print("no pmc for", tag, e)
+os.makedirs(os.path.join(R, "profiles", "r03"), exist_ok=True)
+json.dump(out, open(os.path.join(R, "profiles", "r03", "pmc.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(R, "gpurun_out", "final", "pmc.json"), "w"), indent=1)
+PY
+for c in 2 1 3 4 5; do
+  python bench.py --config $c --check > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err
+  tail -c 400 $O/bench_cfg$c.json | head -c 200; echo
+done
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --complex --check --no-cpu-baseline > $O/bench_cfg2_complex.json 2> $O/bench_cfg2_complex.err
+TR="python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1"
+$TR --master-port 29611 bench.py --gpus 1 --steps 300 --warmup 10 --no-cpu-baseline --no-e2e > $O/bench_cfg2_rccl_gather32.json 2> $O/bench_rccl_gather32.err
+$TR --master-port 29612 bench.py --gpus 1 --steps 300 --warmup 10 --gather-every 1 --no-cpu-baseline --no-e2e > $O/bench_cfg2_rccl_gather1.json 2> $O/bench_rccl_gather1.err
+$TR --master-port 29613 bench.py --gpus 1 --steps 300 --warmup 10 --exchange goal --no-cpu-baseline --no-e2e > $O/bench_cfg2_rccl_goal.json 2> $O/bench_rccl_goal.err
+python bench.py --steps 300 --warmup 10 --exchange goal --no-cpu-baseline --no-e2e > $O/bench_cfg2_goal_single.json 2>/dev/null
+# ODE solver variant
+python tests/perf/bench_ode.py --config 2 --out $O/ode_cfg2.json > $O/ode_cfg2.log 2>&1
+python tests/perf/bench_ode.py --config 2 --complex-ops --solvers rk4 --batches 2048,131072 --rho-batches 16384 --out $O/ode_cfg2_complex.json > /dev/null 2>&1
+python tests/perf/bench_ode.py --config 3 --steps schrodinger --solvers rk4,tsit5 --batches 256,2048,16384 --out $O/ode_cfg3.json > /dev/null 2>&1
+python tests/perf/bench_ode.py --config 5 --steps schrodinger --solvers rk4 --batches 1024,8192 --out $O/ode_cfg5.json > /dev/null 2>&1
+C3P_ODE_WG=1 python tests/perf/bench_ode.py --config 2 --solvers rk4 --batches 2048 --rho-batches 2048 --out $O/ode_cfg2_round1_kernel.json > /dev/null 2>&1
+C3P_ODE_WG=1 python tests/perf/bench_ode.py --config 3 --steps schrodinger --solvers rk4 --batches 2048 --out $O/ode_cfg3_round1_kernel.json > /dev/null 2>&1
+bash tools/profile_ode.sh 16384 > /dev/null 2>&1
+cp gpurun_out/r03/ode_pmc_summary.txt gpurun_out/r03/ode_kernel_stats.csv $O/
+# gradients (kernels unchanged this round: timing only)
+python tools/bench_grad.py --config 2 --batch 256 --reps 20 > $O/grad_cfg2.json
+python tools/bench_grad.py --config 3 --batch 256 --reps 3 > $O/grad_cfg3.json
+python tools/bench_grad.py --config 5 --batch 256 --reps 3 > $O/grad_cfg5.json
+python tools/bench_midd_real_vs_complex.py > $O/midd_real_vs_complex.json 2> /dev/null
+python tests/perf/bench_complex_path.py > $O/complex_path_cfg2.json 2> /dev/null
+./tools/ubench_dpp > $O/ubench_dpp.txt 2>&1
+ls $O | wc -l
