@@ -68,6 +68,9 @@ struct DeviceWs {
   hipEvent_t done = nullptr;
   hipStream_t last_stream = nullptr;
   bool has_last = false;
+  // a BLOCKING stream of the library's own: calls made on the legacy default stream (what torch hands over by default)
+  // cannot capture graphs; work enqueued here is ordered against the default stream by the legacy-stream rule
+  hipStream_t aux = nullptr;
 };
 
 std::mutex g_mu;  // guards the table of per-device workspaces only
@@ -1007,8 +1010,14 @@ int run_vjp_tiled(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const c
   t.D = D;
   t.Dm = Dm;
   t.fr_phase = fr_phase;
+  // the per-slice launch sequences are replayed as hipGraphs, which the legacy default stream cannot capture
+  hipStream_t run = st;
+  if (!run) {
+    if (!w->aux) HIP_TRY(hipStreamCreate(&w->aux));
+    run = w->aux;
+  }
   std::string err;
-  if (c3p_tiled_vjp_run(t, U_bar, grad, v, Bc, st, err)) return fail("%s", err.c_str());
+  if (c3p_tiled_vjp_run(t, U_bar, grad, v, Bc, run, err)) return fail("%s", err.c_str());
   return 0;
 }
 
@@ -1224,7 +1233,7 @@ void c3p_shutdown(void) {
     DeviceWs* w = all[d];
     if (!w) continue;
     std::lock_guard<std::mutex> lk(w->mu);
-    bool any = w->ev0 != nullptr || w->done != nullptr;
+    bool any = w->ev0 != nullptr || w->done != nullptr || w->aux != nullptr;
     for (int s = 0; s < SL_COUNT; ++s) any = any || w->ptr[s];
     if (!any) continue;
     (void)hipSetDevice((int)d);
@@ -1243,6 +1252,10 @@ void c3p_shutdown(void) {
     if (w->done) {
       (void)hipEventDestroy(w->done);
       w->done = nullptr;
+    }
+    if (w->aux) {
+      (void)hipStreamDestroy(w->aux);
+      w->aux = nullptr;
     }
   }
   // the remembered stream may be destroyed by the caller after a shutdown: never touch it again
@@ -1804,8 +1817,11 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
     done = (rc == 0);
     if (done) g_last_kernel = C3P_KERNEL_MFMA;
   }
-  if (!done && !(flags & C3P_FORCE_GENERIC) && D > 40 && !gen_bar_out) {
-    // beyond the on-chip sweeps: forward partials in HBM, one pair evaluation of T18 per slice on the tiled MFMA GEMM
+  // beyond the on-chip sweeps: forward partials in HBM, one pair evaluation of T18 per slice on the tiled MFMA GEMM.  ~35
+  // launches per slice: below a few hundred samples the launches, not the GEMMs, set the time, and the VALU sweep (which
+  // stops at D = 64) is faster for 41 <= D <= 64 (profiles/r03/grad_tiled.json: D = 48, B = 64: 151 ms against 545 ms)
+  const bool tiled_grad = D > 64 || (D > 40 && (B >= 384 || getenv("C3P_TILED_GRAD")));
+  if (!done && !(flags & C3P_FORCE_GENERIC) && tiled_grad && !gen_bar_out) {
     if (run_vjp_tiled(w, 0, A.h0, h0_bstride, A.hks, hks_bstride, A.signals, nullptr, dt, B, K, N, D, D, A.fr_phase, A.Ubar, A.grad, st))
       return -1;
     done = true;

@@ -35,12 +35,16 @@ struct TG {
 
 // ---- C = A B (+ Add), batched over blockIdx.z ------------------------------------------------------------------------
 // (Add may alias C: every element is read and written by the same thread; C must not alias A or B)
+// nptr (optional): the slice index lives in device memory (the per-slice launch sequences of the backward sweep are captured
+// once into a hipGraph and replayed): B += (*nptr + noff) * nstride.
 __global__ void __launch_bounds__(256) tg_gemm_kernel(const double* A, const double* Bm, const double* Add, double* C, int rows2,
-                                                      int DPC, long strideA, long strideB, long strideC) {
+                                                      int DPC, long strideA, long strideB, long strideC, const int* nptr = nullptr,
+                                                      int noff = 0, long nstride = 0) {
   __shared__ double As[2][TG_BM * TG_SA];
   __shared__ double Bs[2][TG_KP * TG_SB];
   A += (long)blockIdx.z * strideA;
   Bm += (long)blockIdx.z * strideB;
+  if (nptr) Bm += (long)(*nptr + noff) * nstride;
   C += (long)blockIdx.z * strideC;
   if (Add) Add += (long)blockIdx.z * strideC;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -284,6 +288,8 @@ struct AsmArgs {
   double* X;     // [Bc][M_COUNT][MS] (slot M_X)
   double* mus;   // [Bc][2] running trace-shift sum
   double* mun;   // [Bc][2] this slice's trace shift
+  const int* nptr;  // slots kernel only: slice index from device memory (n = *nptr + noff) when set
+  int noff;
 };
 
 // X = 2^-s (G0 + sum_k c_k G_k)  (propagation.py:426-439), or 2^-s G(H_n) for per-slice Hamiltonians (:295-308)
@@ -337,7 +343,8 @@ __global__ void __launch_bounds__(256) tg_assemble_slots_kernel(AsmArgs P, int n
   double* X = P.X + (long)b * nslots * MS;
   const int ts = P.tab_per_sample ? b : 0;
   const double* T = P.tables + (long)ts * (1 + P.K) * MS;
-  const double* sg = P.signals + ((long)(P.b0 + b) * P.K) * P.N + P.n;
+  const int n = P.nptr ? *P.nptr + P.noff : P.n;
+  const double* sg = P.signals + ((long)(P.b0 + b) * P.K) * P.N + n;
   if (e < MS) {
     double v = T[e];
     for (int k = 0; k < P.K; ++k) v = fma(sg[(long)k * P.N], T[(long)(k + 1) * MS + e], v);
@@ -356,6 +363,8 @@ __global__ void __launch_bounds__(256) tg_assemble_slots_kernel(AsmArgs P, int n
     P.mus[2 * b + 1] = c3p_phase_add(P.mus[2 * b + 1], mi);
   }
 }
+
+__global__ void tg_count_kernel(int* n, int by) { *n += by; }
 
 // T18 combinations (c3p_common.h): from X, A2, A3, A6 -> T1 = B1, T2 = B5, T3 = B4, T4 = B3, X <- B2
 __global__ void __launch_bounds__(256) tg_combo_kernel(double* mats, int Dm, int DPR, int DPC) {
@@ -410,12 +419,12 @@ enum {
 
 // dst = src^H in the half-image layout: dst[2i][j] = src[2j][i], dst[2i+1][j] = -src[2j+1][i]
 __global__ void __launch_bounds__(256) tg_adjoint_kernel(const double* src, long sstride, double* dst, long dstride, int Dm, int DPR,
-                                                         int DPC) {
+                                                         int DPC, const int* nptr = nullptr, int noff = 0) {
   const long MS = 2L * DPR * DPC;
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= MS) return;
   const double* S = src + (long)blockIdx.y * sstride;
-  double* Dd = dst + (long)blockIdx.y * dstride;
+  double* Dd = dst + (long)blockIdx.y * dstride + (nptr ? (long)(*nptr + noff) * MS : 0);
   const int r = (int)(e / DPC), c = (int)(e - (long)r * DPC);
   const int i = r >> 1, p = r & 1;
   double v = 0.0;
@@ -495,9 +504,10 @@ __global__ void __launch_bounds__(256) tg_ubar_kernel(const cplx* ubar, const do
 // grad[b][k][n] = scale <Xbar, G_k> + Re(mu_k tau): one block per (k, sample)
 __global__ void __launch_bounds__(256) tg_graddot_kernel(const double* mats, int nslots, int slot, const double* tables, const double* meta,
                                                          int tab_per_sample, int K, const double* tau, double scale, double* grad, int b0,
-                                                         int n, int N, long MS) {
+                                                         const int* nptr, int noff, int N, long MS) {
   __shared__ double r1[256];
   const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int n = *nptr + noff;
   const double* X = mats + ((long)b * nslots + slot) * MS;
   const int ts = tab_per_sample ? b : 0;
   const double* G = tables + ((long)ts * (1 + K) + (k + 1)) * MS;
@@ -690,13 +700,44 @@ int c3p_tiled_run(const TiledArgs& A, void* ws, int Bc, hipStream_t st, std::str
 size_t c3p_tiled_vjp_ws_bytes(int Dm, int K, int N, int Bc, bool per_sample_tables) {
   const TG g(Dm);
   const size_t nt = per_sample_tables ? (size_t)Bc : 1;
-  return ((size_t)Bc * V_COUNT * g.MS + (size_t)Bc * N * g.MS + 2 * nt * (1 + K) * (g.MS + 4) + 12 * (size_t)Bc + 64) * sizeof(double);
+  return ((size_t)Bc * V_COUNT * g.MS + (size_t)Bc * (N + 1) * g.MS + 2 * nt * (1 + K) * (g.MS + 4) + 12 * (size_t)Bc + 64) * sizeof(double);
 }
 
 int c3p_tiled_vjp_chunk(int Dm, int K, int N, int B, bool per_sample_tables, size_t budget_bytes) {
   int bc = B;
   while (bc > 1 && c3p_tiled_vjp_ws_bytes(Dm, K, N, bc, per_sample_tables) > budget_bytes) bc = (bc + 1) / 2;
   return bc;
+}
+
+// Replays `body(pair)` `pairs` times.  With `use_graph` the body is captured ONCE into a hipGraph (it must be identical from
+// replay to replay: the slice index lives in device memory) and launched as a graph -- ~35 kernel launches per slice are
+// what bounds this sweep at a few hundred samples; otherwise (capture unsupported on this stream, e.g. the legacy default
+// stream, or the caller is capturing itself) the launches are issued one by one.
+template <typename F>
+int tg_replay(hipStream_t st, bool use_graph, int pairs, F&& body, std::string& err) {
+  if (pairs <= 0) return 0;
+  if (use_graph && pairs >= 2) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      body();
+      hipError_t e = hipStreamEndCapture(st, &graph);
+      if (e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+        for (int i = 0; i < pairs; ++i) TG_TRY(hipGraphLaunch(exec, st));
+        (void)hipGraphExecDestroy(exec);
+        (void)hipGraphDestroy(graph);
+        return 0;
+      }
+      if (graph) (void)hipGraphDestroy(graph);
+      (void)hipGetLastError();
+      err = "hipGraph capture of the slice sequence failed";
+      return -1;  // the captured launches did not run: no silent fallback with a half-advanced counter
+    }
+    (void)hipGetLastError();
+  }
+  for (int i = 0; i < pairs; ++i) body();
+  TG_TRY(hipGetLastError());
+  return 0;
 }
 
 int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, void* ws, int Bc, hipStream_t st, std::string& err) {
@@ -706,8 +747,8 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, void*
   const int K = A.K, N = A.N;
   const size_t nt = per_sample ? (size_t)Bc : 1;
   double* mats = reinterpret_cast<double*>(ws);
-  double* store = mats + (size_t)Bc * V_COUNT * MS;          // [Bc][N][MS]: adjoints of the forward partial products
-  double* tables = store + (size_t)Bc * N * MS;              // G_k - mu_k
+  double* store = mats + (size_t)Bc * V_COUNT * MS;          // [Bc][N + 1][MS]: slot n = B_n^H, adjoints of the forward partial products
+  double* tables = store + (size_t)Bc * (N + 1) * MS;        // G_k - mu_k
   double* tables_adj = tables + nt * (1 + K) * MS;           // their adjoints
   double* meta = tables_adj + nt * (1 + K) * MS;
   double* meta_adj = meta + nt * (1 + K) * 4;
@@ -716,9 +757,20 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, void*
   double* junk = mun + 2 * (size_t)Bc;  // trace-shift outputs of the backward assemblies (unused)
   double* tau = junk + 4 * (size_t)Bc;
   unsigned long long* red = reinterpret_cast<unsigned long long*>(tau + 2 * (size_t)Bc);
+  int* nctr = reinterpret_cast<int*>(red + 32);  // slice counter of the replayed launch sequences
   const unsigned ebl = (unsigned)((MS + 255) / 256);
   const dim3 ggrid((unsigned)(g.DPC / TG_BN), (unsigned)(2 * g.DPR / TG_BM), 1);
-  const long VS = (long)V_COUNT * MS, SS = (long)N * MS;
+  const long VS = (long)V_COUNT * MS, SS = (long)(N + 1) * MS;
+  // Replaying the slice sequences as hipGraphs is OPT-IN (C3P_TILED_GRAPH=1): measured at cfg4's operators, B = 16 / 64,
+  // 501 / 759 ms with graphs against 495 / 754 ms without -- the sweep is bound by the latency of its ~47 dependent small
+  // kernels per slice (a 192-deep GEMM on a 96 x 128 half image is 12 K-panels of ~0.8 us each), not by launch overhead.
+  // Graphs need a capturable stream: not the legacy default stream, not a stream that is itself being captured.
+  bool use_graph = st != nullptr && getenv("C3P_TILED_GRAPH") != nullptr;
+  if (use_graph) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) use_graph = false;
+    (void)hipGetLastError();
+  }
 
   for (int b0 = 0; b0 < A.B; b0 += Bc) {
     const int nb = A.B - b0 < Bc ? A.B - b0 : Bc;
@@ -742,14 +794,14 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, void*
       hipLaunchKernelGGL(tg_meta_kernel, dim3(1 + K, nts), dim3(256), 0, st, T);
       hipLaunchKernelGGL(tg_table_kernel, dim3(ebl, 1 + K, nts), dim3(256), 0, st, T, g.DPR, g.DPC);
       hipLaunchKernelGGL(tg_adjoint_kernel, dim3(ebl, (unsigned)(nts * (1 + K))), dim3(256), 0, st, tables, MS, tables_adj, MS, A.Dm,
-                         g.DPR, g.DPC);
+                         g.DPR, g.DPC, (const int*)nullptr, 0);
     }
     hipLaunchKernelGGL(tg_sigmax_kernel, dim3(K), dim3(256), 0, st, A.signals + (long)b0 * K * N, nb, K, N, red);
     TG_TRY(hipGetLastError());
     std::vector<double> hm((size_t)nts * (1 + K) * 4);
     std::vector<unsigned long long> hr(64);
     TG_TRY(hipMemcpyAsync(hm.data(), meta, hm.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    TG_TRY(hipMemcpyAsync(hr.data(), red, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    TG_TRY(hipMemcpyAsync(hr.data(), red, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     TG_TRY(hipStreamSynchronize(st));
     double bound = 0.0;
     for (int ti = 0; ti <= K; ++ti) {
@@ -768,25 +820,25 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, void*
       }
     }
     const double scale = ldexp(1.0, -s18);
-    // the adjoint generators' trace shifts are the conjugates (only the assemblies of the backward sweep read them; unused)
     TG_TRY(hipMemcpyAsync(meta_adj, meta, nt * (1 + K) * 4 * sizeof(double), hipMemcpyDeviceToDevice, st));
     TG_TRY(hipMemsetAsync(mus, 0, 2 * (size_t)Bc * sizeof(double), st));
+    TG_TRY(hipMemsetAsync(nctr, 0, sizeof(int), st));
     const dim3 eg(ebl, (unsigned)nb);
     dim3 gg = ggrid;
     gg.z = (unsigned)nb;
     auto M = [&](int slot) -> double* { return mats + (long)slot * MS; };
     auto gemm = [&](int a, int b, int add, int c) {
       hipLaunchKernelGGL(tg_gemm_kernel, gg, dim3(256), 0, st, M(a), M(b), add >= 0 ? M(add) : nullptr, M(c), 2 * g.DPR, g.DPC, VS, VS,
-                         VS);
+                         VS, (const int*)nullptr, 0, 0L);
     };
-    auto assemble = [&](const double* tabs, const double* mt, int n, double* ms, double* mn) {
+    // X (or X^H) of slice *nctr + off into slot V_Y
+    auto assemble = [&](const double* tabs, const double* mt, int off, double* ms, double* mn) {
       AsmArgs P = {};
       P.tables = tabs;
       P.meta = mt;
       P.tab_per_sample = per_sample ? 1 : 0;
       P.signals = A.signals;
       P.b0 = b0;
-      P.n = n;
       P.K = K;
       P.N = N;
       P.clp = A.clp;
@@ -795,12 +847,20 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, void*
       P.Dm = A.Dm;
       P.dt = A.dt;
       P.scale = scale;
-      P.X = mats;  // slot V_Y == M_X == 0 of a V_COUNT-slot sample block
+      P.X = mats;  // slot V_Y == 0 of a V_COUNT-slot sample block
       P.mus = ms;
       P.mun = mn;
+      P.nptr = nctr;
+      P.noff = off;
       hipLaunchKernelGGL(tg_assemble_slots_kernel, eg, dim3(256), 0, st, P, V_COUNT, g.DPR, g.DPC);
     };
-    // value side of T18 + squarings from the generator in slot V_Y; returns the slot of exp
+    auto copy_slot = [&](int src, int dst) -> int {
+      for (int b = 0; b < nb; ++b)
+        TG_TRY(hipMemcpyAsync(mats + (long)b * VS + (long)dst * MS, mats + (long)b * VS + (long)src * MS, MS * sizeof(double),
+                              hipMemcpyDeviceToDevice, st));
+      return 0;
+    };
+    // value side of T18 + squarings from the generator in slot V_Y; returns the slot of exp (the same for every slice)
     auto t18_value = [&]() -> int {
       gemm(V_Y, V_Y, -1, V_A2);
       gemm(V_Y, V_A2, -1, V_A3);
@@ -817,40 +877,55 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, void*
       }
       return e;
     };
-    // ---- forward: partial products P_n = E_n ... E_0 (trace-shifted), their adjoints stored ----
-    int pcur = V_P0;
-    for (int n = 0; n < N; ++n) {
-      assemble(tables, meta, n, mus, mun);
+    // ---- forward: partial products P_n = E_n ... E_0 (trace-shifted), their adjoints stored (slot n + 1 = B_{n+1}^H) ----
+    // one forward slice at counter + off: P_out = E P_in, adjoint -> store[n + 1] (the last one is never read)
+    auto fwd_slice = [&](int off, int pin, int pout) {
+      assemble(tables, meta, off, mus, mun);
       const int e = t18_value();
-      if (n == 0) {
-        for (int b = 0; b < nb; ++b)
-          TG_TRY(hipMemcpyAsync(mats + (long)b * VS + (long)pcur * MS, mats + (long)b * VS + (long)e * MS, MS * sizeof(double),
-                                hipMemcpyDeviceToDevice, st));
-      } else {
-        const int pn = pcur == V_P0 ? V_P1 : V_P0;
-        gemm(e, pcur, -1, pn);
-        pcur = pn;
-      }
-      if (n + 1 < N)  // B_{n+1}^H = P_n^H
-        hipLaunchKernelGGL(tg_adjoint_kernel, eg, dim3(256), 0, st, M(pcur), VS, store + (long)(n + 1) * MS, SS, A.Dm, g.DPR, g.DPC);
+      gemm(e, pin, -1, pout);
+      hipLaunchKernelGGL(tg_adjoint_kernel, eg, dim3(256), 0, st, M(pout), VS, store + MS, SS, A.Dm, g.DPR, g.DPC, (const int*)nctr, off);
+    };
+    int pcur = V_P0;
+    {
+      // slice 0: P_0 = E_0
+      assemble(tables, meta, 0, mus, mun);
+      const int e = t18_value();
+      if (copy_slot(e, pcur)) return -1;
+      if (N > 1)
+        hipLaunchKernelGGL(tg_adjoint_kernel, eg, dim3(256), 0, st, M(pcur), VS, store + MS, SS, A.Dm, g.DPR, g.DPC, (const int*)nctr, 0);
+      hipLaunchKernelGGL(tg_count_kernel, dim3(1), dim3(1), 0, st, nctr, 1);
       TG_TRY(hipGetLastError());
     }
+    {
+      int rem = N - 1;  // slices 1 .. N-1; the store has N slots (index n + 1 <= N - 1 is guaranteed by skipping the last write below)
+      if (rem > 0 && (rem & 1)) {
+        const int pn = pcur == V_P0 ? V_P1 : V_P0;
+        fwd_slice(0, pcur, pn);
+        hipLaunchKernelGGL(tg_count_kernel, dim3(1), dim3(1), 0, st, nctr, 1);
+        pcur = pn;
+        --rem;
+      }
+      const int pa = pcur, pb = pcur == V_P0 ? V_P1 : V_P0;
+      if (tg_replay(st, use_graph, rem / 2, [&]() {
+            fwd_slice(0, pa, pb);
+            fwd_slice(1, pb, pa);
+            hipLaunchKernelGGL(tg_count_kernel, dim3(1), dim3(1), 0, st, nctr, 2);
+          }, err))
+        return -1;
+    }
+    // (the counter is now N; the adjoint of P_{N-1} went to store slot N, which is one past the end: the store is sized N + 1)
     // ---- cotangent of the trace-shifted product and the trace-shift term ----
     int lcur = V_L0;
     hipLaunchKernelGGL(tg_ubar_kernel, dim3((unsigned)nb), dim3(256), 0, st, U_bar + (long)b0 * A.Dm * A.Dm, mus,
                        A.fr_phase ? A.fr_phase + (long)b0 * A.Dm : nullptr, M(pcur), VS, M(lcur), VS, tau, A.Dm, g.DPR, g.DPC);
+    hipLaunchKernelGGL(tg_count_kernel, dim3(1), dim3(1), 0, st, nctr, -1);  // counter = N - 1
     // ---- backward: Ebar_n = Lambda_n B_n^H, Xbar_n = L(X_n^H)[Ebar_n] by the pair evaluation of T18, Lambda_{n-1} = E_n^H Lambda_n ----
-    for (int n = N - 1; n >= 0; --n) {
-      if (n > 0) {
-        hipLaunchKernelGGL(tg_gemm_kernel, gg, dim3(256), 0, st, M(lcur), store + (long)n * MS, (const double*)nullptr, M(V_V), 2 * g.DPR,
-                           g.DPC, VS, SS, VS);
-      } else {
-        for (int b = 0; b < nb; ++b)
-          TG_TRY(hipMemcpyAsync(mats + (long)b * VS + (long)V_V * MS, mats + (long)b * VS + (long)lcur * MS, MS * sizeof(double),
-                                hipMemcpyDeviceToDevice, st));
-      }
-      assemble(tables_adj, meta_adj, n, junk, junk + 2 * (size_t)Bc);  // Y = X_n^H (scaled)
-      // derivative side first where it needs the un-overwritten values
+    // one backward slice at n = counter + off >= 1
+    auto bwd_slice = [&](int off, int lin, int lout, bool first_slice_zero) {
+      if (!first_slice_zero)
+        hipLaunchKernelGGL(tg_gemm_kernel, gg, dim3(256), 0, st, M(lin), store, (const double*)nullptr, M(V_V), 2 * g.DPR, g.DPC, VS, SS,
+                           VS, (const int*)nctr, off, MS);
+      assemble(tables_adj, meta_adj, off, junk, junk + 2 * (size_t)Bc);  // Y = X_n^H (scaled)
       gemm(V_Y, V_Y, -1, V_A2);
       gemm(V_V, V_Y, -1, V_DA2);
       gemm(V_Y, V_V, V_DA2, V_DA2);
@@ -881,12 +956,28 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, void*
         std::swap(de, dq);
       }
       hipLaunchKernelGGL(tg_graddot_kernel, dim3((unsigned)K, (unsigned)nb), dim3(256), 0, st, mats, V_COUNT, de, tables, meta,
-                         per_sample ? 1 : 0, K, tau, scale, grad, b0, n, N, MS);
-      if (n > 0) {
+                         per_sample ? 1 : 0, K, tau, scale, grad, b0, (const int*)nctr, off, N, MS);
+      if (lout >= 0) gemm(e, lin, -1, lout);  // Lambda_{n-1} = E_n^H Lambda_n
+    };
+    {
+      int rem = N - 1;  // slices N-1 .. 1
+      if (rem > 0 && (rem & 1)) {
         const int ln = lcur == V_L0 ? V_L1 : V_L0;
-        gemm(e, lcur, -1, ln);  // Lambda_{n-1} = E_n^H Lambda_n
+        bwd_slice(0, lcur, ln, false);
+        hipLaunchKernelGGL(tg_count_kernel, dim3(1), dim3(1), 0, st, nctr, -1);
         lcur = ln;
+        --rem;
       }
+      const int la = lcur, lb = lcur == V_L0 ? V_L1 : V_L0;
+      if (tg_replay(st, use_graph, rem / 2, [&]() {
+            bwd_slice(0, la, lb, false);
+            bwd_slice(-1, lb, la, false);
+            hipLaunchKernelGGL(tg_count_kernel, dim3(1), dim3(1), 0, st, nctr, -2);
+          }, err))
+        return -1;
+      // slice 0: B_0 = I, Ebar_0 = Lambda_0 (the counter is 0)
+      if (copy_slot(lcur, V_V)) return -1;
+      bwd_slice(0, lcur, -1, true);
       TG_TRY(hipGetLastError());
     }
   }

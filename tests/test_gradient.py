@@ -318,7 +318,13 @@ def test_unitary_vjp_above_40_on_the_tiled_sweep(prop, D, N):
     sig = rng.uniform(-1, 1, size=(B, K, N))
     Ubar = rng.normal(size=(B, D, D)) + 1j * rng.normal(size=(B, D, D))
     ph = rng.uniform(0, 2 * np.pi, size=(B, D))
-    g = np.asarray(prop.propagate_batch_vjp(h0, hks, sig, 1.0, Ubar, fr_phase=ph))
+    import os
+
+    os.environ["C3P_TILED_GRAD"] = "1"  # (41 <= D <= 64 takes the VALU sweep at this batch size by default)
+    try:
+        g = np.asarray(prop.propagate_batch_vjp(h0, hks, sig, 1.0, Ubar, fr_phase=ph))
+    finally:
+        os.environ.pop("C3P_TILED_GRAD")
     assert _lib.last_kernel() == "mfma"
     for b in range(B):
         want = o.pwc_signal_gradient(h0, hks, sig[b], 1.0, Ubar[b], ph[b])
