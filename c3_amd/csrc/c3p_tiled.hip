@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "c3p_tiled.h"
@@ -62,33 +63,46 @@ __global__ void __launch_bounds__(256) tg_gemm_kernel(const double* A, const dou
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (tg_d4){0.0, 0.0, 0.0, 0.0};
   const int npanel = rows2 / TG_KP;
-  double2 av = *reinterpret_cast<const double2*>(ap);
-  double2 bv0 = *reinterpret_cast<const double2*>(bp), bv1 = *reinterpret_cast<const double2*>(bp + 2);
-  for (int pn = 0; pn < npanel; ++pn) {
-    double* as = As[pn & 1];
-    double* bs = Bs[pn & 1];
+  // operand panels are fetched TWO iterations ahead (register ring of two): with one panel of look-ahead a small product
+  // (12 panels at Dm = 81, a handful of workgroups per CU) ran at one memory round trip per panel
+  double2 av[2], bv0[2], bv1[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int pq = q < npanel ? q : 0;
+    av[q] = *reinterpret_cast<const double2*>(ap + (long)pq * (TG_KP / 2));
+    const double* bn = bp + (long)pq * TG_KP * DPC;
+    bv0[q] = *reinterpret_cast<const double2*>(bn);
+    bv1[q] = *reinterpret_cast<const double2*>(bn + 2);
+  }
+  // one panel: stage slot Q (compile-time: a run-time selection between the two register slots would make every iteration
+  // wait for BOTH outstanding fetches), refill it with panel pn + 2, multiply
+  auto panel = [&](int pn, auto qtag) {
+    constexpr int Q = decltype(qtag)::value;
+    double* as = As[Q];
+    double* bs = Bs[Q];
+    const double2 avc = av[Q], b0c = bv0[Q], b1c = bv1[Q];
     // expand R(A): a value of a Re row feeds (row, 2j) and (row + 1, 2j + 1); of an Im row (row - 1, 2j + 1) negated and (row, 2j)
     if (a_p == 0) {
-      as[a_rb * TG_SA + 2 * a_j] = av.x;
-      as[(a_rb + 1) * TG_SA + 2 * a_j + 1] = av.x;
-      as[a_rb * TG_SA + 2 * a_j + 2] = av.y;
-      as[(a_rb + 1) * TG_SA + 2 * a_j + 3] = av.y;
+      as[a_rb * TG_SA + 2 * a_j] = avc.x;
+      as[(a_rb + 1) * TG_SA + 2 * a_j + 1] = avc.x;
+      as[a_rb * TG_SA + 2 * a_j + 2] = avc.y;
+      as[(a_rb + 1) * TG_SA + 2 * a_j + 3] = avc.y;
     } else {
-      as[a_rb * TG_SA + 2 * a_j + 1] = -av.x;
-      as[(a_rb + 1) * TG_SA + 2 * a_j] = av.x;
-      as[a_rb * TG_SA + 2 * a_j + 3] = -av.y;
-      as[(a_rb + 1) * TG_SA + 2 * a_j + 2] = av.y;
+      as[a_rb * TG_SA + 2 * a_j + 1] = -avc.x;
+      as[(a_rb + 1) * TG_SA + 2 * a_j] = avc.x;
+      as[a_rb * TG_SA + 2 * a_j + 3] = -avc.y;
+      as[(a_rb + 1) * TG_SA + 2 * a_j + 2] = avc.y;
     }
-    bs[b_row * TG_SB + b_c + 0] = bv0.x;
-    bs[b_row * TG_SB + b_c + 1] = bv0.y;
-    bs[b_row * TG_SB + b_c + 2] = bv1.x;
-    bs[b_row * TG_SB + b_c + 3] = bv1.y;
-    __syncthreads();  // (double buffered: the next iteration writes the other buffer, one barrier per panel)
-    if (pn + 1 < npanel) {
-      av = *reinterpret_cast<const double2*>(ap + (long)(pn + 1) * (TG_KP / 2));
-      const double* bn = bp + (long)(pn + 1) * TG_KP * DPC;
-      bv0 = *reinterpret_cast<const double2*>(bn);
-      bv1 = *reinterpret_cast<const double2*>(bn + 2);
+    bs[b_row * TG_SB + b_c + 0] = b0c.x;
+    bs[b_row * TG_SB + b_c + 1] = b0c.y;
+    bs[b_row * TG_SB + b_c + 2] = b1c.x;
+    bs[b_row * TG_SB + b_c + 3] = b1c.y;
+    __syncthreads();  // (double buffered: the next panel writes the other buffer, one barrier per panel)
+    if (pn + 2 < npanel) {
+      av[Q] = *reinterpret_cast<const double2*>(ap + (long)(pn + 2) * (TG_KP / 2));
+      const double* bn = bp + (long)(pn + 2) * TG_KP * DPC;
+      bv0[Q] = *reinterpret_cast<const double2*>(bn);
+      bv1[Q] = *reinterpret_cast<const double2*>(bn + 2);
     }
 #pragma unroll
     for (int ks = 0; ks < TG_KP / 4; ++ks) {
@@ -102,6 +116,10 @@ __global__ void __launch_bounds__(256) tg_gemm_kernel(const double* A, const dou
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
+  };
+  for (int pn = 0; pn < npanel; pn += 2) {
+    panel(pn, std::integral_constant<int, 0>{});
+    if (pn + 1 < npanel) panel(pn + 1, std::integral_constant<int, 1>{});
   }
   // D layout of 16x16x4: register v of lane l = element (4 v + l / 16, l % 16)
 #pragma unroll
