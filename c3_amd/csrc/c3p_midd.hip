@@ -28,6 +28,9 @@
 #include "c3p_common.h"
 #include "c3p_kernels.h"
 #include "c3p_midd.h"
+#ifndef C3P_MDR_BIG_WGS
+#define C3P_MDR_BIG_WGS 2  // workgroups per CU of the 48-row real classes (D = 33..40): 2 = 256 registers per wave
+#endif
 
 // The file is compiled as up to three translation units (__graft_entry__.build passes -DC3P_MIDD_PART=1|2|3: complex
 // chain kernels + tables, real-Hamiltonian instance, gradient sweep) so that they build concurrently; without the
@@ -417,7 +420,7 @@ struct MDR {
   static constexpr int WI = SWZ ? 32 : W;              // image row stride
   static constexpr int AREA = NIMG * 16 * NIGR * WI;   // doubles
   static constexpr int KP = 3;                         // control lines whose tables stay in registers
-  static constexpr int WGS = (AREA * 8 + 6144) * 3 <= 160 * 1024 ? 3 : 2;
+  static constexpr int WGS = (AREA * 8 + 6144) * 3 <= 160 * 1024 ? 3 : (C3P_MDR_BIG_WGS);
 };
 
 template <int NIG, int NJ, int W, bool DUS, int WV>

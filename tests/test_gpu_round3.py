@@ -401,3 +401,40 @@ def test_fused_infidelity_sum(prop):
     # host-pointer route
     r = fid.infid_sum(ideal, U, [0, 1], [3, 3], kind="unitary", want_each=True)
     assert np.abs(r["each"] - np.array([o.unitary_infid(ideal, U[b], index=[0, 1], dims=[3, 3]) for b in range(wl.B)]).real).max() < 1e-13
+
+
+# --------------------------------------------------------------------------
+# edge cases of the lane-row ODE kernels (the reference's loops accept them: propagation.py:687-752)
+# --------------------------------------------------------------------------
+
+
+def test_ode_row_edge_cases(prop):
+    """One sample, two time samples (the minimum the interpolation needs), a one-level system, a sample count that is not
+    a multiple of the samples per wavefront, an empty batch."""
+    from c3_amd import _lib
+
+    # N = 2, B = 1, D = 1 .. 3
+    for D in (1, 2, 3):
+        h0, hks, sig, ts = _ode_problem(D, 1, 1, 2, False, D)
+        psi = np.ones((D, 1), complex) / np.sqrt(D)
+        for solver in ("rk4", "rk5"):
+            out = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], psi, solver, "schrodinger"))
+            ref = o.ode_solver_arrays(h0, hks, sig[0], ts, psi, solver, "schrodinger")["states"]
+            assert out.shape == (1, 2, D, 1) and np.abs(out[0] - ref).max() < 1e-13
+        rho = psi @ psi.conj().T
+        out = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], rho, "rk4", "von_neumann"))
+        ref = o.ode_solver_arrays(h0, hks, sig[0], ts, rho, "rk4", "von_neumann")["states"]
+        assert np.abs(out[0] - ref).max() < 1e-13
+    assert _lib.last_kernel() == "ode_row"
+    # empty batch
+    h0, hks, sig, ts = _ode_problem(4, 2, 3, 10, False, 9)
+    out = prop.ode_solve_batch(h0, hks, sig[:0], ts[1] - ts[0], np.ones((4, 1), complex) / 2)
+    assert tuple(np.asarray(out).shape) == (0, 10, 4, 1)
+    # more control lines than the lane-row kernels hold in registers: the workgroup kernel takes over, same results
+    h0, hks, sig, ts = _ode_problem(5, 6, 3, 12, False, 21)
+    psi = np.zeros((5, 1), complex)
+    psi[1, 0] = 1.0
+    out = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], psi, "rk4", "schrodinger"))
+    assert _lib.last_kernel() == "ode_wg"
+    for b in range(3):
+        assert np.abs(out[b] - o.ode_solver_arrays(h0, hks, sig[b], ts, psi, "rk4", "schrodinger")["states"]).max() < 1e-12

@@ -52,6 +52,8 @@ cp gpurun_out/r03/ode_pmc_summary.txt gpurun_out/r03/ode_kernel_stats.csv $O/
 python tools/bench_grad.py --config 2 --batch 256 --reps 20 > $O/grad_cfg2.json
 python tools/bench_grad.py --config 3 --batch 256 --reps 3 > $O/grad_cfg3.json
 python tools/bench_grad.py --config 5 --batch 256 --reps 3 > $O/grad_cfg5.json
+python tools/bench_grad_tiled.py --out $O/grad_tiled.json > /dev/null 2>&1
+python tests/checks/check_tiled.py --time > $O/tiled_check.txt 2>&1
 python tools/bench_midd_real_vs_complex.py > $O/midd_real_vs_complex.json 2> /dev/null
 python tests/perf/bench_complex_path.py > $O/complex_path_cfg2.json 2> /dev/null
 ./tools/ubench_dpp > $O/ubench_dpp.txt 2>&1
