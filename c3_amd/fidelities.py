@@ -67,6 +67,9 @@ def gate_overlaps(ideal, actual, index=None, dims=None):
     return (out[0] if squeeze else out), L
 
 
+_rows_cache: Dict[tuple, object] = {}
+
+
 def infid_sum(ideal, actual, index=None, dims=None, kind: str = "unitary", want_each: bool = False):
     """Fused goal epilogue (c3p_gate_infid): returns `{"sum": [sum_b infid[b], B], "each": [B] or None}` for a batch of
     propagators on the device -- one small launch instead of the overlap kernel plus element-wise host-framework ops;
@@ -86,7 +89,12 @@ def infid_sum(ideal, actual, index=None, dims=None, kind: str = "unitary", want_
     if tuple(G.shape) != (L, L):
         raise C3PropError(f"C3:Error: ideal gate must be [{L},{L}] for index {index}, got {tuple(G.shape)}")
     if call.device:
-        rows_d = call.torch.as_tensor(rows, device=call.dev)
+        # the row indices are a function of (dims, index): uploaded once per device, not per call (an optimiser calls this
+        # every iteration)
+        key = (tuple(int(d) for d in dims), tuple(index) if index else None, str(call.dev))
+        rows_d = _rows_cache.get(key)
+        if rows_d is None:
+            rows_d = _rows_cache[key] = call.torch.as_tensor(rows, device=call.dev)
         out = call.torch.empty((2,), dtype=call.torch.float64, device=call.dev)
         each = call.torch.empty((B,), dtype=call.torch.float64, device=call.dev) if want_each else None
     else:
