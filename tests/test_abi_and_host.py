@@ -215,3 +215,14 @@ def test_computational_rows_match_projector():
         want = [int(np.argmax(P[:, a])) for a in range(P.shape[1])]
         assert list(fidelities.computational_rows(dims, index)) == want
     assert set(fidelities.fidelities) >= {"unitary_infid", "unitary_infid_set", "average_infid", "average_infid_set"}
+
+
+def test_dpp_blocks_are_hazard_guarded():
+    """The ODE lane-row kernels feed `v_fmac_f64_dpp` from inline asm; the ISA the compiler produced must keep every DPP
+    run behind its `s_nop` and free of VALU EXEC writes (tools/check_dpp_hazards.py; the mid-D source compiles in seconds,
+    the D <= 16 source -- 140 kernels -- is checked by `python tools/check_dpp_hazards.py` and in the closing script)."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazards.py"), "c3p_ode_rowq.hip"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
