@@ -989,14 +989,15 @@ int run_pwc_tiled(DeviceWs* w, const ChainArgs& a, bool per_slice, cplx* U_out, 
 // Tiled backward sweep (c3p_tiled.hip): any matrix dimension, unitary and Lindblad generators
 int run_vjp_tiled(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals,
                   const cplx* clp, double dt, int B, int K, int N, int D, int Dm, const double* fr_phase, const cplx* U_bar,
-                  double* grad, hipStream_t st) {
-  const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
+                  double* grad, hipStream_t st, bool per_slice = false, cplx* zout = nullptr) {
+  const bool per_sample = !per_slice && ((h0_bs != 0) || (hk_bs != 0));
   const int Bc = c3p_tiled_vjp_chunk(Dm, K, N, B, per_sample, (size_t)24 << 30);
   void* v;
   if (ws_get(w, SL_SCRATCH, c3p_tiled_vjp_ws_bytes(Dm, K, N, Bc, per_sample), &v)) return -1;
   if (g_dry) return 0;
   TiledArgs t = {};
   t.lindblad = lindblad;
+  t.per_slice = per_slice ? 1 : 0;
   t.h0 = h0;
   t.h0_bstride = h0_bs;
   t.hks = hks;
@@ -1017,7 +1018,7 @@ int run_vjp_tiled(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const c
     run = w->aux;
   }
   std::string err;
-  if (c3p_tiled_vjp_run(t, U_bar, grad, v, Bc, run, err)) return fail("%s", err.c_str());
+  if (c3p_tiled_vjp_run(t, U_bar, grad, zout, v, Bc, run, err)) return fail("%s", err.c_str());
   return 0;
 }
 
@@ -1749,9 +1750,37 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
                         const double* signals, double dt, int B, int K, int N, int D, int flags,
                         const double* fr_phase, const void* U_bar, double* grad_signals, void* gen_bar_out,
                         void* stream) {
+  if (flags & C3P_ORDER_RIGHT) return fail("c3p_pwc_unitary_vjp: unsupported flag");
+  if (flags & C3P_PER_SLICE_H) {
+    // branch B of pwc (propagation.py:295-308): the Hamiltonians are handed over per slice, so the result is the cotangent of
+    // every slice GENERATOR G_n = -i dt H_n (gen_bar_out) -- what the tape propagates on into model.get_Hamiltonian
+    if (B < 0 || N <= 0 || D <= 0) return fail("bad sizes B=%d N=%d D=%d", B, N, D);
+    if (B == 0) return 0;
+    if (!h0 || !U_bar || !gen_bar_out) return fail("per-slice gradient: h0 (the Hamiltonians), U_bar and gen_bar_out are required");
+    const size_t cs = sizeof(cplx);
+    hipStream_t st = (hipStream_t)stream;
+    WsLock lk(st);
+    DeviceWs* w = lk.w;
+    if (!w) return fail("no HIP device");
+    if (!lk.ok) return fail("hipStreamWaitEvent on the previous call's stream failed");
+    Stage sg{w, st};
+    const void *d_h = h0, *d_ph = fr_phase, *d_ub = U_bar;
+    void* d_z = gen_bar_out;
+    if (flags & C3P_HOST_PTRS) {
+      if (sg.in(h0, (size_t)(h0_bstride ? B : 1) * N * D * D * cs, &d_h)) return -1;
+      if (sg.in(U_bar, (size_t)B * D * D * cs, &d_ub)) return -1;
+      if (fr_phase && sg.in(fr_phase, (size_t)B * D * sizeof(double), &d_ph)) return -1;
+      if (sg.out(gen_bar_out, (size_t)B * N * D * D * cs, &d_z)) return -1;
+    }
+    g_last_kernel = C3P_KERNEL_MFMA;
+    if (run_vjp_tiled(w, 0, (const cplx*)d_h, h0_bstride, nullptr, 0, nullptr, nullptr, dt, B, 0, N, D, D, (const double*)d_ph,
+                      (const cplx*)d_ub, nullptr, st, true, (cplx*)d_z))
+      return -1;
+    if (flags & C3P_HOST_PTRS) return sg.finish();
+    return 0;
+  }
   if (B < 0 || K <= 0 || N <= 0 || D <= 0) return fail("bad sizes B=%d K=%d N=%d D=%d", B, K, N, D);
   if (D > 40 && gen_bar_out) return fail("gen_bar_out (per-slice generator cotangents) is available for D <= 40, got %d", D);
-  if (flags & (C3P_PER_SLICE_H | C3P_ORDER_RIGHT)) return fail("c3p_pwc_unitary_vjp: unsupported flag");
   if (B == 0) return 0;
   if (!h0 || !hks || !signals || !U_bar || !grad_signals) return fail("NULL pointer argument");
   const size_t cs = sizeof(cplx);

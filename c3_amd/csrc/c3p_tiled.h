@@ -36,4 +36,6 @@ int c3p_tiled_run(const TiledArgs& A, void* ws, int Bc, hipStream_t st, std::str
 //   U_bar [B,Dm,Dm]: d loss = Re sum conj(U_bar) dU;   grad f64 [B,K,N]
 int c3p_tiled_vjp_chunk(int Dm, int K, int N, int B, bool per_sample_tables, size_t budget_bytes);
 size_t c3p_tiled_vjp_ws_bytes(int Dm, int K, int N, int Bc, bool per_sample_tables);
-int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, void* ws, int Bc, hipStream_t st, std::string& err);
+//   per_slice (branch B): h0 = per-slice Hamiltonians, no signals; the result is zout c128 [B,N,Dm,Dm], the cotangent of every
+//   slice generator (grad unused)
+int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx* zout, void* ws, int Bc, hipStream_t st, std::string& err);

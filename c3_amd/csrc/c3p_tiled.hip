@@ -308,6 +308,7 @@ struct AsmArgs {
   double* mun;   // [Bc][2] this slice's trace shift
   const int* nptr;  // slots kernel only: slice index from device memory (n = *nptr + noff) when set
   int noff;
+  int adjoint;      // slots kernel, per-slice mode: assemble X^H instead of X
 };
 
 // X = 2^-s (G0 + sum_k c_k G_k)  (propagation.py:426-439), or 2^-s G(H_n) for per-slice Hamiltonians (:295-308)
@@ -359,9 +360,24 @@ __global__ void __launch_bounds__(256) tg_assemble_slots_kernel(AsmArgs P, int n
   const long MS = 2L * DPR * DPC;
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   double* X = P.X + (long)b * nslots * MS;
+  const int n = P.nptr ? *P.nptr + P.noff : P.n;
+  if (P.hs) {  // per-slice Hamiltonians (branch B): no tables, no trace shift
+    if (e < MS) {
+      const int r = (int)(e / DPC), c = (int)(e - (long)r * DPC);
+      const int i = r >> 1, p = r & 1;
+      double out = 0.0;
+      if (i < P.Dm && c < P.Dm) {
+        const cplx* h = P.hs + (long)(P.b0 + b) * P.hs_bstride + (long)n * P.Dh * P.Dh;
+        const cplx g = P.adjoint ? cconj(tg_gelem(h, P.clp, P.lindblad, P.Dh, P.Dm, P.dt, true, c, i))
+                                 : tg_gelem(h, P.clp, P.lindblad, P.Dh, P.Dm, P.dt, true, i, c);
+        out = P.scale * (p ? g.y : g.x);
+      }
+      X[e] = out;
+    }
+    return;
+  }
   const int ts = P.tab_per_sample ? b : 0;
   const double* T = P.tables + (long)ts * (1 + P.K) * MS;
-  const int n = P.nptr ? *P.nptr + P.noff : P.n;
   const double* sg = P.signals + ((long)(P.b0 + b) * P.K) * P.N + n;
   if (e < MS) {
     double v = T[e];
@@ -517,6 +533,19 @@ __global__ void __launch_bounds__(256) tg_ubar_kernel(const cplx* ubar, const do
     tau[2 * b] = r1[0];
     tau[2 * b + 1] = r2[0];
   }
+}
+
+// Z[b][n] = scale Xbar as interleaved complex [Dm][Dm] (per-slice mode: the cotangent of the slice generator)
+__global__ void __launch_bounds__(256) tg_genbar_kernel(const double* mats, int nslots, int slot, double scale, cplx* zout, long z_bstride,
+                                                        const int* nptr, int noff, int Dm, int DPR, int DPC) {
+  const int b = blockIdx.y;
+  const long MS = 2L * DPR * DPC;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)Dm * Dm) return;
+  const int n = *nptr + noff;
+  const int i = (int)(e / Dm), j = (int)(e - (long)i * Dm);
+  const double* M = mats + ((long)b * nslots + slot) * MS;
+  zout[(long)b * z_bstride + (long)n * Dm * Dm + e] = cmake(scale * M[(long)(2 * i) * DPC + j], scale * M[(long)(2 * i + 1) * DPC + j]);
 }
 
 // grad[b][k][n] = scale <Xbar, G_k> + Re(mu_k tau): one block per (k, sample)
@@ -758,11 +787,12 @@ int tg_replay(hipStream_t st, bool use_graph, int pairs, F&& body, std::string& 
   return 0;
 }
 
-int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, void* ws, int Bc, hipStream_t st, std::string& err) {
+int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx* zout, void* ws, int Bc, hipStream_t st, std::string& err) {
   const TG g(A.Dm);
   const long MS = g.MS;
-  const bool per_sample = (A.h0_bstride != 0 || A.hks_bstride != 0);
-  const int K = A.K, N = A.N;
+  const bool per_slice = A.per_slice != 0;  // branch B: h0 = per-slice Hamiltonians, result = generator cotangents (zout)
+  const bool per_sample = !per_slice && (A.h0_bstride != 0 || A.hks_bstride != 0);
+  const int K = per_slice ? 0 : A.K, N = A.N;
   const size_t nt = per_sample ? (size_t)Bc : 1;
   double* mats = reinterpret_cast<double*>(ws);
   double* store = mats + (size_t)Bc * V_COUNT * MS;          // [Bc][N + 1][MS]: slot n = B_n^H, adjoints of the forward partial products
@@ -794,40 +824,56 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, void*
     const int nb = A.B - b0 < Bc ? A.B - b0 : Bc;
     const int nts = per_sample ? nb : 1;
     TG_TRY(hipMemsetAsync(red, 0, 64 * sizeof(unsigned long long), st));
-    TabArgs T = {};
-    T.h0 = A.h0;
-    T.h0_bstride = A.h0_bstride;
-    T.hks = A.hks;
-    T.hks_bstride = A.hks_bstride;
-    T.clp = A.clp;
-    T.dt = A.dt;
-    T.K = K;
-    T.Dh = A.D;
-    T.Dm = A.Dm;
-    T.lindblad = A.lindblad;
-    T.b0 = per_sample ? b0 : 0;
-    T.tables = tables;
-    T.meta = meta;
-    if (b0 == 0 || per_sample) {
-      hipLaunchKernelGGL(tg_meta_kernel, dim3(1 + K, nts), dim3(256), 0, st, T);
-      hipLaunchKernelGGL(tg_table_kernel, dim3(ebl, 1 + K, nts), dim3(256), 0, st, T, g.DPR, g.DPC);
-      hipLaunchKernelGGL(tg_adjoint_kernel, dim3(ebl, (unsigned)(nts * (1 + K))), dim3(256), 0, st, tables, MS, tables_adj, MS, A.Dm,
-                         g.DPR, g.DPC, (const int*)nullptr, 0);
-    }
-    hipLaunchKernelGGL(tg_sigmax_kernel, dim3(K), dim3(256), 0, st, A.signals + (long)b0 * K * N, nb, K, N, red);
-    TG_TRY(hipGetLastError());
-    std::vector<double> hm((size_t)nts * (1 + K) * 4);
-    std::vector<unsigned long long> hr(64);
-    TG_TRY(hipMemcpyAsync(hm.data(), meta, hm.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    TG_TRY(hipMemcpyAsync(hr.data(), red, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    TG_TRY(hipStreamSynchronize(st));
     double bound = 0.0;
-    for (int ti = 0; ti <= K; ++ti) {
-      double nk = 0.0;
-      for (int sidx = 0; sidx < nts; ++sidx) nk = std::max(nk, hm[((size_t)sidx * (1 + K) + ti) * 4 + 2]);
-      double cm = 1.0;
-      if (ti > 0) memcpy(&cm, &hr[ti - 1], 8);
-      bound += cm * nk;
+    if (!per_slice) {
+      TabArgs T = {};
+      T.h0 = A.h0;
+      T.h0_bstride = A.h0_bstride;
+      T.hks = A.hks;
+      T.hks_bstride = A.hks_bstride;
+      T.clp = A.clp;
+      T.dt = A.dt;
+      T.K = K;
+      T.Dh = A.D;
+      T.Dm = A.Dm;
+      T.lindblad = A.lindblad;
+      T.b0 = per_sample ? b0 : 0;
+      T.tables = tables;
+      T.meta = meta;
+      if (b0 == 0 || per_sample) {
+        hipLaunchKernelGGL(tg_meta_kernel, dim3(1 + K, nts), dim3(256), 0, st, T);
+        hipLaunchKernelGGL(tg_table_kernel, dim3(ebl, 1 + K, nts), dim3(256), 0, st, T, g.DPR, g.DPC);
+        hipLaunchKernelGGL(tg_adjoint_kernel, dim3(ebl, (unsigned)(nts * (1 + K))), dim3(256), 0, st, tables, MS, tables_adj, MS, A.Dm,
+                           g.DPR, g.DPC, (const int*)nullptr, 0);
+      }
+      hipLaunchKernelGGL(tg_sigmax_kernel, dim3(K), dim3(256), 0, st, A.signals + (long)b0 * K * N, nb, K, N, red);
+      TG_TRY(hipGetLastError());
+      std::vector<double> hm((size_t)nts * (1 + K) * 4);
+      std::vector<unsigned long long> hr(64);
+      TG_TRY(hipMemcpyAsync(hm.data(), meta, hm.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      TG_TRY(hipMemcpyAsync(hr.data(), red, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+      TG_TRY(hipStreamSynchronize(st));
+      for (int ti = 0; ti <= K; ++ti) {
+        double nk = 0.0;
+        for (int sidx = 0; sidx < nts; ++sidx) nk = std::max(nk, hm[((size_t)sidx * (1 + K) + ti) * 4 + 2]);
+        double cm = 1.0;
+        if (ti > 0) memcpy(&cm, &hr[ti - 1], 8);
+        bound += cm * nk;
+      }
+      TG_TRY(hipMemcpyAsync(meta_adj, meta, nt * (1 + K) * 4 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    } else {
+      const long nmat = (long)nb * N;
+      hipLaunchKernelGGL(tg_hnorm_kernel, dim3((unsigned)nmat), dim3(64), 0, st, A.h0 + (long)b0 * A.h0_bstride, A.h0_bstride, N, A.D, red);
+      if (A.lindblad) hipLaunchKernelGGL(tg_hnorm_kernel, dim3(1), dim3(64), 0, st, A.clp, 0L, 1, A.Dm, red + 2);
+      TG_TRY(hipGetLastError());
+      std::vector<unsigned long long> hr(64);
+      TG_TRY(hipMemcpyAsync(hr.data(), red, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+      TG_TRY(hipStreamSynchronize(st));
+      double h1, hi, c1;
+      memcpy(&h1, &hr[0], 8);
+      memcpy(&hi, &hr[1], 8);
+      memcpy(&c1, &hr[2], 8);
+      bound = A.lindblad ? A.dt * (h1 + hi + c1) : A.dt * h1;
     }
     int s18 = 0;
     {
@@ -838,7 +884,6 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, void*
       }
     }
     const double scale = ldexp(1.0, -s18);
-    TG_TRY(hipMemcpyAsync(meta_adj, meta, nt * (1 + K) * 4 * sizeof(double), hipMemcpyDeviceToDevice, st));
     TG_TRY(hipMemsetAsync(mus, 0, 2 * (size_t)Bc * sizeof(double), st));
     TG_TRY(hipMemsetAsync(nctr, 0, sizeof(int), st));
     const dim3 eg(ebl, (unsigned)nb);
@@ -870,6 +915,11 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, void*
       P.mun = mn;
       P.nptr = nctr;
       P.noff = off;
+      if (per_slice) {
+        P.hs = A.h0;
+        P.hs_bstride = A.h0_bstride;
+        P.adjoint = (tabs == tables_adj) ? 1 : 0;
+      }
       hipLaunchKernelGGL(tg_assemble_slots_kernel, eg, dim3(256), 0, st, P, V_COUNT, g.DPR, g.DPC);
     };
     auto copy_slot = [&](int src, int dst) -> int {
@@ -973,8 +1023,12 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, void*
         std::swap(e, o);
         std::swap(de, dq);
       }
-      hipLaunchKernelGGL(tg_graddot_kernel, dim3((unsigned)K, (unsigned)nb), dim3(256), 0, st, mats, V_COUNT, de, tables, meta,
-                         per_sample ? 1 : 0, K, tau, scale, grad, b0, (const int*)nctr, off, N, MS);
+      if (per_slice)
+        hipLaunchKernelGGL(tg_genbar_kernel, dim3((unsigned)(((long)A.Dm * A.Dm + 255) / 256), (unsigned)nb), dim3(256), 0, st, mats, V_COUNT,
+                           de, scale, zout + (long)b0 * N * A.Dm * A.Dm, (long)N * A.Dm * A.Dm, (const int*)nctr, off, A.Dm, g.DPR, g.DPC);
+      else
+        hipLaunchKernelGGL(tg_graddot_kernel, dim3((unsigned)K, (unsigned)nb), dim3(256), 0, st, mats, V_COUNT, de, tables, meta,
+                           per_sample ? 1 : 0, K, tau, scale, grad, b0, (const int*)nctr, off, N, MS);
       if (lout >= 0) gemm(e, lin, -1, lout);  // Lambda_{n-1} = E_n^H Lambda_n
     };
     {

@@ -289,6 +289,42 @@ def propagate_batch_vjp(h0, hks, signals, dt: float, U_bar, *, fr_phase=None, fo
     return grad, g0, gk
 
 
+def propagate_per_slice_vjp(hs, dt: float, U_bar, *, fr_phase=None):
+    """Branch B of `pwc` (propagation.py:295-308: the model hands over one Hamiltonian per slice): vector-Jacobian
+    product of `propagate_batch(hs, None, None, dt)` w.r.t. the Hamiltonians.  hs [N,D,D] or [B,N,D,D]; returns the
+    cotangents of the Hamiltonians, [B,N,D,D] with d loss = Re sum conj(H_bar) dH (the slice generator is G_n = -i dt H_n, so
+    H_bar = i dt Z with Z the generator cotangent the library returns) -- what the reference's tape propagates on into
+    `model.get_Hamiltonian(signal)`."""
+    call = _Call(hs, U_bar, fr_phase)
+    hs = call.c128(hs)
+    D = int(hs.shape[-1])
+    if hs.ndim == 3:
+        B, N, bs = 1, int(hs.shape[0]), 0
+    elif hs.ndim == 4:
+        B, N = int(hs.shape[0]), int(hs.shape[1])
+        bs = N * D * D
+    else:
+        raise C3PropError(f"C3:Error: per-slice Hamiltonian must be [N,D,D] or [B,N,D,D], got {tuple(hs.shape)}")
+    U_bar = call.c128(U_bar)
+    if U_bar.ndim == 2:
+        U_bar = U_bar[None]
+    if hs.ndim == 3 and int(U_bar.shape[0]) != 1:
+        B = int(U_bar.shape[0])  # one Hamiltonian stack shared by B cotangents
+    if tuple(U_bar.shape) != (B, D, D):
+        raise C3PropError(f"C3:Error: U_bar must be [{B},{D},{D}], got {tuple(U_bar.shape)}")
+    if fr_phase is not None:
+        fr_phase = call.f64(fr_phase)
+        if tuple(fr_phase.shape) != (B, D):
+            raise C3PropError(f"C3:Error: fr_phase must be [{B},{D}], got {tuple(fr_phase.shape)}")
+    Z = call.empty((B, N, D, D))
+    _lib.check(
+        _lib.load().c3p_pwc_unitary_vjp(
+            _ptr(hs), bs, None, 0, None, float(dt), B, 0, N, D, call.flags | _lib.PER_SLICE_H, _ptr(fr_phase), _ptr(U_bar), None, _ptr(Z), call.stream
+        )
+    )
+    return (1j * dt) * Z
+
+
 def propagate_batch_lindblad_vjp(h0, hks, signals, dt: float, col_ops, U_bar, *, fr_phase=None):
     """Vector-Jacobian product of `propagate_batch(..., lindbladian=True)` w.r.t. the control samples: the reference
     tapes tf_propagation_lind (propagation.py:551-585) under the same GradientTape (optimizers/optimizer.py:206-216).

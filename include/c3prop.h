@@ -179,6 +179,10 @@ int c3p_rk4_unitary(const void* h0, const void* hks, const double* signals, cons
  *   gen_bar_out c128 [B,N,D,D] or NULL: Z[b,n], the cotangent of the slice generator G_n = -i dt H_n
  *   (d loss = Re sum conj(Z) dG); the gradient w.r.t. MODEL parameters follows by contraction, e.g.
  *   d loss / d h0 = i dt sum_n Z[b,n] (what ModelLearning differentiates, c3/optimizers/modellearning.py:300-341).
+ * With C3P_PER_SLICE_H (branch B of pwc, propagation.py:295-308): h0 = the per-slice Hamiltonians [N,D,D] (h0_bstride 0) or
+ *   [B,N,D,D], hks / signals / grad_signals NULL, K = 0, and gen_bar_out [B,N,D,D] (required) receives the cotangent of every
+ *   slice generator G_n = -i dt H_n, i.e. d loss / d H_n = i dt Z[b,n]: what the tape hands back to model.get_Hamiltonian.
+ *   Any dimension (tiled backward sweep).
  */
 int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride,
                         const double* signals, double dt, int B, int K, int N, int D, int flags,

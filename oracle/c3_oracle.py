@@ -1242,6 +1242,31 @@ def pwc_signal_gradient(h0, hks, signals, dt, Ubar, fr_phase=None) -> np.ndarray
     return g
 
 
+def pwc_per_slice_hamiltonian_cotangents(Hs, dt, Ubar, fr_phase=None) -> np.ndarray:
+    """Branch B (propagation.py:295-308): cotangents of the per-slice Hamiltonians, H_bar[n] with
+    d loss = Re sum conj(H_bar[n]) dH[n] for d loss = Re sum conj(Ubar) dU, U = diag(e^{i phase}) prod_n exp(-i H_n dt).
+    H_bar[n] = conj(-i dt) L(X_n^H)[W_n], W_n the cotangent of the slice exponential (L = Frechet derivative of exp).
+    Pinned by finite differences of the pinned propagator oracle (tests/test_gradient.py)."""
+    Hs = np.asarray(Hs, dtype=np.complex128)
+    N, D = Hs.shape[0], Hs.shape[-1]
+    Xs = [-1j * dt * Hs[n] for n in range(N)]
+    Es = [expm(X) for X in Xs]
+    pre = [np.eye(D, dtype=np.complex128)]
+    for n in range(N):
+        pre.append(Es[n] @ pre[-1])
+    post = [None] * N
+    acc = np.eye(D, dtype=np.complex128)
+    for n in range(N - 1, -1, -1):
+        post[n] = acc
+        acc = acc @ Es[n]
+    ph = np.exp(1j * np.asarray(fr_phase)) if fr_phase is not None else np.ones(D)
+    out = np.zeros((N, D, D), dtype=np.complex128)
+    for n in range(N):
+        W = (post[n].conj().T * np.conj(ph)[None, :]) @ np.asarray(Ubar) @ pre[n].conj().T
+        out[n] = (1j * dt) * expm_frechet(Xs[n].conj().T, W)
+    return out
+
+
 def pwc_lindblad_signal_gradient(h0, hks, col_ops, signals, dt, Ubar, fr_phase=None) -> np.ndarray:
     """d loss / d signals[k, n] for loss with d loss = Re sum conj(Ubar) dU, U the Lindblad superoperator of
     propagation.py:551-585 (what the reference obtains by taping tf_propagation_lind, optimizer.py:206-216): one

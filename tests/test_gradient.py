@@ -329,3 +329,43 @@ def test_unitary_vjp_above_40_on_the_tiled_sweep(prop, D, N):
     for b in range(B):
         want = o.pwc_signal_gradient(h0, hks, sig[b], 1.0, Ubar[b], ph[b])
         assert np.abs(g[b] - want).max() < 1e-10 * np.abs(want).max()
+
+
+def test_oracle_per_slice_cotangents_match_finite_differences():
+    rng = np.random.default_rng(12)
+    D, N = 4, 5
+    herm = lambda: (lambda a: (a + a.conj().T) / 2)(rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))
+    Hs = np.stack([herm() for _ in range(N)])
+    Ubar = rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))
+    ph = rng.uniform(0, 2 * np.pi, size=D)
+    dt = 0.4
+    Hb = o.pwc_per_slice_hamiltonian_cotangents(Hs, dt, Ubar, ph)
+
+    def loss(H):
+        U = o.propagate_batch(H, None, None, dt) if False else None
+        U = np.eye(D, dtype=complex)
+        for n in range(N):
+            U = o.expm(-1j * dt * H[n]) @ U
+        return np.real(np.vdot(Ubar, np.exp(1j * ph)[:, None] * U))
+
+    for trial in range(4):
+        dH = np.stack([rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)) for _ in range(N)])  # any direction, not only Hermitian
+        eps = 1e-6
+        fd = (loss(Hs + eps * dH) - loss(Hs - eps * dH)) / (2 * eps)
+        assert abs(fd - np.real(np.sum(np.conj(Hb) * dH))) < 1e-8 * max(1.0, abs(fd))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,N,B", [(3, 11, 2), (9, 8, 3), (24, 6, 2), (50, 4, 1)])
+def test_per_slice_vjp_vs_oracle(prop, D, N, B):
+    """c3p_pwc_unitary_vjp with C3P_PER_SLICE_H (branch B): cotangents of the per-slice Hamiltonians on the tiled sweep."""
+    rng = np.random.default_rng(D + N)
+    herm = lambda s: (lambda a: s * (a + a.conj().T) / 2)(rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))
+    Hs = np.stack([np.stack([herm(0.6 / np.sqrt(D)) for _ in range(N)]) for _ in range(B)])
+    Ubar = rng.normal(size=(B, D, D)) + 1j * rng.normal(size=(B, D, D))
+    ph = rng.uniform(0, 2 * np.pi, size=(B, D))
+    dt = 1.3
+    got = np.asarray(prop.propagate_per_slice_vjp(Hs, dt, Ubar, fr_phase=ph))
+    for b in range(B):
+        want = o.pwc_per_slice_hamiltonian_cotangents(Hs[b], dt, Ubar[b], ph[b])
+        assert np.abs(got[b] - want).max() < 1e-10 * np.abs(want).max()
