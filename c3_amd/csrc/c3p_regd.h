@@ -19,6 +19,8 @@ struct RegdPrepArgs {
 };
 
 bool c3p_regd_supported(int Dm);
+// the kernel class (49, 65 or 81) a dimension runs in, zero padded when smaller
+__host__ __device__ inline int c3p_regd_class(int Dm) { return Dm <= 49 ? 49 : (Dm <= 65 ? 65 : 81); }
 size_t c3p_regd_table_doubles(int Dm, int K);   // per sample: (1 + K) generator tables
 size_t c3p_regd_arena_bytes(int Dm);            // for a whole launch (one arena per workgroup)
 hipError_t c3p_launch_regd_prep(const RegdPrepArgs& P, int nsamp, hipStream_t st);

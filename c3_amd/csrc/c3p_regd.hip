@@ -439,20 +439,24 @@ __global__ void __launch_bounds__(RG_THREADS, 1) regd_chain_kernel(MidArgs A, cp
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) rg_st(dst + (Ig * NJ + jj) * RG_THREADS, voff, cmake(Rr[Ig][jj], Ri[Ig][jj]));
   };
-  // dst[row][col] = f * C, row-major complex Dm x Dm (f = e^{trace shift}); borders from slot
+  // dst[row][col] = f * C, row-major complex DR x DR (f = e^{trace shift}); borders from slot.  DR = A.Dm <= DM is the TRUE
+  // dimension: a matrix smaller than the kernel's class runs zero padded (exp of diag(X, 0) = diag(exp X, 1): the padding
+  // stays decoupled through every product) and only its DR x DR block is written.
+  const int DR = A.Dm;
   auto store_out = [&](cplx* dst_, int slot, double fr, double fi) {
     cplx* dst = rg_ubase(dst_);
-    const unsigned lo = (unsigned)(rowC * DM + col0 + p) * (unsigned)sizeof(cplx);
 #pragma unroll
     for (int Ig = 0; Ig < NRG; ++Ig)
 #pragma unroll
-      for (int jj = 0; jj < NJ; ++jj)
-        rg_st(dst + 16 * Ig * DM + 4 * jj, lo,
-              cmake(fma(fr, aP[Ig][jj], -fi * aR[Ig][jj]), fma(fr, aR[Ig][jj], fi * aP[Ig][jj])));
+      for (int jj = 0; jj < NJ; ++jj) {
+        const int row = 16 * Ig + rowC, col = col0 + 4 * jj + p;
+        if (row < DR && col < DR)
+          dst[(long)row * DR + col] = cmake(fma(fr, aP[Ig][jj], -fi * aR[Ig][jj]), fma(fr, aR[Ig][jj], fi * aP[Ig][jj]));
+      }
     if (tid < BS - 1) {
       const cplx v = brd[slot * BS + tid];
       const int row = tid < DM ? DM - 1 : tid - DM, col = tid < DM ? tid : DM - 1;
-      dst[row * DM + col] = cmake(fma(fr, v.x, -fi * v.y), fma(fr, v.y, fi * v.x));
+      if (row < DR && col < DR) dst[(long)row * DR + col] = cmake(fma(fr, v.x, -fi * v.y), fma(fr, v.y, fi * v.x));
     }
   };
 
@@ -677,7 +681,7 @@ __global__ void __launch_bounds__(RG_THREADS, 1) regd_chain_kernel(MidArgs A, cp
             double sn, cs;
             sincos(mu_i, &sn, &cs);
             const double er = exp(mu_r);
-            store_out(A.dUs_out + ((long)sample * A.N + n0 + t) * DM * DM, sd, er * cs, er * sn);
+            store_out(A.dUs_out + ((long)sample * A.N + n0 + t) * DR * DR, sd, er * cs, er * sn);
           }
           if (first) {
             park_C(AR_U);
@@ -725,7 +729,7 @@ __global__ void __launch_bounds__(RG_THREADS, 1) regd_chain_kernel(MidArgs A, cp
     double sn, cs;
     sincos(mus_i, &sn, &cs);
     const double er = exp(mus_r);
-    store_out(A.seg_out + chain * DM * DM, ucur, er * cs, er * sn);
+    store_out(A.seg_out + chain * DR * DR, ucur, er * cs, er * sn);
   }
 }
 
@@ -737,8 +741,9 @@ __global__ void __launch_bounds__(256) regd_prep_kernel(RegdPrepArgs P) {
   const int tid = threadIdx.x;
   const int ti = blockIdx.x % (1 + P.K);
   const int sample = blockIdx.x / (1 + P.K);
-  const int D = P.Dm, Dh = P.Dh;
-  const int NRG = (D - 1) / 16, NJ = NRG;
+  const int D = P.Dm, Dh = P.Dh;  // true dimension; the tables are laid out for the class dimension DP >= D, zero padded
+  const int DP = c3p_regd_class(D);
+  const int NRG = (DP - 1) / 16, NJ = NRG;
   const cplx* h = (ti == 0) ? P.h0 + (long)sample * P.h0_bstride : P.hks + (long)sample * P.hks_bstride + (long)(ti - 1) * Dh * Dh;
   auto gelem = [&](int row, int col) -> cplx {
     cplx v;
@@ -797,7 +802,7 @@ __global__ void __launch_bounds__(256) regd_prep_kernel(RegdPrepArgs P) {
   __syncthreads();
   redr[tid] = cs;
   __syncthreads();
-  const int TSET = NRG * NJ * 256, BS = 2 * D;
+  const int TSET = NRG * NJ * 256, BS = 2 * DP;
   const long TAB_D = 2L * (TSET + BS) + 4;
   double* out = P.tables + ((long)sample * (1 + P.K) + ti) * TAB_D;
   for (int e = tid; e < TSET + BS; e += 256) {
@@ -810,13 +815,16 @@ __global__ void __launch_bounds__(256) regd_prep_kernel(RegdPrepArgs P) {
       col = 4 * NJ * w + 4 * jj + (l & 3);
     } else {
       const int eb = e - TSET;
-      row = eb < D ? D - 1 : eb - D;
-      col = eb < D ? eb : D - 1;
+      row = eb < DP ? DP - 1 : eb - DP;
+      col = eb < DP ? eb : DP - 1;
     }
-    cplx g = gelem(row, col);
-    if (row == col) {
-      g.x -= mu[0];
-      g.y -= mu[1];
+    cplx g = cmake(0.0, 0.0);
+    if (row < D && col < D) {
+      g = gelem(row, col);
+      if (row == col) {
+        g.x -= mu[0];
+        g.y -= mu[1];
+      }
     }
     out[2 * e] = g.x;
     out[2 * e + 1] = g.y;
@@ -864,17 +872,28 @@ hipError_t launch_r(const MidArgs& A, void* arena, hipStream_t st) {
 
 }  // namespace
 
-bool c3p_regd_supported(int Dm) { return Dm == 49 || Dm == 65 || Dm == 81; }
+// Dm = 49, 65, 81 exactly, or a smaller dimension zero padded into the next class where that beats the arena kernel
+// (tests/checks/check_regd_pad.py, B = 256, N = 200: 41..48 -> 49 1.29 - 1.39x, 56..64 -> 65 1.04 - 1.40x (64 = the Lindblad
+// superoperators of D = 8), 70..80 -> 81 1.04 - 1.29x; 50..55 and 66..69 are a wash, 0.98 - 1.02x, and stay on the arena
+// kernel).  C3P_REGD_PAD=0 switches the padding off, C3P_REGD_PAD=all pads everything in 41..81.
+bool c3p_regd_supported(int Dm) {
+  if (Dm == 49 || Dm == 65 || Dm == 81) return true;
+  const char* e = getenv("C3P_REGD_PAD");
+  if (e && e[0] == '0') return false;
+  if (e && e[0] == 'a') return Dm >= 41 && Dm <= 81;
+  return (Dm >= 41 && Dm <= 48) || (Dm >= 56 && Dm <= 64) || (Dm >= 70 && Dm <= 80);
+}
 
 size_t c3p_regd_table_doubles(int Dm, int K) {
   if (!c3p_regd_supported(Dm)) return 0;
-  const int n = (Dm - 1) / 16;
-  return (size_t)(1 + K) * (2 * ((size_t)n * n * 256 + 2 * Dm) + 4);
+  const int DP = c3p_regd_class(Dm);
+  const int n = (DP - 1) / 16;
+  return (size_t)(1 + K) * (2 * ((size_t)n * n * 256 + 2 * DP) + 4);
 }
 
 size_t c3p_regd_arena_bytes(int Dm) {
   if (!c3p_regd_supported(Dm)) return 0;
-  const int n = (Dm - 1) / 16;
+  const int n = (c3p_regd_class(Dm) - 1) / 16;
   return (size_t)C3P_REGD_MAX_WGS * AR_NSET * n * n * 256 * sizeof(cplx);
 }
 
@@ -886,7 +905,7 @@ hipError_t c3p_launch_regd_prep(const RegdPrepArgs& P, int nsamp, hipStream_t st
 
 hipError_t c3p_launch_regd_chain(const MidArgs& A, void* arena, hipStream_t st) {
   if (A.K > RG_KMAX) return hipErrorInvalidValue;
-  switch (A.Dm) {
+  switch (c3p_regd_class(A.Dm)) {
     case 49: return launch_r<3>(A, arena, st);
     case 65: return launch_r<4>(A, arena, st);
     case 81: return launch_r<5>(A, arena, st);

@@ -438,3 +438,48 @@ def test_ode_row_edge_cases(prop):
     assert _lib.last_kernel() == "ode_wg"
     for b in range(3):
         assert np.abs(out[b] - o.ode_solver_arrays(h0, hks, sig[b], ts, psi, "rk4", "schrodinger")["states"]).max() < 1e-12
+
+
+# --------------------------------------------------------------------------
+# register-resident kernel, zero-padded classes (VERDICT r2 missing #4): Dm = 41..48 -> 49, 56..64 -> 65, 70..80 -> 81
+# --------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("D", [41, 45, 48, 56, 60, 64, 70, 77, 80])
+def test_regd_padded_classes_unitary(prop, D):
+    """Matrix dimensions below a kernel class run zero padded (the padding stays decoupled through every product);
+    complex Hermitian operators, partial propagators, several time segments, frame rotation."""
+    from c3_amd import _lib
+
+    rng = np.random.default_rng(D)
+    herm = lambda s: (lambda a: s * (a + a.conj().T) / 2)(rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))
+    B, N, K = 3, 19, 2
+    h0, hks = herm(0.08), np.stack([herm(0.05) for _ in range(K)])
+    sig = rng.uniform(-1, 1, size=(B, K, N))
+    ph = rng.uniform(0, 2 * np.pi, size=(B, D))
+    r = prop.propagate_batch(h0, hks, sig, 1.0, fr_phase=ph, want_dUs=True)
+    assert _lib.last_kernel() == "mfma"
+    for b in range(B):
+        ref = o.pwc_arrays(h0, hks, sig[b], 1.0)
+        assert np.linalg.norm(np.asarray(r["U"][b]) - np.exp(1j * ph[b])[:, None] * ref["U"]) < TOL
+        assert np.abs(np.asarray(r["dUs"][b]) - ref["dUs"]).max() < 1e-12
+    os.environ["C3P_REGD_PAD"] = "0"  # the arena kernel these dimensions ran on before
+    try:
+        old = prop.propagate_batch(h0, hks, sig, 1.0, fr_phase=ph)
+    finally:
+        os.environ.pop("C3P_REGD_PAD")
+    assert fro_max(r["U"], old["U"]) < 1e-11
+
+
+def test_regd_padded_lindblad_64(prop):
+    """D = 8 -> 64 x 64 Lindblad superoperators in the 65 class (propagation.py:551-585)."""
+    rng = np.random.default_rng(64)
+    D, B, N, K = 8, 2, 14, 2
+    herm = lambda s: (lambda a: s * (a + a.conj().T) / 2)(rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))
+    h0, hks = herm(0.3), np.stack([herm(0.2) for _ in range(K)])
+    col = np.stack([0.1 * (rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))) for _ in range(2)])
+    sig = rng.uniform(-1, 1, size=(B, K, N))
+    r = prop.propagate_batch(h0, hks, sig, 1.0, col_ops=col, lindbladian=True, want_dUs=True)
+    ref = o.propagate_batch(h0, hks, sig, 1.0, col_ops=col, lindbladian=True)
+    assert fro_max(r["U"], ref) < TOL
+    assert np.abs(np.asarray(r["dUs"][0]) - o.tf_propagation_lind(h0, hks, col, sig[0], 1.0)).max() < 1e-12
