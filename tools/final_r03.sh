@@ -48,6 +48,9 @@ C3P_ODE_WG=1 python tests/perf/bench_ode.py --config 2 --solvers rk4 --batches 2
 C3P_ODE_WG=1 python tests/perf/bench_ode.py --config 3 --steps schrodinger --solvers rk4 --batches 2048 --out $O/ode_cfg3_round1_kernel.json > /dev/null 2>&1
 bash tools/profile_ode.sh 16384 > /dev/null 2>&1
 cp gpurun_out/r03/ode_pmc_summary.txt gpurun_out/r03/ode_kernel_stats.csv $O/
+python tools/ode_pmc_to_json.py 16384 1000 > $O/ode_roofline.json
+python tools/check_dpp_hazards.py > $O/dpp_hazard_check.txt 2>&1
+python tests/checks/check_regd_pad.py > $O/regd_padded_classes.txt 2>/dev/null
 # gradients (kernels unchanged this round: timing only)
 python tools/bench_grad.py --config 2 --batch 256 --reps 20 > $O/grad_cfg2.json
 python tools/bench_grad.py --config 3 --batch 256 --reps 3 > $O/grad_cfg3.json
