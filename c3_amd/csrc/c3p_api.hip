@@ -1395,6 +1395,36 @@ int c3p_superop(const void* A, int n, int D, int which, int flags, void* out, vo
   return kron_common(A, nullptr, n, D, D, which + 1, flags, out, stream);
 }
 
+}  // extern "C"
+
+namespace {
+// Segmented integration (see c3p_ode_solve): `a` describes the plain problem (M = 1: a state, or M = D: rk4_unitary).
+// U_out (or NULL) receives the step map of the whole interval [B,D,D]; psi_out (or NULL) = map x init.
+int ode_segmented(DeviceWs* w, OdeArgs a, int nseg, const cplx* init, long init_bstride, cplx* U_out, cplx* psi_out, hipStream_t st) {
+  const int D = a.D, B = a.B;
+  const size_t cs = sizeof(cplx);
+  void *v_id, *v_maps, *v_U = U_out;
+  if (ws_get(w, SL_CLP, (size_t)D * D * cs, &v_id)) return -1;
+  if (ws_get(w, SL_SEG_A, (size_t)B * nseg * D * D * cs, &v_maps)) return -1;
+  if (!v_U && ws_get(w, SL_SCRATCH, (size_t)B * D * D * cs, &v_U)) return -1;
+  if (g_dry) return 0;
+  LAUNCH_TRY(c3p_launch_ode_identity((cplx*)v_id, D, st));
+  a.M = D;
+  a.init = (const cplx*)v_id;
+  a.init_bstride = 0;
+  a.want_all = 0;
+  a.seg_count = nseg;
+  a.seg_len = (a.n_steps + nseg - 1) / nseg;
+  a.states = (cplx*)v_maps;
+  LAUNCH_TRY(c3p_launch_ode_row(a, nullptr, st));
+  if (combine_smalld(w, (const cplx*)v_maps, B, nseg, D, 0, nullptr, (cplx*)v_U, st)) return -1;
+  if (psi_out) HIP_TRY(c3p_launch_ode_apply((const cplx*)v_U, init, init_bstride, psi_out, B, D, st));
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
 int c3p_ode_solve(const void* h0, const void* hks, const double* signals, const void* col_ops,
                   int C, double dt, int B, int K, int N, int D, int solver, int step,
                   const void* init, int64_t init_bstride, int want_all, int flags, void* states,
@@ -1454,7 +1484,15 @@ int c3p_ode_solve(const void* h0, const void* hks, const double* signals, const 
     if (C > 0 && ws_get(w, SL_TABLES, c3p_ode_row_aux_bytes(D, C), &aux)) return -1;
     g_last_kernel = C3P_KERNEL_ODE_ROW;
     if (record_start(w, st)) return -1;
-    LAUNCH_TRY(c3p_launch_ode_row(a, aux, st));
+    const int nseg = (step == C3P_STEP_SCHRODINGER) ? c3p_ode_row_segments(a) : 0;
+    if (nseg > 0) {
+      // small batch, final state only: the equations are linear, so the interval is cut into nseg time segments, every
+      // segment integrates the D columns of the identity (its step map), the maps are multiplied in order by the small-D
+      // chain kernel and the product is applied to the initial state -- D x the arithmetic on nseg x D x the lanes
+      if (ode_segmented(w, a, nseg, (const cplx*)d_init, init_bstride, nullptr, (cplx*)d_states, st)) return -1;
+    } else {
+      LAUNCH_TRY(c3p_launch_ode_row(a, aux, st));
+    }
     if (record_stop(w, st)) return -1;
     if (flags & C3P_HOST_PTRS) return sg.finish();
     return 0;
@@ -1515,12 +1553,7 @@ int c3p_rk4_unitary(const void* h0, const void* hks, const double* signals, cons
   // identity initial state, shared by all samples
   void* v_id;
   if (ws_get(w, SL_CLP, (size_t)D * D * cs, &v_id)) return -1;
-  {
-    std::vector<cplx> eye((size_t)D * D, cmake(0, 0));
-    for (int i = 0; i < D; ++i) eye[(size_t)i * D + i] = cmake(1, 0);
-    HIP_TRY(hipMemcpyAsync(v_id, eye.data(), eye.size() * cs, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
-  }
+  LAUNCH_TRY(c3p_launch_ode_identity((cplx*)v_id, D, st));  // (on the device: no host round trip, capturable)
   OdeArgs a = {};
   a.h0 = (const cplx*)d_h0;
   a.hks = (const cplx*)d_hks;
@@ -1545,7 +1578,12 @@ int c3p_rk4_unitary(const void* h0, const void* hks, const double* signals, cons
     g_last_kernel = C3P_KERNEL_ODE_ROW;
     a.want_all = 0;
     a.states = (cplx*)d_U;
-    LAUNCH_TRY(c3p_launch_ode_row(a, nullptr, st));
+    const int nseg = c3p_ode_row_segments(a);
+    if (nseg > 0) {  // few gates: time segments fill the chip (see c3p_ode_solve)
+      if (ode_segmented(w, a, nseg, nullptr, 0, (cplx*)d_U, nullptr, st)) return -1;
+    } else {
+      LAUNCH_TRY(c3p_launch_ode_row(a, nullptr, st));
+    }
     if (d_dUs) {
       a.want_all = 1;
       a.reset_each_step = 1;

@@ -26,6 +26,10 @@ struct OdeArgs {
   cplx* states;
   cplx* scratch;
   long scratch_stride;
+  // time segments (lane-row vector kernel, final state / propagator only): with seg_count > 0 every (sample, column) is
+  // integrated over seg_count step ranges of seg_len steps from the IDENTITY, and states receives the segment maps
+  // [B, seg_count, D, M] (their ordered product is the step map of the whole interval: the equations are linear)
+  int seg_count, seg_len;
 };
 
 // padded copies of the collapse operators for the lane-row rho kernel (c3p_ode_row.hip), written by its prep kernel
@@ -47,3 +51,7 @@ hipError_t c3p_launch_ode_row(const OdeArgs& A, void* aux, hipStream_t st);
 // pieces of the control amplitudes
 bool c3p_ode_rowq_supported(const OdeArgs& A);
 hipError_t c3p_launch_ode_rowq(const OdeArgs& A, hipStream_t st);
+// segmented integration of small batches (c3p_ode_row.hip): segment count (0 = off), and psi_out = U psi0
+int c3p_ode_row_segments(const OdeArgs& A);
+hipError_t c3p_launch_ode_apply(const cplx* U, const cplx* init, long init_bstride, cplx* out, int B, int D, hipStream_t st);
+hipError_t c3p_launch_ode_identity(cplx* out, int D, hipStream_t st);  // [D,D] identity on the device (no host round trip)

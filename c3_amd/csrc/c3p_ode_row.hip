@@ -70,11 +70,14 @@ __global__ void __launch_bounds__(64) ode_vec_kernel(OdeArgs A) {
   __shared__ double sig[4 * KT * 16];
   const int lane = threadIdx.x, r = lane >> 4, i = lane & 15;
   const int D = A.D, K = A.K, N = A.N, M = A.M, us = A.u_stride;
-  const long nv = (long)A.B * M;
+  const int SG = A.seg_count > 0 ? A.seg_count : 1;  // time segments per (sample, column)
+  const long nv = (long)A.B * SG * M;
   long v = (long)blockIdx.x * 4 + r;
   const bool live = v < nv;
   if (!live) v = nv - 1;
-  const int b = (int)(v / M), col = (int)(v - (long)b * M);
+  const int b = (int)(v / ((long)SG * M)), seg = (int)((v / M) % SG), col = (int)(v % M);
+  const int n_begin = A.seg_count > 0 ? seg * A.seg_len : 0;
+  const int n_end = A.seg_count > 0 ? (n_begin + A.seg_len < A.n_steps ? n_begin + A.seg_len : A.n_steps) : A.n_steps;
   const bool row = i < D;
 
   // rows of the operators (zero padded to DP columns; lanes i >= D hold zero rows)
@@ -112,7 +115,7 @@ __global__ void __launch_bounds__(64) ode_vec_kernel(OdeArgs A) {
   const int SPC = chunk_steps(us);
   double pre[KT];
   {
-    const int base = chunk_base(0, us, N);
+    const int base = chunk_base(n_begin, us, N);
     int idx = base + i;
     if (idx > N - 1) idx = N - 1;
 #pragma unroll
@@ -121,9 +124,13 @@ __global__ void __launch_bounds__(64) ode_vec_kernel(OdeArgs A) {
   double Hr[DP], Hi[REALH ? 1 : DP];
   const long ssz = (long)D * M;
   const long eo = A.transpose_out ? (long)col * D + i : (long)i * M + col;
-  cplx* outp = A.states + (long)b * (A.want_all ? (long)A.n_steps : 1) * ssz + eo;
+  cplx* outp = A.states + ((long)b * SG + seg) * (A.want_all ? (long)A.n_steps : 1) * ssz + eo;
 
-  for (int n0 = 0; n0 < A.n_steps; n0 += SPC) {
+  // The step loops run over the RELATIVE step index (wave-uniform: the four rows of a wavefront may integrate different
+  // segments, i.e. different absolute steps n = n_begin + j; a row past its segment end keeps its state)
+  const int nrel = A.seg_count > 0 ? A.seg_len : A.n_steps;
+  for (int j0 = 0; j0 < nrel; j0 += SPC) {
+    const int n0 = n_begin + j0;
     const int base = chunk_base(n0, us, N);
 #pragma unroll
     for (int k = 0; k < KT; ++k) sig[(r * KT + k) * 16 + i] = pre[k];
@@ -141,7 +148,9 @@ __global__ void __launch_bounds__(64) ode_vec_kernel(OdeArgs A) {
       if (lo > N - 2) lo = N - 2;
       if (lo < 0) lo = 0;
       const double f = u - (double)lo;
-      const double* sp = &sig[r * KT * 16 + (lo - base)];
+      int li = lo - base;
+      li = li < 0 ? 0 : (li > 14 ? 14 : li);  // (only a row past its segment end can leave the chunk; its step is discarded)
+      const double* sp = &sig[r * KT * 16 + li];
       double c[KT];
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
@@ -162,13 +171,15 @@ __global__ void __launch_bounds__(64) ode_vec_kernel(OdeArgs A) {
         }
       }
     };
-    const int n1 = (n0 + SPC < A.n_steps) ? n0 + SPC : A.n_steps;
-    for (int n = n0; n < n1; ++n) {
+    const int j1 = (j0 + SPC < nrel) ? j0 + SPC : nrel;
+    for (int jr = j0; jr < j1; ++jr) {
+      const int n = n_begin + jr;
+      const bool act = n < n_end;
       double kr[S], ki[S];
       static_for<0, S>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         if constexpr (s == 0) {
-          if (n == 0) assemble(tab_of(SOLVER).node[0], n);  // later steps: carried over from the previous step's last node
+          if (jr == 0) assemble(tab_of(SOLVER).node[0], n);  // later steps: carried over from the previous step's last node
         } else if constexpr (tab_of(SOLVER).node[s] != tab_of(SOLVER).node[s - 1]) {
           assemble(tab_of(SOLVER).node[s], n);
         }
@@ -192,14 +203,17 @@ __global__ void __launch_bounds__(64) ode_vec_kernel(OdeArgs A) {
           ki[s] = -dt * (w[0] + w[2]);
         }
       });
+      double qr = pr, qi = pi;
       static_for<0, S>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr double bj = tab_of(SOLVER).b[j];
         if constexpr (bj != 0.0) {
-          pr = fma(bj, kr[j], pr);
-          pi = fma(bj, ki[j], pi);
+          qr = fma(bj, kr[j], qr);
+          qi = fma(bj, ki[j], qi);
         }
       });
+      pr = act ? qr : pr;
+      pi = act ? qi : pi;
       if (A.want_all && live && row) outp[(long)n * ssz] = cmake(pr, pi);
       if (A.reset_each_step) {
         pr = ir;
@@ -504,6 +518,21 @@ __global__ void ode_colprep_kernel(const cplx* col, int C, int D, int DP, cplx* 
   }
 }
 
+// psi_out[b] = U[b] psi0[b]: the step map of the whole interval applied to the initial state (segmented integration)
+__global__ void __launch_bounds__(64) ode_apply_kernel(const cplx* U, const cplx* init, long init_bstride, cplx* out, int D) {
+  const int b = blockIdx.x, i = threadIdx.x;
+  if (i >= D) return;
+  const cplx* Ub = U + (long)b * D * D + (long)i * D;
+  const cplx* p = init + (long)b * init_bstride;
+  cplx s = cmake(0.0, 0.0);
+  for (int j = 0; j < D; ++j) cfma(s, Ub[j], p[j]);
+  out[(long)b * D + i] = s;
+}
+
+__global__ void ode_identity_kernel(cplx* out, int D) {
+  for (int e = threadIdx.x; e < D * D; e += blockDim.x) out[e] = cmake((e / D == e % D) ? 1.0 : 0.0, 0.0);
+}
+
 int pad_dim(int D) {
   const int dps[] = {2, 3, 4, 6, 9, 12, 16};
   for (int d : dps)
@@ -575,7 +604,7 @@ size_t c3p_ode_row_aux_bytes(int D, int C) {
 hipError_t c3p_launch_ode_row(const OdeArgs& A, void* aux, hipStream_t st) {
   const int DP = pad_dim(A.D);
   const bool vec = (A.step == C3P_STEP_SCHRODINGER_ID || A.step == C3P_STEP_PROPAGATOR_ID);
-  const long nv = vec ? (long)A.B * A.M : (long)A.B;
+  const long nv = vec ? (long)A.B * A.M * (A.seg_count > 0 ? A.seg_count : 1) : (long)A.B;
   const dim3 grid((unsigned)((nv + 3) / 4));
   if (vec) {
     switch (DP) {
@@ -609,4 +638,30 @@ hipError_t c3p_launch_ode_row(const OdeArgs& A, void* aux, hipStream_t st) {
     case 12: return launch_mat1<12>(A, X, grid, st);
     default: return launch_mat1<16>(A, X, grid, st);
   }
+}
+
+// Time segments for small batches (final state / propagator only): how many segments make the launch fill the chip.
+// 0 = integrate in one piece.  The segment maps cost D columns per sample instead of one state, so this only pays while the
+// plain launch would leave most wave slots empty.
+int c3p_ode_row_segments(const OdeArgs& A) {
+  if (getenv("C3P_ODE_NO_SEG")) return 0;
+  if (A.D < 2 || A.D > 12 || A.want_all || A.reset_each_step || A.n_steps < 64) return 0;  // (the combine runs on the small-D chain kernel)
+  const long cols = A.D;                          // columns integrated per segment
+  const long plain_waves = ((long)A.B * A.M + 3) / 4;
+  if (plain_waves >= 1024) return 0;              // one wave per SIMD already: the direct integration is the cheaper one
+  long S = (6 * 1024) / ((long)A.B * cols);       // 1 - 1.5 waves per SIMD (measured, D = 9, 1000 rk4 steps: B = 16 0.120 ms and
+                                                  // B = 64 0.128 ms against 0.50 ms direct; B = 256 with three segments 0.35 ms)
+  if (S > 8) S = 8;                               // one combine launch (the small-D chain kernel folds up to 8 matrices)
+  if (S > A.n_steps / 32) S = A.n_steps / 32;
+  return S >= 2 ? (int)S : 0;
+}
+
+hipError_t c3p_launch_ode_identity(cplx* out, int D, hipStream_t st) {
+  hipLaunchKernelGGL(ode_identity_kernel, dim3(1), dim3(256), 0, st, out, D);
+  return hipGetLastError();
+}
+
+hipError_t c3p_launch_ode_apply(const cplx* U, const cplx* init, long init_bstride, cplx* out, int B, int D, hipStream_t st) {
+  hipLaunchKernelGGL(ode_apply_kernel, dim3((unsigned)B), dim3(64), 0, st, U, init, init_bstride, out, D);
+  return hipGetLastError();
 }

@@ -483,3 +483,43 @@ def test_regd_padded_lindblad_64(prop):
     ref = o.propagate_batch(h0, hks, sig, 1.0, col_ops=col, lindbladian=True)
     assert fro_max(r["U"], ref) < TOL
     assert np.abs(np.asarray(r["dUs"][0]) - o.tf_propagation_lind(h0, hks, col, sig[0], 1.0)).max() < 1e-12
+
+
+@pytest.mark.parametrize("D,K,real", [(3, 1, True), (9, 2, True), (9, 2, False), (12, 3, False)])
+def test_ode_row_time_segments_small_batches(prop, D, K, real):
+    """Final state of a SMALL batch: the interval is cut into time segments whose step maps (D columns each) are integrated
+    in parallel and multiplied in order (the equations are linear) -- same numbers as the direct integration to rounding,
+    and as the oracle's solver; uneven last segment, all four solvers."""
+    B, N = 5, 203
+    h0, hks, sig, ts = _ode_problem(D, K, B, N, real, 900 + D)
+    rng = np.random.default_rng(D)
+    psi = rng.normal(size=(B, D, 1)) + 1j * rng.normal(size=(B, D, 1))
+    for solver in ("rk4", "rk38", "rk5", "tsit5"):
+        seg = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], psi, solver, "schrodinger", final_only=True))
+        os.environ["C3P_ODE_NO_SEG"] = "1"
+        try:
+            direct = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], psi, solver, "schrodinger", final_only=True))
+        finally:
+            os.environ.pop("C3P_ODE_NO_SEG")
+        assert np.abs(seg - direct).max() < 1e-12 * max(1.0, np.abs(direct).max())
+        for b in (0, B - 1):
+            ref = o.ode_solver_arrays(h0, hks, sig[b], ts, psi[b], solver, "schrodinger", final_only=True)["states"]
+            assert np.abs(seg[b] - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+
+
+def test_rk4_unitary_time_segments(prop):
+    import ctypes
+
+    from c3_amd import _lib
+
+    D, K, B, Ns = 6, 2, 2, 401
+    h0, hks, sig, _ = _ode_problem(D, K, B, Ns, False, 55)
+    lib = _lib.load()
+    U = np.zeros((B, D, D), complex)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    h0c, hkc, sgc = np.ascontiguousarray(h0), np.ascontiguousarray(hks), np.ascontiguousarray(sig)
+    rc = lib.c3p_rk4_unitary(p(h0c), p(hkc), p(sgc), None, 0, 0.02, B, K, Ns, D, 1, p(U), None, None)
+    assert rc == 0 and _lib.last_kernel() == "ode_row"
+    for b in range(B):
+        Hs = h0[None] + np.einsum("kn,kij->nij", sig[b], hks)
+        assert np.abs(U[b] - o.gen_u_rk4(Hs, 0.02, D)).max() < 1e-12
