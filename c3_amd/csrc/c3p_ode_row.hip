@@ -640,20 +640,29 @@ hipError_t c3p_launch_ode_row(const OdeArgs& A, void* aux, hipStream_t st) {
   }
 }
 
-// Time segments for small batches (final state / propagator only): how many segments make the launch fill the chip.
-// 0 = integrate in one piece.  The segment maps cost D columns per sample instead of one state, so this only pays while the
-// plain launch would leave most wave slots empty.
+// Time segments for small batches (final state / propagator only): how many segments to cut the time axis into.
+// 0 = integrate in one piece.  The segment maps cost D columns per sample instead of one state, and a wavefront that shares
+// its SIMD runs slower (one wave alone: 0.50 us per rk4 step at D = 9, i.e. ~70 % of the SIMD's fp64 issue rate already;
+// w waves per SIMD: ~0.14 + 0.34 w us), so the choice minimises  n_steps / S * c(waves per SIMD)  + the fixed cost of the
+// extra launches (identity, combine, apply: ~50 us) over S = 1..8 (the small-D chain kernel folds up to 8 maps in one launch).
+// Measured, D = 9, 1000 rk4 steps (direct 0.50 ms): B = 16 0.117 ms (S = 8), B = 64 0.128 ms (S = 7), B = 256 0.35 ms (S = 3).
 int c3p_ode_row_segments(const OdeArgs& A) {
   if (getenv("C3P_ODE_NO_SEG")) return 0;
   if (A.D < 2 || A.D > 12 || A.want_all || A.reset_each_step || A.n_steps < 64) return 0;  // (the combine runs on the small-D chain kernel)
-  const long cols = A.D;                          // columns integrated per segment
-  const long plain_waves = ((long)A.B * A.M + 3) / 4;
-  if (plain_waves >= 1024) return 0;              // one wave per SIMD already: the direct integration is the cheaper one
-  long S = (6 * 1024) / ((long)A.B * cols);       // 1 - 1.5 waves per SIMD (measured, D = 9, 1000 rk4 steps: B = 16 0.120 ms and
-                                                  // B = 64 0.128 ms against 0.50 ms direct; B = 256 with three segments 0.35 ms)
-  if (S > 8) S = 8;                               // one combine launch (the small-D chain kernel folds up to 8 matrices)
-  if (S > A.n_steps / 32) S = A.n_steps / 32;
-  return S >= 2 ? (int)S : 0;
+  auto step_cost = [](long rows) {  // relative time of one RK step when `rows` DPP rows (4 per wave) are spread over 1024 SIMDs
+    const long w = (rows + 4095) / 4096;
+    return w <= 1 ? 0.50 : 0.14 + 0.34 * (double)w;
+  };
+  const double fixed = 50.0 * (A.solver == 0 || A.solver == 1 ? 1.0 : 0.55);  // in units of rk4 steps' microseconds (7-stage solvers: longer steps)
+  if ((long)A.B * A.M > 4096) return 0;  // more than one wave per SIMD already: throughput, not latency (not measured beyond)
+  const double direct = (double)A.n_steps * step_cost((long)A.B * A.M);
+  double best = direct * 0.8;  // a segmented launch has to win by a margin
+  int pick = 0;
+  for (int S = 2; S <= 8 && S <= A.n_steps / 32; ++S) {
+    const double c = (double)((A.n_steps + S - 1) / S) * step_cost((long)A.B * S * A.D) + fixed;
+    if (c < best) best = c, pick = S;
+  }
+  return pick;
 }
 
 hipError_t c3p_launch_ode_identity(cplx* out, int D, hipStream_t st) {
