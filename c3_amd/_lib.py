@@ -18,7 +18,7 @@ PER_SLICE_H = 0x2
 ORDER_RIGHT = 0x4
 FORCE_GENERIC = 0x8
 
-KERNEL_NAMES = {0: "none", 1: "generic_lds", 2: "generic_global", 3: "smalld", 4: "mfma", 5: "ode_wg", 6: "ode_row"}
+KERNEL_NAMES = {0: "none", 1: "generic_lds", 2: "generic_global", 3: "smalld", 4: "mfma", 5: "ode_wg", 6: "ode_row", 7: "ode_mfma"}
 
 SOLVERS = {"rk4": 0, "rk38": 1, "rk5": 2, "tsit5": 3}
 STEPS = {"schrodinger": 0, "von_neumann": 1, "lindblad": 2}

@@ -1506,6 +1506,15 @@ int c3p_ode_solve(const void* h0, const void* hks, const double* signals, const 
     if (flags & C3P_HOST_PTRS) return sg.finish();
     return 0;
   }
+  if (c3p_ode_rhoq_supported(a)) {
+    // 17 <= D <= 48 rho-valued states: register tiles + 16x16x4 fp64 MFMA products (c3p_ode_rhoq.hip)
+    g_last_kernel = C3P_KERNEL_ODE_MFMA;
+    if (record_start(w, st)) return -1;
+    LAUNCH_TRY(c3p_launch_ode_rhoq(a, st));
+    if (record_stop(w, st)) return -1;
+    if (flags & C3P_HOST_PTRS) return sg.finish();
+    return 0;
+  }
   g_last_kernel = C3P_KERNEL_ODE_WG;
   const size_t elems = c3p_ode_elems(D, M, C);
   const bool global = elems * cs > (size_t)(150 * 1024);

@@ -30,6 +30,7 @@ struct OdeArgs {
   // integrated over seg_count step ranges of seg_len steps from the IDENTITY, and states receives the segment maps
   // [B, seg_count, D, M] (their ordered product is the step map of the whole interval: the equations are linear)
   int seg_count, seg_len;
+  int rho_general;  // matrix-core rho kernel: do not use the Hermitian shortcut (set by its launcher from C3P_ODE_RHO_GENERAL)
 };
 
 // padded copies of the collapse operators for the lane-row rho kernel (c3p_ode_row.hip), written by its prep kernel
@@ -51,6 +52,10 @@ hipError_t c3p_launch_ode_row(const OdeArgs& A, void* aux, hipStream_t st);
 // pieces of the control amplitudes
 bool c3p_ode_rowq_supported(const OdeArgs& A);
 hipError_t c3p_launch_ode_rowq(const OdeArgs& A, hipStream_t st);
+// Matrix-core rho-valued solver for 17 <= D <= 48 (c3p_ode_rhoq.hip): von Neumann (D <= 48) and Lindblad (D <= 32) steps,
+// one workgroup per sample, every matrix as 16 x 16 register tiles, products on v_mfma_f64_16x16x4_f64
+bool c3p_ode_rhoq_supported(const OdeArgs& A);
+hipError_t c3p_launch_ode_rhoq(const OdeArgs& A, hipStream_t st);
 // segmented integration of small batches (c3p_ode_row.hip): segment count (0 = off), and psi_out = U psi0
 int c3p_ode_row_segments(const OdeArgs& A);
 hipError_t c3p_launch_ode_apply(const cplx* U, const cplx* init, long init_bstride, cplx* out, int B, int D, hipStream_t st);

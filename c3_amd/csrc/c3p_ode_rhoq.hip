@@ -1,0 +1,567 @@
+// Matrix-core ODE solver for rho-valued states at 17 <= D <= 48 (round 3): von Neumann and Lindblad steps of
+// ode_solver / ode_solver_final_state (c3/libraries/propagation.py:687-752, tableaux :755-883, step functions :886-904)
+// with the Hamiltonian of Model.Hs_of_t (c3/model.py:641-697) on linearly interpolated controls
+// (c3/utils/tf_utils.py:521-559) -- the dimensions of BASELINE cfg3 (D = 27) and cfg5 (D = 36), where the state is a
+// D x D matrix and a stage is two (von Neumann) or 2 + 2 C (Lindblad) D x D x D complex products: GEMM-shaped, so it runs
+// on `v_mfma_f64_16x16x4_f64`.  (D <= 16 stays on the lane-row kernel of c3p_ode_row.hip, anything else on c3p_ode.hip.)
+//
+//  * One workgroup per sample, NT x NT wavefronts (NT = ceil(D / 16): 4 waves for D <= 32, 9 for D <= 48); wave (I, J)
+//    owns the 16 x 16 tile (I, J) of EVERY matrix in the C/D layout of the instruction (register v of lane l = element
+//    (4 v + l / 16, l % 16)): rho, the RK stages k_1 .. k_S, the operator tiles of h0 and the hk, the assembled H(t).
+//    Everything elementwise (stage arguments, H(t) = h0 + sum_k c_k(t) hk, the RK update) is register arithmetic on four
+//    elements per lane; the tableau is a template parameter, zero coefficients vanish at compile time.
+//  * Only product OPERANDS pass through LDS: per stage every wave writes its tile of H(t) and of the stage argument Y to
+//    zero-padded planes (separate real / imaginary planes, row stride 16 NT + 2 doubles: the A-fragment reads -- 16 rows x
+//    2 columns per half wave -- are conflict free, the B-fragment reads two-way), one barrier, then
+//        acc = H Y - Y H      in ONE accumulator pair: per K-step of 4 the A fragments H(I, k), Y(I, k) and the B
+//    fragments Y(k, J), H(k, J), eight real MFMAs (four when the operators are real: that instance is picked on the device,
+//    both are launched and the one that does not apply exits), alternating between the real and the imaginary accumulator.
+//    The K loop stops at ceil(D / 4) steps (the padding columns are zero).  k_s = -i dt acc.
+//  * Lindblad: with G = sum_m C_m^+ C_m the anticommutator is folded into L = H - (i/2) G, R = H + (i/2) G:
+//    -i (L Y - Y R) = -i [H, Y] - {G, Y} / 2 (the same commutator loop on complex planes), and every jump term is two more
+//    products, T = C_m Y (written back to an LDS plane by the owning waves, one barrier) and T C_m^+ (the B fragment of C^+
+//    is the conjugated A-pattern read of C).  The C_m sit in LDS planes for the whole integration; D <= 32 only (LDS).
+//  * Control amplitudes: every lane reads the two neighbouring samples of its K lines one stage AHEAD (plain vector loads of
+//    one address: a broadcast; they return under the previous stage's products).  `Hs` is never materialised.
+#include <type_traits>
+#include <utility>
+
+#include "c3p_common.h"
+#include "c3p_ode.h"
+#include "c3p_ode_tab.h"
+
+extern __shared__ __attribute__((aligned(16))) unsigned char c3p_ode_rhoq_smem[];
+
+namespace {
+
+constexpr int RK = 4;  // control lines held in registers
+
+__host__ __device__ constexpr OdeTableau rtab_of(int solver) {
+  constexpr OdeTableau t[4] = C3P_ODE_TABLEAUX;
+  return t[solver];
+}
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <int I, int N, class F>
+__device__ __forceinline__ void rstatic_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    rstatic_for<I + 1, N>(f);
+  }
+}
+
+// MODE 0: von Neumann, real operators; 1: von Neumann, complex operators; 2: Lindblad (complex planes)
+__host__ __device__ constexpr int rho_planes(int mode, int C) { return mode == 0 ? 5 : (mode == 1 ? 6 : 8 + 2 * C); }
+__host__ __device__ constexpr size_t rho_lds_bytes(int NT, int mode, int C) {
+  return (size_t)rho_planes(mode, C) * (16 * NT) * (16 * NT + 2) * sizeof(double);
+}
+
+__device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+// Workgroups per CU the register budget is set for: three for the four-stage solvers on real operators (168 registers),
+// two for the other von Neumann instances (256), one for Lindblad (its planes fill the LDS anyway) and for the 9-wave
+// workgroups of D > 32 (three waves on one SIMD: 168 registers whatever is asked for).
+__host__ __device__ constexpr int rho_min_wgs(int NT, int solver, int mode) {
+#ifndef C3P_RHOQ_WGS_REAL4
+#define C3P_RHOQ_WGS_REAL4 2
+#endif
+  return NT != 2 || mode == 2 ? 1 : (mode == 0 && solver < 2 ? C3P_RHOQ_WGS_REAL4 : 2);
+}
+
+template <int NT, int SOLVER, int MODE, bool HERM>
+__global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) ode_rhoq_kernel(OdeArgs A) {
+  constexpr bool CPX = MODE != 0;
+  constexpr bool LIND = MODE == 2;
+  constexpr int S = rtab_of(SOLVER).stages;
+  constexpr int DP = 16 * NT, LD = DP + 2, PL = DP * LD;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int I = wave / NT, J = wave - I * NT;
+  const int lr = lane >> 4, lc = lane & 15;
+  const int D = A.D, K = A.K, N = A.N, us = A.u_stride;
+  const int b = blockIdx.x;
+  double* lds = reinterpret_cast<double*>(c3p_ode_rhoq_smem);
+  // planes: left operator (H or L), stage argument, [Lindblad: right operator R, product T, collapse operators]
+  double* const Lr = lds;
+  double* const Li = CPX ? lds + PL : lds;
+  double* const Yr = lds + (CPX ? 2 : 1) * PL;
+  double* const Yi = Yr + PL;
+  double* const Rr = LIND ? lds + 4 * PL : Lr;
+  double* const Ri = LIND ? lds + 5 * PL : Li;
+  double* const Pr = LIND ? Rr : Yi + PL;  // H Y (Hermitian shortcut); never live together with R
+  double* const Pi = Pr + PL;
+  double* const Tr = lds + 6 * PL;
+  double* const Ti = lds + 7 * PL;
+  double* const Cp = lds + 8 * PL;  // [m][re, im] planes
+
+  // own elements: register v <-> (row[v], col)
+  const int col = 16 * J + lc;
+  int eoff[4];   // offset of the element in an LDS plane
+  bool valid[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int row = 16 * I + 4 * v + lr;
+    eoff[v] = row * LD + col;
+    valid[v] = row < D && col < D;
+  }
+
+  // operator tiles -> registers
+  double h0r[4], h0i[CPX ? 4 : 1], hkr[RK][4], hki[RK][CPX ? 4 : 1];
+  bool im0 = true;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int row = 16 * I + 4 * v + lr;
+    cplx z = cmake(0, 0);
+    if (valid[v]) z = A.h0[row * D + col];
+    h0r[v] = z.x;
+    if constexpr (CPX) h0i[v] = z.y;
+    im0 = im0 && z.y == 0.0;
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+      cplx zk = cmake(0, 0);
+      if (valid[v] && k < K) zk = A.hks[((long)k * D + row) * D + col];
+      hkr[k][v] = zk.x;
+      if constexpr (CPX) hki[k][v] = zk.y;
+      im0 = im0 && zk.y == 0.0;
+    }
+  }
+  if constexpr (!LIND) {
+    const bool allreal = __syncthreads_and((int)im0) != 0;
+    if (allreal != (MODE == 0)) return;  // the other instance integrates this launch
+  }
+
+  // Hermitian shortcut: with H = H^+ and rho = rho^+ every stage argument Y is Hermitian and Y H = (H Y)^+ -- ONE product
+  // per commutator, the other half is the conjugate transpose of the result, fetched through LDS from the wave that owns
+  // the mirrored tile.  (Lindblad: Y R = Y L^+ = (L Y)^+ likewise.)  Checked here, per sample and operator: mirrored
+  // elements may differ by 1e-15 of the operator's largest element (a dressed `V^T H V` is symmetric to a few units in the
+  // last place of its largest entries, not bit for bit); the result then differs from the two-product form by at most
+  // 2 T |H - H^+| / 2 <= 1e-15 |H| T, the size of the rounding errors of the integration itself.
+  bool hm = true;
+  auto herm_of = [&](const double (&xr)[4], const double (&xi)[4]) {
+    double mx = 0.0;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      Yr[eoff[v]] = xr[v];
+      Yi[eoff[v]] = xi[v];
+      mx = fmax(mx, fmax(fabs(xr[v]), fabs(xi[v])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    if (lane == 0) Yr[wave * LD + DP] = mx;  // the two padding columns of a plane row are never read by the products
+    __syncthreads();
+    double scale = 0.0;
+    for (int w = 0; w < NT * NT; ++w) scale = fmax(scale, Yr[w * LD + DP]);
+    const double tol = 1e-15 * scale;
+    bool ok = true;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int t = col * LD + 16 * I + 4 * v + lr;
+      ok = ok && fabs(Yr[t] - xr[v]) <= tol && fabs(Yi[t] + xi[v]) <= tol;
+    }
+    __syncthreads();
+    return ok;
+  };
+  {
+    double zr[4], zi[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      zr[v] = h0r[v];
+      zi[v] = 0.0;
+      if constexpr (CPX) zi[v] = h0i[v];
+    }
+    hm = herm_of(zr, zi) && hm;
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+      if (k < K) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          zr[v] = hkr[k][v];
+          zi[v] = 0.0;
+          if constexpr (CPX) zi[v] = hki[k][v];
+        }
+        hm = herm_of(zr, zi) && hm;
+      }
+    }
+  }
+
+  // Lindblad: collapse operators -> LDS planes, G = sum_m C_m^+ C_m -> (1/2) G in registers
+  double g2r[LIND ? 4 : 1], g2i[LIND ? 4 : 1];
+  if constexpr (LIND) {
+    for (int m = 0; m < A.C; ++m) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = 16 * I + 4 * v + lr;
+        cplx z = cmake(0, 0);
+        if (valid[v]) z = A.col_ops[((long)m * D + row) * D + col];
+        Cp[(2 * m) * PL + eoff[v]] = z.x;
+        Cp[(2 * m + 1) * PL + eoff[v]] = z.y;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int row = 16 * I + 4 * v + lr;
+      double sr = 0.0, si = 0.0;
+      for (int m = 0; m < A.C; ++m) {
+        const double* cr = Cp + (2 * m) * PL;
+        const double* ci = cr + PL;
+        for (int k = 0; k < D; ++k) {  // conj(C[k][row]) C[k][col]
+          const double ar = cr[k * LD + row], ai = ci[k * LD + row], br = cr[k * LD + col], bi = ci[k * LD + col];
+          sr += ar * br + ai * bi;
+          si += ar * bi - ai * br;
+        }
+      }
+      g2r[v] = 0.5 * sr;
+      g2i[v] = 0.5 * si;
+    }
+  }
+
+  // state tile
+  double pr[4], pi[4];
+  const cplx* init = A.init + (long)b * A.init_bstride;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int row = 16 * I + 4 * v + lr;
+    cplx z = cmake(0, 0);
+    if (valid[v]) z = init[(long)row * D + col];
+    pr[v] = z.x;
+    pi[v] = z.y;
+  }
+  hm = herm_of(pr, pi) && hm;
+  // (the instance built for the other case integrates this sample: both are launched)
+  if (((__syncthreads_and((int)hm) != 0) && !A.rho_general) != HERM) return;
+  constexpr bool herm = HERM;
+  const bool tail_barrier = !(herm && (!LIND || A.C == 0));  // see the end of a stage
+  const double dt = A.dt;
+  const double* sg = A.signals + (long)b * K * N;
+  // interpolated control amplitudes at u = (n + node) * u_stride samples: linear, linear extrapolation past the last
+  // sample (tf_utils.py:557-559).  Two phases: the loads are ISSUED right behind a stage's first barrier (unconditional,
+  // one address per line: lines past K read line 0 and meet zero operators) and COMBINED behind its products.
+  double raw0[RK], raw1[RK], rawf = 0.0;
+  auto fetch_issue = [&](double u) {
+    int lo = (int)floor(u);
+    if (lo > N - 2) lo = N - 2;
+    if (lo < 0) lo = 0;
+    rawf = u - (double)lo;
+#ifdef C3P_RHOQ_X_NOFETCH
+    lo = 0;
+#endif
+    if (K > 0) {
+#pragma unroll
+      for (int k = 0; k < RK; ++k) {
+        const double* y = sg + (long)(k < K ? k : 0) * N + lo;
+        raw0[k] = y[0];
+        raw1[k] = y[1];
+      }
+    }
+  };
+  double cur[RK];
+  auto fetch_finish = [&]() {
+#pragma unroll
+    for (int k = 0; k < RK; ++k) cur[k] = K > 0 ? fma(rawf, raw1[k] - raw0[k], raw0[k]) : 0.0;
+  };
+  fetch_issue(rtab_of(SOLVER).node[0] * (double)us);
+  fetch_finish();
+  const int ksteps = (D + 3) >> 2;
+  const int aoff = (16 * I + lc) * LD + lr;  // A fragment of row tile I: element (row lc, k = lr) of a K-step
+  const int boff = lr * LD + 16 * J + lc;    // B fragment of column tile J: element (k = lr, column lc)
+  const int coff = (16 * J + lc) * LD + lr;  // A-pattern read at row tile J: B fragment of a conjugate transpose
+  const long ssz = (long)D * D;
+  cplx* outp = A.states + (long)b * (A.want_all ? (long)A.n_steps : 1) * ssz;
+
+#ifdef C3P_RHOQ_TIMING
+  long long tp[6] = {0, 0, 0, 0, 0, 0};
+#define RHOQ_T(i, a, b) tp[i] += (b) - (a)
+#define RHOQ_NOW() clock64()
+#else
+#define RHOQ_T(i, a, b)
+#define RHOQ_NOW() 0
+#endif
+  for (int n = 0; n < A.n_steps; ++n) {
+    double kr[S][4], ki[S][4], qr[4], qi[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      qr[v] = pr[v];
+      qi[v] = pi[v];
+    }
+    rstatic_for<0, S>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      // H(t) at this stage's node and the stage argument, own tile
+      [[maybe_unused]] const long long t0 = RHOQ_NOW();
+      {
+        constexpr double nn = (s + 1 < S) ? rtab_of(SOLVER).node[s + 1 < S ? s + 1 : 0] : 1.0 + rtab_of(SOLVER).node[0];
+        fetch_issue(((double)n + nn) * (double)us);
+      }
+      double yr[4], yi[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        double hr = h0r[v];
+#pragma unroll
+        for (int k = 0; k < RK; ++k) hr = fma(cur[k], hkr[k][v], hr);
+        double hi = 0.0;
+        if constexpr (CPX) {
+          hi = h0i[v];
+#pragma unroll
+          for (int k = 0; k < RK; ++k) hi = fma(cur[k], hki[k][v], hi);
+        }
+        yr[v] = pr[v];
+        yi[v] = pi[v];
+        rstatic_for<0, s>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          constexpr double a = rtab_of(SOLVER).a[s][j];
+          if constexpr (a != 0.0) {
+            yr[v] = fma(a, kr[j][v], yr[v]);
+            yi[v] = fma(a, ki[j][v], yi[v]);
+          }
+        });
+        if constexpr (LIND) {
+          Lr[eoff[v]] = hr + g2i[v];  // L = H - (i/2) G
+          Li[eoff[v]] = hi - g2r[v];
+          if constexpr (!herm) {
+            Rr[eoff[v]] = hr - g2i[v];  // R = H + (i/2) G
+            Ri[eoff[v]] = hi + g2r[v];
+          }
+        } else {
+          Lr[eoff[v]] = hr;
+          if constexpr (CPX) Li[eoff[v]] = hi;
+        }
+        Yr[eoff[v]] = yr[v];
+        Yi[eoff[v]] = yi[v];
+      }
+      [[maybe_unused]] const long long t1 = RHOQ_NOW();
+      __syncthreads();
+      [[maybe_unused]] const long long t2 = RHOQ_NOW();
+      fetch_finish();  // amplitudes of the NEXT node (issued at the top of this stage; H(t) of this stage is in LDS by now)
+      d4 accR = {0.0, 0.0, 0.0, 0.0}, accI = {0.0, 0.0, 0.0, 0.0};
+      // fragments are fetched one K-step ahead of the MFMAs that use them (two register sets, loop unrolled by two)
+      auto kloop = [&](auto nsc, auto&& load, auto&& mma) {
+        constexpr int NS = decltype(nsc)::value;  // register sets: fragments are fetched NS - 1 K-steps ahead of their MFMAs
+        double f[NS][8];
+        rstatic_for<0, NS - 1>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          if (i < ksteps) load(i, f[i]);
+        });
+        for (int kk = 0; kk < ksteps; kk += NS) {
+          rstatic_for<0, NS>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (kk + j < ksteps) {
+              if (kk + j + NS - 1 < ksteps) load(kk + j + NS - 1, f[(j + NS - 1) % NS]);
+#ifndef C3P_RHOQ_X_NOMFMA
+              mma(f[j]);
+#else
+              accR[0] += f[j][0] + f[j][2] + f[j][3];
+#endif
+            }
+          });
+        }
+      };
+      if constexpr (herm) {
+        // acc = H Y (L Y); [0..1] H as left operand, [2..3] Y as right
+        kloop(
+            std::integral_constant<int, 4>{},
+            [&](int kk, double (&f)[8]) {
+              const int ao = aoff + 4 * kk, bo = boff + 4 * kk * LD;
+              f[0] = Lr[ao];
+              f[2] = Yr[bo];
+              f[3] = Yi[bo];
+              if constexpr (CPX) f[1] = Li[ao];
+            },
+            [&](const double (&f)[8]) {
+              accR = mfma(f[0], f[2], accR);
+              accI = mfma(f[0], f[3], accI);
+              if constexpr (CPX) {
+                accR = mfma(-f[1], f[3], accR);
+                accI = mfma(f[1], f[2], accI);
+              }
+            });
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          Pr[eoff[v]] = accR[v];
+          Pi[eoff[v]] = accI[v];
+        }
+      } else {
+        // acc = H Y - Y H (L Y - Y R); [0..1] H as left operand, [2..3] Y as right, [4..5] Y as left, [6..7] H (R) as right
+        kloop(
+            std::integral_constant<int, 3>{},
+            [&](int kk, double (&f)[8]) {
+              const int ao = aoff + 4 * kk, bo = boff + 4 * kk * LD;
+              f[0] = Lr[ao];
+              f[2] = Yr[bo];
+              f[3] = Yi[bo];
+              f[4] = Yr[ao];
+              f[5] = Yi[ao];
+              f[6] = Rr[bo];
+              if constexpr (CPX) {
+                f[1] = Li[ao];
+                f[7] = Ri[bo];
+              }
+            },
+            [&](const double (&f)[8]) {
+              if constexpr (CPX) {
+                accR = mfma(f[0], f[2], accR);
+                accI = mfma(f[0], f[3], accI);
+                accR = mfma(-f[1], f[3], accR);
+                accI = mfma(f[1], f[2], accI);
+                accR = mfma(-f[4], f[6], accR);
+                accI = mfma(-f[4], f[7], accI);
+                accR = mfma(f[5], f[7], accR);
+                accI = mfma(-f[5], f[6], accI);
+              } else {
+                accR = mfma(f[0], f[2], accR);
+                accI = mfma(f[0], f[3], accI);
+                accR = mfma(-f[4], f[6], accR);
+                accI = mfma(-f[5], f[6], accI);
+              }
+            });
+      }
+      bool p_pending = herm;  // the tiles of H Y are written, not yet fenced
+      [[maybe_unused]] const long long t3 = RHOQ_NOW();
+      [[maybe_unused]] const long long t4 = t3;
+      // k_s = -i dt acc (+ dt sum_m C_m Y C_m^+)
+      d4 jR = {0.0, 0.0, 0.0, 0.0}, jI = {0.0, 0.0, 0.0, 0.0};
+      if constexpr (LIND) {
+        for (int m = 0; m < A.C; ++m) {
+          const double* cr = Cp + (2 * m) * PL;
+          const double* ci = cr + PL;
+          d4 tR = {0.0, 0.0, 0.0, 0.0}, tI = {0.0, 0.0, 0.0, 0.0};
+          for (int kk = 0; kk < ksteps; ++kk) {
+            const int ao = aoff + 4 * kk, bo = boff + 4 * kk * LD;
+            const double ar = cr[ao], ai = ci[ao], br = Yr[bo], bi = Yi[bo];
+            tR = mfma(ar, br, tR);
+            tI = mfma(ar, bi, tI);
+            tR = mfma(-ai, bi, tR);
+            tI = mfma(ai, br, tI);
+          }
+          if (m > 0) __syncthreads();  // the previous jump term's readers of T are done
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            Tr[eoff[v]] = tR[v];
+            Ti[eoff[v]] = tI[v];
+          }
+          __syncthreads();
+          p_pending = false;
+          for (int kk = 0; kk < ksteps; ++kk) {
+            const int ao = aoff + 4 * kk, co = coff + 4 * kk;
+            const double ar = Tr[ao], ai = Ti[ao], br = cr[co], bi = ci[co];  // B = C^+: (br, -bi)
+            jR = mfma(ar, br, jR);
+            jI = mfma(ai, br, jI);
+            jR = mfma(ai, bi, jR);
+            jI = mfma(-ar, bi, jI);
+          }
+        }
+      }
+      if (p_pending) __syncthreads();
+      [[maybe_unused]] const long long t5 = RHOQ_NOW();
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        double cr_ = accR[v], ci_ = accI[v];
+        if constexpr (herm) {  // H Y - (H Y)^+: the mirrored element of the mirrored tile
+          const int t = col * LD + 16 * I + 4 * v + lr;
+          cr_ -= Pr[t];
+          ci_ += Pi[t];
+        }
+        kr[s][v] = dt * (ci_ + jR[v]);
+        ki[s][v] = dt * (jI[v] - cr_);
+        constexpr double bs = rtab_of(SOLVER).b[s];
+        if constexpr (bs != 0.0) {  // the RK update accumulates as the stages arrive (rk4: one stage live at a time)
+          qr[v] = fma(bs, kr[s][v], qr[v]);
+          qi[v] = fma(bs, ki[s][v], qi[v]);
+        }
+      }
+      // every wave is done reading the planes of this stage -- not needed on the Hermitian von Neumann path: the next
+      // write of L / Y follows this wave's read of P, which follows the barrier behind every wave's products
+      if (tail_barrier) __syncthreads();
+      [[maybe_unused]] const long long t6 = RHOQ_NOW();
+      RHOQ_T(0, t0, t1);
+      RHOQ_T(1, t1, t2);
+      RHOQ_T(2, t2, t3);
+      RHOQ_T(3, t3, t4);
+      RHOQ_T(4, t4, t5);
+      RHOQ_T(5, t5, t6);
+    });
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      pr[v] = qr[v];
+      pi[v] = qi[v];
+    }
+    if (A.want_all) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (valid[v]) outp[(long)n * ssz + (long)(16 * I + 4 * v + lr) * D + col] = cmake(pr[v], pi[v]);
+    }
+  }
+#ifdef C3P_RHOQ_TIMING
+  if (b == 0 && (tid == 0 || tid == 64 * NT * NT - 1))
+    printf("rhoq NT=%d solver=%d mode=%d herm=%d tid=%d: assemble+write %lld, barrier1 %lld, products %lld, fetch wait %lld, (jumps+) barrier2 %lld, k + tail %lld cycles per stage\n",
+           NT, SOLVER, MODE, (int)herm, tid, tp[0] / (A.n_steps * S), tp[1] / (A.n_steps * S), tp[2] / (A.n_steps * S), tp[3] / (A.n_steps * S), tp[4] / (A.n_steps * S), tp[5] / (A.n_steps * S));
+#endif
+  if (!A.want_all) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      if (valid[v]) outp[(long)(16 * I + 4 * v + lr) * D + col] = cmake(pr[v], pi[v]);
+  }
+}
+
+template <int NT, int SOLVER, int MODE, bool HERM>
+hipError_t launch_rho4(const OdeArgs& A, hipStream_t st) {
+  const size_t lds = rho_lds_bytes(NT, MODE, A.C);
+  if (lds > 48 * 1024) {
+    // per launch: the attribute is per DEVICE, and one process may drive several GPUs
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ode_rhoq_kernel<NT, SOLVER, MODE, HERM>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((ode_rhoq_kernel<NT, SOLVER, MODE, HERM>), dim3((unsigned)A.B), dim3(64 * NT * NT), lds, st, A);
+  return hipGetLastError();
+}
+
+// Every instance that could apply is launched: the operators (real / complex) and the symmetry of operators and initial
+// state (Hermitian shortcut or the general two-product form) are inspected on the device, per sample, and the instances
+// that do not apply exit after the prologue.
+template <int NT, int SOLVER, int MODE>
+hipError_t launch_rho3(const OdeArgs& A, hipStream_t st) {
+  if (!A.rho_general) {
+    hipError_t e = launch_rho4<NT, SOLVER, MODE, true>(A, st);
+    if (e != hipSuccess) return e;
+  }
+  return launch_rho4<NT, SOLVER, MODE, false>(A, st);
+}
+
+template <int NT, int SOLVER>
+hipError_t launch_rho2(const OdeArgs& A, hipStream_t st) {
+  if (A.step == C3P_STEP_LINDBLAD_ID) {
+    if constexpr (NT == 2) return launch_rho3<NT, SOLVER, 2>(A, st);
+    return hipErrorInvalidValue;
+  }
+  hipError_t e = launch_rho3<NT, SOLVER, 0>(A, st);
+  if (e != hipSuccess) return e;
+  return launch_rho3<NT, SOLVER, 1>(A, st);
+}
+
+template <int NT>
+hipError_t launch_rho1(const OdeArgs& A, hipStream_t st) {
+  switch (A.solver) {
+    case 0: return launch_rho2<NT, 0>(A, st);
+    case 1: return launch_rho2<NT, 1>(A, st);
+    case 2: return launch_rho2<NT, 2>(A, st);
+    case 3: return launch_rho2<NT, 3>(A, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace
+
+bool c3p_ode_rhoq_supported(const OdeArgs& A) {
+  if (getenv("C3P_ODE_WG")) return false;
+  if (A.D < 17 || A.D > 48 || A.M != A.D || A.K > RK || A.hs || A.N < 2) return false;
+  if (A.reset_each_step || A.transpose_out || A.seg_count > 0) return false;
+  if (A.step == C3P_STEP_VON_NEUMANN_ID) return true;
+  if (A.step != C3P_STEP_LINDBLAD_ID || A.D > 32) return false;
+  return rho_lds_bytes(2, 2, A.C) <= (size_t)(150 * 1024);
+}
+
+hipError_t c3p_launch_ode_rhoq(const OdeArgs& A0, hipStream_t st) {
+  OdeArgs A = A0;
+  A.rho_general = getenv("C3P_ODE_RHO_GENERAL") != nullptr;  // A/B switch: two products per commutator for every input
+  return A.D <= 32 ? launch_rho1<2>(A, st) : launch_rho1<3>(A, st);
+}

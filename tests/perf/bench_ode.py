@@ -21,6 +21,9 @@ import numpy as np
 import torch
 
 from c3_amd import _lib, propagation as prop
+
+if os.environ.get("C3P_LIB"):  # A/B builds of the library (e.g. the -DC3P_RHOQ_TIMING probes)
+    _lib.LIB_PATH = os.path.abspath(os.environ["C3P_LIB"])
 from c3_amd.workloads import make_workload
 from oracle import c3_oracle as o
 
@@ -48,6 +51,7 @@ def main():
     ap.add_argument("--rho-batches", default="256,2048,16384")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--complex-ops", action="store_true", help="add an imaginary part to the control operators (complex instance)")
+    ap.add_argument("--synth-col", action="store_true", help="synthetic collapse operators where the config has none (lindblad step)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     dev = "cuda:0"
@@ -63,6 +67,10 @@ def main():
     if col_np is None:
         wl4 = make_workload(4, B=1, N=4)
         col_np = wl4.col_ops if wl4.D == D else None
+    if col_np is None and a.synth_col:
+        # two real band operators (a relaxation-like superdiagonal, a dephasing-like diagonal) for configs without their own
+        lower = np.diag(np.sqrt(np.arange(1, D) % 3 + 1.0), 1)
+        col_np = np.stack([0.05 * lower, 0.03 * np.diag(np.arange(D) % 3).astype(float)]).astype(complex)
     psi0 = np.zeros((D, 1), complex)
     psi0[0, 0] = 1.0
     rho0 = psi0 @ psi0.conj().T

@@ -523,3 +523,58 @@ def test_rk4_unitary_time_segments(prop):
     for b in range(B):
         Hs = h0[None] + np.einsum("kn,kij->nij", sig[b], hks)
         assert np.abs(U[b] - o.gen_u_rk4(Hs, 0.02, D)).max() < 1e-12
+
+
+# --------------------------------------------------------------------------
+# matrix-core rho-valued ODE kernel (c3p_ode_rhoq.hip): von Neumann / Lindblad states at 17 <= D <= 48
+# --------------------------------------------------------------------------
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["rk4", "rk38", "rk5", "tsit5"])
+@pytest.mark.parametrize("D,K,C,real", [(17, 1, 0, True), (27, 3, 0, True), (27, 3, 0, False), (32, 4, 0, False), (33, 2, 0, True),
+                                        (36, 3, 0, False), (48, 1, 0, True), (17, 2, 1, False), (27, 3, 2, True), (32, 1, 3, False)])
+def test_ode_rhoq_density_matrices(prop, solver, D, K, C, real):
+    """von_neumann (propagation.py:902-904) and lindblad (:886-894) on 16 x 16 register tiles + fp64 MFMA products:
+    trajectory and final state against the oracle's solver, real and complex operators, every tile-count class, dimensions
+    that are not multiples of 4 or 16."""
+    from c3_amd import _lib
+
+    B, N = 3, 11
+    h0, hks, sig, ts = _ode_problem(D, K, B, N, real, 11 * D + C)
+    rng = np.random.default_rng(D + C)
+    a = rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))
+    rho = a @ a.conj().T
+    rho /= np.trace(rho)
+    col = np.stack([0.2 * (rng.normal(size=(D, D)) + (0 if real else 1j) * rng.normal(size=(D, D))) for _ in range(C)]) if C else None
+    step = "lindblad" if C else "von_neumann"
+    out = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], rho, solver, step, col_ops=col))
+    assert _lib.last_kernel() == "ode_mfma"
+    fin = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], rho, solver, step, col_ops=col, final_only=True))
+    for b in range(B):
+        ref = o.ode_solver_arrays(h0, hks, sig[b], ts, rho, solver, step, col=col)["states"]
+        assert np.abs(out[b] - ref).max() < 1e-11
+        assert np.abs(fin[b] - ref[-1]).max() < 1e-11
+
+
+@pytest.mark.gpu
+def test_ode_rhoq_matches_workgroup_kernel_per_sample_states(prop):
+    """Per-sample initial states and the round-1 kernel as a second opinion (C3P_ODE_WG=1) at cfg3's dimension."""
+    from c3_amd import _lib
+
+    D, K, B, N = 27, 3, 6, 40
+    h0, hks, sig, ts = _ode_problem(D, K, B, N, True, 5)
+    rng = np.random.default_rng(1)
+    a = rng.normal(size=(B, D, D)) + 1j * rng.normal(size=(B, D, D))
+    rho = a @ a.conj().transpose(0, 2, 1)
+    rho /= np.trace(rho, axis1=1, axis2=2)[:, None, None]
+    new = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], rho, "tsit5", "von_neumann", final_only=True))
+    assert _lib.last_kernel() == "ode_mfma"
+    os.environ["C3P_ODE_WG"] = "1"
+    try:
+        old = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], rho, "tsit5", "von_neumann", final_only=True))
+        assert _lib.last_kernel() == "ode_wg"
+    finally:
+        os.environ.pop("C3P_ODE_WG")
+    assert np.abs(new - old).max() < 1e-12
+    assert np.abs(np.trace(new, axis1=1, axis2=2) - 1.0).max() < 1e-12
