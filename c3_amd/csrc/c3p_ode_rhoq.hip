@@ -21,8 +21,16 @@
 //    -i (L Y - Y R) = -i [H, Y] - {G, Y} / 2 (the same commutator loop on complex planes), and every jump term is two more
 //    products, T = C_m Y (written back to an LDS plane by the owning waves, one barrier) and T C_m^+ (the B fragment of C^+
 //    is the conjugated A-pattern read of C).  The C_m sit in LDS planes for the whole integration; D <= 32 only (LDS).
-//  * Control amplitudes: every lane reads the two neighbouring samples of its K lines one stage AHEAD (plain vector loads of
-//    one address: a broadcast; they return under the previous stage's products).  `Hs` is never materialised.
+//  * Hermitian shortcut (the usual case: Hermitian operators, rho(0) a density matrix): every stage argument is Hermitian,
+//    so Y H = (H Y)^+ -- ONE product per commutator (half the MFMAs), written to a plane, and the other half is the
+//    conjugate of the mirrored element read back behind one more barrier.  Symmetry is checked per sample in the prologue;
+//    the general two-product instance stays for everything else (`C3P_ODE_RHO_GENERAL=1` forces it).
+//  * Control amplitudes: a step only looks at u_stride + 2 samples per line; that window sits in one register (lane 4 k + i =
+//    sample base + i of line k), is fetched ONE STEP ahead by a single vector load and read with v_readlane; the barriers
+//    of the step loop wait for LDS only, so the load stays in flight.  `Hs` is never materialised.
+//  * K-loop fragments are fetched three K-steps (two in the general form) ahead of their MFMAs.  Built with
+//    `-mllvm -amdgpu-mfma-vgpr-form` (see __graft_entry__.py: without it the accumulators are copied between the two
+//    register files around every loop iteration).  `-DC3P_RHOQ_TIMING` prints a per-phase cycle budget of a stage.
 #include <type_traits>
 #include <utility>
 
@@ -42,6 +50,7 @@ __host__ __device__ constexpr OdeTableau rtab_of(int solver) {
 }
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef const double __attribute__((address_space(4)))* cdouble_ptr;  // constant address space: uniform loads become s_load
 
 template <int I, int N, class F>
 __device__ __forceinline__ void rstatic_for(F&& f) {
@@ -57,17 +66,17 @@ __host__ __device__ constexpr size_t rho_lds_bytes(int NT, int mode, int C) {
   return (size_t)rho_planes(mode, C) * (16 * NT) * (16 * NT + 2) * sizeof(double);
 }
 
+// workgroup barrier that waits for this wave's LDS traffic only (`__syncthreads` also drains the vector-memory counter, i.e.
+// the signal window that is meant to stay in flight, and the trajectory stores)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
-// Workgroups per CU the register budget is set for: three for the four-stage solvers on real operators (168 registers),
-// two for the other von Neumann instances (256), one for Lindblad (its planes fill the LDS anyway) and for the 9-wave
-// workgroups of D > 32 (three waves on one SIMD: 168 registers whatever is asked for).
-__host__ __device__ constexpr int rho_min_wgs(int NT, int solver, int mode) {
-#ifndef C3P_RHOQ_WGS_REAL4
-#define C3P_RHOQ_WGS_REAL4 2
-#endif
-  return NT != 2 || mode == 2 ? 1 : (mode == 0 && solver < 2 ? C3P_RHOQ_WGS_REAL4 : 2);
-}
+// Workgroups per CU the register budget is set for: two for the von Neumann instances at D <= 32 (256 registers; a budget
+// of 168 for three was tried on the four-stage solvers: 75 - 134 registers spilled inside the stage loop, 1.6x SLOWER),
+// one for Lindblad (its planes fill the LDS anyway) and for the 9-wave workgroups of D > 32 (three waves on one SIMD: 168
+// registers whatever is asked for -- the seven-stage solvers spill there).
+__host__ __device__ constexpr int rho_min_wgs(int NT, int solver, int mode) { return NT != 2 || mode == 2 ? 1 : 2; }
 
 template <int NT, int SOLVER, int MODE, bool HERM>
 __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) ode_rhoq_kernel(OdeArgs A) {
@@ -233,35 +242,43 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
   constexpr bool herm = HERM;
   const bool tail_barrier = !(herm && (!LIND || A.C == 0));  // see the end of a stage
   const double dt = A.dt;
+  // Control amplitudes at u = (n + node) * u_stride samples: linear interpolation, linear extrapolation past the last
+  // sample (tf_utils.py:557-559).  A step only looks at the samples base .. base + u_stride + 1 of every line
+  // (base = u_stride n): that window lives in ONE register, lane 4 k + i holding sample base + i of line k, and is fetched
+  // ONE STEP AHEAD by one vector load (the barriers of the step loop wait for LDS only, so the load stays in flight for a
+  // whole step); a stage reads its two neighbours out of it with v_readlane.  Lines past K read line 0 and meet zero operators.
   const double* sg = A.signals + (long)b * K * N;
-  // interpolated control amplitudes at u = (n + node) * u_stride samples: linear, linear extrapolation past the last
-  // sample (tf_utils.py:557-559).  Two phases: the loads are ISSUED right behind a stage's first barrier (unconditional,
-  // one address per line: lines past K read line 0 and meet zero operators) and COMBINED behind its products.
-  double raw0[RK], raw1[RK], rawf = 0.0;
-  auto fetch_issue = [&](double u) {
+  const int wk = (lane >> 2) & 3, wi = lane & 3;  // u_stride <= 2: four samples per line
+  auto window_base = [&](int n) {
+    int base = us * n;
+    if (base > N - 2) base = N - 2;
+    return base < 0 ? 0 : base;
+  };
+  auto load_window = [&](int base) {
+    int idx = base + wi;
+    if (idx > N - 1) idx = N - 1;
+    return K > 0 ? sg[(long)(wk < K ? wk : 0) * N + idx] : 0.0;
+  };
+  int wbase = 0;
+  double winv = 0.0, nwinv = load_window(window_base(0));
+  auto lane_value = [&](double x, int l) {  // x of lane l (uniform l)
+    const long long bits = __double_as_longlong(x);
+    const int lo32 = __builtin_amdgcn_readlane((int)bits, l), hi32 = __builtin_amdgcn_readlane((int)(bits >> 32), l);
+    return __longlong_as_double(((long long)hi32 << 32) | (unsigned int)lo32);
+  };
+  auto amplitudes = [&](double u, double (&c)[RK]) {
     int lo = (int)floor(u);
     if (lo > N - 2) lo = N - 2;
     if (lo < 0) lo = 0;
-    rawf = u - (double)lo;
-#ifdef C3P_RHOQ_X_NOFETCH
-    lo = 0;
-#endif
-    if (K > 0) {
+    const double f = u - (double)lo;
+    int li = __builtin_amdgcn_readfirstlane(lo - wbase);  // 0 .. u_stride
+    li = li < 0 ? 0 : (li > 2 ? 2 : li);
 #pragma unroll
-      for (int k = 0; k < RK; ++k) {
-        const double* y = sg + (long)(k < K ? k : 0) * N + lo;
-        raw0[k] = y[0];
-        raw1[k] = y[1];
-      }
+    for (int k = 0; k < RK; ++k) {
+      const double y0 = lane_value(winv, 4 * k + li), y1 = lane_value(winv, 4 * k + li + 1);
+      c[k] = fma(f, y1 - y0, y0);
     }
   };
-  double cur[RK];
-  auto fetch_finish = [&]() {
-#pragma unroll
-    for (int k = 0; k < RK; ++k) cur[k] = K > 0 ? fma(rawf, raw1[k] - raw0[k], raw0[k]) : 0.0;
-  };
-  fetch_issue(rtab_of(SOLVER).node[0] * (double)us);
-  fetch_finish();
   const int ksteps = (D + 3) >> 2;
   const int aoff = (16 * I + lc) * LD + lr;  // A fragment of row tile I: element (row lc, k = lr) of a K-step
   const int boff = lr * LD + 16 * J + lc;    // B fragment of column tile J: element (k = lr, column lc)
@@ -278,6 +295,9 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
 #define RHOQ_NOW() 0
 #endif
   for (int n = 0; n < A.n_steps; ++n) {
+    winv = nwinv;
+    wbase = window_base(n);
+    nwinv = load_window(window_base(n + 1));
     double kr[S][4], ki[S][4], qr[4], qi[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -288,10 +308,8 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
       constexpr int s = decltype(sc)::value;
       // H(t) at this stage's node and the stage argument, own tile
       [[maybe_unused]] const long long t0 = RHOQ_NOW();
-      {
-        constexpr double nn = (s + 1 < S) ? rtab_of(SOLVER).node[s + 1 < S ? s + 1 : 0] : 1.0 + rtab_of(SOLVER).node[0];
-        fetch_issue(((double)n + nn) * (double)us);
-      }
+      double cur[RK];
+      amplitudes(((double)n + rtab_of(SOLVER).node[s]) * (double)us, cur);
       double yr[4], yi[4];
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
@@ -329,9 +347,8 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
         Yi[eoff[v]] = yi[v];
       }
       [[maybe_unused]] const long long t1 = RHOQ_NOW();
-      __syncthreads();
+      lds_barrier();
       [[maybe_unused]] const long long t2 = RHOQ_NOW();
-      fetch_finish();  // amplitudes of the NEXT node (issued at the top of this stage; H(t) of this stage is in LDS by now)
       d4 accR = {0.0, 0.0, 0.0, 0.0}, accI = {0.0, 0.0, 0.0, 0.0};
       // fragments are fetched one K-step ahead of the MFMAs that use them (two register sets, loop unrolled by two)
       auto kloop = [&](auto nsc, auto&& load, auto&& mma) {
@@ -346,11 +363,7 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
             constexpr int j = decltype(jc)::value;
             if (kk + j < ksteps) {
               if (kk + j + NS - 1 < ksteps) load(kk + j + NS - 1, f[(j + NS - 1) % NS]);
-#ifndef C3P_RHOQ_X_NOMFMA
               mma(f[j]);
-#else
-              accR[0] += f[j][0] + f[j][2] + f[j][3];
-#endif
             }
           });
         }
@@ -432,13 +445,13 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
             tR = mfma(-ai, bi, tR);
             tI = mfma(ai, br, tI);
           }
-          if (m > 0) __syncthreads();  // the previous jump term's readers of T are done
+          if (m > 0) lds_barrier();  // the previous jump term's readers of T are done
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             Tr[eoff[v]] = tR[v];
             Ti[eoff[v]] = tI[v];
           }
-          __syncthreads();
+          lds_barrier();
           p_pending = false;
           for (int kk = 0; kk < ksteps; ++kk) {
             const int ao = aoff + 4 * kk, co = coff + 4 * kk;
@@ -450,7 +463,7 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
           }
         }
       }
-      if (p_pending) __syncthreads();
+      if (p_pending) lds_barrier();
       [[maybe_unused]] const long long t5 = RHOQ_NOW();
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
@@ -470,7 +483,7 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
       }
       // every wave is done reading the planes of this stage -- not needed on the Hermitian von Neumann path: the next
       // write of L / Y follows this wave's read of P, which follows the barrier behind every wave's products
-      if (tail_barrier) __syncthreads();
+      if (tail_barrier) lds_barrier();
       [[maybe_unused]] const long long t6 = RHOQ_NOW();
       RHOQ_T(0, t0, t1);
       RHOQ_T(1, t1, t2);
@@ -554,7 +567,7 @@ hipError_t launch_rho1(const OdeArgs& A, hipStream_t st) {
 bool c3p_ode_rhoq_supported(const OdeArgs& A) {
   if (getenv("C3P_ODE_WG")) return false;
   if (A.D < 17 || A.D > 48 || A.M != A.D || A.K > RK || A.hs || A.N < 2) return false;
-  if (A.reset_each_step || A.transpose_out || A.seg_count > 0) return false;
+  if (A.reset_each_step || A.transpose_out || A.seg_count > 0 || A.u_stride < 1 || A.u_stride > 2) return false;
   if (A.step == C3P_STEP_VON_NEUMANN_ID) return true;
   if (A.step != C3P_STEP_LINDBLAD_ID || A.D > 32) return false;
   return rho_lds_bytes(2, 2, A.C) <= (size_t)(150 * 1024);
