@@ -1603,6 +1603,22 @@ int c3p_rk4_unitary(const void* h0, const void* hks, const double* signals, cons
     if (flags & C3P_HOST_PTRS) return sg.finish();
     return 0;
   }
+  if (c3p_ode_rhoq_supported(a)) {
+    // 17 <= D <= 48: the propagator is a D x D matrix state with ONE product per stage: matrix-core kernel (c3p_ode_rhoq.hip)
+    g_last_kernel = C3P_KERNEL_ODE_MFMA;
+    a.want_all = 0;
+    a.states = (cplx*)d_U;
+    LAUNCH_TRY(c3p_launch_ode_rhoq(a, st));
+    if (d_dUs) {
+      a.want_all = 1;
+      a.reset_each_step = 1;
+      a.transpose_out = 1;
+      a.states = (cplx*)d_dUs;
+      LAUNCH_TRY(c3p_launch_ode_rhoq(a, st));
+    }
+    if (flags & C3P_HOST_PTRS) return sg.finish();
+    return 0;
+  }
   if (c3p_ode_rowq_supported(a)) {
     g_last_kernel = C3P_KERNEL_ODE_ROW;
     a.want_all = 0;

@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
   // elements may differ by 1e-15 of the operator's largest element (a dressed `V^T H V` is symmetric to a few units in the
   // last place of its largest entries, not bit for bit); the result then differs from the two-product form by at most
   // 2 T |H - H^+| / 2 <= 1e-15 |H| T, the size of the rounding errors of the integration itself.
+  const bool prop = A.step == C3P_STEP_PROPAGATOR_ID;  // Y' = -i H Y on a matrix of column states: one product, no mirror
   bool hm = true;
   auto herm_of = [&](const double (&xr)[4], const double (&xi)[4]) {
     double mx = 0.0;
@@ -170,7 +171,7 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
     __syncthreads();
     return ok;
   };
-  {
+  if (!prop) {
     double zr[4], zi[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -236,11 +237,15 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
     pr[v] = z.x;
     pi[v] = z.y;
   }
-  hm = herm_of(pr, pi) && hm;
-  // (the instance built for the other case integrates this sample: both are launched)
-  if (((__syncthreads_and((int)hm) != 0) && !A.rho_general) != HERM) return;
+  if (prop) {
+    if (!HERM) return;  // (only the one-product instance is launched for the propagator step)
+  } else {
+    hm = herm_of(pr, pi) && hm;
+    // (the instance built for the other case integrates this sample: both are launched)
+    if (((__syncthreads_and((int)hm) != 0) && !A.rho_general) != HERM) return;
+  }
   constexpr bool herm = HERM;
-  const bool tail_barrier = !(herm && (!LIND || A.C == 0));  // see the end of a stage
+  const bool tail_barrier = prop || !(herm && (!LIND || A.C == 0));  // see the end of a stage
   const double dt = A.dt;
   // Control amplitudes at u = (n + node) * u_stride samples: linear interpolation, linear extrapolation past the last
   // sample (tf_utils.py:557-559).  A step only looks at the samples base .. base + u_stride + 1 of every line
@@ -285,6 +290,12 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
   const int coff = (16 * J + lc) * LD + lr;  // A-pattern read at row tile J: B fragment of a conjugate transpose
   const long ssz = (long)D * D;
   cplx* outp = A.states + (long)b * (A.want_all ? (long)A.n_steps : 1) * ssz;
+  long oidx[4];  // (gen_du_rk4 stacks the propagated vectors as rows: transposed store)
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int row = 16 * I + 4 * v + lr;
+    oidx[v] = A.transpose_out ? (long)col * D + row : (long)row * D + col;
+  }
 
 #ifdef C3P_RHOQ_TIMING
   long long tp[6] = {0, 0, 0, 0, 0, 0};
@@ -387,10 +398,12 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
                 accI = mfma(f[1], f[2], accI);
               }
             });
+        if (!prop) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          Pr[eoff[v]] = accR[v];
-          Pi[eoff[v]] = accI[v];
+          for (int v = 0; v < 4; ++v) {
+            Pr[eoff[v]] = accR[v];
+            Pi[eoff[v]] = accI[v];
+          }
         }
       } else {
         // acc = H Y - Y H (L Y - Y R); [0..1] H as left operand, [2..3] Y as right, [4..5] Y as left, [6..7] H (R) as right
@@ -427,7 +440,7 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
               }
             });
       }
-      bool p_pending = herm;  // the tiles of H Y are written, not yet fenced
+      bool p_pending = herm && !prop;  // the tiles of H Y are written, not yet fenced
       [[maybe_unused]] const long long t3 = RHOQ_NOW();
       [[maybe_unused]] const long long t4 = t3;
       // k_s = -i dt acc (+ dt sum_m C_m Y C_m^+)
@@ -469,9 +482,11 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
       for (int v = 0; v < 4; ++v) {
         double cr_ = accR[v], ci_ = accI[v];
         if constexpr (herm) {  // H Y - (H Y)^+: the mirrored element of the mirrored tile
-          const int t = col * LD + 16 * I + 4 * v + lr;
-          cr_ -= Pr[t];
-          ci_ += Pi[t];
+          if (!prop) {
+            const int t = col * LD + 16 * I + 4 * v + lr;
+            cr_ -= Pr[t];
+            ci_ += Pi[t];
+          }
         }
         kr[s][v] = dt * (ci_ + jR[v]);
         ki[s][v] = dt * (jI[v] - cr_);
@@ -500,7 +515,16 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
     if (A.want_all) {
 #pragma unroll
       for (int v = 0; v < 4; ++v)
-        if (valid[v]) outp[(long)n * ssz + (long)(16 * I + 4 * v + lr) * D + col] = cmake(pr[v], pi[v]);
+        if (valid[v]) outp[(long)n * ssz + oidx[v]] = cmake(pr[v], pi[v]);
+    }
+    if (A.reset_each_step) {  // per-step propagators: every step starts from the initial state again
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        cplx z = cmake(0, 0);
+        if (valid[v]) z = init[(long)(16 * I + 4 * v + lr) * D + col];
+        pr[v] = z.x;
+        pi[v] = z.y;
+      }
     }
   }
 #ifdef C3P_RHOQ_TIMING
@@ -511,7 +535,7 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
   if (!A.want_all) {
 #pragma unroll
     for (int v = 0; v < 4; ++v)
-      if (valid[v]) outp[(long)(16 * I + 4 * v + lr) * D + col] = cmake(pr[v], pi[v]);
+      if (valid[v]) outp[oidx[v]] = cmake(pr[v], pi[v]);
   }
 }
 
@@ -533,6 +557,7 @@ hipError_t launch_rho4(const OdeArgs& A, hipStream_t st) {
 // that do not apply exit after the prologue.
 template <int NT, int SOLVER, int MODE>
 hipError_t launch_rho3(const OdeArgs& A, hipStream_t st) {
+  if (A.step == C3P_STEP_PROPAGATOR_ID) return launch_rho4<NT, SOLVER, MODE, true>(A, st);
   if (!A.rho_general) {
     hipError_t e = launch_rho4<NT, SOLVER, MODE, true>(A, st);
     if (e != hipSuccess) return e;
@@ -567,7 +592,9 @@ hipError_t launch_rho1(const OdeArgs& A, hipStream_t st) {
 bool c3p_ode_rhoq_supported(const OdeArgs& A) {
   if (getenv("C3P_ODE_WG")) return false;
   if (A.D < 17 || A.D > 48 || A.M != A.D || A.K > RK || A.hs || A.N < 2) return false;
-  if (A.reset_each_step || A.transpose_out || A.seg_count > 0 || A.u_stride < 1 || A.u_stride > 2) return false;
+  if (A.seg_count > 0 || A.u_stride < 1 || A.u_stride > 2) return false;
+  if (A.step == C3P_STEP_PROPAGATOR_ID) return !getenv("C3P_ODE_PROP_ROWS");  // (A/B switch: the lane-row column kernel)
+  if (A.reset_each_step || A.transpose_out) return false;
   if (A.step == C3P_STEP_VON_NEUMANN_ID) return true;
   if (A.step != C3P_STEP_LINDBLAD_ID || A.D > 32) return false;
   return rho_lds_bytes(2, 2, A.C) <= (size_t)(150 * 1024);

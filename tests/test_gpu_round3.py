@@ -367,11 +367,45 @@ def test_ode_rowq_cfg3_long_and_rk4_unitary(prop):
     dUs = np.zeros((B, (Ns - 1) // 2, D, D), complex)
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     h0c, hkc, sgc = np.ascontiguousarray(h0), np.ascontiguousarray(hks), np.ascontiguousarray(sig)
-    rc = lib.c3p_rk4_unitary(p(h0c), p(hkc), p(sgc), None, 0, 0.1, B, K, Ns, D, 1, p(U), p(dUs), None)
-    assert rc == 0 and _lib.last_kernel() == "ode_row"
+    for env, kern in ((None, "ode_mfma"), ("C3P_ODE_PROP_ROWS", "ode_row")):  # matrix-core kernel, lane-row column kernel
+        if env:
+            os.environ[env] = "1"
+        try:
+            U[:] = 0
+            dUs[:] = 0
+            rc = lib.c3p_rk4_unitary(p(h0c), p(hkc), p(sgc), None, 0, 0.1, B, K, Ns, D, 1, p(U), p(dUs), None)
+        finally:
+            if env:
+                os.environ.pop(env)
+        assert rc == 0 and _lib.last_kernel() == kern
+        for b in range(B):
+            Hs = h0[None] + np.einsum("kn,kij->nij", sig[b], hks)
+            ref = o.rk4_unitary_arrays(Hs, 0.1, D)
+            assert np.abs(U[b] - ref["U"]).max() < 1e-12
+            assert np.abs(dUs[b] - ref["dUs"]).max() < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,K,real", [(17, 1, True), (27, 3, True), (32, 2, False), (36, 3, True), (48, 4, False)])
+def test_rk4_unitary_matrix_core(prop, D, K, real):
+    """rk4_unitary (propagation.py:71-101,221-255) at 17 <= D <= 48 on the matrix-core kernel (one product per stage, stride-2
+    sample windows, per-step propagators stored transposed from a state that is reset every step) against the oracle."""
+    import ctypes
+
+    from c3_amd import _lib
+
+    B, Ns = 3, 21
+    h0, hks, sig, _ = _ode_problem(D, K, B, Ns, real, 300 + D)
+    lib = _lib.load()
+    U = np.zeros((B, D, D), complex)
+    dUs = np.zeros((B, (Ns - 1) // 2, D, D), complex)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    h0c, hkc, sgc = np.ascontiguousarray(h0), np.ascontiguousarray(hks), np.ascontiguousarray(sig)
+    rc = lib.c3p_rk4_unitary(p(h0c), p(hkc), p(sgc), None, 0, 0.05, B, K, Ns, D, 1, p(U), p(dUs), None)
+    assert rc == 0 and _lib.last_kernel() == "ode_mfma"
     for b in range(B):
         Hs = h0[None] + np.einsum("kn,kij->nij", sig[b], hks)
-        ref = o.rk4_unitary_arrays(Hs, 0.1, D)
+        ref = o.rk4_unitary_arrays(Hs, 0.05, D)
         assert np.abs(U[b] - ref["U"]).max() < 1e-12
         assert np.abs(dUs[b] - ref["dUs"]).max() < 1e-12
 
