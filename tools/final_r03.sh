@@ -46,6 +46,20 @@ python tests/perf/bench_ode.py --config 3 --steps schrodinger --solvers rk4,tsit
 python tests/perf/bench_ode.py --config 5 --steps schrodinger --solvers rk4 --batches 1024,8192 --out $O/ode_cfg5.json > /dev/null 2>&1
 C3P_ODE_WG=1 python tests/perf/bench_ode.py --config 2 --solvers rk4 --batches 2048 --rho-batches 2048 --out $O/ode_cfg2_round1_kernel.json > /dev/null 2>&1
 C3P_ODE_WG=1 python tests/perf/bench_ode.py --config 3 --steps schrodinger --solvers rk4 --batches 2048 --out $O/ode_cfg3_round1_kernel.json > /dev/null 2>&1
+# small final-state batches (time segments) and the direct integration beside them
+python tests/perf/bench_ode.py --config 2 --steps schrodinger --solvers rk4,tsit5 --batches 16,64,128,256,340,455,512 --out $O/ode_small_batches.json > /dev/null 2>&1
+C3P_ODE_NO_SEG=1 python tests/perf/bench_ode.py --config 2 --steps schrodinger --solvers rk4,tsit5 --batches 16,64,256,512 --out $O/ode_small_batches_direct.json > /dev/null 2>&1
+# rho-valued states at D = 27 / 36 on the matrix-core kernel, the round-1 kernel and the A/B switches beside it; rk4_unitary
+python tests/perf/bench_ode.py --config 3 --steps von_neumann,lindblad --synth-col --solvers rk4,tsit5 --rho-batches 256,1536 --out $O/ode_rho_cfg3.json > /dev/null 2>&1
+python tests/perf/bench_ode.py --config 5 --steps von_neumann --solvers rk4,tsit5 --rho-batches 256,1024 --out $O/ode_rho_cfg5.json > /dev/null 2>&1
+C3P_ODE_WG=1 python tests/perf/bench_ode.py --config 3 --steps von_neumann,lindblad --synth-col --solvers rk4 --rho-batches 256 --out $O/ode_rho_cfg3_round1_kernel.json > /dev/null 2>&1
+C3P_ODE_WG=1 python tests/perf/bench_ode.py --config 5 --steps von_neumann --solvers rk4 --rho-batches 256 --out $O/ode_rho_cfg5_round1_kernel.json > /dev/null 2>&1
+C3P_ODE_RHO_GENERAL=1 python tests/perf/bench_ode.py --config 3 --steps von_neumann --solvers rk4 --rho-batches 1536 --out $O/ode_rho_cfg3_general.json > /dev/null 2>&1
+python tests/perf/bench_ode.py --config 3 --complex-ops --steps von_neumann --solvers rk4 --rho-batches 1536 --out $O/ode_rho_cfg3_complex.json > /dev/null 2>&1
+python tests/perf/bench_rk4_unitary.py --config 3 --batches 64,256,1024 --out $O/rk4_unitary_cfg3.json > /dev/null 2>&1
+python tests/perf/bench_rk4_unitary.py --config 5 --batches 256 --out $O/rk4_unitary_cfg5.json > /dev/null 2>&1
+bash tools/profile_ode_rho.sh 3 1536 > /dev/null 2>&1
+cp gpurun_out/r03/ode_rho_pmc_summary.txt gpurun_out/r03/ode_rho_kernel_stats.csv $O/
 bash tools/profile_ode.sh 16384 > /dev/null 2>&1
 cp gpurun_out/r03/ode_pmc_summary.txt gpurun_out/r03/ode_kernel_stats.csv $O/
 python tools/ode_pmc_to_json.py 16384 1000 > $O/ode_roofline.json
