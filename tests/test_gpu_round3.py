@@ -612,3 +612,57 @@ def test_ode_rhoq_matches_workgroup_kernel_per_sample_states(prop):
         os.environ.pop("C3P_ODE_WG")
     assert np.abs(new - old).max() < 1e-12
     assert np.abs(np.trace(new, axis1=1, axis2=2) - 1.0).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_ode_rhoq_general_inputs_take_the_two_product_form(prop):
+    """A non-Hermitian 'state' and a non-Hermitian control operator are legal inputs of ode_solver (propagation.py:687-752
+    makes no assumption): the per-sample symmetry check must send them to the general instance, and a batch may mix both."""
+    D, K, B, N = 20, 2, 4, 9
+    h0, hks, sig, ts = _ode_problem(D, K, B, N, False, 41)
+    rng = np.random.default_rng(3)
+    a = rng.normal(size=(B, D, D)) + 1j * rng.normal(size=(B, D, D))
+    rho = a @ a.conj().transpose(0, 2, 1)
+    rho[1] = a[1]  # not Hermitian
+    rho[3] = a[3] + 0.5 * a[3].T
+    for hk_general in (False, True):
+        hk = hks.copy()
+        if hk_general:
+            hk[1] = hk[1] + 0.3 * rng.normal(size=(D, D))  # not Hermitian either
+        out = np.asarray(prop.ode_solve_batch(h0, hk, sig, ts[1] - ts[0], rho, "rk38", "von_neumann", final_only=True))
+        for b in range(B):
+            ref = o.ode_solver_arrays(h0, hk, sig[b], ts, rho[b], "rk38", "von_neumann", final_only=True)["states"]
+            assert np.abs(out[b] - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,step", [(3, "von_neumann"), (3, "lindblad"), (5, "von_neumann")])
+def test_ode_rhoq_full_size_properties(prop, cfg, step):
+    """BASELINE cfg3 / cfg5 operators and slice counts (N = 2000 / 5000) on the matrix-core kernel: the RK step preserves the
+    trace and Hermiticity exactly (rounding), the one-product and the two-product forms agree, two samples against the
+    oracle's solver."""
+    wl = workloads.make_workload(cfg, B=16)
+    D = wl.D
+    psi = np.zeros((D, 1), complex)
+    psi[1, 0] = 0.6
+    psi[2, 0] = 0.8j
+    rho = psi @ psi.conj().T
+    col = None
+    if step == "lindblad":
+        col = np.stack([0.05 * np.diag(np.sqrt(np.arange(1, D) % 3 + 1.0), 1), 0.03 * np.diag(np.arange(D) % 3).astype(float)]).astype(complex)
+    run = lambda: np.asarray(prop.ode_solve_batch(wl.h0, wl.hks, wl.signals, wl.dt, rho, "rk4", step, col_ops=col, final_only=True))
+    out = run()
+    from c3_amd import _lib
+
+    assert _lib.last_kernel() == "ode_mfma"
+    assert np.abs(np.trace(out, axis1=1, axis2=2) - 1.0).max() < 1e-11
+    assert np.abs(out - out.conj().transpose(0, 2, 1)).max() < 1e-13
+    os.environ["C3P_ODE_RHO_GENERAL"] = "1"
+    try:
+        gen = run()
+    finally:
+        os.environ.pop("C3P_ODE_RHO_GENERAL")
+    assert np.abs(out - gen).max() < 1e-11
+    for b in (0, 15):
+        ref = o.ode_solver_arrays(wl.h0, wl.hks, wl.signals[b], wl.ts, rho, "rk4", step, col=col, final_only=True)["states"]
+        assert np.abs(out[b] - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
