@@ -72,11 +72,13 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
-// Workgroups per CU the register budget is set for: two for the von Neumann instances at D <= 32 (256 registers; a budget
-// of 168 for three was tried on the four-stage solvers: 75 - 134 registers spilled inside the stage loop, 1.6x SLOWER),
-// one for Lindblad (its planes fill the LDS anyway) and for the 9-wave workgroups of D > 32 (three waves on one SIMD: 168
-// registers whatever is asked for -- the seven-stage solvers spill there).
-__host__ __device__ constexpr int rho_min_wgs(int NT, int solver, int mode) { return NT != 2 || mode == 2 ? 1 : 2; }
+// Workgroups per CU the register budget is set for: three for the four-stage solvers on real operators (168 registers: ~20
+// spilled, and still 16 - 26 % faster at B >= 768 than two workgroups with none), two for the other von Neumann instances at
+// D <= 32 (256), one for Lindblad (its planes fill the LDS anyway) and for the 9-wave workgroups of D > 32 (three waves on
+// one SIMD: 168 registers whatever is asked for -- the seven-stage solvers spill there).
+__host__ __device__ constexpr int rho_min_wgs(int NT, int solver, int mode) {
+  return NT != 2 || mode == 2 ? 1 : (mode == 0 && solver < 2 ? 3 : 2);
+}
 
 template <int NT, int SOLVER, int MODE, bool HERM>
 __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) ode_rhoq_kernel(OdeArgs A) {
