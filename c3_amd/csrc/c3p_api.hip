@@ -1713,6 +1713,58 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
   void* clp;
   if (ws_get(w, SL_CLP, (size_t)Dm * Dm * cs, &clp)) return -1;
   LAUNCH_TRY(c3p_launch_clp((const cplx*)d_col, C, D, (cplx*)clp, st));
+  if (Dm <= 36 && !getenv("C3P_TILED_GRAD")) {
+    // small superoperators (D <= 6): the whole sweep in three kernels on dense generator tables (c3p_grad.hip, general form) --
+    // the tiled path below spends ~0.4 ms of launches per slice whatever the batch
+    const int nb = (h0_bstride || hks_bstride) ? B : 1;
+    const long gsz = (long)Dm * Dm;
+    void* tab;
+    if (ws_get(w, SL_TABLES, (size_t)nb * (K + 1) * gsz * cs, &tab)) return -1;
+    LAUNCH_TRY(c3p_launch_lind_generators((const cplx*)d_h0, h0_bstride, (const cplx*)d_hks, hks_bstride, (const cplx*)clp, nb, K, D,
+                                          (cplx*)tab, st));
+    GradArgs A = {};
+    A.h0 = (const cplx*)tab;
+    A.h0_bstride = nb > 1 ? (long)(K + 1) * gsz : 0;
+    A.hks = (const cplx*)tab + gsz;
+    A.hks_bstride = A.h0_bstride;
+    A.signals = (const double*)d_sig;
+    A.fr_phase = (const double*)d_ph;
+    A.Ubar = (const cplx*)d_ub;
+    A.dt = dt;
+    A.B = B;
+    A.K = K;
+    A.N = N;
+    A.D = Dm;
+    A.ld = Dm | 1;
+    A.grad = (double*)d_grad;
+    A.general = 1;
+    long S = 4096 / B;
+    if (S > N / 8) S = N / 8;
+    if (S < 1) S = 1;
+    A.S = (int)S;
+    void* v;
+    if (ws_get(w, SL_SEG_A, (size_t)B * A.S * gsz * cs, &v)) return -1;
+    A.seg = (cplx*)v;
+    if (ws_get(w, SL_SEG_B, (size_t)B * A.S * gsz * cs, &v)) return -1;
+    A.Mb = (cplx*)v;
+    if (ws_get(w, SL_OUT1, ((size_t)B * A.S + (size_t)B * N) * gsz * cs, &v)) return -1;  // (SL_OUT0 stages grad_signals)
+    A.pre = (cplx*)v;
+    A.pstore = A.pre + (size_t)B * A.S * gsz;
+    const bool global = c3p_grad_lds_bytes_general(Dm) > 150 * 1024;
+    if (global) {
+      A.scratch_stride = (long)C3P_GRAD_NMAT_GENERAL * A.ld * Dm;
+      if (ws_get(w, SL_SCRATCH, (size_t)B * A.S * A.scratch_stride * cs, &v)) return -1;
+      A.scratch = (cplx*)v;
+    }
+    g_last_kernel = global ? C3P_KERNEL_GENERIC_GLOBAL : C3P_KERNEL_GENERIC_LDS;
+    if (record_start(w, st)) return -1;
+    LAUNCH_TRY(c3p_launch_grad_seg(A, global, st));
+    LAUNCH_TRY(c3p_launch_grad_scan_general(A, global, st));
+    LAUNCH_TRY(c3p_launch_grad_bwd_general(A, global, st));
+    if (record_stop(w, st)) return -1;
+    if (flags & C3P_HOST_PTRS) return sg.finish();
+    return 0;
+  }
   g_last_kernel = C3P_KERNEL_MFMA;
   if (record_start(w, st)) return -1;
   if (run_vjp_tiled(w, 1, (const cplx*)d_h0, h0_bstride, (const cplx*)d_hks, hks_bstride, (const double*)d_sig, (const cplx*)clp, dt, B,

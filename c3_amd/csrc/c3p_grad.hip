@@ -235,9 +235,11 @@ struct Shared {
 };
 
 // X~ = -i dt (H_n - tr(H_n)/D) / 2^s into buffer `dst`; returns s and the removed shift mu = -i dt tr(H_n)/D.
+// general generators (A.general): X = dt (G_0 + sum c_k G_k); conjT: X^H is assembled instead (all that follows -- shift, norm,
+// scaling -- then refers to the matrix that is exponentiated)
 template <bool GLOBAL>
 __device__ void assemble(const GMem<GLOBAL>& M, const GradArgs& A, Shared& sh, int b, int n, int dst, int tid, int nt,
-                         int& s_out, double& mu_r, double& mu_i) {
+                         int& s_out, double& mu_r, double& mu_i, bool conjT = false) {
   const int D = A.D, ld = A.ld;
   const cplx* h0b = A.h0 + (long)b * A.h0_bstride;
   const cplx* hkb = A.hks + (long)b * A.hks_bstride;
@@ -251,7 +253,11 @@ __device__ void assemble(const GMem<GLOBAL>& M, const GradArgs& A, Shared& sh, i
       h.x = fma(c, x.x, h.x);
       h.y = fma(c, x.y, h.y);
     }
-    M.st(dst + i * ld + j, cmake(h.y * A.dt, -h.x * A.dt));  // -i dt h
+    const cplx x = A.general ? cmake(h.x * A.dt, h.y * A.dt) : cmake(h.y * A.dt, -h.x * A.dt);  // dt G or -i dt h
+    if (conjT)
+      M.st(dst + j * ld + i, cconj(x));
+    else
+      M.st(dst + i * ld + j, x);
   }
   __syncthreads();
   if (tid == 0) {
@@ -470,6 +476,173 @@ __global__ void __launch_bounds__(256) grad_bwd_kernel(GradArgs A) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// General (non-unitary) generators: the Lindblad path (c3/optimizers/optimizer.py:206-216 over propagation.py:551-585).
+//   U = FR dU_{N-1} ... dU_0,  dU_n = exp(X_n),  X_n = dt (G_0 + sum_k c_k(n) G_k)
+//   grad[k,n] = Re <Ubar, FR S_n L(X_n; dt G_k) P_n> = Re <L(X_n^H; M_n), dt G_k>,   M_n = A_n P_n^H,
+//   P_n = dU_{n-1} ... dU_0 (prefix),  A_n = S_n^H FR^H Ubar,  S_n = dU_{N-1} ... dU_{n+1} (suffix).
+// A_n runs backwards (A_{n-1} = dU_n^H A_n), P_n forwards, and a dissipative slice has no cheap inverse to turn one of them
+// around: the scan leaves the prefix at the START and the left adjoint at the END of every segment, the sweep of a segment first
+// walks forward storing P_n of each of its slices (memory: [B,N,D,D]), then backward with ONE pair evaluation per slice
+// at Y = X_n^H: its value exp(X_n^H) = dU_n^H advances A, its derivative L(X_n^H; M_n) is the cotangent of the generator.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool GLOBAL>
+__global__ void __launch_bounds__(256) grad_scan_general_kernel(GradArgs A) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int b = blockIdx.x;
+  const int D = A.D, ld = A.ld, msz = ld * D;
+  GMem<GLOBAL> M;
+  M.g = GLOBAL ? A.scratch + (long)b * A.S * A.scratch_stride : nullptr;
+  int bU = 0, bV = msz;
+  const int bS = 2 * msz;
+  const cplx* segb = A.seg + (long)b * A.S * D * D;
+  for (int e = tid; e < D * D; e += nt) M.st(bU + (e / D) * ld + (e % D), cmake((e / D) == (e % D) ? 1.0 : 0.0, 0.0));
+  __syncthreads();
+  cplx* pb = A.pre + (long)b * A.S * D * D;
+  for (int j = 0; j < A.S; ++j) {  // prefix in front of segment j
+    copy_out(M, pb + (long)j * D * D, bU, D, ld, tid, nt);
+    if (j == A.S - 1) break;
+    copy_in(M, bS, segb + (long)j * D * D, D, ld, tid, nt);
+    mm(M, bV, bS, bU, D, ld, tid, nt);
+    const int t = bU;
+    bU = bV;
+    bV = t;
+  }
+  __syncthreads();
+  const cplx* ub = A.Ubar + (long)b * D * D;
+  for (int e = tid; e < D * D; e += nt) {  // FR^H Ubar: row i times e^{-i phi_i}
+    const int i = e / D, j = e - i * D;
+    cplx v = ub[e];
+    if (A.fr_phase) {
+      double sn, cs;
+      sincos(A.fr_phase[(long)b * D + i], &sn, &cs);
+      v = cmul(cmake(cs, -sn), v);
+    }
+    M.st(bU + i * ld + j, v);
+  }
+  __syncthreads();
+  cplx* mb = A.Mb + (long)b * A.S * D * D;
+  for (int j = A.S - 1; j >= 0; --j) {  // left adjoint behind segment j
+    copy_out(M, mb + (long)j * D * D, bU, D, ld, tid, nt);
+    if (j == 0) break;
+    copy_in(M, bS, segb + (long)j * D * D, D, ld, tid, nt);
+    gmm<GLOBAL, false, true, false>(M, bV, bS, bU, D, ld, tid, nt);  // S_j^H A
+    const int t = bU;
+    bU = bV;
+    bV = t;
+  }
+}
+
+template <bool GLOBAL>
+__global__ void __launch_bounds__(256) grad_bwd_general_kernel(GradArgs A) {
+  __shared__ Shared sh;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int wg = blockIdx.x;
+  const int b = wg / A.S, seg = wg - b * A.S;
+  const int n0 = (int)(((long)seg * A.N) / A.S), n1 = (int)(((long)(seg + 1) * A.N) / A.S);
+  const int D = A.D, ld = A.ld, msz = ld * D;
+  GMem<GLOBAL> M;
+  M.g = GLOBAL ? A.scratch + (long)wg * A.scratch_stride : nullptr;
+  Bufs q;
+  q.A = 0, q.A2 = msz, q.A3 = 2 * msz, q.A6 = 3 * msz, q.T1 = 4 * msz, q.T2 = 5 * msz, q.A9 = 6 * msz, q.T = 7 * msz;
+  q.dA = 8 * msz, q.dA2 = 9 * msz, q.dA3 = 10 * msz, q.dA6 = 11 * msz, q.dT1 = 12 * msz, q.dT2 = 13 * msz,
+  q.dA9 = 14 * msz, q.dT = 15 * msz;
+  const int bP = 16 * msz, bA = 17 * msz, bM = 18 * msz, bV = 19 * msz;
+  const cplx* gkb = A.hks + (long)b * A.hks_bstride;
+  cplx* ps = A.pstore + (long)b * A.N * D * D;
+  auto phase_of = [](double mr, double mi) {
+    double sn, cs;
+    sincos(mi, &sn, &cs);
+    const double er = exp(mr);
+    return cmake(er * cs, er * sn);
+  };
+  // forward: the prefix in front of every slice of this segment
+  copy_in(M, bP, A.pre + (long)wg * D * D, D, ld, tid, nt);
+  for (int n = n0; n < n1; ++n) {
+    copy_out(M, ps + (long)n * D * D, bP, D, ld, tid, nt);
+    if (n == n1 - 1) break;
+    int s;
+    double mr, mi;
+    assemble(M, A, sh, b, n, q.A, tid, nt, s, mr, mi);
+    t18_pair<GLOBAL, false>(M, q, s, D, ld, tid, nt);
+    mm(M, bV, q.T, bP, D, ld, tid, nt);
+    const cplx ph = phase_of(mr, mi);
+    for (int e = tid; e < D * D; e += nt) {
+      const int o = (e / D) * ld + (e % D);
+      M.st(bP + o, cmul(ph, M.ld(bV + o)));
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  // backward
+  copy_in(M, bA, A.Mb + (long)wg * D * D, D, ld, tid, nt);
+  for (int n = n1 - 1; n >= n0; --n) {
+    copy_in(M, bP, ps + (long)n * D * D, D, ld, tid, nt);
+    gmm<GLOBAL, false, false, true>(M, bM, bA, bP, D, ld, tid, nt);  // M = A P_n^H
+    int s;
+    double mr, mi;
+    assemble(M, A, sh, b, n, q.A, tid, nt, s, mr, mi, true);  // Y = X_n^H
+    const double sc = ldexp(1.0, -s);
+    for (int e = tid; e < D * D; e += nt) {
+      const int o = (e / D) * ld + (e % D);
+      M.st(q.dA + o, cscale(M.ld(bM + o), sc));
+    }
+    __syncthreads();
+    t18_pair<GLOBAL, true>(M, q, s, D, ld, tid, nt);  // T = e^{-mu} exp(Y), dT = e^{-mu} L(Y; M)
+    const cplx ph = phase_of(mr, mi);
+    // grad[k,n] = Re <Z, dt G_k>, Z = e^{mu} dT
+    for (int k = 0; k < A.K; ++k) {
+      double part = 0.0;
+      for (int e = tid; e < D * D; e += nt) {
+        const cplx z = cmul(ph, M.ld(q.dT + (e / D) * ld + (e % D)));
+        const cplx g = gkb[(long)k * D * D + e];
+        part = fma(z.x, g.x, part);
+        part = fma(z.y, g.y, part);
+      }
+      sh.red[tid] = part;
+      __syncthreads();
+      if (tid == 0) {
+        double tot = 0.0;
+        for (int t = 0; t < nt; ++t) tot += sh.red[t];
+        A.grad[((long)b * A.K + k) * A.N + n] = tot * A.dt;
+      }
+      __syncthreads();
+    }
+    if (n > n0) {
+      mm(M, bV, q.T, bA, D, ld, tid, nt);  // A <- dU_n^H A
+      for (int e = tid; e < D * D; e += nt) {
+        const int o = (e / D) * ld + (e % D);
+        M.st(bA + o, cmul(ph, M.ld(bV + o)));
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// row r = (i,j), column c = (k,l) of -i (H (x) 1 - 1 (x) H^T) [+ clp]: -i (H[i,k] d_jl - d_ik H[l,j])
+__global__ void lind_gen_kernel(const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const cplx* clp, int K, int D, cplx* out) {
+  const int Dm = D * D;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)Dm * Dm) return;
+  const int b = blockIdx.y, which = blockIdx.z;
+  const cplx* H = which == 0 ? h0 + (long)b * h0_bs : hks + (long)b * hk_bs + (long)(which - 1) * D * D;
+  const int r = (int)(e / Dm), c = (int)(e - (long)r * Dm);
+  const int i = r / D, j = r - i * D, k = c / D, l = c - k * D;
+  cplx v = which == 0 ? clp[e] : cmake(0, 0);
+  if (j == l) {
+    const cplx h = H[i * D + k];
+    v.x += h.y;
+    v.y -= h.x;
+  }
+  if (i == k) {
+    const cplx h = H[l * D + j];
+    v.x -= h.y;
+    v.y += h.x;
+  }
+  out[((long)b * (K + 1) + which) * Dm * Dm + e] = v;
+}
+
 }  // namespace
 
 int c3p_grad_threads(int D) { return D <= 10 ? 64 : (D <= 20 ? 128 : 256); }
@@ -513,4 +686,36 @@ hipError_t c3p_launch_grad_scan(const GradArgs& A, bool global_scratch, hipStrea
 hipError_t c3p_launch_grad_bwd(const GradArgs& A, bool global_scratch, hipStream_t st) {
   return global_scratch ? launch_one(grad_bwd_kernel<true>, (unsigned)(A.B * A.S), A, true, st)
                         : launch_one(grad_bwd_kernel<false>, (unsigned)(A.B * A.S), A, false, st);
+}
+
+size_t c3p_grad_lds_bytes_general(int D) { return (size_t)C3P_GRAD_NMAT_GENERAL * (D | 1) * D * sizeof(cplx); }
+
+namespace {
+template <typename KT>
+hipError_t launch_general(KT kern, unsigned grid, const GradArgs& A, bool global_scratch, hipStream_t st) {
+  const int nt = c3p_grad_threads(A.D);
+  const size_t lds = global_scratch ? 0 : c3p_grad_lds_bytes_general(A.D);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), lds, st, A);
+  return hipGetLastError();
+}
+}  // namespace
+
+hipError_t c3p_launch_grad_scan_general(const GradArgs& A, bool global_scratch, hipStream_t st) {
+  return global_scratch ? launch_general(grad_scan_general_kernel<true>, (unsigned)A.B, A, true, st)
+                        : launch_general(grad_scan_general_kernel<false>, (unsigned)A.B, A, false, st);
+}
+hipError_t c3p_launch_grad_bwd_general(const GradArgs& A, bool global_scratch, hipStream_t st) {
+  return global_scratch ? launch_general(grad_bwd_general_kernel<true>, (unsigned)(A.B * A.S), A, true, st)
+                        : launch_general(grad_bwd_general_kernel<false>, (unsigned)(A.B * A.S), A, false, st);
+}
+hipError_t c3p_launch_lind_generators(const cplx* h0, long h0_bstride, const cplx* hks, long hks_bstride, const cplx* clp, int nb,
+                                      int K, int D, cplx* out, hipStream_t st) {
+  const long nel = (long)D * D * D * D;
+  hipLaunchKernelGGL(lind_gen_kernel, dim3((unsigned)((nel + 255) / 256), (unsigned)nb, (unsigned)(K + 1)), dim3(256), 0, st, h0, h0_bstride,
+                     hks, hks_bstride, clp, K, D, out);
+  return hipGetLastError();
 }

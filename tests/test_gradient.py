@@ -1,4 +1,6 @@
 """Gradient of the propagators w.r.t. the control samples."""
+import os
+
 import numpy as np
 import pytest
 
@@ -283,6 +285,42 @@ def test_lindblad_vjp_vs_oracle(prop, dims, N, B, C):
     g = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar, fr_phase=ph))
     for b in range(B):
         want = o.pwc_lindblad_signal_gradient(h0, hks, col, sig[b], dt, Ubar[b], ph[b])
+        assert np.abs(g[b] - want).max() < 1e-10 * np.abs(want).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,N,B,C,per_sample", [(2, 100, 3, 1, False), (3, 64, 2, 2, True), (4, 40, 2, 1, False), (5, 17, 2, 2, False), (6, 9, 2, 1, True)])
+def test_lindblad_vjp_small_superoperators_general_sweep(prop, D, N, B, C, per_sample):
+    """D^2 <= 36: the three-kernel sweep for general (non-unitary) generators -- several time segments per sample (prefix and
+    left adjoint of every segment from the scan), LDS (D <= 4) and global-scratch (D = 5, 6) variants, per-sample operators,
+    moderate dissipation -- against the FD-pinned oracle and against the tiled sweep (C3P_TILED_GRAD=1) on the same inputs."""
+    from c3_amd import _lib
+
+    rng = np.random.default_rng(100 * D + N)
+    herm = lambda s: (lambda a: s * (a + a.conj().T) / 2)(rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))
+    K = 2
+    nb = B if per_sample else 1
+    h0 = np.stack([herm(0.8) for _ in range(nb)])
+    hks = np.stack([np.stack([herm(0.5) for _ in range(K)]) for _ in range(nb)])
+    if not per_sample:
+        h0, hks = h0[0], hks[0]
+    col = np.stack([0.25 * (rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))) for _ in range(C)])
+    sig = rng.uniform(-1, 1, size=(B, K, N))
+    Dm = D * D
+    Ubar = rng.normal(size=(B, Dm, Dm)) + 1j * rng.normal(size=(B, Dm, Dm))
+    ph = rng.uniform(0, 2 * np.pi, size=(B, Dm))
+    dt = 0.3
+    g = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar, fr_phase=ph))
+    assert _lib.last_kernel() in ("generic_lds", "generic_global")
+    os.environ["C3P_TILED_GRAD"] = "1"
+    try:
+        gt = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar, fr_phase=ph))
+        assert _lib.last_kernel() == "mfma"
+    finally:
+        os.environ.pop("C3P_TILED_GRAD")
+    assert np.abs(g - gt).max() < 1e-10 * np.abs(gt).max()
+    for b in range(B):
+        want = o.pwc_lindblad_signal_gradient(h0[b] if per_sample else h0, hks[b] if per_sample else hks, col, sig[b], dt, Ubar[b], ph[b])
         assert np.abs(g[b] - want).max() < 1e-10 * np.abs(want).max()
 
 
