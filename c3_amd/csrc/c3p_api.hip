@@ -699,6 +699,94 @@ int run_vjp_smalld(DeviceWs* w, GradArgs& G, hipStream_t st) {
   return 0;
 }
 
+// Lindblad gradient on the small-D MFMA kernels (superoperators up to 12 x 12, D <= 3), general-generator form: slice
+// propagators + segment products from the forward chain kernel, the general scan of c3p_grad.hip (prefix at the start, left
+// adjoint at the end of every segment), then smalld_grad_general_kernel.  Returns 1 when not applicable.
+int run_vjp_lind_smalld(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals, const cplx* clp,
+                        double dt, int B, int K, int N, int D, int Dm, const double* fr_phase, const cplx* Ubar, double* grad,
+                        hipStream_t st) {
+  const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
+  const int S = pick_segments(B, N, K, Dm, per_sample, 4096);
+  if (S < 0) return 1;
+  const int nsamp = per_sample ? B : 1;
+  const size_t tdoubles = (size_t)nsamp * c3p_smalld_table_doubles(Dm, K);
+  // (the backward kernel keeps BOTH table sets in LDS)
+  if ((2 * c3p_smalld_table_doubles(Dm, K) + 8 * (size_t)c3p_smalld_mat_doubles(Dm) + 4 * (size_t)K * ((N + S - 1) / S)) * sizeof(double) > 60 * 1024)
+    return 1;
+  void* v;
+  if (ws_get(w, SL_TABLES, 2 * tdoubles * sizeof(double), &v)) return -1;
+  double* tabs = (double*)v;
+  PrepArgs p = {};
+  p.h0 = h0;
+  p.h0_bstride = h0_bs;
+  p.hks = hks;
+  p.hks_bstride = hk_bs;
+  p.clp = clp;
+  p.dt = dt;
+  p.K = K;
+  p.Dh = D;
+  p.lindblad = 1;
+  p.tables = tabs;
+  LAUNCH_TRY(c3p_launch_smalld_prep(p, Dm, nsamp, st));
+  p.conjT = 1;
+  p.tables = tabs + tdoubles;
+  LAUNCH_TRY(c3p_launch_smalld_prep(p, Dm, nsamp, st));
+  const size_t msz = (size_t)Dm * Dm * sizeof(cplx);
+  void *sv, *mv, *bv;
+  if (ws_get(w, SL_SEG_A, (size_t)B * S * msz, &sv)) return -1;
+  if (ws_get(w, SL_SEG_B, (size_t)B * S * msz, &mv)) return -1;
+  if (ws_get(w, SL_OUT1, ((size_t)B * S + 2 * (size_t)B * N) * msz, &bv)) return -1;  // (SL_OUT0 stages grad_signals)
+  cplx* pre = (cplx*)bv;
+  cplx* dUs = pre + (size_t)B * S * Dm * Dm;
+  cplx* pstore = dUs + (size_t)B * N * Dm * Dm;
+  SmallArgs a = {};
+  a.tables = tabs;
+  a.tab_per_sample = per_sample ? 1 : 0;
+  a.signals = signals;
+  a.B = B;
+  a.K = K;
+  a.N = N;
+  a.Dm = Dm;
+  a.S = S;
+  a.Lmax = (N + S - 1) / S;
+  a.mode = C3P_MODE_LINDBLAD;
+  a.seg_out = (cplx*)sv;
+  a.dUs_out = dUs;
+  LAUNCH_TRY(c3p_launch_smalld_chain(a, st));
+  GradArgs G = {};
+  G.Ubar = Ubar;
+  G.fr_phase = fr_phase;
+  G.B = B;
+  G.K = K;
+  G.N = N;
+  G.D = Dm;
+  G.ld = Dm | 1;
+  G.S = S;
+  G.seg = (cplx*)sv;
+  G.Mb = (cplx*)mv;
+  G.pre = pre;
+  G.general = 1;
+  LAUNCH_TRY(c3p_launch_grad_scan_general(G, false, st));
+  SmallGradArgs g = {};
+  g.tables = tabs;
+  g.tables_h = tabs + tdoubles;
+  g.tab_per_sample = a.tab_per_sample;
+  g.signals = signals;
+  g.Mb = G.Mb;
+  g.pre = pre;
+  g.dUs = dUs;
+  g.pstore = pstore;
+  g.grad = grad;
+  g.B = B;
+  g.K = K;
+  g.N = N;
+  g.Dm = Dm;
+  g.S = S;
+  g.Lmax = a.Lmax;
+  LAUNCH_TRY(c3p_launch_smalld_grad_general(g, st));
+  return 0;
+}
+
 // ---------------------------------------------------------------------------
 // Mid-D MFMA path (13 <= Dm <= 40): one 4-wave workgroup per chain, matrices as LDS images
 // ---------------------------------------------------------------------------
@@ -1713,6 +1801,20 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
   void* clp;
   if (ws_get(w, SL_CLP, (size_t)Dm * Dm * cs, &clp)) return -1;
   LAUNCH_TRY(c3p_launch_clp((const cplx*)d_col, C, D, (cplx*)clp, st));
+  if (Dm <= kSmallDLimit && c3p_smalld_supported(Dm) && K <= 8 && !(flags & C3P_FORCE_GENERIC) && !getenv("C3P_TILED_GRAD") &&
+      !getenv("C3P_VALU_GRAD")) {
+    // superoperators up to 12 x 12 (D <= 3): the same general-generator sweep on the small-D matrix-core kernels
+    if (record_start(w, st)) return -1;
+    const int rc = run_vjp_lind_smalld(w, (const cplx*)d_h0, h0_bstride, (const cplx*)d_hks, hks_bstride, (const double*)d_sig,
+                                       (const cplx*)clp, dt, B, K, N, D, Dm, (const double*)d_ph, (const cplx*)d_ub, (double*)d_grad, st);
+    if (rc < 0) return -1;
+    if (rc == 0) {
+      g_last_kernel = C3P_KERNEL_SMALLD;
+      if (record_stop(w, st)) return -1;
+      if (flags & C3P_HOST_PTRS) return sg.finish();
+      return 0;
+    }
+  }
   if (Dm <= 36 && !getenv("C3P_TILED_GRAD")) {
     // small superoperators (D <= 6): the whole sweep in three kernels on dense generator tables (c3p_grad.hip, general form) --
     // the tiled path below spends ~0.4 ms of launches per slice whatever the batch

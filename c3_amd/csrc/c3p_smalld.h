@@ -51,6 +51,11 @@ struct SmallGradArgs {
   int B, K, N, Dm, S, Lmax;
   // the real-Hamiltonian sweep (smalld_grad_real_kernel) has taken the samples it can: this launch skips them
   int skip_real;
+  // general (non-unitary) generators, e.g. Lindblad superoperators (smalld_grad_general_kernel; method in c3p_grad.hip):
+  const double* tables_h;  // tables of the conjugate-transposed generators G_k^H (PrepArgs.conjT)
+  const cplx* pre;         // [B,S,Dm,Dm] prefix product at the START of each segment; Mb = LEFT adjoint at its end
+  const cplx* dUs;         // [B,N,Dm,Dm] slice propagators of the forward pass
+  cplx* pstore;            // [B,N,Dm,Dm] scratch: prefix product in front of every slice
 };
 
 struct PrepArgs {
@@ -61,6 +66,7 @@ struct PrepArgs {
   const cplx* clp;  // Lindblad dissipator [Dm*Dm] or null
   double dt;
   int K, Dh, lindblad;
+  int conjT;  // tables of G^H instead of G (backward sweep of general generators)
   double* tables;
   int* counters;  // zeroed here (one launch fewer than a memset node); may be null
   int ncounters;
@@ -72,5 +78,6 @@ size_t c3p_smalld_table_doubles(int Dm, int K);
 bool c3p_smalld_supported(int Dm);
 hipError_t c3p_launch_smalld_chain(const SmallArgs& A, hipStream_t st);
 hipError_t c3p_launch_smalld_grad(const SmallGradArgs& A, hipStream_t st);
+hipError_t c3p_launch_smalld_grad_general(const SmallGradArgs& A, hipStream_t st);  // general generators (Lindblad)
 hipError_t c3p_launch_smalld_grad_real(const SmallGradArgs& A, hipStream_t st);  // real-Hamiltonian sweep only (c3p_launch_smalld_grad calls it)
 hipError_t c3p_launch_smalld_prep(const PrepArgs& P, int Dm, int nsamp, hipStream_t st);

@@ -1292,8 +1292,9 @@ __global__ void __launch_bounds__(64) smalld_prep_kernel(PrepArgs P) {
       }
       v = cscale(v, P.dt);
     }
-    g[2 * e] = v.x;
-    g[2 * e + 1] = v.y;
+    const int eo = P.conjT ? col * D + row : e;  // G^H: element (col, row) = conj(G[row][col])
+    g[2 * eo] = v.x;
+    g[2 * eo + 1] = P.conjT ? -v.y : v.y;
   }
   __syncthreads();
   if (tid == 0) {
@@ -1671,6 +1672,301 @@ __global__ void __launch_bounds__(64, 1) smalld_grad_kernel(SmallGradArgs A) {
       mm_img<D>(img1, roff, negmask, T, V);
       mat_zero<D>(M);
       mm_img<D>(img0, roff, negmask, V, M);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward sweep for GENERAL generators (Lindblad superoperators up to 12 x 12, i.e. D <= 3): the slices are not unitary, so
+// the adjoint state cannot be carried as M_n = dU_n^H M_{n+1} dU_n.  Method of c3p_grad.hip (general form):
+//   grad[k,n] = Re <L(X_n^H; M_n), G_k>,  M_n = A_n P_n^H,  P_n = dU_{n-1} .. dU_0 (prefix),  A_n = S_n^H FR^H Ubar (left adjoint).
+// Per chain: a forward walk over the segment, P <- dU_n P with the slice propagators of the forward pass (one product per
+// slice), every P_n stored; then backwards, ONE pair evaluation of T18 per slice at Y = X_n^H (tables of G^H): the value
+// exp(Y) = dU_n^H advances A, the derivative L(Y; M_n) is the generator's cotangent.  The trace shifts do not cancel here: A and
+// the derivative carry them as ONE complex scalar per chain, applied to the complex inner product <dT, G_k> at the end.
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(64, 1) smalld_grad_general_kernel(SmallGradArgs A) {
+  using C = SD<D>;
+  constexpr int NBI = C::NBI, NJ = C::NJ, W = C::W, MAT = C::MAT;
+  typedef double Mat[NBI][NJ];
+  const int lane = threadIdx.x;
+  LanePos lp;
+  lp.r = lane >> 4;
+  lp.b = (lane >> 2) & 3;
+  lp.c = lane & 3;
+  lp.idx16 = lp.r * 4 + lp.c;
+  const int K = A.K;
+  double* tab = c3p_sd_lds;                 // G tables: inner products
+  double* tabh = tab + (1 + K) * (MAT + 4);  // G^H tables: the matrix that is exponentiated
+  double* img0 = tabh + (1 + K) * (MAT + 4);
+  double* img1 = img0 + 4 * MAT;
+  double* sg = img1 + 4 * MAT;
+
+  const long chain = (long)blockIdx.x * 4 + lp.b;
+  const long nchains = (long)A.B * A.S;
+  const bool valid = chain < nchains;
+  const long cc = valid ? chain : nchains - 1;
+  const int sample = (int)(cc / A.S);
+  const int seg = (int)(cc - (long)sample * A.S);
+  const int n0 = (int)(((long)seg * A.N) / A.S);
+  const int n1 = (int)(((long)(seg + 1) * A.N) / A.S);
+  const int len = n1 - n0;
+
+  const int woff = lp.b * MAT + lp.r * W + lp.c;
+  const int roff = lp.b * MAT + (2 * (lp.c >> 1) + ((lp.c ^ lp.r) & 1)) * W + (lp.r >> 1);
+  const unsigned negmask = (((lp.c & 1) == 0) && ((lp.r & 1) == 1)) ? 0x80000000u : 0u;
+  const int toff = lp.r * W + lp.c;
+  const int poff = (lp.r ^ 1) * W + lp.c;  // the same element's other part (Re <-> Im) in a table
+  const int ddelta = (lp.r & 1) ? 1000 : ((lp.r >> 1) - lp.c);
+  const int rhalf = lp.r >> 1;
+
+  const long tsz = (long)(1 + K) * (MAT + 4);
+  const double* gt0 = A.tables + (long)(A.tab_per_sample ? sample : 0) * tsz;
+  const double* gh0 = A.tables_h + (long)(A.tab_per_sample ? sample : 0) * tsz;
+  for (int e = lane; e < (int)tsz; e += 64) {
+    tab[e] = gt0[e];
+    tabh[e] = gh0[e];
+  }
+  __syncthreads();
+  double nrm = tabh[MAT + 2];
+  for (int k = 0; k < K; ++k) {
+    const double* s = A.signals + ((long)sample * K + k) * A.N + n0;
+    double cmax = 0.0;
+    for (int t = lp.idx16; t < A.Lmax; t += 16) {
+      const double v = (valid && t < len) ? s[t] : 0.0;
+      sg[(lp.b * K + k) * A.Lmax + t] = v;
+      cmax = fmax(cmax, fabs(v));
+    }
+    cmax = fmax(cmax, __shfl_xor(cmax, 1));
+    cmax = fmax(cmax, __shfl_xor(cmax, 2));
+    cmax = fmax(cmax, __shfl_xor(cmax, 16));
+    cmax = fmax(cmax, __shfl_xor(cmax, 32));
+    nrm = fma(cmax, tabh[(k + 1) * (MAT + 4) + MAT + 2], nrm);
+  }
+  nrm = fmax(nrm, __shfl_xor(nrm, 4));
+  nrm = fmax(nrm, __shfl_xor(nrm, 8));
+  nrm = readfirstlane_f64(nrm);
+  int ps = 0;
+  {
+    double p = C3P_T18_THETA;
+    while (p < nrm && ps < 40) {
+      p *= 2.0;
+      ++ps;
+    }
+  }
+  ps = __builtin_amdgcn_readfirstlane(ps);
+  const double scale = ldexp(1.0, -ps);
+  __syncthreads();
+
+  // element (row, col), part r & 1 of a plain complex matrix in global memory -> D layout (TR: its conjugate transpose)
+  auto load_plain = [&](Mat& m, const cplx* srcc, bool on, bool TR) {
+    const double* src = reinterpret_cast<const double*>(srcc);
+#pragma unroll
+    for (int I = 0; I < NBI; ++I)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) {
+        const int row = 2 * I + (lp.r >> 1), col = 4 * J + lp.c;
+        double v = 0.0;
+        if (on && row < D && col < D) {
+          v = TR ? src[(col * D + row) * 2 + (lp.r & 1)] : src[(row * D + col) * 2 + (lp.r & 1)];
+          if (TR && (lp.r & 1)) v = -v;
+        }
+        m[I][J] = v;
+      }
+  };
+  auto set_identity = [&](Mat& m) {
+#pragma unroll
+    for (int I = 0; I < NBI; ++I)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) {
+        const int row = 2 * I + (lp.r >> 1), col = 4 * J + lp.c;
+        m[I][J] = (!(lp.r & 1) && row == col && row < D) ? 1.0 : 0.0;
+      }
+  };
+
+  // ---- forward: the prefix in front of every slice of the segment ----
+  cplx* pst = A.pstore + ((long)sample * A.N + n0) * D * D;
+  {
+    Mat P;
+    load_plain(P, A.pre + cc * D * D, valid, false);
+    const cplx* du = A.dUs + ((long)sample * A.N + n0) * D * D;
+    for (int t = 0; t < A.Lmax; ++t) {
+      const bool act = valid && t < len;
+      store_plain<D>(P, reinterpret_cast<double*>(pst + (long)(act ? t : 0) * D * D), 1.0, 0.0, nullptr, lp, act);
+      if (t + 1 == A.Lmax) break;
+      Mat E, V;
+      if (__builtin_amdgcn_readfirstlane((int)__any(act)) == 0) continue;
+      load_plain(E, du + (long)(act ? t : 0) * D * D, act, false);
+      if (!act) set_identity(E);
+      write_image<D>(E, img0, woff);
+      mat_zero<D>(V);
+      mm_img<D>(img0, roff, negmask, P, V);
+#pragma unroll
+      for (int I = 0; I < NBI; ++I)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) P[I][J] = V[I][J];
+    }
+  }
+  __threadfence_block();
+
+  // ---- backward ----
+  Mat Aa;  // left adjoint, WITHOUT the trace shifts of the slices behind it: they accumulate in (ams_r, ams_i)
+  load_plain(Aa, A.Mb + cc * D * D, valid, false);
+  double ams_r = 0.0, ams_i = 0.0;
+  for (int t = A.Lmax - 1; t >= 0; --t) {
+    const bool act = valid && t < len;
+    const double sc = act ? scale : 0.0;
+    Mat X, dX;
+    {
+      Mat PH, Mn;
+      load_plain(PH, pst + (long)(act ? t : 0) * D * D, act, true);
+      write_image<D>(Aa, img0, woff);
+      mat_zero<D>(Mn);
+      mm_img<D>(img0, roff, negmask, PH, Mn);  // M_n = A P_n^H
+#pragma unroll
+      for (int I = 0; I < NBI; ++I)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) dX[I][J] = scale * Mn[I][J];
+    }
+    double mu_r = act ? tabh[MAT + 0] : 0.0, mu_i = act ? tabh[MAT + 1] : 0.0;  // trace shift of Y = X_n^H
+#pragma unroll
+    for (int I = 0; I < NBI; ++I)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) X[I][J] = sc * tabh[toff + I * 4 * W + J * 4];
+    for (int k = 0; k < K; ++k) {
+      const double c0 = sg[(lp.b * K + k) * A.Lmax + t];  // zero for inactive slices
+      const double ck = sc * c0;
+      const double* tk = tabh + (k + 1) * (MAT + 4);
+      mu_r = fma(c0, tk[MAT + 0], mu_r);
+      mu_i = fma(c0, tk[MAT + 1], mu_i);
+#pragma unroll
+      for (int I = 0; I < NBI; ++I)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) X[I][J] = fma(ck, tk[toff + I * 4 * W + J * 4], X[I][J]);
+    }
+    write_image<D>(X, img0, woff);
+    write_image<D>(dX, img1, woff);
+    Mat A2, dA2, A3, dA3, A6, dA6;
+    mat_zero<D>(A2), mat_zero<D>(dA2), mat_zero<D>(A3), mat_zero<D>(dA3), mat_zero<D>(A6), mat_zero<D>(dA6);
+    mm_img<D>(img0, roff, negmask, X, A2);
+    mm_img<D>(img0, roff, negmask, dX, dA2);
+    mm_img<D>(img1, roff, negmask, X, dA2);
+    mm_img<D>(img0, roff, negmask, A2, A3);
+    mm_img<D>(img0, roff, negmask, dA2, dA3);
+    mm_img<D>(img1, roff, negmask, A2, dA3);
+    write_image<D>(A3, img0, woff);
+    write_image<D>(dA3, img1, woff);
+    mm_img<D>(img0, roff, negmask, A3, A6);
+    mm_img<D>(img0, roff, negmask, dA3, dA6);
+    mm_img<D>(img1, roff, negmask, A3, dA6);
+    Mat A9, dA9;
+    {
+      Mat B1, dB1;
+      lincomb6<D>(B1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0, X, A2, A3, A6, ddelta, rhalf);
+      lincomb6<D>(dB1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0, dX, dA2, dA3, dA6, ddelta, rhalf);
+      write_image<D>(B1, img0, woff);
+      write_image<D>(dB1, img1, woff);
+    }
+    {
+      Mat B5, dB5;
+      lincomb6<D>(B5, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64, X, A2, A3, A6, ddelta, rhalf);
+      lincomb6<D>(dB5, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64, dX, dA2, dA3, dA6, ddelta, rhalf);
+      lincomb6<D>(A9, C3P_T18_B03, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63, X, A2, A3, A6, ddelta, rhalf);
+      lincomb6<D>(dA9, 0.0, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63, dX, dA2, dA3, dA6, ddelta, rhalf);
+      mm_img<D>(img0, roff, negmask, B5, A9);
+      mm_img<D>(img0, roff, negmask, dB5, dA9);
+      mm_img<D>(img1, roff, negmask, B5, dA9);
+    }
+    Mat T, dT;
+    {
+      Mat L, dL;
+      lincomb6<D>(L, C3P_T18_B02, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62, X, A2, A3, A6, ddelta, rhalf);
+      lincomb6<D>(dL, 0.0, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62, dX, dA2, dA3, dA6, ddelta, rhalf);
+#pragma unroll
+      for (int I = 0; I < NBI; ++I)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) {
+          L[I][J] += A9[I][J];
+          dL[I][J] += dA9[I][J];
+        }
+      write_image<D>(L, img0, woff);
+      write_image<D>(dL, img1, woff);
+    }
+    lincomb6<D>(T, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61, X, A2, A3, A6, ddelta, rhalf);
+    lincomb6<D>(dT, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61, dX, dA2, dA3, dA6, ddelta, rhalf);
+    mm_img<D>(img0, roff, negmask, A9, T);
+    mm_img<D>(img0, roff, negmask, dA9, dT);
+    mm_img<D>(img1, roff, negmask, A9, dT);
+    for (int it = 0; it < ps; ++it) {
+      write_image<D>(T, img0, woff);
+      write_image<D>(dT, img1, woff);
+      Mat T2, dT2;
+      mat_zero<D>(T2), mat_zero<D>(dT2);
+      mm_img<D>(img0, roff, negmask, T, T2);
+      mm_img<D>(img0, roff, negmask, dT, dT2);
+      mm_img<D>(img1, roff, negmask, T, dT2);
+#pragma unroll
+      for (int I = 0; I < NBI; ++I)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) {
+          T[I][J] = T2[I][J];
+          dT[I][J] = dT2[I][J];
+        }
+    }
+    // ---- grad[k] = Re <e^{ams + mu} dT, G_k> = Re( conj(e^{ams + mu}) <dT, G_k> ), complex inner product <Z, G> = sum conj(Z) G ----
+    {
+      double sn, cs;
+      sincos(ams_i + mu_i, &sn, &cs);
+      const double er = exp(ams_r + mu_r);
+      const double pr = er * cs, pi = er * sn;
+      double trr = 0.0, tri = 0.0;
+#pragma unroll
+      for (int I = 0; I < NBI; ++I)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J)
+          if (2 * I - 4 * J >= -1 && 2 * I - 4 * J <= 3) {
+            const bool on = (((lp.r >> 1) - lp.c) == 4 * J - 2 * I) && (2 * I + rhalf < D);
+            const double v = on ? dT[I][J] : 0.0;
+            if (lp.r & 1)
+              tri += v;
+            else
+              trr += v;
+          }
+      for (int k = 0; k < K; ++k) {
+        const double* tk = tab + (k + 1) * (MAT + 4);
+        // trace part: conj(tr Z) mu_k
+        double re = fma(tk[MAT + 0], trr, tk[MAT + 1] * tri);
+        double im = fma(tk[MAT + 1], trr, -tk[MAT + 0] * tri);
+#pragma unroll
+        for (int I = 0; I < NBI; ++I)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) {
+            const double z = dT[I][J];
+            re = fma(z, tk[toff + I * 4 * W + J * 4], re);
+            const double go = tk[poff + I * 4 * W + J * 4];  // r even: Im G of my element; r odd: Re G
+            im = (lp.r & 1) ? fma(-z, go, im) : fma(z, go, im);
+          }
+        double part = fma(pr, re, pi * im);
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (act && lp.idx16 == 0) A.grad[((long)sample * K + k) * A.N + n0 + t] = part;
+      }
+    }
+    // ---- A <- dU_n^H A = e^{mu} T A ----
+    {
+      Mat V;
+      write_image<D>(T, img0, woff);
+      mat_zero<D>(V);
+      mm_img<D>(img0, roff, negmask, Aa, V);
+#pragma unroll
+      for (int I = 0; I < NBI; ++I)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) Aa[I][J] = V[I][J];
+      ams_r += mu_r;
+      ams_i = c3p_phase_add(ams_i, mu_i);
     }
   }
 }
@@ -2090,6 +2386,17 @@ hipError_t launch_grad_t(const SmallGradArgs& A, hipStream_t st) {
 }
 
 template <int D>
+hipError_t launch_grad_general_t(const SmallGradArgs& A, hipStream_t st) {
+  using C = SD<D>;
+  const long nchains = (long)A.B * A.S;
+  const unsigned grid = (unsigned)((nchains + 3) / 4);
+  const size_t lds = (size_t)(2 * (1 + A.K) * (C::MAT + 4) + 8 * C::MAT + 4 * A.K * A.Lmax) * sizeof(double);
+  if (lds > 60 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(smalld_grad_general_kernel<D>, dim3(grid), dim3(64), lds, st, A);
+  return hipGetLastError();
+}
+
+template <int D>
 hipError_t launch_prep_t(const PrepArgs& P, int nsamp, hipStream_t st) {
   hipLaunchKernelGGL(smalld_prep_kernel<D>, dim3((unsigned)(nsamp * (1 + P.K))), dim3(64), 0, st, P);
   return hipGetLastError();
@@ -2153,6 +2460,11 @@ hipError_t c3p_launch_smalld_grad(const SmallGradArgs& A_, hipStream_t st) {
     A.skip_real = 1;
   }
   SD_DISPATCH(launch_grad_t, A, st)
+}
+
+hipError_t c3p_launch_smalld_grad_general(const SmallGradArgs& A, hipStream_t st) {
+  const int Dm = A.Dm;
+  SD_DISPATCH(launch_grad_general_t, A, st)
 }
 
 hipError_t c3p_launch_smalld_prep(const PrepArgs& P, int Dm, int nsamp, hipStream_t st) {
