@@ -884,6 +884,103 @@ int run_pwc_midd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   return 0;
 }
 
+// Lindblad gradient on the mid-D MFMA kernels (16 x 16, 25 x 25, 36 x 36 superoperators: D = 4, 5, 6), general-generator
+// form; see run_vjp_lind_smalld.  Returns 1 when not applicable.
+int run_vjp_lind_midd(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals, const cplx* clp,
+                      double dt, int B, int K, int N, int D, int Dm, const double* fr_phase, const cplx* Ubar, double* grad,
+                      hipStream_t st) {
+  int nig, nj, wd;
+  if (!c3p_midd_geometry(Dm, &nig, &nj, &wd) || K > 16) return 1;
+  if (!((nig == 2 && nj == 4) || (nig == 4 && nj == 7) || (nig == 5 && nj == 9))) return 1;
+  long S = ((Dm <= 32 ? 1024 : 512) + B - 1) / B;  // one workgroup per CU: two to four rounds
+  const long smax = N / 8 > 1 ? N / 8 : 1;
+  if (S > smax) S = smax;
+  if (S < 1) S = 1;
+  auto lds_need = [&](long s) { return c3p_midd_grad_image_bytes(Dm) + (size_t)K * ((N + s - 1) / s) * sizeof(double); };
+  while (lds_need(S) > (size_t)150 * 1024 && S < N) ++S;
+  if (lds_need(S) > (size_t)150 * 1024) return 1;
+  const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
+  const int nsamp = per_sample ? B : 1;
+  const size_t tdoubles = (size_t)nsamp * c3p_midd_table_doubles(Dm, K);
+  void* v;
+  if (ws_get(w, SL_TABLES, 2 * tdoubles * sizeof(double), &v)) return -1;
+  double* tabs = (double*)v;
+  MidPrepArgs p = {};
+  p.h0 = h0;
+  p.h0_bstride = h0_bs;
+  p.hks = hks;
+  p.hks_bstride = hk_bs;
+  p.clp = clp;
+  p.dt = dt;
+  p.K = K;
+  p.Dh = D;
+  p.Dm = Dm;
+  p.lindblad = 1;
+  p.rows = 16 * nig;
+  p.W = wd;
+  p.tables = tabs;
+  LAUNCH_TRY(c3p_launch_midd_prep(p, nsamp, st));
+  p.conjT = 1;
+  p.tables = tabs + tdoubles;
+  LAUNCH_TRY(c3p_launch_midd_prep(p, nsamp, st));
+  const size_t msz = (size_t)Dm * Dm * sizeof(cplx);
+  void *sv, *mv, *bv;
+  if (ws_get(w, SL_SEG_A, (size_t)B * S * msz, &sv)) return -1;
+  if (ws_get(w, SL_SEG_B, (size_t)B * S * msz, &mv)) return -1;
+  if (ws_get(w, SL_OUT1, ((size_t)B * S + 2 * (size_t)B * N) * msz, &bv)) return -1;  // (SL_OUT0 stages grad_signals)
+  cplx* pre = (cplx*)bv;
+  cplx* dUs = pre + (size_t)B * S * Dm * Dm;
+  cplx* pstore = dUs + (size_t)B * N * Dm * Dm;
+  MidArgs a = {};
+  a.tables = tabs;
+  a.tab_per_sample = per_sample ? 1 : 0;
+  a.signals = signals;
+  a.B = B;
+  a.K = K;
+  a.N = N;
+  a.Dm = Dm;
+  a.S = (int)S;
+  a.Lmax = (int)((N + S - 1) / S);
+  a.mode = C3P_MODE_LINDBLAD;
+  a.seg_out = (cplx*)sv;
+  a.dUs_out = dUs;
+  a.no_t18 = getenv("C3P_NO_T18") ? 1 : 0;
+  a.no_real = 1;
+  LAUNCH_TRY(c3p_launch_midd_chain(a, st));
+  GradArgs G = {};
+  G.Ubar = Ubar;
+  G.fr_phase = fr_phase;
+  G.B = B;
+  G.K = K;
+  G.N = N;
+  G.D = Dm;
+  G.ld = Dm | 1;
+  G.S = (int)S;
+  G.seg = (cplx*)sv;
+  G.Mb = (cplx*)mv;
+  G.pre = pre;
+  G.general = 1;
+  LAUNCH_TRY(c3p_launch_grad_scan_general(G, false, st));
+  MidGradArgs g = {};
+  g.tables = tabs;
+  g.tables_h = tabs + tdoubles;
+  g.tab_per_sample = a.tab_per_sample;
+  g.signals = signals;
+  g.Mb = G.Mb;
+  g.pre = pre;
+  g.dUs = dUs;
+  g.pstore = pstore;
+  g.grad = grad;
+  g.B = B;
+  g.K = K;
+  g.N = N;
+  g.Dm = Dm;
+  g.S = (int)S;
+  g.Lmax = a.Lmax;
+  LAUNCH_TRY(c3p_launch_midd_grad_general(g, st));
+  return 0;
+}
+
 // ---------------------------------------------------------------------------
 // Big-D MFMA path (81 x 81 Lindblad superoperators): 8-wave workgroup per chain, global arena
 // ---------------------------------------------------------------------------
@@ -1810,6 +1907,19 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
     if (rc < 0) return -1;
     if (rc == 0) {
       g_last_kernel = C3P_KERNEL_SMALLD;
+      if (record_stop(w, st)) return -1;
+      if (flags & C3P_HOST_PTRS) return sg.finish();
+      return 0;
+    }
+  }
+  if (Dm >= 13 && Dm <= 36 && !(flags & C3P_FORCE_GENERIC) && !getenv("C3P_TILED_GRAD") && !getenv("C3P_VALU_GRAD")) {
+    // 16 x 16 .. 36 x 36 superoperators (D = 4, 5, 6): the same sweep on the mid-D matrix-core kernels
+    if (record_start(w, st)) return -1;
+    const int rc = run_vjp_lind_midd(w, (const cplx*)d_h0, h0_bstride, (const cplx*)d_hks, hks_bstride, (const double*)d_sig,
+                                     (const cplx*)clp, dt, B, K, N, D, Dm, (const double*)d_ph, (const cplx*)d_ub, (double*)d_grad, st);
+    if (rc < 0) return -1;
+    if (rc == 0) {
+      g_last_kernel = C3P_KERNEL_MFMA;
       if (record_stop(w, st)) return -1;
       if (flags & C3P_HOST_PTRS) return sg.finish();
       return 0;

@@ -705,8 +705,19 @@ hipError_t launch_general(KT kern, unsigned grid, const GradArgs& A, bool global
 }  // namespace
 
 hipError_t c3p_launch_grad_scan_general(const GradArgs& A, bool global_scratch, hipStream_t st) {
-  return global_scratch ? launch_general(grad_scan_general_kernel<true>, (unsigned)A.B, A, true, st)
-                        : launch_general(grad_scan_general_kernel<false>, (unsigned)A.B, A, false, st);
+  // the scan keeps three matrices: they fit the LDS at every dimension the on-chip sweeps reach
+  const size_t lds3 = (size_t)3 * A.ld * A.D * sizeof(cplx);
+  if (lds3 <= (size_t)150 * 1024) {
+    auto kern = grad_scan_general_kernel<false>;
+    if (lds3 > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)A.B), dim3(c3p_grad_threads(A.D)), lds3, st, A);
+    return hipGetLastError();
+  }
+  (void)global_scratch;
+  return launch_general(grad_scan_general_kernel<true>, (unsigned)A.B, A, true, st);
 }
 hipError_t c3p_launch_grad_bwd_general(const GradArgs& A, bool global_scratch, hipStream_t st) {
   return global_scratch ? launch_general(grad_bwd_general_kernel<true>, (unsigned)(A.B * A.S), A, true, st)

@@ -33,6 +33,11 @@ struct MidGradArgs {
   int B, K, N, Dm, S, Lmax;
   // the real-Hamiltonian sweep (midd_grad_real_kernel) has taken the chains it can: this launch skips them
   int skip_real;
+  // general (non-unitary) generators, e.g. Lindblad superoperators (midd_grad_general_kernel; method in c3p_grad.hip):
+  const double* tables_h;  // tables of the conjugate-transposed generators G_k^H (MidPrepArgs.conjT)
+  const cplx* pre;         // [B,S,Dm,Dm] prefix product at the START of each segment; Mb = LEFT adjoint at its end
+  const cplx* dUs;         // [B,N,Dm,Dm] slice propagators of the forward pass
+  cplx* pstore;            // [B,N,Dm,Dm] scratch: prefix product in front of every slice
 };
 
 struct MidPrepArgs {
@@ -43,6 +48,7 @@ struct MidPrepArgs {
   const cplx* clp;
   double dt;
   int K, Dh, Dm, lindblad;
+  int conjT;  // tables of G^H instead of G (backward sweep of general generators)
   int rows, W;
   int tile_nig, tile_nj;  // != 0: emit tile-major images (big-D kernel) instead of rows x W
   double* tables;
@@ -56,4 +62,6 @@ size_t c3p_midd_grad_image_bytes(int Dm);
 hipError_t c3p_launch_midd_chain(const MidArgs& A, hipStream_t st);
 hipError_t c3p_launch_midd_real(const MidArgs& A, hipStream_t st);  // real-Hamiltonian instance only (c3p_launch_midd_chain calls it)
 hipError_t c3p_launch_midd_grad(const MidGradArgs& A, hipStream_t st);
+// general generators (Lindblad superoperators 16 x 16, 25 x 25, 36 x 36); hipErrorInvalidValue for other dimensions
+hipError_t c3p_launch_midd_grad_general(const MidGradArgs& A, hipStream_t st);
 hipError_t c3p_launch_midd_prep(const MidPrepArgs& P, int nsamp, hipStream_t st);

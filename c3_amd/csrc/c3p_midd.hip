@@ -1136,7 +1136,8 @@ __global__ void __launch_bounds__(256) midd_prep_kernel(MidPrepArgs P) {
   const int D = P.Dm, Dh = P.Dh;
   const cplx* h = (ti == 0) ? P.h0 + (long)sample * P.h0_bstride
                             : P.hks + (long)sample * P.hks_bstride + (long)(ti - 1) * Dh * Dh;
-  auto gelem = [&](int row, int col) -> cplx {
+  auto gelem = [&](int row_, int col_) -> cplx {
+    const int row = P.conjT ? col_ : row_, col = P.conjT ? row_ : col_;  // G^H: element (r, c) = conj(G[c][r])
     cplx v;
     if (!P.lindblad) {
       const cplx x = h[row * D + col];
@@ -1156,6 +1157,7 @@ __global__ void __launch_bounds__(256) midd_prep_kernel(MidPrepArgs P) {
       }
       v = cscale(v, P.dt);
     }
+    if (P.conjT) v.y = -v.y;
     return v;
   };
   double tr = 0, tim = 0;
@@ -1590,6 +1592,346 @@ __global__ void __launch_bounds__(256, 1) midd_grad_kernel(MidGradArgs A) {
     case 1: midd_grad_body<NIG, NJ, W, 1>(A, cm, chain, i0, i1, i2, i3, red); break;
     case 2: midd_grad_body<NIG, NJ, W, 2>(A, cm, chain, i0, i1, i2, i3, red); break;
     default: midd_grad_body<NIG, NJ, W, 3>(A, cm, chain, i0, i1, i2, i3, red); break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward sweep for GENERAL generators in the mid-D layout (Lindblad superoperators of two qubits, 16 x 16, and of
+// D = 5 / 6): method of c3p_grad.hip's general form, layout of midd_grad_body.  Forward over the segment with the slice
+// propagators of the forward pass (P <- dU_n P, every P_n stored), then backwards: M_n = A P_n^H, pair evaluation of T18 at
+// Y = X_n^H (tables of G^H), grad[k] = Re(conj(e^{shift}) <dT, G_k>), A <- T A; the trace shifts ride along as one scalar.
+// ---------------------------------------------------------------------------------------------
+template <int NIG, int NJ, int W, int WV>
+__device__ __forceinline__ void midd_grad_general_body(const MidGradArgs& A, const MidCommon& cm, long chain, double* i0,
+                                                       double* i1, double* i2, double* i3, double* red) {
+  using T = WaveTiles<NIG, NJ, W, WV>;
+  constexpr int IMG = MD<NIG, NJ>::ROWS * W, NE = T::NE;
+  typedef TileRegs<T::NBW, T::NSW> Regs;
+  const int D = cm.D, K = cm.K;
+  const int lbig = cm.lbig, lsmall = cm.lsmall;
+  const int rbig = cm.r, rsmall = 4 * cm.b + cm.r;
+  const int cbig = 4 * cm.b + cm.c, csmall = cm.c;
+  const double* tabs = cm.tabs;                                                                    // G^H: the exponent
+  const double* tabg = A.tables + (long)(A.tab_per_sample ? cm.sample : 0) * (1 + K) * (IMG + 4);  // G: inner products
+  auto eoff = [&](int e) -> int { return T::off0(e) + (T::is_big(e) ? lbig : lsmall); };
+  auto erow = [&](int e) -> int { return T::row0(e) + (T::is_big(e) ? rbig : rsmall); };
+  auto ecol = [&](int e) -> int { return T::col0(e) + (T::is_big(e) ? cbig : csmall); };
+  auto store_tiles = [&](double* img, const Regs& v) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) img[eoff(e)] = v.get(e);
+  };
+  auto store_tiles_H = [&](double* img, const Regs& v) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int row = erow(e), col = ecol(e);
+      const int ci = row >> 1, p = row & 1;
+      if (ci < D && col < D) img[(2 * col + p) * W + ci] = p ? -v.get(e) : v.get(e);
+    }
+  };
+  auto zero = [&](Regs& v) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v.set(e, 0.0);
+  };
+  auto load_plain = [&](Regs& v, const cplx* srcc) {
+    const double* src = reinterpret_cast<const double*>(srcc);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int row = erow(e), col = ecol(e);
+      const int ci = row >> 1;
+      v.set(e, (ci < D && col < D) ? src[(ci * D + col) * 2 + (row & 1)] : 0.0);
+    }
+  };
+  auto store_plain = [&](cplx* dstc, const Regs& v) {
+    double* dst = reinterpret_cast<double*>(dstc);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int row = erow(e), col = ecol(e);
+      const int ci = row >> 1;
+      if (ci < D && col < D) dst[(ci * D + col) * 2 + (row & 1)] = v.get(e);
+    }
+  };
+  auto product = [&](const double* imgA, const double* imgB, Regs& acc) { mm_tiles_pf<NIG, NJ, W, WV, 3>(imgA, imgB, cm, acc); };
+  auto is_diag = [&](int e) -> bool {
+    const int row = erow(e), col = ecol(e);
+    return ((row & 1) == 0) && ((row >> 1) == col) && (col < D);
+  };
+  auto comb = [&](Regs& out, double c0, double cx, double c2, double c3, double c6, const Regs& X, const Regs& A2,
+                  const Regs& A3, const Regs& A6) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      double v = cx * X.get(e);
+      v = fma(c2, A2.get(e), v);
+      v = fma(c3, A3.get(e), v);
+      v = fma(c6, A6.get(e), v);
+      v += (c0 != 0.0 && is_diag(e)) ? c0 : 0.0;
+      out.set(e, v);
+    }
+  };
+
+  // ---- forward: the prefix in front of every slice (full values: the slice propagators carry their trace shifts) ----
+  cplx* pst = A.pstore + ((long)cm.sample * A.N + cm.n0) * D * D;
+  {
+    Regs P;
+    load_plain(P, A.pre + chain * D * D);
+    const cplx* du = A.dUs + ((long)cm.sample * A.N + cm.n0) * D * D;
+    for (int t = 0; t < cm.len; ++t) {
+      store_plain(pst + (long)t * D * D, P);
+      if (t + 1 == cm.len) break;
+      Regs E, V;
+      load_plain(E, du + (long)t * D * D);
+      __syncthreads();
+      store_tiles(i0, E);
+      store_tiles(i1, P);
+      __syncthreads();
+      zero(V);
+      product(i0, i1, V);
+      P = V;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  // ---- backward ----
+  Regs Aa;  // left adjoint without the trace shifts of the slices behind it: they accumulate in (ams_r, ams_i)
+  load_plain(Aa, A.Mb + chain * D * D);
+  double ams_r = 0.0, ams_i = 0.0;
+  for (int t = cm.len - 1; t >= 0; --t) {
+    Regs X, dX;
+    {
+      Regs Pn, Mn;
+      load_plain(Pn, pst + (long)t * D * D);
+      __syncthreads();  // the previous slice's last product has left the images
+      store_tiles(i0, Aa);
+      store_tiles_H(i1, Pn);
+      __syncthreads();
+      zero(Mn);
+      product(i0, i1, Mn);  // M_n = A P_n^H
+#pragma unroll
+      for (int e = 0; e < NE; ++e) dX.set(e, cm.scale * Mn.get(e));
+    }
+    double mu_r = tabs[IMG + 0], mu_i = tabs[IMG + 1];  // trace shift of Y = X_n^H
+#pragma unroll
+    for (int e = 0; e < NE; ++e) X.set(e, cm.scale * tabs[eoff(e)]);
+    for (int k = 0; k < K; ++k) {
+      const double c0 = cm.sg[k * A.Lmax + t];
+      const double ck = cm.scale * c0;
+      const double* tk = tabs + (long)(k + 1) * (IMG + 4);
+      mu_r = fma(c0, tk[IMG + 0], mu_r);
+      mu_i = fma(c0, tk[IMG + 1], mu_i);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) X.set(e, fma(ck, tk[eoff(e)], X.get(e)));
+    }
+    __syncthreads();
+    store_tiles(i0, X);
+    store_tiles(i1, dX);
+    __syncthreads();
+    Regs A2, dA2, A3, dA3, A6, dA6;
+    zero(A2), zero(dA2), zero(A3), zero(dA3), zero(A6), zero(dA6);
+    product(i0, i0, A2);
+    product(i0, i1, dA2);
+    product(i1, i0, dA2);
+    store_tiles(i2, A2);
+    store_tiles(i3, dA2);
+    __syncthreads();
+    product(i0, i2, A3);
+    product(i0, i3, dA3);
+    product(i1, i2, dA3);
+    __syncthreads();
+    store_tiles(i0, A3);
+    store_tiles(i1, dA3);
+    __syncthreads();
+    product(i0, i0, A6);
+    product(i0, i1, dA6);
+    product(i1, i0, dA6);
+    Regs A9, dA9;
+    {
+      Regs B1, dB1, B5, dB5;
+      comb(B1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0, X, A2, A3, A6);
+      comb(dB1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0, dX, dA2, dA3, dA6);
+      comb(B5, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64, X, A2, A3, A6);
+      comb(dB5, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64, dX, dA2, dA3, dA6);
+      __syncthreads();
+      store_tiles(i0, B1);
+      store_tiles(i1, dB1);
+      store_tiles(i2, B5);
+      store_tiles(i3, dB5);
+    }
+    comb(A9, C3P_T18_B03, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63, X, A2, A3, A6);
+    comb(dA9, 0.0, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63, dX, dA2, dA3, dA6);
+    __syncthreads();
+    product(i0, i2, A9);
+    product(i0, i3, dA9);
+    product(i1, i2, dA9);
+    Regs Tm, dT;
+    {
+      Regs L, dL;
+      comb(L, C3P_T18_B02, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62, X, A2, A3, A6);
+      comb(dL, 0.0, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62, dX, dA2, dA3, dA6);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        L.set(e, L.get(e) + A9.get(e));
+        dL.set(e, dL.get(e) + dA9.get(e));
+      }
+      __syncthreads();
+      store_tiles(i0, L);
+      store_tiles(i1, dL);
+      store_tiles(i2, A9);
+      store_tiles(i3, dA9);
+    }
+    comb(Tm, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61, X, A2, A3, A6);
+    comb(dT, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61, dX, dA2, dA3, dA6);
+    __syncthreads();
+    product(i0, i2, Tm);
+    product(i0, i3, dT);
+    product(i1, i2, dT);
+    for (int it = 0; it < cm.ps; ++it) {
+      __syncthreads();
+      store_tiles(i0, Tm);
+      store_tiles(i1, dT);
+      __syncthreads();
+      Regs T2, dT2;
+      zero(T2), zero(dT2);
+      product(i0, i0, T2);
+      product(i0, i1, dT2);
+      product(i1, i0, dT2);
+      Tm = T2;
+      dT = dT2;
+    }
+    // ---- A <- T A (issued first: its operands go to the images while the inner products run on registers) ----
+    __syncthreads();
+    store_tiles(i0, Tm);
+    store_tiles(i1, Aa);
+    __syncthreads();
+    // ---- grad[k] = Re( conj(e^{ams + mu}) <dT, G_k> ), <Z, G> = sum conj(Z) G ----
+    {
+      double sn, cs;
+      sincos(ams_i + mu_i, &sn, &cs);
+      const double er = exp(ams_r + mu_r);
+      const double pr = er * cs, pi = er * sn;
+      double trr = 0.0, tri = 0.0;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int row = erow(e), col = ecol(e);
+        const bool dg = ((row >> 1) == col) && (col < D);
+        const double v = dg ? dT.get(e) : 0.0;
+        if (row & 1)
+          tri += v;
+        else
+          trr += v;
+      }
+      for (int o = 32; o >= 1; o >>= 1) {
+        trr += __shfl_xor(trr, o);
+        tri += __shfl_xor(tri, o);
+      }
+      for (int k = 0; k < K; ++k) {
+        const double* tk = tabg + (long)(k + 1) * (IMG + 4);
+        double re = 0.0, im = 0.0;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const double z = dT.get(e);
+          const int o = eoff(e);
+          const bool odd = erow(e) & 1;
+          re = fma(z, tk[o], re);
+          const double go = tk[odd ? o - W : o + W];  // the other half of the same complex element
+          im = odd ? fma(-z, go, im) : fma(z, go, im);
+        }
+        for (int o = 32; o >= 1; o >>= 1) {
+          re += __shfl_xor(re, o);
+          im += __shfl_xor(im, o);
+        }
+        // trace part conj(tr Z) mu_k: every wave adds the share of its own diagonal elements
+        re += fma(tk[IMG + 0], trr, tk[IMG + 1] * tri);
+        im += fma(tk[IMG + 1], trr, -tk[IMG + 0] * tri);
+        if (cm.lane == 0) red[WV * 16 + k] = fma(pr, re, pi * im);
+      }
+    }
+    Regs V;
+    zero(V);
+    product(i0, i1, V);
+    Aa = V;
+    ams_r += mu_r;
+    ams_i = c3p_phase_add(ams_i, mu_i);
+    __syncthreads();  // partial sums visible
+    if (WV == 0 && cm.lane < K)
+      A.grad[((long)cm.sample * K + cm.lane) * A.N + cm.n0 + t] =
+          red[cm.lane] + red[16 + cm.lane] + red[32 + cm.lane] + red[48 + cm.lane];
+  }
+}
+
+template <int NIG, int NJ, int W>
+__global__ void __launch_bounds__(256, 1) midd_grad_general_kernel(MidGradArgs A) {
+  using C = MD<NIG, NJ>;
+  constexpr int IMG = C::ROWS * W;
+  const int tid = threadIdx.x;
+  MidCommon cm;
+  cm.lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  cm.r = cm.lane >> 4;
+  cm.b = (cm.lane >> 2) & 3;
+  cm.c = cm.lane & 3;
+  cm.D = A.Dm;
+  cm.nbk = (2 * cm.D + 3) / 4;
+  cm.K = A.K;
+  const int K = A.K;
+  double* i0 = c3p_md_lds;
+  double* i1 = i0 + IMG;
+  double* i2 = i1 + IMG;
+  double* i3 = i2 + IMG;
+  cm.sg = i3 + IMG;
+  __shared__ double red[64];
+  __shared__ double redn[NW];
+  const long chain = blockIdx.x;
+  cm.sample = (int)(chain / A.S);
+  const int seg = (int)(chain - (long)cm.sample * A.S);
+  cm.n0 = (int)(((long)seg * A.N) / A.S);
+  const int n1 = (int)(((long)(seg + 1) * A.N) / A.S);
+  cm.len = n1 - cm.n0;
+  cm.aoff = (4 * cm.b + (cm.c & ~1) + ((cm.c ^ cm.r) & 1)) * W + (cm.r >> 1);
+  cm.boff = cm.r * W + cm.c;
+  cm.lsmall = (4 * cm.b + cm.r) * W + cm.c;
+  cm.lbig = cm.r * W + 4 * cm.b + cm.c;
+  cm.negmask = (((cm.c & 1) == 0) && ((cm.r & 1) == 1)) ? 0x80000000u : 0u;
+  for (int e = tid; e < 4 * IMG; e += 256) c3p_md_lds[e] = 0.0;
+  __syncthreads();
+  cm.tabs = A.tables_h + (long)(A.tab_per_sample ? cm.sample : 0) * (1 + K) * (IMG + 4);  // the matrix exponentiated is X^H
+  double nrm = cm.tabs[IMG + 2];
+  for (int k = 0; k < K; ++k) {
+    const double* s = A.signals + ((long)cm.sample * K + k) * A.N + cm.n0;
+    double cmax = 0.0;
+    for (int t = tid; t < cm.len; t += 256) {
+      const double v = s[t];
+      cm.sg[k * A.Lmax + t] = v;
+      cmax = fmax(cmax, fabs(v));
+    }
+    for (int o = 32; o >= 1; o >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, o));
+    if (cm.lane == 0) redn[wave] = cmax;
+    __syncthreads();
+    cmax = fmax(fmax(redn[0], redn[1]), fmax(redn[2], redn[3]));
+    __syncthreads();
+    nrm = fma(cmax, cm.tabs[(long)(k + 1) * (IMG + 4) + IMG + 2], nrm);
+  }
+  nrm = md_rfl(nrm);
+  int ps = 0;
+  {
+    double p = C3P_T18_THETA;
+    while (p < nrm && ps < 40) {
+      p *= 2.0;
+      ++ps;
+    }
+  }
+  cm.ps = __builtin_amdgcn_readfirstlane(ps);
+  cm.pr = 0;
+  cm.t18 = 1;
+  cm.scale = ldexp(1.0, -cm.ps);
+  cm.buf0 = i0;
+  cm.buf1 = i1;
+  cm.buf2 = i2;
+  __syncthreads();
+  switch (wave) {
+    case 0: midd_grad_general_body<NIG, NJ, W, 0>(A, cm, chain, i0, i1, i2, i3, red); break;
+    case 1: midd_grad_general_body<NIG, NJ, W, 1>(A, cm, chain, i0, i1, i2, i3, red); break;
+    case 2: midd_grad_general_body<NIG, NJ, W, 2>(A, cm, chain, i0, i1, i2, i3, red); break;
+    default: midd_grad_general_body<NIG, NJ, W, 3>(A, cm, chain, i0, i1, i2, i3, red); break;
   }
 }
 
@@ -2172,6 +2514,20 @@ hipError_t launch_grad_t(const MidGradArgs& A, hipStream_t st) {
   return hipGetLastError();
 }
 
+template <int NIG, int NJ, int W>
+hipError_t launch_grad_general_t(const MidGradArgs& A, hipStream_t st) {
+  constexpr int IMG = MD<NIG, NJ>::ROWS * W;
+  const size_t lds = (size_t)(4 * IMG + A.K * A.Lmax) * sizeof(double);
+  if (lds > 158 * 1024) return hipErrorInvalidValue;
+  auto kern = midd_grad_general_kernel<NIG, NJ, W>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((long)A.B * A.S)), dim3(256), lds, st, A);
+  return hipGetLastError();
+}
+
 // *launched = false (and hipSuccess) when the real sweep does not apply: more control lines than the kernel keeps in
 // registers, or the eight real images and the segment's control amplitudes do not fit the LDS
 template <int NIG, int NJ, int W>
@@ -2281,6 +2637,16 @@ hipError_t launch_grad_real(const MidGradArgs& A, int nig, int nj, hipStream_t s
   return hipErrorInvalidValue;
 }
 }  // namespace
+
+// (the classes of the Lindblad superoperators of D = 4, 5, 6 only: 16 x 16, 25 x 25, 36 x 36)
+hipError_t c3p_launch_midd_grad_general(const MidGradArgs& A, hipStream_t st) {
+  int nig, nj, w;
+  if (!c3p_midd_geometry(A.Dm, &nig, &nj, &w)) return hipErrorInvalidValue;
+  if (nig == 2 && nj == 4) return launch_grad_general_t<2, 4, 17>(A, st);
+  if (nig == 4 && nj == 7) return launch_grad_general_t<4, 7, 29>(A, st);
+  if (nig == 5 && nj == 9) return launch_grad_general_t<5, 9, 37>(A, st);
+  return hipErrorInvalidValue;
+}
 
 hipError_t c3p_launch_midd_grad(const MidGradArgs& A_, hipStream_t st) {
   int nig, nj, w;

@@ -292,8 +292,8 @@ def test_lindblad_vjp_vs_oracle(prop, dims, N, B, C):
 @pytest.mark.parametrize("D,N,B,C,per_sample", [(2, 100, 3, 1, False), (3, 64, 2, 2, True), (4, 40, 2, 1, False), (5, 17, 2, 2, False), (6, 9, 2, 1, True)])
 def test_lindblad_vjp_small_superoperators_general_sweep(prop, D, N, B, C, per_sample):
     """D^2 <= 36: the sweep for general (non-unitary) generators -- several time segments per sample (prefix and left adjoint
-    of every segment from the scan); matrix-core small-D kernel (D <= 3), VALU kernels in LDS (D = 4) and in global scratch
-    (D = 5, 6), per-sample operators,
+    of every segment from the scan); matrix-core small-D kernel (D <= 3), mid-D kernel (D = 4, 5, 6), and the VALU kernels in
+    LDS / global scratch as a second opinion, per-sample operators,
     moderate dissipation -- against the FD-pinned oracle and against the tiled sweep (C3P_TILED_GRAD=1) on the same inputs."""
     from c3_amd import _lib
 
@@ -312,7 +312,7 @@ def test_lindblad_vjp_small_superoperators_general_sweep(prop, D, N, B, C, per_s
     ph = rng.uniform(0, 2 * np.pi, size=(B, Dm))
     dt = 0.3
     g = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar, fr_phase=ph))
-    assert _lib.last_kernel() == ("smalld" if D <= 3 else "generic_lds" if D <= 4 else "generic_global")
+    assert _lib.last_kernel() == ("smalld" if D <= 3 else "mfma")
     os.environ["C3P_TILED_GRAD"] = "1"
     try:
         gt = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar, fr_phase=ph))
@@ -320,14 +320,13 @@ def test_lindblad_vjp_small_superoperators_general_sweep(prop, D, N, B, C, per_s
     finally:
         os.environ.pop("C3P_TILED_GRAD")
     assert np.abs(g - gt).max() < 1e-10 * np.abs(gt).max()
-    if D <= 3:  # the VALU form of the same sweep (what D = 4 .. 6 run)
-        os.environ["C3P_VALU_GRAD"] = "1"
-        try:
-            gv = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar, fr_phase=ph))
-            assert _lib.last_kernel() == "generic_lds"
-        finally:
-            os.environ.pop("C3P_VALU_GRAD")
-        assert np.abs(gv - gt).max() < 1e-10 * np.abs(gt).max()
+    os.environ["C3P_VALU_GRAD"] = "1"  # the VALU form of the same sweep
+    try:
+        gv = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar, fr_phase=ph))
+        assert _lib.last_kernel() == ("generic_lds" if D <= 4 else "generic_global")
+    finally:
+        os.environ.pop("C3P_VALU_GRAD")
+    assert np.abs(gv - gt).max() < 1e-10 * np.abs(gt).max()
     for b in range(B):
         want = o.pwc_lindblad_signal_gradient(h0[b] if per_sample else h0, hks[b] if per_sample else hks, col, sig[b], dt, Ubar[b], ph[b])
         assert np.abs(g[b] - want).max() < 1e-10 * np.abs(want).max()
