@@ -200,8 +200,8 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
  * (c3p_tiled.hip).  c3p_pwc_unitary_vjp uses the same sweep above D = 40 (any dimension; gen_bar_out only up to D = 40).
  * D <= 6 (superoperators up to 36 x 36): three kernels per call instead of ~35 launches per slice -- segment products, a scan
  * that leaves prefix and left adjoint at the segment boundaries, and a sweep that stores the prefix of every slice of its
- * segment and evaluates the pair at X_n^H on the way back (general-generator form: c3p_smalld.hip on the matrix cores for
- * D <= 3, c3p_grad.hip above; C3P_TILED_GRAD=1 selects the tiled sweep). */
+ * segment and evaluates the pair at X_n^H on the way back (general-generator form on the matrix cores: c3p_smalld.hip for
+ * D <= 3, c3p_midd.hip for D = 4 .. 6; c3p_grad.hip is the VALU fallback; C3P_TILED_GRAD=1 selects the tiled sweep). */
 int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride,
                          const double* signals, const void* col_ops, int C, double dt, int B, int K, int N, int D,
                          int flags, const double* fr_phase, const void* U_bar, double* grad_signals, void* stream);
