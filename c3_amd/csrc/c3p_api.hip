@@ -1898,12 +1898,34 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
   void* clp;
   if (ws_get(w, SL_CLP, (size_t)Dm * Dm * cs, &clp)) return -1;
   LAUNCH_TRY(c3p_launch_clp((const cplx*)d_col, C, D, (cplx*)clp, st));
+  // The general-generator sweeps keep the slice propagators and the prefix of every slice: 2 N D^4 complex per sample.  Large
+  // batches are processed in chunks of samples that keep that below 24 GB (C3P_GRAD_CHUNK overrides the chunk size).
+  auto in_chunks = [&](auto&& run) -> int {  // run(b0, nb) -> 0 done, 1 not applicable, -1 error
+    long Bc = (long)(((size_t)24 << 30) / (2 * (size_t)N * Dm * Dm * cs));
+    if (const char* e = getenv("C3P_GRAD_CHUNK")) Bc = atol(e);
+    if (Bc < 1) Bc = 1;
+    for (long b0 = 0; b0 < B; b0 += Bc) {
+      const int rc = run(b0, (int)(B - b0 < Bc ? B - b0 : Bc));
+      if (rc != 0) return rc;
+    }
+    return 0;
+  };
+  const cplx* p_h0 = (const cplx*)d_h0;
+  const cplx* p_hk = (const cplx*)d_hks;
+  const double* p_sig = (const double*)d_sig;
+  const double* p_ph = (const double*)d_ph;
+  const cplx* p_ub = (const cplx*)d_ub;
+  double* p_grad = (double*)d_grad;
+  const long gsz = (long)Dm * Dm;
+  auto phase_at = [&](long b0) { return p_ph ? p_ph + b0 * Dm : nullptr; };
   if (Dm <= kSmallDLimit && c3p_smalld_supported(Dm) && K <= 8 && !(flags & C3P_FORCE_GENERIC) && !getenv("C3P_TILED_GRAD") &&
       !getenv("C3P_VALU_GRAD")) {
-    // superoperators up to 12 x 12 (D <= 3): the same general-generator sweep on the small-D matrix-core kernels
+    // superoperators up to 12 x 12 (D <= 3): the general-generator sweep on the small-D matrix-core kernels
     if (record_start(w, st)) return -1;
-    const int rc = run_vjp_lind_smalld(w, (const cplx*)d_h0, h0_bstride, (const cplx*)d_hks, hks_bstride, (const double*)d_sig,
-                                       (const cplx*)clp, dt, B, K, N, D, Dm, (const double*)d_ph, (const cplx*)d_ub, (double*)d_grad, st);
+    const int rc = in_chunks([&](long b0, int nb) {
+      return run_vjp_lind_smalld(w, p_h0 + b0 * h0_bstride, h0_bstride, p_hk + b0 * hks_bstride, hks_bstride, p_sig + b0 * K * N,
+                                 (const cplx*)clp, dt, nb, K, N, D, Dm, phase_at(b0), p_ub + b0 * gsz, p_grad + b0 * K * N, st);
+    });
     if (rc < 0) return -1;
     if (rc == 0) {
       g_last_kernel = C3P_KERNEL_SMALLD;
@@ -1915,8 +1937,10 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
   if (Dm >= 13 && Dm <= 36 && !(flags & C3P_FORCE_GENERIC) && !getenv("C3P_TILED_GRAD") && !getenv("C3P_VALU_GRAD")) {
     // 16 x 16 .. 36 x 36 superoperators (D = 4, 5, 6): the same sweep on the mid-D matrix-core kernels
     if (record_start(w, st)) return -1;
-    const int rc = run_vjp_lind_midd(w, (const cplx*)d_h0, h0_bstride, (const cplx*)d_hks, hks_bstride, (const double*)d_sig,
-                                     (const cplx*)clp, dt, B, K, N, D, Dm, (const double*)d_ph, (const cplx*)d_ub, (double*)d_grad, st);
+    const int rc = in_chunks([&](long b0, int nb) {
+      return run_vjp_lind_midd(w, p_h0 + b0 * h0_bstride, h0_bstride, p_hk + b0 * hks_bstride, hks_bstride, p_sig + b0 * K * N,
+                               (const cplx*)clp, dt, nb, K, N, D, Dm, phase_at(b0), p_ub + b0 * gsz, p_grad + b0 * K * N, st);
+    });
     if (rc < 0) return -1;
     if (rc == 0) {
       g_last_kernel = C3P_KERNEL_MFMA;
@@ -1926,53 +1950,56 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
     }
   }
   if (Dm <= 36 && !getenv("C3P_TILED_GRAD")) {
-    // small superoperators (D <= 6): the whole sweep in three kernels on dense generator tables (c3p_grad.hip, general form) --
-    // the tiled path below spends ~0.4 ms of launches per slice whatever the batch
-    const int nb = (h0_bstride || hks_bstride) ? B : 1;
-    const long gsz = (long)Dm * Dm;
-    void* tab;
-    if (ws_get(w, SL_TABLES, (size_t)nb * (K + 1) * gsz * cs, &tab)) return -1;
-    LAUNCH_TRY(c3p_launch_lind_generators((const cplx*)d_h0, h0_bstride, (const cplx*)d_hks, hks_bstride, (const cplx*)clp, nb, K, D,
-                                          (cplx*)tab, st));
-    GradArgs A = {};
-    A.h0 = (const cplx*)tab;
-    A.h0_bstride = nb > 1 ? (long)(K + 1) * gsz : 0;
-    A.hks = (const cplx*)tab + gsz;
-    A.hks_bstride = A.h0_bstride;
-    A.signals = (const double*)d_sig;
-    A.fr_phase = (const double*)d_ph;
-    A.Ubar = (const cplx*)d_ub;
-    A.dt = dt;
-    A.B = B;
-    A.K = K;
-    A.N = N;
-    A.D = Dm;
-    A.ld = Dm | 1;
-    A.grad = (double*)d_grad;
-    A.general = 1;
-    long S = 4096 / B;
-    if (S > N / 8) S = N / 8;
-    if (S < 1) S = 1;
-    A.S = (int)S;
-    void* v;
-    if (ws_get(w, SL_SEG_A, (size_t)B * A.S * gsz * cs, &v)) return -1;
-    A.seg = (cplx*)v;
-    if (ws_get(w, SL_SEG_B, (size_t)B * A.S * gsz * cs, &v)) return -1;
-    A.Mb = (cplx*)v;
-    if (ws_get(w, SL_OUT1, ((size_t)B * A.S + (size_t)B * N) * gsz * cs, &v)) return -1;  // (SL_OUT0 stages grad_signals)
-    A.pre = (cplx*)v;
-    A.pstore = A.pre + (size_t)B * A.S * gsz;
-    const bool global = c3p_grad_lds_bytes_general(Dm) > 150 * 1024;
-    if (global) {
-      A.scratch_stride = (long)C3P_GRAD_NMAT_GENERAL * A.ld * Dm;
-      if (ws_get(w, SL_SCRATCH, (size_t)B * A.S * A.scratch_stride * cs, &v)) return -1;
-      A.scratch = (cplx*)v;
-    }
-    g_last_kernel = global ? C3P_KERNEL_GENERIC_GLOBAL : C3P_KERNEL_GENERIC_LDS;
+    // the same sweep in three VALU kernels on dense generator tables (c3p_grad.hip, general form): fallback and second opinion
+    bool global = false;
+    auto run_valu = [&](long b0, int nb) -> int {
+      const int nt = (h0_bstride || hks_bstride) ? nb : 1;
+      void* tab;
+      if (ws_get(w, SL_TABLES, (size_t)nt * (K + 1) * gsz * cs, &tab)) return -1;
+      LAUNCH_TRY(c3p_launch_lind_generators(p_h0 + b0 * h0_bstride, h0_bstride, p_hk + b0 * hks_bstride, hks_bstride, (const cplx*)clp, nt,
+                                            K, D, (cplx*)tab, st));
+      GradArgs A = {};
+      A.h0 = (const cplx*)tab;
+      A.h0_bstride = nt > 1 ? (long)(K + 1) * gsz : 0;
+      A.hks = (const cplx*)tab + gsz;
+      A.hks_bstride = A.h0_bstride;
+      A.signals = p_sig + b0 * K * N;
+      A.fr_phase = phase_at(b0);
+      A.Ubar = p_ub + b0 * gsz;
+      A.dt = dt;
+      A.B = nb;
+      A.K = K;
+      A.N = N;
+      A.D = Dm;
+      A.ld = Dm | 1;
+      A.grad = p_grad + b0 * K * N;
+      A.general = 1;
+      long S = 4096 / nb;
+      if (S > N / 8) S = N / 8;
+      if (S < 1) S = 1;
+      A.S = (int)S;
+      void* v;
+      if (ws_get(w, SL_SEG_A, (size_t)nb * A.S * gsz * cs, &v)) return -1;
+      A.seg = (cplx*)v;
+      if (ws_get(w, SL_SEG_B, (size_t)nb * A.S * gsz * cs, &v)) return -1;
+      A.Mb = (cplx*)v;
+      if (ws_get(w, SL_OUT1, ((size_t)nb * A.S + (size_t)nb * N) * gsz * cs, &v)) return -1;  // (SL_OUT0 stages grad_signals)
+      A.pre = (cplx*)v;
+      A.pstore = A.pre + (size_t)nb * A.S * gsz;
+      global = c3p_grad_lds_bytes_general(Dm) > 150 * 1024;
+      if (global) {
+        A.scratch_stride = (long)C3P_GRAD_NMAT_GENERAL * A.ld * Dm;
+        if (ws_get(w, SL_SCRATCH, (size_t)nb * A.S * A.scratch_stride * cs, &v)) return -1;
+        A.scratch = (cplx*)v;
+      }
+      LAUNCH_TRY(c3p_launch_grad_seg(A, global, st));
+      LAUNCH_TRY(c3p_launch_grad_scan_general(A, global, st));
+      LAUNCH_TRY(c3p_launch_grad_bwd_general(A, global, st));
+      return 0;
+    };
     if (record_start(w, st)) return -1;
-    LAUNCH_TRY(c3p_launch_grad_seg(A, global, st));
-    LAUNCH_TRY(c3p_launch_grad_scan_general(A, global, st));
-    LAUNCH_TRY(c3p_launch_grad_bwd_general(A, global, st));
+    if (in_chunks(run_valu) != 0) return -1;
+    g_last_kernel = global ? C3P_KERNEL_GENERIC_GLOBAL : C3P_KERNEL_GENERIC_LDS;
     if (record_stop(w, st)) return -1;
     if (flags & C3P_HOST_PTRS) return sg.finish();
     return 0;

@@ -333,6 +333,35 @@ def test_lindblad_vjp_small_superoperators_general_sweep(prop, D, N, B, C, per_s
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("D", [2, 4])
+def test_lindblad_vjp_sample_chunks(prop, D):
+    """Large batches run the general-generator sweep in chunks of samples (its workspace is 2 N D^4 complex per sample):
+    C3P_GRAD_CHUNK=2 on five samples with per-sample operators and frame phases must reproduce the single-chunk result."""
+    rng = np.random.default_rng(D)
+    herm = lambda s: (lambda a: s * (a + a.conj().T) / 2)(rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))
+    B, K, N, Dm = 5, 2, 24, D * D
+    h0 = np.stack([herm(0.8) for _ in range(B)])
+    hks = np.stack([np.stack([herm(0.5) for _ in range(K)]) for _ in range(B)])
+    col = np.stack([0.25 * (rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))])
+    sig = rng.uniform(-1, 1, size=(B, K, N))
+    Ubar = rng.normal(size=(B, Dm, Dm)) + 1j * rng.normal(size=(B, Dm, Dm))
+    ph = rng.uniform(0, 2 * np.pi, size=(B, Dm))
+    one = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, 0.3, col, Ubar, fr_phase=ph))
+    os.environ["C3P_GRAD_CHUNK"] = "2"
+    try:
+        many = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, 0.3, col, Ubar, fr_phase=ph))
+        os.environ["C3P_VALU_GRAD"] = "1"
+        valu = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, 0.3, col, Ubar, fr_phase=ph))
+    finally:
+        os.environ.pop("C3P_GRAD_CHUNK")
+        os.environ.pop("C3P_VALU_GRAD", None)
+    assert np.abs(one - many).max() < 1e-12 * np.abs(one).max()
+    assert np.abs(one - valu).max() < 1e-10 * np.abs(one).max()
+    want = o.pwc_lindblad_signal_gradient(h0[4], hks[4], col, sig[4], 0.3, Ubar[4], ph[4])
+    assert np.abs(many[4] - want).max() < 1e-10 * np.abs(want).max()
+
+
+@pytest.mark.gpu
 def test_lindblad_vjp_cfg4_operators_on_device(prop):
     """cfg4's operators (81 x 81 superoperators), device-resident tensors, against the oracle on both samples."""
     import torch
