@@ -362,6 +362,26 @@ def test_lindblad_vjp_sample_chunks(prop, D):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("D,N", [(2, 400), (3, 300), (4, 200)])
+def test_lindblad_vjp_strong_dissipation(prop, D, N):
+    """Strongly damped chains (the smallest eigenvalue of the total superoperator is ~1e-32): the general-generator sweeps never
+    invert a slice -- prefixes run forwards, the left adjoint backwards -- so they must stay at rounding level against the oracle."""
+    rng = np.random.default_rng(5 + D)
+    herm = lambda s: (lambda a: s * (a + a.conj().T) / 2)(rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))
+    K, B, Dm = 2, 2, D * D
+    h0, hks = herm(2.0), np.stack([herm(1.0) for _ in range(K)])
+    col = np.stack([np.diag(np.sqrt(np.arange(1, D)), 1).astype(complex), 0.7 * np.diag(np.arange(D)).astype(complex)]) * (1.5 if D == 2 else 1.0)
+    sig = rng.uniform(-1, 1, size=(B, K, N))
+    Ubar = rng.normal(size=(B, Dm, Dm)) + 1j * rng.normal(size=(B, Dm, Dm))
+    g = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, 0.25, col, Ubar))
+    U = np.asarray(prop.propagate_batch(h0, hks, sig, 0.25, col_ops=col, lindbladian=True)["U"])
+    assert np.abs(np.linalg.eigvals(U[0])).min() < 1e-25
+    for b in range(B):
+        want = o.pwc_lindblad_signal_gradient(h0, hks, col, sig[b], 0.25, Ubar[b])
+        assert np.abs(g[b] - want).max() < 1e-11 * np.abs(want).max()
+
+
+@pytest.mark.gpu
 def test_lindblad_vjp_cfg4_operators_on_device(prop):
     """cfg4's operators (81 x 81 superoperators), device-resident tensors, against the oracle on both samples."""
     import torch
