@@ -174,3 +174,71 @@ def average_infid_cotangent(ideal, actual, index: List[int] = [0], dims=[2]):
     """(U_bar, infid) for 1 - (|s|^2/L + 1)/(L + 1) (fidelities.py:290-313): U_bar = -2 s P G P^T / (L (L+1))."""
     Ubar, s, L = _cotangent(ideal, actual, index, dims, lambda L: -2.0 / (L * (L + 1)))
     return Ubar, 1 - (abs(s) ** 2 / L + 1) / (L + 1)
+
+
+# --------------------------------------------------------------------------
+# open-system counterpart (fidelities.py:221-285): the same epilogue on projected SUPERoperators
+# --------------------------------------------------------------------------
+
+
+def _super_overlap(ideal, actual, index, dims):
+    """t[b] = tr(A[b] B^+), A = P_s^T S[b] P_s (P_s = P (x) P, tf_project_to_comp(.., to_super=True)), B = tf_super(ideal) =
+    ideal (x) conj(ideal); the rows of P_s are the pairs (i, j) of computational rows: i D + j.  One c3p_gate_overlap launch."""
+    call = _Call(actual, ideal)
+    S = call.c128(actual)
+    squeeze = S.ndim == 2
+    if squeeze:
+        S = S[None]
+    B, Dm = int(S.shape[0]), int(S.shape[-1])
+    if dims is None or int(np.prod(dims)) ** 2 != Dm:
+        raise C3PropError(f"C3:Error: dims {dims} do not match the superoperator dimension {Dm}")
+    D = int(np.prod(dims))
+    rows = computational_rows(dims, index)
+    L = int(rows.shape[0])
+    srows = (rows[:, None].astype(np.int64) * D + rows[None, :]).reshape(-1).astype(np.int32)
+    Gi = np.asarray(ideal.detach().cpu().numpy() if hasattr(ideal, "detach") else ideal, dtype=np.complex128)
+    if Gi.shape != (L, L):
+        raise C3PropError(f"C3:Error: ideal gate must be [{L},{L}] for index {index}, got {Gi.shape}")
+    Gs = np.kron(Gi, np.conj(Gi))
+    if call.device:
+        rows_d = call.torch.as_tensor(srows, device=call.dev)
+        G = call.torch.as_tensor(Gs, device=call.dev)
+        out = call.torch.empty((B,), dtype=call.torch.complex128, device=call.dev)
+    else:
+        rows_d, G = srows, np.ascontiguousarray(Gs)
+        out = np.empty((B,), dtype=np.complex128)
+    _lib.check(_lib.load().c3p_gate_overlap(_ptr(S), B, Dm, _ptr(rows_d), L * L, _ptr(G), call.flags, _ptr(out), call.stream))
+    return (out[0] if squeeze else out), L, srows, Gs, call, squeeze, B, Dm
+
+
+@fid_reg_deco
+def lindbladian_unitary_infid(ideal, actual, index: List[int] = [0], dims=[2]):
+    """fidelities.py:221-249: 1 - |sqrt(tr(A B^+)) / L|^2 = 1 - |tr(A B^+)| / L^2; `actual` may be a batch [B,D^2,D^2]."""
+    t, L = _super_overlap(ideal, actual, index, dims)[:2]
+    return 1 - abs(t) / L**2
+
+
+@fid_reg_deco
+def lindbladian_unitary_infid_set(propagators: dict, instructions: dict, index, dims, n_eval=-1):
+    """Mean over gates (fidelities.py:252-285)."""
+    vals = [np.asarray(lindbladian_unitary_infid(_ideal_of(instructions, g, dims, index), U, index, dims)) for g, U in propagators.items()]
+    return np.mean(vals, axis=0)
+
+
+def lindbladian_unitary_infid_cotangent(ideal, actual, index: List[int] = [0], dims=[2]):
+    """(S_bar, infid) in the convention of `propagation.propagate_batch_lindblad_vjp` (d loss = Re sum conj(S_bar) dS):
+    from 1 - |t| / L^2 with t = sum A conj(B):  S_bar = -(t / |t|) / L^2 * P_s B P_s^T."""
+    t, L, srows, Gs, call, squeeze, B, Dm = _super_overlap(ideal, actual, index, dims)
+    tv = t.reshape(1) if squeeze else t
+    if call.device:
+        tt = call.torch
+        emb = tt.zeros((Dm, Dm), dtype=tt.complex128, device=call.dev)
+        r = tt.as_tensor(srows.astype(np.int64), device=call.dev)
+        emb[r[:, None], r[None, :]] = tt.as_tensor(Gs, device=call.dev)
+        Sbar = (-(tv / tv.abs()) / L**2)[:, None, None] * emb[None]
+    else:
+        emb = np.zeros((Dm, Dm), dtype=np.complex128)
+        emb[np.ix_(srows, srows)] = Gs
+        tv = np.asarray(tv)
+        Sbar = (-(tv / np.abs(tv)) / L**2)[:, None, None] * emb[None]
+    return (Sbar[0] if squeeze else Sbar), 1 - abs(t) / L**2

@@ -20,7 +20,8 @@ import numpy as np
 from . import fidelities, propagation, signals
 from ._lib import C3PropError
 
-_COTANGENTS = {"unitary_infid": fidelities.unitary_infid_cotangent, "average_infid": fidelities.average_infid_cotangent}
+_COTANGENTS = {"unitary_infid": fidelities.unitary_infid_cotangent, "average_infid": fidelities.average_infid_cotangent,
+               "lindbladian_unitary_infid": fidelities.lindbladian_unitary_infid_cotangent}
 
 
 def goal_run_with_grad(
@@ -39,12 +40,17 @@ def goal_run_with_grad(
     *,
     fr_phase=None,
     fid_func: str = "unitary_infid",
+    col_ops=None,
     device="cuda:0",
 ) -> Dict:
     """goals [B] and their gradients w.r.t. every envelope row, carrier pair and frame-rotation phase.
 
     Returns {"goal": [B], "grad_env": [B,K,E,NPAR], "grad_carrier": [B,K,2], "grad_fr_phase": [B,D] or None,
     "U": [B,D,D]} as torch CUDA tensors.
+
+    `col_ops` [C,D,D] switches to the open-system path (model.lindbladian, propagation.py:551-585): U are the D^2 x D^2
+    superoperators, `fid_func` an open-system goal ("lindbladian_unitary_infid", fidelities.py:221-249), `fr_phase` [B,D^2]
+    the row phases of the superoperator, and the control gradient comes from `propagate_batch_lindblad_vjp`.
     """
     import torch
 
@@ -60,9 +66,19 @@ def goal_run_with_grad(
     h0d, hkd = as_dev(h0, np.complex128), as_dev(hks, np.complex128)
     ph = None if fr_phase is None else as_dev(fr_phase, np.float64)
     sig = signals.synthesize_signals(env, env_shapes, car, t_start, t_end, awg_res, sim_res)
-    U = propagation.propagate_batch(h0d, hkd, sig, dt, fr_phase=ph)["U"]
-    U_bar, goal = _COTANGENTS[fid_func](ideal, U, index, dims)
-    g_sig = propagation.propagate_batch_vjp(h0d, hkd, sig, dt, U_bar, fr_phase=ph)
+    if col_ops is not None:
+        if not fid_func.startswith("lindbladian"):
+            raise C3PropError(f"C3:Error: '{fid_func}' is a closed-system goal; the Lindblad path needs a lindbladian_* one")
+        cold = as_dev(col_ops, np.complex128)
+        U = propagation.propagate_batch(h0d, hkd, sig, dt, col_ops=cold, lindbladian=True, fr_phase=ph)["U"]
+        U_bar, goal = _COTANGENTS[fid_func](ideal, U, index, dims)
+        g_sig = propagation.propagate_batch_lindblad_vjp(h0d, hkd, sig, dt, cold, U_bar, fr_phase=ph)
+    else:
+        if fid_func.startswith("lindbladian"):
+            raise C3PropError(f"C3:Error: '{fid_func}' needs collapse operators (col_ops)")
+        U = propagation.propagate_batch(h0d, hkd, sig, dt, fr_phase=ph)["U"]
+        U_bar, goal = _COTANGENTS[fid_func](ideal, U, index, dims)
+        g_sig = propagation.propagate_batch_vjp(h0d, hkd, sig, dt, U_bar, fr_phase=ph)
     g_env, g_car = signals.synthesize_signals_vjp(env, env_shapes, car, t_start, t_end, awg_res, sim_res, g_sig)
     g_ph = None
     if ph is not None:

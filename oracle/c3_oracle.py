@@ -967,6 +967,21 @@ def unitary_infid(ideal, actual, index=None, dims=None):
     return 1 - tf_unitary_overlap(actual_comp, ideal, lvls=2 ** len(index))
 
 
+def tf_superoper_unitary_overlap(A, B, lvls=None):
+    """tf_utils.py:369-377: |sqrt(tr(A B^+)) / lvls|^2."""
+    if lvls is None:
+        lvls = np.sqrt(B.shape[0])
+    return np.abs(np.sqrt(np.trace(A @ np.conj(B.T)) + 0j) / lvls) ** 2
+
+
+def lindbladian_unitary_infid(ideal, actual, index=(0,), dims=(2,)):
+    """fidelities.py:221-249: the unitary overlap of the projected superoperator with tf_super(ideal)."""
+    index = list(index)
+    U_ideal = tf_super(np.asarray(ideal))
+    actual_comp = tf_project_to_comp(actual, dims=dims, index=index, to_super=True)
+    return 1 - tf_superoper_unitary_overlap(actual_comp, U_ideal, lvls=2 ** len(index))
+
+
 def pauli_basis(dims=(2,)):
     """qt_utils.py:10-44."""
     paulis = []

@@ -205,6 +205,57 @@ def test_goal_run_with_grad_pulse_parameters(prop):
 
 
 @pytest.mark.gpu
+def test_goal_run_with_grad_open_system(prop):
+    """The same loop body through the Lindblad path (model.lindbladian: tf_propagation_lind, propagation.py:551-585, under the
+    tape of optimizer.py:206-216) with the open-system goal lindbladian_unitary_infid (fidelities.py:221-249): goal against
+    the oracle's literal tf_super / tf_project_to_comp(to_super) / tf_superoper_unitary_overlap chain, pulse-parameter
+    gradients against finite differences of the oracle pipeline; one qutrit, 9 x 9 superoperators (matrix-core sweep)."""
+    from c3_amd import _lib, fidelities as fd_, optimal_control as oc, signals as sg
+
+    w = make_workload(1, B=1, N=8)  # one qutrit: operators only
+    T, awg_res, sim_res = 7e-9, 2e9, 100e9
+    TWO_PI = 2 * np.pi
+    B = 2
+    rng = np.random.default_rng(9)
+    amps = rng.uniform(0.3, 0.5, size=B)
+    chans = [[dict(shape="gaussian_nonorm", amp=amps, xy_angle=0.1, freq_offset=-50e6 * TWO_PI, delta=-0.8, t_final=T, sigma=T / 4, use_t_before=True, drag=True)]]
+    env, shapes = sg.pack_components(chans, B=B)
+    carrier = np.tile(np.array([[5.0e9 * TWO_PI, 1e9 * TWO_PI]]), (B, 1, 1))
+    D = w.D
+    a = np.diag(np.sqrt(np.arange(1, D)), 1).astype(complex)
+    col = np.stack([np.sqrt(1 / 40e-9) * a, np.sqrt(0.5 / 60e-9) * 2 * a.conj().T @ a])  # T1 / T2* collapse operators (chip.py:216-242)
+    p1 = rng.uniform(0, 2 * np.pi, size=(B, D))
+    ph_super = (p1[:, :, None] - p1[:, None, :]).reshape(B, D * D)
+    ideal = np.array([[1, -1j], [-1j, 1]]) / np.sqrt(2)
+    r = oc.goal_run_with_grad(w.h0, w.hks, env, shapes, carrier, 0.0, T, awg_res, sim_res, ideal, [0], [3], fr_phase=ph_super,
+                              fid_func="lindbladian_unitary_infid", col_ops=col)
+    assert _lib.last_kernel() in ("smalld", "generic_lds")
+    goal = r["goal"].cpu().numpy()
+    genv = r["grad_env"].cpu().numpy()
+
+    def oracle_goal(env_b, b):
+        c = {name: env_b[0, 0, slot] for name, slot in sg.ENV_SLOTS.items() if name != "flags"}
+        fl = int(env_b[0, 0, sg.ENV_SLOTS["flags"]])
+        c.update(shape=int(shapes[0, 0]), use_t_before=bool(fl & 1), drag=bool(fl & 2))
+        vals = o.generate_signal([c], carrier[b, 0, 0], carrier[b, 0, 1], 0.0, T, awg_res, sim_res)["values"]
+        ts = o.create_ts(0.0, T, sim_res)
+        S = o.propagate_batch(w.h0, w.hks, vals[None, None], ts[1] - ts[0], col_ops=col, lindbladian=True, fr_phase=p1[b][None])[0]
+        return o.lindbladian_unitary_infid(ideal, S, index=[0], dims=[3])
+
+    for b in range(B):
+        assert abs(goal[b] - oracle_goal(env[b], b)) < 1e-11
+        for (name, h) in [("amp", 1e-6), ("xy_angle", 1e-6), ("delta", 1e-5), ("freq_offset", 1e3)]:
+            ep, em = env[b].copy(), env[b].copy()
+            ep[0, 0, sg.ENV_SLOTS[name]] += h
+            em[0, 0, sg.ENV_SLOTS[name]] -= h
+            fdv = (oracle_goal(ep, b) - oracle_goal(em, b)) / (2 * h)
+            assert abs(fdv - genv[b, 0, 0, sg.ENV_SLOTS[name]]) < 2e-6 * abs(fdv) + 1e-16, (b, name)
+    # host-pointer form of the epilogue and its registry entry
+    S = r["U"].cpu().numpy()
+    assert np.abs(np.asarray(fd_.fidelities["lindbladian_unitary_infid"](ideal, S, [0], [3])) - goal).max() < 1e-13
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg,N,generic", [(2, 40, False), (2, 40, True), (3, 16, False)])
 def test_vjp_model_gradients(prop, cfg, N, generic):
     """Cotangents of the Hamiltonians themselves (model-parameter fits, modellearning.py:300-341): contraction

@@ -98,3 +98,20 @@ def test_exp_closed_form(theta):
     A, want = _pauli_problem(theta, rng)
     assert np.abs(o.expm(A) - want).max() < 1e-13 * max(1.0, theta)
     assert np.abs(o.tf_expm(A, 100) - want).max() < 1e-6 * max(1.0, np.exp(theta) * 1e-8)
+
+
+def test_oracle_lindbladian_unitary_infid_known_answers():
+    """fidelities.py:221-249 restated: a unitary channel U (x) conj(U) that acts as the ideal gate on the computational
+    subspace has infidelity 0 (whatever it does outside), the identity channel against X has 1, and a depolarised mix sits in
+    between by the mixing weight."""
+    from oracle import c3_oracle as o
+
+    X = np.array([[0, 1], [1, 0]], complex)
+    U = np.eye(3, dtype=complex)
+    U[:2, :2] = X
+    U[2, 2] = np.exp(0.3j)
+    S = np.kron(U, U.conj())
+    assert abs(o.lindbladian_unitary_infid(X, S, index=[0], dims=[3])) < 1e-15
+    assert abs(o.lindbladian_unitary_infid(X, np.eye(9, dtype=complex), index=[0], dims=[3]) - 1.0) < 1e-15
+    mix = 0.7 * S + 0.3 * np.eye(9)
+    assert abs(o.lindbladian_unitary_infid(X, mix, index=[0], dims=[3]) - 0.3) < 1e-15
