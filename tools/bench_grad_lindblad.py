@@ -9,6 +9,7 @@ from c3_amd import _lib, propagation as prop
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", default="2:256:1000,3:256:1000,3:16:1000,4:256:1000,5:64:500,6:64:500")
 ap.add_argument("--tiled-max-n", type=int, default=1000)
+ap.add_argument("--no-tiled", action="store_true", help="skip the tiled-sweep comparison (profiling runs)")
 ap.add_argument("--out", default=None)
 a = ap.parse_args()
 rows = []
@@ -36,12 +37,14 @@ for case in a.cases.split(","):
     g = prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar)
     kern = _lib.last_kernel()
     vjp = timed(lambda: prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar))
-    os.environ["C3P_TILED_GRAD"] = "1"
-    try:
-        gt = prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar)
-        tiled = timed(lambda: prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar), reps=1)
-    finally:
-        os.environ.pop("C3P_TILED_GRAD")
+    gt, tiled = g, float("nan")
+    if not a.no_tiled:
+        os.environ["C3P_TILED_GRAD"] = "1"
+        try:
+            gt = prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar)
+            tiled = timed(lambda: prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar), reps=1)
+        finally:
+            os.environ.pop("C3P_TILED_GRAD")
     row = {"D": D, "Dm": Dm, "B": B, "N": N, "kernel": kern, "forward_ms": fwd * 1e3, "vjp_ms": vjp * 1e3, "vjp_over_forward": vjp / fwd,
            "tiled_vjp_ms": tiled * 1e3, "speedup_vs_tiled": tiled / vjp, "gradients_per_s": B / vjp,
            "max_rel_diff_vs_tiled": float((g - gt).abs().max() / gt.abs().max())}
