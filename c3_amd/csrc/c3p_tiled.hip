@@ -133,6 +133,108 @@ __global__ void __launch_bounds__(256) tg_gemm_kernel(const double* A, const dou
       }
 }
 
+// ---- several independent products in ONE launch, each C = A0 B0 (+ A1 B1) (+ Add) on slots of the per-sample matrix block ----
+// The backward sweep is a chain of small GEMMs (a few hundred workgroups, 10 - 15 us each) and at small batches the launches,
+// not the arithmetic, set the time: the pair evaluation of T18 has two independent results per dependency level (value and
+// derivative), and every derivative is a SUM of two products (product rule).  One task = one result; blockIdx.z = task * nb +
+// sample; the K loop runs over the panels of the first pair and then of the second.  Same tile code as tg_gemm_kernel.
+struct TgTasks {
+  int n;
+  int a0[2], b0[2], a1[2], b1[2], add[2], c[2];  // slot indices; a1 < 0: one product; add < 0: none
+};
+
+__global__ void __launch_bounds__(256) tg_gemm_tasks_kernel(double* mats, long VS, long MS, TgTasks T, int nb, int rows2, int DPC) {
+  __shared__ double As[2][TG_BM * TG_SA];
+  __shared__ double Bs[2][TG_KP * TG_SB];
+  const int task = blockIdx.z / nb, sample = blockIdx.z - task * nb;
+  double* base = mats + (long)sample * VS;
+  const bool dual = T.a1[task] >= 0;
+  const double* A0 = base + (long)T.a0[task] * MS;
+  const double* B0 = base + (long)T.b0[task] * MS;
+  const double* A1 = dual ? base + (long)T.a1[task] * MS : A0;
+  const double* B1 = dual ? base + (long)T.b1[task] * MS : B0;
+  const double* Add = T.add[task] >= 0 ? base + (long)T.add[task] * MS : nullptr;
+  double* C = base + (long)T.c[task] * MS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r0 = blockIdx.y * TG_BM, c0 = blockIdx.x * TG_BN;
+  const int a_row = tid >> 2, a_j = (tid & 3) * 2;
+  const int b_row = tid >> 4, b_c = (tid & 15) * 4;
+  const long aoff = (long)(r0 + a_row) * DPC + a_j, boff = (long)b_row * DPC + c0 + b_c;
+  const int a_rb = a_row & ~1, a_p = a_row & 1;
+  tg_d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (tg_d4){0.0, 0.0, 0.0, 0.0};
+  const int np1 = rows2 / TG_KP;
+  const int npanel = dual ? 2 * np1 : np1;
+  auto a_at = [&](int pn) { return (pn < np1 ? A0 : A1) + aoff + (long)(pn < np1 ? pn : pn - np1) * (TG_KP / 2); };
+  auto b_at = [&](int pn) { return (pn < np1 ? B0 : B1) + boff + (long)(pn < np1 ? pn : pn - np1) * TG_KP * DPC; };
+  double2 av[2], bv0[2], bv1[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int pq = q < npanel ? q : 0;
+    av[q] = *reinterpret_cast<const double2*>(a_at(pq));
+    const double* bn = b_at(pq);
+    bv0[q] = *reinterpret_cast<const double2*>(bn);
+    bv1[q] = *reinterpret_cast<const double2*>(bn + 2);
+  }
+  auto panel = [&](int pn, auto qtag) {
+    constexpr int Q = decltype(qtag)::value;
+    double* as = As[Q];
+    double* bs = Bs[Q];
+    const double2 avc = av[Q], b0c = bv0[Q], b1c = bv1[Q];
+    if (a_p == 0) {
+      as[a_rb * TG_SA + 2 * a_j] = avc.x;
+      as[(a_rb + 1) * TG_SA + 2 * a_j + 1] = avc.x;
+      as[a_rb * TG_SA + 2 * a_j + 2] = avc.y;
+      as[(a_rb + 1) * TG_SA + 2 * a_j + 3] = avc.y;
+    } else {
+      as[a_rb * TG_SA + 2 * a_j + 1] = -avc.x;
+      as[(a_rb + 1) * TG_SA + 2 * a_j] = avc.x;
+      as[a_rb * TG_SA + 2 * a_j + 3] = -avc.y;
+      as[(a_rb + 1) * TG_SA + 2 * a_j + 2] = avc.y;
+    }
+    bs[b_row * TG_SB + b_c + 0] = b0c.x;
+    bs[b_row * TG_SB + b_c + 1] = b0c.y;
+    bs[b_row * TG_SB + b_c + 2] = b1c.x;
+    bs[b_row * TG_SB + b_c + 3] = b1c.y;
+    __syncthreads();
+    if (pn + 2 < npanel) {
+      av[Q] = *reinterpret_cast<const double2*>(a_at(pn + 2));
+      const double* bn = b_at(pn + 2);
+      bv0[Q] = *reinterpret_cast<const double2*>(bn);
+      bv1[Q] = *reinterpret_cast<const double2*>(bn + 2);
+    }
+#pragma unroll
+    for (int ks = 0; ks < TG_KP / 4; ++ks) {
+      double af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = as[(32 * wr + 16 * i + (lane & 15)) * TG_SA + 4 * ks + (lane >> 4)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = bs[(4 * ks + (lane >> 4)) * TG_SB + 32 * wc + 16 * j + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  for (int pn = 0; pn < npanel; pn += 2) {
+    panel(pn, std::integral_constant<int, 0>{});
+    if (pn + 1 < npanel) panel(pn + 1, std::integral_constant<int, 1>{});
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const long e = (long)(r0 + 32 * wr + 16 * i + 4 * v + (lane >> 4)) * DPC + c0 + 32 * wc + 16 * j + (lane & 15);
+        C[e] = acc[i][j][v] + (Add ? Add[e] : 0.0);
+      }
+}
+
 // ---- generator elements ------------------------------------------------------------------------------------------------
 // G = -i dt h (unitary) or the Lindblad generator dt (clp - i (h (x) I - I (x) h^T)) (propagation.py:565-582); with_clp only
 // for the drift table / per-slice generators
@@ -487,6 +589,44 @@ __global__ void __launch_bounds__(256) tg_combo_slots_kernel(double* mats, int n
   M[sx * MS + e] = fma(C3P_T18_B61, a6, fma(C3P_T18_B31, a3, fma(C3P_T18_B21, a2, C3P_T18_B11 * x)));
 }
 
+// value and derivative side of the T18 combinations in one launch (backward slices: two launches fewer per slice)
+__global__ void __launch_bounds__(256) tg_combo2_slots_kernel(double* mats, int nslots, int sx, int s2, int s3, int s6, int t1, int t2,
+                                                              int t3, int t4, int dx, int d2, int d3, int d6, int u1, int u2, int u3,
+                                                              int u4, int Dm, int DPR, int DPC) {
+  const int b = blockIdx.y;
+  const long MS = 2L * DPR * DPC;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= MS) return;
+  double* M = mats + (long)b * nslots * MS;
+  const int r = (int)(e / DPC), c = (int)(e - (long)r * DPC);
+  const double dg = ((r & 1) == 0 && (r >> 1) == c && c < Dm) ? 1.0 : 0.0;
+  {
+    const double x = M[sx * MS + e], a2 = M[s2 * MS + e], a3 = M[s3 * MS + e], a6 = M[s6 * MS + e];
+    M[t1 * MS + e] = fma(C3P_T18_A31, a3, fma(C3P_T18_A21, a2, C3P_T18_A11 * x));
+    M[t2 * MS + e] = fma(C3P_T18_B64, a6, fma(C3P_T18_B34, a3, C3P_T18_B24 * a2));
+    M[t3 * MS + e] = fma(C3P_T18_B63, a6, fma(C3P_T18_B33, a3, fma(C3P_T18_B23, a2, fma(C3P_T18_B13, x, C3P_T18_B03 * dg))));
+    M[t4 * MS + e] = fma(C3P_T18_B62, a6, fma(C3P_T18_B32, a3, fma(C3P_T18_B22, a2, fma(C3P_T18_B12, x, C3P_T18_B02 * dg))));
+    M[sx * MS + e] = fma(C3P_T18_B61, a6, fma(C3P_T18_B31, a3, fma(C3P_T18_B21, a2, C3P_T18_B11 * x)));
+  }
+  {
+    const double x = M[dx * MS + e], a2 = M[d2 * MS + e], a3 = M[d3 * MS + e], a6 = M[d6 * MS + e];
+    M[u1 * MS + e] = fma(C3P_T18_A31, a3, fma(C3P_T18_A21, a2, C3P_T18_A11 * x));
+    M[u2 * MS + e] = fma(C3P_T18_B64, a6, fma(C3P_T18_B34, a3, C3P_T18_B24 * a2));
+    M[u3 * MS + e] = fma(C3P_T18_B63, a6, fma(C3P_T18_B33, a3, fma(C3P_T18_B23, a2, C3P_T18_B13 * x)));
+    M[u4 * MS + e] = fma(C3P_T18_B62, a6, fma(C3P_T18_B32, a3, fma(C3P_T18_B22, a2, C3P_T18_B12 * x)));
+    M[dx * MS + e] = fma(C3P_T18_B61, a6, fma(C3P_T18_B31, a3, fma(C3P_T18_B21, a2, C3P_T18_B11 * x)));
+  }
+}
+
+__global__ void __launch_bounds__(256) tg_add2_slots_kernel(double* mats, int nslots, int sa, int sb, int sd, int ta, int tb, int td,
+                                                            long MS) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= MS) return;
+  double* M = mats + (long)blockIdx.y * nslots * MS;
+  M[sd * MS + e] = M[sa * MS + e] + M[sb * MS + e];
+  M[td * MS + e] = M[ta * MS + e] + M[tb * MS + e];
+}
+
 __global__ void __launch_bounds__(256) tg_add_slots_kernel(double* mats, int nslots, int sa, int sb, int sd, long MS) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= MS) return;
@@ -814,6 +954,7 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
   // kernels per slice (a 192-deep GEMM on a 96 x 128 half image is 12 K-panels of ~0.8 us each), not by launch overhead.
   // Graphs need a capturable stream: not the legacy default stream, not a stream that is itself being captured.
   bool use_graph = st != nullptr && getenv("C3P_TILED_GRAPH") != nullptr;
+  const bool no_batch = getenv("C3P_TILED_NO_BATCH") != nullptr;  // A/B switch: one launch per product in the backward slices
   if (use_graph) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) use_graph = false;
@@ -994,32 +1135,46 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
         hipLaunchKernelGGL(tg_gemm_kernel, gg, dim3(256), 0, st, M(lin), store, (const double*)nullptr, M(V_V), 2 * g.DPR, g.DPC, VS, SS,
                            VS, (const int*)nctr, off, MS);
       assemble(tables_adj, meta_adj, off, junk, junk + 2 * (size_t)Bc);  // Y = X_n^H (scaled)
-      gemm(V_Y, V_Y, -1, V_A2);
-      gemm(V_V, V_Y, -1, V_DA2);
-      gemm(V_Y, V_V, V_DA2, V_DA2);
-      gemm(V_Y, V_A2, -1, V_A3);
-      gemm(V_V, V_A2, -1, V_DA3);
-      gemm(V_Y, V_DA2, V_DA3, V_DA3);
-      gemm(V_A3, V_A3, -1, V_A6);
-      gemm(V_DA3, V_A3, -1, V_DA6);
-      gemm(V_A3, V_DA3, V_DA6, V_DA6);
-      hipLaunchKernelGGL(tg_combo_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_Y, V_A2, V_A3, V_A6, V_T1, V_T2, V_T3, V_T4, 1,
-                         A.Dm, g.DPR, g.DPC);
-      hipLaunchKernelGGL(tg_combo_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_V, V_DA2, V_DA3, V_DA6, V_DT1, V_DT2, V_DT3,
-                         V_DT4, 0, A.Dm, g.DPR, g.DPC);
-      gemm(V_T1, V_T2, V_T3, V_A2);       // A9 = B1 B5 + B4
-      gemm(V_DT1, V_T2, V_DT3, V_DA2);    // dA9 = dB1 B5 + dB4
-      gemm(V_T1, V_DT2, V_DA2, V_DA2);    //      + B1 dB5
-      hipLaunchKernelGGL(tg_add_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_T4, V_A2, V_A3, MS);     // L = B3 + A9
-      hipLaunchKernelGGL(tg_add_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_DT4, V_DA2, V_DA3, MS);  // dL
-      gemm(V_A3, V_A2, V_Y, V_A6);        // F = L A9 + B2
-      gemm(V_DA3, V_A2, V_V, V_DA6);      // dF = dL A9 + dB2
-      gemm(V_A3, V_DA2, V_DA6, V_DA6);    //     + L dA9
+      // two results per dependency level (value, derivative), every derivative the sum of two products: one launch per level
+      // (C3P_TILED_NO_BATCH=1: one launch per product, the first form of this sweep)
+      auto level = [&](int va, int vb, int vadd, int vc, int da0, int db0, int da1, int db1, int dadd, int dc) {
+        if (no_batch) {
+          gemm(va, vb, vadd, vc);
+          gemm(da0, db0, dadd, dc);
+          gemm(da1, db1, dc, dc);
+          return;
+        }
+        TgTasks T = {};
+        T.n = 2;
+        T.a0[0] = va, T.b0[0] = vb, T.a1[0] = -1, T.b1[0] = -1, T.add[0] = vadd, T.c[0] = vc;
+        T.a0[1] = da0, T.b0[1] = db0, T.a1[1] = da1, T.b1[1] = db1, T.add[1] = dadd, T.c[1] = dc;
+        dim3 g2 = ggrid;
+        g2.z = (unsigned)(2 * nb);
+        hipLaunchKernelGGL(tg_gemm_tasks_kernel, g2, dim3(256), 0, st, mats, VS, MS, T, nb, 2 * g.DPR, g.DPC);
+      };
+      level(V_Y, V_Y, -1, V_A2, V_V, V_Y, V_Y, V_V, -1, V_DA2);
+      level(V_Y, V_A2, -1, V_A3, V_V, V_A2, V_Y, V_DA2, -1, V_DA3);
+      level(V_A3, V_A3, -1, V_A6, V_DA3, V_A3, V_A3, V_DA3, -1, V_DA6);
+      if (no_batch) {
+        hipLaunchKernelGGL(tg_combo_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_Y, V_A2, V_A3, V_A6, V_T1, V_T2, V_T3, V_T4, 1,
+                           A.Dm, g.DPR, g.DPC);
+        hipLaunchKernelGGL(tg_combo_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_V, V_DA2, V_DA3, V_DA6, V_DT1, V_DT2, V_DT3,
+                           V_DT4, 0, A.Dm, g.DPR, g.DPC);
+      } else {
+        hipLaunchKernelGGL(tg_combo2_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_Y, V_A2, V_A3, V_A6, V_T1, V_T2, V_T3, V_T4,
+                           V_V, V_DA2, V_DA3, V_DA6, V_DT1, V_DT2, V_DT3, V_DT4, A.Dm, g.DPR, g.DPC);
+      }
+      level(V_T1, V_T2, V_T3, V_A2, V_DT1, V_T2, V_T1, V_DT2, V_DT3, V_DA2);  // A9 = B1 B5 + B4; dA9 = dB1 B5 + B1 dB5 + dB4
+      if (no_batch) {
+        hipLaunchKernelGGL(tg_add_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_T4, V_A2, V_A3, MS);     // L = B3 + A9
+        hipLaunchKernelGGL(tg_add_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_DT4, V_DA2, V_DA3, MS);  // dL
+      } else {
+        hipLaunchKernelGGL(tg_add2_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_T4, V_A2, V_A3, V_DT4, V_DA2, V_DA3, MS);
+      }
+      level(V_A3, V_A2, V_Y, V_A6, V_DA3, V_A2, V_A3, V_DA2, V_V, V_DA6);  // F = L A9 + B2; dF = dL A9 + L dA9 + dB2
       int e = V_A6, o = V_T1, de = V_DA6, dq = V_DT1;
       for (int it = 0; it < s18; ++it) {
-        gemm(de, e, -1, dq);
-        gemm(e, de, dq, dq);
-        gemm(e, e, -1, o);
+        level(e, e, -1, o, de, e, e, de, -1, dq);
         std::swap(e, o);
         std::swap(de, dq);
       }
