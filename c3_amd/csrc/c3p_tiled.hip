@@ -235,6 +235,81 @@ __global__ void __launch_bounds__(256) tg_gemm_tasks_kernel(double* mats, long V
       }
 }
 
+// The same with 32 x 32 output tiles (one 16 x 16 MFMA tile per wave): a wave of the 64 x 64 form issues 192 dependent-accumulator
+// MFMAs per product at Dm = 81 (5 us whatever the batch); for small batches a quarter of that per wave and four times the
+// workgroups is the better split.
+constexpr int TG_SB32 = 48;
+__global__ void __launch_bounds__(256) tg_gemm_tasks32_kernel(double* mats, long VS, long MS, TgTasks T, int nb, int rows2, int DPC) {
+  __shared__ double As[2][32 * TG_SA];
+  __shared__ double Bs[2][TG_KP * TG_SB32];
+  const int task = blockIdx.z / nb, sample = blockIdx.z - task * nb;
+  double* base = mats + (long)sample * VS;
+  const bool dual = T.a1[task] >= 0;
+  const double* A0 = base + (long)T.a0[task] * MS;
+  const double* B0 = base + (long)T.b0[task] * MS;
+  const double* A1 = dual ? base + (long)T.a1[task] * MS : A0;
+  const double* B1 = dual ? base + (long)T.b1[task] * MS : B0;
+  const double* Add = T.add[task] >= 0 ? base + (long)T.add[task] * MS : nullptr;
+  double* C = base + (long)T.c[task] * MS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  // loaders: A_h panel 32 rows x 8 complex columns (one double per thread), B_h panel 16 rows x 32 columns (two per thread)
+  const int a_row = tid >> 3, a_j = tid & 7;
+  const int b_row = tid >> 4, b_c = (tid & 15) * 2;
+  const long aoff = (long)(r0 + a_row) * DPC + a_j, boff = (long)b_row * DPC + c0 + b_c;
+  const int a_rb = a_row & ~1, a_p = a_row & 1;
+  tg_d4 acc = (tg_d4){0.0, 0.0, 0.0, 0.0};
+  const int np1 = rows2 / TG_KP;
+  const int npanel = dual ? 2 * np1 : np1;
+  auto a_at = [&](int pn) { return (pn < np1 ? A0 : A1) + aoff + (long)(pn < np1 ? pn : pn - np1) * (TG_KP / 2); };
+  auto b_at = [&](int pn) { return (pn < np1 ? B0 : B1) + boff + (long)(pn < np1 ? pn : pn - np1) * TG_KP * DPC; };
+  double av[2];
+  double2 bv[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int pq = q < npanel ? q : 0;
+    av[q] = *a_at(pq);
+    bv[q] = *reinterpret_cast<const double2*>(b_at(pq));
+  }
+  auto panel = [&](int pn, auto qtag) {
+    constexpr int Q = decltype(qtag)::value;
+    double* as = As[Q];
+    double* bs = Bs[Q];
+    const double x = av[Q];
+    const double2 bc = bv[Q];
+    if (a_p == 0) {
+      as[a_rb * TG_SA + 2 * a_j] = x;
+      as[(a_rb + 1) * TG_SA + 2 * a_j + 1] = x;
+    } else {
+      as[a_rb * TG_SA + 2 * a_j + 1] = -x;
+      as[(a_rb + 1) * TG_SA + 2 * a_j] = x;
+    }
+    bs[b_row * TG_SB32 + b_c + 0] = bc.x;
+    bs[b_row * TG_SB32 + b_c + 1] = bc.y;
+    __syncthreads();
+    if (pn + 2 < npanel) {
+      av[Q] = *a_at(pn + 2);
+      bv[Q] = *reinterpret_cast<const double2*>(b_at(pn + 2));
+    }
+#pragma unroll
+    for (int ks = 0; ks < TG_KP / 4; ++ks) {
+      const double af = as[(16 * wr + (lane & 15)) * TG_SA + 4 * ks + (lane >> 4)];
+      const double bf = bs[(4 * ks + (lane >> 4)) * TG_SB32 + 16 * wc + (lane & 15)];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+    }
+  };
+  for (int pn = 0; pn < npanel; pn += 2) {
+    panel(pn, std::integral_constant<int, 0>{});
+    if (pn + 1 < npanel) panel(pn + 1, std::integral_constant<int, 1>{});
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const long e = (long)(r0 + 16 * wr + 4 * v + (lane >> 4)) * DPC + c0 + 16 * wc + (lane & 15);
+    C[e] = acc[v] + (Add ? Add[e] : 0.0);
+  }
+}
+
 // ---- generator elements ------------------------------------------------------------------------------------------------
 // G = -i dt h (unitary) or the Lindblad generator dt (clp - i (h (x) I - I (x) h^T)) (propagation.py:565-582); with_clp only
 // for the drift table / per-slice generators
@@ -955,6 +1030,7 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
   // Graphs need a capturable stream: not the legacy default stream, not a stream that is itself being captured.
   bool use_graph = st != nullptr && getenv("C3P_TILED_GRAPH") != nullptr;
   const bool no_batch = getenv("C3P_TILED_NO_BATCH") != nullptr;  // A/B switch: one launch per product in the backward slices
+  const char* t32e = getenv("C3P_TILED_TILE32");
   if (use_graph) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) use_graph = false;
@@ -1030,6 +1106,8 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
     const dim3 eg(ebl, (unsigned)nb);
     dim3 gg = ggrid;
     gg.z = (unsigned)nb;
+    // small batches: 32 x 32 output tiles in the backward levels (see tg_gemm_tasks32_kernel); C3P_TILED_TILE32=0/1 overrides
+    const bool tile32 = t32e ? atoi(t32e) != 0 : ((long)ggrid.x * ggrid.y * nb * 2 < 1024);
     auto M = [&](int slot) -> double* { return mats + (long)slot * MS; };
     auto gemm = [&](int a, int b, int add, int c) {
       hipLaunchKernelGGL(tg_gemm_kernel, gg, dim3(256), 0, st, M(a), M(b), add >= 0 ? M(add) : nullptr, M(c), 2 * g.DPR, g.DPC, VS, VS,
@@ -1150,7 +1228,13 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
         T.a0[1] = da0, T.b0[1] = db0, T.a1[1] = da1, T.b1[1] = db1, T.add[1] = dadd, T.c[1] = dc;
         dim3 g2 = ggrid;
         g2.z = (unsigned)(2 * nb);
-        hipLaunchKernelGGL(tg_gemm_tasks_kernel, g2, dim3(256), 0, st, mats, VS, MS, T, nb, 2 * g.DPR, g.DPC);
+        if (tile32) {
+          g2.x *= 2;
+          g2.y *= 2;
+          hipLaunchKernelGGL(tg_gemm_tasks32_kernel, g2, dim3(256), 0, st, mats, VS, MS, T, nb, 2 * g.DPR, g.DPC);
+        } else {
+          hipLaunchKernelGGL(tg_gemm_tasks_kernel, g2, dim3(256), 0, st, mats, VS, MS, T, nb, 2 * g.DPR, g.DPC);
+        }
       };
       level(V_Y, V_Y, -1, V_A2, V_V, V_Y, V_Y, V_V, -1, V_DA2);
       level(V_Y, V_A2, -1, V_A3, V_V, V_A2, V_Y, V_DA2, -1, V_DA3);
