@@ -37,3 +37,28 @@ def propagate_samples(h0, hks, signals, dt, *, col_ops=None, lindbladian=False, 
         return np.stack([_one(j) for j in jobs])
     with mp.get_context("spawn").Pool(workers, initializer=_init) as pool:
         return np.stack(pool.map(_one, jobs, chunksize=1))
+
+
+def _one_ode(job):
+    h0, hks, sig, ts, init, solver, step, col = job
+    from oracle import c3_oracle as o
+
+    return o.ode_solver_arrays(h0, hks, sig, ts, init, solver, step, col=col, final_only=True)["states"]
+
+
+def ode_final_states(h0, hks, signals, ts, init, solver, step, *, col_ops=None, workers=None):
+    """oracle.ode_solver_arrays(final_only) over the samples of `signals` [n,K,N], one process per sample."""
+    import numpy as np
+
+    n = int(signals.shape[0])
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    workers = max(1, min(n, workers or 32, avail))
+    jobs = [(h0, hks, signals[i], ts, init, solver, step, col_ops) for i in range(n)]
+    if workers == 1:
+        _init()
+        return np.stack([_one_ode(j) for j in jobs])
+    with mp.get_context("spawn").Pool(workers, initializer=_init) as pool:
+        return np.stack(pool.map(_one_ode, jobs, chunksize=1))

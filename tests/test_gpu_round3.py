@@ -666,3 +666,29 @@ def test_ode_rhoq_full_size_properties(prop, cfg, step):
     for b in (0, 15):
         ref = o.ode_solver_arrays(wl.h0, wl.hks, wl.signals[b], wl.ts, rho, "rk4", step, col=col, final_only=True)["states"]
         assert np.abs(out[b] - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,step,solver,n", [(2, "schrodinger", "rk4", 32), (2, "schrodinger", "tsit5", 32), (2, "von_neumann", "rk4", 32),
+                                               (2, "lindblad", "rk5", 16), (3, "schrodinger", "rk4", 16), (3, "von_neumann", "rk4", 8),
+                                               (3, "lindblad", "rk4", 8), (5, "von_neumann", "rk38", 4)])
+def test_ode_full_size_parity_many_samples(prop, cfg, step, solver, n):
+    """The ODE solver variant at BASELINE's operators and slice counts (N = 1000 / 2000 / 5000), every kernel family (lane-row
+    vector / matrix, mid-D lane-row, matrix core), n samples each against the oracle's solver of the same tableau (one oracle
+    process per sample on the host cores): relative 1e-11 of the largest state element."""
+    from tests.oracle_pool import ode_final_states
+
+    wl = workloads.make_workload(cfg, B=n)
+    D = wl.D
+    psi = np.zeros((D, 1), complex)
+    psi[0, 0] = 0.6
+    psi[1, 0] = 0.8j
+    init = psi if step == "schrodinger" else psi @ psi.conj().T
+    col = None
+    if step == "lindblad":
+        col = np.stack([0.05 * np.diag(np.sqrt(np.arange(1, D) % 3 + 1.0), 1), 0.03 * np.diag(np.arange(D) % 3).astype(float)]).astype(complex)
+    out = np.asarray(prop.ode_solve_batch(wl.h0, wl.hks, wl.signals, wl.dt, init, solver, step, col_ops=col, final_only=True))
+    ref = ode_final_states(wl.h0, wl.hks, wl.signals, wl.ts, init, solver, step, col_ops=col)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.isfinite(out).all()
+    assert np.abs(out - ref).max() < 1e-11 * scale
