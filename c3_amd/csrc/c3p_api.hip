@@ -1601,10 +1601,38 @@ int ode_segmented(DeviceWs* w, OdeArgs a, int nseg, const cplx* init, long init_
   a.seg_count = nseg;
   a.seg_len = (a.n_steps + nseg - 1) / nseg;
   a.states = (cplx*)v_maps;
-  LAUNCH_TRY(c3p_launch_ode_row(a, nullptr, st));
-  if (combine_smalld(w, (const cplx*)v_maps, B, nseg, D, 0, nullptr, (cplx*)v_U, st)) return -1;
+  if (D > 16) {
+    // 17 <= D <= 48: the segment maps on the matrix-core kernel (propagator step: one product per stage), combined on the
+    // mid-D chain kernel
+    a.step = C3P_STEP_PROPAGATOR_ID;
+    LAUNCH_TRY(c3p_launch_ode_rhoq(a, st));
+    if (combine_midd(w, (const cplx*)v_maps, B, nseg, D, 0, nullptr, (cplx*)v_U, st)) return -1;
+  } else {
+    LAUNCH_TRY(c3p_launch_ode_row(a, nullptr, st));
+    if (combine_smalld(w, (const cplx*)v_maps, B, nseg, D, 0, nullptr, (cplx*)v_U, st)) return -1;
+  }
   if (psi_out) HIP_TRY(c3p_launch_ode_apply((const cplx*)v_U, init, init_bstride, psi_out, B, D, st));
   return 0;
+}
+
+// Time segments for few samples at 17 <= D <= 48 (final state / propagator only): one workgroup per (sample, segment) on the
+// matrix-core kernel.  A sample alone keeps ONE CU busy for n_steps x ~5 us; S segments spread it over S CUs (the chip has
+// 256), at the price of the ordered product of S maps.  min_gain: how many segments the change has to offer at least
+// (a vector state that would otherwise run on the lane-row kernel pays 1.5x per step for becoming a matrix).
+int ode_mfma_segments(const OdeArgs& a0, int min_segments) {
+  if (getenv("C3P_ODE_NO_SEG")) return 0;
+  if (a0.D < 17 || a0.D > 48 || a0.want_all || a0.reset_each_step || a0.transpose_out || a0.hs || a0.K > 4 || a0.n_steps < 64) return 0;
+  int nig, nj, wd;
+  if (!c3p_midd_geometry(a0.D, &nig, &nj, &wd)) return 0;  // (the ordered product of the maps runs on the mid-D chain kernel: D <= 40)
+  OdeArgs a = a0;
+  a.step = C3P_STEP_PROPAGATOR_ID;
+  a.M = a.D;
+  a.seg_count = 2;
+  if (!c3p_ode_rhoq_supported(a)) return 0;
+  long S = 512 / a.B;
+  if (S > a.n_steps / 16) S = a.n_steps / 16;
+  if (S > 64) S = 64;
+  return S >= min_segments ? (int)S : 0;
 }
 }  // namespace
 
@@ -1681,6 +1709,18 @@ int c3p_ode_solve(const void* h0, const void* hks, const double* signals, const 
     if (record_stop(w, st)) return -1;
     if (flags & C3P_HOST_PTRS) return sg.finish();
     return 0;
+  }
+  if (step == C3P_STEP_SCHRODINGER) {
+    const int nseg = ode_mfma_segments(a, 4);
+    if (nseg > 0) {
+      // few states at 17 <= D <= 48, final state only: segment maps on the matrix-core kernel, psi = U psi0
+      g_last_kernel = C3P_KERNEL_ODE_MFMA;
+      if (record_start(w, st)) return -1;
+      if (ode_segmented(w, a, nseg, (const cplx*)d_init, init_bstride, nullptr, (cplx*)d_states, st)) return -1;
+      if (record_stop(w, st)) return -1;
+      if (flags & C3P_HOST_PTRS) return sg.finish();
+      return 0;
+    }
   }
   if (c3p_ode_rowq_supported(a)) {
     // 17 <= D <= 48 vector states: several DPP rows per sample, operators in LDS (c3p_ode_rowq.hip)
@@ -1793,7 +1833,12 @@ int c3p_rk4_unitary(const void* h0, const void* hks, const double* signals, cons
     g_last_kernel = C3P_KERNEL_ODE_MFMA;
     a.want_all = 0;
     a.states = (cplx*)d_U;
-    LAUNCH_TRY(c3p_launch_ode_rhoq(a, st));
+    const int nseg = ode_mfma_segments(a, 2);
+    if (nseg > 0) {  // few gates: one workgroup per (gate, time segment)
+      if (ode_segmented(w, a, nseg, nullptr, 0, (cplx*)d_U, nullptr, st)) return -1;
+    } else {
+      LAUNCH_TRY(c3p_launch_ode_rhoq(a, st));
+    }
     if (d_dUs) {
       a.want_all = 1;
       a.reset_each_step = 1;

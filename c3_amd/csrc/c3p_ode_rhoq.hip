@@ -90,7 +90,12 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
   const int I = wave / NT, J = wave - I * NT;
   const int lr = lane >> 4, lc = lane & 15;
   const int D = A.D, K = A.K, N = A.N, us = A.u_stride;
-  const int b = blockIdx.x;
+  // time segments (propagator step, final result only): workgroup (b, seg) integrates steps [seg seg_len, (seg + 1) seg_len) from
+  // A.init (the identity) and writes the step map of its segment to states[b, seg]
+  const int SG = A.seg_count > 0 ? A.seg_count : 1;
+  const int b = blockIdx.x / SG, seg = blockIdx.x - b * SG;
+  const int n_begin = A.seg_count > 0 ? seg * A.seg_len : 0;
+  const int n_end = A.seg_count > 0 ? (n_begin + A.seg_len < A.n_steps ? n_begin + A.seg_len : A.n_steps) : A.n_steps;
   double* lds = reinterpret_cast<double*>(c3p_ode_rhoq_smem);
   // planes: left operator (H or L), stage argument, [Lindblad: right operator R, product T, collapse operators]
   double* const Lr = lds;
@@ -267,7 +272,7 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
     return K > 0 ? sg[(long)(wk < K ? wk : 0) * N + idx] : 0.0;
   };
   int wbase = 0;
-  double winv = 0.0, nwinv = load_window(window_base(0));
+  double winv = 0.0, nwinv = load_window(window_base(n_begin));
   auto lane_value = [&](double x, int l) {  // x of lane l (uniform l)
     const long long bits = __double_as_longlong(x);
     const int lo32 = __builtin_amdgcn_readlane((int)bits, l), hi32 = __builtin_amdgcn_readlane((int)(bits >> 32), l);
@@ -291,7 +296,7 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
   const int boff = lr * LD + 16 * J + lc;    // B fragment of column tile J: element (k = lr, column lc)
   const int coff = (16 * J + lc) * LD + lr;  // A-pattern read at row tile J: B fragment of a conjugate transpose
   const long ssz = (long)D * D;
-  cplx* outp = A.states + (long)b * (A.want_all ? (long)A.n_steps : 1) * ssz;
+  cplx* outp = A.states + (A.seg_count > 0 ? (long)blockIdx.x : (long)b * (A.want_all ? (long)A.n_steps : 1)) * ssz;
   long oidx[4];  // (gen_du_rk4 stacks the propagated vectors as rows: transposed store)
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
@@ -307,7 +312,7 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
 #define RHOQ_T(i, a, b)
 #define RHOQ_NOW() 0
 #endif
-  for (int n = 0; n < A.n_steps; ++n) {
+  for (int n = n_begin; n < n_end; ++n) {
     winv = nwinv;
     wbase = window_base(n);
     nwinv = load_window(window_base(n + 1));
@@ -550,7 +555,8 @@ hipError_t launch_rho4(const OdeArgs& A, hipStream_t st) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((ode_rhoq_kernel<NT, SOLVER, MODE, HERM>), dim3((unsigned)A.B), dim3(64 * NT * NT), lds, st, A);
+  hipLaunchKernelGGL((ode_rhoq_kernel<NT, SOLVER, MODE, HERM>), dim3((unsigned)(A.B * (A.seg_count > 0 ? A.seg_count : 1))), dim3(64 * NT * NT), lds,
+                     st, A);
   return hipGetLastError();
 }
 
@@ -594,8 +600,10 @@ hipError_t launch_rho1(const OdeArgs& A, hipStream_t st) {
 bool c3p_ode_rhoq_supported(const OdeArgs& A) {
   if (getenv("C3P_ODE_WG")) return false;
   if (A.D < 17 || A.D > 48 || A.M != A.D || A.K > RK || A.hs || A.N < 2) return false;
-  if (A.seg_count > 0 || A.u_stride < 1 || A.u_stride > 2) return false;
-  if (A.step == C3P_STEP_PROPAGATOR_ID) return !getenv("C3P_ODE_PROP_ROWS");  // (A/B switch: the lane-row column kernel)
+  if (A.u_stride < 1 || A.u_stride > 2) return false;
+  if (A.step == C3P_STEP_PROPAGATOR_ID)
+    return !getenv("C3P_ODE_PROP_ROWS") && (A.seg_count == 0 || (!A.want_all && !A.reset_each_step && !A.transpose_out));
+  if (A.seg_count > 0) return false;  // (A/B switch: the lane-row column kernel)
   if (A.reset_each_step || A.transpose_out) return false;
   if (A.step == C3P_STEP_VON_NEUMANN_ID) return true;
   if (A.step != C3P_STEP_LINDBLAD_ID || A.D > 32) return false;

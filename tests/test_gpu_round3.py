@@ -692,3 +692,66 @@ def test_ode_full_size_parity_many_samples(prop, cfg, step, solver, n):
     scale = max(1.0, float(np.abs(ref).max()))
     assert np.isfinite(out).all()
     assert np.abs(out - ref).max() < 1e-11 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,K,B,N,real", [(20, 2, 5, 200, False), (27, 3, 2, 160, True), (36, 1, 3, 130, False), (40, 2, 1, 100, True)])
+def test_ode_mid_dimension_time_segments(prop, D, K, B, N, real):
+    """Few states at 17 <= D <= 40, final state only: the time axis is cut into segments whose step maps are integrated in
+    parallel on the matrix-core kernel (one workgroup per sample and segment), multiplied in order on the mid-D chain kernel and
+    applied to the initial state.  Same RK steps, re-associated products: against the oracle's sequential integration and
+    against the direct integration (C3P_ODE_NO_SEG=1), per-sample initial states."""
+    from c3_amd import _lib
+
+    h0, hks, sig, ts = _ode_problem(D, K, B, N, real, 900 + D)
+    rng = np.random.default_rng(D)
+    psi = rng.normal(size=(B, D, 1)) + 1j * rng.normal(size=(B, D, 1))
+    for solver in ("rk4", "rk5"):
+        fin = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], psi, solver, "schrodinger", final_only=True))
+        assert _lib.last_kernel() == "ode_mfma"
+        os.environ["C3P_ODE_NO_SEG"] = "1"
+        try:
+            direct = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], psi, solver, "schrodinger", final_only=True))
+            assert _lib.last_kernel() == "ode_row"
+        finally:
+            os.environ.pop("C3P_ODE_NO_SEG")
+        assert np.abs(fin - direct).max() < 1e-12
+        for b in range(B):
+            ref = o.ode_solver_arrays(h0, hks, sig[b], ts, psi[b], solver, "schrodinger", final_only=True)["states"]
+            assert np.abs(fin[b] - ref).max() < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,B,Ns", [(27, 3, 257), (40, 1, 161)])
+def test_rk4_unitary_mid_dimension_time_segments(prop, D, B, Ns):
+    """rk4_unitary for a handful of gates at 17 <= D <= 40: one workgroup per (gate, time segment), ordered product of the
+    segment maps; against the oracle and the unsegmented launch."""
+    import ctypes
+
+    from c3_amd import _lib
+
+    K = 2
+    h0, hks, sig, _ = _ode_problem(D, K, B, Ns, False, 70 + D)
+    lib = _lib.load()
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    h0c, hkc, sgc = np.ascontiguousarray(h0), np.ascontiguousarray(hks), np.ascontiguousarray(sig)
+    res = {}
+    for env in (None, "C3P_ODE_NO_SEG"):
+        if env:
+            os.environ[env] = "1"
+        try:
+            U = np.zeros((B, D, D), complex)
+            dUs = np.zeros((B, (Ns - 1) // 2, D, D), complex)
+            rc = lib.c3p_rk4_unitary(p(h0c), p(hkc), p(sgc), None, 0, 0.02, B, K, Ns, D, 1, p(U), p(dUs), None)
+            assert rc == 0 and _lib.last_kernel() == "ode_mfma"
+            res[env] = (U, dUs)
+        finally:
+            if env:
+                os.environ.pop(env)
+    assert np.abs(res[None][0] - res["C3P_ODE_NO_SEG"][0]).max() < 1e-12
+    assert np.abs(res[None][1] - res["C3P_ODE_NO_SEG"][1]).max() == 0.0
+    for b in range(B):
+        Hs = h0[None] + np.einsum("kn,kij->nij", sig[b], hks)
+        ref = o.rk4_unitary_arrays(Hs, 0.02, D)
+        assert np.abs(res[None][0][b] - ref["U"]).max() < 1e-12
+        assert np.abs(res[None][1][b] - ref["dUs"]).max() < 1e-12

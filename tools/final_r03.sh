@@ -57,6 +57,10 @@ C3P_ODE_WG=1 python tests/perf/bench_ode.py --config 5 --steps von_neumann --sol
 C3P_ODE_RHO_GENERAL=1 python tests/perf/bench_ode.py --config 3 --steps von_neumann --solvers rk4 --rho-batches 1536 --out $O/ode_rho_cfg3_general.json > /dev/null 2>&1
 python tests/perf/bench_ode.py --config 3 --complex-ops --steps von_neumann --solvers rk4 --rho-batches 1536 --out $O/ode_rho_cfg3_complex.json > /dev/null 2>&1
 python tests/perf/bench_rk4_unitary.py --config 3 --batches 64,256,1024 --out $O/rk4_unitary_cfg3.json > /dev/null 2>&1
+python tests/perf/bench_rk4_unitary.py --config 3 --batches 4,16,64,256 --out $O/rk4_unitary_cfg3_small.json > /dev/null 2>&1
+python tests/perf/bench_rk4_unitary.py --config 5 --batches 4,64 --out $O/rk4_unitary_cfg5_small.json > /dev/null 2>&1
+python tests/perf/bench_ode.py --config 3 --steps schrodinger --solvers rk4,tsit5 --batches 4,16,64,128,256 --out $O/ode_cfg3_small_batches.json > /dev/null 2>&1
+C3P_ODE_NO_SEG=1 python tests/perf/bench_ode.py --config 3 --steps schrodinger --solvers rk4 --batches 4,64 --out $O/ode_cfg3_small_batches_direct.json > /dev/null 2>&1
 python tests/perf/bench_rk4_unitary.py --config 5 --batches 256 --out $O/rk4_unitary_cfg5.json > /dev/null 2>&1
 bash tools/profile_ode_rho.sh 3 1536 > /dev/null 2>&1
 cp gpurun_out/r03/ode_rho_pmc_summary.txt gpurun_out/r03/ode_rho_kernel_stats.csv $O/
