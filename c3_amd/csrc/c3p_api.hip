@@ -981,6 +981,125 @@ int run_vjp_lind_midd(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, 
   return 0;
 }
 
+// Gradient for supplied per-slice generators X_n = coef hs[b,n] (branch B of pwc: the result is the cotangent of every X_n) on the
+// on-chip general-generator sweeps (D <= 40): hmeta pre-pass, forward chain kernel in its supplied-generator mode (segment
+// products + slice propagators), general scan, then the small-D / mid-D sweep kernel in its supplied-generator mode.
+// Nothing is assumed about the generators.  Returns 1 when not applicable.
+int run_vjp_xg_general(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, double coef_i, int B, int N, int D,
+                       const double* fr_phase, const cplx* Ubar, cplx* zout, hipStream_t st) {
+  const bool small = D <= kSmallDLimit && c3p_smalld_supported(D);
+  int nig = 0, nj = 0, wd = 0;
+  if (!small && !c3p_midd_geometry(D, &nig, &nj, &wd)) return 1;
+  long S;
+  if (small) {
+    S = pick_segments(B, N, 0, D, false, 4096);
+    if (S < 0) return 1;
+  } else {
+    S = ((D <= 32 ? 1024 : 512) + B - 1) / B;
+    const long smax = N / 8 > 1 ? N / 8 : 1;
+    if (S > smax) S = smax;
+    if (S < 1) S = 1;
+    if (c3p_midd_grad_image_bytes(D) > (size_t)150 * 1024) return 1;
+  }
+  void *mv, *sv, *bv, *av;
+  if (ws_get(w, SL_TABLES, (size_t)B * N * 4 * sizeof(double), &mv)) return -1;
+  const size_t msz = (size_t)D * D * sizeof(cplx);
+  if (ws_get(w, SL_SEG_A, (size_t)B * S * msz, &sv)) return -1;
+  if (ws_get(w, SL_SEG_B, (size_t)B * S * msz, &av)) return -1;
+  if (ws_get(w, SL_OUT1, ((size_t)B * S + 2 * (size_t)B * N) * msz, &bv)) return -1;  // (SL_OUT0 stages gen_bar_out)
+  cplx* pre = (cplx*)bv;
+  cplx* dUs = pre + (size_t)B * S * D * D;
+  cplx* pstore = dUs + (size_t)B * N * D * D;
+  LAUNCH_TRY(c3p_launch_hmeta(hs, hs_bstride, (long)B * N, N, D, coef_r, coef_i, (double*)mv, st));
+  const int Lmax = (int)((N + S - 1) / S);
+  if (small) {
+    SmallArgs a = {};
+    a.hs = hs;
+    a.hs_bstride = hs_bstride;
+    a.meta = (const double*)mv;
+    a.coef_r = coef_r;
+    a.coef_i = coef_i;
+    a.B = B;
+    a.N = N;
+    a.Dm = D;
+    a.S = (int)S;
+    a.Lmax = Lmax;
+    a.mode = C3P_MODE_EXPM;
+    a.seg_out = (cplx*)sv;
+    a.dUs_out = dUs;
+    LAUNCH_TRY(c3p_launch_smalld_chain(a, st));
+  } else {
+    MidArgs a = {};
+    a.hs = hs;
+    a.hs_bstride = hs_bstride;
+    a.meta = (const double*)mv;
+    a.coef_r = coef_r;
+    a.coef_i = coef_i;
+    a.B = B;
+    a.N = N;
+    a.Dm = D;
+    a.S = (int)S;
+    a.Lmax = Lmax;
+    a.mode = C3P_MODE_EXPM;
+    a.seg_out = (cplx*)sv;
+    a.dUs_out = dUs;
+    a.no_t18 = getenv("C3P_NO_T18") ? 1 : 0;
+    a.no_real = 1;
+    LAUNCH_TRY(c3p_launch_midd_chain(a, st));
+  }
+  GradArgs G = {};
+  G.Ubar = Ubar;
+  G.fr_phase = fr_phase;
+  G.B = B;
+  G.N = N;
+  G.D = D;
+  G.ld = D | 1;
+  G.S = (int)S;
+  G.seg = (cplx*)sv;
+  G.Mb = (cplx*)av;
+  G.pre = pre;
+  G.general = 1;
+  LAUNCH_TRY(c3p_launch_grad_scan_general(G, false, st));
+  if (small) {
+    SmallGradArgs g = {};
+    g.Mb = G.Mb;
+    g.pre = pre;
+    g.dUs = dUs;
+    g.pstore = pstore;
+    g.zout = zout;
+    g.hs = hs;
+    g.hs_bstride = hs_bstride;
+    g.meta = (const double*)mv;
+    g.coef_r = coef_r;
+    g.coef_i = coef_i;
+    g.B = B;
+    g.N = N;
+    g.Dm = D;
+    g.S = (int)S;
+    g.Lmax = Lmax;
+    LAUNCH_TRY(c3p_launch_smalld_grad_general(g, st));
+  } else {
+    MidGradArgs g = {};
+    g.Mb = G.Mb;
+    g.pre = pre;
+    g.dUs = dUs;
+    g.pstore = pstore;
+    g.zout = zout;
+    g.hs = hs;
+    g.hs_bstride = hs_bstride;
+    g.meta = (const double*)mv;
+    g.coef_r = coef_r;
+    g.coef_i = coef_i;
+    g.B = B;
+    g.N = N;
+    g.Dm = D;
+    g.S = (int)S;
+    g.Lmax = Lmax;
+    LAUNCH_TRY(c3p_launch_midd_grad_general(g, st));
+  }
+  return 0;
+}
+
 // ---------------------------------------------------------------------------
 // Big-D MFMA path (81 x 81 Lindblad superoperators): 8-wave workgroup per chain, global arena
 // ---------------------------------------------------------------------------
@@ -2170,6 +2289,26 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
       if (sg.in(U_bar, (size_t)B * D * D * cs, &d_ub)) return -1;
       if (fr_phase && sg.in(fr_phase, (size_t)B * D * sizeof(double), &d_ph)) return -1;
       if (sg.out(gen_bar_out, (size_t)B * N * D * D * cs, &d_z)) return -1;
+    }
+    if (D <= 40 && !(flags & C3P_FORCE_GENERIC) && !getenv("C3P_TILED_GRAD")) {
+      // on-chip general-generator sweeps (nothing assumed about the slice Hamiltonians), in chunks of samples that keep the
+      // slice propagators + prefixes (2 N D^2 complex per sample) below 24 GB
+      long Bc = (long)(((size_t)24 << 30) / (2 * (size_t)N * D * D * cs));
+      if (const char* e = getenv("C3P_GRAD_CHUNK")) Bc = atol(e);
+      if (Bc < 1) Bc = 1;
+      int rc = 0;
+      for (long b0 = 0; b0 < B && rc == 0; b0 += Bc) {
+        const int nb = (int)(B - b0 < Bc ? B - b0 : Bc);
+        rc = run_vjp_xg_general(w, (const cplx*)d_h + b0 * h0_bstride, h0_bstride, 0.0, -dt, nb, N, D,
+                                d_ph ? (const double*)d_ph + b0 * D : nullptr, (const cplx*)d_ub + b0 * D * D,
+                                (cplx*)d_z + b0 * (long)N * D * D, st);
+      }
+      if (rc < 0) return -1;
+      if (rc == 0) {
+        g_last_kernel = D <= kSmallDLimit ? C3P_KERNEL_SMALLD : C3P_KERNEL_MFMA;
+        if (flags & C3P_HOST_PTRS) return sg.finish();
+        return 0;
+      }
     }
     g_last_kernel = C3P_KERNEL_MFMA;
     if (run_vjp_tiled(w, 0, (const cplx*)d_h, h0_bstride, nullptr, 0, nullptr, nullptr, dt, B, 0, N, D, D, (const double*)d_ph,

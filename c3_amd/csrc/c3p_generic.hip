@@ -431,16 +431,34 @@ __global__ void __launch_bounds__(64) hmeta_kernel(const cplx* hs, long bstride,
     }
     cs = fmax(cs, sum);
   }
+  double rs = 0;  // largest row sum: ||X - mu||_inf = the 1-norm of X^H (backward sweeps of general generators)
+  for (int i = tid; i < D; i += 64) {
+    double sum = 0;
+    for (int j = 0; j < D; ++j) {
+      const cplx x = h[i * D + j];
+      double vr = cr * x.x - ci * x.y, vi = cr * x.y + ci * x.x;
+      if (i == j) {
+        vr -= mu[0];
+        vi -= mu[1];
+      }
+      sum += hypot(vr, vi);
+    }
+    rs = fmax(rs, sum);
+  }
   rr[tid] = cs;
+  ri[tid] = rs;
   __syncthreads();
   if (tid == 0) {
-    double nrm = 0;
-    for (int i = 0; i < 64; ++i) nrm = fmax(nrm, rr[i]);
+    double nrm = 0, nri = 0;
+    for (int i = 0; i < 64; ++i) {
+      nrm = fmax(nrm, rr[i]);
+      nri = fmax(nri, ri[i]);
+    }
     double* o = meta + m * 4;
     o[0] = mu[0];
     o[1] = mu[1];
     o[2] = nrm;
-    o[3] = 0.0;
+    o[3] = nri;
   }
 }
 
@@ -483,13 +501,26 @@ __global__ void __launch_bounds__(256) hmeta_small_kernel(const cplx* hs, long b
       }
       cs += hypot(v.x, v.y);
     }
-  for (int o = 32; o > 0; o >>= 1) cs = fmax(cs, __shfl_xor(cs, o));
+  double rs = 0.0;  // row sums: ||X - mu||_inf = the 1-norm of X^H
+  if (lane < D)
+    for (int j = 0; j < D; ++j) {
+      cplx v = stage[w][lane * D + j];
+      if (j == lane) {
+        v.x -= mur;
+        v.y -= mui;
+      }
+      rs += hypot(v.x, v.y);
+    }
+  for (int o = 32; o > 0; o >>= 1) {
+    cs = fmax(cs, __shfl_xor(cs, o));
+    rs = fmax(rs, __shfl_xor(rs, o));
+  }
   if (lane == 0) {
     double* o4 = meta + m * 4;
     o4[0] = mur;
     o4[1] = mui;
     o4[2] = cs;
-    o4[3] = 0.0;
+    o4[3] = rs;
   }
 }
 

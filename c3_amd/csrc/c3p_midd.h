@@ -38,6 +38,11 @@ struct MidGradArgs {
   const cplx* pre;         // [B,S,Dm,Dm] prefix product at the START of each segment; Mb = LEFT adjoint at its end
   const cplx* dUs;         // [B,N,Dm,Dm] slice propagators of the forward pass
   cplx* pstore;            // [B,N,Dm,Dm] scratch: prefix product in front of every slice
+  // supplied generators (X_n = coef hs[b,n], as MidArgs): no tables, no signals; the result is zout[b,n] = the cotangent of X_n
+  const cplx* hs;
+  long hs_bstride;
+  const double* meta;
+  double coef_r, coef_i;
 };
 
 struct MidPrepArgs {

@@ -1601,18 +1601,18 @@ __global__ void __launch_bounds__(256, 1) midd_grad_kernel(MidGradArgs A) {
 // propagators of the forward pass (P <- dU_n P, every P_n stored), then backwards: M_n = A P_n^H, pair evaluation of T18 at
 // Y = X_n^H (tables of G^H), grad[k] = Re(conj(e^{shift}) <dT, G_k>), A <- T A; the trace shifts ride along as one scalar.
 // ---------------------------------------------------------------------------------------------
-template <int NIG, int NJ, int W, int WV>
+template <int NIG, int NJ, int W, int WV, bool XG>
 __device__ __forceinline__ void midd_grad_general_body(const MidGradArgs& A, const MidCommon& cm, long chain, double* i0,
                                                        double* i1, double* i2, double* i3, double* red) {
   using T = WaveTiles<NIG, NJ, W, WV>;
   constexpr int IMG = MD<NIG, NJ>::ROWS * W, NE = T::NE;
   typedef TileRegs<T::NBW, T::NSW> Regs;
-  const int D = cm.D, K = cm.K;
+  const int D = cm.D, K = XG ? 0 : cm.K;
   const int lbig = cm.lbig, lsmall = cm.lsmall;
   const int rbig = cm.r, rsmall = 4 * cm.b + cm.r;
   const int cbig = 4 * cm.b + cm.c, csmall = cm.c;
   const double* tabs = cm.tabs;                                                                    // G^H: the exponent
-  const double* tabg = A.tables + (long)(A.tab_per_sample ? cm.sample : 0) * (1 + K) * (IMG + 4);  // G: inner products
+  const double* tabg = XG ? nullptr : A.tables + (long)(A.tab_per_sample ? cm.sample : 0) * (1 + K) * (IMG + 4);  // G: inner products
   auto eoff = [&](int e) -> int { return T::off0(e) + (T::is_big(e) ? lbig : lsmall); };
   auto erow = [&](int e) -> int { return T::row0(e) + (T::is_big(e) ? rbig : rsmall); };
   auto ecol = [&](int e) -> int { return T::col0(e) + (T::is_big(e) ? cbig : csmall); };
@@ -1709,9 +1709,29 @@ __device__ __forceinline__ void midd_grad_general_body(const MidGradArgs& A, con
 #pragma unroll
       for (int e = 0; e < NE; ++e) dX.set(e, cm.scale * Mn.get(e));
     }
-    double mu_r = tabs[IMG + 0], mu_i = tabs[IMG + 1];  // trace shift of Y = X_n^H
+    double mu_r, mu_i;  // trace shift of Y = X_n^H
+    if constexpr (XG) {
+      // supplied generator: Y = conj(coef) hs[b,n]^H - conj(mu_n); element (ci, col) = conj(coef hs[col][ci])
+      const long m = (long)cm.sample * A.N + cm.n0 + t;
+      mu_r = A.meta[m * 4 + 0];
+      mu_i = -A.meta[m * 4 + 1];
+      const double2* src = reinterpret_cast<const double2*>(A.hs) + (long)cm.sample * A.hs_bstride + (long)(cm.n0 + t) * D * D;
 #pragma unroll
-    for (int e = 0; e < NE; ++e) X.set(e, cm.scale * tabs[eoff(e)]);
+      for (int e = 0; e < NE; ++e) {
+        const int row = erow(e), col = ecol(e);
+        const int ci = row >> 1;
+        const bool in = ci < D && col < D;
+        const double2 h = src[in ? col * D + ci : 0];
+        double v = (row & 1) ? -fma(A.coef_r, h.y, A.coef_i * h.x) : fma(A.coef_r, h.x, -A.coef_i * h.y);
+        v -= (ci == col) ? ((row & 1) ? mu_i : mu_r) : 0.0;
+        X.set(e, in ? cm.scale * v : 0.0);
+      }
+    } else {
+      mu_r = tabs[IMG + 0];
+      mu_i = tabs[IMG + 1];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) X.set(e, cm.scale * tabs[eoff(e)]);
+    }
     for (int k = 0; k < K; ++k) {
       const double c0 = cm.sg[k * A.Lmax + t];
       const double ck = cm.scale * c0;
@@ -1808,6 +1828,17 @@ __device__ __forceinline__ void midd_grad_general_body(const MidGradArgs& A, con
       sincos(ams_i + mu_i, &sn, &cs);
       const double er = exp(ams_r + mu_r);
       const double pr = er * cs, pi = er * sn;
+      if (A.zout != nullptr) {  // Z_n = e^{shift} dT, the cotangent of the generator X_n (Re / Im rows of an element: lanes l, l ^ 16)
+        double* dst = reinterpret_cast<double*>(A.zout) + ((long)cm.sample * A.N + cm.n0 + t) * D * D * 2;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const int row = erow(e), col = ecol(e);
+          const int ci = row >> 1;
+          const double mine = dT.get(e), other = __shfl_xor(mine, 16);
+          const double outv = (row & 1) ? fma(pr, mine, pi * other) : fma(pr, mine, -pi * other);
+          if (ci < D && col < D) dst[(ci * D + col) * 2 + (row & 1)] = outv;
+        }
+      }
       double trr = 0.0, tri = 0.0;
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
@@ -1858,7 +1889,7 @@ __device__ __forceinline__ void midd_grad_general_body(const MidGradArgs& A, con
   }
 }
 
-template <int NIG, int NJ, int W>
+template <int NIG, int NJ, int W, bool XG>
 __global__ void __launch_bounds__(256, 1) midd_grad_general_kernel(MidGradArgs A) {
   using C = MD<NIG, NJ>;
   constexpr int IMG = C::ROWS * W;
@@ -1871,8 +1902,8 @@ __global__ void __launch_bounds__(256, 1) midd_grad_general_kernel(MidGradArgs A
   cm.c = cm.lane & 3;
   cm.D = A.Dm;
   cm.nbk = (2 * cm.D + 3) / 4;
-  cm.K = A.K;
-  const int K = A.K;
+  cm.K = XG ? 0 : A.K;
+  const int K = cm.K;
   double* i0 = c3p_md_lds;
   double* i1 = i0 + IMG;
   double* i2 = i1 + IMG;
@@ -1893,8 +1924,21 @@ __global__ void __launch_bounds__(256, 1) midd_grad_general_kernel(MidGradArgs A
   cm.negmask = (((cm.c & 1) == 0) && ((cm.r & 1) == 1)) ? 0x80000000u : 0u;
   for (int e = tid; e < 4 * IMG; e += 256) c3p_md_lds[e] = 0.0;
   __syncthreads();
-  cm.tabs = A.tables_h + (long)(A.tab_per_sample ? cm.sample : 0) * (1 + K) * (IMG + 4);  // the matrix exponentiated is X^H
-  double nrm = cm.tabs[IMG + 2];
+  double nrm = 0.0;
+  if constexpr (XG) {
+    // supplied generators: the 1-norm of X_n^H is the row-sum norm of X_n (slot 3 of the hmeta pass)
+    cm.tabs = nullptr;
+    const double* mt = A.meta + ((long)cm.sample * A.N + cm.n0) * 4;
+    for (int t = tid; t < cm.len; t += 256) nrm = fmax(nrm, mt[(long)t * 4 + 3]);
+    for (int o = 32; o >= 1; o >>= 1) nrm = fmax(nrm, __shfl_xor(nrm, o));
+    if (cm.lane == 0) redn[wave] = nrm;
+    __syncthreads();
+    nrm = fmax(fmax(redn[0], redn[1]), fmax(redn[2], redn[3]));
+    __syncthreads();
+  } else {
+    cm.tabs = A.tables_h + (long)(A.tab_per_sample ? cm.sample : 0) * (1 + K) * (IMG + 4);  // the matrix exponentiated is X^H
+    nrm = cm.tabs[IMG + 2];
+  }
   for (int k = 0; k < K; ++k) {
     const double* s = A.signals + ((long)cm.sample * K + k) * A.N + cm.n0;
     double cmax = 0.0;
@@ -1928,10 +1972,10 @@ __global__ void __launch_bounds__(256, 1) midd_grad_general_kernel(MidGradArgs A
   cm.buf2 = i2;
   __syncthreads();
   switch (wave) {
-    case 0: midd_grad_general_body<NIG, NJ, W, 0>(A, cm, chain, i0, i1, i2, i3, red); break;
-    case 1: midd_grad_general_body<NIG, NJ, W, 1>(A, cm, chain, i0, i1, i2, i3, red); break;
-    case 2: midd_grad_general_body<NIG, NJ, W, 2>(A, cm, chain, i0, i1, i2, i3, red); break;
-    default: midd_grad_general_body<NIG, NJ, W, 3>(A, cm, chain, i0, i1, i2, i3, red); break;
+    case 0: midd_grad_general_body<NIG, NJ, W, 0, XG>(A, cm, chain, i0, i1, i2, i3, red); break;
+    case 1: midd_grad_general_body<NIG, NJ, W, 1, XG>(A, cm, chain, i0, i1, i2, i3, red); break;
+    case 2: midd_grad_general_body<NIG, NJ, W, 2, XG>(A, cm, chain, i0, i1, i2, i3, red); break;
+    default: midd_grad_general_body<NIG, NJ, W, 3, XG>(A, cm, chain, i0, i1, i2, i3, red); break;
   }
 }
 
@@ -2514,18 +2558,22 @@ hipError_t launch_grad_t(const MidGradArgs& A, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int NIG, int NJ, int W>
-hipError_t launch_grad_general_t(const MidGradArgs& A, hipStream_t st) {
+template <int NIG, int NJ, int W, bool XG>
+hipError_t launch_grad_general_x(const MidGradArgs& A, hipStream_t st) {
   constexpr int IMG = MD<NIG, NJ>::ROWS * W;
-  const size_t lds = (size_t)(4 * IMG + A.K * A.Lmax) * sizeof(double);
+  const size_t lds = (size_t)(4 * IMG + (XG ? 0 : A.K) * A.Lmax) * sizeof(double);
   if (lds > 158 * 1024) return hipErrorInvalidValue;
-  auto kern = midd_grad_general_kernel<NIG, NJ, W>;
+  auto kern = midd_grad_general_kernel<NIG, NJ, W, XG>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)((long)A.B * A.S)), dim3(256), lds, st, A);
   return hipGetLastError();
+}
+template <int NIG, int NJ, int W>
+hipError_t launch_grad_general_t(const MidGradArgs& A, hipStream_t st) {
+  return A.hs != nullptr ? launch_grad_general_x<NIG, NJ, W, true>(A, st) : launch_grad_general_x<NIG, NJ, W, false>(A, st);
 }
 
 // *launched = false (and hipSuccess) when the real sweep does not apply: more control lines than the kernel keeps in
@@ -2638,13 +2686,16 @@ hipError_t launch_grad_real(const MidGradArgs& A, int nig, int nj, hipStream_t s
 }
 }  // namespace
 
-// (the classes of the Lindblad superoperators of D = 4, 5, 6 only: 16 x 16, 25 x 25, 36 x 36)
 hipError_t c3p_launch_midd_grad_general(const MidGradArgs& A, hipStream_t st) {
   int nig, nj, w;
   if (!c3p_midd_geometry(A.Dm, &nig, &nj, &w)) return hipErrorInvalidValue;
   if (nig == 2 && nj == 4) return launch_grad_general_t<2, 4, 17>(A, st);
+  if (nig == 3 && nj == 5) return launch_grad_general_t<3, 5, 21>(A, st);
+  if (nig == 3 && nj == 6) return launch_grad_general_t<3, 6, 25>(A, st);
   if (nig == 4 && nj == 7) return launch_grad_general_t<4, 7, 29>(A, st);
+  if (nig == 4 && nj == 8) return launch_grad_general_t<4, 8, 33>(A, st);
   if (nig == 5 && nj == 9) return launch_grad_general_t<5, 9, 37>(A, st);
+  if (nig == 5 && nj == 10) return launch_grad_general_t<5, 10, 41>(A, st);
   return hipErrorInvalidValue;
 }
 

@@ -19,7 +19,7 @@ struct SmallArgs {
   // C3P_MODE_EXPM (generators supplied per slice: X_n = coef hs[b,n], shifted by meta's mu_n)
   const cplx* hs;          // [B,N,Dm,Dm] or [N,Dm,Dm] (hs_bstride 0)
   long hs_bstride;         // complex elements between samples
-  const double* meta;      // [B*N][4] = {Re mu, Im mu, ||X - mu||_1, 0} from c3p_launch_hmeta
+  const double* meta;      // [B*N][4] = {Re mu, Im mu, ||X - mu||_1, ||X - mu||_inf} from c3p_launch_hmeta
   double coef_r, coef_i;   // -i dt -> (0, -dt); 1 for c3p_expm
   const double* fr_phase;  // [B,Dm] or null
   int B, K, N, Dm;
@@ -56,6 +56,11 @@ struct SmallGradArgs {
   const cplx* pre;         // [B,S,Dm,Dm] prefix product at the START of each segment; Mb = LEFT adjoint at its end
   const cplx* dUs;         // [B,N,Dm,Dm] slice propagators of the forward pass
   cplx* pstore;            // [B,N,Dm,Dm] scratch: prefix product in front of every slice
+  // supplied generators (X_n = coef hs[b,n], as SmallArgs): no tables, no signals; the result is zout[b,n] = the cotangent of X_n
+  const cplx* hs;
+  long hs_bstride;
+  const double* meta;
+  double coef_r, coef_i;
 };
 
 struct PrepArgs {

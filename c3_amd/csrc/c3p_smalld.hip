@@ -1685,7 +1685,7 @@ __global__ void __launch_bounds__(64, 1) smalld_grad_kernel(SmallGradArgs A) {
 // exp(Y) = dU_n^H advances A, the derivative L(Y; M_n) is the generator's cotangent.  The trace shifts do not cancel here: A and
 // the derivative carry them as ONE complex scalar per chain, applied to the complex inner product <dT, G_k> at the end.
 // ---------------------------------------------------------------------------------------------
-template <int D>
+template <int D, bool XG = false>
 __global__ void __launch_bounds__(64, 1) smalld_grad_general_kernel(SmallGradArgs A) {
   using C = SD<D>;
   constexpr int NBI = C::NBI, NJ = C::NJ, W = C::W, MAT = C::MAT;
@@ -1696,7 +1696,7 @@ __global__ void __launch_bounds__(64, 1) smalld_grad_general_kernel(SmallGradArg
   lp.b = (lane >> 2) & 3;
   lp.c = lane & 3;
   lp.idx16 = lp.r * 4 + lp.c;
-  const int K = A.K;
+  const int K = XG ? 0 : A.K;
   double* tab = c3p_sd_lds;                 // G tables: inner products
   double* tabh = tab + (1 + K) * (MAT + 4);  // G^H tables: the matrix that is exponentiated
   double* img0 = tabh + (1 + K) * (MAT + 4);
@@ -1722,14 +1722,26 @@ __global__ void __launch_bounds__(64, 1) smalld_grad_general_kernel(SmallGradArg
   const int rhalf = lp.r >> 1;
 
   const long tsz = (long)(1 + K) * (MAT + 4);
-  const double* gt0 = A.tables + (long)(A.tab_per_sample ? sample : 0) * tsz;
-  const double* gh0 = A.tables_h + (long)(A.tab_per_sample ? sample : 0) * tsz;
-  for (int e = lane; e < (int)tsz; e += 64) {
-    tab[e] = gt0[e];
-    tabh[e] = gh0[e];
+  double nrm = 0.0;
+  if constexpr (XG) {
+    // supplied generators: the matrix exponentiated is X_n^H, whose 1-norm is the row-sum norm of X_n (slot 3 of the hmeta pass)
+    const double* mt = A.meta + ((long)sample * A.N + n0) * 4;
+    for (int t = lp.idx16; t < A.Lmax; t += 16)
+      if (valid && t < len) nrm = fmax(nrm, mt[(long)t * 4 + 3]);
+    nrm = fmax(nrm, __shfl_xor(nrm, 1));
+    nrm = fmax(nrm, __shfl_xor(nrm, 2));
+    nrm = fmax(nrm, __shfl_xor(nrm, 16));
+    nrm = fmax(nrm, __shfl_xor(nrm, 32));
+  } else {
+    const double* gt0 = A.tables + (long)(A.tab_per_sample ? sample : 0) * tsz;
+    const double* gh0 = A.tables_h + (long)(A.tab_per_sample ? sample : 0) * tsz;
+    for (int e = lane; e < (int)tsz; e += 64) {
+      tab[e] = gt0[e];
+      tabh[e] = gh0[e];
+    }
+    __syncthreads();
+    nrm = tabh[MAT + 2];
   }
-  __syncthreads();
-  double nrm = tabh[MAT + 2];
   for (int k = 0; k < K; ++k) {
     const double* s = A.signals + ((long)sample * K + k) * A.N + n0;
     double cmax = 0.0;
@@ -1829,11 +1841,34 @@ __global__ void __launch_bounds__(64, 1) smalld_grad_general_kernel(SmallGradArg
 #pragma unroll
         for (int J = 0; J < NJ; ++J) dX[I][J] = scale * Mn[I][J];
     }
-    double mu_r = act ? tabh[MAT + 0] : 0.0, mu_i = act ? tabh[MAT + 1] : 0.0;  // trace shift of Y = X_n^H
+    double mu_r = 0.0, mu_i = 0.0;  // trace shift of Y = X_n^H
+    if constexpr (XG) {
+      // Y = conj(coef) hs[b,n]^H - conj(mu_n): element (row, col) = conj(coef hs[col][row])
+      const long m = (long)sample * A.N + n0 + (act ? t : 0);
+      mu_r = act ? A.meta[m * 4 + 0] : 0.0;
+      mu_i = act ? -A.meta[m * 4 + 1] : 0.0;
+      const double2* src = reinterpret_cast<const double2*>(A.hs) + (long)sample * A.hs_bstride + (long)(n0 + (act ? t : 0)) * D * D;
+      const double mine = (lp.r & 1) ? mu_i : mu_r;
+#pragma unroll
+      for (int I = 0; I < NBI; ++I)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) {
+          const int row = 2 * I + (lp.r >> 1), col = 4 * J + lp.c;
+          const bool in = row < D && col < D;
+          const double2 h = src[in ? col * D + row : 0];
+          // coef h = (cr hx - ci hy) + i (cr hy + ci hx); conjugated for the transpose
+          double v = (lp.r & 1) ? -fma(A.coef_r, h.y, A.coef_i * h.x) : fma(A.coef_r, h.x, -A.coef_i * h.y);
+          v -= (row == col) ? mine : 0.0;
+          X[I][J] = in ? sc * v : 0.0;
+        }
+    } else {
+    mu_r = act ? tabh[MAT + 0] : 0.0;
+    mu_i = act ? tabh[MAT + 1] : 0.0;
 #pragma unroll
     for (int I = 0; I < NBI; ++I)
 #pragma unroll
       for (int J = 0; J < NJ; ++J) X[I][J] = sc * tabh[toff + I * 4 * W + J * 4];
+    }
     for (int k = 0; k < K; ++k) {
       const double c0 = sg[(lp.b * K + k) * A.Lmax + t];  // zero for inactive slices
       const double ck = sc * c0;
@@ -1920,6 +1955,10 @@ __global__ void __launch_bounds__(64, 1) smalld_grad_general_kernel(SmallGradArg
       sincos(ams_i + mu_i, &sn, &cs);
       const double er = exp(ams_r + mu_r);
       const double pr = er * cs, pi = er * sn;
+      if (A.zout != nullptr) {  // Z_n = e^{shift} dT: the cotangent of the generator X_n
+        double* dst = reinterpret_cast<double*>(A.zout) + ((long)sample * A.N + n0 + (act ? t : 0)) * D * D * 2;
+        store_plain<D>(dT, dst, pr, pi, nullptr, lp, act);
+      }
       double trr = 0.0, tri = 0.0;
 #pragma unroll
       for (int I = 0; I < NBI; ++I)
@@ -2392,7 +2431,10 @@ hipError_t launch_grad_general_t(const SmallGradArgs& A, hipStream_t st) {
   const unsigned grid = (unsigned)((nchains + 3) / 4);
   const size_t lds = (size_t)(2 * (1 + A.K) * (C::MAT + 4) + 8 * C::MAT + 4 * A.K * A.Lmax) * sizeof(double);
   if (lds > 60 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(smalld_grad_general_kernel<D>, dim3(grid), dim3(64), lds, st, A);
+  if (A.hs != nullptr)
+    hipLaunchKernelGGL((smalld_grad_general_kernel<D, true>), dim3(grid), dim3(64), lds, st, A);
+  else
+    hipLaunchKernelGGL((smalld_grad_general_kernel<D, false>), dim3(grid), dim3(64), lds, st, A);
   return hipGetLastError();
 }
 

@@ -183,7 +183,8 @@ int c3p_rk4_unitary(const void* h0, const void* hks, const double* signals, cons
  * With C3P_PER_SLICE_H (branch B of pwc, propagation.py:295-308): h0 = the per-slice Hamiltonians [N,D,D] (h0_bstride 0) or
  *   [B,N,D,D], hks / signals / grad_signals NULL, K = 0, and gen_bar_out [B,N,D,D] (required) receives the cotangent of every
  *   slice generator G_n = -i dt H_n, i.e. d loss / d H_n = i dt Z[b,n]: what the tape hands back to model.get_Hamiltonian.
- *   Any dimension (tiled backward sweep).
+ *   Any dimension: on-chip general-generator sweeps up to D = 40 (nothing assumed about the Hamiltonians), the tiled
+ *   backward sweep above.
  */
 int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride,
                         const double* signals, double dt, int B, int K, int N, int D, int flags,

@@ -504,7 +504,8 @@ def test_oracle_per_slice_cotangents_match_finite_differences():
 @pytest.mark.gpu
 @pytest.mark.parametrize("D,N,B", [(3, 11, 2), (9, 8, 3), (24, 6, 2), (50, 4, 1)])
 def test_per_slice_vjp_vs_oracle(prop, D, N, B):
-    """c3p_pwc_unitary_vjp with C3P_PER_SLICE_H (branch B): cotangents of the per-slice Hamiltonians on the tiled sweep."""
+    """c3p_pwc_unitary_vjp with C3P_PER_SLICE_H (branch B): cotangents of the per-slice Hamiltonians (on-chip general-generator
+    sweeps up to D = 40, the tiled sweep above)."""
     rng = np.random.default_rng(D + N)
     herm = lambda s: (lambda a: s * (a + a.conj().T) / 2)(rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))
     Hs = np.stack([np.stack([herm(0.6 / np.sqrt(D)) for _ in range(N)]) for _ in range(B)])
@@ -512,6 +513,44 @@ def test_per_slice_vjp_vs_oracle(prop, D, N, B):
     ph = rng.uniform(0, 2 * np.pi, size=(B, D))
     dt = 1.3
     got = np.asarray(prop.propagate_per_slice_vjp(Hs, dt, Ubar, fr_phase=ph))
+    for b in range(B):
+        want = o.pwc_per_slice_hamiltonian_cotangents(Hs[b], dt, Ubar[b], ph[b])
+        assert np.abs(got[b] - want).max() < 1e-10 * np.abs(want).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,N,B,hermitian", [(2, 90, 3, True), (5, 70, 2, False), (12, 40, 2, True), (13, 33, 2, False), (20, 26, 1, True),
+                                             (24, 20, 2, True), (27, 64, 2, True), (32, 18, 1, False), (36, 17, 1, True), (40, 16, 1, True)])
+def test_per_slice_vjp_on_chip_sweeps(prop, D, N, B, hermitian):
+    """Branch B on the on-chip general-generator sweeps: every small-D dimension class and every mid-D geometry class, several
+    time segments, Hermitian and NON-Hermitian slice Hamiltonians (nothing is assumed about them: the squaring plan of the
+    backward pass uses the row-sum norm of X_n, i.e. the 1-norm of the X_n^H it exponentiates), frame phases -- against the
+    FD-pinned oracle and against the tiled sweep on the same inputs."""
+    from c3_amd import _lib
+
+    rng = np.random.default_rng(7 * D + N)
+    def mat(s):
+        a = rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))
+        h = s * (a + a.conj().T) / 2
+        if hermitian:
+            return h
+        # a lossy effective Hamiltonian H - i Gamma (Gamma >= 0: the chain decays instead of blowing up) plus a non-normal
+        # part with very different row and column sums
+        g = rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))
+        up = np.triu(rng.normal(size=(D, D)), 1) * (1.0 + np.arange(D)[:, None]) / D
+        return h - 1j * 0.3 * s * (g @ g.conj().T) / D + 0.5 * s * up
+    Hs = np.stack([np.stack([mat(0.5 / np.sqrt(D)) for _ in range(N)]) for _ in range(B)])
+    Ubar = rng.normal(size=(B, D, D)) + 1j * rng.normal(size=(B, D, D))
+    ph = rng.uniform(0, 2 * np.pi, size=(B, D))
+    dt = 1.1
+    got = np.asarray(prop.propagate_per_slice_vjp(Hs, dt, Ubar, fr_phase=ph))
+    assert _lib.last_kernel() == ("smalld" if D <= 12 else "mfma")
+    os.environ["C3P_TILED_GRAD"] = "1"
+    try:
+        tiled = np.asarray(prop.propagate_per_slice_vjp(Hs, dt, Ubar, fr_phase=ph))
+    finally:
+        os.environ.pop("C3P_TILED_GRAD")
+    assert np.abs(got - tiled).max() < 1e-10 * np.abs(tiled).max()
     for b in range(B):
         want = o.pwc_per_slice_hamiltonian_cotangents(Hs[b], dt, Ubar[b], ph[b])
         assert np.abs(got[b] - want).max() < 1e-10 * np.abs(want).max()

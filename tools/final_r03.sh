@@ -77,6 +77,7 @@ python tools/bench_grad_tiled.py --out $O/grad_tiled.json > /dev/null 2>&1
 # Lindblad gradients at D <= 6: matrix-core general-generator sweeps, and the VALU form of the same sweep beside them
 python tools/bench_grad_lindblad.py --cases 2:256:1000,3:256:1000,3:16:1000,3:1024:1000,4:256:1000,4:64:1000,5:64:500,6:64:500 --out $O/grad_lindblad_small_mfma.json > /dev/null 2>&1
 C3P_VALU_GRAD=1 python tools/bench_grad_lindblad.py --out $O/grad_lindblad_small.json > /dev/null 2>&1
+python tools/bench_grad_per_slice.py --out $O/grad_per_slice.json > /dev/null 2>&1
 python tests/checks/check_tiled.py --time > $O/tiled_check.txt 2>&1
 python tools/bench_midd_real_vs_complex.py > $O/midd_real_vs_complex.json 2> /dev/null
 python tests/perf/bench_complex_path.py > $O/complex_path_cfg2.json 2> /dev/null
