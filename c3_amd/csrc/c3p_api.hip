@@ -1435,6 +1435,20 @@ int pwc_common(int lindblad, const void* h0, int64_t h0_bstride, const void* hks
     if (rc < 0) return -1;
     done = (rc == 0);
   }
+  if (!done && !(flags & C3P_FORCE_GENERIC) && per_slice && lindblad && K == 0 && Dm <= 40 &&
+      (size_t)B * N * Dm * Dm * cs <= ((size_t)16 << 30)) {
+    // branch B with model.lindbladian (propagation.py:295-308 into :551-585): the dense superoperator generator of every slice,
+    // then the supplied-generator mode of the matrix-core chain kernels with X_n = dt L_n
+    void* gv;
+    if (ws_get(w, SL_SCRATCH, (size_t)B * N * Dm * Dm * cs, &gv)) return -1;
+    LAUNCH_TRY(c3p_launch_lind_slice_generators(a.h0, a.h0_bstride, a.clp, B, N, D, (cplx*)gv, st));
+    const long gbs = (long)N * Dm * Dm;
+    const int rc = (Dm <= kSmallDLimit && c3p_smalld_supported(Dm))
+                       ? run_xg_smalld(w, (const cplx*)gv, gbs, dt, 0.0, B, N, Dm, a.fr_phase, (cplx*)d_U, a.dUs_out, st)
+                       : run_xg_midd(w, (const cplx*)gv, gbs, dt, 0.0, B, N, Dm, a.fr_phase, (cplx*)d_U, a.dUs_out, st);
+    if (rc < 0) return -1;
+    done = (rc == 0);
+  }
   if (!done && !(flags & C3P_FORCE_GENERIC) && !per_slice && Dm <= kSmallDLimit && c3p_smalld_supported(Dm) && K <= 8) {
     const int rc = run_pwc_smalld(w, lindblad, a.h0, a.h0_bstride, a.hks, a.hks_bstride, a.signals, a.clp, dt,
                                   B, K, N, D, Dm, a.fr_phase, (cplx*)d_U, a.dUs_out, st);

@@ -40,5 +40,7 @@ hipError_t c3p_launch_grad_scan_general(const GradArgs& A, bool global_scratch, 
 hipError_t c3p_launch_grad_bwd_general(const GradArgs& A, bool global_scratch, hipStream_t st);
 // dense Lindblad generators [nb][(K+1)][D^2 x D^2]: G_0 = -i (spre(h0) - spost(h0)) + clp, G_k = -i (spre(hk) - spost(hk))
 // (propagation.py:551-582); nb = B when an operator stride is non-zero, else 1
+// per-slice variant: out[b,n] = -i (spre(hs[b,n]) - spost(hs[b,n])) + clp for every slice Hamiltonian (branch B + lindbladian)
+hipError_t c3p_launch_lind_slice_generators(const cplx* hs, long hs_bstride, const cplx* clp, int B, int N, int D, cplx* out, hipStream_t st);
 hipError_t c3p_launch_lind_generators(const cplx* h0, long h0_bstride, const cplx* hks, long hks_bstride, const cplx* clp, int nb,
                                       int K, int D, cplx* out, hipStream_t st);

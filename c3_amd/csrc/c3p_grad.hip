@@ -643,6 +643,30 @@ __global__ void lind_gen_kernel(const cplx* h0, long h0_bs, const cplx* hks, lon
   out[((long)b * (K + 1) + which) * Dm * Dm + e] = v;
 }
 
+// dense superoperator generator of every slice Hamiltonian (no dt): row (i,j), column (k,l)
+__global__ void lind_slice_gen_kernel(const cplx* hs, long hs_bs, const cplx* clp, int N, int D, cplx* out) {
+  const int Dm = D * D;
+  const long e = (long)blockIdx.y * blockDim.x + threadIdx.x;
+  if (e >= (long)Dm * Dm) return;
+  const long m = blockIdx.x;  // b N + n
+  const long b = m / N, n = m - b * N;
+  const cplx* H = hs + b * hs_bs + n * (long)D * D;
+  const int r = (int)(e / Dm), c = (int)(e - (long)r * Dm);
+  const int i = r / D, j = r - i * D, k = c / D, l = c - k * D;
+  cplx v = clp[e];
+  if (j == l) {
+    const cplx h = H[i * D + k];
+    v.x += h.y;
+    v.y -= h.x;
+  }
+  if (i == k) {
+    const cplx h = H[l * D + j];
+    v.x -= h.y;
+    v.y += h.x;
+  }
+  out[m * Dm * Dm + e] = v;
+}
+
 }  // namespace
 
 int c3p_grad_threads(int D) { return D <= 10 ? 64 : (D <= 20 ? 128 : 256); }
@@ -728,5 +752,12 @@ hipError_t c3p_launch_lind_generators(const cplx* h0, long h0_bstride, const cpl
   const long nel = (long)D * D * D * D;
   hipLaunchKernelGGL(lind_gen_kernel, dim3((unsigned)((nel + 255) / 256), (unsigned)nb, (unsigned)(K + 1)), dim3(256), 0, st, h0, h0_bstride,
                      hks, hks_bstride, clp, K, D, out);
+  return hipGetLastError();
+}
+
+hipError_t c3p_launch_lind_slice_generators(const cplx* hs, long hs_bstride, const cplx* clp, int B, int N, int D, cplx* out, hipStream_t st) {
+  const long nel = (long)D * D * D * D;
+  hipLaunchKernelGGL(lind_slice_gen_kernel, dim3((unsigned)((long)B * N), (unsigned)((nel + 255) / 256)), dim3(256), 0, st, hs, hs_bstride, clp, N,
+                     D, out);
   return hipGetLastError();
 }

@@ -755,3 +755,23 @@ def test_rk4_unitary_mid_dimension_time_segments(prop, D, B, Ns):
         ref = o.rk4_unitary_arrays(Hs, 0.02, D)
         assert np.abs(res[None][0][b] - ref["U"]).max() < 1e-12
         assert np.abs(res[None][1][b] - ref["dUs"]).max() < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,N,B", [(2, 50, 3), (3, 40, 2), (4, 21, 2), (5, 12, 1), (6, 9, 2)])
+def test_lindblad_with_per_slice_hamiltonians_on_matrix_cores(prop, D, N, B):
+    """Branch B together with model.lindbladian (propagation.py:295-308 into :551-585): the superoperator generator of every
+    slice Hamiltonian is formed densely and propagated by the supplied-generator mode of the matrix-core chain kernels (before:
+    the generic LDS kernel); U and the per-slice propagators against the oracle, per-sample Hamiltonians."""
+    from c3_amd import _lib
+
+    rng = np.random.default_rng(31 * D + N)
+    H = np.stack([np.stack([_rand_herm(rng, D, 0.4) for _ in range(N)]) for _ in range(B)])
+    col = np.stack([0.15 * (rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))) for _ in range(2)])
+    r = prop.propagate_batch(H, None, None, 0.7, col_ops=col, lindbladian=True, want_dUs=True)
+    assert _lib.last_kernel() == ("smalld" if D * D <= 12 else "mfma")
+    U, dUs = np.asarray(r["U"]), np.asarray(r["dUs"])
+    for b in range(B):
+        ref = o.pwc_arrays(H[b], None, None, 0.7, col_ops=col, lindbladian=True)
+        assert np.linalg.norm(U[b] - ref["U"]) < TOL
+        assert np.abs(dUs[b] - ref["dUs"]).max() < 1e-12
