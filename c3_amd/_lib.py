@@ -35,6 +35,8 @@ SIGNATURES = {
     "c3p_last_error": (C.c_char_p, []),
     "c3p_last_kernel": (_i, []),
     "c3p_set_profiling": (_i, [_i]),
+    "c3p_set_option": (_i, [C.c_char_p, C.c_char_p]),
+    "c3p_get_option": (C.c_long, [C.c_char_p]),
     "c3p_reserve": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "c3p_workspace_generation": (C.c_long, []),
     "c3p_last_kernel_ms": (_d, []),
@@ -100,3 +102,35 @@ def require_gpu() -> None:
 
 def last_kernel() -> str:
     return KERNEL_NAMES.get(load().c3p_last_kernel(), "?")
+
+
+def set_option(name: str, value) -> None:
+    """c3p_set_option: `value` an int, "all", or None (back to the default)."""
+    check(load().c3p_set_option(name.encode(), None if value is None else str(value).encode()))
+
+
+def get_option(name: str) -> int:
+    return int(load().c3p_get_option(name.encode()))
+
+
+class options:
+    """Context manager for A/B switches of the library's option table (include/c3prop.h: c3p_set_option):
+
+        with _lib.options(no_regd=1): ...
+
+    restores the previous values on exit."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+        self.old = {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, None if v < 0 else v)
+        return False

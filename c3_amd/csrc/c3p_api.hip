@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstring>
 #include <cstdlib>
+#include <cctype>
 
 #include "../../include/c3prop.h"
 #include "c3p_kernels.h"
@@ -28,6 +29,34 @@ thread_local std::string g_err;
 thread_local int g_last_kernel = C3P_KERNEL_NONE;
 thread_local hipStream_t g_call_stream = nullptr;  // stream of the call in flight (capture check on workspace growth)
 thread_local bool g_dry = false;  // c3p_reserve: run the planning and size the workspace, launch nothing
+
+// ---- the options table (c3p_kernels.h) ----
+const char* const g_opt_names[C3P_OPT_COUNT] = {
+#define C3P_OPT_NAME(n) #n,
+    C3P_OPTION_LIST(C3P_OPT_NAME)
+#undef C3P_OPT_NAME
+};
+std::atomic<long> g_opt_val[C3P_OPT_COUNT];
+std::once_flag g_opt_once;
+
+long parse_opt_value(const char* v) {
+  if (!v || !*v) return 1;  // NAME= : a switch that is set
+  char* end = nullptr;
+  const long x = strtol(v, &end, 10);
+  if (end != v && *end == 0) return x;
+  if (!strcmp(v, "all")) return 2;
+  if (!strcmp(v, "unset") || !strcmp(v, "default")) return -1;
+  return 1;
+}
+
+void opt_init() {
+  for (int i = 0; i < C3P_OPT_COUNT; ++i) {
+    std::string env = "C3P_";
+    for (const char* c = g_opt_names[i]; *c; ++c) env += (char)toupper((unsigned char)*c);
+    const char* v = getenv(env.c_str());  // read ONCE, here
+    g_opt_val[i].store(v ? parse_opt_value(v) : -1, std::memory_order_relaxed);
+  }
+}
 
 int fail(const char* fmt, ...) {
   char buf[512];
@@ -325,8 +354,8 @@ int pick_segments(int B, int N, int K, int Dm, bool need_mult4, long slots = 819
   // B S chains run in ceil(B S / slots) rounds of N / S slices (+ the table build and plan of the prologue):
   // take the S that minimises rounds x segment length, so that the last round is not a mostly idle tail
   // (B = 300 with the old "fill the machine twice" rule ran a second round at 2 % occupancy).
-  if (const char* e = getenv("C3P_SMALLD_SEGMENTS")) {  // tuning override
-    const long S = atol(e);
+  if (c3p_opt(C3P_OPT_smalld_segments) > 0) {  // tuning override
+    const long S = c3p_opt(C3P_OPT_smalld_segments);
     if (S >= 1 && S <= N && (!need_mult4 || S % 4 == 0)) return (int)S;
   }
   // (the backward sweep runs one wave per SIMD: 4096 slots)
@@ -362,8 +391,8 @@ int run_pwc_smalld(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const 
   const int S = pick_segments(B, N, K, Dm, per_sample);
   if (S < 0) return 1;  // not applicable -> caller falls back to the generic kernel
   const int nsamp = per_sample ? B : 1;
-  const bool fuse = (S > 1) && (S % 4 == 0) && !getenv("C3P_NO_FUSE");
-  const bool inline_tables = !lindblad && !getenv("C3P_PREP_KERNEL");
+  const bool fuse = (S > 1) && (S % 4 == 0) && !c3p_opt_on(C3P_OPT_no_fuse);
+  const bool inline_tables = !lindblad && !c3p_opt_on(C3P_OPT_prep_kernel);
   int* counters = nullptr;
   if (fuse) {
     void* cv;
@@ -440,7 +469,7 @@ int run_vjp_midd(DeviceWs* w, GradArgs& G, hipStream_t st) {
   const size_t img_bytes = (size_t)16 * nig * wd * sizeof(double);
   // backward sweep: one workgroup per CU (two for the real-Hamiltonian kernel at D <= 32); two to four rounds
   long target = D <= 32 ? 2048 : 512;  // (D <= 32: four rounds of the two-per-CU sweep; 1024 -> 2048 measured -2 % at cfg3)
-  if (const char* e = getenv("C3P_GRAD_TARGET")) target = atol(e) > 0 ? atol(e) : target;  // tuning override
+  if (c3p_opt(C3P_OPT_grad_target) > 0) target = c3p_opt(C3P_OPT_grad_target);  // tuning override
   long S = (target + B - 1) / B;
   const long smax = N / 8 > 1 ? N / 8 : 1;
   if (S > smax) S = smax;
@@ -516,8 +545,8 @@ int run_vjp_midd(DeviceWs* w, GradArgs& G, hipStream_t st) {
 // `slots` resident workgroups, each N / S slices long (+ a few slices' worth of prologue): take the S that
 // minimises rounds x segment length, so that the last round is not a mostly idle tail.
 static long pick_segments_rounds(long B, long N, long slots, long smax, long min_len = 100) {
-  if (const char* e = getenv("C3P_SEGMENTS")) {  // tuning override
-    const long S = atol(e);
+  if (c3p_opt(C3P_OPT_segments) > 0) {  // tuning override
+    const long S = c3p_opt(C3P_OPT_segments);
     if (S >= 1 && S <= (N > 1 ? N : 1)) return S;
   }
   long best = 1;
@@ -537,7 +566,7 @@ static long pick_segments_rounds(long B, long N, long slots, long smax, long min
   // (cfg5, B = 1024): S = 1 (2 rounds) 6.13e3, S = 4 6.28e3, S = 12 6.33e3 propagators/s; cfg3 (B = 512): 3 -> 12 segments
   // +1 %.  At least 12 rounds, segments of at least min_len slices (100; 400 in the 16-row class, whose slices are short
   // against the per-segment prologue: D = 13 measured 20 % slower with 100).
-  if (!getenv("C3P_NO_MANY_ROUNDS")) {
+  if (!c3p_opt_on(C3P_OPT_no_many_rounds)) {
     long want = (12 * slots + B - 1) / B;
     const long cap = N / min_len > 1 ? N / min_len : 1;
     if (want > cap) want = cap;
@@ -575,8 +604,8 @@ int run_xg_midd(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, dou
   a.Lmax = (int)((N + S - 1) / S);
   a.mode = C3P_MODE_EXPM;
   a.dUs_out = dUs_out;
-  a.no_t18 = getenv("C3P_NO_T18") ? 1 : 0;
-  a.no_real = getenv("C3P_NO_REAL") ? 1 : 0;
+  a.no_t18 = c3p_opt_on(C3P_OPT_no_t18) ? 1 : 0;
+  a.no_real = c3p_opt_on(C3P_OPT_no_real) ? 1 : 0;
   if (S == 1) {
     a.seg_out = U_out;
     a.fr_phase = fr_phase;
@@ -616,7 +645,7 @@ int run_xg_smalld(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, d
   a.Lmax = (N + S - 1) / S;
   a.mode = C3P_MODE_EXPM;
   a.dUs_out = dUs_out;
-  const bool fuse = (S > 1) && (S % 4 == 0) && !getenv("C3P_NO_FUSE");
+  const bool fuse = (S > 1) && (S % 4 == 0) && !c3p_opt_on(C3P_OPT_no_fuse);
   if (S == 1) {
     a.seg_out = U_out;
     a.fr_phase = fr_phase;
@@ -646,7 +675,7 @@ int run_xg_smalld(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, d
 int run_vjp_smalld(DeviceWs* w, GradArgs& G, hipStream_t st) {
   const int D = G.D, B = G.B, K = G.K, N = G.N;
   const bool per_sample = (G.h0_bstride != 0) || (G.hks_bstride != 0);
-  const int S = pick_segments(B, N, K, D, per_sample, getenv("C3P_GRAD_SLOTS") ? atol(getenv("C3P_GRAD_SLOTS")) : 4096);
+  const int S = pick_segments(B, N, K, D, per_sample, c3p_opt(C3P_OPT_grad_slots) > 0 ? c3p_opt(C3P_OPT_grad_slots) : 4096);
   if (S < 0) return 1;
   const int nsamp = per_sample ? B : 1;
   void* v;
@@ -866,8 +895,8 @@ int run_pwc_midd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   a.Lmax = (int)((N + S - 1) / S);
   a.mode = lindblad ? C3P_MODE_LINDBLAD : C3P_MODE_UNITARY;
   a.dUs_out = dUs_out;
-  a.no_t18 = getenv("C3P_NO_T18") ? 1 : 0;
-  a.no_real = getenv("C3P_NO_REAL") ? 1 : 0;
+  a.no_t18 = c3p_opt_on(C3P_OPT_no_t18) ? 1 : 0;
+  a.no_real = c3p_opt_on(C3P_OPT_no_real) ? 1 : 0;
   if (S == 1) {
     a.seg_out = U_out;
     a.fr_phase = fr_phase;
@@ -944,7 +973,7 @@ int run_vjp_lind_midd(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, 
   a.mode = C3P_MODE_LINDBLAD;
   a.seg_out = (cplx*)sv;
   a.dUs_out = dUs;
-  a.no_t18 = getenv("C3P_NO_T18") ? 1 : 0;
+  a.no_t18 = c3p_opt_on(C3P_OPT_no_t18) ? 1 : 0;
   a.no_real = 1;
   LAUNCH_TRY(c3p_launch_midd_chain(a, st));
   GradArgs G = {};
@@ -1043,7 +1072,7 @@ int run_vjp_xg_general(DeviceWs* w, const cplx* hs, long hs_bstride, double coef
     a.mode = C3P_MODE_EXPM;
     a.seg_out = (cplx*)sv;
     a.dUs_out = dUs;
-    a.no_t18 = getenv("C3P_NO_T18") ? 1 : 0;
+    a.no_t18 = c3p_opt_on(C3P_OPT_no_t18) ? 1 : 0;
     a.no_real = 1;
     LAUNCH_TRY(c3p_launch_midd_chain(a, st));
   }
@@ -1193,8 +1222,14 @@ int run_pwc_regd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   if (S > smax) S = smax;
   if (S < 1) S = 1;
   const int nsamp = per_sample ? B : 1;
+  // Lindblad superoperators of Hermitian Hamiltonians: the whole chain in real arithmetic in the Hermitian basis
+  // (c3p_regr.hip); the complex kernel keeps the samples whose tables are not real there
+  const bool hb = lindblad && c3p_regr_supported(D, Dm) && !c3p_opt_on(C3P_OPT_no_hermitian_basis);
+  const size_t ctab = (((size_t)nsamp * c3p_regd_table_doubles(Dm, K) * sizeof(double)) + 255) & ~(size_t)255;
+  const size_t rtab = hb ? ((((size_t)nsamp * c3p_regr_table_doubles(Dm, K) * sizeof(double)) + 255) & ~(size_t)255) : 0;
+  const size_t ftab = hb ? (size_t)nsamp * (1 + K) * sizeof(int) : 0;
   void* v;
-  if (ws_get(w, SL_TABLES, (size_t)nsamp * c3p_regd_table_doubles(Dm, K) * sizeof(double), &v)) return -1;
+  if (ws_get(w, SL_TABLES, ctab + rtab + ftab, &v)) return -1;
   RegdPrepArgs p = {};
   p.h0 = h0;
   p.h0_bstride = h0_bs;
@@ -1208,6 +1243,9 @@ int run_pwc_regd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   p.lindblad = lindblad;
   p.tables = (double*)v;
   LAUNCH_TRY(c3p_launch_regd_prep(p, nsamp, st));
+  double* rtables = reinterpret_cast<double*>(static_cast<char*>(v) + ctab);
+  int* tabflag = reinterpret_cast<int*>(static_cast<char*>(v) + ctab + rtab);
+  if (hb) LAUNCH_TRY(c3p_launch_regr_prep(p, nsamp, rtables, tabflag, st));
   void* av;
   if (ws_get(w, SL_SCRATCH, c3p_regd_arena_bytes(Dm), &av)) return -1;
   MidArgs a = {};
@@ -1222,6 +1260,10 @@ int run_pwc_regd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   a.Lmax = (int)((N + S - 1) / S);
   a.mode = lindblad ? C3P_MODE_LINDBLAD : C3P_MODE_UNITARY;
   a.dUs_out = dUs_out;
+  if (hb) {
+    a.hb_tables = rtables;
+    a.hb_tabflag = tabflag;
+  }
   cplx* seg = U_out;
   if (S > 1) {
     void* sv;
@@ -1231,8 +1273,14 @@ int run_pwc_regd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   a.seg_out = seg;
   g_last_kernel = C3P_KERNEL_MFMA;
   if (record_start(w, st)) return -1;
+  if (hb) LAUNCH_TRY(c3p_launch_regr_chain(a, st));
   LAUNCH_TRY(c3p_launch_regd_chain(a, av, st));
   if (record_stop(w, st)) return -1;
+  if (hb) {
+    // back to the reference's vectorisation, in place (real results sit in the second half of their complex slots)
+    LAUNCH_TRY(c3p_launch_hb_to_complex(seg, (long)B * S, (int)S, tabflag, per_sample ? 1 : 0, K, D, st));
+    if (dUs_out) LAUNCH_TRY(c3p_launch_hb_to_complex(dUs_out, (long)B * N, N, tabflag, per_sample ? 1 : 0, K, D, st));
+  }
   if (S == 1 && fr_phase) LAUNCH_TRY(c3p_launch_rowphase(U_out, fr_phase, B, Dm, st));
   if (S > 1) {
     // ordered combine of the few segment products with the generic kernel (GIVEN mode)
@@ -1461,7 +1509,7 @@ int pwc_common(int lindblad, const void* h0, int64_t h0_bstride, const void* hks
     if (rc < 0) return -1;
     done = (rc == 0);
   }
-  if (!done && !(flags & C3P_FORCE_GENERIC) && !per_slice && c3p_regd_supported(Dm) && K <= 16 && !getenv("C3P_NO_REGD")) {
+  if (!done && !(flags & C3P_FORCE_GENERIC) && !per_slice && c3p_regd_supported(Dm) && K <= 16 && !c3p_opt_on(C3P_OPT_no_regd)) {
     const int rc = run_pwc_regd(w, lindblad, a.h0, a.h0_bstride, a.hks, a.hks_bstride, a.signals, a.clp, dt, B,
                                 K, N, D, Dm, a.fr_phase, (cplx*)d_U, a.dUs_out, st);
     if (rc < 0) return -1;
@@ -1475,7 +1523,7 @@ int pwc_common(int lindblad, const void* h0, int64_t h0_bstride, const void* hks
   }
   // beyond the on-chip kernels: Dm >= 93, and supplied / per-slice generators at Dm >= 41 (the generic kernel would run
   // those from global scratch at a few percent of the roofline, and stops at Dm = 256)
-  if (!done && !(flags & C3P_FORCE_GENERIC) && !getenv("C3P_NO_TILED") && (Dm >= 93 || (per_slice && Dm >= 41)) &&
+  if (!done && !(flags & C3P_FORCE_GENERIC) && !c3p_opt_on(C3P_OPT_no_tiled) && (Dm >= 93 || (per_slice && Dm >= 41)) &&
       (per_slice ? K == 0 : true)) {
     if (run_pwc_tiled(w, a, per_slice, (cplx*)d_U, st)) return -1;
     done = true;
@@ -1486,6 +1534,11 @@ int pwc_common(int lindblad, const void* h0, int64_t h0_bstride, const void* hks
 }
 
 }  // namespace
+
+long c3p_opt(C3pOption o) {
+  std::call_once(g_opt_once, opt_init);
+  return g_opt_val[o].load(std::memory_order_relaxed);
+}
 
 extern "C" {
 
@@ -1502,6 +1555,25 @@ int c3p_device_count(void) {
 
 const char* c3p_last_error(void) { return g_err.c_str(); }
 int c3p_last_kernel(void) { return g_last_kernel; }
+
+int c3p_set_option(const char* name, const char* value) {
+  if (!name) return fail("c3p_set_option: null name");
+  std::call_once(g_opt_once, opt_init);
+  for (int i = 0; i < C3P_OPT_COUNT; ++i)
+    if (!strcmp(name, g_opt_names[i])) {
+      g_opt_val[i].store(value ? parse_opt_value(value) : -1, std::memory_order_relaxed);
+      return 0;
+    }
+  return fail("c3p_set_option: unknown option '%s'", name);
+}
+
+long c3p_get_option(const char* name) {
+  if (!name) return -2;
+  std::call_once(g_opt_once, opt_init);
+  for (int i = 0; i < C3P_OPT_COUNT; ++i)
+    if (!strcmp(name, g_opt_names[i])) return g_opt_val[i].load(std::memory_order_relaxed);
+  return -2;
+}
 
 int c3p_set_profiling(int enable) {
   DeviceWs* w = ws_for_current_device();
@@ -1753,7 +1825,7 @@ int ode_segmented(DeviceWs* w, OdeArgs a, int nseg, const cplx* init, long init_
 // 256), at the price of the ordered product of S maps.  min_gain: how many segments the change has to offer at least
 // (a vector state that would otherwise run on the lane-row kernel pays 1.5x per step for becoming a matrix).
 int ode_mfma_segments(const OdeArgs& a0, int min_segments) {
-  if (getenv("C3P_ODE_NO_SEG")) return 0;
+  if (c3p_opt_on(C3P_OPT_ode_no_seg)) return 0;
   if (a0.D < 17 || a0.D > 48 || a0.want_all || a0.reset_each_step || a0.transpose_out || a0.hs || a0.K > 4 || a0.n_steps < 64) return 0;
   int nig, nj, wd;
   if (!c3p_midd_geometry(a0.D, &nig, &nj, &wd)) return 0;  // (the ordered product of the maps runs on the mid-D chain kernel: D <= 40)
@@ -2080,7 +2152,7 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
   // batches are processed in chunks of samples that keep that below 24 GB (C3P_GRAD_CHUNK overrides the chunk size).
   auto in_chunks = [&](auto&& run) -> int {  // run(b0, nb) -> 0 done, 1 not applicable, -1 error
     long Bc = (long)(((size_t)24 << 30) / (2 * (size_t)N * Dm * Dm * cs));
-    if (const char* e = getenv("C3P_GRAD_CHUNK")) Bc = atol(e);
+    if (c3p_opt(C3P_OPT_grad_chunk) > 0) Bc = c3p_opt(C3P_OPT_grad_chunk);
     if (Bc < 1) Bc = 1;
     for (long b0 = 0; b0 < B; b0 += Bc) {
       const int rc = run(b0, (int)(B - b0 < Bc ? B - b0 : Bc));
@@ -2096,8 +2168,8 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
   double* p_grad = (double*)d_grad;
   const long gsz = (long)Dm * Dm;
   auto phase_at = [&](long b0) { return p_ph ? p_ph + b0 * Dm : nullptr; };
-  if (Dm <= kSmallDLimit && c3p_smalld_supported(Dm) && K <= 8 && !(flags & C3P_FORCE_GENERIC) && !getenv("C3P_TILED_GRAD") &&
-      !getenv("C3P_VALU_GRAD")) {
+  if (Dm <= kSmallDLimit && c3p_smalld_supported(Dm) && K <= 8 && !(flags & C3P_FORCE_GENERIC) && !c3p_opt_on(C3P_OPT_tiled_grad) &&
+      !c3p_opt_on(C3P_OPT_valu_grad)) {
     // superoperators up to 12 x 12 (D <= 3): the general-generator sweep on the small-D matrix-core kernels
     if (record_start(w, st)) return -1;
     const int rc = in_chunks([&](long b0, int nb) {
@@ -2112,7 +2184,7 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
       return 0;
     }
   }
-  if (Dm >= 13 && Dm <= 36 && !(flags & C3P_FORCE_GENERIC) && !getenv("C3P_TILED_GRAD") && !getenv("C3P_VALU_GRAD")) {
+  if (Dm >= 13 && Dm <= 36 && !(flags & C3P_FORCE_GENERIC) && !c3p_opt_on(C3P_OPT_tiled_grad) && !c3p_opt_on(C3P_OPT_valu_grad)) {
     // 16 x 16 .. 36 x 36 superoperators (D = 4, 5, 6): the same sweep on the mid-D matrix-core kernels
     if (record_start(w, st)) return -1;
     const int rc = in_chunks([&](long b0, int nb) {
@@ -2127,7 +2199,7 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
       return 0;
     }
   }
-  if (Dm <= 36 && !getenv("C3P_TILED_GRAD")) {
+  if (Dm <= 36 && !c3p_opt_on(C3P_OPT_tiled_grad)) {
     // the same sweep in three VALU kernels on dense generator tables (c3p_grad.hip, general form): fallback and second opinion
     bool global = false;
     auto run_valu = [&](long b0, int nb) -> int {
@@ -2304,11 +2376,11 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
       if (fr_phase && sg.in(fr_phase, (size_t)B * D * sizeof(double), &d_ph)) return -1;
       if (sg.out(gen_bar_out, (size_t)B * N * D * D * cs, &d_z)) return -1;
     }
-    if (D <= 40 && !(flags & C3P_FORCE_GENERIC) && !getenv("C3P_TILED_GRAD")) {
+    if (D <= 40 && !(flags & C3P_FORCE_GENERIC) && !c3p_opt_on(C3P_OPT_tiled_grad)) {
       // on-chip general-generator sweeps (nothing assumed about the slice Hamiltonians), in chunks of samples that keep the
       // slice propagators + prefixes (2 N D^2 complex per sample) below 24 GB
       long Bc = (long)(((size_t)24 << 30) / (2 * (size_t)N * D * D * cs));
-      if (const char* e = getenv("C3P_GRAD_CHUNK")) Bc = atol(e);
+      if (c3p_opt(C3P_OPT_grad_chunk) > 0) Bc = c3p_opt(C3P_OPT_grad_chunk);
       if (Bc < 1) Bc = 1;
       int rc = 0;
       for (long b0 = 0; b0 < B && rc == 0; b0 += Bc) {
@@ -2332,7 +2404,7 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
     return 0;
   }
   if (B < 0 || K <= 0 || N <= 0 || D <= 0) return fail("bad sizes B=%d K=%d N=%d D=%d", B, K, N, D);
-  if (D > 40 && gen_bar_out) return fail("gen_bar_out (per-slice generator cotangents) is available for D <= 40, got %d", D);
+  if (D > 64 && gen_bar_out) return fail("gen_bar_out (per-slice generator cotangents) is available for D <= 64, got %d", D);
   if (B == 0) return 0;
   if (!h0 || !hks || !signals || !U_bar || !grad_signals) return fail("NULL pointer argument");
   const size_t cs = sizeof(cplx);
@@ -2401,7 +2473,7 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
   // beyond the on-chip sweeps: forward partials in HBM, one pair evaluation of T18 per slice on the tiled MFMA GEMM.  ~35
   // launches per slice: below a few hundred samples the launches, not the GEMMs, set the time, and the VALU sweep (which
   // stops at D = 64) is faster for 41 <= D <= 64 (profiles/r03/grad_tiled.json: D = 48, B = 64: 151 ms against 545 ms)
-  const bool tiled_grad = D > 64 || (D > 40 && (B >= 384 || getenv("C3P_TILED_GRAD")));
+  const bool tiled_grad = D > 64 || (D > 40 && (B >= 384 || c3p_opt_on(C3P_OPT_tiled_grad)));
   if (!done && !(flags & C3P_FORCE_GENERIC) && tiled_grad && !gen_bar_out) {
     if (run_vjp_tiled(w, 0, A.h0, h0_bstride, A.hks, hks_bstride, A.signals, nullptr, dt, B, K, N, D, D, A.fr_phase, A.Ubar, A.grad, st))
       return -1;

@@ -2,6 +2,48 @@
 #pragma once
 #include "c3p_common.h"
 
+// ---- tuning / diagnostic options -------------------------------------------------------------------------------------
+// ONE table for the whole library (it replaces the getenv() calls that used to sit in the dispatch code): set through the
+// C ABI (c3p_set_option(name, value), include/c3prop.h) or, ONCE at the first use, from environment variables of the same
+// names in upper case with the prefix C3P_ (C3P_NO_REGD=1 python ...).  Values are integers; -1 = not set.  Reads are
+// relaxed atomic loads: safe from any thread, against c3p_set_option from another one.
+#define C3P_OPTION_LIST(X)                                                                                             \
+  X(no_regd)            /* 41 <= Dm <= 81: arena kernel (c3p_bigd.hip) instead of the register-resident ones */       \
+  X(regd_pad)           /* 0: no zero-padded classes; 2: pad everything in 41..81; unset: the measured default */      \
+  X(no_hermitian_basis) /* Lindblad chains at D = 7..9 on the complex kernel (c3p_regd.hip) instead of c3p_regr.hip */ \
+  X(no_tiled)           /* Dm >= 93: generic kernel instead of the tiled path */                                       \
+  X(no_mw)              /* small D: one-wave workgroups + ticket instead of workgroup-per-sample */                    \
+  X(mw_skew)            /* per mille of a pair's slices given to the older wave */                                     \
+  X(no_fuse)            /* small D: separate combine launch */                                                         \
+  X(prep_kernel)        /* small D: separate table kernel */                                                           \
+  X(smalld_segments)    /* segments per sample, small D */                                                             \
+  X(segments)           /* segments per sample, mid D */                                                               \
+  X(no_many_rounds)     /* mid D: round-1 segment rule */                                                              \
+  X(no_t18)             /* Paterson-Stockmeyer plan only */                                                            \
+  X(no_real)            /* real Hamiltonians on the complex instances */                                               \
+  X(no_real_grad)       /* real Hamiltonians on the general backward sweeps */                                         \
+  X(grad_target)        /* chains per launch of the VALU backward sweep */                                             \
+  X(grad_slots)         /* resident wave slots assumed by the backward sweeps' segment rule */                         \
+  X(grad_chunk)         /* samples per chunk of the general-generator sweeps */                                        \
+  X(tiled_grad)         /* tiled backward sweep wherever it applies */                                                 \
+  X(valu_grad)          /* VALU backward sweeps instead of the matrix-core ones */                                     \
+  X(tiled_graph)        /* tiled sweep: replay slices as hipGraphs */                                                  \
+  X(tiled_no_batch)     /* tiled sweep: one launch per product */                                                      \
+  X(tiled_tile32)       /* tiled sweep: 0 / 1 forces the 64 x 64 / 32 x 32 output tiles */                             \
+  X(ode_wg)             /* ODE: workgroup-per-sample kernel of round 1 */                                              \
+  X(ode_prop_rows)      /* rk4_unitary at 17 <= D <= 48 on the lane-row column kernel */                               \
+  X(ode_rho_general)    /* matrix-core ODE kernel: two products per commutator for every input */                      \
+  X(ode_no_seg)         /* ODE: no time segments for small final-state batches */
+
+enum C3pOption {
+#define C3P_OPT_ENUM(n) C3P_OPT_##n,
+  C3P_OPTION_LIST(C3P_OPT_ENUM)
+#undef C3P_OPT_ENUM
+      C3P_OPT_COUNT
+};
+long c3p_opt(C3pOption o);                                     // -1 = not set
+inline bool c3p_opt_on(C3pOption o) { return c3p_opt(o) > 0; }  // a switch: set to a positive value
+
 #define C3P_MODE_UNITARY 0   // assemble -i dt H, exponentiate, chain
 #define C3P_MODE_LINDBLAD 1  // assemble dt L(H), exponentiate, chain
 #define C3P_MODE_EXPM 2      // exponentiate supplied matrices (no chain when N == 1)

@@ -20,6 +20,10 @@ struct MidArgs {
   int no_real;  // debug/tuning: keep real Hamiltonians on the complex path
   cplx* seg_out;
   cplx* dUs_out;
+  // Lindblad chains in the Hermitian basis (c3p_regr.hip): real generator tables and one flag per table (1 = real); the real
+  // kernel takes the samples whose tables are all real, the complex one (given the flags) skips exactly those
+  const double* hb_tables;
+  const int* hb_tabflag;
 };
 
 // Backward sweep of the control gradient (c3p_grad.hip for the method)

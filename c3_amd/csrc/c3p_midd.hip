@@ -2706,7 +2706,7 @@ hipError_t c3p_launch_midd_grad(const MidGradArgs& A_, hipStream_t st) {
   A.skip_real = 0;
   // real Hamiltonians first (reverse mode through the cos / sin evaluation), then the general sweep for the rest; the
   // per-slice generator cotangents (zout) only exist in the general sweep
-  if (A.zout == nullptr && !getenv("C3P_NO_REAL_GRAD")) {
+  if (A.zout == nullptr && !c3p_opt_on(C3P_OPT_no_real_grad)) {
     bool launched = false;
     hipError_t e = launch_grad_real(A, nig, nj, st, &launched);
     if (e != hipSuccess) return e;

@@ -1,6 +1,7 @@
 // Launcher interface of the ODE state-solver kernel (c3p_ode.hip).
 #pragma once
 #include "c3p_common.h"
+#include "c3p_kernels.h"
 
 #define C3P_STEP_SCHRODINGER_ID 0
 #define C3P_STEP_VON_NEUMANN_ID 1

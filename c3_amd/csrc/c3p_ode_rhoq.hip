@@ -598,11 +598,11 @@ hipError_t launch_rho1(const OdeArgs& A, hipStream_t st) {
 }  // namespace
 
 bool c3p_ode_rhoq_supported(const OdeArgs& A) {
-  if (getenv("C3P_ODE_WG")) return false;
+  if (c3p_opt_on(C3P_OPT_ode_wg)) return false;
   if (A.D < 17 || A.D > 48 || A.M != A.D || A.K > RK || A.hs || A.N < 2) return false;
   if (A.u_stride < 1 || A.u_stride > 2) return false;
   if (A.step == C3P_STEP_PROPAGATOR_ID)
-    return !getenv("C3P_ODE_PROP_ROWS") && (A.seg_count == 0 || (!A.want_all && !A.reset_each_step && !A.transpose_out));
+    return !c3p_opt_on(C3P_OPT_ode_prop_rows) && (A.seg_count == 0 || (!A.want_all && !A.reset_each_step && !A.transpose_out));
   if (A.seg_count > 0) return false;  // (A/B switch: the lane-row column kernel)
   if (A.reset_each_step || A.transpose_out) return false;
   if (A.step == C3P_STEP_VON_NEUMANN_ID) return true;
@@ -612,6 +612,6 @@ bool c3p_ode_rhoq_supported(const OdeArgs& A) {
 
 hipError_t c3p_launch_ode_rhoq(const OdeArgs& A0, hipStream_t st) {
   OdeArgs A = A0;
-  A.rho_general = getenv("C3P_ODE_RHO_GENERAL") != nullptr;  // A/B switch: two products per commutator for every input
+  A.rho_general = c3p_opt_on(C3P_OPT_ode_rho_general);  // A/B switch: two products per commutator for every input
   return A.D <= 32 ? launch_rho1<2>(A, st) : launch_rho1<3>(A, st);
 }

@@ -587,7 +587,7 @@ hipError_t launch_mat1(const OdeArgs& A, const OdeRowAux& X, dim3 grid, hipStrea
 }  // namespace
 
 bool c3p_ode_row_supported(const OdeArgs& A) {
-  if (getenv("C3P_ODE_WG")) return false;  // A/B switch: the workgroup-per-sample kernel of c3p_ode.hip
+  if (c3p_opt_on(C3P_OPT_ode_wg)) return false;  // A/B switch: the workgroup-per-sample kernel of c3p_ode.hip
   if (A.D > 16 || A.K > 4 || A.hs || A.N < 2) return false;
   if (A.u_stride != 1 && A.u_stride != 2) return false;
   if (A.step == C3P_STEP_SCHRODINGER_ID || A.step == C3P_STEP_PROPAGATOR_ID) return true;
@@ -648,7 +648,7 @@ hipError_t c3p_launch_ode_row(const OdeArgs& A, void* aux, hipStream_t st) {
 // extra launches (identity, combine, apply: ~50 us) over S = 1..8 (the small-D chain kernel folds up to 8 maps in one launch).
 // Measured, D = 9, 1000 rk4 steps (direct 0.50 ms): B = 16 0.117 ms (S = 8), B = 64 0.128 ms (S = 7), B = 256 0.35 ms (S = 3).
 int c3p_ode_row_segments(const OdeArgs& A) {
-  if (getenv("C3P_ODE_NO_SEG")) return 0;
+  if (c3p_opt_on(C3P_OPT_ode_no_seg)) return 0;
   if (A.D < 2 || A.D > 12 || A.want_all || A.reset_each_step || A.n_steps < 64) return 0;  // (the combine runs on the small-D chain kernel)
   auto step_cost = [](long rows) {  // relative time of one RK step when `rows` DPP rows (4 per wave) are spread over 1024 SIMDs
     const long w = (rows + 4095) / 4096;

@@ -330,7 +330,7 @@ int q_cols(int D) {
 }  // namespace
 
 bool c3p_ode_rowq_supported(const OdeArgs& A) {
-  if (getenv("C3P_ODE_WG")) return false;
+  if (c3p_opt_on(C3P_OPT_ode_wg)) return false;
   if (A.D < 17 || A.D > 48 || A.K > QK || A.hs || A.N < 2) return false;
   if (A.u_stride != 1 && A.u_stride != 2) return false;
   if (A.step != C3P_STEP_SCHRODINGER_ID && A.step != C3P_STEP_PROPAGATOR_ID) return false;

@@ -27,3 +27,20 @@ hipError_t c3p_launch_regd_prep(const RegdPrepArgs& P, int nsamp, hipStream_t st
 // MidArgs as for the mid-D / big-D kernels (tables in the layout c3p_launch_regd_prep writes); seg_out gets the
 // B x S segment products without frame-rotation phases
 hipError_t c3p_launch_regd_chain(const MidArgs& A, void* arena, hipStream_t st);
+
+// ---- Lindblad chains in the Hermitian basis, real arithmetic (c3p_regr.hip) ----
+// all (1 + K) generator tables of a sample real in the Hermitian basis (flags written by c3p_launch_regr_prep)?
+__device__ __forceinline__ bool c3p_hb_sample_is_real(const int* tabflag, int sample_or_0, int K) {
+  bool r = true;
+  for (int k = 0; k <= K; ++k) r = r && (tabflag[sample_or_0 * (1 + K) + k] != 0);
+  return r;
+}
+bool c3p_regr_supported(int Dh, int Dm);       // Dm = Dh^2 in a class of the register-resident kernels (Dh = 7, 8, 9)
+size_t c3p_regr_table_doubles(int Dm, int K);  // per sample: (1 + K) real generator tables
+// same arguments as c3p_launch_regd_prep (lindblad = 1); tabflag: [nsamp][1 + K]
+hipError_t c3p_launch_regr_prep(const RegdPrepArgs& P, int nsamp, double* tables, int* tabflag, hipStream_t st);
+// MidArgs with hb_tables / hb_tabflag set; the REAL segment products (and slice propagators) are written to the second
+// half of their complex slots in seg_out (dUs_out): c3p_launch_hb_to_complex turns them into the complex matrices in place
+hipError_t c3p_launch_regr_chain(const MidArgs& A, hipStream_t st);
+hipError_t c3p_launch_hb_to_complex(cplx* mats, long nmat, int mats_per_sample, const int* tabflag, int tab_per_sample, int K,
+                                    int Dh, hipStream_t st);

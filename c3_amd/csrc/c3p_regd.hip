@@ -463,6 +463,8 @@ __global__ void __launch_bounds__(RG_THREADS, 1) regd_chain_kernel(MidArgs A, cp
   const long nchains = (long)A.B * A.S;
   for (long chain = blockIdx.x; chain < nchains; chain += gridDim.x) {
     const int sample = (int)(chain / A.S);
+    // Lindblad chains of Hermitian Hamiltonians run in real arithmetic in the Hermitian basis (c3p_regr.hip)
+    if (A.hb_tabflag && c3p_hb_sample_is_real(A.hb_tabflag, A.tab_per_sample ? sample : 0, K)) continue;
     const int seg = (int)(chain - (long)sample * A.S);
     const int n0 = (int)(((long)seg * A.N) / A.S);
     const int n1 = (int)(((long)(seg + 1) * A.N) / A.S);
@@ -878,9 +880,9 @@ hipError_t launch_r(const MidArgs& A, void* arena, hipStream_t st) {
 // kernel).  C3P_REGD_PAD=0 switches the padding off, C3P_REGD_PAD=all pads everything in 41..81.
 bool c3p_regd_supported(int Dm) {
   if (Dm == 49 || Dm == 65 || Dm == 81) return true;
-  const char* e = getenv("C3P_REGD_PAD");
-  if (e && e[0] == '0') return false;
-  if (e && e[0] == 'a') return Dm >= 41 && Dm <= 81;
+  const long e = c3p_opt(C3P_OPT_regd_pad);
+  if (e == 0) return false;
+  if (e == 2) return Dm >= 41 && Dm <= 81;
   return (Dm >= 41 && Dm <= 48) || (Dm >= 56 && Dm <= 64) || (Dm >= 70 && Dm <= 80);
 }
 

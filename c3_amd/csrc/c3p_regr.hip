@@ -1,0 +1,796 @@
+// Lindblad superoperator chains in REAL arithmetic on the f64 matrix cores: Dm = D^2 = 49, 64 (padded to 65), 81 -- the
+// 81 x 81 superoperators of two qutrits (BASELINE cfg4, c3/libraries/propagation.py:551-585).
+//
+// The Lindblad generator L(rho) = -i [H, rho] + sum_c C rho C^+ - 1/2 {C^+ C, rho} maps Hermitian matrices to Hermitian
+// matrices whenever H is Hermitian (whatever the collapse operators are).  In a basis of Hermitian matrices
+//     E_ii,   (E_ij + E_ji) / sqrt 2,   i (E_ji - E_ij) / sqrt 2        (i < j)
+// the superoperator is therefore a REAL Dm x Dm matrix: X' = T X T^+ with the (sparse, unitary) change of basis T from the
+// row-major vectorisation the reference uses (tf_utils.py:271-280).  The whole chain runs in that basis,
+//     U = prod_n exp(X_n) = T^+ ( prod_n exp(X'_n) ) T,
+// with real products -- a quarter of the multiplications of a complex product (a third of the three-product form of
+// c3p_regd.hip) and half the bytes per matrix: every matrix a slice needs (X, X^2, the T18 combinations, the running
+// product) now fits the register file, so NOTHING leaves the CU between the tables and the segment product (the complex
+// kernel parks five tile sets per slice in a global arena: 1 TB per cfg4 launch).  The basis change costs two tiny kernels:
+// the generator tables are transformed once per call (regr_prep_kernel, four generator elements per table element) and
+// the segment products / slice propagators are transformed back in place (hb_to_complex_kernel).  Same result up to
+// rounding (T is unitary with entries 0, 1, +-1/sqrt 2, +-i/sqrt 2).
+//
+// Non-Hermitian Hamiltonians (the C ABI takes any matrix) leave an imaginary part in X': regr_prep_kernel flags every
+// table whose imaginary part exceeds 1e-14 of its largest element, the real kernel takes the samples whose tables are all
+// flagged real and the complex kernel of c3p_regd.hip the others (both are launched; a workgroup skips what is not its own).
+//
+// Layout and product loop follow c3p_regd.hip: one workgroup of four waves (one per SIMD, 512 registers), a (Dm-1)^2
+// CORE in registers (wave w owns 4 n columns as n x n tiles in the C/D layout of v_mfma_f64_4x4x4_4b_f64, which is also a
+// valid B operand once rotated by 0..3 lane groups) plus a one-element BORDER in LDS slots; the left operand streams from
+// one LDS image (real, row stride LD); exp = T18 (Bader-Blanes-Casas, 5 products) + s squarings, then the chain product.
+#include <cstdio>
+#include <utility>
+
+#include "c3p_common.h"
+#include "c3p_kernels.h"
+#include "c3p_midd.h"
+#include "c3p_regd.h"
+
+extern __shared__ __attribute__((aligned(16))) double c3p_rr_lds[];
+
+namespace {
+
+constexpr int RR_WAVES = 4;
+constexpr int RR_THREADS = 64 * RR_WAVES;
+constexpr int RR_CH = 32;    // control amplitudes staged per chunk of slices
+constexpr int RR_KMAX = 16;  // control lines
+enum { S_M0 = 0, S_M1, S_M2, S_M3, S_R0, S_R1, S_U0, S_U1, S_NSLOT };
+enum { OP_P1 = 0, OP_P2, OP_P3, OP_P4, OP_EX, OP_CH };
+
+template <int NRG>
+struct RR {
+  static constexpr int DM = 16 * NRG + 1;
+  static constexpr int NJ = NRG;       // column blocks per wave
+  static constexpr int NT = NRG * NJ;  // tiles per wave
+  // image row stride (doubles): A-fragment reads (16 rows x 4 columns per 32 lanes) at most two-way on the 32 bank
+  // pairs for every rotation, the 16-lane tile stores conflict free (brute-forced: 17 mod 32, or 2 mod 4)
+  static constexpr int LD = (NRG == 4) ? DM + 1 : DM;
+  static constexpr int BS = 2 * DM;  // border slot: row DM-1 (DM elements, corner last), column DM-1 (DM elements, corner last)
+  static constexpr int DMP = DM + 1;
+  static constexpr int IMG_D = DM * LD;
+  static constexpr int TSET = NT * RR_THREADS;  // elements of a tile set: element (tile, thread) at tile * 256 + thread
+  static constexpr int TAB_D = TSET + BS + 4;   // doubles per generator table: tile set, border slot, {mu, norm1, 0, 0}
+  static constexpr int LDS_D = IMG_D + S_NSLOT * BS + 8 * DMP + RR_KMAX * RR_CH + 2 * RR_WAVES;
+};
+
+template <typename F, int... Is>
+__device__ __forceinline__ void rr_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void rr_static_for(F&& f) {
+  rr_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// the four 4-lane groups of every 16-lane row rotated by S groups (DPP row_ror): MFMA block b then holds what block
+// (b - S) mod 4 held
+template <int S>
+__device__ __forceinline__ double rr_rot(double v) {
+  if constexpr (S == 0) {
+    return v;
+  } else {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x120 + 4 * S, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x120 + 4 * S, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+  }
+}
+
+__device__ __forceinline__ int rr_opq(int v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T* rr_ubase(T* p) {
+  return p + rr_opq(0);
+}
+// workgroup barrier that waits for the LDS traffic only
+__device__ __forceinline__ void rr_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ double rr_rfl(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readfirstlane(lo);
+  hi = __builtin_amdgcn_readfirstlane(hi);
+  return __hiloint2double(hi, lo);
+}
+
+template <int NRG, bool DUS>
+__global__ void __launch_bounds__(RR_THREADS, 1) regr_chain_kernel(MidArgs A, long long* dbg) {
+  using G = RR<NRG>;
+  constexpr int DM = G::DM, NJ = G::NJ, LD = G::LD, BS = G::BS, DMP = G::DMP;
+  constexpr int TSET = G::TSET;
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  int tid = tid0, lane = tid & 63;
+  int q = lane >> 4, b = (lane >> 2) & 3, p = lane & 3;
+  double* img = c3p_rr_lds;
+  double* brd = img + G::IMG_D;
+  double* cpart = brd + S_NSLOT * BS;
+  double* rpart = cpart + 4 * DMP;
+  double* sg = rpart + 4 * DMP;
+  double* red = sg + RR_KMAX * RR_CH;
+  const int col0 = 4 * NJ * wave;  // first column of this wave
+  int rowC = 4 * b + q;            // row of a C/D-layout element inside its row group
+  int rowA = 4 * b + p;            // row of an A-fragment element inside its row group
+  const int K = A.K;
+  // lane indices are re-derived from an opaque copy of the thread id at the start of every phase: otherwise the compiler
+  // hoists every address / mask that depends on them out of the slice loop and spills them
+  auto refresh = [&]() {
+    int t_ = tid0;
+    asm volatile("" : "+v"(t_));
+    tid = t_;
+    lane = tid & 63;
+    q = lane >> 4, b = (lane >> 2) & 3, p = lane & 3;
+    rowC = 4 * b + q;
+    rowA = 4 * b + p;
+  };
+
+#ifdef C3P_REGR_TIMING
+  long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tq = 0;
+#define RR_TICK(i)                  \
+  {                                 \
+    const long long tn = clock64(); \
+    tacc[i] += tn - tq;             \
+    tq = tn;                        \
+  }
+#else
+#define RR_TICK(i)
+#endif
+  double Rm[NRG][NJ];   // right operand of the next product
+  double acc[NRG][NJ];  // accumulators = the product
+  double Xs[NRG][NJ];   // X, later B2
+  double A2s[NRG][NJ];  // X^2, later B3
+  double Us[NRG][NJ];   // running product of the segment
+
+  auto mfma = [](double a, double bb, double c) -> double { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, bb, c, 0, 0, 0); };
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) acc[Ig][jj] = 0.0;
+  };
+  // a border element (slot index tid) also sits in the image: row DM-1 or column DM-1
+  auto border_to_image = [&](double v) {
+    if (tid < DM) img[(DM - 1) * LD + tid] = v;
+    else if (tid < 2 * DM - 1) img[(tid - DM) * LD + DM - 1] = v;
+  };
+
+  // C = (init) + L R: L = the LDS image, R = Rm with borders in slot sr; the accumulators carry the initial value (its
+  // border in slot si, or si < 0); border of C -> slot sd (by finalize, after the barrier that publishes the partials).
+  // Column DM-1 of C is one more B column (the border column of R, from its slot) on the K-steps with s == wave: four
+  // partial sums, one per wave; row DM-1 of C uses the tiles of R block by block (A operand = row DM-1 of L in the i = 0
+  // row of every block): four partial sums, one per MFMA block.  The k = DM-1 terms: finalize / the rank-1 update.
+  double cornerA = 0.0, cornerR = 0.0;
+  auto product = [&](int sr) {
+    const double* rb = brd + sr * BS;
+#pragma unroll
+    for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) asm volatile("" : "+v"(Rm[Ig][jj]));
+    double cP[NRG];
+    double rP[NJ + 1];
+#pragma unroll
+    for (int Ig = 0; Ig < NRG; ++Ig) cP[Ig] = 0.0;
+#pragma unroll
+    for (int jj = 0; jj <= NJ; ++jj) rP[jj] = 0.0;
+    {
+      // one pass = the four K-steps of one row group of R (row 0 of Rm; the rows move up at the end of the pass).  K-step
+      // s: MFMA block b multiplies by block (b - s) mod 4 of the tile, its A fragment is taken at the k of that block.
+      const double* pa = img + rowA * LD;
+      const double* pr = img + (DM - 1) * LD + rowC;  // row DM-1 of L at this lane's k
+      const double* pc = rb + DM;                     // column DM-1 of R
+      int ko[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) ko[s] = 4 * ((b - s) & 3) + q;
+      double aC[NRG], aN[NRG];
+      double br[NJ];
+#pragma unroll
+      for (int Ig = 0; Ig < NRG; ++Ig) aC[Ig] = pa[16 * Ig * LD + ko[0]];
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) br[jj] = Rm[0][jj];
+      RR_TICK(10)
+#pragma unroll 1
+      for (int it = 0; it < NRG; ++it) {
+        rr_static_for<4>([&](auto s_) {
+          constexpr int sx = decltype(s_)::value;
+          constexpr int sn = (sx + 1) & 3, rn = (sx == 3) ? 1 : 0;  // next step: rotation, row of Rm
+          // source order = issue order (sched_barrier): one MFMA, then at most one piece of the next step's operand
+          // preparation (an A-fragment load or a tile rotation), so that it issues in the shadow of the matrix pipe
+          double brN[NJ];
+          rr_static_for<NRG>([&](auto Ig_) {
+            constexpr int Ig = decltype(Ig_)::value;
+            rr_static_for<NJ>([&](auto jj_) {
+              constexpr int jj = decltype(jj_)::value;
+              constexpr int u = Ig * NJ + jj;  // preparation slot (NRG + NJ pieces over NRG * NJ slots)
+              acc[Ig][jj] = mfma(aC[Ig], br[jj], acc[Ig][jj]);
+              if constexpr (u < NRG) {
+                aN[u] = pa[16 * u * LD + (sx == 3 ? 16 : 0) + ko[sn]];  // (the very last prefetch is unused)
+              } else if constexpr (u < NRG + NJ) {
+                brN[u - NRG] = rr_rot<sn>(Rm[rn][u - NRG]);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            });
+          });
+          if (sx == wave) {  // this wave's share of column DM-1
+            const double vb = pc[ko[sx]];
+            const double cb = (p == 0) ? vb : 0.0;
+#pragma unroll
+            for (int Ig = 0; Ig < NRG; ++Ig) cP[Ig] = mfma(aC[Ig], cb, cP[Ig]);
+          }
+#pragma unroll
+          for (int Ig = 0; Ig < NRG; ++Ig) aC[Ig] = aN[Ig];
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) br[jj] = brN[jj];
+        });
+        // row DM-1 (and, on wave 0, the corner): partial sums over the k of each MFMA block
+        {
+          const double va = pr[0];
+          const double ar = (p == 0) ? va : 0.0;
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) rP[jj] = mfma(ar, Rm[0][jj], rP[jj]);
+          if (wave == 0) {
+            const double vb = rb[DM + 16 * it + rowC];
+            const double cb = (p == 0) ? vb : 0.0;
+            rP[NJ] = mfma(ar, cb, rP[NJ]);
+          }
+        }
+#pragma unroll
+        for (int Ig = 0; Ig + 1 < NRG; ++Ig)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) Rm[Ig][jj] = Rm[Ig + 1][jj];
+        pa += 16;
+        pr += 16;
+        pc += 16;
+      }
+    }
+    RR_TICK(0)
+    if (q == 0) {
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) rpart[b * DMP + col0 + 4 * jj + p] = rP[jj];
+      if (wave == 0 && p == 0) rpart[b * DMP + DM - 1] = rP[NJ];
+    }
+    if (p == 0) {
+#pragma unroll
+      for (int Ig = 0; Ig < NRG; ++Ig) cpart[wave * DMP + 16 * Ig + rowC] = cP[Ig];
+    }
+    cornerA = img[(DM - 1) * LD + DM - 1];
+    cornerR = rb[BS - 1];
+    // k = DM-1: rank-1 update of the core
+    {
+      double a80[NRG], b80[NJ];
+#pragma unroll
+      for (int Ig = 0; Ig < NRG; ++Ig) a80[Ig] = img[(16 * Ig + rowC) * LD + DM - 1];
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) b80[jj] = rb[col0 + 4 * jj + p];
+#pragma unroll
+      for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) acc[Ig][jj] = fma(a80[Ig], b80[jj], acc[Ig][jj]);
+    }
+  };
+  // after the barrier: the border of the product, one element per lane
+  auto finalize = [&](int sr, int si, int sd) {
+    if (tid < BS) {
+      double v, f;
+      if (tid < DM || tid == BS - 1) {
+        const int j = tid < DM ? tid : DM - 1;
+        v = (rpart[j] + rpart[DMP + j]) + (rpart[2 * DMP + j] + rpart[3 * DMP + j]);
+        f = brd[sr * BS + tid];
+        v = fma(cornerA, f, v);
+      } else {
+        const int i = tid - DM;
+        v = (cpart[i] + cpart[DMP + i]) + (cpart[2 * DMP + i] + cpart[3 * DMP + i]);
+        f = img[i * LD + DM - 1];
+        v = fma(f, cornerR, v);
+      }
+      if (si >= 0) v += brd[si * BS + tid];
+      brd[sd * BS + tid] = v;
+    }
+  };
+  auto image_from_C = [&]() {
+#pragma unroll
+    for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p] = acc[Ig][jj];
+  };
+  auto R_from_C = [&]() {
+#pragma unroll
+    for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) Rm[Ig][jj] = acc[Ig][jj];
+  };
+  // dst[row][col] = f C (f = e^{trace shift}), row-major REAL DR x DR; borders from slot.  DR = A.Dm <= DM is the true
+  // dimension (smaller matrices run zero padded: the padding stays decoupled through every product).
+  const int DR = A.Dm;
+  auto store_out = [&](double* dst_, int slot, double f) {
+    double* dst = rr_ubase(dst_);
+#pragma unroll
+    for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) {
+        const int row = 16 * Ig + rowC, col = col0 + 4 * jj + p;
+        if (row < DR && col < DR) dst[(long)row * DR + col] = f * acc[Ig][jj];
+      }
+    if (tid < BS - 1) {
+      const double v = brd[slot * BS + tid];
+      const int row = tid < DM ? DM - 1 : tid - DM, col = tid < DM ? tid : DM - 1;
+      if (row < DR && col < DR) dst[(long)row * DR + col] = f * v;
+    }
+  };
+
+  const long nchains = (long)A.B * A.S;
+  const long mat_c = (long)DR * DR;  // complex elements of an output slot; the real result goes to its second half
+  for (long chain = blockIdx.x; chain < nchains; chain += gridDim.x) {
+    const int sample = (int)(chain / A.S);
+    if (!c3p_hb_sample_is_real(A.hb_tabflag, A.tab_per_sample ? sample : 0, K)) continue;  // the complex kernel's
+    const int seg = (int)(chain - (long)sample * A.S);
+    const int n0 = (int)(((long)seg * A.N) / A.S);
+    const int n1 = (int)(((long)(seg + 1) * A.N) / A.S);
+    const int len = n1 - n0;
+    const double* tabs = A.hb_tables + (long)(A.tab_per_sample ? sample : 0) * (1 + K) * G::TAB_D;
+    auto meta = [&](int k1) -> const double* { return tabs + (long)k1 * G::TAB_D + (TSET + BS); };
+    __syncthreads();  // the previous chain is done with the LDS
+    // plan: squarings from ||G0||_1 + sum_k max_t |c_k(t)| ||G_k||_1 over the segment
+    double nrm = meta(0)[1];
+    for (int k = 0; k < K; ++k) {
+      const double* s = A.signals + ((long)sample * K + k) * A.N + n0;
+      double cmax = 0.0;
+      for (int t = tid; t < len; t += RR_THREADS) cmax = fmax(cmax, fabs(s[t]));
+      for (int o = 32; o >= 1; o >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, o));
+      if (lane == 0) red[wave] = cmax;
+      __syncthreads();
+      cmax = 0.0;
+      for (int w = 0; w < RR_WAVES; ++w) cmax = fmax(cmax, red[w]);
+      __syncthreads();
+      nrm = fma(cmax, meta(k + 1)[1], nrm);
+    }
+    nrm = rr_rfl(nrm);
+    int s18 = 0;
+    {
+      double pth = C3P_T18_THETA;
+      while (pth < nrm && s18 < 40) {
+        pth *= 2.0;
+        ++s18;
+      }
+    }
+    const int ps = __builtin_amdgcn_readfirstlane(s18);
+    const double scale = ldexp(1.0, -ps);
+
+    double mu = 0.0, mus = 0.0;
+    auto stage_signals = [&](int t) {  // slices [t, t + RR_CH) of the segment
+      for (int e = tid; e < K * RR_CH; e += RR_THREADS) {
+        const int k = e / RR_CH, tt = e - k * RR_CH;
+        sg[e] = (t + tt < len) ? A.signals[((long)sample * K + k) * A.N + n0 + t + tt] : 0.0;
+      }
+    };
+    // X = 2^-s (G0 + sum_k c_k G_k) for slice tt of the staged chunk (tables: L2 resident, shared by all workgroups):
+    // tiles -> Xs, Rm and the image, borders -> slot M0 and the image; trace shift of the slice -> mu
+    auto assemble = [&](int tt) {
+      mu = meta(0)[0];
+      double bv = 0.0;
+      if (tid < BS) bv = scale * tabs[TSET + tid];
+      for (int k = 0; k < K; ++k) {
+        const double c = sg[k * RR_CH + tt];
+        mu = fma(c, meta(k + 1)[0], mu);
+        if (tid < BS) bv = fma(scale * c, tabs[(long)(k + 1) * G::TAB_D + TSET + tid], bv);
+      }
+      if (tid < BS) {
+        brd[S_M0 * BS + tid] = bv;
+        border_to_image(bv);
+      }
+      for (int k1 = 0; k1 <= K; ++k1) {
+        const double* src = rr_ubase(tabs + (long)k1 * G::TAB_D);
+        double v[NRG][NJ];
+#pragma unroll
+        for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) v[Ig][jj] = src[(Ig * NJ + jj) * RR_THREADS + tid];
+        __builtin_amdgcn_sched_barrier(0);
+        const double w = k1 ? scale * sg[(k1 - 1) * RR_CH + tt] : scale;
+#pragma unroll
+        for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) Xs[Ig][jj] = k1 ? fma(w, v[Ig][jj], Xs[Ig][jj]) : w * v[Ig][jj];
+      }
+#pragma unroll
+      for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+          Rm[Ig][jj] = Xs[Ig][jj];
+          img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p] = Xs[Ig][jj];
+        }
+    };
+
+    int t = 0;
+    bool first = true;
+    int ucur = S_U0;
+    stage_signals(0);
+    __syncthreads();
+    assemble(0);
+    zero_acc();
+    int op = OP_P1, sr = S_M0, si = -1, sd = S_M1, sq_left = 0;
+    __syncthreads();
+#ifdef C3P_REGR_TIMING
+    tq = clock64();
+#endif
+    for (;;) {
+      refresh();
+      product(sr);
+      RR_TICK(1)
+      rr_bar();  // A: everyone is done with the image; border partials are visible
+      RR_TICK(2)
+      refresh();
+      finalize(sr, si, sd);
+      const int op_in = op;
+      bool next_slice = false;
+      if (op == OP_P1) {  // C = A2: kept, and the right operand of the next product (the image still holds X)
+#pragma unroll
+        for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) A2s[Ig][jj] = acc[Ig][jj];
+        R_from_C();
+        zero_acc();
+        op = OP_P2, sr = S_M1, si = -1, sd = S_M2;
+      } else if (op == OP_P2) {  // C = A3 = X A2: A3 becomes both operands
+        image_from_C();
+        if (tid < BS) border_to_image(brd[S_M2 * BS + tid]);
+        R_from_C();
+        zero_acc();
+        op = OP_P3, sr = S_M2, si = -1, sd = S_M3;
+      } else if (op == OP_P3) {  // C = A6: the T18 combinations of X, A2, A3 (image), A6 (C)
+#pragma unroll
+        for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) {
+            const double dg = (16 * Ig + rowC == col0 + 4 * jj + p) ? 1.0 : 0.0;
+            const double x = Xs[Ig][jj], a2 = A2s[Ig][jj], a6 = acc[Ig][jj];
+            const double a3 = img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p];  // the left operand of A6 = A3 A3
+            // B1 -> image (left operand of A9 = B1 B5 + B4)
+            img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p] = fma(C3P_T18_A31, a3, fma(C3P_T18_A21, a2, C3P_T18_A11 * x));
+            // B2, B3 stay in registers (in the places of X and A2)
+            Xs[Ig][jj] = fma(C3P_T18_B61, a6, fma(C3P_T18_B31, a3, fma(C3P_T18_B21, a2, C3P_T18_B11 * x)));
+            A2s[Ig][jj] = fma(C3P_T18_B62, a6, fma(C3P_T18_B32, a3, fma(C3P_T18_B22, a2, fma(C3P_T18_B12, x, C3P_T18_B02 * dg))));
+            // B5 -> right operand, B4 -> initial value of the accumulators
+            Rm[Ig][jj] = fma(C3P_T18_B64, a6, fma(C3P_T18_B34, a3, C3P_T18_B24 * a2));
+            acc[Ig][jj] = fma(C3P_T18_B63, a6, fma(C3P_T18_B33, a3, fma(C3P_T18_B23, a2, fma(C3P_T18_B13, x, C3P_T18_B03 * dg))));
+          }
+        if (tid < BS) {
+          const double dg = (tid == DM - 1 || tid == BS - 1) ? 1.0 : 0.0;
+          const double x = brd[S_M0 * BS + tid], a2 = brd[S_M1 * BS + tid], a3 = brd[S_M2 * BS + tid], a6 = brd[S_M3 * BS + tid];
+          border_to_image(fma(C3P_T18_A31, a3, fma(C3P_T18_A21, a2, C3P_T18_A11 * x)));
+          brd[S_M3 * BS + tid] = fma(C3P_T18_B61, a6, fma(C3P_T18_B31, a3, fma(C3P_T18_B21, a2, C3P_T18_B11 * x)));                            // B2
+          brd[S_M0 * BS + tid] = fma(C3P_T18_B62, a6, fma(C3P_T18_B32, a3, fma(C3P_T18_B22, a2, fma(C3P_T18_B12, x, C3P_T18_B02 * dg))));       // B3
+          brd[S_M1 * BS + tid] = fma(C3P_T18_B64, a6, fma(C3P_T18_B34, a3, C3P_T18_B24 * a2));                                                  // B5
+          brd[S_M2 * BS + tid] = fma(C3P_T18_B63, a6, fma(C3P_T18_B33, a3, fma(C3P_T18_B23, a2, fma(C3P_T18_B13, x, C3P_T18_B03 * dg))));       // B4
+        }
+        op = OP_P4, sr = S_M1, si = S_M2, sd = S_R0;
+      } else if (op == OP_P4) {  // C = A9: left operand B3 + A9, right operand A9, initial value B2
+#pragma unroll
+        for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p] = A2s[Ig][jj] + acc[Ig][jj];
+        if (tid < BS) border_to_image(brd[S_M0 * BS + tid] + brd[S_R0 * BS + tid]);
+        R_from_C();
+#pragma unroll
+        for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) acc[Ig][jj] = Xs[Ig][jj];
+        op = OP_EX, sr = S_R0, si = S_M3, sd = S_R1, sq_left = ps;
+      } else if (op == OP_EX) {  // C = T18 or one of its squarings
+        if (sq_left > 0) {
+          image_from_C();
+          if (tid < BS) border_to_image(brd[sd * BS + tid]);
+          R_from_C();
+          zero_acc();
+          sr = sd, sd = sd ^ 1, si = -1;
+          --sq_left;
+        } else {  // C = exp(X - mu)
+          if constexpr (DUS) {
+            store_out(reinterpret_cast<double*>(A.dUs_out + ((long)sample * A.N + n0 + t) * mat_c) + mat_c, sd, exp(mu));
+          }
+          if (first) {
+#pragma unroll
+            for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+              for (int jj = 0; jj < NJ; ++jj) Us[Ig][jj] = acc[Ig][jj];
+            if (tid < BS) brd[S_U0 * BS + tid] = brd[sd * BS + tid];
+            ucur = S_U0;
+            first = false;
+            mus = mu;
+            next_slice = true;
+          } else {  // U <- C U
+            image_from_C();
+            if (tid < BS) border_to_image(brd[sd * BS + tid]);
+#pragma unroll
+            for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+              for (int jj = 0; jj < NJ; ++jj) Rm[Ig][jj] = Us[Ig][jj];
+            zero_acc();
+            mus += mu;
+            op = OP_CH, sr = ucur, si = -1, sd = ucur ^ 1;
+          }
+        }
+      } else {  // OP_CH: C = the running product
+#pragma unroll
+        for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) Us[Ig][jj] = acc[Ig][jj];
+        ucur ^= 1;
+        next_slice = true;
+      }
+      if (next_slice) {
+        ++t;
+        if (t == len) break;
+        if ((t % RR_CH) == 0) {
+          stage_signals(t);
+          __syncthreads();
+        }
+        assemble(t % RR_CH);
+        zero_acc();
+        op = OP_P1, sr = S_M0, si = -1, sd = S_M1;
+      }
+      RR_TICK(4 + op_in)
+      rr_bar();  // B: image and border slots of this phase are visible
+      RR_TICK(3)
+    }
+#ifdef C3P_REGR_TIMING
+    if (blockIdx.x == 0 && tid == 0 && dbg)
+      for (int i = 0; i < 12; ++i) dbg[i] = tacc[i];
+#endif
+    // segment product (basis change and frame-rotation row phases are separate epilogues); the last product sits in
+    // Us = acc and its border in slot ucur
+#pragma unroll
+    for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) acc[Ig][jj] = Us[Ig][jj];
+    store_out(reinterpret_cast<double*>(A.seg_out + chain * mat_c) + mat_c, ucur, exp(mus));
+  }
+}
+
+// ---- the change of basis ------------------------------------------------------------------------------------------------
+// index a = i D + j of the row-major vectorisation, partner a' = j D + i.  Rows of T:
+//   i == j: e_a;   i < j: (e_a + e_a') / sqrt 2;   i > j: i (e_a - e_a') / sqrt 2      [a' is the (j, i) element, j < i]
+// hb_row: the (at most two) non-zeros of ROW a of T;  hb_col: the non-zeros of COLUMN a of T.
+__device__ __forceinline__ int hb_row(int a, int D, int (&idx)[2], cplx (&t)[2]) {
+  const double r = 0.70710678118654752440;
+  const int i = a / D, j = a - i * D, ap = j * D + i;
+  if (i == j) {
+    idx[0] = a, t[0] = cmake(1.0, 0.0);
+    return 1;
+  }
+  if (i < j) {
+    idx[0] = a, t[0] = cmake(r, 0.0);
+    idx[1] = ap, t[1] = cmake(r, 0.0);
+  } else {
+    idx[0] = ap, t[0] = cmake(0.0, -r);
+    idx[1] = a, t[1] = cmake(0.0, r);
+  }
+  return 2;
+}
+__device__ __forceinline__ int hb_col(int a, int D, int (&idx)[2], cplx (&t)[2]) {
+  const double r = 0.70710678118654752440;
+  const int i = a / D, j = a - i * D, ap = j * D + i;
+  if (i == j) {
+    idx[0] = a, t[0] = cmake(1.0, 0.0);
+    return 1;
+  }
+  if (i < j) {  // T[a, a] = r (row a is the symmetric combination), T[a', a] = -i r
+    idx[0] = a, t[0] = cmake(r, 0.0);
+    idx[1] = ap, t[1] = cmake(0.0, -r);
+  } else {  // T[a', a] = r (row a' is the symmetric combination), T[a, a] = +i r
+    idx[0] = ap, t[0] = cmake(r, 0.0);
+    idx[1] = a, t[1] = cmake(0.0, r);
+  }
+  return 2;
+}
+
+// Real generator tables in the kernel's layout: G' = Re(T G T^+) with G the Lindblad generator pieces
+// L0 = dt (clp - i (H0 (x) I - I (x) H0^T)), Lk = -i dt (Hk (x) I - I (x) Hk^T) (propagation.py:565-582), trace shifted;
+// flag = 1 when |Im(T G T^+)| <= 1e-14 max |T G T^+| everywhere (a Hermitian Hamiltonian).
+__global__ void __launch_bounds__(256) regr_prep_kernel(RegdPrepArgs P, double* tables, int* tabflag) {
+  __shared__ double red0[256], red1[256];
+  __shared__ double mu_s;
+  const int tid = threadIdx.x;
+  const int ti = blockIdx.x % (1 + P.K);
+  const int sample = blockIdx.x / (1 + P.K);
+  const int D = P.Dm, Dh = P.Dh;
+  const int DP = c3p_regd_class(D);
+  const int NRG = (DP - 1) / 16, NJ = NRG;
+  const cplx* h = (ti == 0) ? P.h0 + (long)sample * P.h0_bstride : P.hks + (long)sample * P.hks_bstride + (long)(ti - 1) * Dh * Dh;
+  auto gelem = [&](int row, int col) -> cplx {
+    const int i = row / Dh, j = row - i * Dh, k = col / Dh, l = col - k * Dh;
+    cplx v = (ti == 0) ? P.clp[(long)row * D + col] : cmake(0, 0);
+    if (j == l) {
+      const cplx x = h[i * Dh + k];
+      v.x += x.y;
+      v.y -= x.x;
+    }
+    if (i == k) {
+      const cplx x = h[l * Dh + j];
+      v.x -= x.y;
+      v.y += x.x;
+    }
+    return cscale(v, P.dt);
+  };
+  // element (a, b) of T G T^+
+  auto helem = [&](int a, int b) -> cplx {
+    int ia[2], ib[2];
+    cplx ta[2], tb[2];
+    const int na = hb_row(a, Dh, ia, ta), nb = hb_row(b, Dh, ib, tb);
+    cplx s = cmake(0.0, 0.0);
+    for (int x = 0; x < na; ++x)
+      for (int y = 0; y < nb; ++y) cfma(s, cmul(ta[x], cconj(tb[y])), gelem(ia[x], ib[y]));
+    return s;
+  };
+  double tr = 0;
+  for (int i = tid; i < D; i += 256) tr += gelem(i, i).x;  // the trace is invariant
+  red0[tid] = tr;
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0;
+    for (int i = 0; i < 256; ++i) a += red0[i];
+    mu_s = a / D;
+  }
+  __syncthreads();
+  const double mu = mu_s;
+  double cs = 0, mre = 0, mim = 0;
+  for (int j = tid; j < D; j += 256) {
+    double s = 0;
+    for (int i = 0; i < D; ++i) {
+      const cplx v = helem(i, j);
+      mre = fmax(mre, fabs(v.x));
+      mim = fmax(mim, fabs(v.y));
+      s += fabs(i == j ? v.x - mu : v.x);
+    }
+    cs = fmax(cs, s);
+  }
+  __syncthreads();
+  red0[tid] = cs;
+  red1[tid] = mre;
+  __syncthreads();
+  double nrm = 0, gmax = 0;
+  if (tid == 0)
+    for (int i = 0; i < 256; ++i) {
+      nrm = fmax(nrm, red0[i]);
+      gmax = fmax(gmax, red1[i]);
+    }
+  __syncthreads();
+  red0[tid] = mim;
+  __syncthreads();
+  const int TSET = NRG * NJ * 256, BS = 2 * DP;
+  const long TAB_D = (long)TSET + BS + 4;
+  double* out = tables + ((long)sample * (1 + P.K) + ti) * TAB_D;
+  for (int e = tid; e < TSET + BS; e += 256) {
+    int row, col;
+    if (e < TSET) {
+      const int tile = e >> 8, t = e & 255;
+      const int w = t >> 6, l = t & 63;
+      const int Ig = tile / NJ, jj = tile - Ig * NJ;
+      row = 16 * Ig + 4 * ((l >> 2) & 3) + (l >> 4);
+      col = 4 * NJ * w + 4 * jj + (l & 3);
+    } else {
+      const int eb = e - TSET;
+      row = eb < DP ? DP - 1 : eb - DP;
+      col = eb < DP ? eb : DP - 1;
+    }
+    double g = 0.0;
+    if (row < D && col < D) {
+      g = helem(row, col).x;
+      if (row == col) g -= mu;
+    }
+    out[e] = g;
+  }
+  if (tid == 0) {
+    double gim = 0;
+    for (int i = 0; i < 256; ++i) gim = fmax(gim, red0[i]);
+    double* m = out + (TSET + BS);
+    m[0] = mu;
+    m[1] = nrm;
+    m[2] = gim;
+    m[3] = gmax;
+    tabflag[sample * (1 + P.K) + ti] = (gim <= 1e-14 * gmax) ? 1 : 0;
+  }
+}
+
+// In place: the REAL Dm x Dm matrix M' in the second half of every complex slot -> the complex matrix T^+ M' T in the slot.
+// One workgroup per matrix; matrices of samples the complex kernel took are left alone.
+__global__ void __launch_bounds__(256) hb_to_complex_kernel(cplx* mats, int mats_per_sample, const int* tabflag, int tab_per_sample,
+                                                            int K, int Dh) {
+  const int Dm = Dh * Dh;
+  const long m = blockIdx.x;
+  const int sample = (int)(m / mats_per_sample);
+  if (!c3p_hb_sample_is_real(tabflag, tab_per_sample ? sample : 0, K)) return;
+  cplx* slot = mats + m * (long)Dm * Dm;
+  const double* src = reinterpret_cast<const double*>(slot) + (long)Dm * Dm;
+  double* sm = c3p_rr_lds;
+  for (int e = threadIdx.x; e < Dm * Dm; e += 256) sm[e] = src[e];
+  __syncthreads();
+  for (int e = threadIdx.x; e < Dm * Dm; e += 256) {
+    const int al = e / Dm, be = e - al * Dm;
+    int ia[2], ib[2];
+    cplx ta[2], tb[2];
+    const int na = hb_col(al, Dh, ia, ta), nb = hb_col(be, Dh, ib, tb);
+    cplx s = cmake(0.0, 0.0);
+    for (int x = 0; x < na; ++x)
+      for (int y = 0; y < nb; ++y) {
+        const cplx c = cmul(cconj(ta[x]), tb[y]);
+        const double v = sm[ia[x] * Dm + ib[y]];
+        s.x = fma(c.x, v, s.x);
+        s.y = fma(c.y, v, s.y);
+      }
+    slot[e] = s;
+  }
+}
+
+template <int NRG>
+hipError_t launch_rr(const MidArgs& A, hipStream_t st) {
+  const size_t lds = (size_t)RR<NRG>::LDS_D * sizeof(double);
+  const long nchains = (long)A.B * A.S;
+  const unsigned grid = (unsigned)(nchains < C3P_REGD_MAX_WGS ? nchains : C3P_REGD_MAX_WGS);
+  auto go = [&](auto kern) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    long long* dbg = nullptr;
+#ifdef C3P_REGR_TIMING
+    static long long* dbg_dev = nullptr;
+    if (!dbg_dev) (void)hipMalloc(&dbg_dev, 12 * sizeof(long long));
+    dbg = dbg_dev;
+#endif
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(RR_THREADS), lds, st, A, dbg);
+#ifdef C3P_REGR_TIMING
+    {
+      long long h[12];
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[regr timing, cycles of wave 0 / block 0, last chain] mfma %lld  borders %lld  barA %lld  barB %lld | post P1 %lld P2 %lld P3 %lld P4 %lld EX %lld CH %lld | product entry %lld\n",
+              h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10]);
+    }
+#endif
+    return hipGetLastError();
+  };
+  if (A.dUs_out) return go(regr_chain_kernel<NRG, true>);
+  return go(regr_chain_kernel<NRG, false>);
+}
+
+}  // namespace
+
+// Lindblad superoperators whose dimension D^2 falls into a class of the register-resident kernels: D = 7 (49), 8 (64 in the
+// 65 class), 9 (81)
+bool c3p_regr_supported(int Dh, int Dm) { return Dm == Dh * Dh && (Dh == 7 || Dh == 8 || Dh == 9) && c3p_regd_supported(Dm); }
+
+size_t c3p_regr_table_doubles(int Dm, int K) {
+  const int DP = c3p_regd_class(Dm);
+  const int n = (DP - 1) / 16;
+  return (size_t)(1 + K) * ((size_t)n * n * 256 + 2 * DP + 4);
+}
+
+hipError_t c3p_launch_regr_prep(const RegdPrepArgs& P, int nsamp, double* tables, int* tabflag, hipStream_t st) {
+  hipLaunchKernelGGL(regr_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K))), dim3(256), 0, st, P, tables, tabflag);
+  return hipGetLastError();
+}
+
+hipError_t c3p_launch_regr_chain(const MidArgs& A, hipStream_t st) {
+  if (A.K > RR_KMAX || !A.hb_tabflag || !A.hb_tables) return hipErrorInvalidValue;
+  switch (c3p_regd_class(A.Dm)) {
+    case 49: return launch_rr<3>(A, st);
+    case 65: return launch_rr<4>(A, st);
+    case 81: return launch_rr<5>(A, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t c3p_launch_hb_to_complex(cplx* mats, long nmat, int mats_per_sample, const int* tabflag, int tab_per_sample, int K,
+                                    int Dh, hipStream_t st) {
+  if (nmat <= 0) return hipSuccess;
+  const size_t lds = (size_t)Dh * Dh * Dh * Dh * sizeof(double);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hb_to_complex_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(hb_to_complex_kernel, dim3((unsigned)nmat), dim3(256), lds, st, mats, mats_per_sample, tabflag, tab_per_sample, K, Dh);
+  return hipGetLastError();
+}

@@ -1369,7 +1369,7 @@ hipError_t launch_chain_t(const SmallArgs& A, hipStream_t st) {
     const size_t wstride = (size_t)(4 * C::IMG + 4 * ((A.K * A.Lmax) | 1));
     const size_t lds_mw = (size_t)((1 + A.K) * (C::MAT + 4) + nW * wstride + (size_t)nW * D * D * 2) * sizeof(double);
     const bool mw = A.fuse && (A.S & 3) == 0 && (nW == 2 || nW == 4 || nW == 8) && (long)A.B * nW <= 2048 &&
-                    lds_mw * (8 / nW) <= (size_t)156 * 1024 && !getenv("C3P_NO_MW");
+                    lds_mw * (8 / nW) <= (size_t)156 * 1024 && !c3p_opt_on(C3P_OPT_no_mw);
     if (mw) {
       // Two waves share a SIMD (nW = 8) and the arbiter serves the older one first: with equal segments wave w leaves its
       // loop at 64 % of the kernel time and wave w + 4 runs the rest alone, at the (slower) one-wave rate.  Give the older
@@ -1378,7 +1378,7 @@ hipError_t launch_chain_t(const SmallArgs& A, hipStream_t st) {
       SmallArgs A2 = A;
       if (nW == 8 && A.N >= 4 * A.S) {
         int skew = 640;
-        if (const char* e = getenv("C3P_MW_SKEW")) skew = atoi(e);
+        if (c3p_opt(C3P_OPT_mw_skew) >= 0) skew = (int)c3p_opt(C3P_OPT_mw_skew);
         if (skew > 500 && skew < 900) {
           const int h = A.S / 2;
           int La = (int)(((long)A.N * skew) / (500L * A.S));  // = skew / 1000 of the 2 N / S slices of a pair of chains
@@ -2496,7 +2496,7 @@ hipError_t c3p_launch_smalld_grad(const SmallGradArgs& A_, hipStream_t st) {
   A.skip_real = 0;
   // real Hamiltonians first (reverse mode through the cos / sin evaluation), then the general sweep for the rest; the
   // per-slice generator cotangents (zout) only exist in the general sweep
-  if (A.zout == nullptr && !getenv("C3P_NO_REAL_GRAD")) {
+  if (A.zout == nullptr && !c3p_opt_on(C3P_OPT_no_real_grad)) {
     const hipError_t e = c3p_launch_smalld_grad_real(A, st);
     if (e != hipSuccess) return e;
     A.skip_real = 1;

@@ -1028,9 +1028,9 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
   // 501 / 759 ms with graphs against 495 / 754 ms without -- the sweep is bound by the latency of its ~47 dependent small
   // kernels per slice (a 192-deep GEMM on a 96 x 128 half image is 12 K-panels of ~0.8 us each), not by launch overhead.
   // Graphs need a capturable stream: not the legacy default stream, not a stream that is itself being captured.
-  bool use_graph = st != nullptr && getenv("C3P_TILED_GRAPH") != nullptr;
-  const bool no_batch = getenv("C3P_TILED_NO_BATCH") != nullptr;  // A/B switch: one launch per product in the backward slices
-  const char* t32e = getenv("C3P_TILED_TILE32");
+  bool use_graph = st != nullptr && c3p_opt_on(C3P_OPT_tiled_graph);
+  const bool no_batch = c3p_opt_on(C3P_OPT_tiled_no_batch);  // A/B switch: one launch per product in the backward slices
+  const long t32e = c3p_opt(C3P_OPT_tiled_tile32);
   if (use_graph) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) use_graph = false;
@@ -1107,7 +1107,7 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
     dim3 gg = ggrid;
     gg.z = (unsigned)nb;
     // small batches: 32 x 32 output tiles in the backward levels (see tg_gemm_tasks32_kernel); C3P_TILED_TILE32=0/1 overrides
-    const bool tile32 = t32e ? atoi(t32e) != 0 : ((long)ggrid.x * ggrid.y * nb * 2 < 1024);
+    const bool tile32 = t32e >= 0 ? t32e != 0 : ((long)ggrid.x * ggrid.y * nb * 2 < 1024);
     auto M = [&](int slot) -> double* { return mats + (long)slot * MS; };
     auto gemm = [&](int a, int b, int add, int c) {
       hipLaunchKernelGGL(tg_gemm_kernel, gg, dim3(256), 0, st, M(a), M(b), add >= 0 ? M(add) : nullptr, M(c), 2 * g.DPR, g.DPC, VS, VS,

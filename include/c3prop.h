@@ -46,6 +46,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: exactly the entry points declared here are exported */
+#pragma GCC visibility push(default)
 
 /* flags */
 #define C3P_HOST_PTRS 0x1     /* all data pointers are host memory                    */
@@ -72,6 +74,16 @@ extern "C" {
 #define C3P_STEP_SCHRODINGER 0
 #define C3P_STEP_VON_NEUMANN 1
 #define C3P_STEP_LINDBLAD 2
+
+/* Tuning / diagnostic options: one process-wide table of integers (kernel selection switches, segment counts; the list
+ * with one line per option is C3P_OPTION_LIST in c3_amd/csrc/c3p_kernels.h).  `value` is a decimal integer, "all" (= 2)
+ * or NULL / "unset" (back to the default, -1).  The table is initialised ONCE, at the first use, from environment
+ * variables of the same names in upper case with the prefix C3P_ (C3P_NO_REGD=1 python ...): later changes of the
+ * environment are not seen -- use this call.  Thread-safe (atomic loads / stores); a call in flight on another thread
+ * sees either value.  No reference counterpart (the reference has no kernel selection).  Unknown name: -1 and
+ * c3p_last_error(); c3p_get_option returns -2 for an unknown name, -1 for an option that is not set. */
+int c3p_set_option(const char* name, const char* value);
+long c3p_get_option(const char* name);
 
 int c3p_version(void);
 int c3p_device_count(void);
@@ -177,7 +189,7 @@ int c3p_rk4_unitary(const void* h0, const void* hks, const double* signals, cons
  *   grad_signals[b,k,n] = d loss / d signals[b,k,n]      (exact: Frechet derivative of every slice)
  *   U_bar c128 [B,D,D]; grad_signals f64 [B,K,N]; other arguments as c3p_pwc_unitary (branch A only,
  *   Hermitian h0 / hks: the adjoint sweep uses the unitarity of the slices; checked for host pointers).
- *   gen_bar_out c128 [B,N,D,D] or NULL: Z[b,n], the cotangent of the slice generator G_n = -i dt H_n
+ *   gen_bar_out c128 [B,N,D,D] or NULL (D <= 64): Z[b,n], the cotangent of the slice generator G_n = -i dt H_n
  *   (d loss = Re sum conj(Z) dG); the gradient w.r.t. MODEL parameters follows by contraction, e.g.
  *   d loss / d h0 = i dt sum_n Z[b,n] (what ModelLearning differentiates, c3/optimizers/modellearning.py:300-341).
  * With C3P_PER_SLICE_H (branch B of pwc, propagation.py:295-308): h0 = the per-slice Hamiltonians [N,D,D] (h0_bstride 0) or
@@ -198,7 +210,7 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
  * The slices are not unitary, so the adjoint state cannot be propagated backwards through inverses: the forward partial
  * products are kept in HBM (N matrices of D^4 complex per sample, processed in chunks of samples that fit 24 GB) and the
  * backward sweep evaluates value and Frechet derivative of every slice's exponential together on the tiled MFMA GEMM
- * (c3p_tiled.hip).  c3p_pwc_unitary_vjp uses the same sweep above D = 40 (any dimension; gen_bar_out only up to D = 40).
+ * (c3p_tiled.hip).  c3p_pwc_unitary_vjp uses the same sweep above D = 40 (any dimension; gen_bar_out up to D = 64: above 40 on the VALU sweep).
  * D <= 6 (superoperators up to 36 x 36): three kernels per call instead of ~35 launches per slice -- segment products, a scan
  * that leaves prefix and left adjoint at the segment boundaries, and a sweep that stores the prefix of every slice of its
  * segment and evaluates the pair at X_n^H on the way back (general-generator form on the matrix cores: c3p_smalld.hip for
@@ -286,6 +298,7 @@ int c3p_gate_overlap(const void* U, int B, int D, const int32_t* comp_rows, int 
 int c3p_gate_infid(const void* U, int B, int D, const int32_t* comp_rows, int L, const void* ideal, int kind,
                    int flags, double* infid_out, double* sum_out, void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -69,9 +69,9 @@ def main():
             ph = torch.as_tensor(np.stack([(p[:, None] - p[None, :]).ravel() for p in wl.fr_phase]), device=dev)
             for env in ("", "1"):
                 if env:
-                    os.environ["C3P_NO_REGD"] = "1"
+                    _lib.set_option("no_regd", "1")
                 else:
-                    os.environ.pop("C3P_NO_REGD", None)
+                    _lib.set_option("no_regd", None)
                 for rep in range(2):
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
@@ -84,7 +84,7 @@ def main():
                 else:
                     Ubig = r["U"].cpu().numpy()
             print("regd vs bigd max |dU|_F:", max(np.linalg.norm(Ureg[b] - Ubig[b]) for b in range(B)))
-        os.environ.pop("C3P_NO_REGD", None)
+        _lib.set_option("no_regd", None)
     return 0 if worst < 1e-10 else 1
 
 

@@ -64,12 +64,12 @@ if "--time" in sys.argv:
         sig = rng.uniform(-1, 1, size=(B, 2, N))
         a3 = [torch.as_tensor(x, device=dev) for x in (h0, hks, sig)]
         for env in ("", "1"):
-            if env: os.environ["C3P_NO_TILED"] = "1"
-            else: os.environ.pop("C3P_NO_TILED", None)
+            if env: _lib.set_option("no_tiled", "1")
+            else: _lib.set_option("no_tiled", None)
             for rep in range(2):
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 propagation.propagate_batch(a3[0], a3[1], a3[2], 1.0)
                 torch.cuda.synchronize(); t1 = time.perf_counter()
             print(f"unitary D={D} B={B} N={N} {'generic' if env else 'tiled'}: {t1 - t0:.3f} s", flush=True)
-        os.environ.pop("C3P_NO_TILED", None)
+        _lib.set_option("no_tiled", None)
 sys.exit(0 if worst < 1e-10 else 1)

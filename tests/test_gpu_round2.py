@@ -56,11 +56,11 @@ def test_regd_lindblad_partials_and_old_kernel(prop):
     r = prop.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt, col_ops=wl.col_ops, lindbladian=True, want_dUs=True)
     d = o.tf_propagation_lind(wl.h0, wl.hks, wl.col_ops, wl.signals[1], wl.dt)
     assert np.abs(np.asarray(r["dUs"][1]) - d).max() < 1e-13
-    os.environ["C3P_NO_REGD"] = "1"
+    _lib.set_option("no_regd", "1")
     try:
         old = prop.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt, col_ops=wl.col_ops, lindbladian=True)
     finally:
-        os.environ.pop("C3P_NO_REGD")
+        _lib.set_option("no_regd", None)
     assert fro_max(r["U"], old["U"]) < 1e-12
 
 

@@ -36,12 +36,12 @@ def test_segment_combine_does_not_alias_its_input(prop, B, N, no_regd):
     """propagation.py:551-585 + tf_utils.py:144-193 at cfg4's operators with few samples and many time segments."""
     wl = workloads.make_workload(4, B=B, N=N)
     if no_regd:
-        os.environ["C3P_NO_REGD"] = "1"
+        _lib.set_option("no_regd", "1")
     try:
         r = prop.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt, col_ops=wl.col_ops, lindbladian=True)
         again = prop.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt, col_ops=wl.col_ops, lindbladian=True)
     finally:
-        os.environ.pop("C3P_NO_REGD", None)
+        _lib.set_option("no_regd", None)
     ref = o.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt, col_ops=wl.col_ops, lindbladian=True)
     assert fro_max(r["U"], ref) < TOL
     assert np.array_equal(np.asarray(r["U"]), np.asarray(again["U"]))
@@ -120,12 +120,12 @@ def test_ode_row_matches_workgroup_kernel_and_cfg2(prop):
     psi[0, 0] = 1.0
     new = {s: np.asarray(prop.ode_solve_batch(wl.h0, wl.hks, wl.signals, wl.dt, psi, s, "schrodinger")) for s in ("rk4", "rk5")}
     assert _lib.last_kernel() == "ode_row"
-    os.environ["C3P_ODE_WG"] = "1"
+    _lib.set_option("ode_wg", "1")
     try:
         old = {s: np.asarray(prop.ode_solve_batch(wl.h0, wl.hks, wl.signals, wl.dt, psi, s, "schrodinger")) for s in ("rk4", "rk5")}
         assert _lib.last_kernel() == "ode_wg"
     finally:
-        os.environ.pop("C3P_ODE_WG")
+        _lib.set_option("ode_wg", None)
     for s in new:
         assert np.abs(new[s] - old[s]).max() < 1e-12
     for b in (0, 17, 36):
@@ -497,11 +497,11 @@ def test_regd_padded_classes_unitary(prop, D):
         ref = o.pwc_arrays(h0, hks, sig[b], 1.0)
         assert np.linalg.norm(np.asarray(r["U"][b]) - np.exp(1j * ph[b])[:, None] * ref["U"]) < TOL
         assert np.abs(np.asarray(r["dUs"][b]) - ref["dUs"]).max() < 1e-12
-    os.environ["C3P_REGD_PAD"] = "0"  # the arena kernel these dimensions ran on before
+    _lib.set_option("regd_pad", "0")  # the arena kernel these dimensions ran on before
     try:
         old = prop.propagate_batch(h0, hks, sig, 1.0, fr_phase=ph)
     finally:
-        os.environ.pop("C3P_REGD_PAD")
+        _lib.set_option("regd_pad", None)
     assert fro_max(r["U"], old["U"]) < 1e-11
 
 
@@ -530,11 +530,11 @@ def test_ode_row_time_segments_small_batches(prop, D, K, real):
     psi = rng.normal(size=(B, D, 1)) + 1j * rng.normal(size=(B, D, 1))
     for solver in ("rk4", "rk38", "rk5", "tsit5"):
         seg = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], psi, solver, "schrodinger", final_only=True))
-        os.environ["C3P_ODE_NO_SEG"] = "1"
+        _lib.set_option("ode_no_seg", "1")
         try:
             direct = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], psi, solver, "schrodinger", final_only=True))
         finally:
-            os.environ.pop("C3P_ODE_NO_SEG")
+            _lib.set_option("ode_no_seg", None)
         assert np.abs(seg - direct).max() < 1e-12 * max(1.0, np.abs(direct).max())
         for b in (0, B - 1):
             ref = o.ode_solver_arrays(h0, hks, sig[b], ts, psi[b], solver, "schrodinger", final_only=True)["states"]
@@ -604,12 +604,12 @@ def test_ode_rhoq_matches_workgroup_kernel_per_sample_states(prop):
     rho /= np.trace(rho, axis1=1, axis2=2)[:, None, None]
     new = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], rho, "tsit5", "von_neumann", final_only=True))
     assert _lib.last_kernel() == "ode_mfma"
-    os.environ["C3P_ODE_WG"] = "1"
+    _lib.set_option("ode_wg", "1")
     try:
         old = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], rho, "tsit5", "von_neumann", final_only=True))
         assert _lib.last_kernel() == "ode_wg"
     finally:
-        os.environ.pop("C3P_ODE_WG")
+        _lib.set_option("ode_wg", None)
     assert np.abs(new - old).max() < 1e-12
     assert np.abs(np.trace(new, axis1=1, axis2=2) - 1.0).max() < 1e-12
 
@@ -657,11 +657,11 @@ def test_ode_rhoq_full_size_properties(prop, cfg, step):
     assert _lib.last_kernel() == "ode_mfma"
     assert np.abs(np.trace(out, axis1=1, axis2=2) - 1.0).max() < 1e-11
     assert np.abs(out - out.conj().transpose(0, 2, 1)).max() < 1e-13
-    os.environ["C3P_ODE_RHO_GENERAL"] = "1"
+    _lib.set_option("ode_rho_general", "1")
     try:
         gen = run()
     finally:
-        os.environ.pop("C3P_ODE_RHO_GENERAL")
+        _lib.set_option("ode_rho_general", None)
     assert np.abs(out - gen).max() < 1e-11
     for b in (0, 15):
         ref = o.ode_solver_arrays(wl.h0, wl.hks, wl.signals[b], wl.ts, rho, "rk4", step, col=col, final_only=True)["states"]
@@ -709,12 +709,12 @@ def test_ode_mid_dimension_time_segments(prop, D, K, B, N, real):
     for solver in ("rk4", "rk5"):
         fin = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], psi, solver, "schrodinger", final_only=True))
         assert _lib.last_kernel() == "ode_mfma"
-        os.environ["C3P_ODE_NO_SEG"] = "1"
+        _lib.set_option("ode_no_seg", "1")
         try:
             direct = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], psi, solver, "schrodinger", final_only=True))
             assert _lib.last_kernel() == "ode_row"
         finally:
-            os.environ.pop("C3P_ODE_NO_SEG")
+            _lib.set_option("ode_no_seg", None)
         assert np.abs(fin - direct).max() < 1e-12
         for b in range(B):
             ref = o.ode_solver_arrays(h0, hks, sig[b], ts, psi[b], solver, "schrodinger", final_only=True)["states"]

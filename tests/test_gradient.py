@@ -364,19 +364,19 @@ def test_lindblad_vjp_small_superoperators_general_sweep(prop, D, N, B, C, per_s
     dt = 0.3
     g = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar, fr_phase=ph))
     assert _lib.last_kernel() == ("smalld" if D <= 3 else "mfma")
-    os.environ["C3P_TILED_GRAD"] = "1"
+    _lib.set_option("tiled_grad", "1")
     try:
         gt = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar, fr_phase=ph))
         assert _lib.last_kernel() == "mfma"
     finally:
-        os.environ.pop("C3P_TILED_GRAD")
+        _lib.set_option("tiled_grad", None)
     assert np.abs(g - gt).max() < 1e-10 * np.abs(gt).max()
-    os.environ["C3P_VALU_GRAD"] = "1"  # the VALU form of the same sweep
+    _lib.set_option("valu_grad", "1")  # the VALU form of the same sweep
     try:
         gv = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar, fr_phase=ph))
         assert _lib.last_kernel() == ("generic_lds" if D <= 4 else "generic_global")
     finally:
-        os.environ.pop("C3P_VALU_GRAD")
+        _lib.set_option("valu_grad", None)
     assert np.abs(gv - gt).max() < 1e-10 * np.abs(gt).max()
     for b in range(B):
         want = o.pwc_lindblad_signal_gradient(h0[b] if per_sample else h0, hks[b] if per_sample else hks, col, sig[b], dt, Ubar[b], ph[b])
@@ -398,14 +398,14 @@ def test_lindblad_vjp_sample_chunks(prop, D):
     Ubar = rng.normal(size=(B, Dm, Dm)) + 1j * rng.normal(size=(B, Dm, Dm))
     ph = rng.uniform(0, 2 * np.pi, size=(B, Dm))
     one = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, 0.3, col, Ubar, fr_phase=ph))
-    os.environ["C3P_GRAD_CHUNK"] = "2"
+    _lib.set_option("grad_chunk", "2")
     try:
         many = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, 0.3, col, Ubar, fr_phase=ph))
-        os.environ["C3P_VALU_GRAD"] = "1"
+        _lib.set_option("valu_grad", "1")
         valu = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, 0.3, col, Ubar, fr_phase=ph))
     finally:
-        os.environ.pop("C3P_GRAD_CHUNK")
-        os.environ.pop("C3P_VALU_GRAD", None)
+        _lib.set_option("grad_chunk", None)
+        _lib.set_option("valu_grad", None)
     assert np.abs(one - many).max() < 1e-12 * np.abs(one).max()
     assert np.abs(one - valu).max() < 1e-10 * np.abs(one).max()
     want = o.pwc_lindblad_signal_gradient(h0[4], hks[4], col, sig[4], 0.3, Ubar[4], ph[4])
@@ -466,11 +466,11 @@ def test_unitary_vjp_above_40_on_the_tiled_sweep(prop, D, N):
     ph = rng.uniform(0, 2 * np.pi, size=(B, D))
     import os
 
-    os.environ["C3P_TILED_GRAD"] = "1"  # (41 <= D <= 64 takes the VALU sweep at this batch size by default)
+    _lib.set_option("tiled_grad", "1")  # (41 <= D <= 64 takes the VALU sweep at this batch size by default)
     try:
         g = np.asarray(prop.propagate_batch_vjp(h0, hks, sig, 1.0, Ubar, fr_phase=ph))
     finally:
-        os.environ.pop("C3P_TILED_GRAD")
+        _lib.set_option("tiled_grad", None)
     assert _lib.last_kernel() == "mfma"
     for b in range(B):
         want = o.pwc_signal_gradient(h0, hks, sig[b], 1.0, Ubar[b], ph[b])
@@ -545,11 +545,11 @@ def test_per_slice_vjp_on_chip_sweeps(prop, D, N, B, hermitian):
     dt = 1.1
     got = np.asarray(prop.propagate_per_slice_vjp(Hs, dt, Ubar, fr_phase=ph))
     assert _lib.last_kernel() == ("smalld" if D <= 12 else "mfma")
-    os.environ["C3P_TILED_GRAD"] = "1"
+    _lib.set_option("tiled_grad", "1")
     try:
         tiled = np.asarray(prop.propagate_per_slice_vjp(Hs, dt, Ubar, fr_phase=ph))
     finally:
-        os.environ.pop("C3P_TILED_GRAD")
+        _lib.set_option("tiled_grad", None)
     assert np.abs(got - tiled).max() < 1e-10 * np.abs(tiled).max()
     for b in range(B):
         want = o.pwc_per_slice_hamiltonian_cotangents(Hs[b], dt, Ubar[b], ph[b])

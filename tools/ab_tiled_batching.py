@@ -2,6 +2,7 @@ import os, sys, time, json
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 from c3_amd import propagation as prop
+from c3_amd import _lib
 from c3_amd.workloads import make_workload
 dev = "cuda:0"; t = lambda x: torch.as_tensor(x, device=dev)
 def timed(fn, reps=2):
@@ -20,7 +21,7 @@ for B in (16, 64, 256):
         r[tag + "_g"] = g
         if env: os.environ.pop(env)
     print("cfg4 N=400 B=%d: batched %.1f ms, per product %.1f ms, x%.2f, rel diff %.1e" % (B, r["batched"], r["per_product"], r["per_product"] / r["batched"], float((r["batched_g"] - r["per_product_g"]).abs().max() / r["per_product_g"].abs().max())), flush=True)
-os.environ["C3P_TILED_GRAD"] = "1"
+_lib.set_option("tiled_grad", "1")
 for D, B in ((48, 64), (64, 64), (64, 512)):
     rng = np.random.default_rng(D)
     herm = lambda sc: (lambda m: sc * (m + m.conj().T) / 2)(rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))

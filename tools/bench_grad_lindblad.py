@@ -39,12 +39,12 @@ for case in a.cases.split(","):
     vjp = timed(lambda: prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar))
     gt, tiled = g, float("nan")
     if not a.no_tiled:
-        os.environ["C3P_TILED_GRAD"] = "1"
+        _lib.set_option("tiled_grad", "1")
         try:
             gt = prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar)
             tiled = timed(lambda: prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar), reps=1)
         finally:
-            os.environ.pop("C3P_TILED_GRAD")
+            _lib.set_option("tiled_grad", None)
     row = {"D": D, "Dm": Dm, "B": B, "N": N, "kernel": kern, "forward_ms": fwd * 1e3, "vjp_ms": vjp * 1e3, "vjp_over_forward": vjp / fwd,
            "tiled_vjp_ms": tiled * 1e3, "speedup_vs_tiled": tiled / vjp, "gradients_per_s": B / vjp,
            "max_rel_diff_vs_tiled": float((g - gt).abs().max() / gt.abs().max())}

@@ -27,12 +27,12 @@ for case in a.cases.split(","):
     g = prop.propagate_per_slice_vjp(Hs, 1.0, Ubar)
     kern = _lib.last_kernel()
     vjp = timed(lambda: prop.propagate_per_slice_vjp(Hs, 1.0, Ubar))
-    os.environ["C3P_TILED_GRAD"] = "1"
+    _lib.set_option("tiled_grad", "1")
     try:
         gt = prop.propagate_per_slice_vjp(Hs, 1.0, Ubar)
         tiled = timed(lambda: prop.propagate_per_slice_vjp(Hs, 1.0, Ubar), reps=1)
     finally:
-        os.environ.pop("C3P_TILED_GRAD")
+        _lib.set_option("tiled_grad", None)
     row = {"D": D, "B": B, "N": N, "kernel": kern, "forward_ms": fwd * 1e3, "vjp_ms": vjp * 1e3, "vjp_over_forward": vjp / fwd,
            "tiled_vjp_ms": tiled * 1e3, "speedup_vs_tiled": tiled / vjp, "max_rel_diff_vs_tiled": float((g - gt).abs().max() / gt.abs().max())}
     rows.append(row)

@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from c3_amd import propagation as prop
+from c3_amd import _lib
 from c3_amd.workloads import make_workload
 
 ap = argparse.ArgumentParser()
@@ -50,10 +51,8 @@ for D, B in ((48, 64), (64, 64)):
     Ubar = torch.randn(B, D, D, dtype=torch.complex128, device=dev)
     tf = timed(lambda: prop.propagate_batch(h0, hks, sig, 1.0))
     tg = timed(lambda: prop.propagate_batch_vjp(h0, hks, sig, 1.0, Ubar))
-    os.environ["C3P_FORCE_VALU_GRAD"] = "1"
     rows.append({"case": f"unitary D={D}", "B": B, "N": N, "Dm": D, "forward_ms": tf * 1e3, "vjp_ms": tg * 1e3, "vjp_over_forward": tg / tf,
                  "gradients_per_s": B / tg})
-    os.environ.pop("C3P_FORCE_VALU_GRAD")
     if D <= 64:
         tv = timed(lambda: prop.propagate_batch_vjp(h0, hks, sig, 1.0, Ubar, force_generic=True))
         rows[-1]["valu_sweep_ms (round 2 path)"] = tv * 1e3

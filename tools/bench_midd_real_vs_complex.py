@@ -3,6 +3,7 @@ import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from c3_amd import propagation as p
+from c3_amd import _lib
 
 dev = torch.device("cuda:0")
 out = {}
@@ -17,9 +18,9 @@ for D in (13, 16, 20, 24, 27, 32, 36, 40):
     res = {}
     for mode in ("real", "complex"):
         if mode == "complex":
-            os.environ["C3P_NO_REAL"] = "1"
+            _lib.set_option("no_real", "1")
         else:
-            os.environ.pop("C3P_NO_REAL", None)
+            _lib.set_option("no_real", None)
         for _ in range(3):
             U = p.propagate_batch(H0, HK, S, 1e-11)["U"]
         torch.cuda.synchronize()
@@ -32,5 +33,5 @@ for D in (13, 16, 20, 24, 27, 32, 36, 40):
     res["max_abs_diff"] = float(np.abs(res.pop("real_U") - res.pop("complex_U")).max())
     res["speedup"] = res["complex_ms"] / res["real_ms"]
     out[D] = res
-os.environ.pop("C3P_NO_REAL", None)
+_lib.set_option("no_real", None)
 print(json.dumps(out))
