@@ -99,7 +99,18 @@ def plan_batch(cfg, scaling, batch, world, rank):
     return per * world, rank * per, (rank + 1) * per, per
 
 
+def _claim_stdout():
+    """File descriptor 1 is handed to stderr for the whole run and a private duplicate of the real stdout is returned:
+    libraries that print banners from C (RCCL's version block at communicator set-up) then cannot put anything in front of
+    the ONE JSON line the driver parses."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    return real
+
+
 def main():
+    real_stdout = _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -108,7 +119,10 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--batch", type=int, default=None, help="weak: samples per GPU; strong: GLOBAL batch")
     ap.add_argument("--slices", type=int, default=None)
-    ap.add_argument("--gather-every", type=int, default=32, help="steps exchanged per all-gather (multi-GPU)")
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="steps exchanged per all-gather (multi-GPU).  Default 1 = north_star's schedule: ONE all-gather of U per batch; "
+                         "the amortised schedule (32) and the gather-free goal exchange are timed beside it and reported as extra keys")
+    ap.add_argument("--no-alt-schedules", action="store_true", help="multi-GPU: skip the side measurements of the other exchange schedules")
     ap.add_argument("--ramp-ms", type=float, default=60.0, help="untimed device clock ramp before the W warmup steps (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive side measurement")
@@ -173,39 +187,76 @@ def main():
     # The only data-path collective is the all-gather of the U slabs (RCCL over xGMI), in stream order, G steps per
     # collective.  (An asynchronous gather beside the chain kernel was measured SLOWER: the RCCL kernel takes CUs away
     # from a grid sized to fill the chip exactly and creates a partial second round.)
-    ring = c3dist.SlabRing(B, b_pad, (Dm, Dm), args.gather_every, device=dev, use_dist=use_dist and args.exchange == "gather")
-    G = ring.G
+    if args.exchange == "goal" and wl.lindblad:
+        raise SystemExit("--exchange goal: unitary configurations only")
+    goal_state = {}
+
+    def make_schedule(exchange, gather_every):
+        """(ring, compute) of one exchange schedule: `gather` = all-gather of the U slabs of `gather_every` steps in one
+        collective; `goal` = fused fidelity per sample + ONE all-reduce of the goal per step, nothing gathered."""
+        ring = c3dist.SlabRing(B, b_pad, (Dm, Dm), gather_every, device=dev, use_dist=use_dist and exchange == "gather")
+        if exchange == "goal":
+            from c3_amd import fidelities
+
+            comp_index = list(range(len(wl.dims)))
+            ideal = torch.eye(2 ** len(wl.dims), dtype=torch.complex128, device=dev)
+            goal_buf = torch.zeros(2, dtype=torch.float64, device=dev)  # {sum of infidelities, samples}
+
+        def compute(out):
+            if bp is not None:
+                bp.run(out=out[:B])
+            if exchange == "goal":
+                # the optimiser loop of SURVEY 8e/8f-1: B infidelities per rank instead of B propagators, one all-reduce
+                # of the goal per step (optimalcontrol_robust.py:49-70 averages them) -- no gather at all
+                g = goal_buf
+                if bp is not None:
+                    g = fidelities.infid_sum(ideal, out[:B], comp_index, list(wl.dims), kind="unitary")["sum"]  # {sum, B}: one launch
+                else:
+                    goal_buf.zero_()
+                if use_dist:
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                goal_state["last"] = g
+
+        return ring, compute
+
+    def time_schedule(ring, compute, steps, warmup):
+        """W untimed warmup steps, then exactly K steps between barrier + synchronize on both sides; returns (wall seconds,
+        MAX over ranks; device ms per step by HIP events on the launch stream)."""
+        G_ = ring.G
+        ring.warm({min(G_, max(1, steps)), steps % G_, warmup % G_, min(G_, max(1, warmup))})  # communicator + every message size
+        for _ in range(warmup):
+            ring.step(compute)
+        ring.drain()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()  # HIP events on the stream the kernels are launched on (torch's current stream), over the timed region
+        for _ in range(steps):
+            ring.step(compute)
+        ev1.record()
+        ring.drain()
+        torch.cuda.synchronize()
+        # The K steps end here on this rank (the last all-gather inside drain() has already waited for every rank's
+        # slabs); the closing barrier follows and the MAX over ranks of the per-rank times is reported, so the
+        # barrier's own latency is not booked as step time.
+        el = time.perf_counter() - t0
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dev_ms = ev0.elapsed_time(ev1) / max(1, steps)
+        if use_dist:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, dev_ms
 
     goal_mode = args.exchange == "goal"
-    if goal_mode and wl.lindblad:
-        raise SystemExit("--exchange goal: unitary configurations only")
-    if goal_mode:
-        from c3_amd import fidelities
-
-        comp_index = list(range(len(wl.dims)))
-        L = 2 ** len(wl.dims)
-        ideal = torch.eye(L, dtype=torch.complex128, device=dev)
-        goal_buf = torch.zeros(2, dtype=torch.float64, device=dev)  # {sum of infidelities, samples}
-        goal_last = [None]
-
-    def compute(out):
-        if bp is not None:
-            bp.run(out=out[:B])
-        if goal_mode:
-            # the optimiser loop of SURVEY 8e/8f-1: B infidelities per rank instead of B propagators, one all-reduce
-            # of the goal per step (optimalcontrol_robust.py:49-70 averages them) -- no gather at all
-            g = goal_buf
-            if bp is not None:
-                g = fidelities.infid_sum(ideal, out[:B], comp_index, list(wl.dims), kind="unitary")["sum"]  # {sum, B}: one launch
-            else:
-                goal_buf.zero_()
-            if use_dist:
-                dist.all_reduce(g, op=dist.ReduceOp.SUM)
-            goal_last[0] = g
-
+    ring, compute = make_schedule(args.exchange, args.gather_every)
+    G = ring.G
     lib = _lib.load()
-    # the communicator and every message size of the run are set up before anything is timed
-    ring.warm({min(G, max(1, args.steps)), args.steps % G, args.warmup % G, min(G, max(1, args.warmup))})
     torch.cuda.synchronize()
     # Untimed clock ramp: the MI355X needs tens of milliseconds of sustained work to reach its steady clocks
     # (measured: 0.210 ms per cfg2 batch after 5 warmup batches, 0.194 ms after 300).  The metric is sustained
@@ -216,33 +267,25 @@ def main():
             for _ in range(16):
                 bp.run(out=ring.buf[0][:B])
             torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        ring.step(compute)
-    ring.drain()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()  # HIP events on the stream the kernels are launched on (torch's current stream), over the timed region
-    for _ in range(args.steps):
-        ring.step(compute)
-    ev1.record()
-    ring.drain()
-    torch.cuda.synchronize()
-    # The K steps end here on this rank (the last all-gather inside drain() has already waited for every rank's
-    # slabs); the closing barrier follows and the MAX over ranks of the per-rank times is reported, so the
-    # barrier's own latency is not booked as step time.
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    device_ms_per_step = ev0.elapsed_time(ev1) / max(1, args.steps)
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, device_ms_per_step = time_schedule(ring, compute, args.steps, args.warmup)
+    goal_last = [goal_state.get("last")]
+    # The other exchange schedules, timed the same way right after the headline one and reported as extra keys of the
+    # SAME line (multi-GPU runs only): the amortised all-gather (32 steps per collective) and the gather-free goal
+    # exchange (fused fidelity + one all-reduce per step; unitary configurations).
+    alt = {}
+    if use_dist and not args.no_alt_schedules:
+        todo = []
+        if not (args.exchange == "gather" and G == 32):
+            todo.append(("all_gather_every_32_steps", "gather", 32))
+        if not (args.exchange == "gather" and G == 1):
+            todo.append(("all_gather_every_step", "gather", 1))
+        if not wl.lindblad and args.exchange != "goal":
+            todo.append(("goal_all_reduce_every_step", "goal", 1))
+        for name, ex, ge in todo:
+            r2, c2 = make_schedule(ex, ge)
+            el2, dms2 = time_schedule(r2, c2, args.steps, args.warmup)
+            alt[name] = {"value": B_glob * args.steps / el2, "ms_per_step": el2 / args.steps * 1e3, "device_ms_per_step": dms2}
+            del r2, c2
     kernel_name = _lib.last_kernel()
 
     err = None
@@ -377,7 +420,7 @@ def main():
 
             out["cpu_baseline"] = cpu_baseline(wl, c3_oracle)
             out["cpu_baseline_allcores"] = cpu_baseline_allcores(args.config, wl)
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 

@@ -1247,7 +1247,7 @@ int run_pwc_regd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   int* tabflag = reinterpret_cast<int*>(static_cast<char*>(v) + ctab + rtab);
   if (hb) LAUNCH_TRY(c3p_launch_regr_prep(p, nsamp, rtables, tabflag, st));
   void* av;
-  if (ws_get(w, SL_SCRATCH, c3p_regd_arena_bytes(Dm), &av)) return -1;
+  if (ws_get(w, SL_SCRATCH, std::max(c3p_regd_arena_bytes(Dm), hb ? c3p_regr_arena_bytes(Dm) : (size_t)0), &av)) return -1;
   MidArgs a = {};
   a.tables = (const double*)v;
   a.tab_per_sample = per_sample ? 1 : 0;
@@ -1273,7 +1273,7 @@ int run_pwc_regd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   a.seg_out = seg;
   g_last_kernel = C3P_KERNEL_MFMA;
   if (record_start(w, st)) return -1;
-  if (hb) LAUNCH_TRY(c3p_launch_regr_chain(a, st));
+  if (hb) LAUNCH_TRY(c3p_launch_regr_chain(a, av, st));
   LAUNCH_TRY(c3p_launch_regd_chain(a, av, st));
   if (record_stop(w, st)) return -1;
   if (hb) {

@@ -11,6 +11,8 @@
   X(no_regd)            /* 41 <= Dm <= 81: arena kernel (c3p_bigd.hip) instead of the register-resident ones */       \
   X(regd_pad)           /* 0: no zero-padded classes; 2: pad everything in 41..81; unset: the measured default */      \
   X(no_hermitian_basis) /* Lindblad chains at D = 7..9 on the complex kernel (c3p_regd.hip) instead of c3p_regr.hip */ \
+  X(regr_waves)         /* c3p_regr.hip, -DC3P_REGR_VARIANTS builds only: 8 = two waves per SIMD, 2 = two lean workgroups per CU */ \
+  X(regr_rolled)        /* c3p_regr.hip, -DC3P_REGR_VARIANTS builds only: rolled product loop */                                \
   X(no_tiled)           /* Dm >= 93: generic kernel instead of the tiled path */                                       \
   X(no_mw)              /* small D: one-wave workgroups + ticket instead of workgroup-per-sample */                    \
   X(mw_skew)            /* per mille of a pair's slices given to the older wave */                                     \

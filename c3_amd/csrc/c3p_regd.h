@@ -41,6 +41,7 @@ size_t c3p_regr_table_doubles(int Dm, int K);  // per sample: (1 + K) real gener
 hipError_t c3p_launch_regr_prep(const RegdPrepArgs& P, int nsamp, double* tables, int* tabflag, hipStream_t st);
 // MidArgs with hb_tables / hb_tabflag set; the REAL segment products (and slice propagators) are written to the second
 // half of their complex slots in seg_out (dUs_out): c3p_launch_hb_to_complex turns them into the complex matrices in place
-hipError_t c3p_launch_regr_chain(const MidArgs& A, hipStream_t st);
+size_t c3p_regr_arena_bytes(int Dm);  // scratch of the two-workgroups-per-CU form
+hipError_t c3p_launch_regr_chain(const MidArgs& A, void* arena, hipStream_t st);
 hipError_t c3p_launch_hb_to_complex(cplx* mats, long nmat, int mats_per_sample, const int* tabflag, int tab_per_sample, int K,
                                     int Dh, hipStream_t st);

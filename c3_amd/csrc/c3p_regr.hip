@@ -35,8 +35,7 @@ extern __shared__ __attribute__((aligned(16))) double c3p_rr_lds[];
 
 namespace {
 
-constexpr int RR_WAVES = 4;
-constexpr int RR_THREADS = 64 * RR_WAVES;
+constexpr int RR_MAXWAVES = 8;
 constexpr int RR_CH = 32;    // control amplitudes staged per chunk of slices
 constexpr int RR_KMAX = 16;  // control lines
 enum { S_M0 = 0, S_M1, S_M2, S_M3, S_R0, S_R1, S_U0, S_U1, S_NSLOT };
@@ -45,17 +44,16 @@ enum { OP_P1 = 0, OP_P2, OP_P3, OP_P4, OP_EX, OP_CH };
 template <int NRG>
 struct RR {
   static constexpr int DM = 16 * NRG + 1;
-  static constexpr int NJ = NRG;       // column blocks per wave
-  static constexpr int NT = NRG * NJ;  // tiles per wave
+  static constexpr int NT = NRG * NRG;  // tiles per column group (4 NRG columns: one wave, or a pair of waves on one SIMD)
   // image row stride (doubles): A-fragment reads (16 rows x 4 columns per 32 lanes) at most two-way on the 32 bank
   // pairs for every rotation, the 16-lane tile stores conflict free (brute-forced: 17 mod 32, or 2 mod 4)
   static constexpr int LD = (NRG == 4) ? DM + 1 : DM;
   static constexpr int BS = 2 * DM;  // border slot: row DM-1 (DM elements, corner last), column DM-1 (DM elements, corner last)
   static constexpr int DMP = DM + 1;
   static constexpr int IMG_D = DM * LD;
-  static constexpr int TSET = NT * RR_THREADS;  // elements of a tile set: element (tile, thread) at tile * 256 + thread
+  static constexpr int TSET = NT * 256;  // elements of a tile set: element (tile, column group, lane) at tile * 256 + group * 64 + lane
   static constexpr int TAB_D = TSET + BS + 4;   // doubles per generator table: tile set, border slot, {mu, norm1, 0, 0}
-  static constexpr int LDS_D = IMG_D + S_NSLOT * BS + 8 * DMP + RR_KMAX * RR_CH + 2 * RR_WAVES;
+  static constexpr int LDS_D = IMG_D + S_NSLOT * BS + 8 * DMP + RR_KMAX * RR_CH + 2 * RR_MAXWAVES;
 };
 
 template <typename F, int... Is>
@@ -99,13 +97,26 @@ __device__ __forceinline__ double rr_rfl(double v) {
   return __hiloint2double(hi, lo);
 }
 
-template <int NRG, bool DUS>
-__global__ void __launch_bounds__(RR_THREADS, 1) regr_chain_kernel(MidArgs A, long long* dbg) {
+// The chain loop of one wave.  NW = 4: one wave per SIMD, wave w owns the 4 NRG columns of column group w (NJ = NRG column
+// blocks).  NW = 8: two waves per SIMD (waves w and w + 4 share one), the column blocks of a group are split between them
+// (NJ = ceil(NRG / 2) for the first, floor for the second: jj0 = first block of this wave inside its group) -- the
+// non-MFMA instructions of one wave (A-fragment reads, tile rotations) issue under the MFMAs of the other.
+// LEAN: the two-workgroups-per-CU form (256 registers per wave, half the LDS): only the operands of the running product
+// (Rm, acc) and ONE parked set (X^2, then B3) stay in registers; X is re-assembled from the (L2-resident) tables where the
+// T18 combinations need it, and B2 and the running product U are parked in a per-workgroup global arena (two sets,
+// 0.2 MB per slice and chain against the 1.0 MB of the complex kernel).  What it buys: the second workgroup's MFMAs run
+// under this one's latencies -- the phases between products (element-wise work, LDS round trips, barriers, table loads)
+// are ~40 % of a slice with one workgroup per CU.
+template <int NRG, int NJ, int NW, bool DUS, bool UNROLL, bool LEAN>
+__device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg, double* arena_base, const int cg, const int jj0, const int wave) {
   using G = RR<NRG>;
-  constexpr int DM = G::DM, NJ = G::NJ, LD = G::LD, BS = G::BS, DMP = G::DMP;
+  constexpr int DM = G::DM, LD = G::LD, BS = G::BS, DMP = G::DMP;
   constexpr int TSET = G::TSET;
+  constexpr int RR_THREADS = 64 * NW;
+  const bool second = jj0 != 0;                         // the second wave of a pair
+  const bool col_owner = (NW == 4) || second;           // column DM-1 of a product: the lighter wave of the pair
+  const bool corner_owner = (cg == 0) && !second;
   const int tid0 = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   int tid = tid0, lane = tid & 63;
   int q = lane >> 4, b = (lane >> 2) & 3, p = lane & 3;
   double* img = c3p_rr_lds;
@@ -114,9 +125,9 @@ __global__ void __launch_bounds__(RR_THREADS, 1) regr_chain_kernel(MidArgs A, lo
   double* rpart = cpart + 4 * DMP;
   double* sg = rpart + 4 * DMP;
   double* red = sg + RR_KMAX * RR_CH;
-  const int col0 = 4 * NJ * wave;  // first column of this wave
-  int rowC = 4 * b + q;            // row of a C/D-layout element inside its row group
-  int rowA = 4 * b + p;            // row of an A-fragment element inside its row group
+  const int col0 = 4 * NRG * cg + 4 * jj0;  // first column of this wave
+  int rowC = 4 * b + q;                     // row of a C/D-layout element inside its row group
+  int rowA = 4 * b + p;                     // row of an A-fragment element inside its row group
   const int K = A.K;
   // lane indices are re-derived from an opaque copy of the thread id at the start of every phase: otherwise the compiler
   // hoists every address / mask that depends on them out of the slice loop and spills them
@@ -144,9 +155,24 @@ __global__ void __launch_bounds__(RR_THREADS, 1) regr_chain_kernel(MidArgs A, lo
 #endif
   double Rm[NRG][NJ];   // right operand of the next product
   double acc[NRG][NJ];  // accumulators = the product
-  double Xs[NRG][NJ];   // X, later B2
+  double Xs[LEAN ? 1 : NRG][LEAN ? 1 : NJ];  // X, later B2 (LEAN: re-assembled / parked in the arena)
   double A2s[NRG][NJ];  // X^2, later B3
-  double Us[NRG][NJ];   // running product of the segment
+  double Us[LEAN ? 1 : NRG][LEAN ? 1 : NJ];  // running product of the segment (LEAN: in the arena)
+  double* arena = arena_base + (long)blockIdx.x * 2 * TSET;  // LEAN: sets {B2, U} of this workgroup
+  auto park = [&](int set, const double (&v)[NRG][NJ]) {
+    double* dst = rr_ubase(arena + set * TSET);
+#pragma unroll
+    for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) dst[(Ig * NJ + jj) * RR_THREADS + tid] = v[Ig][jj];
+  };
+  auto unpark = [&](int set, double (&v)[NRG][NJ]) {
+    const double* src = rr_ubase(arena + set * TSET);
+#pragma unroll
+    for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) v[Ig][jj] = src[(Ig * NJ + jj) * RR_THREADS + tid];
+  };
 
   auto mfma = [](double a, double bb, double c) -> double { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, bb, c, 0, 0, 0); };
   auto zero_acc = [&]() {
@@ -163,8 +189,8 @@ __global__ void __launch_bounds__(RR_THREADS, 1) regr_chain_kernel(MidArgs A, lo
 
   // C = (init) + L R: L = the LDS image, R = Rm with borders in slot sr; the accumulators carry the initial value (its
   // border in slot si, or si < 0); border of C -> slot sd (by finalize, after the barrier that publishes the partials).
-  // Column DM-1 of C is one more B column (the border column of R, from its slot) on the K-steps with s == wave: four
-  // partial sums, one per wave; row DM-1 of C uses the tiles of R block by block (A operand = row DM-1 of L in the i = 0
+  // Column DM-1 of C is one more B column (the border column of R, from its slot): four partial sums, one per column
+  // group; row DM-1 of C uses the tiles of R block by block (A operand = row DM-1 of L in the i = 0
   // row of every block): four partial sums, one per MFMA block.  The k = DM-1 terms: finalize / the rank-1 update.
   double cornerA = 0.0, cornerR = 0.0;
   auto product = [&](int sr) {
@@ -184,7 +210,6 @@ __global__ void __launch_bounds__(RR_THREADS, 1) regr_chain_kernel(MidArgs A, lo
       // s: MFMA block b multiplies by block (b - s) mod 4 of the tile, its A fragment is taken at the k of that block.
       const double* pa = img + rowA * LD;
       const double* pr = img + (DM - 1) * LD + rowC;  // row DM-1 of L at this lane's k
-      const double* pc = rb + DM;                     // column DM-1 of R
       int ko[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) ko[s] = 4 * ((b - s) & 3) + q;
@@ -195,11 +220,18 @@ __global__ void __launch_bounds__(RR_THREADS, 1) regr_chain_kernel(MidArgs A, lo
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) br[jj] = Rm[0][jj];
       RR_TICK(10)
-#pragma unroll 1
-      for (int it = 0; it < NRG; ++it) {
+      // One pass.  IT >= 0: pass IT of the UNROLLED loop (row IT of Rm and the image offsets are static: no register
+      // rotation -- the rolled form moves the tiles of R up one row per pass, ~90 register-file copies per 106 MFMAs once R
+      // lives in the accumulation registers); IT = -1: the rolled form (row 0, pointers advance).
+      int itr = 0;
+      auto pass = [&](auto it_) {
+        constexpr int IT = decltype(it_)::value;
+        constexpr int R0 = IT < 0 ? 0 : IT;
+        constexpr int R1 = IT < 0 ? 1 : (IT + 1 < NRG ? IT + 1 : IT);
+        constexpr int OFF = IT < 0 ? 0 : 16 * IT;
         rr_static_for<4>([&](auto s_) {
           constexpr int sx = decltype(s_)::value;
-          constexpr int sn = (sx + 1) & 3, rn = (sx == 3) ? 1 : 0;  // next step: rotation, row of Rm
+          constexpr int sn = (sx + 1) & 3, rn = (sx == 3) ? R1 : R0;  // next step: rotation, row of Rm
           // source order = issue order (sched_barrier): one MFMA, then at most one piece of the next step's operand
           // preparation (an A-fragment load or a tile rotation), so that it issues in the shadow of the matrix pipe
           double brN[NJ];
@@ -207,57 +239,88 @@ __global__ void __launch_bounds__(RR_THREADS, 1) regr_chain_kernel(MidArgs A, lo
             constexpr int Ig = decltype(Ig_)::value;
             rr_static_for<NJ>([&](auto jj_) {
               constexpr int jj = decltype(jj_)::value;
-              constexpr int u = Ig * NJ + jj;  // preparation slot (NRG + NJ pieces over NRG * NJ slots)
+              constexpr int u = Ig * NJ + jj;  // preparation slot: NRG + NJ pieces over NRG * NJ slots
+              constexpr int OPS = (NRG + NJ + NRG * NJ - 1) / (NRG * NJ);
               acc[Ig][jj] = mfma(aC[Ig], br[jj], acc[Ig][jj]);
-              if constexpr (u < NRG) {
-                aN[u] = pa[16 * u * LD + (sx == 3 ? 16 : 0) + ko[sn]];  // (the very last prefetch is unused)
-              } else if constexpr (u < NRG + NJ) {
-                brN[u - NRG] = rr_rot<sn>(Rm[rn][u - NRG]);
-              }
+              rr_static_for<OPS>([&](auto o_) {
+                constexpr int op = u * OPS + decltype(o_)::value;
+                if constexpr (op < NRG) {
+                  aN[op] = pa[16 * op * LD + OFF + (sx == 3 ? 16 : 0) + ko[sn]];  // (the very last prefetch is unused)
+                } else if constexpr (op < NRG + NJ) {
+                  brN[op - NRG] = rr_rot<sn>(Rm[rn][op - NRG]);
+                }
+              });
               __builtin_amdgcn_sched_barrier(0);
             });
           });
-          if (sx == wave) {  // this wave's share of column DM-1
-            const double vb = pc[ko[sx]];
-            const double cb = (p == 0) ? vb : 0.0;
-#pragma unroll
-            for (int Ig = 0; Ig < NRG; ++Ig) cP[Ig] = mfma(aC[Ig], cb, cP[Ig]);
-          }
 #pragma unroll
           for (int Ig = 0; Ig < NRG; ++Ig) aC[Ig] = aN[Ig];
 #pragma unroll
           for (int jj = 0; jj < NJ; ++jj) br[jj] = brN[jj];
+          // a basic-block boundary per K-step (an opaque, never taken scalar branch)
+          if (rr_opq(0) != 0) asm volatile("s_sleep 1");
         });
-        // row DM-1 (and, on wave 0, the corner): partial sums over the k of each MFMA block
+        // row DM-1 (and, on one wave, the corner): partial sums over the k of each MFMA block
         {
-          const double va = pr[0];
+          const double va = pr[OFF];
           const double ar = (p == 0) ? va : 0.0;
 #pragma unroll
-          for (int jj = 0; jj < NJ; ++jj) rP[jj] = mfma(ar, Rm[0][jj], rP[jj]);
-          if (wave == 0) {
-            const double vb = rb[DM + 16 * it + rowC];
+          for (int jj = 0; jj < NJ; ++jj) rP[jj] = mfma(ar, Rm[R0][jj], rP[jj]);
+          if (corner_owner) {
+            const double vb = rb[DM + (IT < 0 ? 16 * itr : OFF) + rowC];
             const double cb = (p == 0) ? vb : 0.0;
             rP[NJ] = mfma(ar, cb, rP[NJ]);
           }
         }
+        if constexpr (IT < 0) {
 #pragma unroll
-        for (int Ig = 0; Ig + 1 < NRG; ++Ig)
+          for (int Ig = 0; Ig + 1 < NRG; ++Ig)
 #pragma unroll
-          for (int jj = 0; jj < NJ; ++jj) Rm[Ig][jj] = Rm[Ig + 1][jj];
-        pa += 16;
-        pr += 16;
-        pc += 16;
+            for (int jj = 0; jj < NJ; ++jj) Rm[Ig][jj] = Rm[Ig + 1][jj];
+          pa += 16;
+          pr += 16;
+          ++itr;
+        }
+      };
+      if constexpr (UNROLL) {
+        rr_static_for<NRG>([&](auto it_) { pass(it_); });
+      } else {
+#pragma unroll 1
+        for (int it = 0; it < NRG; ++it) pass(std::integral_constant<int, -1>{});
+      }
+    }
+    // Column DM-1 of C: one more B column (the border column of R, from its slot).  MFMA block b of column group g takes
+    // the k of block (b - g) mod 4 of every row group: over the four groups every block meets every k -- four partial
+    // sums, one per group.  Its own short loop (A fragments one row group ahead): inside the main loop, as "the K-step
+    // s == g", the branch was if-converted into four times the MFMAs on the two-waves-per-SIMD instance.
+    if (col_owner) {
+      const int kb = 4 * ((b - cg) & 3) + q;
+      const double* pa = img + rowA * LD + kb;
+      const double* pc = rb + DM + kb;
+      double aB[NRG], aBn[NRG];
+#pragma unroll
+      for (int Ig = 0; Ig < NRG; ++Ig) aB[Ig] = pa[16 * Ig * LD];
+#pragma unroll 1
+      for (int it = 0; it < NRG; ++it) {
+        const double vb = pc[16 * it];
+#pragma unroll
+        for (int Ig = 0; Ig < NRG; ++Ig) aBn[Ig] = pa[16 * Ig * LD + 16 * it + (it + 1 < NRG ? 16 : 0)];
+        const double cb = (p == 0) ? vb : 0.0;
+#pragma unroll
+        for (int Ig = 0; Ig < NRG; ++Ig) cP[Ig] = mfma(aB[Ig], cb, cP[Ig]);
+#pragma unroll
+        for (int Ig = 0; Ig < NRG; ++Ig) aB[Ig] = aBn[Ig];
       }
     }
     RR_TICK(0)
     if (q == 0) {
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) rpart[b * DMP + col0 + 4 * jj + p] = rP[jj];
-      if (wave == 0 && p == 0) rpart[b * DMP + DM - 1] = rP[NJ];
+      if (corner_owner && p == 0) rpart[b * DMP + DM - 1] = rP[NJ];
     }
-    if (p == 0) {
+    if (p == 0 && col_owner) {
 #pragma unroll
-      for (int Ig = 0; Ig < NRG; ++Ig) cpart[wave * DMP + 16 * Ig + rowC] = cP[Ig];
+      for (int Ig = 0; Ig < NRG; ++Ig) cpart[cg * DMP + 16 * Ig + rowC] = cP[Ig];
     }
     cornerA = img[(DM - 1) * LD + DM - 1];
     cornerR = rb[BS - 1];
@@ -346,7 +409,7 @@ __global__ void __launch_bounds__(RR_THREADS, 1) regr_chain_kernel(MidArgs A, lo
       if (lane == 0) red[wave] = cmax;
       __syncthreads();
       cmax = 0.0;
-      for (int w = 0; w < RR_WAVES; ++w) cmax = fmax(cmax, red[w]);
+      for (int w = 0; w < NW; ++w) cmax = fmax(cmax, red[w]);
       __syncthreads();
       nrm = fma(cmax, meta(k + 1)[1], nrm);
     }
@@ -369,6 +432,23 @@ __global__ void __launch_bounds__(RR_THREADS, 1) regr_chain_kernel(MidArgs A, lo
         sg[e] = (t + tt < len) ? A.signals[((long)sample * K + k) * A.N + n0 + t + tt] : 0.0;
       }
     };
+    // tiles of X = 2^-s (G0 + sum_k c_k G_k) for slice tt of the staged chunk (tables: L2 resident, shared by all workgroups)
+    auto assemble_tiles = [&](int tt, auto& dst) {
+      for (int k1 = 0; k1 <= K; ++k1) {
+        const double* src = rr_ubase(tabs + (long)k1 * G::TAB_D);
+        double v[NRG][NJ];
+#pragma unroll
+        for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) v[Ig][jj] = src[(Ig * NRG + jj0 + jj) * 256 + cg * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+        const double w = k1 ? scale * sg[(k1 - 1) * RR_CH + tt] : scale;
+#pragma unroll
+        for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) dst[Ig][jj] = k1 ? fma(w, v[Ig][jj], dst[Ig][jj]) : w * v[Ig][jj];
+      }
+    };
     // X = 2^-s (G0 + sum_k c_k G_k) for slice tt of the staged chunk (tables: L2 resident, shared by all workgroups):
     // tiles -> Xs, Rm and the image, borders -> slot M0 and the image; trace shift of the slice -> mu
     auto assemble = [&](int tt) {
@@ -384,27 +464,22 @@ __global__ void __launch_bounds__(RR_THREADS, 1) regr_chain_kernel(MidArgs A, lo
         brd[S_M0 * BS + tid] = bv;
         border_to_image(bv);
       }
-      for (int k1 = 0; k1 <= K; ++k1) {
-        const double* src = rr_ubase(tabs + (long)k1 * G::TAB_D);
-        double v[NRG][NJ];
+      if constexpr (LEAN) {
+        assemble_tiles(tt, Rm);
 #pragma unroll
         for (int Ig = 0; Ig < NRG; ++Ig)
 #pragma unroll
-          for (int jj = 0; jj < NJ; ++jj) v[Ig][jj] = src[(Ig * NJ + jj) * RR_THREADS + tid];
-        __builtin_amdgcn_sched_barrier(0);
-        const double w = k1 ? scale * sg[(k1 - 1) * RR_CH + tt] : scale;
+          for (int jj = 0; jj < NJ; ++jj) img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p] = Rm[Ig][jj];
+      } else {
+        assemble_tiles(tt, Xs);
 #pragma unroll
         for (int Ig = 0; Ig < NRG; ++Ig)
 #pragma unroll
-          for (int jj = 0; jj < NJ; ++jj) Xs[Ig][jj] = k1 ? fma(w, v[Ig][jj], Xs[Ig][jj]) : w * v[Ig][jj];
+          for (int jj = 0; jj < NJ; ++jj) {
+            Rm[Ig][jj] = Xs[Ig][jj];
+            img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p] = Xs[Ig][jj];
+          }
       }
-#pragma unroll
-      for (int Ig = 0; Ig < NRG; ++Ig)
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) {
-          Rm[Ig][jj] = Xs[Ig][jj];
-          img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p] = Xs[Ig][jj];
-        }
     };
 
     int t = 0;
@@ -444,17 +519,20 @@ __global__ void __launch_bounds__(RR_THREADS, 1) regr_chain_kernel(MidArgs A, lo
         zero_acc();
         op = OP_P3, sr = S_M2, si = -1, sd = S_M3;
       } else if (op == OP_P3) {  // C = A6: the T18 combinations of X, A2, A3 (image), A6 (C)
+        if constexpr (LEAN) assemble_tiles(t % RR_CH, Rm);  // X again (the right operand is spent: its registers are free)
 #pragma unroll
         for (int Ig = 0; Ig < NRG; ++Ig)
 #pragma unroll
           for (int jj = 0; jj < NJ; ++jj) {
             const double dg = (16 * Ig + rowC == col0 + 4 * jj + p) ? 1.0 : 0.0;
-            const double x = Xs[Ig][jj], a2 = A2s[Ig][jj], a6 = acc[Ig][jj];
+            const double x = LEAN ? Rm[Ig][jj] : Xs[Ig][jj], a2 = A2s[Ig][jj], a6 = acc[Ig][jj];
             const double a3 = img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p];  // the left operand of A6 = A3 A3
             // B1 -> image (left operand of A9 = B1 B5 + B4)
             img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p] = fma(C3P_T18_A31, a3, fma(C3P_T18_A21, a2, C3P_T18_A11 * x));
             // B2, B3 stay in registers (in the places of X and A2)
-            Xs[Ig][jj] = fma(C3P_T18_B61, a6, fma(C3P_T18_B31, a3, fma(C3P_T18_B21, a2, C3P_T18_B11 * x)));
+            const double b2 = fma(C3P_T18_B61, a6, fma(C3P_T18_B31, a3, fma(C3P_T18_B21, a2, C3P_T18_B11 * x)));
+            if constexpr (LEAN) rr_ubase(arena)[(Ig * NJ + jj) * RR_THREADS + tid] = b2;
+            else Xs[Ig][jj] = b2;
             A2s[Ig][jj] = fma(C3P_T18_B62, a6, fma(C3P_T18_B32, a3, fma(C3P_T18_B22, a2, fma(C3P_T18_B12, x, C3P_T18_B02 * dg))));
             // B5 -> right operand, B4 -> initial value of the accumulators
             Rm[Ig][jj] = fma(C3P_T18_B64, a6, fma(C3P_T18_B34, a3, C3P_T18_B24 * a2));
@@ -480,7 +558,10 @@ __global__ void __launch_bounds__(RR_THREADS, 1) regr_chain_kernel(MidArgs A, lo
 #pragma unroll
         for (int Ig = 0; Ig < NRG; ++Ig)
 #pragma unroll
-          for (int jj = 0; jj < NJ; ++jj) acc[Ig][jj] = Xs[Ig][jj];
+          for (int jj = 0; jj < NJ; ++jj) {
+            if constexpr (!LEAN) acc[Ig][jj] = Xs[Ig][jj];
+          }
+        if constexpr (LEAN) unpark(0, acc);
         op = OP_EX, sr = S_R0, si = S_M3, sd = S_R1, sq_left = ps;
       } else if (op == OP_EX) {  // C = T18 or one of its squarings
         if (sq_left > 0) {
@@ -495,10 +576,14 @@ __global__ void __launch_bounds__(RR_THREADS, 1) regr_chain_kernel(MidArgs A, lo
             store_out(reinterpret_cast<double*>(A.dUs_out + ((long)sample * A.N + n0 + t) * mat_c) + mat_c, sd, exp(mu));
           }
           if (first) {
+            if constexpr (LEAN) {
+              park(1, acc);
+            } else {
 #pragma unroll
-            for (int Ig = 0; Ig < NRG; ++Ig)
+              for (int Ig = 0; Ig < NRG; ++Ig)
 #pragma unroll
-              for (int jj = 0; jj < NJ; ++jj) Us[Ig][jj] = acc[Ig][jj];
+                for (int jj = 0; jj < NJ; ++jj) Us[Ig][jj] = acc[Ig][jj];
+            }
             if (tid < BS) brd[S_U0 * BS + tid] = brd[sd * BS + tid];
             ucur = S_U0;
             first = false;
@@ -507,20 +592,28 @@ __global__ void __launch_bounds__(RR_THREADS, 1) regr_chain_kernel(MidArgs A, lo
           } else {  // U <- C U
             image_from_C();
             if (tid < BS) border_to_image(brd[sd * BS + tid]);
+            if constexpr (LEAN) {
+              unpark(1, Rm);
+            } else {
 #pragma unroll
-            for (int Ig = 0; Ig < NRG; ++Ig)
+              for (int Ig = 0; Ig < NRG; ++Ig)
 #pragma unroll
-              for (int jj = 0; jj < NJ; ++jj) Rm[Ig][jj] = Us[Ig][jj];
+                for (int jj = 0; jj < NJ; ++jj) Rm[Ig][jj] = Us[Ig][jj];
+            }
             zero_acc();
             mus += mu;
             op = OP_CH, sr = ucur, si = -1, sd = ucur ^ 1;
           }
         }
       } else {  // OP_CH: C = the running product
+        if constexpr (LEAN) {
+          if (t + 1 < len) park(1, acc);  // (the last one is written out from the accumulators)
+        } else {
 #pragma unroll
-        for (int Ig = 0; Ig < NRG; ++Ig)
+          for (int Ig = 0; Ig < NRG; ++Ig)
 #pragma unroll
-          for (int jj = 0; jj < NJ; ++jj) Us[Ig][jj] = acc[Ig][jj];
+            for (int jj = 0; jj < NJ; ++jj) Us[Ig][jj] = acc[Ig][jj];
+        }
         ucur ^= 1;
         next_slice = true;
       }
@@ -545,11 +638,25 @@ __global__ void __launch_bounds__(RR_THREADS, 1) regr_chain_kernel(MidArgs A, lo
 #endif
     // segment product (basis change and frame-rotation row phases are separate epilogues); the last product sits in
     // Us = acc and its border in slot ucur
+    if constexpr (!LEAN) {
 #pragma unroll
-    for (int Ig = 0; Ig < NRG; ++Ig)
+      for (int Ig = 0; Ig < NRG; ++Ig)
 #pragma unroll
-      for (int jj = 0; jj < NJ; ++jj) acc[Ig][jj] = Us[Ig][jj];
+        for (int jj = 0; jj < NJ; ++jj) acc[Ig][jj] = Us[Ig][jj];
+    }
     store_out(reinterpret_cast<double*>(A.seg_out + chain * mat_c) + mat_c, ucur, exp(mus));
+  }
+}
+
+template <int NRG, int NW, bool DUS, bool UNROLL, bool LEAN>
+__global__ void __launch_bounds__(64 * NW, LEAN ? 2 : NW / 4) regr_chain_kernel(MidArgs A, double* arena, long long* dbg) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  if constexpr (NW == 4) {
+    regr_chain_body<NRG, NRG, 4, DUS, UNROLL, LEAN>(A, dbg, arena, wave, 0, wave);
+  } else {
+    constexpr int NJ0 = (NRG + 1) / 2, NJ1 = NRG / 2;
+    if (wave < 4) regr_chain_body<NRG, NJ0, 8, DUS, UNROLL, false>(A, dbg, arena, wave, 0, wave);
+    else regr_chain_body<NRG, NJ1, 8, DUS, UNROLL, false>(A, dbg, arena, wave - 4, NJ0, wave);
   }
 }
 
@@ -728,11 +835,12 @@ __global__ void __launch_bounds__(256) hb_to_complex_kernel(cplx* mats, int mats
   }
 }
 
-template <int NRG>
-hipError_t launch_rr(const MidArgs& A, hipStream_t st) {
+template <int NRG, int NW, bool LEAN>
+hipError_t launch_rr(const MidArgs& A, void* arena, hipStream_t st) {
   const size_t lds = (size_t)RR<NRG>::LDS_D * sizeof(double);
   const long nchains = (long)A.B * A.S;
-  const unsigned grid = (unsigned)(nchains < C3P_REGD_MAX_WGS ? nchains : C3P_REGD_MAX_WGS);
+  const long maxg = LEAN ? 2 * C3P_REGD_MAX_WGS : C3P_REGD_MAX_WGS;
+  const unsigned grid = (unsigned)(nchains < maxg ? nchains : maxg);
   auto go = [&](auto kern) -> hipError_t {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -742,20 +850,26 @@ hipError_t launch_rr(const MidArgs& A, hipStream_t st) {
     if (!dbg_dev) (void)hipMalloc(&dbg_dev, 12 * sizeof(long long));
     dbg = dbg_dev;
 #endif
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(RR_THREADS), lds, st, A, dbg);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, A, reinterpret_cast<double*>(arena), dbg);
 #ifdef C3P_REGR_TIMING
     {
       long long h[12];
       (void)hipStreamSynchronize(st);
       (void)hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost);
-      fprintf(stderr, "[regr timing, cycles of wave 0 / block 0, last chain] mfma %lld  borders %lld  barA %lld  barB %lld | post P1 %lld P2 %lld P3 %lld P4 %lld EX %lld CH %lld | product entry %lld\n",
+      fprintf(stderr, "[regr timing, cycles of wave 0 / block 0, all its chains] mfma %lld  borders %lld  barA %lld  barB %lld | post P1 %lld P2 %lld P3 %lld P4 %lld EX %lld CH %lld | product entry %lld\n",
               h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10]);
     }
 #endif
     return hipGetLastError();
   };
-  if (A.dUs_out) return go(regr_chain_kernel<NRG, true>);
-  return go(regr_chain_kernel<NRG, false>);
+#ifdef C3P_REGR_VARIANTS
+  const bool unroll = c3p_opt(C3P_OPT_regr_rolled) <= 0;
+  if (A.dUs_out) return unroll ? go(regr_chain_kernel<NRG, NW, true, true, LEAN>) : go(regr_chain_kernel<NRG, NW, true, false, LEAN>);
+  return unroll ? go(regr_chain_kernel<NRG, NW, false, true, LEAN>) : go(regr_chain_kernel<NRG, NW, false, false, LEAN>);
+#else
+  if (A.dUs_out) return go(regr_chain_kernel<NRG, NW, true, true, LEAN>);
+  return go(regr_chain_kernel<NRG, NW, false, true, LEAN>);
+#endif
 }
 
 }  // namespace
@@ -775,14 +889,33 @@ hipError_t c3p_launch_regr_prep(const RegdPrepArgs& P, int nsamp, double* tables
   return hipGetLastError();
 }
 
-hipError_t c3p_launch_regr_chain(const MidArgs& A, hipStream_t st) {
+// arena: c3p_regr_arena_bytes() of scratch (the two-workgroups-per-CU form parks two tile sets per workgroup there)
+size_t c3p_regr_arena_bytes(int Dm) {
+  const int n = (c3p_regd_class(Dm) - 1) / 16;
+  return (size_t)2 * C3P_REGD_MAX_WGS * 2 * n * n * 256 * sizeof(double);
+}
+
+hipError_t c3p_launch_regr_chain(const MidArgs& A, void* arena, hipStream_t st) {
   if (A.K > RR_KMAX || !A.hb_tabflag || !A.hb_tables) return hipErrorInvalidValue;
-  switch (c3p_regd_class(A.Dm)) {
-    case 49: return launch_rr<3>(A, st);
-    case 65: return launch_rr<4>(A, st);
-    case 81: return launch_rr<5>(A, st);
-    default: return hipErrorInvalidValue;
-  }
+  // The regular build holds ONE form: four waves (one per SIMD, 512 registers), the product loop unrolled over the row groups
+  // of the right operand.  -DC3P_REGR_VARIANTS (tools/ab_build.sh) adds the forms it was measured against
+  // (profiles/r04/regr_variants.txt): regr_waves = 8 (two waves per SIMD, column blocks split), regr_waves = 2 (two lean
+  // workgroups per CU, B2 and U parked in a global arena), regr_rolled = 1 (rolled product loop).
+  const int cls = c3p_regd_class(A.Dm);
+#ifdef C3P_REGR_VARIANTS
+  const long mode = c3p_opt(C3P_OPT_regr_waves);
+#define C3P_RR_CASE(N)                                        \
+  if (mode == 8) return launch_rr<N, 8, false>(A, arena, st); \
+  if (mode == 2) return launch_rr<N, 4, true>(A, arena, st);  \
+  return launch_rr<N, 4, false>(A, arena, st);
+#else
+#define C3P_RR_CASE(N) return launch_rr<N, 4, false>(A, arena, st);
+#endif
+  if (cls == 49) { C3P_RR_CASE(3) }
+  if (cls == 65) { C3P_RR_CASE(4) }
+  if (cls == 81) { C3P_RR_CASE(5) }
+#undef C3P_RR_CASE
+  return hipErrorInvalidValue;
 }
 
 hipError_t c3p_launch_hb_to_complex(cplx* mats, long nmat, int mats_per_sample, const int* tabflag, int tab_per_sample, int K,

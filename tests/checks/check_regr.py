@@ -1,12 +1,18 @@
 """Lindblad chains in the Hermitian basis (c3p_regr.hip) against the complex kernel (c3p_regd.hip) and the oracle.
-   python tests/checks/check_regr.py [--time]"""
+   python tests/checks/check_regr.py [--time] [--waves 8|2] [--rolled]   (the last two: tools/ab_build.sh variants c3p_regr.hip -DC3P_REGR_VARIANTS, C3P_LIB=...)"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np, torch
 from c3_amd import propagation as prop, _lib, workloads
 from oracle import c3_oracle as o
 
+if os.environ.get("C3P_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["C3P_LIB"])
 dev = torch.device("cuda:0")
+if "--waves" in sys.argv:
+    _lib.set_option("regr_waves", sys.argv[sys.argv.index("--waves") + 1])
+if "--rolled" in sys.argv:
+    _lib.set_option("regr_rolled", 1)
 t = lambda a: torch.as_tensor(a, device=dev)
 rng = np.random.default_rng(7)
 worst = 0.0

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from c3_amd import workloads
+from c3_amd import _lib, workloads
 from oracle import c3_oracle as o
 
 pytestmark = pytest.mark.gpu

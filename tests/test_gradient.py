@@ -4,6 +4,7 @@ import os
 import numpy as np
 import pytest
 
+from c3_amd import _lib
 from c3_amd.workloads import make_workload
 from oracle import c3_oracle as o
 
