@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP64_TFLOPS = 78.6  # MI355X dense fp64 (vector = matrix; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 # thresholds of the reference's expm (tf.linalg.expm, Higham 2005 Pade 3/5/7/9/13 chosen from ||A||_1)
 _PADE_THETA = (1.495585217958292e-2, 2.539398330063230e-1, 9.504178996162932e-1, 2.097847961257068, 5.371920351148152)
@@ -72,16 +72,25 @@ def algorithmic_flops_per_prop(wl):
     return float(tot)
 
 
-def kernel_sources_digest():
-    """sha1 over the sources of the propagator path this bench times (the ODE state solvers and the signal kernels are
-    separate translation units that it never launches): PMC numbers in profiles/ are only quoted for the build they were
-    taken on."""
+# translation units that hold the DOMINANT kernel of each BASELINE configuration (+ the headers they include): an edit of
+# another kernel family (gradients, ODE solvers, the API layer) does not invalidate a configuration's PMC profile
+_KERNEL_SOURCES = {
+    1: ("c3p_smalld.hip", "c3p_smalld.h", "c3p_common.h"),
+    2: ("c3p_smalld.hip", "c3p_smalld.h", "c3p_common.h"),
+    3: ("c3p_midd.hip", "c3p_midd.h", "c3p_common.h"),
+    4: ("c3p_regr.hip", "c3p_regd.h", "c3p_midd.h", "c3p_common.h"),
+    5: ("c3p_midd.hip", "c3p_midd.h", "c3p_common.h"),
+}
+
+
+def kernel_sources_digest(config=2):
+    """sha1 over the sources of the chain kernel this configuration runs on: PMC numbers in profiles/ are only quoted for
+    the build of that kernel they were taken on."""
     h = hashlib.sha1()
     d = os.path.join(ROOT, "c3_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")) and not name.startswith(("c3p_ode", "c3p_signal")):
-            h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+    for name in _KERNEL_SOURCES.get(int(config), ()):
+        h.update(name.encode())
+        h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:12]
 
 
@@ -335,26 +344,27 @@ def main():
         traffic = issued = useful = None
         pmc_exact = False
         pfile = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc.json")
-        digest = kernel_sources_digest()
+        digest = kernel_sources_digest(args.config)
         ent = {}
         if os.path.exists(pfile) and not args.generic:
             try:
                 ent = json.load(open(pfile)).get(f"cfg{args.config}{'_complex' if args.complex_ops else ''}", {})
             except Exception:
                 ent = {}
-        if ent.get("issued_flop_per_launch") and ent.get("batch") and ent.get("slices"):
-            per = 1.0 / (ent["batch"] * ent["slices"]) * (B * wl.N)
-            issued = ent["issued_flop_per_launch"] * per
-            useful = ent.get("useful_flop_per_launch", ent["issued_flop_per_launch"]) * per
-            pmc_exact = ent.get("kernel_sources_digest") == digest and ent["batch"] == B and ent["slices"] == wl.N
-            if pmc_exact:
-                traffic = ent.get("hbm_bytes_per_launch")
+        # The hardware figures are quoted ONLY for the exact build, batch and slice count that was profiled: nothing is
+        # scaled from another run and nothing is clamped (a stale profile must not pass as a measurement of this build).
+        if ent.get("issued_flop_per_launch") and ent.get("kernel_sources_digest") == digest and ent.get("batch") == B and ent.get("slices") == wl.N:
+            pmc_exact = True
+            issued = ent["issued_flop_per_launch"]
+            useful = ent.get("useful_flop_per_launch", issued)
+            traffic = ent.get("hbm_bytes_per_launch")
         if useful is not None:
             achieved = useful / t_step / 1e12
+            frac = achieved / PEAK_FP64_TFLOPS
             frac_source = "useful issued flops (PMC: MFMA flops x tile utilisation + fp64 VALU flops)"
         else:
-            achieved = min(achieved_alg, PEAK_FP64_TFLOPS)
-            frac_source = "algorithmic flops (no PMC profile for this configuration)"
+            achieved = frac = None
+            frac_source = "no PMC profile of this build / batch / slice count: only frac_algorithmic is reported"
         out = {
             "metric": "full-gate propagators/s",
             "value": value,
@@ -379,7 +389,7 @@ def main():
                 "baseline_batch": f"{cfg['B']} on {cfg.get('gpus', 1)} GPU(s)",
                 "clock_ramp_ms": args.ramp_ms,
                 "throughput": f"sustained: after a {args.ramp_ms:g} ms untimed clock ramp and {args.warmup} warmup steps",
-                "parallelism": ((f"dp{world} ({args.scaling}: batch sharded; one RCCL all-gather of U per {G} steps)" if args.exchange == "gather" else f"dp{world} ({args.scaling}: batch sharded; fused fidelity, one RCCL all-reduce of the goal per step, no gather)") if world > 1 else ("single GPU" if args.exchange == "gather" else "single GPU, fused fidelity per step")),
+                "parallelism": ((f"dp{world} ({args.scaling}: batch sharded; " + ("one RCCL all-gather of U per step" if G == 1 else f"one RCCL all-gather of U per {G} steps") + ")" if args.exchange == "gather" else f"dp{world} ({args.scaling}: batch sharded; fused fidelity, one RCCL all-reduce of the goal per step, no gather)") if world > 1 else ("single GPU" if args.exchange == "gather" else "single GPU, fused fidelity per step")),
                 "exchange": args.exchange,
                 "kernel": kernel_name,
             },
@@ -388,7 +398,7 @@ def main():
                 "achieved": achieved,
                 "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP64_TFLOPS,
+                "frac": frac,
                 "frac_source": frac_source,
                 "traffic": traffic,
                 "achieved_algorithmic": achieved_alg,
@@ -399,14 +409,16 @@ def main():
                 "issued_frac": None if issued is None else issued / t_step / 1e12 / PEAK_FP64_TFLOPS,
                 "useful_flop_per_launch": useful,
                 "mfma_tile_utilisation": ent.get("mfma_tile_utilisation"),
-                "pmc_profile": f"profiles/{PROFILE_ROUND}/pmc.json" if issued is not None else None,
+                "pmc_profile": f"profiles/{PROFILE_ROUND}/pmc.json" if pmc_exact else None,
                 "pmc_exact_match": pmc_exact,
                 "pmc_avg_launch_us": ent.get("avg_launch_us") if pmc_exact else None,
                 "kernel": f"chain kernel ({kernel_name})",
                 "device_ms_per_step": device_ms_per_step,
-                "note": "fp64 compute-bound path. frac = USEFUL issued flops / device time per step (HIP events over the timed region, launch gaps included) / dense fp64 peak: flops the kernel really issues (PMC) with the zero padding of its MFMA tiles taken out -- at most 1 by construction. frac_algorithmic = SURVEY 8d's figure (the reference's complex Pade order per slice + product tree) over the same time: a method that needs fewer flops than the reference's (real cos / sin evaluation of real Hamiltonians) can exceed 1 there; it is an algorithm credit, not a hardware one. traffic = HBM-side bytes per launch from the same PMC passes (only for the exact build / batch profiled). pmc_exact_match false: the per-sample-and-slice PMC figures of another build / batch of this configuration were scaled",
+                "note": "fp64 compute-bound path. frac = USEFUL issued flops / device time per step (HIP events over the timed region, launch gaps included) / dense fp64 peak: flops the kernel really issues (PMC) with the zero padding of its MFMA tiles taken out; null unless the committed PMC profile is of exactly this kernel build, batch and slice count (pmc_exact_match). frac_algorithmic = SURVEY 8d's figure (the reference's complex Pade order per slice + product tree) over the same time: a method that needs fewer flops than the reference's (real cos / sin evaluation of real Hamiltonians; Lindblad chains in real arithmetic in the Hermitian basis) exceeds the hardware fraction there and can exceed 1; it is an algorithm credit, not a hardware one. traffic = HBM-side bytes per launch from the same PMC passes",
             },
         }
+        if alt:
+            out["other_exchange_schedules"] = dict(alt, note="same steps / warmup, timed right after the headline schedule in the same process; value = whole-job propagators/s")
         if goal_mode and goal_last[0] is not None:
             g = goal_last[0].cpu().numpy()
             out["goal"] = {"mean_unitary_infidelity_vs_identity": float(g[0] / max(g[1], 1.0)), "samples": int(g[1])}
@@ -414,7 +426,9 @@ def main():
             out["max_fro_err_vs_oracle"] = err
             out["oracle_samples_checked"] = nchk
         if world == 1 and not args.no_e2e and bp is not None:
+            t_e = time.perf_counter()
             out["e2e"] = e2e_rates(wl, fr, propagation, torch, dev)
+            out["e2e"]["wall_s"] = time.perf_counter() - t_e
         if world == 1 and not args.no_cpu_baseline:
             from oracle import c3_oracle  # the CPU restatement, timed beside the GPU path (checker only)
 
@@ -425,7 +439,7 @@ def main():
         dist.destroy_process_group()
 
 
-def e2e_rates(wl, fr, propagation, torch, dev, reps=5):
+def e2e_rates(wl, fr, propagation, torch, dev, reps=3):
     """PCIe-inclusive rates (never the reported `value`): host numpy in / out through C3P_HOST_PTRS
     (control samples in, U out, synchronous)."""
     def host():
@@ -452,30 +466,39 @@ def _oracle_run(wl, oracle, nb):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(wl, oracle):
-    """The numpy oracle (reference algorithm: batched per-slice Pade expm + pairwise tree
-    product) timed single-threaded on a bounded sample of the same workload."""
+def cpu_baseline(wl, oracle, budget_s=8.0):
+    """The numpy oracle (reference algorithm: batched per-slice Pade expm + pairwise tree product) timed single-threaded on
+    a bounded sample of the same workload: one untimed sample (imports, LAPACK warm-up), then up to three timed repeats of
+    `nb` samples inside `budget_s` seconds; the MEDIAN repeat is reported."""
     try:
         from threadpoolctl import threadpool_limits
     except Exception:  # pragma: no cover
         threadpool_limits = None
 
+    t_leg = time.perf_counter()
     ctx = threadpool_limits(limits=1) if threadpool_limits else None
     try:
         if ctx is not None:
             ctx.__enter__()
+        _oracle_run(wl, oracle, 1)  # untimed
         t1 = _oracle_run(wl, oracle, 1)
-        nb = int(max(1, min(wl.B, round(10.0 / max(t1, 1e-3)))))
-        t = _oracle_run(wl, oracle, nb)
+        nb = int(max(1, min(wl.B, (budget_s / 3.0) / max(t1, 1e-4))))
+        times = []
+        while len(times) < 3 and (not times or time.perf_counter() - t_leg + times[-1] < budget_s):
+            times.append(_oracle_run(wl, oracle, nb))
     finally:
         if ctx is not None:
             ctx.__exit__(None, None, None)
+    t = sorted(times)[len(times) // 2]
     return {
         "value": nb / t,
         "unit": "propagators/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"{nb} of {wl.B} samples of {wl.name}, numpy oracle (Higham Pade expm per slice + tf_matmul_n tree), 1 thread, {os.cpu_count()} host cores present",
+        "repeats": len(times),
+        "rates_of_the_repeats": [nb / x for x in times],
+        "wall_s": time.perf_counter() - t_leg,
+        "sample": f"{nb} of {wl.B} samples of {wl.name}, numpy oracle (Higham Pade expm per slice + tf_matmul_n tree), 1 thread, median of {len(times)} repeats after one untimed sample; {os.cpu_count()} host cores present",
     }
 
 
@@ -533,15 +556,17 @@ def effective_cores():
     return n, ", ".join(how)
 
 
-def cpu_baseline_allcores(cfg_index, wl, budget_s=2.0):
+def cpu_baseline_allcores(cfg_index, wl, budget_s=20.0):
     """The same oracle process-parallel over samples, with a persistent worker pool (workers started and warmed --
     imports, one sample each -- BEFORE anything is timed).  The worker count is swept in powers of two up to the usable
-    hardware threads and every rate is reported: `value` is the best of the sweep and `cores` the worker count that gave
-    it, so a box whose lease cannot feed all its threads (memory bandwidth, SMT, cgroup limits) does not quote a
-    nominal core count it does not scale to."""
+    hardware threads (at most 32 workers); every count is timed THREE times and its MEDIAN rate reported; `value` is the
+    best median and `cores` the worker count that gave it.  The whole leg is bounded by `budget_s` seconds of wall clock:
+    the per-worker sample shrinks to fit, and the sweep stops (lowest counts first dropped) if the budget runs out."""
     import multiprocessing as mp
 
+    t_leg = time.perf_counter()
     cores, how = effective_cores()
+    workers = min(cores, 32)
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -551,21 +576,32 @@ def cpu_baseline_allcores(cfg_index, wl, budget_s=2.0):
     except Exception:
         pass
     ctx = mp.get_context("spawn")  # the parent holds a HIP context: no fork
-    sweep = {}
-    with ctx.Pool(cores, initializer=_pool_init) as pool:
-        warm = pool.map(_pool_work, [(cfg_index, wl.N, 0, 1)] * cores)  # untimed: start-up + one sample per worker
-        t1 = min(warm)
-        per = int(max(1, min(64, round(budget_s / max(t1, 1e-3)))))
-        w = 1
+    sweep, raw = {}, {}
+    with ctx.Pool(workers, initializer=_pool_init) as pool:
+        warm = pool.map(_pool_work, [(cfg_index, wl.N, 0, 1)] * workers)  # untimed: start-up + one sample per worker
+        t_start = time.perf_counter() - t_leg
+        t1 = sorted(warm)[len(warm) // 2]
         counts = []
-        while w < cores:
+        w = 1
+        while w < workers:
             counts.append(w)
             w *= 2
-        counts.append(cores)
-        for w in counts:
-            t0 = time.perf_counter()
-            pool.map(_pool_work, [(cfg_index, wl.N, i * per, per) for i in range(w)], chunksize=1)
-            sweep[w] = w * per / (time.perf_counter() - t0)
+        counts.append(workers)
+        left = max(2.0, budget_s - t_start)
+        # 3 repeats x len(counts) timed maps inside what is left of the budget
+        per = int(max(1, min(64, (left / (3.0 * len(counts))) / max(t1, 1e-4))))
+        for w in reversed(counts):  # the full width first: it is the one that matters if the budget runs out
+            if time.perf_counter() - t_leg > budget_s and sweep:
+                break
+            rates = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                pool.map(_pool_work, [(cfg_index, wl.N, i * per, per) for i in range(w)], chunksize=1)
+                rates.append(w * per / (time.perf_counter() - t0))
+                if time.perf_counter() - t_leg > budget_s:
+                    break
+            raw[w] = rates
+            sweep[w] = sorted(rates)[len(rates) // 2]
     best = max(sweep, key=sweep.get)
     return {
         "value": sweep[best],
@@ -575,9 +611,12 @@ def cpu_baseline_allcores(cfg_index, wl, budget_s=2.0):
         "how_counted": how,
         "kind": "port",
         "cpu_model": model,
-        "rate_by_workers": {str(k): v for k, v in sweep.items()},
-        "scaling_1_to_8_workers": (sweep.get(8, 0.0) / sweep[1]) if 8 in sweep else None,
-        "sample": f"{per} samples of {wl.name.rsplit(' B=', 1)[0]} per worker, numpy oracle, one single-threaded process per worker, persistent pool (start-up and a warm-up sample excluded), worker counts {counts}; value = the best rate of the sweep",
+        "rate_by_workers": {str(k): sweep[k] for k in sorted(sweep)},
+        "repeats_by_workers": {str(k): raw[k] for k in sorted(raw)},
+        "scaling_1_to_8_workers": (sweep[8] / sweep[1]) if (8 in sweep and 1 in sweep) else None,
+        "pool_start_s": t_start,
+        "wall_s": time.perf_counter() - t_leg,
+        "sample": f"{per} samples of {wl.name.rsplit(' B=', 1)[0]} per worker, numpy oracle, one single-threaded process per worker, persistent pool (start-up and a warm-up sample excluded), worker counts {sorted(sweep)}, median of up to 3 repeats each; value = the best median; leg bounded to {budget_s:g} s",
     }
 
 

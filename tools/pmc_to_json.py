@@ -68,7 +68,7 @@ def main():
         "avg_launch_us": sum(dur[dom]) / len(dur[dom]) / 1e3,
         "batch": hi - lo,
         "slices": c["N"],
-        "kernel_sources_digest": bench.kernel_sources_digest(),
+        "kernel_sources_digest": bench.kernel_sources_digest(cfg),
         "resources": meta,
         "counters_per_launch": avg,
     }
