@@ -389,7 +389,7 @@ def main():
                 "baseline_batch": f"{cfg['B']} on {cfg.get('gpus', 1)} GPU(s)",
                 "clock_ramp_ms": args.ramp_ms,
                 "throughput": f"sustained: after a {args.ramp_ms:g} ms untimed clock ramp and {args.warmup} warmup steps",
-                "parallelism": ((f"dp{world} ({args.scaling}: batch sharded; " + ("one RCCL all-gather of U per step" if G == 1 else f"one RCCL all-gather of U per {G} steps") + ")" if args.exchange == "gather" else f"dp{world} ({args.scaling}: batch sharded; fused fidelity, one RCCL all-reduce of the goal per step, no gather)") if world > 1 else ("single GPU" if args.exchange == "gather" else "single GPU, fused fidelity per step")),
+                "parallelism": ((f"dp{world} ({args.scaling}: batch sharded; " + ("one RCCL all-gather of U per step" if G == 1 else f"one RCCL all-gather of U per {G} steps") + ")" if args.exchange == "gather" else f"dp{world} ({args.scaling}: batch sharded; fused fidelity, one RCCL all-reduce of the goal per step, no gather)") if use_dist else ("single GPU" if args.exchange == "gather" else "single GPU, fused fidelity per step")),
                 "exchange": args.exchange,
                 "kernel": kernel_name,
             },

@@ -80,7 +80,7 @@ int fail(const char* fmt, ...) {
   } while (0)
 
 // Per-device workspace slots, grown lazily, freed by c3p_shutdown().
-enum Slot { SL_SEG_A = 0, SL_SEG_B, SL_SCRATCH, SL_CLP, SL_TABLES, SL_COUNTERS, SL_COUNTERS2, SL_IN0, SL_IN1, SL_IN2, SL_IN3, SL_IN4, SL_IN5, SL_OUT0, SL_OUT1, SL_COUNT };
+enum Slot { SL_SEG_A = 0, SL_SEG_B, SL_SCRATCH, SL_CLP, SL_TABLES, SL_COUNTERS, SL_COUNTERS2, SL_IN0, SL_IN1, SL_IN2, SL_IN3, SL_IN4, SL_IN5, SL_OUT0, SL_OUT1, SL_OUT2, SL_OUT3, SL_COUNT };
 
 struct DeviceWs {
   std::mutex mu;  // one lock per device: calls on different GPUs of one process do not serialise
@@ -1392,6 +1392,7 @@ struct Stage {
       return 0;
     }
     void* d;
+    if (in_slot > SL_IN5) return fail("internal: out of input staging slots");
     if (ws_get(w, (Slot)in_slot++, bytes, &d)) return -1;
     HIP_TRY(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, st));
     *dev = d;
@@ -1403,6 +1404,7 @@ struct Stage {
       return 0;
     }
     void* d;
+    if (out_slot > SL_OUT3) return fail("internal: out of output staging slots");
     if (ws_get(w, (Slot)out_slot++, bytes, &d)) return -1;
     backs.push_back({host, d, bytes});
     *dev = d;
@@ -2126,6 +2128,7 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
   if (flags & (C3P_PER_SLICE_H | C3P_ORDER_RIGHT)) return fail("c3p_pwc_lindblad_vjp: unsupported flag");
   if (B == 0) return 0;
   if (!h0 || !hks || !signals || !col_ops || !U_bar || !grad_signals) return fail("NULL pointer argument");
+  if (h0_bstride < 0 || hks_bstride < 0) return fail("negative batch stride");
   const size_t cs = sizeof(cplx);
   const int Dm = D * D;
   hipStream_t st = (hipStream_t)stream;
@@ -2137,8 +2140,8 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
   const void *d_h0 = h0, *d_hks = hks, *d_sig = signals, *d_ph = fr_phase, *d_ub = U_bar, *d_col = col_ops;
   void* d_grad = grad_signals;
   if (flags & C3P_HOST_PTRS) {
-    if (sg.in(h0, (size_t)(h0_bstride ? B : 1) * D * D * cs, &d_h0)) return -1;
-    if (sg.in(hks, (size_t)(hks_bstride ? B : 1) * K * D * D * cs, &d_hks)) return -1;
+    if (sg.in(h0, ((size_t)(B - 1) * (size_t)h0_bstride + (size_t)D * D) * cs, &d_h0)) return -1;
+    if (sg.in(hks, ((size_t)(B - 1) * (size_t)hks_bstride + (size_t)K * D * D) * cs, &d_hks)) return -1;
     if (sg.in(signals, (size_t)B * K * N * sizeof(double), &d_sig)) return -1;
     if (sg.in(col_ops, (size_t)C * D * D * cs, &d_col)) return -1;
     if (sg.in(U_bar, (size_t)B * Dm * Dm * cs, &d_ub)) return -1;
@@ -2350,6 +2353,20 @@ int c3p_synth_signals(const double* env_params, const int32_t* env_shapes, const
   return 0;
 }
 
+// fused goal of c3p_pwc_unitary_goal_vjp (device pointers after staging)
+struct GoalSpec {
+  const int32_t* rows;
+  int L;
+  const void* ideal;
+  int kind;
+  double* infid;
+  double* gphase;
+  void* U_out;
+};
+static int unitary_vjp_branch_a(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride, const double* signals,
+                                double dt, int B, int K, int N, int D, int flags, const double* fr_phase, const void* U_bar,
+                                double* grad_signals, void* gen_bar_out, void* stream, const GoalSpec* goal);
+
 int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride,
                         const double* signals, double dt, int B, int K, int N, int D, int flags,
                         const double* fr_phase, const void* U_bar, double* grad_signals, void* gen_bar_out,
@@ -2403,10 +2420,39 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
     if (flags & C3P_HOST_PTRS) return sg.finish();
     return 0;
   }
+  if (!U_bar) return fail("NULL pointer argument");
+  return unitary_vjp_branch_a(h0, h0_bstride, hks, hks_bstride, signals, dt, B, K, N, D, flags, fr_phase, U_bar, grad_signals,
+                              gen_bar_out, stream, nullptr);
+}
+
+int c3p_pwc_unitary_goal_vjp(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride, const double* signals,
+                             double dt, int B, int K, int N, int D, int flags, const double* fr_phase, const int32_t* comp_rows,
+                             int L, const void* ideal, int kind, double* infid_out, double* grad_signals, double* grad_fr_phase,
+                             void* U_out, void* stream) {
+  if (flags & (C3P_ORDER_RIGHT | C3P_PER_SLICE_H)) return fail("c3p_pwc_unitary_goal_vjp: unsupported flag");
+  if (L <= 0 || L > D || L > C3P_GOAL_LMAX) return fail("bad computational subspace size L=%d (D=%d, at most %d)", L, D, C3P_GOAL_LMAX);
+  if (kind != 0 && kind != 1) return fail("unknown infidelity kind %d", kind);
+  if (!comp_rows || !ideal || !infid_out) return fail("NULL pointer argument");
+  if (grad_fr_phase && !fr_phase) return fail("grad_fr_phase needs fr_phase");
+  if (D > 64 || (D > 40 && (B >= 384 || c3p_opt_on(C3P_OPT_tiled_grad))))
+    return fail("the fused goal runs on the on-chip and VALU backward sweeps (D <= 40, or D <= 64 below 384 samples): use "
+                "c3p_pwc_unitary, c3p_gate_overlap and c3p_pwc_unitary_vjp for D=%d B=%d", D, B);
+  if (flags & C3P_HOST_PTRS)
+    for (int a = 0; a < L; ++a)
+      if (comp_rows[a] < 0 || comp_rows[a] >= D) return fail("comp_rows[%d]=%d outside [0,%d)", a, comp_rows[a], D);
+  GoalSpec g = {comp_rows, L, ideal, kind, infid_out, grad_fr_phase, U_out};
+  return unitary_vjp_branch_a(h0, h0_bstride, hks, hks_bstride, signals, dt, B, K, N, D, flags, fr_phase, nullptr, grad_signals,
+                              nullptr, stream, &g);
+}
+
+static int unitary_vjp_branch_a(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride, const double* signals,
+                                double dt, int B, int K, int N, int D, int flags, const double* fr_phase, const void* U_bar,
+                                double* grad_signals, void* gen_bar_out, void* stream, const GoalSpec* goal) {
   if (B < 0 || K <= 0 || N <= 0 || D <= 0) return fail("bad sizes B=%d K=%d N=%d D=%d", B, K, N, D);
   if (D > 64 && gen_bar_out) return fail("gen_bar_out (per-slice generator cotangents) is available for D <= 64, got %d", D);
   if (B == 0) return 0;
-  if (!h0 || !hks || !signals || !U_bar || !grad_signals) return fail("NULL pointer argument");
+  if (!h0 || !hks || !signals || (!U_bar && !goal) || !grad_signals) return fail("NULL pointer argument");
+  if (h0_bstride < 0 || hks_bstride < 0) return fail("negative batch stride");
   const size_t cs = sizeof(cplx);
   hipStream_t st = (hipStream_t)stream;
   WsLock lk(st);
@@ -2432,15 +2478,46 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
           }
         if (dev > 1e-9 * mag) return fail("c3p_pwc_unitary_vjp needs Hermitian Hamiltonians (deviation %.3g)", dev);
       }
-    if (sg.in(h0, (size_t)(h0_bstride ? B : 1) * D * D * cs, &d_h0)) return -1;
-    if (sg.in(hks, (size_t)(hks_bstride ? B : 1) * K * D * D * cs, &d_hks)) return -1;
+    if (sg.in(h0, ((size_t)(B - 1) * (size_t)h0_bstride + (size_t)D * D) * cs, &d_h0)) return -1;
+    if (sg.in(hks, ((size_t)(B - 1) * (size_t)hks_bstride + (size_t)K * D * D) * cs, &d_hks)) return -1;
     if (sg.in(signals, (size_t)B * K * N * sizeof(double), &d_sig)) return -1;
-    if (sg.in(U_bar, (size_t)B * D * D * cs, &d_ub)) return -1;
+    if (U_bar && sg.in(U_bar, (size_t)B * D * D * cs, &d_ub)) return -1;
     if (fr_phase && sg.in(fr_phase, (size_t)B * D * sizeof(double), &d_ph)) return -1;
     if (sg.out(grad_signals, (size_t)B * K * N * sizeof(double), &d_grad)) return -1;
     if (gen_bar_out && sg.out(gen_bar_out, (size_t)B * N * D * D * cs, &d_zout)) return -1;
   }
+  GoalSpec gd = {};
+  if (goal) {
+    gd = *goal;
+    if (flags & C3P_HOST_PTRS) {
+      const void* t;
+      void* o;
+      if (sg.in(goal->rows, (size_t)goal->L * sizeof(int32_t), &t)) return -1;
+      gd.rows = (const int32_t*)t;
+      if (sg.in(goal->ideal, (size_t)goal->L * goal->L * cs, &t)) return -1;
+      gd.ideal = t;
+      if (sg.out(goal->infid, (size_t)B * sizeof(double), &o)) return -1;
+      gd.infid = (double*)o;
+      if (goal->gphase) {
+        if (sg.out(goal->gphase, (size_t)B * D * sizeof(double), &o)) return -1;
+        gd.gphase = (double*)o;
+      }
+      if (goal->U_out) {
+        if (sg.out(goal->U_out, (size_t)B * D * D * cs, &o)) return -1;
+        gd.U_out = o;
+      }
+    }
+  }
   GradArgs A = {};
+  if (goal) {
+    A.goal_rows = (const int*)gd.rows;
+    A.goal_L = gd.L;
+    A.goal_ideal = (const cplx*)gd.ideal;
+    A.goal_kind = gd.kind;
+    A.goal_infid = gd.infid;
+    A.goal_gphase = gd.gphase;
+    A.goal_U = (cplx*)gd.U_out;
+  }
   A.h0 = (const cplx*)d_h0;
   A.h0_bstride = h0_bstride;
   A.hks = (const cplx*)d_hks;

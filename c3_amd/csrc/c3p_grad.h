@@ -24,7 +24,17 @@ struct GradArgs {
   int general;
   cplx* pre;     // [B,S,D,D] prefix product at the START of each segment        (general only; Mb then holds the LEFT adjoint
   cplx* pstore;  // [B,N,D,D] prefix product in front of every slice              A = S^H FR^H Ubar at the end of each segment)
+  // fused goal (c3p_pwc_unitary_goal_vjp): when goal_rows is set the scan kernel, which forms the total product anyway,
+  // evaluates the gate infidelity of U = FR P and takes ITS cotangent as Ubar (Ubar above is then not read):
+  //   s = tr(G^+ U[rows, rows]),  infid = 1 - |s / L|^2 (kind 0) or 1 - (|s|^2 / L + 1) / (L + 1) (kind 1),  Ubar = c s G on (rows x rows)
+  const int* goal_rows;    // [L] computational rows (fidelities.py:154-184 via tf_project_to_comp), L <= C3P_GOAL_LMAX
+  const cplx* goal_ideal;  // [L,L]
+  int goal_L, goal_kind;
+  double* goal_infid;   // [B]
+  double* goal_gphase;  // [B,D] or null: d infid / d fr_phase
+  cplx* goal_U;         // [B,D,D] or null: the propagators themselves
 };
+#define C3P_GOAL_LMAX 64
 
 #define C3P_GRAD_NMAT 19  // matrices a backward workgroup keeps (LDS or scratch)
 #define C3P_GRAD_NMAT_GENERAL 20

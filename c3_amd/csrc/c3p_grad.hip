@@ -393,14 +393,63 @@ __global__ void __launch_bounds__(256) grad_scan_kernel(GradArgs A) {
     bU = bV;
     bV = t;
   }
+  // fused goal: the total product P is in bU, so the gate infidelity of U = FR P and its cotangent are formed here
+  // (fidelities.py:154-184, 290-313) instead of a forward call, an overlap kernel and host-framework ops in front of this one
+  __shared__ double gsh[2 * C3P_GOAL_LMAX + 4];
+  const bool goal = A.goal_rows != nullptr;
+  if (goal) {
+    const int L = A.goal_L;
+    if (tid < L) {
+      const int ra = A.goal_rows[tid];
+      double sn = 0.0, cs = 1.0;
+      if (A.fr_phase) sincos(A.fr_phase[(long)b * D + ra], &sn, &cs);
+      cplx acc = cmake(0, 0);
+      for (int c = 0; c < L; ++c) {
+        const cplx g = A.goal_ideal[tid * L + c];
+        acc = cadd(acc, cmul(cmake(g.x, -g.y), M.ld(bU + ra * ld + A.goal_rows[c])));
+      }
+      acc = cmul(cmake(cs, sn), acc);
+      gsh[2 * tid] = acc.x, gsh[2 * tid + 1] = acc.y;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double sr = 0.0, si = 0.0;
+      for (int a = 0; a < L; ++a) sr += gsh[2 * a], si += gsh[2 * a + 1];
+      const double s2 = sr * sr + si * si;
+      const double coef = A.goal_kind == 0 ? -2.0 / ((double)L * L) : -2.0 / ((double)L * (L + 1));
+      A.goal_infid[b] = A.goal_kind == 0 ? 1.0 - s2 / ((double)L * L) : 1.0 - (s2 / L + 1.0) / (L + 1.0);
+      gsh[2 * C3P_GOAL_LMAX] = coef * sr, gsh[2 * C3P_GOAL_LMAX + 1] = coef * si;
+    }
+    __syncthreads();
+    // d infid / d phi_i = -Im sum_j conj(Ubar_ij) U_ij = -Im(conj(c s) * s_i), s_i the row's share of the overlap
+    if (A.goal_gphase != nullptr) {
+      for (int i = tid; i < D; i += nt) A.goal_gphase[(long)b * D + i] = 0.0;
+      __syncthreads();
+      if (tid < L) {
+        const double cr = gsh[2 * C3P_GOAL_LMAX], ci = gsh[2 * C3P_GOAL_LMAX + 1];
+        A.goal_gphase[(long)b * D + A.goal_rows[tid]] = -(cr * gsh[2 * tid + 1] - ci * gsh[2 * tid]);
+      }
+    }
+  }
   for (int e = tid; e < D * D; e += nt) {
     const int i = e / D, j = e - i * D;
-    cplx v = ub[e];
-    if (A.fr_phase) {
-      double sn, cs;
-      sincos(A.fr_phase[(long)b * D + i], &sn, &cs);
-      v = cmul(cmake(cs, -sn), v);
+    double sn = 0.0, cs = 1.0;
+    if (A.fr_phase) sincos(A.fr_phase[(long)b * D + i], &sn, &cs);
+    cplx v;
+    if (goal) {
+      if (A.goal_U != nullptr) A.goal_U[(long)b * D * D + e] = cmul(cmake(cs, sn), M.ld(bU + i * ld + j));
+      int ai = -1, aj = -1;
+      for (int a = 0; a < A.goal_L; ++a) {
+        const int r = A.goal_rows[a];
+        ai = (r == i) ? a : ai;
+        aj = (r == j) ? a : aj;
+      }
+      v = cmake(0, 0);
+      if (ai >= 0 && aj >= 0) v = cmul(cmake(gsh[2 * C3P_GOAL_LMAX], gsh[2 * C3P_GOAL_LMAX + 1]), A.goal_ideal[ai * A.goal_L + aj]);
+    } else {
+      v = ub[e];
     }
+    if (A.fr_phase) v = cmul(cmake(cs, -sn), v);
     M.st(bS + i * ld + j, v);
   }
   __syncthreads();

@@ -221,8 +221,12 @@ def lindbladian_unitary_infid(ideal, actual, index: List[int] = [0], dims=[2]):
 @fid_reg_deco
 def lindbladian_unitary_infid_set(propagators: dict, instructions: dict, index, dims, n_eval=-1):
     """Mean over gates (fidelities.py:252-285)."""
-    vals = [np.asarray(lindbladian_unitary_infid(_ideal_of(instructions, g, dims, index), U, index, dims)) for g, U in propagators.items()]
-    return np.mean(vals, axis=0)
+    vals = [lindbladian_unitary_infid(_ideal_of(instructions, g, dims, index), U, index, dims) for g, U in propagators.items()]
+    if any(hasattr(v, "detach") for v in vals):  # device propagators: reduce on the device
+        import torch
+
+        return torch.stack([v if hasattr(v, "detach") else torch.as_tensor(v) for v in vals]).mean(dim=0)
+    return np.mean([np.asarray(v) for v in vals], axis=0)
 
 
 def lindbladian_unitary_infid_cotangent(ideal, actual, index: List[int] = [0], dims=[2]):

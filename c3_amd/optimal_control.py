@@ -42,6 +42,7 @@ def goal_run_with_grad(
     fid_func: str = "unitary_infid",
     col_ops=None,
     device="cuda:0",
+    fused: Optional[bool] = None,
 ) -> Dict:
     """goals [B] and their gradients w.r.t. every envelope row, carrier pair and frame-rotation phase.
 
@@ -51,6 +52,10 @@ def goal_run_with_grad(
     `col_ops` [C,D,D] switches to the open-system path (model.lindbladian, propagation.py:551-585): U are the D^2 x D^2
     superoperators, `fid_func` an open-system goal ("lindbladian_unitary_infid", fidelities.py:221-249), `fr_phase` [B,D^2]
     the row phases of the superoperator, and the control gradient comes from `propagate_batch_lindblad_vjp`.
+
+    `fused` (closed systems; default: wherever the library serves the shape) takes goal and gradient from ONE pass over the
+    chains (`propagation.propagate_batch_goal_vjp`); False runs forward pass, cotangent and vector-Jacobian product as three
+    calls -- same numbers, the forward segment products computed twice.
     """
     import torch
 
@@ -76,6 +81,15 @@ def goal_run_with_grad(
     else:
         if fid_func.startswith("lindbladian"):
             raise C3PropError(f"C3:Error: '{fid_func}' needs collapse operators (col_ops)")
+        B, D = int(sig.shape[0]), int(h0d.shape[-1])
+        if fused is None:
+            fused = propagation.goal_vjp_is_fused(B, D)
+        if fused:
+            # ONE pass over the chains: the backward pass's scan of the segment products evaluates the goal and starts the
+            # adjoint sweep from its cotangent (c3p_pwc_unitary_goal_vjp); no second forward pass, no host-framework ops
+            r = propagation.propagate_batch_goal_vjp(h0d, hkd, sig, dt, ideal, index, dims, kind="unitary" if fid_func == "unitary_infid" else "average", fr_phase=ph)
+            g_env, g_car = signals.synthesize_signals_vjp(env, env_shapes, car, t_start, t_end, awg_res, sim_res, r["grad_signals"])
+            return {"goal": r["goal"], "grad_env": g_env, "grad_carrier": g_car, "grad_fr_phase": r["grad_fr_phase"], "U": r["U"]}
         U = propagation.propagate_batch(h0d, hkd, sig, dt, fr_phase=ph)["U"]
         U_bar, goal = _COTANGENTS[fid_func](ideal, U, index, dims)
         g_sig = propagation.propagate_batch_vjp(h0d, hkd, sig, dt, U_bar, fr_phase=ph)

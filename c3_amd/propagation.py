@@ -289,6 +289,75 @@ def propagate_batch_vjp(h0, hks, signals, dt: float, U_bar, *, fr_phase=None, fo
     return grad, g0, gk
 
 
+_goal_rows_cache: Dict[tuple, object] = {}
+
+
+def goal_vjp_is_fused(B: int, D: int) -> bool:
+    """Shapes `propagate_batch_goal_vjp` serves (the on-chip and VALU backward sweeps, include/c3prop.h)."""
+    return D <= 40 or (D <= 64 and B < 384 and _lib.get_option("tiled_grad") <= 0)
+
+
+def propagate_batch_goal_vjp(h0, hks, signals, dt: float, ideal, index, dims, *, kind: str = "unitary", fr_phase=None, want_U: bool = True, check_hermitian: bool = True):
+    """Goal and gradient of one optimiser evaluation from ONE pass over the chains (c3p_pwc_unitary_goal_vjp).
+
+    The reference evaluates `goal_run = fid_func(compute_propagators())` (optimizers/optimalcontrol.py:200-228) under a
+    GradientTape (optimizers/optimizer.py:206-216).  Returns `{"goal": f64 [B], "grad_signals": f64 [B,K,N],
+    "grad_fr_phase": f64 [B,D] or None, "U": c128 [B,D,D] or None}` with goal = unitary_infid (kind "unitary",
+    fidelities.py:154-184) or average_infid ("average", :290-313) of every sample and grad = d goal[b] / d signals[b]."""
+    from .fidelities import computational_rows
+
+    call = _Call(h0, hks, signals, fr_phase, ideal)
+    h0 = call.c128(h0)
+    hks = call.c128(hks)
+    signals = call.f64(signals)
+    if signals.ndim != 3:
+        raise C3PropError(f"C3:Error: signals must be [B,K,N], got {tuple(signals.shape)}")
+    B, K, N = (int(s) for s in signals.shape)
+    D = int(h0.shape[-1])
+    h0_bs = _bstride(h0, 2, B, "h0")
+    hk_bs = _bstride(hks, 3, B, "hks")
+    if int(hks.shape[-3]) != K:
+        raise C3PropError(f"C3:Error: {K} signal channels but {int(hks.shape[-3])} control Hamiltonians")
+    if kind not in ("unitary", "average"):
+        raise C3PropError(f"C3:Error: unknown infidelity kind '{kind}'")
+    if dims is None or int(np.prod(dims)) != D:
+        raise C3PropError(f"C3:Error: dims {dims} do not match the propagator dimension {D}")
+    if check_hermitian:
+        _require_hermitian(call, "h0", h0)
+        _require_hermitian(call, "hks", hks)
+    rows = computational_rows(dims, index)
+    L = int(rows.shape[0])
+    G = call.c128(ideal)
+    if tuple(G.shape) != (L, L):
+        raise C3PropError(f"C3:Error: ideal gate must be [{L},{L}] for index {index}, got {tuple(G.shape)}")
+    if fr_phase is not None:
+        fr_phase = call.f64(fr_phase)
+        if tuple(fr_phase.shape) != (B, D):
+            raise C3PropError(f"C3:Error: fr_phase must be [{B},{D}], got {tuple(fr_phase.shape)}")
+    if call.device:
+        t = call.torch
+        key = (tuple(int(d) for d in dims), tuple(index) if index else None, str(call.dev))
+        rows_d = _goal_rows_cache.get(key)
+        if rows_d is None:
+            rows_d = _goal_rows_cache[key] = t.as_tensor(rows, device=call.dev)
+        goal = t.empty((B,), dtype=t.float64, device=call.dev)
+        grad = t.empty((B, K, N), dtype=t.float64, device=call.dev)
+        gph = t.empty((B, D), dtype=t.float64, device=call.dev) if fr_phase is not None else None
+    else:
+        rows_d = rows
+        goal = np.empty((B,), dtype=np.float64)
+        grad = np.empty((B, K, N), dtype=np.float64)
+        gph = np.empty((B, D), dtype=np.float64) if fr_phase is not None else None
+    U = call.empty((B, D, D)) if want_U else None
+    _lib.check(
+        _lib.load().c3p_pwc_unitary_goal_vjp(
+            _ptr(h0), h0_bs, _ptr(hks), hk_bs, _ptr(signals), float(dt), B, K, N, D, call.flags, _ptr(fr_phase), _ptr(rows_d), L, _ptr(G),
+            0 if kind == "unitary" else 1, _ptr(goal), _ptr(grad), _ptr(gph), _ptr(U), call.stream
+        )
+    )
+    return {"goal": goal, "grad_signals": grad, "grad_fr_phase": gph, "U": U}
+
+
 def propagate_per_slice_vjp(hs, dt: float, U_bar, *, fr_phase=None):
     """Branch B of `pwc` (propagation.py:295-308: the model hands over one Hamiltonian per slice): vector-Jacobian
     product of `propagate_batch(hs, None, None, dt)` w.r.t. the Hamiltonians.  hs [N,D,D] or [B,N,D,D]; returns the

@@ -83,6 +83,36 @@ def pack_components(channels: Sequence[Sequence[Dict]], B: int = 1):
     return env, shapes
 
 
+_shapes_cache: Dict[tuple, object] = {}
+
+
+def _shapes(call, env_shapes, K: int, E: int):
+    """(host int32 [K,E], the array the library call takes): validated once per distinct table; on the device path the upload
+    is cached per (table, device) -- an optimiser calls the synthesis and its vjp every iteration with the same shapes, and a
+    pageable host-to-device copy per call is a synchronisation (and illegal inside a stream capture)."""
+    if _is_torch(env_shapes) and env_shapes.is_cuda:
+        key = ("dev", env_shapes.data_ptr(), env_shapes._version, tuple(env_shapes.shape), str(env_shapes.dtype))
+        hit = _shapes_cache.get(key)
+        if hit is not None:
+            return hit
+    shapes_np = np.ascontiguousarray(np.asarray(env_shapes.cpu() if _is_torch(env_shapes) else env_shapes, dtype=np.int32))
+    if shapes_np.shape != (K, E):
+        raise C3PropError(f"C3:Error: env_shapes must be [{K},{E}], got {shapes_np.shape}")
+    if shapes_np.max(initial=-1) >= len(ENV_SHAPES):
+        raise C3PropError("C3:Error: env_shapes holds an unknown shape id")
+    if not call.device:
+        return shapes_np, shapes_np
+    key2 = (shapes_np.tobytes(), shapes_np.shape, str(call.dev))
+    shp = _shapes_cache.get(key2)
+    if shp is None:
+        if len(_shapes_cache) > 64:
+            _shapes_cache.clear()
+        shp = _shapes_cache[key2] = call.torch.as_tensor(shapes_np, device=call.dev)
+    if _is_torch(env_shapes) and env_shapes.is_cuda:
+        _shapes_cache[key] = (shapes_np, shp)
+    return shapes_np, shp
+
+
 def synthesize_signals(env_params, env_shapes, carrier, t_start: float, t_end: float, awg_res: float, sim_res: float, *, want_iq: bool = False, device=None):
     """signals [B,K,N] (and optionally the AWG-resolution I/Q [B,K,2,Na]) from parameter rows.
 
@@ -99,11 +129,7 @@ def synthesize_signals(env_params, env_shapes, carrier, t_start: float, t_end: f
     if env.ndim != 4 or env.shape[-1] != ENV_NPAR:
         raise C3PropError(f"C3:Error: env_params must be [B,K,E,{ENV_NPAR}], got {tuple(env.shape)}")
     B, K, E = (int(x) for x in env.shape[:3])
-    shapes_np = np.ascontiguousarray(np.asarray(env_shapes.cpu() if _is_torch(env_shapes) else env_shapes, dtype=np.int32))
-    if shapes_np.shape != (K, E):
-        raise C3PropError(f"C3:Error: env_shapes must be [{K},{E}], got {shapes_np.shape}")
-    if shapes_np.max(initial=-1) >= len(ENV_SHAPES):
-        raise C3PropError("C3:Error: env_shapes holds an unknown shape id")
+    shapes_np, shp = _shapes(call, env_shapes, K, E)
     car = call.f64(carrier)
     if tuple(car.shape) != (B, K, 2):
         raise C3PropError(f"C3:Error: carrier must be [{B},{K},2], got {tuple(car.shape)}")
@@ -111,11 +137,9 @@ def synthesize_signals(env_params, env_shapes, carrier, t_start: float, t_end: f
     if N <= 0 or Na <= 1:
         raise C3PropError(f"C3:Error: empty time grid (N={N}, AWG samples={Na})")
     if call.device:
-        shp = call.torch.as_tensor(shapes_np, device=call.dev)
         sig = call.torch.empty((B, K, N), dtype=call.torch.float64, device=call.dev)
         iq = call.torch.empty((B, K, 2, Na), dtype=call.torch.float64, device=call.dev) if want_iq else None
     else:
-        shp = shapes_np
         sig = np.empty((B, K, N), dtype=np.float64)
         iq = np.empty((B, K, 2, Na), dtype=np.float64) if want_iq else None
     _lib.check(
@@ -138,9 +162,7 @@ def synthesize_signals_vjp(env_params, env_shapes, carrier, t_start: float, t_en
     if env.ndim != 4 or env.shape[-1] != ENV_NPAR:
         raise C3PropError(f"C3:Error: env_params must be [B,K,E,{ENV_NPAR}], got {tuple(env.shape)}")
     B, K, E = (int(x) for x in env.shape[:3])
-    shapes_np = np.ascontiguousarray(np.asarray(env_shapes.cpu() if _is_torch(env_shapes) else env_shapes, dtype=np.int32))
-    if shapes_np.shape != (K, E) or shapes_np.max(initial=-1) >= len(ENV_SHAPES):
-        raise C3PropError(f"C3:Error: env_shapes must be [{K},{E}] of known shape ids")
+    shapes_np, shp = _shapes(call, env_shapes, K, E)
     car = call.f64(carrier)
     if tuple(car.shape) != (B, K, 2):
         raise C3PropError(f"C3:Error: carrier must be [{B},{K},2], got {tuple(car.shape)}")
@@ -152,11 +174,9 @@ def synthesize_signals_vjp(env_params, env_shapes, carrier, t_start: float, t_en
         raise C3PropError(f"C3:Error: grad_signals must be [{B},{K},{N}], got {tuple(gs.shape)}")
     if call.device:
         t = call.torch
-        shp = t.as_tensor(shapes_np, device=call.dev)
         genv = t.empty((B, K, E, ENV_NPAR), dtype=t.float64, device=call.dev)
         gcar = t.empty((B, K, 2), dtype=t.float64, device=call.dev)
     else:
-        shp = shapes_np
         genv = np.empty((B, K, E, ENV_NPAR), dtype=np.float64)
         gcar = np.empty((B, K, 2), dtype=np.float64)
     _lib.check(

@@ -203,6 +203,23 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
                         const double* fr_phase, const void* U_bar, double* grad_signals, void* gen_bar_out,
                         void* stream);
 
+/* One optimiser evaluation of a closed-system gate goal, fused: the goal AND its gradient w.r.t. the control samples from ONE
+ * pass over the chains.  The reference evaluates goal_run = fid_func(compute_propagators()) (c3/optimizers/optimalcontrol.py:
+ * 200-228) under a GradientTape (c3/optimizers/optimizer.py:206-216); the three-call form here is c3p_pwc_unitary ->
+ * c3p_gate_overlap (+ the cotangent, element-wise) -> c3p_pwc_unitary_vjp, whose third call recomputes the segment products of
+ * the first.  This entry forms them once: the per-sample scan of the backward pass, which multiplies the segment products
+ * anyway, evaluates infid[b] of U = FR P and takes its cotangent
+ *   U_bar[b] = c s G on (comp_rows x comp_rows),  s = tr(G^+ U[rows,rows]),  c = -2/L^2 (kind 0, unitary_infid fidelities.py:
+ *   154-184) or -2/(L(L+1)) (kind 1, average_infid :290-313)
+ * as the start of the adjoint sweep.  Arguments as c3p_pwc_unitary_vjp (branch A only, Hermitian h0 / hks) and c3p_gate_infid:
+ *   infid_out f64 [B]; grad_signals f64 [B,K,N] = d infid[b] / d signals[b,k,n];
+ *   grad_fr_phase f64 [B,D] or NULL = d infid[b] / d fr_phase[b,i] (needs fr_phase); U_out c128 [B,D,D] or NULL.
+ * On the on-chip and VALU backward sweeps (D <= 40, or D <= 64 below 384 samples); other shapes: error, use the three calls. */
+int c3p_pwc_unitary_goal_vjp(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride,
+                             const double* signals, double dt, int B, int K, int N, int D, int flags,
+                             const double* fr_phase, const int32_t* comp_rows, int L, const void* ideal, int kind,
+                             double* infid_out, double* grad_signals, double* grad_fr_phase, void* U_out, void* stream);
+
 /* The same vector-Jacobian product through the LINDBLAD path (c3p_pwc_lindblad; the reference tapes
  * tf_propagation_lind just as well, c3/libraries/propagation.py:551-585 under c3/optimizers/optimizer.py:206-216):
  *   U_bar c128 [B,D^2,D^2] (d loss = Re sum conj(U_bar) dU of the superoperators), grad_signals f64 [B,K,N],

@@ -38,7 +38,7 @@ def main():
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         for env in (None, "C3P_ODE_PROP_ROWS"):
             if env:
-                os.environ[env] = "1"
+                _lib.set_option(env[4:].lower(), "1")
             try:
                 fn = lambda: lib.c3p_rk4_unitary(p(h0), p(hks), p(sig), None, 0, wl.dt, B, K, Ns, D, 0, p(U), None, None)
                 assert fn() == 0
@@ -52,7 +52,7 @@ def main():
                     best = min(best, time.perf_counter() - t0)
             finally:
                 if env:
-                    os.environ.pop(env)
+                    _lib.set_option(env[4:].lower(), None)
             got = U[:2].cpu().numpy()
             err = 0.0
             for b in range(2):

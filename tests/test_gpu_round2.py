@@ -452,9 +452,9 @@ def test_vjp_real_hamiltonian_small_dims(prop, D, amp, monkeypatch):
     sig = rng.normal(size=(B, K, N)) * 2e9
     Ubar = rng.normal(size=(B, D, D)) + 1j * rng.normal(size=(B, D, D))
     g = np.asarray(prop.propagate_batch_vjp(h0, hks, sig, 1e-11, Ubar))
-    monkeypatch.setenv("C3P_NO_REAL_GRAD", "1")
+    _lib.set_option("no_real_grad", "1")
     g0 = np.asarray(prop.propagate_batch_vjp(h0, hks, sig, 1e-11, Ubar))
-    monkeypatch.delenv("C3P_NO_REAL_GRAD")
+    _lib.set_option("no_real_grad", None)
     # (at 8e11 most dimensions are past three squarings of theta_16 and are handed to the general sweep, whose error
     # grows with the number of squarings: |H| dt ~ 10 rad per slice is two orders above any C3 model)
     tol = 1e-10 if amp < 5e11 else 2e-9
@@ -487,9 +487,9 @@ def test_vjp_real_hamiltonian_mid_dims(prop, D, amp, monkeypatch):
     ph = rng.uniform(0, 6, size=(B, D))
     g = np.asarray(prop.propagate_batch_vjp(h0, hks, sig, 1e-11, Ubar, fr_phase=ph))
     assert _lib.last_kernel() == "mfma"
-    monkeypatch.setenv("C3P_NO_REAL_GRAD", "1")
+    _lib.set_option("no_real_grad", "1")
     g0 = np.asarray(prop.propagate_batch_vjp(h0, hks, sig, 1e-11, Ubar, fr_phase=ph))
-    monkeypatch.delenv("C3P_NO_REAL_GRAD")
+    _lib.set_option("no_real_grad", None)
     tol = 1e-10 if amp < 5e11 else 2e-9
     for b in range(B):
         want = o.pwc_signal_gradient(h0[b] if per_sample else h0, hks, sig[b], 1e-11, Ubar[b], ph[b])
@@ -556,12 +556,12 @@ def test_smalld_workgroup_per_sample_mode(prop, cfg, B, N, monkeypatch):
     mode; with the default uneven segments (older waves take the longer ones) equal to rounding; spot parity against the oracle"""
     w = workloads.make_workload(cfg, B=B, N=N)
     U = np.asarray(prop.propagate_batch(w.h0, w.hks, w.signals, w.dt, fr_phase=w.fr_phase)["U"])
-    monkeypatch.setenv("C3P_MW_SKEW", "500")
+    _lib.set_option("mw_skew", "500")
     Ue = np.asarray(prop.propagate_batch(w.h0, w.hks, w.signals, w.dt, fr_phase=w.fr_phase)["U"])
-    monkeypatch.delenv("C3P_MW_SKEW")
-    monkeypatch.setenv("C3P_NO_MW", "1")
+    _lib.set_option("mw_skew", None)
+    _lib.set_option("no_mw", "1")
     U0 = np.asarray(prop.propagate_batch(w.h0, w.hks, w.signals, w.dt, fr_phase=w.fr_phase)["U"])
-    monkeypatch.delenv("C3P_NO_MW")
+    _lib.set_option("no_mw", None)
     assert np.array_equal(Ue, U0)
     assert np.abs(U - U0).max() < 1e-12
     idx = np.unique(np.linspace(0, B - 1, 4).astype(int))
@@ -583,9 +583,9 @@ def test_smalld_workgroup_per_sample_mode_per_sample_and_lindblad(prop, monkeypa
     hks = np.stack([sym() for _ in range(K)]).astype(np.complex128)
     sig = rng.normal(size=(B, K, N)) * 2e9
     U = np.asarray(prop.propagate_batch(h0, hks, sig, 1e-11)["U"])
-    monkeypatch.setenv("C3P_NO_MW", "1")
+    _lib.set_option("no_mw", "1")
     U0 = np.asarray(prop.propagate_batch(h0, hks, sig, 1e-11)["U"])
-    monkeypatch.delenv("C3P_NO_MW")
+    _lib.set_option("no_mw", None)
     assert np.abs(U - U0).max() < 1e-12
     for b in (0, 100, 255):
         assert np.abs(U[b] - o.propagate_batch(h0[b], hks, sig[b : b + 1], 1e-11)[0]).max() < 1e-11
@@ -597,9 +597,9 @@ def test_smalld_workgroup_per_sample_mode_per_sample_and_lindblad(prop, monkeypa
     col = (rng.normal(size=(2, D, D)) + 1j * rng.normal(size=(2, D, D))) * 3e3
     sig = rng.normal(size=(B, K, N)) * 2e9
     U = np.asarray(prop.propagate_batch(h0, hks, sig, 1e-11, col_ops=col, lindbladian=True)["U"])
-    monkeypatch.setenv("C3P_NO_MW", "1")
+    _lib.set_option("no_mw", "1")
     U0 = np.asarray(prop.propagate_batch(h0, hks, sig, 1e-11, col_ops=col, lindbladian=True)["U"])
-    monkeypatch.delenv("C3P_NO_MW")
+    _lib.set_option("no_mw", None)
     assert np.abs(U - U0).max() < 1e-12
     ref = o.propagate_batch(h0, hks, sig[:2], 1e-11, col_ops=col, lindbladian=True)
     assert np.abs(U[:2] - ref).max() < 1e-11

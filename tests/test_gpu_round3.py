@@ -383,14 +383,14 @@ def test_ode_rowq_cfg3_long_and_rk4_unitary(prop):
     h0c, hkc, sgc = np.ascontiguousarray(h0), np.ascontiguousarray(hks), np.ascontiguousarray(sig)
     for env, kern in ((None, "ode_mfma"), ("C3P_ODE_PROP_ROWS", "ode_row")):  # matrix-core kernel, lane-row column kernel
         if env:
-            os.environ[env] = "1"
+            _lib.set_option(env[4:].lower(), "1")
         try:
             U[:] = 0
             dUs[:] = 0
             rc = lib.c3p_rk4_unitary(p(h0c), p(hkc), p(sgc), None, 0, 0.1, B, K, Ns, D, 1, p(U), p(dUs), None)
         finally:
             if env:
-                os.environ.pop(env)
+                _lib.set_option(env[4:].lower(), None)
         assert rc == 0 and _lib.last_kernel() == kern
         for b in range(B):
             Hs = h0[None] + np.einsum("kn,kij->nij", sig[b], hks)
@@ -752,7 +752,7 @@ def test_rk4_unitary_mid_dimension_time_segments(prop, D, B, Ns):
     res = {}
     for env in (None, "C3P_ODE_NO_SEG"):
         if env:
-            os.environ[env] = "1"
+            _lib.set_option(env[4:].lower(), "1")
         try:
             U = np.zeros((B, D, D), complex)
             dUs = np.zeros((B, (Ns - 1) // 2, D, D), complex)
@@ -761,7 +761,7 @@ def test_rk4_unitary_mid_dimension_time_segments(prop, D, B, Ns):
             res[env] = (U, dUs)
         finally:
             if env:
-                os.environ.pop(env)
+                _lib.set_option(env[4:].lower(), None)
     assert np.abs(res[None][0] - res["C3P_ODE_NO_SEG"][0]).max() < 1e-12
     assert np.abs(res[None][1] - res["C3P_ODE_NO_SEG"][1]).max() == 0.0
     for b in range(B):
