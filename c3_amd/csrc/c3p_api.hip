@@ -1339,6 +1339,106 @@ int run_pwc_tiled(DeviceWs* w, const ChainArgs& a, bool per_slice, cplx* U_out, 
 }
 
 // Tiled backward sweep (c3p_tiled.hip): any matrix dimension, unitary and Lindblad generators
+// ---------------------------------------------------------------------------
+// Lindblad control gradient at D = 7, 8, 9 (49 x 49 .. 81 x 81 superoperators, cfg4) in the Hermitian basis: forward chain
+// kernel with the transposed local prefixes kept in HBM, real segment scan, on-chip backward sweep (c3p_regrg.hip).
+// Returns 1 when a Hamiltonian is not Hermitian (complex tables in that basis): the caller falls back to the tiled sweep.
+// ---------------------------------------------------------------------------
+int run_vjp_lind_regr(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals, const cplx* clp,
+                      double dt, int B, int K, int N, int D, int Dm, const double* fr_phase, const cplx* Ubar, double* grad,
+                      hipStream_t st) {
+  if (!c3p_regr_supported(D, Dm) || K > 16 || K < 1) return 1;
+  const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
+  const int nsamp = per_sample ? B : 1;
+  // segments: fill the 256 workgroup slots evenly (rounds of 256 chains), few segments
+  long S = 1;
+  {
+    const long smax = N / 4 > 1 ? N / 4 : 1;
+    double best = -1.0;
+    for (long s = 1; s <= 32 && s <= smax; ++s) {
+      const long chains = (long)B * s, rounds = (chains + C3P_REGD_MAX_WGS - 1) / C3P_REGD_MAX_WGS;
+      const double eff = (double)chains / (double)(rounds * C3P_REGD_MAX_WGS) - 0.004 * (double)s;
+      if (eff > best + 1e-12) best = eff, S = s;
+    }
+    if (c3p_opt(C3P_OPT_segments) > 0) S = std::min<long>(c3p_opt(C3P_OPT_segments), smax);
+  }
+  const size_t msz = (size_t)Dm * Dm;
+  const size_t tabd = c3p_regr_table_doubles(Dm, K);
+  const size_t tab1 = (((size_t)nsamp * tabd * sizeof(double)) + 255) & ~(size_t)255;
+  const size_t ftab = (((size_t)nsamp * (1 + K) * sizeof(int)) + 255) & ~(size_t)255;
+  void* v;
+  if (ws_get(w, SL_TABLES, 2 * tab1 + 2 * ftab, &v)) return -1;
+  double* tab_f = (double*)v;
+  double* tab_t = reinterpret_cast<double*>(static_cast<char*>(v) + tab1);
+  int* flag_f = reinterpret_cast<int*>(static_cast<char*>(v) + 2 * tab1);
+  int* flag_t = reinterpret_cast<int*>(static_cast<char*>(v) + 2 * tab1 + ftab);
+  RegdPrepArgs p = {};
+  p.h0 = h0;
+  p.h0_bstride = h0_bs;
+  p.hks = hks;
+  p.hks_bstride = hk_bs;
+  p.clp = clp;
+  p.dt = dt;
+  p.K = K;
+  p.Dh = D;
+  p.Dm = Dm;
+  p.lindblad = 1;
+  LAUNCH_TRY(c3p_launch_regr_prep_t(p, nsamp, tab_f, flag_f, 0, st));
+  LAUNCH_TRY(c3p_launch_regr_prep_t(p, nsamp, tab_t, flag_t, 1, st));
+  {
+    std::vector<int> hf((size_t)nsamp * (1 + K));
+    HIP_TRY(hipMemcpyAsync(hf.data(), flag_f, hf.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int f : hf)
+      if (!f) return 1;  // a non-Hermitian Hamiltonian: complex generator in the Hermitian basis
+  }
+  void *sv, *bv, *qv, *av;
+  if (ws_get(w, SL_SEG_A, (size_t)B * S * msz * sizeof(cplx), &sv)) return -1;
+  if (ws_get(w, SL_SEG_B, ((size_t)3 * B * S + B) * msz * sizeof(double) + (size_t)B * sizeof(double), &bv)) return -1;
+  if (ws_get(w, SL_OUT1, (size_t)B * N * msz * sizeof(double), &qv)) return -1;
+  if (ws_get(w, SL_SCRATCH, std::max(c3p_regr_grad_arena_bytes(Dm), c3p_regr_arena_bytes(Dm)), &av)) return -1;
+  double* pre = (double*)bv;
+  double* suf = pre + (size_t)B * S * msz;
+  double* lam = suf + (size_t)B * S * msz;
+  double* ubr = lam + (size_t)B * S * msz;
+  double* tau = ubr + (size_t)B * msz;
+  MidArgs a = {};
+  a.tab_per_sample = per_sample ? 1 : 0;
+  a.signals = signals;
+  a.B = B;
+  a.K = K;
+  a.N = N;
+  a.Dm = Dm;
+  a.S = (int)S;
+  a.Lmax = (int)((N + S - 1) / S);
+  a.mode = C3P_MODE_LINDBLAD;
+  a.hb_tables = tab_f;
+  a.hb_tabflag = flag_f;
+  a.hb_qT = (double*)qv;
+  a.seg_out = (cplx*)sv;
+  LAUNCH_TRY(c3p_launch_regr_chain(a, av, st));
+  LAUNCH_TRY(c3p_launch_hb_ubar(Ubar, fr_phase, B, D, ubr, st));
+  LAUNCH_TRY(c3p_launch_regr_scan((const cplx*)sv, ubr, B, (int)S, Dm, pre, suf, lam, tau, st));
+  RegrGradArgs g = {};
+  g.tables = tab_f;
+  g.tables_t = tab_t;
+  g.tab_per_sample = a.tab_per_sample;
+  g.signals = signals;
+  g.qT = (const double*)qv;
+  g.lam = lam;
+  g.tau = tau;
+  g.grad = grad;
+  g.arena = (double*)av;
+  g.B = B;
+  g.K = K;
+  g.N = N;
+  g.Dm = Dm;
+  g.S = (int)S;
+  g.degree = c3p_opt(C3P_OPT_regr_grad_degree) > 0 ? (int)c3p_opt(C3P_OPT_regr_grad_degree) : 0;
+  LAUNCH_TRY(c3p_launch_regr_grad(g, st));
+  return 0;
+}
+
 int run_vjp_tiled(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals,
                   const cplx* clp, double dt, int B, int K, int N, int D, int Dm, const double* fr_phase, const cplx* U_bar,
                   double* grad, hipStream_t st, bool per_slice = false, cplx* zout = nullptr) {
@@ -2256,6 +2356,28 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
     if (record_stop(w, st)) return -1;
     if (flags & C3P_HOST_PTRS) return sg.finish();
     return 0;
+  }
+  if (c3p_regr_supported(D, Dm) && !(flags & C3P_FORCE_GENERIC) && !c3p_opt_on(C3P_OPT_tiled_grad) && !c3p_opt_on(C3P_OPT_no_hermitian_basis)) {
+    // 49 x 49 .. 81 x 81 superoperators (D = 7, 8, 9; cfg4): on-chip backward sweep in the Hermitian basis, real arithmetic; the
+    // transposed local prefix of every slice (N D^4 doubles per sample) is kept in HBM: chunks of samples below 24 GB
+    if (record_start(w, st)) return -1;
+    long Bc = (long)(((size_t)24 << 30) / ((size_t)N * Dm * Dm * sizeof(double)));
+    if (c3p_opt(C3P_OPT_grad_chunk) > 0) Bc = c3p_opt(C3P_OPT_grad_chunk);
+    if (Bc < 1) Bc = 1;
+    int rc = 0;
+    for (long b0 = 0; b0 < B && rc == 0; b0 += Bc) {
+      const int nb = (int)(B - b0 < Bc ? B - b0 : Bc);
+      rc = run_vjp_lind_regr(w, p_h0 + b0 * h0_bstride, h0_bstride, p_hk + b0 * hks_bstride, hks_bstride, p_sig + b0 * K * N,
+                             (const cplx*)clp, dt, nb, K, N, D, Dm, phase_at(b0), p_ub + b0 * gsz, p_grad + b0 * K * N, st);
+      if (rc == 1 && b0 > 0) return fail("internal: the Hermitian-basis sweep declined a later chunk");
+    }
+    if (rc < 0) return -1;
+    if (rc == 0) {
+      g_last_kernel = C3P_KERNEL_MFMA;
+      if (record_stop(w, st)) return -1;
+      if (flags & C3P_HOST_PTRS) return sg.finish();
+      return 0;
+    }
   }
   g_last_kernel = C3P_KERNEL_MFMA;
   if (record_start(w, st)) return -1;

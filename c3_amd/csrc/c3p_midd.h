@@ -24,6 +24,9 @@ struct MidArgs {
   // kernel takes the samples whose tables are all real, the complex one (given the flags) skips exactly those
   const double* hb_tables;
   const int* hb_tabflag;
+  // backward sweep in the Hermitian basis (c3p_regrg.hip): when set, the real kernel also stores the TRANSPOSED local prefix
+  // Q_n^T = (E_n ... E_n0)^T of every slice of its segment, real row-major [B,N,Dm,Dm]
+  double* hb_qT;
 };
 
 // Backward sweep of the control gradient (c3p_grad.hip for the method)

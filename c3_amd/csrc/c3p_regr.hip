@@ -30,72 +30,11 @@
 #include "c3p_kernels.h"
 #include "c3p_midd.h"
 #include "c3p_regd.h"
+#include "c3p_regr_common.h"
 
 extern __shared__ __attribute__((aligned(16))) double c3p_rr_lds[];
 
 namespace {
-
-constexpr int RR_MAXWAVES = 8;
-constexpr int RR_CH = 32;    // control amplitudes staged per chunk of slices
-constexpr int RR_KMAX = 16;  // control lines
-enum { S_M0 = 0, S_M1, S_M2, S_M3, S_R0, S_R1, S_U0, S_U1, S_NSLOT };
-enum { OP_P1 = 0, OP_P2, OP_P3, OP_P4, OP_EX, OP_CH };
-
-template <int NRG>
-struct RR {
-  static constexpr int DM = 16 * NRG + 1;
-  static constexpr int NT = NRG * NRG;  // tiles per column group (4 NRG columns: one wave, or a pair of waves on one SIMD)
-  // image row stride (doubles): A-fragment reads (16 rows x 4 columns per 32 lanes) at most two-way on the 32 bank
-  // pairs for every rotation, the 16-lane tile stores conflict free (brute-forced: 17 mod 32, or 2 mod 4)
-  static constexpr int LD = (NRG == 4) ? DM + 1 : DM;
-  static constexpr int BS = 2 * DM;  // border slot: row DM-1 (DM elements, corner last), column DM-1 (DM elements, corner last)
-  static constexpr int DMP = DM + 1;
-  static constexpr int IMG_D = DM * LD;
-  static constexpr int TSET = NT * 256;  // elements of a tile set: element (tile, column group, lane) at tile * 256 + group * 64 + lane
-  static constexpr int TAB_D = TSET + BS + 4;   // doubles per generator table: tile set, border slot, {mu, norm1, 0, 0}
-  static constexpr int LDS_D = IMG_D + S_NSLOT * BS + 8 * DMP + RR_KMAX * RR_CH + 2 * RR_MAXWAVES;
-};
-
-template <typename F, int... Is>
-__device__ __forceinline__ void rr_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-  (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void rr_static_for(F&& f) {
-  rr_static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-// the four 4-lane groups of every 16-lane row rotated by S groups (DPP row_ror): MFMA block b then holds what block
-// (b - S) mod 4 held
-template <int S>
-__device__ __forceinline__ double rr_rot(double v) {
-  if constexpr (S == 0) {
-    return v;
-  } else {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_mov_dpp(lo, 0x120 + 4 * S, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_mov_dpp(hi, 0x120 + 4 * S, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-  }
-}
-
-__device__ __forceinline__ int rr_opq(int v) {
-  asm volatile("" : "+s"(v));
-  return v;
-}
-template <typename T>
-__device__ __forceinline__ T* rr_ubase(T* p) {
-  return p + rr_opq(0);
-}
-// workgroup barrier that waits for the LDS traffic only
-__device__ __forceinline__ void rr_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-__device__ __forceinline__ double rr_rfl(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readfirstlane(lo);
-  hi = __builtin_amdgcn_readfirstlane(hi);
-  return __hiloint2double(hi, lo);
-}
 
 // The chain loop of one wave.  NW = 4: one wave per SIMD, wave w owns the 4 NRG columns of column group w (NJ = NRG column
 // blocks).  NW = 8: two waves per SIMD (waves w and w + 4 share one), the column blocks of a group are split between them
@@ -107,7 +46,7 @@ __device__ __forceinline__ double rr_rfl(double v) {
 // 0.2 MB per slice and chain against the 1.0 MB of the complex kernel).  What it buys: the second workgroup's MFMAs run
 // under this one's latencies -- the phases between products (element-wise work, LDS round trips, barriers, table loads)
 // are ~40 % of a slice with one workgroup per CU.
-template <int NRG, int NJ, int NW, bool DUS, bool UNROLL, bool LEAN>
+template <int NRG, int NJ, int NW, bool DUS, bool UNROLL, bool LEAN, bool QT = false>
 __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg, double* arena_base, const int cg, const int jj0, const int wave) {
   using G = RR<NRG>;
   constexpr int DM = G::DM, LD = G::LD, BS = G::BS, DMP = G::DMP;
@@ -387,6 +326,22 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
     }
   };
 
+  // QT: the transposed running product of the segment after every slice (backward sweep in the Hermitian basis, c3p_regrg.hip)
+  auto store_qT = [&](double* dst_, int slot, double f) {
+    double* dst = rr_ubase(dst_);
+#pragma unroll
+    for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) {
+        const int row = 16 * Ig + rowC, col = col0 + 4 * jj + p;
+        if (row < DR && col < DR) dst[(long)col * DR + row] = f * acc[Ig][jj];
+      }
+    if (tid < BS - 1) {
+      const double v = brd[slot * BS + tid];
+      const int row = tid < DM ? DM - 1 : tid - DM, col = tid < DM ? tid : DM - 1;
+      if (row < DR && col < DR) dst[(long)col * DR + row] = f * v;
+    }
+  };
   const long nchains = (long)A.B * A.S;
   const long mat_c = (long)DR * DR;  // complex elements of an output slot; the real result goes to its second half
   for (long chain = blockIdx.x; chain < nchains; chain += gridDim.x) {
@@ -588,6 +543,7 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
             ucur = S_U0;
             first = false;
             mus = mu;
+            if constexpr (QT) store_qT(A.hb_qT + ((long)sample * A.N + n0 + t) * mat_c, sd, exp(mus));
             next_slice = true;
           } else {  // U <- C U
             image_from_C();
@@ -615,6 +571,7 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
             for (int jj = 0; jj < NJ; ++jj) Us[Ig][jj] = acc[Ig][jj];
         }
         ucur ^= 1;
+        if constexpr (QT) store_qT(A.hb_qT + ((long)sample * A.N + n0 + t) * mat_c, ucur, exp(mus));
         next_slice = true;
       }
       if (next_slice) {
@@ -648,11 +605,11 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
   }
 }
 
-template <int NRG, int NW, bool DUS, bool UNROLL, bool LEAN>
+template <int NRG, int NW, bool DUS, bool UNROLL, bool LEAN, bool QT = false>
 __global__ void __launch_bounds__(64 * NW, LEAN ? 2 : NW / 4) regr_chain_kernel(MidArgs A, double* arena, long long* dbg) {
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   if constexpr (NW == 4) {
-    regr_chain_body<NRG, NRG, 4, DUS, UNROLL, LEAN>(A, dbg, arena, wave, 0, wave);
+    regr_chain_body<NRG, NRG, 4, DUS, UNROLL, LEAN, QT>(A, dbg, arena, wave, 0, wave);
   } else {
     constexpr int NJ0 = (NRG + 1) / 2, NJ1 = NRG / 2;
     if (wave < 4) regr_chain_body<NRG, NJ0, 8, DUS, UNROLL, false>(A, dbg, arena, wave, 0, wave);
@@ -660,47 +617,11 @@ __global__ void __launch_bounds__(64 * NW, LEAN ? 2 : NW / 4) regr_chain_kernel(
   }
 }
 
-// ---- the change of basis ------------------------------------------------------------------------------------------------
-// index a = i D + j of the row-major vectorisation, partner a' = j D + i.  Rows of T:
-//   i == j: e_a;   i < j: (e_a + e_a') / sqrt 2;   i > j: i (e_a - e_a') / sqrt 2      [a' is the (j, i) element, j < i]
-// hb_row: the (at most two) non-zeros of ROW a of T;  hb_col: the non-zeros of COLUMN a of T.
-__device__ __forceinline__ int hb_row(int a, int D, int (&idx)[2], cplx (&t)[2]) {
-  const double r = 0.70710678118654752440;
-  const int i = a / D, j = a - i * D, ap = j * D + i;
-  if (i == j) {
-    idx[0] = a, t[0] = cmake(1.0, 0.0);
-    return 1;
-  }
-  if (i < j) {
-    idx[0] = a, t[0] = cmake(r, 0.0);
-    idx[1] = ap, t[1] = cmake(r, 0.0);
-  } else {
-    idx[0] = ap, t[0] = cmake(0.0, -r);
-    idx[1] = a, t[1] = cmake(0.0, r);
-  }
-  return 2;
-}
-__device__ __forceinline__ int hb_col(int a, int D, int (&idx)[2], cplx (&t)[2]) {
-  const double r = 0.70710678118654752440;
-  const int i = a / D, j = a - i * D, ap = j * D + i;
-  if (i == j) {
-    idx[0] = a, t[0] = cmake(1.0, 0.0);
-    return 1;
-  }
-  if (i < j) {  // T[a, a] = r (row a is the symmetric combination), T[a', a] = -i r
-    idx[0] = a, t[0] = cmake(r, 0.0);
-    idx[1] = ap, t[1] = cmake(0.0, -r);
-  } else {  // T[a', a] = r (row a' is the symmetric combination), T[a, a] = +i r
-    idx[0] = ap, t[0] = cmake(r, 0.0);
-    idx[1] = a, t[1] = cmake(0.0, r);
-  }
-  return 2;
-}
-
+// ---- the change of basis (c3p_hb_row / c3p_hb_col: c3p_regd.h) ---------------------------------------------------------
 // Real generator tables in the kernel's layout: G' = Re(T G T^+) with G the Lindblad generator pieces
 // L0 = dt (clp - i (H0 (x) I - I (x) H0^T)), Lk = -i dt (Hk (x) I - I (x) Hk^T) (propagation.py:565-582), trace shifted;
 // flag = 1 when |Im(T G T^+)| <= 1e-14 max |T G T^+| everywhere (a Hermitian Hamiltonian).
-__global__ void __launch_bounds__(256) regr_prep_kernel(RegdPrepArgs P, double* tables, int* tabflag) {
+__global__ void __launch_bounds__(256) regr_prep_kernel(RegdPrepArgs P, double* tables, int* tabflag, int transpose) {
   __shared__ double red0[256], red1[256];
   __shared__ double mu_s;
   const int tid = threadIdx.x;
@@ -725,11 +646,12 @@ __global__ void __launch_bounds__(256) regr_prep_kernel(RegdPrepArgs P, double* 
     }
     return cscale(v, P.dt);
   };
-  // element (a, b) of T G T^+
-  auto helem = [&](int a, int b) -> cplx {
+  // element (a, b) of T G T^+ (transpose: of its transpose -- the backward sweep exponentiates X^T)
+  auto helem = [&](int a_, int b_) -> cplx {
+    const int a = transpose ? b_ : a_, b = transpose ? a_ : b_;
     int ia[2], ib[2];
     cplx ta[2], tb[2];
-    const int na = hb_row(a, Dh, ia, ta), nb = hb_row(b, Dh, ib, tb);
+    const int na = c3p_hb_row(a, Dh, ia, ta), nb = c3p_hb_row(b, Dh, ib, tb);
     cplx s = cmake(0.0, 0.0);
     for (int x = 0; x < na; ++x)
       for (int y = 0; y < nb; ++y) cfma(s, cmul(ta[x], cconj(tb[y])), gelem(ia[x], ib[y]));
@@ -822,7 +744,7 @@ __global__ void __launch_bounds__(256) hb_to_complex_kernel(cplx* mats, int mats
     const int al = e / Dm, be = e - al * Dm;
     int ia[2], ib[2];
     cplx ta[2], tb[2];
-    const int na = hb_col(al, Dh, ia, ta), nb = hb_col(be, Dh, ib, tb);
+    const int na = c3p_hb_col(al, Dh, ia, ta), nb = c3p_hb_col(be, Dh, ib, tb);
     cplx s = cmake(0.0, 0.0);
     for (int x = 0; x < na; ++x)
       for (int y = 0; y < nb; ++y) {
@@ -867,6 +789,9 @@ hipError_t launch_rr(const MidArgs& A, void* arena, hipStream_t st) {
   if (A.dUs_out) return unroll ? go(regr_chain_kernel<NRG, NW, true, true, LEAN>) : go(regr_chain_kernel<NRG, NW, true, false, LEAN>);
   return unroll ? go(regr_chain_kernel<NRG, NW, false, true, LEAN>) : go(regr_chain_kernel<NRG, NW, false, false, LEAN>);
 #else
+  if constexpr (NW == 4 && !LEAN) {
+    if (A.hb_qT) return A.dUs_out ? hipErrorInvalidValue : go(regr_chain_kernel<NRG, 4, false, true, false, true>);
+  }
   if (A.dUs_out) return go(regr_chain_kernel<NRG, NW, true, true, LEAN>);
   return go(regr_chain_kernel<NRG, NW, false, true, LEAN>);
 #endif
@@ -884,9 +809,12 @@ size_t c3p_regr_table_doubles(int Dm, int K) {
   return (size_t)(1 + K) * ((size_t)n * n * 256 + 2 * DP + 4);
 }
 
-hipError_t c3p_launch_regr_prep(const RegdPrepArgs& P, int nsamp, double* tables, int* tabflag, hipStream_t st) {
-  hipLaunchKernelGGL(regr_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K))), dim3(256), 0, st, P, tables, tabflag);
+hipError_t c3p_launch_regr_prep_t(const RegdPrepArgs& P, int nsamp, double* tables, int* tabflag, int transpose, hipStream_t st) {
+  hipLaunchKernelGGL(regr_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K))), dim3(256), 0, st, P, tables, tabflag, transpose);
   return hipGetLastError();
+}
+hipError_t c3p_launch_regr_prep(const RegdPrepArgs& P, int nsamp, double* tables, int* tabflag, hipStream_t st) {
+  return c3p_launch_regr_prep_t(P, nsamp, tables, tabflag, 0, st);
 }
 
 // arena: c3p_regr_arena_bytes() of scratch (the two-workgroups-per-CU form parks two tile sets per workgroup there)

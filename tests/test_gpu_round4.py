@@ -112,3 +112,92 @@ def test_goal_run_with_grad_fused_equals_unfused(prop):
         for key in ("goal", "grad_env", "grad_carrier", "grad_fr_phase", "U"):
             x, y = a[key].cpu().numpy(), b[key].cpu().numpy()
             assert np.abs(x - y).max() <= 1e-11 * max(np.abs(y).max(), 1e-30), (fid_func, key)
+
+
+# --------------------------------------------------------------------------
+# Lindblad control gradient at D = 7, 8, 9 (49 x 49 .. 81 x 81 superoperators): on-chip backward sweep in the Hermitian basis
+# (c3p_regrg.hip) -- the taped tf_propagation_lind (propagation.py:551-585 under optimizers/optimizer.py:206-216)
+# --------------------------------------------------------------------------
+
+
+def _lind_case(D, B, K, N, C, seed, per_sample=False, hscale=0.8, cscale=0.25):
+    rng = np.random.default_rng(seed)
+    herm = lambda s: (lambda a: s * (a + a.conj().T) / 2)(rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))
+    nb = B if per_sample else 1
+    h0 = np.stack([herm(hscale) for _ in range(nb)])
+    hks = np.stack([np.stack([herm(0.5 * hscale / 0.8) for _ in range(K)]) for _ in range(nb)])
+    if not per_sample:
+        h0, hks = h0[0], hks[0]
+    col = np.stack([cscale * (rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))) for _ in range(C)])
+    sig = rng.uniform(-1, 1, size=(B, K, N))
+    Dm = D * D
+    Ubar = rng.normal(size=(B, Dm, Dm)) + 1j * rng.normal(size=(B, Dm, Dm))
+    ph = rng.uniform(0, 2 * np.pi, size=(B, Dm))
+    return h0, hks, col, sig, Ubar, ph
+
+
+@pytest.mark.parametrize("D,N,B,K,C,per_sample,segments,dt", [
+    (9, 9, 2, 2, 2, False, None, 0.1),   # one segment per sample, no squarings at the highest degree
+    (9, 17, 3, 2, 1, True, 4, 0.3),      # several segments (scan: prefix, suffix, fold), per-sample operators, squarings
+    (8, 12, 2, 3, 2, False, 3, 0.25),    # 64 x 64 in the zero-padded 65 class
+    (7, 16, 2, 1, 1, True, 2, 0.3),      # 49 x 49
+])
+def test_lindblad_vjp_hermitian_basis_sweep(prop, D, N, B, K, C, per_sample, segments, dt):
+    """against the FD-pinned oracle gradient (one Frechet derivative per (k, n)) and against the tiled sweep on the same inputs"""
+    h0, hks, col, sig, Ubar, ph = _lind_case(D, B, K, N, C, 1000 + 10 * D + N, per_sample)
+    _lib.set_option("segments", segments)
+    try:
+        g = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar, fr_phase=ph))
+        assert _lib.last_kernel() == "mfma"
+        _lib.set_option("tiled_grad", "1")
+        gt = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, dt, col, Ubar, fr_phase=ph))
+    finally:
+        _lib.set_option("segments", None)
+        _lib.set_option("tiled_grad", None)
+    assert np.abs(g - gt).max() < 1e-10 * np.abs(gt).max()
+    for b in (0, B - 1):
+        hb0 = h0[b] if per_sample else h0
+        hbk = hks[b] if per_sample else hks
+        want = o.pwc_lindblad_signal_gradient(hb0, hbk, col, sig[b], dt, Ubar[b], ph[b])
+        assert np.abs(g[b] - want).max() < 1e-10 * np.abs(want).max()
+
+
+def test_lindblad_vjp_hermitian_basis_degrees_chunks_and_fallback(prop):
+    """every Taylor degree of the pair evaluation (8, 12, 16, 20: different Horner depths and squaring counts) gives the same
+    gradient; sample chunks reproduce the single-chunk result; a non-Hermitian Hamiltonian (complex generator in the Hermitian
+    basis) falls back to the tiled sweep and still matches the oracle."""
+    D, B, K, N = 9, 5, 2, 11
+    h0, hks, col, sig, Ubar, ph = _lind_case(D, B, K, N, 1, 77, per_sample=True)
+    ref = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, 0.2, col, Ubar, fr_phase=ph))
+    for deg in (8, 12, 16, 20):
+        with _lib.options(regr_grad_degree=deg):
+            g = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, 0.2, col, Ubar, fr_phase=ph))
+        assert np.abs(g - ref).max() < 2e-11 * np.abs(ref).max(), deg
+    with _lib.options(grad_chunk=2, segments=3):
+        many = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, 0.2, col, Ubar, fr_phase=ph))
+    assert np.abs(many - ref).max() < 1e-11 * np.abs(ref).max()
+    want = o.pwc_lindblad_signal_gradient(h0[3], hks[3], col, sig[3], 0.2, Ubar[3], ph[3])
+    assert np.abs(ref[3] - want).max() < 1e-10 * np.abs(want).max()
+    # lossy (non-Hermitian) drift: the generator is complex in the Hermitian basis
+    hn = h0[0] - 0.05j * np.diag(np.arange(D))
+    gn = np.asarray(prop.propagate_batch_lindblad_vjp(hn, hks[0], sig[:2], 0.2, col, Ubar[:2], fr_phase=ph[:2]))
+    want = o.pwc_lindblad_signal_gradient(hn, hks[0], col, sig[1], 0.2, Ubar[1], ph[1])
+    assert np.abs(gn[1] - want).max() < 1e-10 * np.abs(want).max()
+
+
+def test_lindblad_vjp_hermitian_basis_strong_dissipation_and_long_chain(prop):
+    """a strongly damped two-qutrit chain (nothing is inverted in the sweep) over 70 slices in 5 segments: signal chunks of 32
+    slices, ragged segment lengths; against the tiled sweep (itself oracle-checked above) and the oracle on one sample."""
+    D, B, K, N = 9, 2, 2, 70
+    rng = np.random.default_rng(3)
+    herm = lambda s: (lambda a: s * (a + a.conj().T) / 2)(rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))
+    h0, hks = herm(1.0), np.stack([herm(0.5) for _ in range(K)])
+    a = np.kron(np.diag(np.sqrt(np.arange(1, 3)), 1), np.eye(3))
+    col = np.stack([0.8 * a, 0.5 * np.kron(np.eye(3), np.diag(np.arange(3.0)))]).astype(complex)
+    sig = rng.uniform(-1, 1, size=(B, K, N))
+    Ubar = rng.normal(size=(B, 81, 81)) + 1j * rng.normal(size=(B, 81, 81))
+    with _lib.options(segments=5):
+        g = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, 0.25, col, Ubar))
+    with _lib.options(tiled_grad=1):
+        gt = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, 0.25, col, Ubar))
+    assert np.abs(g - gt).max() < 1e-10 * np.abs(gt).max()
