@@ -78,7 +78,7 @@ _KERNEL_SOURCES = {
     1: ("c3p_smalld.hip", "c3p_smalld.h", "c3p_common.h"),
     2: ("c3p_smalld.hip", "c3p_smalld.h", "c3p_common.h"),
     3: ("c3p_midd.hip", "c3p_midd.h", "c3p_common.h"),
-    4: ("c3p_regr.hip", "c3p_regd.h", "c3p_midd.h", "c3p_common.h"),
+    4: ("c3p_regr.hip", "c3p_regr_common.h", "c3p_regd.h", "c3p_midd.h", "c3p_common.h"),
     5: ("c3p_midd.hip", "c3p_midd.h", "c3p_common.h"),
 }
 

@@ -378,6 +378,263 @@ __device__ __forceinline__ void rcomb(double (&out)[RD<D>::NB][RD<D>::NB], doubl
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// "Core + border" form of the real path for D = 4 NC + 1 (D = 9: the 8 + 1 split).  A 9 x 9 matrix in
+// 12 x 12 tiles spends 6 of the 12 MFMAs of a symmetric product (10 of the 18 of a chain product) on the tiles of its last
+// row and column, which carry 4, 4 and 1 of 16 elements.  Here the (D-1) x (D-1) core tiles exactly (NC x NC tiles, no padding
+// at all) and the last row / column / corner are carried separately, per chain, in the lanes of its MFMA block:
+//   symmetric matrix (SMat): core tiles (upper, lower mirrored for operands), the border column twice -- vr[I] = M[4I+r][D-1]
+//     (replicated over c) and vc[J] = M[4J+c][D-1] (replicated over r) --, the corner s (all 16 lanes);
+//   general matrix (GMat, the chain state): core, column border cr (r form) / cc (c form), row border rc[J] = M[D-1][4J+c], s.
+// Border of a product: column = core x vector on the vector unit (one FMA per tile and lane + a quad reduction by DPP),
+// its c form by one lane swap; corner = dot product (quad reduction); the ROW border of a chain product is a vector-matrix
+// product whose sum runs over the r lanes (16 apart: no DPP reach) -- it stays on the matrix cores as ONE A tile per K-step
+// whose only row is the border (4 MFMAs instead of the 10 of the padded tiles).  Measured in isolation
+// (tools/ubench_sym9.hip, profiles/r04/ubench_sym9.txt): a dependent symmetric product 284 ns against 315 ns per wave at two
+// waves per SIMD.
+// ---------------------------------------------------------------------------------------------
+template <int NC>
+struct SMat {
+  double m[NC][NC];
+  double vr[NC], vc[NC];
+  double s;
+};
+template <int NC>
+struct GMat {
+  double m[NC][NC];
+  double cr[NC], cc[NC], rc[NC];
+  double s;
+};
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// sum over the four lanes of a quad (the column index c), result in all four
+__device__ __forceinline__ double quad_sum(double v) {
+  v += dpp_f64<0xB1>(v);  // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);  // quad_perm [2,3,0,1]
+  return v;
+}
+
+template <int NC>
+__device__ __forceinline__ void s8_zero(SMat<NC>& a) {
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+#pragma unroll
+    for (int J = 0; J < NC; ++J) a.m[I][J] = 0.0;
+    a.vr[I] = a.vc[I] = 0.0;
+  }
+  a.s = 0.0;
+}
+
+// C += A B for symmetric commuting A, B (upper core tiles, vr, s of C; s8_finish completes the operand form of C)
+template <int NC>
+__device__ __forceinline__ void mm_s8(const SMat<NC>& a, const SMat<NC>& b, SMat<NC>& c) {
+#pragma unroll
+  for (int K = 0; K < NC; ++K)
+#pragma unroll
+    for (int I = 0; I < NC; ++I)
+#pragma unroll
+      for (int J = I; J < NC; ++J) c.m[I][J] = mfma4(a.m[K][I], b.m[K][J], c.m[I][J]);
+  double t[NC], cs = 0.0;
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+    t[I] = 0.0;
+#pragma unroll
+    for (int K = 0; K < NC; ++K) t[I] = fma(a.m[I][K], b.vc[K], t[I]);
+    cs = fma(a.vc[I], b.vc[I], cs);
+  }
+#pragma unroll
+  for (int I = 0; I < NC; ++I) c.vr[I] += fma(a.vr[I], b.s, quad_sum(t[I]));
+  c.s += fma(a.s, b.s, quad_sum(cs));
+#pragma unroll
+  for (int I = 0; I < NC; ++I)
+#pragma unroll
+    for (int J = I; J < NC; ++J) c.m[I][J] = fma(a.vr[I], b.vc[J], c.m[I][J]);
+}
+// two products with one left operand, interleaved (C1 += A B1, C2 += A B2)
+template <int NC>
+__device__ __forceinline__ void mm_s8x2(const SMat<NC>& a, const SMat<NC>& b1, SMat<NC>& c1, const SMat<NC>& b2, SMat<NC>& c2) {
+#pragma unroll
+  for (int K = 0; K < NC; ++K)
+#pragma unroll
+    for (int I = 0; I < NC; ++I)
+#pragma unroll
+      for (int J = I; J < NC; ++J) {
+        c1.m[I][J] = mfma4(a.m[K][I], b1.m[K][J], c1.m[I][J]);
+        c2.m[I][J] = mfma4(a.m[K][I], b2.m[K][J], c2.m[I][J]);
+      }
+  double t1[NC], t2[NC], cs1 = 0.0, cs2 = 0.0;
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+    t1[I] = t2[I] = 0.0;
+#pragma unroll
+    for (int K = 0; K < NC; ++K) {
+      t1[I] = fma(a.m[I][K], b1.vc[K], t1[I]);
+      t2[I] = fma(a.m[I][K], b2.vc[K], t2[I]);
+    }
+    cs1 = fma(a.vc[I], b1.vc[I], cs1);
+    cs2 = fma(a.vc[I], b2.vc[I], cs2);
+  }
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+    c1.vr[I] += fma(a.vr[I], b1.s, quad_sum(t1[I]));
+    c2.vr[I] += fma(a.vr[I], b2.s, quad_sum(t2[I]));
+  }
+  c1.s += fma(a.s, b1.s, quad_sum(cs1));
+  c2.s += fma(a.s, b2.s, quad_sum(cs2));
+#pragma unroll
+  for (int I = 0; I < NC; ++I)
+#pragma unroll
+    for (int J = I; J < NC; ++J) {
+      c1.m[I][J] = fma(a.vr[I], b1.vc[J], c1.m[I][J]);
+      c2.m[I][J] = fma(a.vr[I], b2.vc[J], c2.m[I][J]);
+    }
+}
+// operand form of a product: lower core tiles by the in-chain lane swap, the c form of the border column
+template <int NC>
+__device__ __forceinline__ void s8_finish(SMat<NC>& a, int swap_lane, int tail_lane) {
+#pragma unroll
+  for (int I = 1; I < NC; ++I)
+#pragma unroll
+    for (int J = 0; J < I; ++J) a.m[I][J] = __shfl(a.m[J][I], swap_lane);
+#pragma unroll
+  for (int J = 0; J < NC; ++J) a.vc[J] = __shfl(a.vr[J], tail_lane);
+}
+// out = c0 I + c1 W1 + c2 W2 (+ c3 W3), every part (operands are complete: the combination is too); ACCUM: only what a
+// product accumulates into (upper core tiles, vr, s) -- the initial value of an accumulation that s8_finish completes later
+template <int NC, bool WITH3, bool ACCUM = false>
+__device__ __forceinline__ void s8_comb(SMat<NC>& out, double c0, double c1, double c2, double c3, const SMat<NC>& W1, const SMat<NC>& W2,
+                                        const SMat<NC>& W3, const LanePos& lp) {
+  auto lc = [&](double x1, double x2, double x3) {
+    double v = c1 * x1;
+    v = fma(c2, x2, v);
+    if constexpr (WITH3) v = fma(c3, x3, v);
+    return v;
+  };
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+#pragma unroll
+    for (int J = ACCUM ? I : 0; J < NC; ++J) {
+      double v = lc(W1.m[I][J], W2.m[I][J], W3.m[I][J]);
+      if (I == J) v += (lp.r == lp.c) ? c0 : 0.0;
+      out.m[I][J] = v;
+    }
+    out.vr[I] = lc(W1.vr[I], W2.vr[I], W3.vr[I]);
+    if constexpr (!ACCUM) out.vc[I] = lc(W1.vc[I], W2.vc[I], W3.vc[I]);
+  }
+  out.s = lc(W1.s, W2.s, W3.s) + c0;
+}
+
+
+// chain step in real blocks for the core + border form: (Ur + i Ui) <- (C - i S)(Ur + i Ui) with three real products
+// (T1 = C Ur, T2 = S Ui, T3 = (C - S)(Ur + Ui): Re = T1 + T2, Im = T3 - T1 + T2), C and S symmetric (complete operand form).
+// The three products are combined BEFORE the quad reductions and lane swaps of the borders (six reductions, eight swaps per
+// step instead of nine and twelve).
+template <int NC>
+__device__ __forceinline__ void chain_step8(const SMat<NC>& Cc, const SMat<NC>& Sc, GMat<NC>& Ur, GMat<NC>& Ui, const LanePos& lp,
+                                            int tail_lane, int row0_lane) {
+  SMat<NC> Dm;
+  GMat<NC> Us;
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+#pragma unroll
+    for (int J = 0; J < NC; ++J) {
+      Dm.m[I][J] = Cc.m[I][J] - Sc.m[I][J];
+      Us.m[I][J] = Ur.m[I][J] + Ui.m[I][J];
+    }
+    Dm.vr[I] = Cc.vr[I] - Sc.vr[I];
+    Dm.vc[I] = Cc.vc[I] - Sc.vc[I];
+    Us.cc[I] = Ur.cc[I] + Ui.cc[I];
+    Us.rc[I] = Ur.rc[I] + Ui.rc[I];
+  }
+  Dm.s = Cc.s - Sc.s;
+  Us.s = Ur.s + Ui.s;
+  double T1[NC][NC], T2[NC][NC], T3[NC][NC], R1[NC], R2[NC], R3[NC];
+  double aC[NC], aS[NC], aD[NC];
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+#pragma unroll
+    for (int J = 0; J < NC; ++J) T1[I][J] = T2[I][J] = T3[I][J] = 0.0;
+    R1[I] = R2[I] = R3[I] = 0.0;
+    // A tile whose only row (i = 0: lanes c = 0) is the border row of the symmetric left operand
+    aC[I] = lp.c == 0 ? Cc.vr[I] : 0.0;
+    aS[I] = lp.c == 0 ? Sc.vr[I] : 0.0;
+    aD[I] = lp.c == 0 ? Dm.vr[I] : 0.0;
+  }
+#pragma unroll
+  for (int K = 0; K < NC; ++K) {
+#pragma unroll
+    for (int I = 0; I < NC; ++I)
+#pragma unroll
+      for (int J = 0; J < NC; ++J) {
+        T1[I][J] = mfma4(Cc.m[K][I], Ur.m[K][J], T1[I][J]);
+        T2[I][J] = mfma4(Sc.m[K][I], Ui.m[K][J], T2[I][J]);
+        T3[I][J] = mfma4(Dm.m[K][I], Us.m[K][J], T3[I][J]);
+      }
+#pragma unroll
+    for (int J = 0; J < NC; ++J) {
+      R1[J] = mfma4(aC[K], Ur.m[K][J], R1[J]);
+      R2[J] = mfma4(aS[K], Ui.m[K][J], R2[J]);
+      R3[J] = mfma4(aD[K], Us.m[K][J], R3[J]);
+    }
+  }
+  // column border and corner: partial sums over the lane's column index, reduced after the three products are combined
+  double pr[NC], pi[NC], cr_ = 0.0, ci_ = 0.0;
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+    double p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+    for (int K = 0; K < NC; ++K) {
+      p1 = fma(Cc.m[I][K], Ur.cc[K], p1);
+      p2 = fma(Sc.m[I][K], Ui.cc[K], p2);
+      p3 = fma(Dm.m[I][K], Us.cc[K], p3);
+    }
+    pr[I] = p1 + p2;
+    pi[I] = (p3 - p1) + p2;
+    const double c1 = Cc.vc[I] * Ur.cc[I], c2 = Sc.vc[I] * Ui.cc[I], c3 = Dm.vc[I] * Us.cc[I];
+    cr_ += c1 + c2;
+    ci_ += (c3 - c1) + c2;
+  }
+  const double e1 = Cc.s * Ur.s, e2 = Sc.s * Ui.s, e3 = Dm.s * Us.s;
+  const double sr = quad_sum(cr_) + (e1 + e2), si = quad_sum(ci_) + ((e3 - e1) + e2);
+  double colr[NC], coli[NC], rowr[NC], rowi[NC];
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+    const double q1 = Cc.vr[I] * Ur.s, q2 = Sc.vr[I] * Ui.s, q3 = Dm.vr[I] * Us.s;
+    colr[I] = quad_sum(pr[I]) + (q1 + q2);
+    coli[I] = quad_sum(pi[I]) + ((q3 - q1) + q2);
+    // row border: the k = D-1 term on top of the matrix-core sums (lanes r = 0 hold the row)
+    const double r1 = fma(Cc.s, Ur.rc[I], R1[I]), r2 = fma(Sc.s, Ui.rc[I], R2[I]), r3 = fma(Dm.s, Us.rc[I], R3[I]);
+    rowr[I] = r1 + r2;
+    rowi[I] = (r3 - r1) + r2;
+  }
+#pragma unroll
+  for (int I = 0; I < NC; ++I)
+#pragma unroll
+    for (int J = 0; J < NC; ++J) {
+      const double t1 = fma(Cc.vr[I], Ur.rc[J], T1[I][J]), t2 = fma(Sc.vr[I], Ui.rc[J], T2[I][J]), t3 = fma(Dm.vr[I], Us.rc[J], T3[I][J]);
+      Ur.m[I][J] = t1 + t2;
+      Ui.m[I][J] = (t3 - t1) + t2;
+    }
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+    Ur.cr[I] = colr[I];
+    Ui.cr[I] = coli[I];
+    Ur.cc[I] = __shfl(colr[I], tail_lane);
+    Ui.cc[I] = __shfl(coli[I], tail_lane);
+    Ur.rc[I] = __shfl(rowr[I], row0_lane);
+    Ui.rc[I] = __shfl(rowi[I], row0_lane);
+  }
+  Ur.s = sr;
+  Ui.s = si;
+}
+
 // q = 4 plan: degree 4r, s squarings, from a bound on ||X||_1
 __device__ __forceinline__ void plan_q4(double nrm, int& r, int& s) {
   // Taylor backward-error bounds for unit roundoff 2^-52 (theta_m of Al-Mohy & Higham scaled by 2^(1/m))
@@ -549,7 +806,7 @@ __device__ __forceinline__ void build_tables(const SmallArgs& A, int sample, dou
 // of one CU).  The tables are built once per workgroup and the waves' partial products meet in LDS behind a barrier,
 // instead of once per wave and through global memory behind a ticket: the fixed cost of a cfg2 batch (29 us of 149:
 // combine 12, table build 4, launch and prologue 13) is what this mode attacks.
-template <int D, bool GIVEN, bool DUS, bool XG = false, bool MW = false>
+template <int D, bool GIVEN, bool DUS, bool XG = false, bool MW = false, bool SPLIT = false>
 __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallArgs A) {
   using C = SD<D>;
   constexpr int NBI = C::NBI, NJ = C::NJ, W = C::W, MAT = C::MAT, IMG = C::IMG;
@@ -753,6 +1010,198 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
       // shallower 7-product evaluation is used.  The variant is chosen per segment OUTSIDE the slice loop (the loop is
       // instantiated twice) so that neither variant's registers burden the other's schedule.
       const bool deg16 = __builtin_amdgcn_readfirstlane((int)(nrm * rscale <= 8.16e-1)) != 0;
+      if constexpr (SPLIT) {
+        // ---- core + border form (D = 4 NC + 1; see SMat / GMat above): the same polynomial evaluation and chain step ----
+        static_assert(!SPLIT || (D % 4 == 1 && D > 4 && !DUS), "core + border form: D = 5, 9 without slice output");
+        constexpr int NC = (D - 1) / 4;
+        typedef SMat<NC> SM;
+        GMat<NC> Gr, Gi;  // the chain state
+        int so[NC], sro[NC], sco[NC];
+#pragma unroll
+        for (int I = 0; I < NC; ++I) {
+          so[I] = (2 * (4 * I + lp.r) + 1) * W + lp.c;
+          sro[I] = (2 * (4 * I + lp.r) + 1) * W + (D - 1);
+          sco[I] = (2 * (4 * I + lp.c) + 1) * W + (D - 1);
+        }
+        constexpr int sso = (2 * (D - 1) + 1) * W + (D - 1);
+        auto split_loop = [&](auto deg16_tag) {
+          constexpr bool DEG16 = decltype(deg16_tag)::value;
+          for (int t = 0; t < tmax; ++t) {
+            const bool act = valid && t < len;
+            const double sc = act ? rscale : 0.0;
+            const double muw = act ? 1.0 : 0.0;
+            double mu_r = muw * tab[MAT + 0], mu_i = muw * tab[MAT + 1];
+            SM Y;
+            {
+              const double f = -sc;
+#pragma unroll
+              for (int I = 0; I < NC; ++I) {
+#pragma unroll
+                for (int J = 0; J < NC; ++J) Y.m[I][J] = f * lds_ld(tab + so[I] + J * 4);
+                Y.vr[I] = f * lds_ld(tab + sro[I]);
+                Y.vc[I] = f * lds_ld(tab + sco[I]);
+              }
+              Y.s = f * lds_ld(tab + sso);
+            }
+            for (int k = 0; k < K; ++k) {
+              const double c0 = sg[lp.b * SG + k * A.Lmax + t];
+              const double f = -sc * c0;
+              const double* tk = tab + (k + 1) * (MAT + 4);
+              mu_r = fma(c0, tk[MAT + 0], mu_r);
+              mu_i = fma(c0, tk[MAT + 1], mu_i);
+#pragma unroll
+              for (int I = 0; I < NC; ++I) {
+#pragma unroll
+                for (int J = 0; J < NC; ++J) Y.m[I][J] = fma(f, lds_ld(tk + so[I] + J * 4), Y.m[I][J]);
+                Y.vr[I] = fma(f, lds_ld(tk + sro[I]), Y.vr[I]);
+                Y.vc[I] = fma(f, lds_ld(tk + sco[I]), Y.vc[I]);
+              }
+              Y.s = fma(f, lds_ld(tk + sso), Y.s);
+            }
+            SM W1, W2, W3, Cm, Sp, acc, acs;
+            s8_zero(W1), s8_zero(W2), s8_zero(W3);
+            mm_s8(Y, Y, W1);  // W = Y^2
+            s8_finish(W1, swap_lane, tail_lane);
+            mm_s8(W1, W1, W2);  // W^2
+            s8_finish(W2, swap_lane, tail_lane);
+            if constexpr (DEG16) {
+              SM W4;
+              s8_zero(W4);
+              mm_s8(W1, W2, W3);
+              mm_s8(W2, W2, W4);
+              s8_finish(W3, swap_lane, tail_lane);
+              s8_finish(W4, swap_lane, tail_lane);
+              s8_comb<NC, true>(acc, c3p_inv_fact[8], -c3p_inv_fact[10], c3p_inv_fact[12], -c3p_inv_fact[14], W1, W2, W3, lp);
+              s8_comb<NC, true>(acs, c3p_inv_fact[9], -c3p_inv_fact[11], c3p_inv_fact[13], -c3p_inv_fact[15], W1, W2, W3, lp);
+#pragma unroll
+              for (int I = 0; I < NC; ++I) {
+#pragma unroll
+                for (int J = 0; J < NC; ++J) {
+                  acc.m[I][J] = fma(c3p_inv_fact[16], W4.m[I][J], acc.m[I][J]);
+                  acs.m[I][J] = fma(c3p_inv_fact[17], W4.m[I][J], acs.m[I][J]);
+                }
+                acc.vr[I] = fma(c3p_inv_fact[16], W4.vr[I], acc.vr[I]);
+                acs.vr[I] = fma(c3p_inv_fact[17], W4.vr[I], acs.vr[I]);
+                acc.vc[I] = fma(c3p_inv_fact[16], W4.vc[I], acc.vc[I]);
+                acs.vc[I] = fma(c3p_inv_fact[17], W4.vc[I], acs.vc[I]);
+              }
+              acc.s = fma(c3p_inv_fact[16], W4.s, acc.s);
+              acs.s = fma(c3p_inv_fact[17], W4.s, acs.s);
+              s8_comb<NC, true, true>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], -c3p_inv_fact[6], W1, W2, W3, lp);
+              s8_comb<NC, true, true>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7], W1, W2, W3, lp);
+              mm_s8x2(W4, acc, Cm, acs, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
+            } else {
+              mm_s8(W1, W2, W3);  // W^3
+              s8_finish(W3, swap_lane, tail_lane);
+              s8_comb<NC, true>(Cm, c3p_inv_fact[12], -c3p_inv_fact[14], c3p_inv_fact[16], -c3p_inv_fact[18], W1, W2, W3, lp);
+              s8_comb<NC, false>(Sp, c3p_inv_fact[13], -c3p_inv_fact[15], c3p_inv_fact[17], 0.0, W1, W2, W3, lp);
+              s8_comb<NC, false, true>(acc, -c3p_inv_fact[6], c3p_inv_fact[8], -c3p_inv_fact[10], 0.0, W1, W2, W3, lp);
+              s8_comb<NC, false, true>(acs, -c3p_inv_fact[7], c3p_inv_fact[9], -c3p_inv_fact[11], 0.0, W1, W2, W3, lp);
+              mm_s8x2(W3, Cm, acc, Sp, acs);
+              s8_finish(acc, swap_lane, tail_lane);
+              s8_finish(acs, swap_lane, tail_lane);
+              s8_comb<NC, false, true>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], 0.0, W1, W2, W3, lp);
+              s8_comb<NC, false, true>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], 0.0, W1, W2, W3, lp);
+              mm_s8x2(W3, acc, Cm, acs, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
+            }
+            s8_finish(Cm, swap_lane, tail_lane);
+            s8_finish(Sp, swap_lane, tail_lane);
+            s8_zero(acc);
+            mm_s8(Y, Sp, acc);  // acc = sin Y
+            s8_finish(acc, swap_lane, tail_lane);
+            // squarings: cos 2Y = (C - S)(C + S), sin 2Y = 2 S C
+            for (int it = 0; it < ps18; ++it) {
+              SM Dm, Sm, C2, SC;
+#pragma unroll
+              for (int I = 0; I < NC; ++I) {
+#pragma unroll
+                for (int J = 0; J < NC; ++J) {
+                  Dm.m[I][J] = Cm.m[I][J] - acc.m[I][J];
+                  Sm.m[I][J] = Cm.m[I][J] + acc.m[I][J];
+                }
+                Dm.vr[I] = Cm.vr[I] - acc.vr[I];
+                Sm.vr[I] = Cm.vr[I] + acc.vr[I];
+                Dm.vc[I] = Cm.vc[I] - acc.vc[I];
+                Sm.vc[I] = Cm.vc[I] + acc.vc[I];
+              }
+              Dm.s = Cm.s - acc.s;
+              Sm.s = Cm.s + acc.s;
+              s8_zero(C2), s8_zero(SC);
+              mm_s8(Dm, Sm, C2);
+              mm_s8(acc, Cm, SC);
+#pragma unroll
+              for (int I = 0; I < NC; ++I) {
+#pragma unroll
+                for (int J = I; J < NC; ++J) {
+                  Cm.m[I][J] = C2.m[I][J];
+                  acc.m[I][J] = 2.0 * SC.m[I][J];
+                }
+                Cm.vr[I] = C2.vr[I];
+                acc.vr[I] = 2.0 * SC.vr[I];
+              }
+              Cm.s = C2.s;
+              acc.s = 2.0 * SC.s;
+              s8_finish(Cm, swap_lane, tail_lane);
+              s8_finish(acc, swap_lane, tail_lane);
+            }
+            if (t == 0) {  // U <- E = C - i S
+#pragma unroll
+              for (int I = 0; I < NC; ++I) {
+#pragma unroll
+                for (int J = 0; J < NC; ++J) {
+                  Gr.m[I][J] = Cm.m[I][J];
+                  Gi.m[I][J] = -acc.m[I][J];
+                }
+                Gr.cr[I] = Cm.vr[I], Gr.cc[I] = Cm.vc[I], Gr.rc[I] = Cm.vc[I];
+                Gi.cr[I] = -acc.vr[I], Gi.cc[I] = -acc.vc[I], Gi.rc[I] = -acc.vc[I];
+              }
+              Gr.s = Cm.s;
+              Gi.s = -acc.s;
+              mus_r = mu_r;
+              mus_i = c3p_phase_add(0.0, mu_i);
+            } else {
+              chain_step8(Cm, acc, Gr, Gi, lp, tail_lane, row0_lane);
+              mus_r += mu_r;
+              mus_i = c3p_phase_add(mus_i, mu_i);
+            }
+          }
+        };
+        if (deg16)
+          split_loop(std::true_type{});
+        else
+          split_loop(std::false_type{});
+        // back to the complex half-image layout of the epilogue (once per segment, through the chain's image)
+        wave_sync();
+        for (int e = lp.idx16; e < 4 * NBI * W; e += 16) img[lp.b * IMG + e] = 0.0;
+        wave_sync();
+#pragma unroll
+        for (int I = 0; I < NC; ++I) {
+          const int i = 4 * I + lp.r;
+#pragma unroll
+          for (int J = 0; J < NC; ++J) {
+            img[lp.b * IMG + (2 * i) * W + 4 * J + lp.c] = Gr.m[I][J];
+            img[lp.b * IMG + (2 * i + 1) * W + 4 * J + lp.c] = Gi.m[I][J];
+          }
+          if (lp.c == 0) {
+            img[lp.b * IMG + (2 * i) * W + D - 1] = Gr.cr[I];
+            img[lp.b * IMG + (2 * i + 1) * W + D - 1] = Gi.cr[I];
+          }
+          if (lp.r == 0) {
+            img[lp.b * IMG + (2 * (D - 1)) * W + 4 * I + lp.c] = Gr.rc[I];
+            img[lp.b * IMG + (2 * (D - 1) + 1) * W + 4 * I + lp.c] = Gi.rc[I];
+          }
+        }
+        if (lp.idx16 == 0) {
+          img[lp.b * IMG + (2 * (D - 1)) * W + D - 1] = Gr.s;
+          img[lp.b * IMG + (2 * (D - 1) + 1) * W + D - 1] = Gi.s;
+        }
+        wave_sync();
+#pragma unroll
+        for (int I = 0; I < NBI; ++I)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) U[I][J] = img[woff + I * 4 * W + J * 4];
+        wave_sync();
+      } else {
       auto real_loop = [&](auto deg16_tag) {
       constexpr bool DEG16 = decltype(deg16_tag)::value;
       for (int t = 0; t < tmax; ++t) {
@@ -948,6 +1397,7 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
 #pragma unroll
         for (int J = 0; J < NJ; ++J) U[I][J] = img[woff + I * 4 * W + J * 4];
       wave_sync();
+      }  // !SPLIT
     } else {
     // the slice loop is instantiated per plan (T18 / Paterson-Stockmeyer) with the branch outside, as on the real path
     auto complex_loop = [&](auto t18_tag) {
@@ -1377,7 +1827,8 @@ hipError_t launch_chain_t(const SmallArgs& A, hipStream_t st) {
       // a pair's slices in per mille, default 640; 500 = equal segments).
       SmallArgs A2 = A;
       if (nW == 8 && A.N >= 4 * A.S) {
-        int skew = 640;
+        // (measured optimum 640 with the padded tiles, 660 with the core + border form of D = 5, 9: tools/sweep_split81.py)
+        int skew = ((D == 9 || D == 5) && !c3p_opt_on(C3P_OPT_no_split81)) ? 660 : 640;
         if (c3p_opt(C3P_OPT_mw_skew) >= 0) skew = (int)c3p_opt(C3P_OPT_mw_skew);
         if (skew > 500 && skew < 900) {
           const int h = A.S / 2;
@@ -1395,13 +1846,21 @@ hipError_t launch_chain_t(const SmallArgs& A, hipStream_t st) {
       if (lds_mw2 > (size_t)156 * 1024) A2 = A;  // (the longer segments need more LDS for their control amplitudes)
       const size_t lds_use = A2.seg_long > 0 ? lds_mw2 : lds_mw;
       auto kern = smalld_chain_kernel<D, false, false, false, true>;
+      if constexpr (D == 9 || D == 5) {
+        // core + border form of the real path (8 + 1 split at D = 9): no_split81 = 1 keeps the padded 12 x 12 tiles
+        if (!c3p_opt_on(C3P_OPT_no_split81)) kern = smalld_chain_kernel<D, false, false, false, true, true>;
+      }
       if (lds_use > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_use);
         if (e != hipSuccess) return e;
       }
       hipLaunchKernelGGL(kern, dim3((unsigned)A.B), dim3(64 * nW), lds_use, st, A2);
     } else {
-      hipLaunchKernelGGL((smalld_chain_kernel<D, false, false>), dim3(grid), dim3(64), lds, st, A);
+      auto kern1 = smalld_chain_kernel<D, false, false>;
+      if constexpr (D == 9 || D == 5) {
+        if (!c3p_opt_on(C3P_OPT_no_split81)) kern1 = smalld_chain_kernel<D, false, false, false, false, true>;
+      }
+      hipLaunchKernelGGL(kern1, dim3(grid), dim3(64), lds, st, A);
     }
   }
   return hipGetLastError();

@@ -54,7 +54,7 @@ def graph_timed(fn, reps, torch, dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cases", default="2:256:1000,2:1024:1000,3:256:2000,5:64:5000,L3:64:1000,L9:16:1000")
+    ap.add_argument("--cases", default="1:256:200,2:256:1000,2:1024:1000,3:256:2000,5:64:5000,L3:64:1000,L9:16:1000,L9:64:1000")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     import torch
@@ -82,7 +82,7 @@ def main():
         else:
             wl = workloads.make_workload(int(tag), B=1, N=8)
             col = None
-            dims = {2: [3, 3], 3: [3, 3, 3], 5: [3, 3, 4]}[int(tag)]
+            dims = {1: [3], 2: [3, 3], 3: [3, 3, 3], 5: [3, 3, 4]}[int(tag)]
         D, K = wl.D, wl.K
         sim_res, awg_res = 100e9, 2e9
         T = N / sim_res
@@ -113,6 +113,10 @@ def main():
         reps = max(2, min(50, int(2e5 / (B * N * (Dm / 9.0) ** 3)) + 2))
         row = {"case": f"{'Lindblad ' if lind else ''}D={D}" + (f" ({Dm}x{Dm})" if lind else ""), "B": B, "N": N, "K": K, "reps": reps}
         row["forward_ms"] = timed(fwd, reps, torch)
+        # the forward pass alone, replayed from a captured hipGraph: what launch gaps cost the 12 - 130 us kernels
+        row["forward_graph_ms"], ferr, _ = graph_timed(fwd, reps, torch, dev)
+        if ferr:
+            row["forward_graph_error"] = ferr
         a = run(False)
         row["three_call_ms"] = timed(lambda: run(False), reps, torch)
         gms, err, _ = graph_timed(lambda: run(False), reps, torch, dev)
@@ -129,7 +133,7 @@ def main():
             row["fused_graph_ms"] = gms
             if err:
                 row["fused_graph_error"] = err
-        best = min(v for k, v in row.items() if k.endswith("_ms") and k != "forward_ms" and v is not None)
+        best = min(v for k, v in row.items() if k.endswith("_ms") and not k.startswith("forward") and v is not None)
         row["best_ms"] = best
         row["iterations_per_s"] = 1e3 / best
         row["gradients_per_s"] = 1e3 * B / best

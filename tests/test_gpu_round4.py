@@ -201,3 +201,45 @@ def test_lindblad_vjp_hermitian_basis_strong_dissipation_and_long_chain(prop):
     with _lib.options(tiled_grad=1):
         gt = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, 0.25, col, Ubar))
     assert np.abs(g - gt).max() < 1e-10 * np.abs(gt).max()
+
+
+# --------------------------------------------------------------------------
+# core + border form of the real small-D path (8 + 1 split at D = 9, 4 + 1 at D = 5): c3p_smalld.hip SMat / GMat
+# (propagation.py:426-440 + tf_utils.py:144-193 on real Hamiltonians)
+# --------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("D,B,N,amp,mw", [
+    (9, 256, 96, 1.0, True),     # cfg2's shape: workgroup per sample, degree-16 variant
+    (9, 8, 250, 1.0, True),      # uneven segments (eight waves per sample)
+    (9, 7, 37, 1.0, False),      # one-wave workgroups + ticket, ragged chains (7 x S not a multiple of four)
+    (9, 5, 40, 2.6, False),      # stronger drive: degree-18 variant
+    (9, 4, 30, 14.0, False),     # squarings
+    (5, 6, 64, 1.0, True),       # 4 + 1
+    (5, 3, 21, 9.0, False),
+])
+def test_smalld_core_plus_border_form(prop, D, B, N, amp, mw):
+    """the same propagators from the core + border form (default) and from the padded tiles (no_split81), both against the
+    oracle on real symmetric Hamiltonians with frame-rotation phases"""
+    rng = np.random.default_rng(D * 100 + N)
+
+    def rsym(scale):
+        a = rng.normal(size=(D, D))
+        return (scale * (a + a.T) / 2).astype(complex)
+
+    h0 = rsym(6e10)
+    hks = np.stack([rsym(1.0), rsym(1.0)])
+    sig = rng.normal(size=(B, 2, N)) * 2e9 * amp
+    ph = rng.uniform(0, 6, size=(B, D))
+    dt = 1e-11
+    with _lib.options(no_mw=None if mw else 1):
+        a = np.asarray(prop.propagate_batch(h0, hks, sig, dt, fr_phase=ph)["U"])
+        assert _lib.last_kernel() == "smalld"
+        with _lib.options(no_split81=1):
+            b = np.asarray(prop.propagate_batch(h0, hks, sig, dt, fr_phase=ph)["U"])
+    ref = o.propagate_batch(h0, hks, sig[:3], dt, fr_phase=ph[:3])
+    for i in range(min(3, B)):
+        assert np.linalg.norm(a[i] - ref[i]) < 1e-10
+        assert np.linalg.norm(b[i] - ref[i]) < 1e-10
+    assert np.abs(a - b).max() < 1e-11
+    assert np.abs(a @ a.conj().transpose(0, 2, 1) - np.eye(D)).max() < 1e-10

@@ -17,6 +17,14 @@ def tile_utilisation(Dm, kernel):
       midd (13..40):     16-row units and 4-column blocks, K in steps of 4 (real instance, Dm = 25..28: columns padded to 32);
       regd (49/65/81):   the 16 n x 16 n core tiles exactly, the border runs on the vector unit: 1.0;
       others:            1.0 (not corrected)."""
+    if Dm in (5, 9) and "smalld_chain_kernel" in kernel and kernel.split("smalld_chain_kernel")[-1].split(">")[0].rstrip().endswith("true"):
+        # core + border form of the real path (round 4): the (Dm-1)^2 core tiles exactly; of the matrix instructions of a slice
+        # (degree-16 variant: 7 symmetric products of NC^2 (NC+1)/2, the chain step's 3 NC^3 core and 3 NC^2 row-border ones)
+        # only the row-border instructions of the chain step carry padding (one of four A rows)
+        nc = (Dm - 1) // 4
+        sym, core, row = 7 * nc * nc * (nc + 1) // 2, 3 * nc**3, 3 * nc * nc
+        return (sym + core + 0.25 * row) / (sym + core + row), (f"small-D kernel, core + border form: {sym} + {core} exact core MFMAs and {row} row-border "
+                                                                f"MFMAs at 1/4 per slice (degree-16 variant); the borders run on the vector unit")
     if Dm <= 12:
         p = 4 * ((Dm + 3) // 4)
         kk = 1.0 if Dm % 4 == 1 else Dm / p
