@@ -181,6 +181,10 @@ def average_infid_cotangent(ideal, actual, index: List[int] = [0], dims=[2]):
 # --------------------------------------------------------------------------
 
 
+_super_cache: Dict[tuple, tuple] = {}
+_super_emb: Dict[tuple, object] = {}
+
+
 def _super_overlap(ideal, actual, index, dims):
     """t[b] = tr(A[b] B^+), A = P_s^T S[b] P_s (P_s = P (x) P, tf_project_to_comp(.., to_super=True)), B = tf_super(ideal) =
     ideal (x) conj(ideal); the rows of P_s are the pairs (i, j) of computational rows: i D + j.  One c3p_gate_overlap launch."""
@@ -195,18 +199,39 @@ def _super_overlap(ideal, actual, index, dims):
     D = int(np.prod(dims))
     rows = computational_rows(dims, index)
     L = int(rows.shape[0])
-    srows = (rows[:, None].astype(np.int64) * D + rows[None, :]).reshape(-1).astype(np.int32)
-    Gi = np.asarray(ideal.detach().cpu().numpy() if hasattr(ideal, "detach") else ideal, dtype=np.complex128)
-    if Gi.shape != (L, L):
-        raise C3PropError(f"C3:Error: ideal gate must be [{L},{L}] for index {index}, got {Gi.shape}")
-    Gs = np.kron(Gi, np.conj(Gi))
+    # rows of P_s, tf_super(ideal) and its embedding into the full superoperator space are functions of (dims, index, ideal):
+    # built once and kept on the device (an optimiser calls this every iteration; a .cpu() / as_tensor per call is a host
+    # synchronisation, and illegal inside a stream capture)
+    key = None
+    if call.device and hasattr(ideal, "data_ptr"):
+        key = (tuple(int(d) for d in dims), tuple(index) if index else None, str(call.dev), ideal.data_ptr(), getattr(ideal, "_version", 0), tuple(ideal.shape))
+    hit = _super_cache.get(key) if key is not None else None
+    if hit is not None:
+        srows, Gs, rows_d, G = hit
+    else:
+        srows = (rows[:, None].astype(np.int64) * D + rows[None, :]).reshape(-1).astype(np.int32)
+        Gi = np.asarray(ideal.detach().cpu().numpy() if hasattr(ideal, "detach") else ideal, dtype=np.complex128)
+        if Gi.shape != (L, L):
+            raise C3PropError(f"C3:Error: ideal gate must be [{L},{L}] for index {index}, got {Gi.shape}")
+        Gs = np.kron(Gi, np.conj(Gi))
+        if call.device:
+            rows_d = call.torch.as_tensor(srows, device=call.dev)
+            G = call.torch.as_tensor(Gs, device=call.dev)
+            if key is not None:
+                if len(_super_cache) > 32:
+                    _super_cache.clear()
+                emb = call.torch.zeros((Dm, Dm), dtype=call.torch.complex128, device=call.dev)
+                r = call.torch.as_tensor(srows.astype(np.int64), device=call.dev)
+                emb[r[:, None], r[None, :]] = G
+                _super_emb[key] = emb
+                _super_cache[key] = (srows, Gs, rows_d, G)
+        else:
+            rows_d, G = srows, np.ascontiguousarray(Gs)
     if call.device:
-        rows_d = call.torch.as_tensor(srows, device=call.dev)
-        G = call.torch.as_tensor(Gs, device=call.dev)
         out = call.torch.empty((B,), dtype=call.torch.complex128, device=call.dev)
     else:
-        rows_d, G = srows, np.ascontiguousarray(Gs)
         out = np.empty((B,), dtype=np.complex128)
+    call.super_key = key
     _lib.check(_lib.load().c3p_gate_overlap(_ptr(S), B, Dm, _ptr(rows_d), L * L, _ptr(G), call.flags, _ptr(out), call.stream))
     return (out[0] if squeeze else out), L, srows, Gs, call, squeeze, B, Dm
 
@@ -236,9 +261,11 @@ def lindbladian_unitary_infid_cotangent(ideal, actual, index: List[int] = [0], d
     tv = t.reshape(1) if squeeze else t
     if call.device:
         tt = call.torch
-        emb = tt.zeros((Dm, Dm), dtype=tt.complex128, device=call.dev)
-        r = tt.as_tensor(srows.astype(np.int64), device=call.dev)
-        emb[r[:, None], r[None, :]] = tt.as_tensor(Gs, device=call.dev)
+        emb = _super_emb.get(getattr(call, "super_key", None)) if getattr(call, "super_key", None) is not None else None
+        if emb is None:
+            emb = tt.zeros((Dm, Dm), dtype=tt.complex128, device=call.dev)
+            r = tt.as_tensor(srows.astype(np.int64), device=call.dev)
+            emb[r[:, None], r[None, :]] = tt.as_tensor(Gs, device=call.dev)
         Sbar = (-(tv / tv.abs()) / L**2)[:, None, None] * emb[None]
     else:
         emb = np.zeros((Dm, Dm), dtype=np.complex128)

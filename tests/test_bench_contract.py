@@ -43,3 +43,13 @@ def test_bench_json_line(lib):
     assert c["wall_s"] < 15.0 and d["cpu_baseline_allcores"]["wall_s"] < 40.0
     assert abs(d["value"] - 256 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
     assert d["max_fro_err_vs_oracle"] < 1e-10
+
+
+def test_design_tables_are_generated_from_the_committed_profiles():
+    """DESIGN.md's measurement tables are the output of tools/design_tables.py over profiles/r04/*.json"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "design_tables.py"), "r04", "--check"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr

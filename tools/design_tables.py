@@ -2,8 +2,9 @@
 """Markdown tables of DESIGN.md section 7 / 5.7 / 6 GENERATED from the committed measurement files of a round
 (profiles/<round>/*.json), so that the document cannot drift from the numbers.
 
-    python tools/design_tables.py r04            # prints the tables; DESIGN.md holds this output verbatim
-    python tools/design_tables.py r04 --check    # exit 1 if DESIGN.md does not contain the generated tables
+    python tools/design_tables.py r04            # prints the tables
+    python tools/design_tables.py r04 --write    # rewrites them in DESIGN.md (between the BEGIN / END generated markers)
+    python tools/design_tables.py r04 --check    # exit 1 if DESIGN.md does not hold exactly the generated tables
 """
 import json
 import os
@@ -86,18 +87,28 @@ def grad_table(rnd):
 
 def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r04"
-    parts = [("bench lines (`bench.py --config C --check`)", bench_table(rnd)), ("exchange schedules", exchange_table(rnd)),
-             ("one optimiser evaluation (`tests/perf/bench_goal_run.py`)", goal_table(rnd)), ("control gradients (`tools/bench_grad.py`)", grad_table(rnd))]
-    text = "\n\n".join(f"<!-- generated by tools/design_tables.py {rnd}: {name} -->\n{tab}" for name, tab in parts if tab)
-    if "--check" in sys.argv:
-        doc = open(os.path.join(ROOT, "DESIGN.md")).read()
-        missing = [name for name, tab in parts if tab and tab not in doc]
-        if missing:
-            print("DESIGN.md is out of date for:", missing)
-            sys.exit(1)
-        print("DESIGN.md holds the generated tables")
+    parts = {"bench": bench_table(rnd), "exchange": exchange_table(rnd), "goal": goal_table(rnd), "grad": grad_table(rnd)}
+    path = os.path.join(ROOT, "DESIGN.md")
+    doc = open(path).read()
+    if "--write" in sys.argv or "--check" in sys.argv:
+        # DESIGN.md holds each table between <!-- BEGIN generated:NAME rNN --> and <!-- END generated:NAME -->
+        new = doc
+        for name, tab in parts.items():
+            b, e = f"<!-- BEGIN generated:{name} {rnd} -->", f"<!-- END generated:{name} -->"
+            if b in new and e in new and tab:
+                i, j = new.index(b) + len(b), new.index(e)
+                new = new[:i] + "\n" + tab + "\n" + new[j:]
+        if "--check" in sys.argv:
+            if new != doc:
+                print("DESIGN.md is out of date: run python tools/design_tables.py", rnd, "--write")
+                sys.exit(1)
+            print("DESIGN.md holds the generated tables")
+            return
+        open(path, "w").write(new)
+        print("DESIGN.md updated")
         return
-    print(text)
+    for name, tab in parts.items():
+        print(f"<!-- {name} -->\n{tab}\n")
 
 
 if __name__ == "__main__":

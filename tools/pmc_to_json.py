@@ -17,7 +17,7 @@ def tile_utilisation(Dm, kernel):
       midd (13..40):     16-row units and 4-column blocks, K in steps of 4 (real instance, Dm = 25..28: columns padded to 32);
       regd (49/65/81):   the 16 n x 16 n core tiles exactly, the border runs on the vector unit: 1.0;
       others:            1.0 (not corrected)."""
-    if Dm in (5, 9) and "smalld_chain_kernel" in kernel and kernel.split("smalld_chain_kernel")[-1].split(">")[0].rstrip().endswith("true"):
+    if Dm in (5, 9) and not os.environ.get("C3P_PMC_COMPLEX") and "smalld_chain_kernel" in kernel and kernel.split("smalld_chain_kernel")[-1].split(">")[0].rstrip().endswith("true"):
         # core + border form of the real path (round 4): the (Dm-1)^2 core tiles exactly; of the matrix instructions of a slice
         # (degree-16 variant: 7 symmetric products of NC^2 (NC+1)/2, the chain step's 3 NC^3 core and 3 NC^2 row-border ones)
         # only the row-border instructions of the chain step carry padding (one of four A rows)

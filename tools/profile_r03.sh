@@ -24,4 +24,5 @@ cd $R
 python tools/pmc_summary.py ${P}_stats ${P}_pmc1 ${P}_pmc2 ${P}_pmc5 ${P}_pmc3 ${P}_pmc4 > gpurun_out/${TAG}_pmc_summary.txt 2>&1
 find ${P}_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats.csv \;
 grep '^{' ${P}_stats.log | tail -1 > gpurun_out/${TAG}_bench_under_rocprof.json
+case "$EXTRA" in *--complex*) export C3P_PMC_COMPLEX=1;; *) unset C3P_PMC_COMPLEX;; esac  # (complex Hamiltonians run the padded-tile loop of the same kernel instance)
 python tools/pmc_to_json.py $C ${P}_stats ${P}_pmc1 ${P}_pmc2 ${P}_pmc5 ${P}_pmc3 ${P}_pmc4 > gpurun_out/pmc_${TAG}.json
