@@ -54,6 +54,9 @@ SIGNATURES = {
     "c3p_pwc_unitary_vjp": (_i, [_vp, _i64, _vp, _i64, _vp, _d, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "c3p_pwc_unitary_goal_vjp": (_i, [_vp, _i64, _vp, _i64, _vp, _d, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "c3p_pwc_lindblad_vjp": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _d, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "c3p_pwc_lindblad_tape_bytes": (C.c_size_t, [_i, _i, _i, _i, C.POINTER(C.c_int)]),
+    "c3p_pwc_lindblad_taped": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _d, _i, _i, _i, _i, _i, _vp, _vp, _vp, C.c_size_t, _i, _vp]),
+    "c3p_pwc_lindblad_vjp_taped": (_i, [_vp, C.c_size_t, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "c3p_synth_signals": (_i, [_vp, _vp, _vp, _d, _d, _d, _d, _i, _i, _i, _i, _vp, _vp, _vp]),
     "c3p_ode_solve": (_i, [_vp, _vp, _vp, _vp, _i, _d, _i, _i, _i, _i, _i, _i, _vp, _i64, _i, _i, _vp, _vp]),
 }

@@ -1342,36 +1342,56 @@ int run_pwc_tiled(DeviceWs* w, const ChainArgs& a, bool per_slice, cplx* U_out, 
 // ---------------------------------------------------------------------------
 // Lindblad control gradient at D = 7, 8, 9 (49 x 49 .. 81 x 81 superoperators, cfg4) in the Hermitian basis: forward chain
 // kernel with the transposed local prefixes kept in HBM, real segment scan, on-chip backward sweep (c3p_regrg.hip).
-// Returns 1 when a Hamiltonian is not Hermitian (complex tables in that basis): the caller falls back to the tiled sweep.
+// The forward half returns 1 when a Hamiltonian is not Hermitian (complex tables in that basis): the caller falls back.
 // ---------------------------------------------------------------------------
-int run_vjp_lind_regr(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals, const cplx* clp,
-                      double dt, int B, int K, int N, int D, int Dm, const double* fr_phase, const cplx* Ubar, double* grad,
-                      hipStream_t st) {
-  if (!c3p_regr_supported(D, Dm) || K > 16 || K < 1) return 1;
+struct LindRegrBufs {  // device buffers of one forward pass (the library's workspace, or a caller-owned tape)
+  double *tab_f, *tab_t;
+  int *flag_f, *flag_t;
+  cplx* seg;   // [B,S] complex slots, the real matrix in the second half of each
+  double* qT;  // [B,N,Dm,Dm]
+};
+static long lind_regr_segments(int B, int N) {
+  // fill the 256 workgroup slots evenly (rounds of 256 chains), few segments
+  long S = 1;
+  const long smax = N / 4 > 1 ? N / 4 : 1;
+  double best = -1.0;
+  for (long s = 1; s <= 32 && s <= smax; ++s) {
+    const long chains = (long)B * s, rounds = (chains + C3P_REGD_MAX_WGS - 1) / C3P_REGD_MAX_WGS;
+    const double eff = (double)chains / (double)(rounds * C3P_REGD_MAX_WGS) - 0.004 * (double)s;
+    if (eff > best + 1e-12) best = eff, S = s;
+  }
+  if (c3p_opt(C3P_OPT_segments) > 0) S = std::min<long>(c3p_opt(C3P_OPT_segments), smax);
+  return S;
+}
+struct LindRegrSizes {
+  size_t tab1, ftab, seg, qT;
+  size_t total() const { return 2 * tab1 + 2 * ftab + seg + qT; }
+};
+static LindRegrSizes lind_regr_sizes(int B, int K, int N, int Dm, long S, int nsamp) {
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  LindRegrSizes z;
+  z.tab1 = up((size_t)nsamp * c3p_regr_table_doubles(Dm, K) * sizeof(double));
+  z.ftab = up((size_t)nsamp * (1 + K) * sizeof(int));
+  z.seg = up((size_t)B * S * Dm * Dm * sizeof(cplx));
+  z.qT = up((size_t)B * N * Dm * Dm * sizeof(double));
+  return z;
+}
+static LindRegrBufs lind_regr_carve(void* base, const LindRegrSizes& z) {
+  char* c = static_cast<char*>(base);
+  LindRegrBufs b;
+  b.tab_f = reinterpret_cast<double*>(c);
+  b.tab_t = reinterpret_cast<double*>(c + z.tab1);
+  b.flag_f = reinterpret_cast<int*>(c + 2 * z.tab1);
+  b.flag_t = reinterpret_cast<int*>(c + 2 * z.tab1 + z.ftab);
+  b.seg = reinterpret_cast<cplx*>(c + 2 * z.tab1 + 2 * z.ftab);
+  b.qT = reinterpret_cast<double*>(c + 2 * z.tab1 + 2 * z.ftab + z.seg);
+  return b;
+}
+// tables of G' and G'^T, Hermiticity flags (read back: one synchronisation per call), forward chain with Q^T
+int lind_regr_forward(DeviceWs* w, const LindRegrBufs& bf, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals,
+                      const cplx* clp, double dt, int B, int K, int N, int D, int Dm, long S, hipStream_t st) {
   const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
   const int nsamp = per_sample ? B : 1;
-  // segments: fill the 256 workgroup slots evenly (rounds of 256 chains), few segments
-  long S = 1;
-  {
-    const long smax = N / 4 > 1 ? N / 4 : 1;
-    double best = -1.0;
-    for (long s = 1; s <= 32 && s <= smax; ++s) {
-      const long chains = (long)B * s, rounds = (chains + C3P_REGD_MAX_WGS - 1) / C3P_REGD_MAX_WGS;
-      const double eff = (double)chains / (double)(rounds * C3P_REGD_MAX_WGS) - 0.004 * (double)s;
-      if (eff > best + 1e-12) best = eff, S = s;
-    }
-    if (c3p_opt(C3P_OPT_segments) > 0) S = std::min<long>(c3p_opt(C3P_OPT_segments), smax);
-  }
-  const size_t msz = (size_t)Dm * Dm;
-  const size_t tabd = c3p_regr_table_doubles(Dm, K);
-  const size_t tab1 = (((size_t)nsamp * tabd * sizeof(double)) + 255) & ~(size_t)255;
-  const size_t ftab = (((size_t)nsamp * (1 + K) * sizeof(int)) + 255) & ~(size_t)255;
-  void* v;
-  if (ws_get(w, SL_TABLES, 2 * tab1 + 2 * ftab, &v)) return -1;
-  double* tab_f = (double*)v;
-  double* tab_t = reinterpret_cast<double*>(static_cast<char*>(v) + tab1);
-  int* flag_f = reinterpret_cast<int*>(static_cast<char*>(v) + 2 * tab1);
-  int* flag_t = reinterpret_cast<int*>(static_cast<char*>(v) + 2 * tab1 + ftab);
   RegdPrepArgs p = {};
   p.h0 = h0;
   p.h0_bstride = h0_bs;
@@ -1383,25 +1403,17 @@ int run_vjp_lind_regr(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, 
   p.Dh = D;
   p.Dm = Dm;
   p.lindblad = 1;
-  LAUNCH_TRY(c3p_launch_regr_prep_t(p, nsamp, tab_f, flag_f, 0, st));
-  LAUNCH_TRY(c3p_launch_regr_prep_t(p, nsamp, tab_t, flag_t, 1, st));
+  LAUNCH_TRY(c3p_launch_regr_prep_t(p, nsamp, bf.tab_f, bf.flag_f, 0, st));
+  LAUNCH_TRY(c3p_launch_regr_prep_t(p, nsamp, bf.tab_t, bf.flag_t, 1, st));
   {
     std::vector<int> hf((size_t)nsamp * (1 + K));
-    HIP_TRY(hipMemcpyAsync(hf.data(), flag_f, hf.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hf.data(), bf.flag_f, hf.size() * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (int f : hf)
       if (!f) return 1;  // a non-Hermitian Hamiltonian: complex generator in the Hermitian basis
   }
-  void *sv, *bv, *qv, *av;
-  if (ws_get(w, SL_SEG_A, (size_t)B * S * msz * sizeof(cplx), &sv)) return -1;
-  if (ws_get(w, SL_SEG_B, ((size_t)3 * B * S + B) * msz * sizeof(double) + (size_t)B * sizeof(double), &bv)) return -1;
-  if (ws_get(w, SL_OUT1, (size_t)B * N * msz * sizeof(double), &qv)) return -1;
+  void* av;
   if (ws_get(w, SL_SCRATCH, std::max(c3p_regr_grad_arena_bytes(Dm), c3p_regr_arena_bytes(Dm)), &av)) return -1;
-  double* pre = (double*)bv;
-  double* suf = pre + (size_t)B * S * msz;
-  double* lam = suf + (size_t)B * S * msz;
-  double* ubr = lam + (size_t)B * S * msz;
-  double* tau = ubr + (size_t)B * msz;
   MidArgs a = {};
   a.tab_per_sample = per_sample ? 1 : 0;
   a.signals = signals;
@@ -1412,19 +1424,33 @@ int run_vjp_lind_regr(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, 
   a.S = (int)S;
   a.Lmax = (int)((N + S - 1) / S);
   a.mode = C3P_MODE_LINDBLAD;
-  a.hb_tables = tab_f;
-  a.hb_tabflag = flag_f;
-  a.hb_qT = (double*)qv;
-  a.seg_out = (cplx*)sv;
+  a.hb_tables = bf.tab_f;
+  a.hb_tabflag = bf.flag_f;
+  a.hb_qT = bf.qT;
+  a.seg_out = bf.seg;
   LAUNCH_TRY(c3p_launch_regr_chain(a, av, st));
+  return 0;
+}
+// cotangent in the Hermitian basis, segment scan, backward sweep (scratch from the workspace)
+int lind_regr_backward(DeviceWs* w, const LindRegrBufs& bf, bool per_sample, const double* signals, int B, int K, int N, int D, int Dm,
+                       long S, const double* fr_phase, const cplx* Ubar, double* grad, hipStream_t st) {
+  const size_t msz = (size_t)Dm * Dm;
+  void *bv, *av;
+  if (ws_get(w, SL_SEG_B, ((size_t)3 * B * S + B) * msz * sizeof(double) + (size_t)B * sizeof(double), &bv)) return -1;
+  if (ws_get(w, SL_SCRATCH, std::max(c3p_regr_grad_arena_bytes(Dm), c3p_regr_arena_bytes(Dm)), &av)) return -1;
+  double* pre = (double*)bv;
+  double* suf = pre + (size_t)B * S * msz;
+  double* lam = suf + (size_t)B * S * msz;
+  double* ubr = lam + (size_t)B * S * msz;
+  double* tau = ubr + (size_t)B * msz;
   LAUNCH_TRY(c3p_launch_hb_ubar(Ubar, fr_phase, B, D, ubr, st));
-  LAUNCH_TRY(c3p_launch_regr_scan((const cplx*)sv, ubr, B, (int)S, Dm, pre, suf, lam, tau, st));
+  LAUNCH_TRY(c3p_launch_regr_scan(bf.seg, ubr, B, (int)S, Dm, pre, suf, lam, tau, st));
   RegrGradArgs g = {};
-  g.tables = tab_f;
-  g.tables_t = tab_t;
-  g.tab_per_sample = a.tab_per_sample;
+  g.tables = bf.tab_f;
+  g.tables_t = bf.tab_t;
+  g.tab_per_sample = per_sample ? 1 : 0;
   g.signals = signals;
-  g.qT = (const double*)qv;
+  g.qT = bf.qT;
   g.lam = lam;
   g.tau = tau;
   g.grad = grad;
@@ -1437,6 +1463,24 @@ int run_vjp_lind_regr(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, 
   g.degree = c3p_opt(C3P_OPT_regr_grad_degree) > 0 ? (int)c3p_opt(C3P_OPT_regr_grad_degree) : 0;
   LAUNCH_TRY(c3p_launch_regr_grad(g, st));
   return 0;
+}
+int run_vjp_lind_regr(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals, const cplx* clp,
+                      double dt, int B, int K, int N, int D, int Dm, const double* fr_phase, const cplx* Ubar, double* grad,
+                      hipStream_t st) {
+  if (!c3p_regr_supported(D, Dm) || K > 16 || K < 1) return 1;
+  const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
+  const long S = lind_regr_segments(B, N);
+  const LindRegrSizes z = lind_regr_sizes(B, K, N, Dm, S, per_sample ? B : 1);
+  void *tv, *sv, *qv;
+  if (ws_get(w, SL_TABLES, 2 * z.tab1 + 2 * z.ftab, &tv)) return -1;
+  if (ws_get(w, SL_SEG_A, z.seg, &sv)) return -1;
+  if (ws_get(w, SL_OUT1, z.qT, &qv)) return -1;
+  LindRegrBufs bf = lind_regr_carve(tv, z);
+  bf.seg = (cplx*)sv;
+  bf.qT = (double*)qv;
+  const int rc = lind_regr_forward(w, bf, h0, h0_bs, hks, hk_bs, signals, clp, dt, B, K, N, D, Dm, S, st);
+  if (rc != 0) return rc;
+  return lind_regr_backward(w, bf, per_sample, signals, B, K, N, D, Dm, S, fr_phase, Ubar, grad, st);
 }
 
 int run_vjp_tiled(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals,
@@ -2386,6 +2430,99 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
     return -1;
   if (record_stop(w, st)) return -1;
   if (flags & C3P_HOST_PTRS) return sg.finish();
+  return 0;
+}
+
+// ---- open-system evaluation from ONE forward pass: a caller-owned tape between c3p_pwc_lindblad_taped and its vjp ----
+size_t c3p_pwc_lindblad_tape_bytes(int B, int K, int N, int D, int* segments_out) {
+  if (B <= 0 || K < 1 || N <= 0 || D <= 0 || !c3p_regr_supported(D, D * D) || K > 16) {
+    if (segments_out) *segments_out = 0;
+    return 0;
+  }
+  const long S = lind_regr_segments(B, N);
+  if (segments_out) *segments_out = (int)S;
+  return lind_regr_sizes(B, K, N, D * D, S, B).total();
+}
+
+int c3p_pwc_lindblad_taped(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride, const double* signals,
+                           const void* col_ops, int C, double dt, int B, int K, int N, int D, int flags, const double* fr_phase,
+                           void* U_out, void* tape, size_t tape_bytes, int segments, void* stream) {
+  if (flags != 0) return fail("c3p_pwc_lindblad_taped takes device pointers and no flags");
+  if (B <= 0 || K < 1 || K > 16 || N <= 0 || D <= 0) return fail("bad sizes B=%d K=%d N=%d D=%d", B, K, N, D);
+  const int Dm = D * D;
+  if (!c3p_regr_supported(D, Dm)) return fail("the taped Lindblad evaluation serves D = 7, 8, 9 (Hermitian-basis kernels), got D=%d", D);
+  if (!h0 || !hks || !signals || !col_ops || C <= 0 || !U_out || !tape) return fail("NULL pointer argument");
+  if (h0_bstride < 0 || hks_bstride < 0) return fail("negative batch stride");
+  if (segments < 1 || segments > N) return fail("bad segment count %d", segments);
+  const LindRegrSizes z = lind_regr_sizes(B, K, N, Dm, segments, B);
+  if (tape_bytes < z.total()) return fail("tape too small: %zu bytes, need %zu (c3p_pwc_lindblad_tape_bytes)", tape_bytes, z.total());
+  hipStream_t st = (hipStream_t)stream;
+  WsLock lk(st);
+  DeviceWs* w = lk.w;
+  if (!w) return fail("no HIP device");
+  if (!lk.ok) return fail("hipStreamWaitEvent on the previous call's stream failed");
+  const size_t cs = sizeof(cplx);
+  void* clp;
+  if (ws_get(w, SL_CLP, (size_t)Dm * Dm * cs, &clp)) return -1;
+  LAUNCH_TRY(c3p_launch_clp((const cplx*)col_ops, C, D, (cplx*)clp, st));
+  const LindRegrBufs bf = lind_regr_carve(tape, z);
+  if (record_start(w, st)) return -1;
+  const int rc = lind_regr_forward(w, bf, (const cplx*)h0, h0_bstride, (const cplx*)hks, hks_bstride, signals, (const cplx*)clp, dt, B, K, N, D,
+                                   Dm, segments, st);
+  if (rc < 0) return -1;
+  if (rc == 1) return fail("a Hamiltonian is not Hermitian: its Lindblad generator is complex in the Hermitian basis (use c3p_pwc_lindblad and c3p_pwc_lindblad_vjp)");
+  if (record_stop(w, st)) return -1;
+  g_last_kernel = C3P_KERNEL_MFMA;
+  // U: the segment products back in the reference's vectorisation (a copy: the tape keeps the real ones), ordered combine
+  const bool per_sample = (h0_bstride != 0) || (hks_bstride != 0);
+  const long S = segments;
+  cplx* segc = (cplx*)U_out;
+  if (S > 1) {
+    void* sv;
+    if (ws_get(w, SL_SEG_A, (size_t)B * S * Dm * Dm * cs, &sv)) return -1;
+    segc = (cplx*)sv;
+  }
+  HIP_TRY(hipMemcpyAsync(segc, bf.seg, (size_t)B * S * Dm * Dm * cs, hipMemcpyDeviceToDevice, st));
+  LAUNCH_TRY(c3p_launch_hb_to_complex(segc, (long)B * S, (int)S, bf.flag_f, per_sample ? 1 : 0, K, D, st));
+  if (S == 1 && fr_phase) LAUNCH_TRY(c3p_launch_rowphase((cplx*)U_out, fr_phase, B, Dm, st));
+  if (S > 1) {
+    ChainArgs c = {};
+    c.mode = C3P_MODE_GIVEN;
+    c.mats = segc;
+    c.B = B;
+    c.N = (int)S;
+    c.D = D;
+    c.Dm = Dm;
+    c.fr_phase = fr_phase;
+    const int keep = g_last_kernel;
+    const int rc2 = run_chain_generic(w, c, (cplx*)U_out, st, /*profile=*/false);
+    g_last_kernel = keep;
+    if (rc2) return -1;
+  }
+  return 0;
+}
+
+int c3p_pwc_lindblad_vjp_taped(const void* tape, size_t tape_bytes, int segments, int per_sample_operators, const double* signals, int B,
+                               int K, int N, int D, int flags, const double* fr_phase, const void* U_bar, double* grad_signals,
+                               void* stream) {
+  if (flags != 0) return fail("c3p_pwc_lindblad_vjp_taped takes device pointers and no flags");
+  if (B <= 0 || K < 1 || K > 16 || N <= 0 || D <= 0) return fail("bad sizes B=%d K=%d N=%d D=%d", B, K, N, D);
+  const int Dm = D * D;
+  if (!c3p_regr_supported(D, Dm)) return fail("the taped Lindblad evaluation serves D = 7, 8, 9, got D=%d", D);
+  if (!tape || !signals || !U_bar || !grad_signals) return fail("NULL pointer argument");
+  if (segments < 1 || segments > N) return fail("bad segment count %d", segments);
+  const LindRegrSizes z = lind_regr_sizes(B, K, N, Dm, segments, B);
+  if (tape_bytes < z.total()) return fail("tape too small: %zu bytes, need %zu", tape_bytes, z.total());
+  hipStream_t st = (hipStream_t)stream;
+  WsLock lk(st);
+  DeviceWs* w = lk.w;
+  if (!w) return fail("no HIP device");
+  if (!lk.ok) return fail("hipStreamWaitEvent on the previous call's stream failed");
+  const LindRegrBufs bf = lind_regr_carve(const_cast<void*>(tape), z);
+  if (record_start(w, st)) return -1;
+  if (lind_regr_backward(w, bf, per_sample_operators != 0, signals, B, K, N, D, Dm, segments, fr_phase, (const cplx*)U_bar, grad_signals, st)) return -1;
+  if (record_stop(w, st)) return -1;
+  g_last_kernel = C3P_KERNEL_MFMA;
   return 0;
 }
 

@@ -75,9 +75,23 @@ def goal_run_with_grad(
         if not fid_func.startswith("lindbladian"):
             raise C3PropError(f"C3:Error: '{fid_func}' is a closed-system goal; the Lindblad path needs a lindbladian_* one")
         cold = as_dev(col_ops, np.complex128)
-        U = propagation.propagate_batch(h0d, hkd, sig, dt, col_ops=cold, lindbladian=True, fr_phase=ph)["U"]
+        B, K, N, D = int(sig.shape[0]), int(sig.shape[1]), int(sig.shape[2]), int(h0d.shape[-1])
+        tape = None
+        if fused is not False and propagation.lindblad_tape_supported(B, K, N, D):
+            # ONE forward pass: the superoperators and, on the tape, what their vector-Jacobian product reads (D = 7, 8, 9)
+            try:
+                r = propagation.propagate_batch_lindblad_taped(h0d, hkd, sig, dt, cold, fr_phase=ph)
+                U, tape = r["U"], r["tape"]
+            except C3PropError as e:  # a non-Hermitian Hamiltonian: the untaped pair serves it
+                if "Hermitian" not in str(e):
+                    raise
+        if tape is None:
+            U = propagation.propagate_batch(h0d, hkd, sig, dt, col_ops=cold, lindbladian=True, fr_phase=ph)["U"]
         U_bar, goal = _COTANGENTS[fid_func](ideal, U, index, dims)
-        g_sig = propagation.propagate_batch_lindblad_vjp(h0d, hkd, sig, dt, cold, U_bar, fr_phase=ph)
+        if tape is not None:
+            g_sig = tape.vjp(U_bar)
+        else:
+            g_sig = propagation.propagate_batch_lindblad_vjp(h0d, hkd, sig, dt, cold, U_bar, fr_phase=ph)
     else:
         if fid_func.startswith("lindbladian"):
             raise C3PropError(f"C3:Error: '{fid_func}' needs collapse operators (col_ops)")

@@ -358,6 +358,83 @@ def propagate_batch_goal_vjp(h0, hks, signals, dt: float, ideal, index, dims, *,
     return {"goal": goal, "grad_signals": grad, "grad_fr_phase": gph, "U": U}
 
 
+class LindbladTape:
+    """The forward intermediates of one `propagate_batch_lindblad_taped` call (device memory owned by this object), as the
+    reference's GradientTape keeps those of `tf_propagation_lind` (propagation.py:551-585 under optimizers/optimizer.py:206-216):
+    `tape.vjp(U_bar)` returns d loss / d signals [B,K,N] without a second forward pass."""
+
+    def __init__(self, buf, nbytes, segments, per_sample, signals, B, K, N, D, fr_phase):
+        self.buf, self.nbytes, self.segments, self.per_sample = buf, nbytes, segments, per_sample
+        self.signals, self.B, self.K, self.N, self.D, self.fr_phase = signals, B, K, N, D, fr_phase
+
+    def vjp(self, U_bar):
+        import torch
+
+        Dm = self.D * self.D
+        U_bar = U_bar.to(torch.complex128).contiguous()
+        if tuple(U_bar.shape) != (self.B, Dm, Dm):
+            raise C3PropError(f"C3:Error: U_bar must be [{self.B},{Dm},{Dm}], got {tuple(U_bar.shape)}")
+        dev = self.buf.device
+        grad = torch.empty((self.B, self.K, self.N), dtype=torch.float64, device=dev)
+        _lib.check(
+            _lib.load().c3p_pwc_lindblad_vjp_taped(
+                self.buf.data_ptr(), self.nbytes, self.segments, 1 if self.per_sample else 0, self.signals.data_ptr(), self.B, self.K, self.N, self.D, 0,
+                _ptr(self.fr_phase), U_bar.data_ptr(), grad.data_ptr(), torch.cuda.current_stream(dev).cuda_stream
+            )
+        )
+        return grad
+
+
+def lindblad_tape_supported(B: int, K: int, N: int, D: int) -> bool:
+    import ctypes
+
+    seg = ctypes.c_int(0)
+    return int(_lib.load().c3p_pwc_lindblad_tape_bytes(B, K, N, D, ctypes.byref(seg))) > 0
+
+
+def propagate_batch_lindblad_taped(h0, hks, signals, dt: float, col_ops, *, fr_phase=None):
+    """`propagate_batch(..., lindbladian=True)` for device tensors that also records a `LindbladTape` (D = 7, 8, 9, Hermitian
+    Hamiltonians; c3p_pwc_lindblad_taped): returns {"U": [B,D^2,D^2], "tape": LindbladTape}.  One forward pass serves the
+    superoperators AND their vector-Jacobian product (`tape.vjp`), where `propagate_batch` + `propagate_batch_lindblad_vjp`
+    compute the chain twice."""
+    import ctypes
+
+    import torch
+
+    call = _Call(h0, hks, signals, col_ops, fr_phase)
+    if not call.device:
+        raise C3PropError("C3:Error: the taped Lindblad evaluation takes device tensors")
+    h0 = call.c128(h0)
+    hks = call.c128(hks)
+    signals = call.f64(signals)
+    col = call.c128(col_ops)
+    if signals.ndim != 3:
+        raise C3PropError(f"C3:Error: signals must be [B,K,N], got {tuple(signals.shape)}")
+    B, K, N = (int(x) for x in signals.shape)
+    D = int(h0.shape[-1])
+    h0_bs = _bstride(h0, 2, B, "h0")
+    hk_bs = _bstride(hks, 3, B, "hks")
+    Dm = D * D
+    if fr_phase is not None:
+        fr_phase = call.f64(fr_phase)
+        if tuple(fr_phase.shape) != (B, Dm):
+            raise C3PropError(f"C3:Error: fr_phase must be [{B},{Dm}], got {tuple(fr_phase.shape)}")
+    lib = _lib.load()
+    seg = ctypes.c_int(0)
+    nbytes = int(lib.c3p_pwc_lindblad_tape_bytes(B, K, N, D, ctypes.byref(seg)))
+    if nbytes <= 0:
+        raise C3PropError(f"C3:Error: the taped Lindblad evaluation serves D = 7, 8, 9 and up to 16 control lines, got D={D} K={K}")
+    buf = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=call.dev)
+    U = call.empty((B, Dm, Dm))
+    _lib.check(
+        lib.c3p_pwc_lindblad_taped(
+            _ptr(h0), h0_bs, _ptr(hks), hk_bs, _ptr(signals), _ptr(col), int(col.shape[0]), float(dt), B, K, N, D, 0, _ptr(fr_phase), _ptr(U),
+            buf.data_ptr(), nbytes, int(seg.value), call.stream
+        )
+    )
+    return {"U": U, "tape": LindbladTape(buf, nbytes, int(seg.value), bool(h0_bs or hk_bs), signals, B, K, N, D, fr_phase)}
+
+
 def propagate_per_slice_vjp(hs, dt: float, U_bar, *, fr_phase=None):
     """Branch B of `pwc` (propagation.py:295-308: the model hands over one Hamiltonian per slice): vector-Jacobian
     product of `propagate_batch(hs, None, None, dt)` w.r.t. the Hamiltonians.  hs [N,D,D] or [B,N,D,D]; returns the

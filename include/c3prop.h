@@ -41,6 +41,7 @@
 #ifndef C3PROP_H
 #define C3PROP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -235,6 +236,27 @@ int c3p_pwc_unitary_goal_vjp(const void* h0, int64_t h0_bstride, const void* hks
 int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride,
                          const double* signals, const void* col_ops, int C, double dt, int B, int K, int N, int D,
                          int flags, const double* fr_phase, const void* U_bar, double* grad_signals, void* stream);
+
+/* Open-system optimiser evaluation from ONE forward pass (D = 7, 8, 9: 49 x 49 .. 81 x 81 superoperators, Hermitian Hamiltonians).
+ * c3p_pwc_lindblad followed by c3p_pwc_lindblad_vjp computes the chain twice (the second time with the per-slice prefixes the
+ * backward sweep reads).  Here the forward call records what the backward pass needs -- the generator tables in the Hermitian
+ * basis, the real segment products, the transposed local prefix of every slice -- on a TAPE the caller owns (device memory, as
+ * the reference's GradientTape keeps the forward intermediates of tf_propagation_lind, c3/libraries/propagation.py:551-585 under
+ * c3/optimizers/optimizer.py:206-216), and the vector-Jacobian product runs from the tape: no second forward pass, nothing of
+ * the evaluation lives in the library's shared workspace between the two calls.
+ *   c3p_pwc_lindblad_tape_bytes: bytes of the tape for a shape (0: shape not served) and the segment count it is laid out for
+ *     (pass it to both calls unchanged);
+ *   c3p_pwc_lindblad_taped: arguments and U_out as c3p_pwc_lindblad (device pointers, flags = 0, no dUs_out);
+ *   c3p_pwc_lindblad_vjp_taped: U_bar, fr_phase, grad_signals as c3p_pwc_lindblad_vjp; signals = the ones the tape was recorded
+ *     with; per_sample_operators = whether h0 / hks had a batch stride.
+ * A non-Hermitian Hamiltonian is an error of the taped forward call (use the untaped pair). */
+size_t c3p_pwc_lindblad_tape_bytes(int B, int K, int N, int D, int* segments_out);
+int c3p_pwc_lindblad_taped(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride, const double* signals,
+                           const void* col_ops, int C, double dt, int B, int K, int N, int D, int flags, const double* fr_phase,
+                           void* U_out, void* tape, size_t tape_bytes, int segments, void* stream);
+int c3p_pwc_lindblad_vjp_taped(const void* tape, size_t tape_bytes, int segments, int per_sample_operators, const double* signals,
+                               int B, int K, int N, int D, int flags, const double* fr_phase, const void* U_bar,
+                               double* grad_signals, void* stream);
 
 /* Control-signal synthesis for the standard drive line LO + AWG -> DAC -> Mixer -> VoltsToHertz
  * (Instruction.get_awg_signal c3/signal/gates.py:341-370, Envelope/EnvelopeDrag

@@ -5,7 +5,7 @@ OptimalControl.goal_run, optimalcontrol.py:200-228, and the noise-instance loop 
 
 Per case: the forward pass alone (propagate_batch on resident signals), the three-call evaluation (forward, cotangent,
 vector-Jacobian product: the forward segment products are computed twice), the fused evaluation (c3p_pwc_unitary_goal_vjp:
-once), each eagerly and replayed from ONE captured hipGraph (torch.cuda.graph around the whole evaluation).
+once; open systems at D = 7, 8, 9: one taped forward pass + the vjp from the tape), each eagerly and replayed from ONE captured hipGraph (torch.cuda.graph around the whole evaluation).
 
     python tests/perf/bench_goal_run.py --out gpurun_out/goal_run.json
 """
@@ -123,6 +123,13 @@ def main():
         row["three_call_graph_ms"] = gms
         if err:
             row["three_call_graph_error"] = err
+        if lind and propagation.lindblad_tape_supported(B, K, N, D):
+            # open systems at D = 7, 8, 9: one forward pass + a tape (run(None)) against forward + vjp recomputing the chain
+            b = run(None)
+            for key in ("goal", "grad_env", "grad_carrier"):
+                x, y = a[key], b[key]
+                assert float((x - y).abs().max()) <= 1e-9 * max(float(y.abs().max()), 1e-30), (case, key)
+            row["fused_ms"] = timed(lambda: run(None), reps, torch)
         if not lind and propagation.goal_vjp_is_fused(B, D):
             b = run(True)
             for key in ("goal", "grad_env", "grad_carrier"):

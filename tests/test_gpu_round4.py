@@ -243,3 +243,57 @@ def test_smalld_core_plus_border_form(prop, D, B, N, amp, mw):
         assert np.linalg.norm(b[i] - ref[i]) < 1e-10
     assert np.abs(a - b).max() < 1e-11
     assert np.abs(a @ a.conj().transpose(0, 2, 1) - np.eye(D)).max() < 1e-10
+
+
+def test_lindblad_taped_evaluation_matches_the_untaped_pair(prop):
+    """c3p_pwc_lindblad_taped + c3p_pwc_lindblad_vjp_taped (one forward pass, caller-owned tape) against c3p_pwc_lindblad +
+    c3p_pwc_lindblad_vjp and the oracle; per-sample operators, several segments; a non-Hermitian Hamiltonian is refused."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.as_tensor(a, device=dev)
+    for D, B, K, N, per_sample, segs in ((9, 3, 2, 14, True, 3), (7, 2, 1, 9, False, None), (8, 2, 2, 8, False, 2)):
+        h0, hks, col, sig, Ubar, ph = _lind_case(D, B, K, N, 1, 500 + D, per_sample)
+        with _lib.options(segments=segs):
+            r = prop.propagate_batch_lindblad_taped(t(h0), t(hks), t(sig), 0.2, t(col), fr_phase=t(ph))
+            g = r["tape"].vjp(t(Ubar)).cpu().numpy()
+            g2 = r["tape"].vjp(t(2.0 * Ubar)).cpu().numpy()  # the tape is reusable
+        U = r["U"].cpu().numpy()
+        U0 = np.asarray(prop.propagate_batch(h0, hks, sig, 0.2, col_ops=col, lindbladian=True, fr_phase=ph)["U"])
+        g0 = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, 0.2, col, Ubar, fr_phase=ph))
+        assert np.abs(U - U0).max() < 1e-11
+        assert np.abs(g - g0).max() < 1e-11 * np.abs(g0).max()
+        assert np.abs(g2 - 2.0 * g0).max() < 2e-11 * np.abs(g0).max()
+        ref = o.propagate_batch(h0[0] if per_sample else h0, hks[0] if per_sample else hks, sig[:1], 0.2, col_ops=col, lindbladian=True)
+        assert np.linalg.norm(U[0] - np.exp(1j * ph[0])[:, None] * ref[0]) < 1e-10
+    assert not prop.lindblad_tape_supported(4, 2, 10, 3)
+    hn = h0 - 0.05j * np.diag(np.arange(D))
+    with pytest.raises(Exception, match="Hermitian"):
+        prop.propagate_batch_lindblad_taped(t(hn), t(hks), t(sig), 0.2, t(col))
+
+
+def test_goal_run_with_grad_open_system_taped_equals_untaped(prop):
+    """optimal_control.goal_run_with_grad(col_ops=...) at two qutrits: the taped evaluation (default) and the untaped pair give
+    the same goal and gradients; a lossy Hamiltonian takes the untaped pair by itself."""
+    from c3_amd import optimal_control as oc, signals as sg
+
+    w = workloads.make_workload(4, B=1, N=8)
+    T, awg_res, sim_res = 0.6e-9, 20e9, 100e9
+    TWO_PI = 2 * np.pi
+    B = 3
+    rng = np.random.default_rng(2)
+    chans = [[dict(shape="gaussian_nonorm", amp=rng.uniform(0.2, 0.5, size=B), xy_angle=0.2 * k, freq_offset=-53e6 * TWO_PI, delta=-0.6, t_final=T, sigma=T / 4, drag=True)]
+             for k in range(2)]
+    env, shapes = sg.pack_components(chans, B=B)
+    carrier = np.tile(np.array([[5.05e9 * TWO_PI, 1e9 * TWO_PI], [5.65e9 * TWO_PI, 1e9 * TWO_PI]]), (B, 1, 1))
+    ph = rng.uniform(0, 6, size=(B, 81))
+    ideal = np.kron(np.array([[1, -1j], [-1j, 1]]) / np.sqrt(2), np.eye(2))
+    kw = dict(fr_phase=ph, fid_func="lindbladian_unitary_infid", col_ops=w.col_ops)
+    a = oc.goal_run_with_grad(w.h0, w.hks, env, shapes, carrier, 0.0, T, awg_res, sim_res, ideal, [0, 1], [3, 3], **kw)
+    b = oc.goal_run_with_grad(w.h0, w.hks, env, shapes, carrier, 0.0, T, awg_res, sim_res, ideal, [0, 1], [3, 3], fused=False, **kw)
+    for key in ("goal", "grad_env", "grad_carrier", "grad_fr_phase"):
+        x, y = a[key].cpu().numpy(), b[key].cpu().numpy()
+        assert np.abs(x - y).max() <= 1e-10 * max(np.abs(y).max(), 1e-30), key
+    hn = w.h0 - 1e6j * np.diag(np.arange(9.0))
+    c = oc.goal_run_with_grad(hn, w.hks, env, shapes, carrier, 0.0, T, awg_res, sim_res, ideal, [0, 1], [3, 3], **kw)
+    assert np.isfinite(c["goal"].cpu().numpy()).all()
