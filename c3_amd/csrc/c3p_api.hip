@@ -1339,6 +1339,20 @@ int run_pwc_tiled(DeviceWs* w, const ChainArgs& a, bool per_slice, cplx* U_out, 
 }
 
 // Tiled backward sweep (c3p_tiled.hip): any matrix dimension, unitary and Lindblad generators
+// Budget (bytes) for the per-sample forward intermediates a backward sweep keeps in HBM: 24 GB, or 60 % of what the device
+// has free plus what the workspace slot that will hold them already owns (a caching allocator of the host framework may hold
+// most of the 288 GB; a smaller part has less) -- the sweeps run in chunks of samples below it.
+static size_t grad_store_budget(DeviceWs* w, Slot slot) {
+  size_t budget = (size_t)24 << 30;
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+    const size_t avail = (size_t)(0.6 * (double)fr) + (w ? w->cap[slot] : 0);
+    if (avail < budget) budget = avail;
+  }
+  if (budget < ((size_t)64 << 20)) budget = (size_t)64 << 20;
+  return budget;
+}
+
 // ---------------------------------------------------------------------------
 // Lindblad control gradient at D = 7, 8, 9 (49 x 49 .. 81 x 81 superoperators, cfg4) in the Hermitian basis: forward chain
 // kernel with the transposed local prefixes kept in HBM, real segment scan, on-chip backward sweep (c3p_regrg.hip).
@@ -1487,7 +1501,7 @@ int run_vjp_tiled(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const c
                   const cplx* clp, double dt, int B, int K, int N, int D, int Dm, const double* fr_phase, const cplx* U_bar,
                   double* grad, hipStream_t st, bool per_slice = false, cplx* zout = nullptr) {
   const bool per_sample = !per_slice && ((h0_bs != 0) || (hk_bs != 0));
-  const int Bc = c3p_tiled_vjp_chunk(Dm, K, N, B, per_sample, (size_t)24 << 30);
+  const int Bc = c3p_tiled_vjp_chunk(Dm, K, N, B, per_sample, grad_store_budget(w, SL_SCRATCH));
   void* v;
   if (ws_get(w, SL_SCRATCH, c3p_tiled_vjp_ws_bytes(Dm, K, N, Bc, per_sample), &v)) return -1;
   if (g_dry) return 0;
@@ -2298,7 +2312,7 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
   // The general-generator sweeps keep the slice propagators and the prefix of every slice: 2 N D^4 complex per sample.  Large
   // batches are processed in chunks of samples that keep that below 24 GB (C3P_GRAD_CHUNK overrides the chunk size).
   auto in_chunks = [&](auto&& run) -> int {  // run(b0, nb) -> 0 done, 1 not applicable, -1 error
-    long Bc = (long)(((size_t)24 << 30) / (2 * (size_t)N * Dm * Dm * cs));
+    long Bc = (long)(grad_store_budget(w, SL_OUT1) / (2 * (size_t)N * Dm * Dm * cs + 1));
     if (c3p_opt(C3P_OPT_grad_chunk) > 0) Bc = c3p_opt(C3P_OPT_grad_chunk);
     if (Bc < 1) Bc = 1;
     for (long b0 = 0; b0 < B; b0 += Bc) {
@@ -2405,7 +2419,7 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
     // 49 x 49 .. 81 x 81 superoperators (D = 7, 8, 9; cfg4): on-chip backward sweep in the Hermitian basis, real arithmetic; the
     // transposed local prefix of every slice (N D^4 doubles per sample) is kept in HBM: chunks of samples below 24 GB
     if (record_start(w, st)) return -1;
-    long Bc = (long)(((size_t)24 << 30) / ((size_t)N * Dm * Dm * sizeof(double)));
+    long Bc = (long)(grad_store_budget(w, SL_OUT1) / ((size_t)N * Dm * Dm * sizeof(double) + 1));
     if (c3p_opt(C3P_OPT_grad_chunk) > 0) Bc = c3p_opt(C3P_OPT_grad_chunk);
     if (Bc < 1) Bc = 1;
     int rc = 0;
@@ -2655,7 +2669,7 @@ int c3p_pwc_unitary_vjp(const void* h0, int64_t h0_bstride, const void* hks, int
     if (D <= 40 && !(flags & C3P_FORCE_GENERIC) && !c3p_opt_on(C3P_OPT_tiled_grad)) {
       // on-chip general-generator sweeps (nothing assumed about the slice Hamiltonians), in chunks of samples that keep the
       // slice propagators + prefixes (2 N D^2 complex per sample) below 24 GB
-      long Bc = (long)(((size_t)24 << 30) / (2 * (size_t)N * D * D * cs));
+      long Bc = (long)(grad_store_budget(w, SL_OUT1) / (2 * (size_t)N * D * D * cs + 1));
       if (c3p_opt(C3P_OPT_grad_chunk) > 0) Bc = c3p_opt(C3P_OPT_grad_chunk);
       if (Bc < 1) Bc = 1;
       int rc = 0;
