@@ -297,3 +297,18 @@ def test_goal_run_with_grad_open_system_taped_equals_untaped(prop):
     hn = w.h0 - 1e6j * np.diag(np.arange(9.0))
     c = oc.goal_run_with_grad(hn, w.hks, env, shapes, carrier, 0.0, T, awg_res, sim_res, ideal, [0, 1], [3, 3], **kw)
     assert np.isfinite(c["goal"].cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("D,B,N,segments", [
+    (7, 2, 75, 1),    # one chain of 75 slices: the control amplitudes are staged in chunks of 32 slices (descending)
+    (7, 40, 16, 8),   # 320 chains on 256 workgroups: a workgroup sweeps a second chain (arena and LDS reuse)
+])
+def test_lindblad_vjp_hermitian_basis_long_chains_and_many_chains(prop, D, B, N, segments):
+    h0, hks, col, sig, Ubar, ph = _lind_case(D, B, 2, N, 1, 31 * D + N, per_sample=False)
+    with _lib.options(segments=segments):
+        g = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, 0.15, col, Ubar, fr_phase=ph))
+    with _lib.options(tiled_grad=1):
+        gt = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, 0.15, col, Ubar, fr_phase=ph))
+    assert np.abs(g - gt).max() < 1e-10 * np.abs(gt).max()
+    want = o.pwc_lindblad_signal_gradient(h0, hks, col, sig[B - 1], 0.15, Ubar[B - 1], ph[B - 1])
+    assert np.abs(g[B - 1] - want).max() < 1e-10 * np.abs(want).max()
