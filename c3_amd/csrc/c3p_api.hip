@@ -1980,6 +1980,37 @@ int ode_segmented(DeviceWs* w, OdeArgs a, int nseg, const cplx* init, long init_
   return 0;
 }
 
+// Trajectory (want_all) of a small batch of Schroedinger states at D <= 12 in time segments: the segment maps as above, the
+// state at the start of every segment from them, then the B x nseg pieces of the trajectory side by side (lane-row kernel).
+int ode_trajectory_segmented(DeviceWs* w, OdeArgs a, int nseg, hipStream_t st) {
+  const int D = a.D, B = a.B;
+  const size_t cs = sizeof(cplx);
+  void *v_id, *v_maps, *v_st;
+  if (ws_get(w, SL_CLP, (size_t)D * D * cs, &v_id)) return -1;
+  if (ws_get(w, SL_SEG_A, (size_t)B * nseg * D * D * cs, &v_maps)) return -1;
+  if (ws_get(w, SL_SEG_B, (size_t)B * nseg * D * cs, &v_st)) return -1;
+  if (g_dry) return 0;
+  LAUNCH_TRY(c3p_launch_ode_identity((cplx*)v_id, D, st));
+  OdeArgs m = a;
+  m.M = D;
+  m.init = (const cplx*)v_id;
+  m.init_bstride = 0;
+  m.want_all = 0;
+  m.seg_count = nseg;
+  m.seg_len = (a.n_steps + nseg - 1) / nseg;
+  m.states = (cplx*)v_maps;
+  LAUNCH_TRY(c3p_launch_ode_row(m, nullptr, st));
+  LAUNCH_TRY(c3p_launch_ode_starts((const cplx*)v_maps, a.init, a.init_bstride, (cplx*)v_st, B, nseg, D, st));
+  OdeArgs t = a;
+  t.init = (const cplx*)v_st;
+  t.init_bstride = D;
+  t.seg_count = nseg;
+  t.seg_len = m.seg_len;
+  t.seg_traj = 1;
+  LAUNCH_TRY(c3p_launch_ode_row(t, nullptr, st));
+  return 0;
+}
+
 // Time segments for few samples at 17 <= D <= 48 (final state / propagator only): one workgroup per (sample, segment) on the
 // matrix-core kernel.  A sample alone keeps ONE CU busy for n_steps x ~5 us; S segments spread it over S CUs (the chip has
 // 256), at the price of the ordered product of S maps.  min_gain: how many segments the change has to offer at least
@@ -2063,7 +2094,11 @@ int c3p_ode_solve(const void* h0, const void* hks, const double* signals, const 
     g_last_kernel = C3P_KERNEL_ODE_ROW;
     if (record_start(w, st)) return -1;
     const int nseg = (step == C3P_STEP_SCHRODINGER) ? c3p_ode_row_segments(a) : 0;
-    if (nseg > 0) {
+    const int tseg = (step == C3P_STEP_SCHRODINGER && nseg == 0) ? c3p_ode_row_traj_segments(a) : 0;
+    if (tseg > 0) {
+      // small batch, whole trajectory: segment maps -> start state of every segment -> the pieces side by side
+      if (ode_trajectory_segmented(w, a, tseg, st)) return -1;
+    } else if (nseg > 0) {
       // small batch, final state only: the equations are linear, so the interval is cut into nseg time segments, every
       // segment integrates the D columns of the identity (its step map), the maps are multiplied in order by the small-D
       // chain kernel and the product is applied to the initial state -- D x the arithmetic on nseg x D x the lanes

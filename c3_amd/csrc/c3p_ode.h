@@ -31,6 +31,9 @@ struct OdeArgs {
   // integrated over seg_count step ranges of seg_len steps from the IDENTITY, and states receives the segment maps
   // [B, seg_count, D, M] (their ordered product is the step map of the whole interval: the equations are linear)
   int seg_count, seg_len;
+  // trajectory from segment start states (lane-row vector kernel, M = 1, want_all): row (b, seg) starts from
+  // init[(b * seg_count + seg) * init_bstride], integrates its own step range and writes states[b, n] of that range
+  int seg_traj;
   int rho_general;  // matrix-core rho kernel: do not use the Hermitian shortcut (set by its launcher from C3P_ODE_RHO_GENERAL)
 };
 
@@ -61,3 +64,7 @@ hipError_t c3p_launch_ode_rhoq(const OdeArgs& A, hipStream_t st);
 int c3p_ode_row_segments(const OdeArgs& A);
 hipError_t c3p_launch_ode_apply(const cplx* U, const cplx* init, long init_bstride, cplx* out, int B, int D, hipStream_t st);
 hipError_t c3p_launch_ode_identity(cplx* out, int D, hipStream_t st);  // [D,D] identity on the device (no host round trip)
+// trajectories of small batches (want_all) in time segments: segment count (0 = off); start states of every segment from the
+// segment maps: starts[b, s] = maps[b, s-1] ... maps[b, 0] init[b]
+int c3p_ode_row_traj_segments(const OdeArgs& A);
+hipError_t c3p_launch_ode_starts(const cplx* maps, const cplx* init, long init_bstride, cplx* starts, int B, int S, int D, hipStream_t st);

@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(64) ode_vec_kernel(OdeArgs A) {
   // real operators take the REALH instance, everything else the complex one (both are launched; wave-uniform exit)
   if ((__all(im0) != 0) != REALH) return;
 
-  const cplx* init = A.init + (long)b * A.init_bstride;
+  const cplx* init = A.init + (A.seg_traj ? (long)b * SG + seg : (long)b) * A.init_bstride;
   double pr = 0.0, pi = 0.0;
   if (row) {
     const cplx z = init[(long)i * M + col];
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(64) ode_vec_kernel(OdeArgs A) {
   double Hr[DP], Hi[REALH ? 1 : DP];
   const long ssz = (long)D * M;
   const long eo = A.transpose_out ? (long)col * D + i : (long)i * M + col;
-  cplx* outp = A.states + ((long)b * SG + seg) * (A.want_all ? (long)A.n_steps : 1) * ssz + eo;
+  cplx* outp = A.states + (A.seg_traj ? (long)b : (long)b * SG + seg) * (A.want_all ? (long)A.n_steps : 1) * ssz + eo;
 
   // The step loops run over the RELATIVE step index (wave-uniform: the four rows of a wavefront may integrate different
   // segments, i.e. different absolute steps n = n_begin + j; a row past its segment end keeps its state)
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(64) ode_vec_kernel(OdeArgs A) {
       });
       pr = act ? qr : pr;
       pi = act ? qi : pi;
-      if (A.want_all && live && row) outp[(long)n * ssz] = cmake(pr, pi);
+      if (A.want_all && live && row && (act || !A.seg_traj)) outp[(long)n * ssz] = cmake(pr, pi);
       if (A.reset_each_step) {
         pr = ir;
         pi = ii;
@@ -664,6 +664,55 @@ int c3p_ode_row_segments(const OdeArgs& A) {
     if (c < best) best = c, pick = S;
   }
   return pick;
+}
+
+// Trajectories (want_all) of small batches: the segment maps of ode_segmented give the state at the START of every segment
+// (one small kernel), and a second pass integrates the B x S pieces side by side, each writing its own range of the
+// trajectory.  Cost model as c3p_ode_row_segments, plus the second pass.
+int c3p_ode_row_traj_segments(const OdeArgs& A) {
+  if (c3p_opt_on(C3P_OPT_ode_no_seg)) return 0;
+  if (A.D < 2 || A.D > 12 || !A.want_all || A.M != 1 || A.reset_each_step || A.transpose_out || A.n_steps < 64) return 0;
+  auto step_cost = [](long rows) {
+    const long w = (rows + 4095) / 4096;
+    return w <= 1 ? 0.50 : 0.14 + 0.34 * (double)w;
+  };
+  const double fixed = 60.0 * (A.solver == 0 || A.solver == 1 ? 1.0 : 0.55);
+  if ((long)A.B > 4096) return 0;
+  const double direct = (double)A.n_steps * step_cost((long)A.B);
+  double best = direct * 0.8;
+  int pick = 0;
+  for (int S = 2; S <= 8 && S <= A.n_steps / 32; ++S) {
+    const double c = (double)((A.n_steps + S - 1) / S) * (step_cost((long)A.B * S * A.D) + step_cost((long)A.B * S)) + fixed;
+    if (c < best) best = c, pick = S;
+  }
+  return pick;
+}
+
+namespace {
+// starts[b, s] = maps[b, s-1] ... maps[b, 0] init[b]  (maps [B, S, D, D] row-major); one wavefront per sample, lane i = row i
+__global__ void __launch_bounds__(64) ode_starts_kernel(const cplx* maps, const cplx* init, long init_bstride, cplx* starts, int S, int D) {
+  __shared__ cplx psi[64];
+  const int i = threadIdx.x;
+  const long b = blockIdx.x;
+  cplx v = i < D ? init[b * init_bstride + i] : cmake(0, 0);
+  for (int s = 0; s < S; ++s) {
+    if (i < D) starts[(b * S + s) * D + i] = v;
+    psi[i] = v;
+    __syncthreads();
+    if (i < D) {
+      const cplx* m = maps + ((b * S + s) * D + i) * D;
+      cplx a = cmake(0, 0);
+      for (int j = 0; j < D; ++j) cfma(a, m[j], psi[j]);
+      v = a;
+    }
+    __syncthreads();
+  }
+}
+}  // namespace
+
+hipError_t c3p_launch_ode_starts(const cplx* maps, const cplx* init, long init_bstride, cplx* starts, int B, int S, int D, hipStream_t st) {
+  hipLaunchKernelGGL(ode_starts_kernel, dim3((unsigned)B), dim3(64), 0, st, maps, init, init_bstride, starts, S, D);
+  return hipGetLastError();
 }
 
 hipError_t c3p_launch_ode_identity(cplx* out, int D, hipStream_t st) {

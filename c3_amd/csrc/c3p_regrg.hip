@@ -687,6 +687,7 @@ size_t c3p_regr_grad_arena_bytes(int Dm) {
 
 hipError_t c3p_launch_regr_grad(const RegrGradArgs& A, hipStream_t st) {
   if (A.K > RR_KMAX || A.K < 1 || !A.tables || !A.tables_t || !A.qT || !A.lam || !A.tau || !A.arena) return hipErrorInvalidValue;
+  if (A.degree != 0 && A.degree != 8 && A.degree != 12 && A.degree != 16 && A.degree != 20) return hipErrorInvalidValue;
   const int cls = c3p_regd_class(A.Dm);
   if (cls == 49) return launch_rg<3>(A, st);
   if (cls == 65) return launch_rg<4>(A, st);

@@ -229,6 +229,10 @@ int c3p_pwc_unitary_goal_vjp(const void* h0, int64_t h0_bstride, const void* hks
  * products are kept in HBM (N matrices of D^4 complex per sample, processed in chunks of samples that fit 24 GB) and the
  * backward sweep evaluates value and Frechet derivative of every slice's exponential together on the tiled MFMA GEMM
  * (c3p_tiled.hip).  c3p_pwc_unitary_vjp uses the same sweep above D = 40 (any dimension; gen_bar_out up to D = 64: above 40 on the VALU sweep).
+ * D = 7, 8, 9 (49 x 49 .. 81 x 81 superoperators, Hermitian Hamiltonians): the whole evaluation in REAL arithmetic in the Hermitian
+ * basis -- forward chain kernel keeping the transposed local prefix of every slice, real segment scan, on-chip backward sweep
+ * (c3p_regrg.hip); the call synchronises the stream once (it reads back whether every Hamiltonian is Hermitian: a complex
+ * generator in that basis falls back to the tiled sweep).
  * D <= 6 (superoperators up to 36 x 36): three kernels per call instead of ~35 launches per slice -- segment products, a scan
  * that leaves prefix and left adjoint at the segment boundaries, and a sweep that stores the prefix of every slice of its
  * segment and evaluates the pair at X_n^H on the way back (general-generator form on the matrix cores: c3p_smalld.hip for

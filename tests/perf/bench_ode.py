@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--complex-ops", action="store_true", help="add an imaginary part to the control operators (complex instance)")
     ap.add_argument("--synth-col", action="store_true", help="synthetic collapse operators where the config has none (lindblad step)")
+    ap.add_argument("--trajectory", action="store_true", help="ode_solver (every state of the trajectory) instead of ode_solver_final_state")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     dev = "cuda:0"
@@ -86,7 +87,7 @@ def main():
             col = torch.as_tensor(col_np, device=dev) if step == "lindblad" else None
             C = int(col_np.shape[0]) if step == "lindblad" else 0
             for solver in a.solvers.split(","):
-                fn = lambda: prop.ode_solve_batch(h0, hks, sig, wl.dt, init, solver, step, col_ops=col, final_only=True)
+                fn = lambda: prop.ode_solve_batch(h0, hks, sig, wl.dt, init, solver, step, col_ops=col, final_only=not a.trajectory)
                 res = fn()
                 torch.cuda.synchronize()
                 kern = _lib.last_kernel()
@@ -96,13 +97,13 @@ def main():
                     res = fn()
                     torch.cuda.synchronize()
                     best = min(best, time.perf_counter() - t0)
-                got = res[:2].cpu().numpy()
+                got = (res[:2, -1] if a.trajectory else res[:2]).cpu().numpy()
                 ref = np.stack([
                     o.ode_solver_arrays(wl.h0, hks_np, wl.signals[b], wl.ts, psi0 if step == "schrodinger" else rho0, solver, step,
                                         col=col_np if step == "lindblad" else None, final_only=True)["states"] for b in range(2)])
                 fl = flops_per_step(D, K, C, solver, step)
                 steps = B * N
-                row = {"step": step, "solver": solver, "B": B, "N": N, "D": D, "K": K, "C": C, "kernel": kern, "complex_ops": bool(a.complex_ops),
+                row = {"step": step, "solver": solver, "trajectory": bool(a.trajectory), "B": B, "N": N, "D": D, "K": K, "C": C, "kernel": kern, "complex_ops": bool(a.complex_ops),
                        "ms": best * 1e3, "rk_steps_per_s": steps / best, "final_states_per_s": B / best,
                        "algorithmic_flop_per_step": fl, "algorithmic_tflops": steps * fl / best * 1e-12, "frac": steps * fl / best / PEAK,
                        "err_vs_oracle_rk": float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max())), "max_abs_state": float(np.abs(ref).max())}

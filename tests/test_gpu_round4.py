@@ -312,3 +312,29 @@ def test_lindblad_vjp_hermitian_basis_long_chains_and_many_chains(prop, D, B, N,
     assert np.abs(g - gt).max() < 1e-10 * np.abs(gt).max()
     want = o.pwc_lindblad_signal_gradient(h0, hks, col, sig[B - 1], 0.15, Ubar[B - 1], ph[B - 1])
     assert np.abs(g[B - 1] - want).max() < 1e-10 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("D,K,real", [(3, 1, True), (9, 2, True), (9, 2, False), (12, 3, False)])
+def test_ode_trajectory_of_small_batches_in_time_segments(prop, D, K, real):
+    """ode_solver (every state of the trajectory, propagation.py:687-752) for a SMALL batch: segment maps -> state at the start
+    of every segment -> the pieces integrated side by side.  Same numbers as the direct integration and as the oracle's
+    sequential solver; uneven last segment, all four solvers, per-sample initial states."""
+    import sys
+
+    sys.path.insert(0, __import__("os").path.dirname(__file__))
+    from test_gpu_round3 import _ode_problem
+
+    B, N = 5, 203
+    h0, hks, sig, ts = _ode_problem(D, K, B, N, real, 1900 + D)
+    rng = np.random.default_rng(D)
+    psi = rng.normal(size=(B, D, 1)) + 1j * rng.normal(size=(B, D, 1))
+    for solver in ("rk4", "rk38", "rk5", "tsit5"):
+        seg = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], psi, solver, "schrodinger"))
+        assert _lib.last_kernel() == "ode_row"
+        with _lib.options(ode_no_seg=1):
+            direct = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], psi, solver, "schrodinger"))
+        assert seg.shape == direct.shape
+        assert np.abs(seg - direct).max() < 1e-12 * max(1.0, np.abs(direct).max())
+        for b in (0, B - 1):
+            ref = o.ode_solver_arrays(h0, hks, sig[b], ts, psi[b], solver, "schrodinger")["states"]
+            assert np.abs(seg[b] - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
