@@ -1999,7 +1999,12 @@ int ode_trajectory_segmented(DeviceWs* w, OdeArgs a, int nseg, hipStream_t st) {
   m.seg_count = nseg;
   m.seg_len = (a.n_steps + nseg - 1) / nseg;
   m.states = (cplx*)v_maps;
-  LAUNCH_TRY(c3p_launch_ode_row(m, nullptr, st));
+  if (D > 16) {
+    m.step = C3P_STEP_PROPAGATOR_ID;  // 17 <= D <= 48: the segment maps on the matrix-core kernel (one product per stage)
+    LAUNCH_TRY(c3p_launch_ode_rhoq(m, st));
+  } else {
+    LAUNCH_TRY(c3p_launch_ode_row(m, nullptr, st));
+  }
   LAUNCH_TRY(c3p_launch_ode_starts((const cplx*)v_maps, a.init, a.init_bstride, (cplx*)v_st, B, nseg, D, st));
   OdeArgs t = a;
   t.init = (const cplx*)v_st;
@@ -2007,8 +2012,28 @@ int ode_trajectory_segmented(DeviceWs* w, OdeArgs a, int nseg, hipStream_t st) {
   t.seg_count = nseg;
   t.seg_len = m.seg_len;
   t.seg_traj = 1;
-  LAUNCH_TRY(c3p_launch_ode_row(t, nullptr, st));
+  if (D > 16)
+    LAUNCH_TRY(c3p_launch_ode_rowq(t, st));
+  else
+    LAUNCH_TRY(c3p_launch_ode_row(t, nullptr, st));
   return 0;
+}
+
+// trajectories of few Schroedinger states at 17 <= D <= 48: segment maps on the matrix-core kernel, pieces on the lane-row
+// kernel of c3p_ode_rowq.hip (one time segment per wavefront)
+int ode_mfma_traj_segments(const OdeArgs& a0) {
+  if (c3p_opt_on(C3P_OPT_ode_no_seg)) return 0;
+  if (a0.D < 17 || a0.D > 48 || !a0.want_all || a0.M != 1 || a0.reset_each_step || a0.transpose_out || a0.hs || a0.K > 4 || a0.n_steps < 64) return 0;
+  OdeArgs a = a0;
+  a.step = C3P_STEP_PROPAGATOR_ID;
+  a.M = a.D;
+  a.want_all = 0;
+  a.seg_count = 2;
+  if (!c3p_ode_rhoq_supported(a) || !c3p_ode_rowq_supported(a0)) return 0;
+  long S = 512 / a0.B;
+  if (S > a0.n_steps / 16) S = a0.n_steps / 16;
+  if (S > 64) S = 64;
+  return S >= 4 ? (int)S : 0;
 }
 
 // Time segments for few samples at 17 <= D <= 48 (final state / propagator only): one workgroup per (sample, segment) on the
@@ -2111,6 +2136,15 @@ int c3p_ode_solve(const void* h0, const void* hks, const double* signals, const 
     return 0;
   }
   if (step == C3P_STEP_SCHRODINGER) {
+    const int tseg = ode_mfma_traj_segments(a);
+    if (tseg > 0) {
+      g_last_kernel = C3P_KERNEL_ODE_ROW;
+      if (record_start(w, st)) return -1;
+      if (ode_trajectory_segmented(w, a, tseg, st)) return -1;
+      if (record_stop(w, st)) return -1;
+      if (flags & C3P_HOST_PTRS) return sg.finish();
+      return 0;
+    }
     const int nseg = ode_mfma_segments(a, 4);
     if (nseg > 0) {
       // few states at 17 <= D <= 48, final state only: segment maps on the matrix-core kernel, psi = U psi0

@@ -105,13 +105,30 @@ __global__ void __launch_bounds__(64 * NW) ode_vecq_kernel(OdeArgs A) {
 
   const long nv = (long)A.B * M;
   long v = ((long)blockIdx.x * NW + wave) * SPW + slot;
-  const bool live = v < nv;
+  bool live = v < nv;
   if (!live) v = nv - 1;
-  const int b = (int)(v / M), col = (int)(v - (long)b * M);
+  int b = (int)(v / M), col = (int)(v - (long)b * M);
+  // trajectory pieces (OdeArgs.seg_traj, M = 1): a WAVEFRONT integrates one time segment (its samples share the absolute step
+  // index, which the chunked control amplitudes and the piecewise-linear advance of H assume), segment-major order
+  int seg = 0, n_begin = 0, n_end = A.n_steps;
+  if (A.seg_traj) {
+    const long vw = (long)blockIdx.x * NW + wave;
+    const long wps = (A.B + SPW - 1) / SPW;  // wavefronts per segment
+    long sg_ = vw / wps;
+    live = sg_ < A.seg_count;
+    if (!live) sg_ = A.seg_count - 1;
+    seg = __builtin_amdgcn_readfirstlane((int)sg_);
+    const long bb = (vw - (vw / wps) * wps) * SPW + slot;
+    live = live && bb < A.B;
+    b = (int)(bb < A.B ? bb : A.B - 1);
+    col = 0;
+    n_begin = seg * A.seg_len;
+    n_end = n_begin + A.seg_len < A.n_steps ? n_begin + A.seg_len : A.n_steps;
+  }
   const int rowi = 16 * q + i;
   const bool rowok = (q < NQ) && rowi < D;
   const int lrow = rowok ? rowi : D;  // padding lanes read the zero row
-  const cplx* init = A.init + (long)b * A.init_bstride;
+  const cplx* init = A.init + (A.seg_traj ? (long)b * A.seg_count + seg : (long)b) * A.init_bstride;
   double pr = 0.0, pi = 0.0;
   if (rowok) {
     const cplx z = init[(long)rowi * M + col];
@@ -125,7 +142,7 @@ __global__ void __launch_bounds__(64 * NW) ode_vecq_kernel(OdeArgs A) {
   const bool loader = (q == 0);  // lanes that fetch the sample's control amplitudes (16 per chunk and control line)
   double pre[QK];
   {
-    const int base = q_chunk_base(0, us, N);
+    const int base = q_chunk_base(n_begin, us, N);
     int idx = base + i;
     if (idx > N - 1) idx = N - 1;
 #pragma unroll
@@ -164,7 +181,7 @@ __global__ void __launch_bounds__(64 * NW) ode_vecq_kernel(OdeArgs A) {
   };
 
   double kpr = 0.0, kpi = 0.0;  // previous stage (all tableaux: a[s][s-1] is applied from registers)
-  for (int n0 = 0; n0 < A.n_steps; n0 += SPC) {
+  for (int n0 = n_begin; n0 < n_end; n0 += SPC) {
     const int base = q_chunk_base(n0, us, N);
     if (loader) {
 #pragma unroll
@@ -218,7 +235,7 @@ __global__ void __launch_bounds__(64 * NW) ode_vecq_kernel(OdeArgs A) {
         u0 = pend;
       }
     };
-    const int n1 = (n0 + SPC < A.n_steps) ? n0 + SPC : A.n_steps;
+    const int n1 = (n0 + SPC < n_end) ? n0 + SPC : n_end;
     for (int n = n0; n < n1; ++n) {
       double th_prev = 0.0;
       double Br = 0.0, Bi = 0.0;  // running sum_j b_j k_j
@@ -287,7 +304,8 @@ hipError_t launch_q2(const OdeArgs& A, hipStream_t st) {
   constexpr int NQP = (NQ == 2) ? 2 : 4;
   constexpr int SPW = 4 / NQP;
   constexpr int NC = 16 * (NQ - 1) + CL;
-  const long nv = (long)A.B * A.M;
+  // (trajectory pieces: seg_count x ceil(B / SPW) wavefronts, one segment per wavefront)
+  const long nv = A.seg_traj ? (long)A.seg_count * ((A.B + SPW - 1) / SPW) * SPW : (long)A.B * A.M;
   hipError_t e;
   {
     // real operators: two wavefronts per SIMD (half the registers, half the LDS)

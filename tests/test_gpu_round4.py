@@ -338,3 +338,25 @@ def test_ode_trajectory_of_small_batches_in_time_segments(prop, D, K, real):
         for b in (0, B - 1):
             ref = o.ode_solver_arrays(h0, hks, sig[b], ts, psi[b], solver, "schrodinger")["states"]
             assert np.abs(seg[b] - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("D,K,real,B", [(20, 2, False, 3), (27, 3, True, 2), (36, 3, True, 5), (40, 1, False, 4)])
+def test_ode_trajectory_time_segments_mid_dimensions(prop, D, K, real, B):
+    """the same at 17 <= D <= 48: segment maps on the matrix-core kernel, the pieces on the lane-row kernel of c3p_ode_rowq.hip
+    (one time segment per wavefront; odd batches leave half-empty wavefronts); against the direct integration and the oracle"""
+    import sys
+
+    sys.path.insert(0, __import__("os").path.dirname(__file__))
+    from test_gpu_round3 import _ode_problem
+
+    N = 150
+    h0, hks, sig, ts = _ode_problem(D, K, B, N, real, 2900 + D)
+    rng = np.random.default_rng(D)
+    psi = rng.normal(size=(B, D, 1)) + 1j * rng.normal(size=(B, D, 1))
+    for solver in ("rk4", "tsit5"):
+        seg = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], psi, solver, "schrodinger"))
+        with _lib.options(ode_no_seg=1):
+            direct = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], psi, solver, "schrodinger"))
+        assert np.abs(seg - direct).max() < 1e-11 * max(1.0, np.abs(direct).max())
+        ref = o.ode_solver_arrays(h0, hks, sig[B - 1], ts, psi[B - 1], solver, "schrodinger")["states"]
+        assert np.abs(seg[B - 1] - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
