@@ -226,3 +226,19 @@ def test_dpp_blocks_are_hazard_guarded():
 
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazards.py"), "c3p_ode_rowq.hip"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_lindblad_tape_layout_is_host_arithmetic(lib):
+    """c3p_pwc_lindblad_tape_bytes needs no device: the tape of the open-system evaluation (include/c3prop.h) is sized from the
+    shape alone -- two table sets, their flags, B x S complex segment slots, B x N real D^2 x D^2 prefixes -- and shapes the
+    Hermitian-basis kernels do not serve report 0."""
+    import ctypes
+
+    seg = ctypes.c_int(-1)
+    n = lib.c3p_pwc_lindblad_tape_bytes(64, 2, 1000, 9, ctypes.byref(seg))
+    assert seg.value == 4  # 64 samples x 4 segments = one round of 256 workgroups
+    assert n >= 64 * 1000 * 81 * 81 * 8 + 64 * 4 * 81 * 81 * 16
+    assert n < 1.02 * (64 * 1000 * 81 * 81 * 8 + 64 * 4 * 81 * 81 * 16) + (1 << 22)
+    for D in (2, 3, 6, 10):
+        assert lib.c3p_pwc_lindblad_tape_bytes(4, 2, 100, D, ctypes.byref(seg)) == 0 and seg.value == 0
+    assert lib.c3p_pwc_lindblad_tape_bytes(4, 17, 100, 9, None) == 0  # more control lines than the kernels hold
