@@ -2,6 +2,7 @@
 #   bash tools/final_r04.sh pmc "4 3" "2 30"      rocprofv3 kernel stats + PMC passes of the bench command (cfg, steps), -> pmc_cfgN.json
 #   bash tools/final_r04.sh bench                  bench lines of every configuration (+ --complex, one-rank RCCL schedules)
 #   bash tools/final_r04.sh grad                   gradient timings
+#   bash tools/final_r04.sh goal                   optimiser evaluation, Lindblad gradient, 8 + 1 A/B, ODE trajectories
 # PMC entries are merged into profiles/r04/pmc.json per configuration (bench.py quotes an entry only while the digest of
 # that configuration's kernel sources still matches), so one configuration can be re-profiled without the others.
 R=$GRAFT_REPO_ROOT
@@ -62,6 +63,17 @@ grad)
   python tools/bench_grad.py --config 5 --batch 256 --reps 3 > $O/grad_cfg5.json
   python tools/bench_grad_tiled.py --out $O/grad_tiled.json > /dev/null 2>&1
   python tools/bench_grad_lindblad.py --cases 2:256:1000,3:256:1000,3:16:1000,3:1024:1000,4:256:1000,4:64:1000,5:64:500,6:64:500 --out $O/grad_lindblad_small_mfma.json > /dev/null 2>&1
+  ;;
+goal)
+  # one optimiser evaluation (closed and open systems), the Hermitian-basis Lindblad gradient, the 8 + 1 A/B, ODE trajectories
+  python tests/perf/bench_goal_run.py --out $O/goal_run.json > $O/goal_run.log 2>&1
+  python tools/bench_grad_lindblad_hb.py --out $O/grad_lindblad_hb.json > $O/grad_lindblad_hb.log 2>&1
+  python tools/ab_split81.py --out $O/ab_split81.json > /dev/null 2>&1
+  ./tools/ubench_sym9 > $O/ubench_sym9.txt 2>&1
+  python tests/perf/bench_ode.py --config 2 --steps schrodinger --solvers rk4,tsit5 --batches 16,64,256,1024 --trajectory --out $O/ode_trajectory_small_batches.json > /dev/null 2>&1
+  C3P_ODE_NO_SEG=1 python tests/perf/bench_ode.py --config 2 --steps schrodinger --solvers rk4,tsit5 --batches 16,64,256,1024 --trajectory --out $O/ode_trajectory_small_batches_direct.json > /dev/null 2>&1
+  python tests/perf/bench_ode.py --config 3 --steps schrodinger --solvers rk4 --batches 4,16,64,256 --trajectory --out $O/ode_trajectory_cfg3_small_batches.json > /dev/null 2>&1
+  C3P_ODE_NO_SEG=1 python tests/perf/bench_ode.py --config 3 --steps schrodinger --solvers rk4 --batches 4,64 --trajectory --out $O/ode_trajectory_cfg3_small_batches_direct.json > /dev/null 2>&1
   ;;
 esac
 ls $O | wc -l
