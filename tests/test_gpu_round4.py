@@ -360,3 +360,16 @@ def test_ode_trajectory_time_segments_mid_dimensions(prop, D, K, real, B):
         assert np.abs(seg - direct).max() < 1e-11 * max(1.0, np.abs(direct).max())
         ref = o.ode_solver_arrays(h0, hks, sig[B - 1], ts, psi[B - 1], solver, "schrodinger")["states"]
         assert np.abs(seg[B - 1] - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+
+
+def test_randomised_parity_sweep_of_the_round4_entry_points(lib):
+    """tools/fuzz_r04.py for a few seconds: fused goal vs three calls, Hermitian-basis Lindblad sweep and taped pair vs the tiled
+    sweep, core + border form vs padded tiles, segmented ODE trajectories vs direct -- random shapes (4 minutes of it:
+    55 000 cases, worst deviation 4e-12)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_r04.py"), "--seconds", "8", "--seed", "7"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
