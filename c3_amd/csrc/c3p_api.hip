@@ -1358,6 +1358,13 @@ static size_t grad_store_budget(DeviceWs* w, Slot slot) {
 // kernel with the transposed local prefixes kept in HBM, real segment scan, on-chip backward sweep (c3p_regrg.hip).
 // The forward half returns 1 when a Hamiltonian is not Hermitian (complex tables in that basis): the caller falls back.
 // ---------------------------------------------------------------------------
+// D = 7, 8, 9 in their own classes.  D = 6 (36 x 36) zero padded in the 49 class is an A/B switch (regr_grad_d6 = 1): measured
+// SLOWER than the complex mid-D general sweep -- 13.4 against 10.3 ms at B = 64, N = 500, 105 against 80 ms at B = 256, N = 1000
+// (profiles/r04/grad_lindblad_d6_*.json): (49 / 36)^3 = 2.5x padded work eats the factor of real arithmetic
+static bool lind_regr_grad_ok(int D, int Dm) {
+  if (c3p_regr_supported(D, Dm)) return true;
+  return Dm == D * D && D == 6 && c3p_opt_on(C3P_OPT_regr_grad_d6);
+}
 struct LindRegrBufs {  // device buffers of one forward pass (the library's workspace, or a caller-owned tape)
   double *tab_f, *tab_t;
   int *flag_f, *flag_t;
@@ -1481,7 +1488,7 @@ int lind_regr_backward(DeviceWs* w, const LindRegrBufs& bf, bool per_sample, con
 int run_vjp_lind_regr(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals, const cplx* clp,
                       double dt, int B, int K, int N, int D, int Dm, const double* fr_phase, const cplx* Ubar, double* grad,
                       hipStream_t st) {
-  if (!c3p_regr_supported(D, Dm) || K > 16 || K < 1) return 1;
+  if (!lind_regr_grad_ok(D, Dm) || K > 16 || K < 1) return 1;
   const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
   const long S = lind_regr_segments(B, N);
   const LindRegrSizes z = lind_regr_sizes(B, K, N, Dm, S, per_sample ? B : 1);
@@ -2414,6 +2421,33 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
       return 0;
     }
   }
+  // 49 x 49 .. 81 x 81 superoperators (D = 7, 8, 9; cfg4) and, zero padded in the 49 class, 36 x 36 (D = 6): on-chip backward sweep in
+  // the Hermitian basis, real arithmetic; the transposed local prefix of every slice (N D^4 doubles per sample) is kept in HBM:
+  // chunks of samples below the budget.  1 = a Hamiltonian is not Hermitian (the caller goes on to the complex sweeps).
+  auto try_regr = [&]() -> int {
+    if (record_start(w, st)) return -1;
+    long Bc = (long)(grad_store_budget(w, SL_OUT1) / ((size_t)N * Dm * Dm * sizeof(double) + 1));
+    if (c3p_opt(C3P_OPT_grad_chunk) > 0) Bc = c3p_opt(C3P_OPT_grad_chunk);
+    if (Bc < 1) Bc = 1;
+    int rc = 0;
+    for (long b0 = 0; b0 < B && rc == 0; b0 += Bc) {
+      const int nb = (int)(B - b0 < Bc ? B - b0 : Bc);
+      rc = run_vjp_lind_regr(w, p_h0 + b0 * h0_bstride, h0_bstride, p_hk + b0 * hks_bstride, hks_bstride, p_sig + b0 * K * N,
+                             (const cplx*)clp, dt, nb, K, N, D, Dm, phase_at(b0), p_ub + b0 * gsz, p_grad + b0 * K * N, st);
+      if (rc == 1 && b0 > 0) return fail("internal: the Hermitian-basis sweep declined a later chunk");
+    }
+    if (rc != 0) return rc;
+    g_last_kernel = C3P_KERNEL_MFMA;
+    if (record_stop(w, st)) return -1;
+    if (flags & C3P_HOST_PTRS) return sg.finish() ? -1 : 0;
+    return 0;
+  };
+  const bool regr_ok = lind_regr_grad_ok(D, Dm) && !(flags & C3P_FORCE_GENERIC) && !c3p_opt_on(C3P_OPT_tiled_grad) &&
+                       !c3p_opt_on(C3P_OPT_valu_grad) && !c3p_opt_on(C3P_OPT_no_hermitian_basis);
+  if (regr_ok && D == 6) {
+    const int rc = try_regr();
+    if (rc <= 0) return rc;
+  }
   if (Dm >= 13 && Dm <= 36 && !(flags & C3P_FORCE_GENERIC) && !c3p_opt_on(C3P_OPT_tiled_grad) && !c3p_opt_on(C3P_OPT_valu_grad)) {
     // 16 x 16 .. 36 x 36 superoperators (D = 4, 5, 6): the same sweep on the mid-D matrix-core kernels
     if (record_start(w, st)) return -1;
@@ -2484,27 +2518,9 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
     if (flags & C3P_HOST_PTRS) return sg.finish();
     return 0;
   }
-  if (c3p_regr_supported(D, Dm) && !(flags & C3P_FORCE_GENERIC) && !c3p_opt_on(C3P_OPT_tiled_grad) && !c3p_opt_on(C3P_OPT_no_hermitian_basis)) {
-    // 49 x 49 .. 81 x 81 superoperators (D = 7, 8, 9; cfg4): on-chip backward sweep in the Hermitian basis, real arithmetic; the
-    // transposed local prefix of every slice (N D^4 doubles per sample) is kept in HBM: chunks of samples below 24 GB
-    if (record_start(w, st)) return -1;
-    long Bc = (long)(grad_store_budget(w, SL_OUT1) / ((size_t)N * Dm * Dm * sizeof(double) + 1));
-    if (c3p_opt(C3P_OPT_grad_chunk) > 0) Bc = c3p_opt(C3P_OPT_grad_chunk);
-    if (Bc < 1) Bc = 1;
-    int rc = 0;
-    for (long b0 = 0; b0 < B && rc == 0; b0 += Bc) {
-      const int nb = (int)(B - b0 < Bc ? B - b0 : Bc);
-      rc = run_vjp_lind_regr(w, p_h0 + b0 * h0_bstride, h0_bstride, p_hk + b0 * hks_bstride, hks_bstride, p_sig + b0 * K * N,
-                             (const cplx*)clp, dt, nb, K, N, D, Dm, phase_at(b0), p_ub + b0 * gsz, p_grad + b0 * K * N, st);
-      if (rc == 1 && b0 > 0) return fail("internal: the Hermitian-basis sweep declined a later chunk");
-    }
-    if (rc < 0) return -1;
-    if (rc == 0) {
-      g_last_kernel = C3P_KERNEL_MFMA;
-      if (record_stop(w, st)) return -1;
-      if (flags & C3P_HOST_PTRS) return sg.finish();
-      return 0;
-    }
+  if (regr_ok && D != 6) {
+    const int rc = try_regr();
+    if (rc <= 0) return rc;
   }
   g_last_kernel = C3P_KERNEL_MFMA;
   if (record_start(w, st)) return -1;

@@ -29,6 +29,7 @@
   X(grad_slots)         /* resident wave slots assumed by the backward sweeps' segment rule */                         \
   X(grad_chunk)         /* samples per chunk of the general-generator sweeps */                                        \
   X(regr_grad_degree)   /* Hermitian-basis Lindblad sweep: force the Taylor degree (8, 12, 16, 20) */                  \
+  X(regr_grad_d6)       /* Lindblad gradient at D = 6 zero padded on the Hermitian-basis sweep (A/B: slower than mid-D) */     \
   X(tiled_grad)         /* tiled backward sweep wherever it applies */                                                 \
   X(valu_grad)          /* VALU backward sweeps instead of the matrix-core ones */                                     \
   X(tiled_graph)        /* tiled sweep: replay slices as hipGraphs */                                                  \
