@@ -429,6 +429,12 @@ def main():
             t_e = time.perf_counter()
             out["e2e"] = e2e_rates(wl, fr, propagation, torch, dev)
             out["e2e"]["wall_s"] = time.perf_counter() - t_e
+        if world == 1 and not args.no_e2e and bp is not None:
+            # the step after the path in every optimiser: goal + gradient of the whole batch -- an extra key, never `value`
+            try:
+                out["optimiser_evaluation"] = evaluation_rates(args.config, wl, fr, propagation, torch, dev, elapsed / args.steps * 1e3)
+            except Exception as e:  # noqa: BLE001  (a side measurement must not cost the headline line)
+                out["optimiser_evaluation"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import c3_oracle  # the CPU restatement, timed beside the GPU path (checker only)
 
@@ -437,6 +443,54 @@ def main():
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
+
+
+def evaluation_rates(cfg, wl, fr, propagation, torch, dev, forward_ms, reps=5):
+    """One optimiser evaluation of this batch on resident control samples: goal (infidelity against an identity gate on the
+    qubit subspace) AND its gradient w.r.t. every control sample.  Closed systems: c3p_pwc_unitary_goal_vjp, one pass over the
+    chains (optimalcontrol.py:200-228 under optimizer.py:206-216); open systems (D = 7, 8, 9): taped forward pass + vjp from the
+    tape.  ms per evaluation, median of `reps`."""
+    import numpy as np
+
+    from c3_amd import fidelities, workloads
+
+    dims = list(workloads.CONFIGS[cfg]["dims"])
+    index = list(range(len(dims)))
+    ideal = torch.eye(2 ** len(dims), dtype=torch.complex128, device=dev)
+    t = lambda a: torch.as_tensor(a, device=dev)
+    h0, hks, sig, ph = t(wl.h0), t(wl.hks), t(wl.signals), t(fr)
+    if wl.lindblad:
+        if not propagation.lindblad_tape_supported(wl.B, wl.K, wl.N, wl.D):
+            return {"skipped": "no taped open-system evaluation for this shape"}
+        col = t(wl.col_ops)
+
+        def run():
+            r = propagation.propagate_batch_lindblad_taped(h0, hks, sig, wl.dt, col, fr_phase=ph)
+            S_bar, goal = fidelities.lindbladian_unitary_infid_cotangent(ideal, r["U"], index, dims)
+            return goal, r["tape"].vjp(S_bar)
+
+        how = "c3p_pwc_lindblad_taped + lindbladian_unitary_infid cotangent + c3p_pwc_lindblad_vjp_taped"
+    else:
+        if not propagation.goal_vjp_is_fused(wl.B, wl.D):
+            return {"skipped": "no fused goal entry for this shape"}
+
+        def run():
+            r = propagation.propagate_batch_goal_vjp(h0, hks, sig, wl.dt, ideal, index, dims, fr_phase=ph, want_U=False)
+            return r["goal"], r["grad_signals"]
+
+        how = "c3p_pwc_unitary_goal_vjp (unitary_infid)"
+    run()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        goal, grad = run()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    ms = 1e3 * float(np.median(ts))
+    return {"ms_per_evaluation": ms, "evaluations_per_s": 1e3 / ms, "gradients_per_s": 1e3 * wl.B / ms, "x_forward": ms / forward_ms, "how": how,
+            "mean_goal": float(goal.mean()), "grad_abs_max": float(grad.abs().max()),
+            "note": "goal + d goal / d every control sample of the batch, inputs resident; tests/perf/bench_goal_run.py times the whole loop body with signal synthesis"}
 
 
 def e2e_rates(wl, fr, propagation, torch, dev, reps=3):
