@@ -41,6 +41,14 @@
 #define C3P_MIDD_HAS(p) 1
 #endif
 
+// 32 + 4 row split of the 48-row real class with 9 column blocks (D = 33..36, cfg5) in the real-Hamiltonian instances: the
+// forward chain kernel (translation unit 2) and the real backward sweep (unit 3), whose products all go through mm_real.
+// -DC3P_MDR_NO_ROWSPLIT builds the padded deal for A/B (tools/ab_build.sh).
+#if !defined(C3P_MDR_NO_ROWSPLIT)
+#define C3P_MDR_ROWSPLIT 1
+#else
+#define C3P_MDR_ROWSPLIT 0
+#endif
 extern __shared__ __attribute__((aligned(16))) double c3p_md_lds[];
 
 namespace {
@@ -95,10 +103,21 @@ struct Sched {
   // ones deal out as 128 / 128 / 96 / 80 matrix-pipe cycles per K-step; with the last NSPLIT = 2 big units dealt as four
   // small ones each it is 112 / 112 / 112 / 96.  (Splitting wherever it lowers the maximum was measured: +2 - 3 % here,
   // 20 - 27 % SLOWER at D <= 24, where small units mean four broadcast B reads and four instructions instead of one.)
-  static constexpr int NSPLIT = (NIG == 3 && NJ == 9) ? 2 : 0;
+  // Round 4, the same class in the real forward instance (RS): its third row group holds 4 of 16 rows (36 = 32 + 4), so the two
+  // 16 x 16 units there are dealt as "wide" units -- ONE v_mfma_f64_4x4x4_4b per K-step (16 cycles instead of 64) whose four
+  // blocks are the four COLUMN blocks of the unit and whose A fragment is rows 32..35 broadcast to all blocks (one more,
+  // conflict-free, LDS read); the result lands in accumulator component 0 of the 16 x 16 register layout, components 1..3 are
+  // the zero padding rows 36..47.  Deal: one full unit per wave, the wide units to waves 2 / 3, the 16 x 4 units of column
+  // block 8 to waves 0 / 1 / 2: 80 / 80 / 96 / 80 matrix-pipe cycles per K-step instead of 112 / 112 / 112 / 96.  Upper bound
+  // measured first with a timing-only build (161.5 -> 141.7 ms per 1024-sample cfg5 batch).
+  static constexpr bool RS = C3P_MDR_ROWSPLIT != 0 && NIG == 3 && NJ == 9;
+  static constexpr int NSPLIT = (!RS && NIG == 3 && NJ == 9) ? 2 : 0;
   static constexpr int NBIG = NIG * NB16 - NSPLIT;
   static constexpr int NSMALL = NIG * JR + 4 * NSPLIT;
-  static constexpr int nbig(int w) { return w < NBIG ? (NBIG - w + NW - 1) / NW : 0; }
+  static constexpr int nbig(int w) {
+    if (RS) return w < 2 ? 1 : 2;
+    return w < NBIG ? (NBIG - w + NW - 1) / NW : 0;
+  }
   // small unit us -> (column block J, row group Ig): first the leftover column blocks, then the split big units
   static constexpr int small_j(int us) {
     if (us < NIG * JR) return 4 * NB16 + us / NIG;
@@ -110,6 +129,7 @@ struct Sched {
     return (NBIG + (us - NIG * JR) / 4) % NIG;
   }
   static constexpr int small_owner(int us) {
+    if (RS) return us;  // (row group us of column block 8)
     int load[NW] = {4 * nbig(0), 4 * nbig(1), 4 * nbig(2), 4 * nbig(3)};
     int owner = 0;
     for (int u = 0; u <= us; ++u) {
@@ -146,8 +166,21 @@ struct WaveTiles {
   static constexpr int NSW = S::nsmall(WV);
   static constexpr int NE = 4 * NBW + NSW;  // doubles per matrix held by each lane of this wave
   // big unit i: ub = WV + 4 i -> (Jg, Ig)
-  static constexpr int bIg(int i) { return (WV + NW * i) % NIG; }
-  static constexpr int bJg(int i) { return (WV + NW * i) / NIG; }
+  // (RS deal: wave 0 (0,0); wave 1 (1,0); wave 2 (0,1) + wide (2,0); wave 3 (1,1) + wide (2,1))
+  static constexpr int bIg(int i) {
+    if (S::RS) return WV < 2 ? WV : (i == 0 ? WV - 2 : 2);
+    return (WV + NW * i) % NIG;
+  }
+  static constexpr int bJg(int i) {
+    if (S::RS) return WV < 2 ? 0 : (i == 0 ? 1 : WV - 2);
+    return (WV + NW * i) / NIG;
+  }
+  static constexpr bool is_wide(int i) { return S::RS && bIg(i) == NIG - 1; }
+  static constexpr bool has_wide() {
+    for (int i = 0; i < NBW; ++i)
+      if (is_wide(i)) return true;
+    return false;
+  }
   // small unit i: us -> (J, Ig)
   static constexpr int sIg(int i) { return S::small_ig(S::small_us(WV, i)); }
   static constexpr int sJ(int i) { return S::small_j(S::small_us(WV, i)); }
@@ -351,6 +384,8 @@ __device__ __forceinline__ void mm_real(const MidCommon& cm,
   constexpr int PF = NIGR >= 3 ? 2 : (NJ < 3 ? NJ : 3);  // the 48-row classes are register-bound: one stage less
   constexpr int NS = PF + 1;
   double a[NS][NIGR], x[NS][NIGR], g[NS][NB16], h[NS][NB16], sb[NS][JR], ub[NS][JR];
+  double aw[NS], xw[NS];  // wide units: rows 32..35 of the left operand(s), the same fragment in all four blocks
+  const double* qw = c3p_md_lds + (cm.c * WI + cm.r);  // plain layout, block 0 of the last row group
   // one base register per lane-offset kind; the image (a compile-time index) goes into the instruction offset
   constexpr int IMGR = 16 * NIGR * WI;
   const double* qa = c3p_md_lds + cm.aoffR;  // plain layout: 16 rows x 4 columns of the left operand
@@ -371,6 +406,10 @@ __device__ __forceinline__ void mm_real(const MidCommon& cm,
         x[st_][Ig] = (TWOA && T::uses_ig(Ig)) ? qa[IA2 * IMGR + Ig * 16 * WI + 4 * (K)] : 0.0;                   \
       }                                                                                                          \
     }                                                                                                            \
+    if constexpr (T::has_wide()) {                                                                               \
+      aw[st_] = qw[IA1 * IMGR + (NIGR - 1) * 16 * WI + 4 * (K)];                                                 \
+      if constexpr (TWOA) xw[st_] = qw[IA2 * IMGR + (NIGR - 1) * 16 * WI + 4 * (K)];                             \
+    }                                                                                                            \
     _Pragma("unroll") for (int Jg = 0; Jg < S::NB16; ++Jg) {                                                     \
       const double* q_ = Jg == 0 ? qg0 : qg1;                                                                    \
       g[st_][Jg] = T::uses_jg(Jg) ? q_[IB1 * IMGR + (K) * 4 * WI + 16 * Jg] : 0.0;                               \
@@ -386,6 +425,12 @@ __device__ __forceinline__ void mm_real(const MidCommon& cm,
   {                                                                                                              \
     constexpr int st_ = (K) % NS;                                                                                \
     _Pragma("unroll") for (int i = 0; i < T::NBW; ++i) {                                                         \
+      if (T::is_wide(i)) {                                                                                       \
+        acc1.big[i][0] = md_mfma4(aw[st_], g[st_][T::bJg(i)], acc1.big[i][0]);                                   \
+        if constexpr (TWOB) acc2.big[i][0] = md_mfma4(aw[st_], h[st_][T::bJg(i)], acc2.big[i][0]);               \
+        if constexpr (TWOA) acc2.big[i][0] = md_mfma4(xw[st_], g[st_][T::bJg(i)], acc2.big[i][0]);               \
+        continue;                                                                                                \
+      }                                                                                                          \
       acc1.big[i] = md_mfma16(a[st_][T::bIg(i)], g[st_][T::bJg(i)], acc1.big[i]);                                \
       if constexpr (TWOB) acc2.big[i] = md_mfma16(a[st_][T::bIg(i)], h[st_][T::bJg(i)], acc2.big[i]);            \
       if constexpr (TWOA) acc2.big[i] = md_mfma16(x[st_][T::bIg(i)], g[st_][T::bJg(i)], acc2.big[i]);            \

@@ -29,6 +29,12 @@ def tile_utilisation(Dm, kernel):
         p = 4 * ((Dm + 3) // 4)
         kk = 1.0 if Dm % 4 == 1 else Dm / p
         return (Dm / p) ** 2 * kk, f"small-D kernel: ({Dm}/{p})^2 rows x columns" + ("" if Dm % 4 == 1 else f" x {Dm}/{p} in K")
+    if 33 <= Dm <= 36 and "midd_chain_kernel" in kernel and "true" in kernel.split("midd_chain_kernel")[-1][:40]:
+        # real instance with the 32 + 4 row split (round 4): four full 16 x 16 units, two wide units (rows 32..35 exactly), three
+        # 16 x 4 units of column block 8 -- 4 x 64 + 2 x 16 + 3 x 16 matrix-pipe cycles per K-step
+        rv = (Dm - 32) / 4.0
+        useful = (Dm / 36.0) * (256.0 + 32.0 * rv + 32.0 * rv + 16.0 * ((Dm - 32) / 16.0) * rv)
+        return useful / 336.0, f"mid-D real instance, 32 + 4 row split: exact rows in the wide units, column block 8 and its last unit carry {Dm - 32} of 4 / 16"
     if Dm <= 40:
         rows = 16 * ((Dm + 15) // 16)
         cols = 4 * ((Dm + 3) // 4)
