@@ -80,7 +80,7 @@ int fail(const char* fmt, ...) {
   } while (0)
 
 // Per-device workspace slots, grown lazily, freed by c3p_shutdown().
-enum Slot { SL_SEG_A = 0, SL_SEG_B, SL_SCRATCH, SL_CLP, SL_TABLES, SL_COUNTERS, SL_COUNTERS2, SL_IN0, SL_IN1, SL_IN2, SL_IN3, SL_IN4, SL_IN5, SL_OUT0, SL_OUT1, SL_OUT2, SL_OUT3, SL_COUNT };
+enum Slot { SL_SEG_A = 0, SL_SEG_B, SL_SCRATCH, SL_CLP, SL_TABLES, SL_COUNTERS, SL_COUNTERS2, SL_IN0, SL_IN1, SL_IN2, SL_IN3, SL_IN4, SL_IN5, SL_OUT0, SL_OUT1, SL_OUT2, SL_OUT3, SL_SEG_F, SL_COUNT };
 
 struct DeviceWs {
   std::mutex mu;  // one lock per device: calls on different GPUs of one process do not serialise
@@ -694,6 +694,15 @@ int run_vjp_smalld(DeviceWs* w, GradArgs& G, hipStream_t st) {
   void *sv, *mv;
   if (ws_get(w, SL_SEG_A, segb, &sv)) return -1;
   if (ws_get(w, SL_SEG_B, segb, &mv)) return -1;
+  // The backward sweep runs one wave per SIMD (S is chosen for its 4096 chain slots), the forward chain kernel two: the
+  // segment products are formed on 2 S segments (twice the waves: 0.24 -> 0.15 ms at cfg2) and multiplied in pairs by one
+  // launch of the chain kernel's supplied-matrix mode (grad_fwd_seg2 = 0: one pass on S segments)
+  int Sf = S;
+  void* fv = sv;
+  if (c3p_opt(C3P_OPT_grad_fwd_seg2) != 0 && (long)B * S <= 4096 && 2L * S <= N / 8) {
+    Sf = 2 * S;
+    if (ws_get(w, SL_SEG_F, 2 * segb, &fv)) return -1;
+  }
   SmallArgs a = {};
   a.tables = p.tables;
   a.tab_per_sample = per_sample ? 1 : 0;
@@ -702,11 +711,25 @@ int run_vjp_smalld(DeviceWs* w, GradArgs& G, hipStream_t st) {
   a.K = K;
   a.N = N;
   a.Dm = D;
+  a.S = Sf;
+  a.Lmax = (N + Sf - 1) / Sf;
+  a.mode = C3P_MODE_UNITARY;
+  a.seg_out = (cplx*)fv;
+  LAUNCH_TRY(c3p_launch_smalld_chain(a, st));
+  if (Sf != S) {
+    SmallArgs c = {};
+    c.mode = C3P_MODE_GIVEN;
+    c.mats = (const cplx*)fv;
+    c.B = B * S;
+    c.N = 2;
+    c.Dm = D;
+    c.S = 1;
+    c.Lmax = 2;
+    c.seg_out = (cplx*)sv;
+    LAUNCH_TRY(c3p_launch_smalld_chain(c, st));
+  }
   a.S = S;
   a.Lmax = (N + S - 1) / S;
-  a.mode = C3P_MODE_UNITARY;
-  a.seg_out = (cplx*)sv;
-  LAUNCH_TRY(c3p_launch_smalld_chain(a, st));
   G.S = S;
   G.seg = (cplx*)sv;
   G.Mb = (cplx*)mv;

@@ -27,6 +27,7 @@
   X(no_real_grad)       /* real Hamiltonians on the general backward sweeps */                                         \
   X(grad_target)        /* chains per launch of the VALU backward sweep */                                             \
   X(grad_slots)         /* resident wave slots assumed by the backward sweeps' segment rule */                         \
+  X(grad_fwd_seg2)      /* small-D gradients: 0 = forward segment products on the backward sweep's S segments, not 2 S */      \
   X(grad_chunk)         /* samples per chunk of the general-generator sweeps */                                        \
   X(regr_grad_degree)   /* Hermitian-basis Lindblad sweep: force the Taylor degree (8, 12, 16, 20) */                  \
   X(regr_grad_d6)       /* Lindblad gradient at D = 6 zero padded on the Hermitian-basis sweep (A/B: slower than mid-D) */     \
