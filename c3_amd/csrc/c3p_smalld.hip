@@ -105,20 +105,28 @@ __device__ __forceinline__ void mm_img(const double* img, int roff, unsigned neg
                                        const double (&zb)[SD<D>::NBI][SD<D>::NJ],
                                        double (&acc)[SD<D>::NBI][SD<D>::NJ]) {
   using C = SD<D>;
+#ifdef C3P_SD_ABSKIP
+  // TIMING-ONLY builds (wrong results; tools/ab_complex_border.sh): what a core + border form of the complex products could
+  // save at most.  1: no matrix instructions for the last column block (D = 9: the block that holds column 8 alone);
+  // 2: none for the last row block and the last K-step either (the 8 x 8 core alone, borders for free)
+  constexpr int SKJ = (D % 4 == 1 && D > 4) ? 1 : 0, SKI = (C3P_SD_ABSKIP >= 2 && D % 4 == 1 && D > 4) ? 1 : 0;
+#else
+  constexpr int SKJ = 0, SKI = 0;
+#endif
   // software pipelined: the A fragments of step K+1 are in flight while step K's MFMAs issue
   double ra[2][C::NBI];
 #pragma unroll
-  for (int I = 0; I < C::NBI; ++I) ra[0][I] = flip_sign(lds_ld(img + roff + I * 4 * C::W), negmask);
+  for (int I = 0; I < C::NBI - SKI; ++I) ra[0][I] = flip_sign(lds_ld(img + roff + I * 4 * C::W), negmask);
 #pragma unroll
-  for (int K = 0; K < C::NBI; ++K) {
-    if (K + 1 < C::NBI) {
+  for (int K = 0; K < C::NBI - SKI; ++K) {
+    if (K + 1 < C::NBI - SKI) {
 #pragma unroll
-      for (int I = 0; I < C::NBI; ++I) ra[(K + 1) & 1][I] = flip_sign(lds_ld(img + roff + I * 4 * C::W + (K + 1) * 2), negmask);
+      for (int I = 0; I < C::NBI - SKI; ++I) ra[(K + 1) & 1][I] = flip_sign(lds_ld(img + roff + I * 4 * C::W + (K + 1) * 2), negmask);
     }
 #pragma unroll
-    for (int I = 0; I < C::NBI; ++I)
+    for (int I = 0; I < C::NBI - SKI; ++I)
 #pragma unroll
-      for (int J = 0; J < C::NJ; ++J) acc[I][J] = mfma4(ra[K & 1][I], zb[K][J], acc[I][J]);
+      for (int J = 0; J < C::NJ - SKJ; ++J) acc[I][J] = mfma4(ra[K & 1][I], zb[K][J], acc[I][J]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
