@@ -2142,6 +2142,26 @@ int c3p_ode_solve(const void* h0, const void* hks, const double* signals, const 
   a.n_steps = N;
   a.u_stride = 1;
   a.states = (cplx*)d_states;
+  if (K > 4 && D <= 16 && N >= 2 && step == C3P_STEP_SCHRODINGER && !c3p_opt_on(C3P_OPT_ode_wg)) {
+    // more than four control lines, vector states: the lane-row kernels hold the rows of four operators in registers; H is
+    // assembled for every sample index first (B N D^2 numbers) and the kernel interpolates it between consecutive samples --
+    // the same linear interpolation, taken after the sum instead of before it.  Beyond 8 GB, and for rho-valued states (no
+    // faster there), the workgroup kernel takes the call.
+    const size_t hb = (size_t)B * N * D * D * cs;
+    if (hb <= ((size_t)8 << 30)) {
+      void* hv;
+      if (ws_get(w, SL_SEG_F, hb, &hv)) return -1;
+      LAUNCH_TRY(c3p_launch_ode_assemble_hs(a, (cplx*)hv, st));
+      a.hs = (const cplx*)hv;
+      a.hs_bstride = (long)N * D * D;
+      a.hs_lerp = 1;
+      if (!c3p_ode_row_supported(a)) {  // (stage slots beyond the LDS: the workgroup kernel assembles H itself)
+        a.hs = nullptr;
+        a.hs_bstride = 0;
+        a.hs_lerp = 0;
+      }
+    }
+  }
   if (c3p_ode_row_supported(a)) {
     // lane-row kernels (c3p_ode_row.hip): one sample per 16-lane row, state and operator rows in registers
     void* aux = nullptr;

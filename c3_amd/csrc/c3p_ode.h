@@ -22,6 +22,7 @@ struct OdeArgs {
   int u_stride;         // stage position in signal-sample units: u = (n + node) * u_stride
   const cplx* hs;       // optional per-sample-index Hamiltonians [B?,N,D,D] (then h0/hks unused)
   long hs_bstride;
+  int hs_lerp;          // hs: 0 = the sample nearest to the stage position (branch B), 1 = linear interpolation of two samples
   int reset_each_step;  // state <- init after every step (per-step propagators)
   int transpose_out;    // store states transposed (gen_du_rk4 stacks propagated vectors as rows)
   cplx* states;
@@ -51,6 +52,7 @@ hipError_t c3p_launch_ode(const OdeArgs& A, bool global_scratch, hipStream_t st)
 bool c3p_ode_row_supported(const OdeArgs& A);
 size_t c3p_ode_row_aux_bytes(int D, int C);
 hipError_t c3p_launch_ode_row(const OdeArgs& A, void* aux, hipStream_t st);
+hipError_t c3p_launch_ode_assemble_hs(const OdeArgs& A, cplx* out, hipStream_t st);  // out [B,N,D,D] = h0 + sum_k c_k hk
 
 // Lane-row vector-state kernel for 17 <= D <= 48 (c3p_ode_rowq.hip): operators in LDS, H(t) advanced along the linear
 // pieces of the control amplitudes

@@ -42,6 +42,14 @@ __host__ __device__ constexpr OdeTableau tab_of(int solver) {
   return t[solver];
 }
 
+// first stage after s whose node differs from its predecessor's (H is assembled again there), -1 if none
+__host__ __device__ constexpr int next_asm_stage(int solver, int s) {
+  const OdeTableau t = tab_of(solver);
+  for (int k = s + 1; k < t.stages; ++k)
+    if (t.node[k] != t.node[k - 1]) return k;
+  return -1;
+}
+
 typedef const double __attribute__((address_space(4)))* cdouble_ptr;  // constant address space: uniform loads become s_load
 
 template <int I, int N, class F>
@@ -64,8 +72,13 @@ __device__ __forceinline__ int chunk_base(int n0, int us, int N) {
 // ---------------------------------------------------------------------------------------------------------------
 // vector state: Schroedinger psi (M = 1) or one column of a propagator (M = D virtual samples per sample)
 // ---------------------------------------------------------------------------------------------------------------
-template <int DP, int KT, int SOLVER, bool REALH>
+// HS: H(t) is read from per-sample-index Hamiltonians hs [B?, N, D, D] instead of being assembled from h0 / hks -- the nearest
+// sample (branch B of get_hs_of_t_ts, propagation.py:164-204, as the workgroup kernel of c3p_ode.hip takes it) or, hs_lerp, the
+// linear interpolation of two consecutive samples (= branch A on Hamiltonians the library assembled itself: more than four
+// control lines).  Lane i reads row i, D contiguous complex numbers per stage node.
+template <int DP, int KT, int SOLVER, bool REALH, bool HS = false>
 __global__ void __launch_bounds__(64) ode_vec_kernel(OdeArgs A) {
+  static_assert(!HS || !REALH, "supplied Hamiltonians run on the complex instance");
   using P = OdeDpp<DP>;
   constexpr int S = tab_of(SOLVER).stages;
   __shared__ double sig[4 * KT * 16];
@@ -87,21 +100,22 @@ __global__ void __launch_bounds__(64) ode_vec_kernel(OdeArgs A) {
 #pragma unroll
   for (int j = 0; j < DP; ++j) {
     cplx z = cmake(0, 0);
-    if (row && j < D) z = A.h0[i * D + j];
+    if (!HS && row && j < D) z = A.h0[i * D + j];
     h0r[j] = z.x;
     if constexpr (!REALH) h0i[j] = z.y;
     im0 = im0 && (z.y == 0.0);
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
       cplx zk = cmake(0, 0);
-      if (row && j < D && k < K) zk = A.hks[((long)k * D + i) * D + j];
+      if (!HS && row && j < D && k < K) zk = A.hks[((long)k * D + i) * D + j];
       hkr[k][j] = zk.x;
       if constexpr (!REALH) hki[k][j] = zk.y;
       im0 = im0 && (zk.y == 0.0);
     }
   }
   // real operators take the REALH instance, everything else the complex one (both are launched; wave-uniform exit)
-  if ((__all(im0) != 0) != REALH) return;
+  if constexpr (!HS)
+    if ((__all(im0) != 0) != REALH) return;
 
   const cplx* init = A.init + (A.seg_traj ? (long)b * SG + seg : (long)b) * A.init_bstride;
   double pr = 0.0, pi = 0.0;
@@ -113,9 +127,10 @@ __global__ void __launch_bounds__(64) ode_vec_kernel(OdeArgs A) {
   const double ir = pr, ii = pi;
   const double dt = A.dt;
   const double* sg = A.signals + (long)b * K * N;
+  const cplx* hrow = HS ? A.hs + (long)b * A.hs_bstride + (long)(row ? i : 0) * D : nullptr;  // row i of sample index 0
   const int SPC = chunk_steps(us);
   double pre[KT];
-  {
+  if constexpr (!HS) {
     const int base = chunk_base(n_begin, us, N);
     int idx = base + i;
     if (idx > N - 1) idx = N - 1;
@@ -133,18 +148,53 @@ __global__ void __launch_bounds__(64) ode_vec_kernel(OdeArgs A) {
   for (int j0 = 0; j0 < nrel; j0 += SPC) {
     const int n0 = n_begin + j0;
     const int base = chunk_base(n0, us, N);
+    if constexpr (!HS) {
 #pragma unroll
-    for (int k = 0; k < KT; ++k) sig[(r * KT + k) * 16 + i] = pre[k];
-    {
+      for (int k = 0; k < KT; ++k) sig[(r * KT + k) * 16 + i] = pre[k];
       const int nb = chunk_base(n0 + SPC, us, N);
       int idx = nb + i;
       if (idx > N - 1) idx = N - 1;
 #pragma unroll
       for (int k = 0; k < KT; ++k) pre[k] = (k < K) ? sg[(long)k * N + idx] : 0.0;
     }
-    auto assemble = [&](double theta, int n) {
+    auto assemble = [&](double theta, int n, double theta_next, int n_next) {
       // linear interpolation of the control amplitudes, linear extrapolation past the last sample (tf_utils.py:557-559)
       const double u = ((double)n + theta) * (double)us;
+      if constexpr (HS) {
+        // (requesting the rows one stage ahead into registers that live across the stage loop was measured: 1.7x slower)
+        // (the two modes are separate straight-line loops: a per-element choice between them serialises the loads, 1.4 - 2.5x)
+        const long hsz = (long)D * D;
+        if (A.hs_lerp) {
+          int lo = (int)floor(u);
+          if (lo > N - 2) lo = N - 2;
+          if (lo < 0) lo = 0;
+          const double f = u - (double)lo;
+          const cplx* p0 = hrow + (long)lo * hsz;
+          const cplx* p1 = p0 + (N > 1 ? hsz : 0);
+#pragma unroll
+          for (int j = 0; j < DP; ++j) {
+            cplx z0 = cmake(0, 0), z1 = cmake(0, 0);
+            if (row && j < D) z0 = p0[j], z1 = p1[j];
+            Hr[j] = fma(f, z1.x - z0.x, z0.x);
+            if constexpr (!REALH) Hi[j] = fma(f, z1.y - z0.y, z0.y);
+          }
+        } else {
+          int iu = (int)(u + 0.5);  // stage positions are integer sample indices there
+          if (iu > N - 1) iu = N - 1;
+          if (iu < 0) iu = 0;
+          const cplx* p0 = hrow + (long)iu * hsz;
+#pragma unroll
+          for (int j = 0; j < DP; ++j) {
+            cplx z0 = cmake(0, 0);
+            if (row && j < D) z0 = p0[j];
+            Hr[j] = z0.x;
+            if constexpr (!REALH) Hi[j] = z0.y;
+          }
+        }
+        (void)theta_next;
+        (void)n_next;
+        return;
+      }
       int lo = (int)floor(u);
       if (lo > N - 2) lo = N - 2;
       if (lo < 0) lo = 0;
@@ -179,10 +229,14 @@ __global__ void __launch_bounds__(64) ode_vec_kernel(OdeArgs A) {
       double kr[S], ki[S];
       static_for<0, S>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
+        // (the stage position after this one that assembles H again: a later stage of this step, or -- stage 0 is carried --
+        // the first such stage of the next step; supplied Hamiltonians are requested one assemble ahead)
+        constexpr int s2 = next_asm_stage(SOLVER, s), s3 = s2 >= 0 ? s2 : next_asm_stage(SOLVER, 0);
+        constexpr double th2 = tab_of(SOLVER).node[s3 >= 0 ? s3 : 0];
         if constexpr (s == 0) {
-          if (jr == 0) assemble(tab_of(SOLVER).node[0], n);  // later steps: carried over from the previous step's last node
+          if (jr == 0) assemble(tab_of(SOLVER).node[0], n, th2, s2 >= 0 ? n : n + 1);  // later steps: carried over from the previous step's last node
         } else if constexpr (tab_of(SOLVER).node[s] != tab_of(SOLVER).node[s - 1]) {
-          assemble(tab_of(SOLVER).node[s], n);
+          assemble(tab_of(SOLVER).node[s], n, th2, s2 >= 0 ? n : n + 1);
         }
         double yr = pr, yi = pi;
         static_for<0, s>([&](auto jc) {
@@ -534,6 +588,25 @@ __global__ void ode_identity_kernel(cplx* out, int D) {
   for (int e = threadIdx.x; e < D * D; e += blockDim.x) out[e] = cmake((e / D == e % D) ? 1.0 : 0.0, 0.0);
 }
 
+// Hs[b][n] = h0 + sum_k c_k[b][n] hk for every sample index (more than four control lines on the lane-row kernels: the rows
+// of four operators fit the registers, the assembled Hamiltonians are read per stage node instead, hs_lerp)
+__global__ void __launch_bounds__(256) ode_assemble_hs_kernel(const cplx* h0, const cplx* hks, const double* signals, int K, int N, int D,
+                                                              cplx* out) {
+  const int n = (int)(blockIdx.x % (unsigned)N), b = (int)(blockIdx.x / (unsigned)N);
+  const double* sg = signals + (long)b * K * N + n;
+  cplx* o = out + ((long)b * N + n) * D * D;
+  for (int e = threadIdx.x; e < D * D; e += blockDim.x) {
+    cplx h = h0[e];
+    for (int k = 0; k < K; ++k) {
+      const double c = sg[(long)k * N];
+      const cplx x = hks[(long)k * D * D + e];
+      h.x = fma(c, x.x, h.x);
+      h.y = fma(c, x.y, h.y);
+    }
+    o[e] = h;
+  }
+}
+
 int pad_dim(int D) {
   const int dps[] = {2, 3, 4, 6, 9, 12, 16};
   for (int d : dps)
@@ -558,6 +631,15 @@ hipError_t launch_vec2(const OdeArgs& A, dim3 grid, hipStream_t st) {
 }
 template <int DP>
 hipError_t launch_vec1(const OdeArgs& A, dim3 grid, hipStream_t st) {
+  if (A.hs) {  // supplied Hamiltonians: one (complex) instance per solver
+    switch (A.solver) {
+      case 0: hipLaunchKernelGGL((ode_vec_kernel<DP, 2, 0, false, true>), grid, dim3(64), 0, st, A); break;
+      case 1: hipLaunchKernelGGL((ode_vec_kernel<DP, 2, 1, false, true>), grid, dim3(64), 0, st, A); break;
+      case 2: hipLaunchKernelGGL((ode_vec_kernel<DP, 2, 2, false, true>), grid, dim3(64), 0, st, A); break;
+      default: hipLaunchKernelGGL((ode_vec_kernel<DP, 2, 3, false, true>), grid, dim3(64), 0, st, A); break;
+    }
+    return hipGetLastError();
+  }
   return A.K <= 2 ? launch_vec2<DP, 2>(A, grid, st) : launch_vec2<DP, 4>(A, grid, st);
 }
 
@@ -588,13 +670,20 @@ hipError_t launch_mat1(const OdeArgs& A, const OdeRowAux& X, dim3 grid, hipStrea
 
 bool c3p_ode_row_supported(const OdeArgs& A) {
   if (c3p_opt_on(C3P_OPT_ode_wg)) return false;  // A/B switch: the workgroup-per-sample kernel of c3p_ode.hip
-  if (A.D > 16 || A.K > 4 || A.hs || A.N < 2) return false;
+  if (A.D > 16 || (A.K > 4 && !A.hs) || A.N < 2) return false;  // (supplied Hamiltonians: no control lines in the kernel)
   if (A.u_stride != 1 && A.u_stride != 2) return false;
   if (A.step == C3P_STEP_SCHRODINGER_ID || A.step == C3P_STEP_PROPAGATOR_ID) return true;
-  // rho-valued steps
-  if (A.reset_each_step || A.transpose_out) return false;
+  // rho-valued steps (supplied Hamiltonians were measured there: the row reads per stage make the lane-row kernel as slow as
+  // the workgroup kernel, 8.6 against 8.6 ms at D = 9, B = 256 -- not instantiated)
+  if (A.hs || A.reset_each_step || A.transpose_out) return false;
   const int DP = pad_dim(A.D);
   return mat_lds(A.D, DP, A.K <= 2 ? 2 : 4, A.solver, A.C).bytes <= (size_t)(150 * 1024);
+}
+
+hipError_t c3p_launch_ode_assemble_hs(const OdeArgs& A, cplx* out, hipStream_t st) {
+  hipLaunchKernelGGL(ode_assemble_hs_kernel, dim3((unsigned)((long)A.N * A.B)), dim3(A.D * A.D >= 256 ? 256 : 64), 0, st, A.h0, A.hks,
+                     A.signals, A.K, A.N, A.D, out);
+  return hipGetLastError();
 }
 
 size_t c3p_ode_row_aux_bytes(int D, int C) {

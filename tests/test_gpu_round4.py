@@ -373,3 +373,63 @@ def test_randomised_parity_sweep_of_the_round4_entry_points(lib):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_r04.py"), "--seconds", "8", "--seed", "7"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ODE solvers: more than four control lines and supplied per-sample-index Hamiltonians on the lane-row kernels
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,K", [(3, 5), (5, 6), (9, 7), (12, 5), (16, 6)])
+def test_ode_row_more_than_four_control_lines(prop, D, K):
+    """propagation.py:687-752 with K > 4 at D <= 16: H(t_n) is assembled for every sample index and the lane-row kernels
+    interpolate it between samples (the same linear interpolation as tf_utils.py:521-559, after the sum instead of before):
+    vector states; rho-valued states keep the workgroup kernel.  Trajectory and final state, against the workgroup kernel
+    (ode_wg) and the oracle."""
+    from c3_amd import _lib
+    import oracle.c3_oracle as o
+
+    rng = np.random.default_rng(100 + D)
+    B, N = 6, 37
+    herm = lambda s, real=False: (lambda m: s * (m + m.conj().T) / 2)(rng.normal(size=(D, D)) + (0 if real else 1j) * rng.normal(size=(D, D)))
+    h0, hks = herm(0.3), np.stack([herm(0.2, k % 2 == 0) for k in range(K)])
+    sig = rng.uniform(-1, 1, size=(B, K, N))
+    ts = (np.arange(N) + 0.5) * 0.05
+    dt = ts[1] - ts[0]
+    psi = rng.normal(size=(B, D, 1)) + 1j * rng.normal(size=(B, D, 1))
+    rho = np.einsum("bik,bjk->bij", psi, psi.conj())
+    col = np.stack([0.2 * (rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))])
+    cases = [("rk4", "schrodinger", psi, None), ("tsit5", "schrodinger", psi, None), ("rk4", "von_neumann", rho, None), ("rk5", "lindblad", rho, col)]
+    for solver, step, init, c in cases:
+        for fin in (False, True):
+            got = np.asarray(prop.ode_solve_batch(h0, hks, sig, dt, init, solver, step, col_ops=c, final_only=fin))
+            # (rho-valued states with K > 4 stay on the workgroup kernel: reading H rows per stage is no faster there)
+            assert _lib.last_kernel() == ("ode_row" if step == "schrodinger" else "ode_wg"), (solver, step)
+            with _lib.options(ode_wg=1):
+                ref = np.asarray(prop.ode_solve_batch(h0, hks, sig, dt, init, solver, step, col_ops=c, final_only=fin))
+                assert _lib.last_kernel() == "ode_wg"
+            assert np.abs(got - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()), (solver, step, fin)
+        full = np.asarray(prop.ode_solve_batch(h0, hks, sig, dt, init, solver, step, col_ops=c))
+        orc = o.ode_solver_arrays(h0, hks, sig[2], ts, init[2], solver, step, col=None if c is None else list(c))["states"]
+        assert np.abs(full[2] - orc).max() < 1e-11 * max(1.0, np.abs(orc).max()), (solver, step)
+
+
+@pytest.mark.parametrize("D", [2, 5, 9, 14])
+def test_rk4_unitary_supplied_hamiltonians_on_lane_rows(prop, D):
+    """Branch B of get_hs_of_t_ts (propagation.py:164-204): per-sample-index Hamiltonians through c3p_rk4_unitary -- the
+    lane-row kernel reads row i of the sample nearest to every stage position (round 1-3: the workgroup kernel)."""
+    from c3_amd import _lib
+    import oracle.c3_oracle as o
+
+    rng = np.random.default_rng(7 + D)
+    Ns = 41
+    Hs = rng.normal(size=(Ns, D, D)) + 1j * rng.normal(size=(Ns, D, D))
+    Hs = 0.4 * (Hs + Hs.conj().transpose(0, 2, 1))
+    dt = 0.07
+    U, dUs = prop._rk4_unitary_device(Hs=Hs, dt=dt)
+    assert _lib.last_kernel() == "ode_row"
+    ref = o.rk4_unitary_arrays(Hs, dt, D)
+    assert np.abs(np.asarray(U) - ref["U"]).max() < 1e-12
+    assert np.abs(np.asarray(dUs) - ref["dUs"]).max() < 1e-12
+    with _lib.options(ode_wg=1):
+        U2, _ = prop._rk4_unitary_device(Hs=Hs, dt=dt)
+        assert _lib.last_kernel() == "ode_wg"
+    assert np.abs(np.asarray(U) - np.asarray(U2)).max() < 1e-13
