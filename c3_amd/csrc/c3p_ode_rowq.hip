@@ -29,7 +29,8 @@ namespace {
 
 __constant__ OdeTableau c3p_rowq_tab[4] = C3P_ODE_TABLEAUX;
 
-constexpr int QK = 4;  // control lines
+constexpr int QKMAX = 8;  // control lines: instances for <= 4 and <= 8 (operators in LDS: c3p_ode_rowq_supported bounds K D^2)
+__host__ __device__ constexpr int q_lines(int K) { return K <= 4 ? 4 : QKMAX; }
 
 struct QLds {
   int ld;  // operator row stride in elements (odd: b128 / b64 rows of consecutive lanes fall on different banks)
@@ -42,7 +43,7 @@ __host__ __device__ inline QLds q_lds(int D, int NC, int K, bool realh, int nw, 
   q.ops_off = 0;
   const int ops = (1 + K) * (D + 1) * q.ld * (realh ? 8 : 16);  // one zero row per operator for the padding lanes
   q.sig_off = (ops + 15) & ~15;
-  q.xch_off = q.sig_off + nw * 2 * QK * 16 * 8;
+  q.xch_off = q.sig_off + nw * 2 * q_lines(K) * 16 * 8;
   q.k_off = q.xch_off + nw * 64 * 16;
   const int stages = solver == 0 ? 0 : (solver == 1 ? 4 : 7);  // rk4: the previous stage stays in registers
   q.bytes = (size_t)q.k_off + (size_t)stages * nw * 64 * 16;
@@ -69,7 +70,7 @@ __device__ __forceinline__ int q_chunk_base(int n0, int us, int N) {
   return b < 0 ? 0 : b;
 }
 
-template <int NQ, int CL, bool REALH, int NW>
+template <int NQ, int CL, bool REALH, int NW, int QK = 4>
 __global__ void __launch_bounds__(64 * NW) ode_vecq_kernel(OdeArgs A) {
   constexpr int NQP = (NQ == 2) ? 2 : 4;  // DPP rows per sample
   constexpr int SPW = 4 / NQP;            // samples per wavefront
@@ -162,6 +163,12 @@ __global__ void __launch_bounds__(64 * NW) ode_vecq_kernel(OdeArgs A) {
       if (k1 == 2) ck = cf[1];
       if (k1 == 3) ck = cf[2];
       if (k1 == 4) ck = cf[3];
+      if constexpr (QK > 4) {
+        if (k1 == 5) ck = cf[4];
+        if (k1 == 6) ck = cf[5];
+        if (k1 == 7) ck = cf[6];
+        if (k1 == 8) ck = cf[7];
+      }
       const int ob = k1 * (D + 1) * LD + lrow * LD;
 #pragma unroll
       for (int g = 0; g < NQ; ++g) {
@@ -299,7 +306,7 @@ __global__ void __launch_bounds__(64 * NW) ode_vecq_kernel(OdeArgs A) {
   if (!A.want_all && live && rowok) outp[0] = cmake(pr, pi);
 }
 
-template <int NQ, int CL>
+template <int NQ, int CL, int QK>
 hipError_t launch_q2(const OdeArgs& A, hipStream_t st) {
   constexpr int NQP = (NQ == 2) ? 2 : 4;
   constexpr int SPW = 4 / NQP;
@@ -312,30 +319,35 @@ hipError_t launch_q2(const OdeArgs& A, hipStream_t st) {
     constexpr int NW = 8;
     const QLds L = q_lds(A.D, NC, A.K, true, NW, A.solver);
     const dim3 grid((unsigned)((nv + NW * SPW - 1) / (NW * SPW)));
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ode_vecq_kernel<NQ, CL, true, NW>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ode_vecq_kernel<NQ, CL, true, NW, QK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ode_vecq_kernel<NQ, CL, true, NW>), grid, dim3(64 * NW), L.bytes, st, A);
+    hipLaunchKernelGGL((ode_vecq_kernel<NQ, CL, true, NW, QK>), grid, dim3(64 * NW), L.bytes, st, A);
   }
   {
     constexpr int NW = 4;
     const QLds L = q_lds(A.D, NC, A.K, false, NW, A.solver);
     const dim3 grid((unsigned)((nv + NW * SPW - 1) / (NW * SPW)));
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ode_vecq_kernel<NQ, CL, false, NW>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ode_vecq_kernel<NQ, CL, false, NW, QK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ode_vecq_kernel<NQ, CL, false, NW>), grid, dim3(64 * NW), L.bytes, st, A);
+    hipLaunchKernelGGL((ode_vecq_kernel<NQ, CL, false, NW, QK>), grid, dim3(64 * NW), L.bytes, st, A);
   }
   return hipGetLastError();
 }
 
+template <int NQ, int QK>
+hipError_t launch_q1k(const OdeArgs& A, hipStream_t st) {
+  const int cl = A.D - 16 * (NQ - 1);
+  if (cl <= 4) return launch_q2<NQ, 4, QK>(A, st);
+  if (cl <= 8) return launch_q2<NQ, 8, QK>(A, st);
+  if (cl <= 12) return launch_q2<NQ, 12, QK>(A, st);
+  return launch_q2<NQ, 16, QK>(A, st);
+}
+// up to four control lines: the instance of rounds 3 (its registers); five to eight: pre / cf / dc of eight lines
 template <int NQ>
 hipError_t launch_q1(const OdeArgs& A, hipStream_t st) {
-  const int cl = A.D - 16 * (NQ - 1);
-  if (cl <= 4) return launch_q2<NQ, 4>(A, st);
-  if (cl <= 8) return launch_q2<NQ, 8>(A, st);
-  if (cl <= 12) return launch_q2<NQ, 12>(A, st);
-  return launch_q2<NQ, 16>(A, st);
+  return A.K <= 4 ? launch_q1k<NQ, 4>(A, st) : launch_q1k<NQ, QKMAX>(A, st);
 }
 
 int q_groups(int D) { return (D + 15) / 16; }
@@ -349,7 +361,7 @@ int q_cols(int D) {
 
 bool c3p_ode_rowq_supported(const OdeArgs& A) {
   if (c3p_opt_on(C3P_OPT_ode_wg)) return false;
-  if (A.D < 17 || A.D > 48 || A.K > QK || A.hs || A.N < 2) return false;
+  if (A.D < 17 || A.D > 48 || A.K > QKMAX || A.hs || A.N < 2) return false;
   if (A.u_stride != 1 && A.u_stride != 2) return false;
   if (A.step != C3P_STEP_SCHRODINGER_ID && A.step != C3P_STEP_PROPAGATOR_ID) return false;
   // both instances are launched (the operators are inspected on the device): both must fit the LDS

@@ -433,3 +433,29 @@ def test_rk4_unitary_supplied_hamiltonians_on_lane_rows(prop, D):
         U2, _ = prop._rk4_unitary_device(Hs=Hs, dt=dt)
         assert _lib.last_kernel() == "ode_wg"
     assert np.abs(np.asarray(U) - np.asarray(U2)).max() < 1e-13
+
+
+@pytest.mark.parametrize("D,K,real", [(18, 5, False), (20, 6, True), (27, 6, False), (27, 8, True), (33, 5, True)])
+def test_ode_rowq_five_to_eight_control_lines(prop, D, K, real):
+    """Vector states at 17 <= D <= 48 with 5 .. 8 control lines: the second instance of ode_vecq_kernel (control amplitudes of
+    eight lines per chunk; operators in LDS as before, as long as they fit) against the workgroup kernel and the oracle."""
+    from c3_amd import _lib
+    import oracle.c3_oracle as o
+
+    rng = np.random.default_rng(300 + D)
+    B, N = 5, 33
+    herm = lambda s: (lambda m: s * (m + m.conj().T) / 2)(rng.normal(size=(D, D)) + (0 if real else 1j) * rng.normal(size=(D, D))).astype(complex)
+    h0, hks = herm(0.2), np.stack([herm(0.1) for _ in range(K)])
+    sig = rng.uniform(-1, 1, size=(B, K, N))
+    ts = (np.arange(N) + 0.5) * 0.05
+    psi = rng.normal(size=(B, D, 1)) + 1j * rng.normal(size=(B, D, 1))
+    for solver in ("rk4", "tsit5"):
+        got = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], psi, solver, "schrodinger"))
+        # (operators + the seven stage slots of tsit5 may exceed the LDS at the larger K D^2: the workgroup kernel takes those)
+        assert _lib.last_kernel() == "ode_row" or (solver == "tsit5" and (1 + K) * D * D > 4000)
+        with _lib.options(ode_wg=1):
+            ref = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], psi, solver, "schrodinger"))
+            assert _lib.last_kernel() == "ode_wg"
+        assert np.abs(got - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()), solver
+        orc = o.ode_solver_arrays(h0, hks, sig[1], ts, psi[1], solver, "schrodinger")["states"]
+        assert np.abs(got[1] - orc).max() < 1e-11 * max(1.0, np.abs(orc).max()), solver
