@@ -753,21 +753,49 @@ int run_vjp_smalld(DeviceWs* w, GradArgs& G, hipStream_t st) {
 
 // Lindblad gradient on the small-D MFMA kernels (superoperators up to 12 x 12, D <= 3), general-generator form: slice
 // propagators + segment products from the forward chain kernel, the general scan of c3p_grad.hip (prefix at the start, left
-// adjoint at the end of every segment), then smalld_grad_general_kernel.  Returns 1 when not applicable.
-int run_vjp_lind_smalld(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals, const cplx* clp,
-                        double dt, int B, int K, int N, int D, int Dm, const double* fr_phase, const cplx* Ubar, double* grad,
-                        hipStream_t st) {
-  const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
-  const int S = pick_segments(B, N, K, Dm, per_sample, 4096);
-  if (S < 0) return 1;
-  const int nsamp = per_sample ? B : 1;
-  const size_t tdoubles = (size_t)nsamp * c3p_smalld_table_doubles(Dm, K);
+// adjoint at the end of every segment), then smalld_grad_general_kernel.  In two halves around a block of memory that holds
+// what the forward half leaves for the backward one -- the workspace (c3p_pwc_lindblad_vjp) or a caller-owned tape
+// (c3p_pwc_lindblad_taped / _vjp_taped: the forward half also serves U, one chain pass per evaluation instead of two).
+struct LindSmallSizes {
+  size_t tabs, seg, dus;  // bytes: both table sets, segment products [B,S,Dm,Dm], slice propagators [B,N,Dm,Dm]
+  size_t total() const { return tabs + seg + dus; }
+};
+LindSmallSizes lind_small_sizes(int B, int K, int N, int Dm, int S, int nsamp) {
+  const size_t msz = (size_t)Dm * Dm * sizeof(cplx);
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  LindSmallSizes z;
+  z.tabs = up(2 * (size_t)nsamp * c3p_smalld_table_doubles(Dm, K) * sizeof(double));
+  z.seg = up((size_t)B * S * msz);
+  z.dus = up((size_t)B * N * msz);
+  return z;
+}
+struct LindSmallBufs {
+  double* tabs;
+  cplx *seg, *dus;
+};
+LindSmallBufs lind_small_carve(void* base, const LindSmallSizes& z) {
+  char* p = static_cast<char*>(base);
+  LindSmallBufs b;
+  b.tabs = reinterpret_cast<double*>(p);
+  b.seg = reinterpret_cast<cplx*>(p + z.tabs);
+  b.dus = reinterpret_cast<cplx*>(p + z.tabs + z.seg);
+  return b;
+}
+// segments of the small-D Lindblad sweep, -1 when the shape is not served (tables + images beyond the LDS of the backward kernel)
+int lind_small_segments(int B, int K, int N, int Dm, bool need_mult4) {
+  if (Dm > 12) return -1;
+  const int S = pick_segments(B, N, K, Dm, need_mult4, 4096);
+  if (S < 0) return -1;
   // (the backward kernel keeps BOTH table sets in LDS)
   if ((2 * c3p_smalld_table_doubles(Dm, K) + 8 * (size_t)c3p_smalld_mat_doubles(Dm) + 4 * (size_t)K * ((N + S - 1) / S)) * sizeof(double) > 60 * 1024)
-    return 1;
-  void* v;
-  if (ws_get(w, SL_TABLES, 2 * tdoubles * sizeof(double), &v)) return -1;
-  double* tabs = (double*)v;
+    return -1;
+  return S;
+}
+int lind_small_forward(const LindSmallBufs& bf, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals, const cplx* clp,
+                       double dt, int B, int K, int N, int D, int Dm, int S, hipStream_t st) {
+  const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
+  const int nsamp = per_sample ? B : 1;
+  const size_t tdoubles = (size_t)nsamp * c3p_smalld_table_doubles(Dm, K);
   PrepArgs p = {};
   p.h0 = h0;
   p.h0_bstride = h0_bs;
@@ -778,21 +806,13 @@ int run_vjp_lind_smalld(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks
   p.K = K;
   p.Dh = D;
   p.lindblad = 1;
-  p.tables = tabs;
+  p.tables = bf.tabs;
   LAUNCH_TRY(c3p_launch_smalld_prep(p, Dm, nsamp, st));
   p.conjT = 1;
-  p.tables = tabs + tdoubles;
+  p.tables = bf.tabs + tdoubles;
   LAUNCH_TRY(c3p_launch_smalld_prep(p, Dm, nsamp, st));
-  const size_t msz = (size_t)Dm * Dm * sizeof(cplx);
-  void *sv, *mv, *bv;
-  if (ws_get(w, SL_SEG_A, (size_t)B * S * msz, &sv)) return -1;
-  if (ws_get(w, SL_SEG_B, (size_t)B * S * msz, &mv)) return -1;
-  if (ws_get(w, SL_OUT1, ((size_t)B * S + 2 * (size_t)B * N) * msz, &bv)) return -1;  // (SL_OUT0 stages grad_signals)
-  cplx* pre = (cplx*)bv;
-  cplx* dUs = pre + (size_t)B * S * Dm * Dm;
-  cplx* pstore = dUs + (size_t)B * N * Dm * Dm;
   SmallArgs a = {};
-  a.tables = tabs;
+  a.tables = bf.tabs;
   a.tab_per_sample = per_sample ? 1 : 0;
   a.signals = signals;
   a.B = B;
@@ -802,9 +822,21 @@ int run_vjp_lind_smalld(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks
   a.S = S;
   a.Lmax = (N + S - 1) / S;
   a.mode = C3P_MODE_LINDBLAD;
-  a.seg_out = (cplx*)sv;
-  a.dUs_out = dUs;
+  a.seg_out = bf.seg;
+  a.dUs_out = bf.dus;
   LAUNCH_TRY(c3p_launch_smalld_chain(a, st));
+  return 0;
+}
+int lind_small_backward(DeviceWs* w, const LindSmallBufs& bf, bool per_sample, const double* signals, int B, int K, int N, int Dm, int S,
+                        const double* fr_phase, const cplx* Ubar, double* grad, hipStream_t st) {
+  const int nsamp = per_sample ? B : 1;
+  const size_t tdoubles = (size_t)nsamp * c3p_smalld_table_doubles(Dm, K);
+  const size_t msz = (size_t)Dm * Dm * sizeof(cplx);
+  void *mv, *bv;
+  if (ws_get(w, SL_SEG_B, (size_t)B * S * msz, &mv)) return -1;
+  if (ws_get(w, SL_SEG_A, ((size_t)B * S + (size_t)B * N) * msz, &bv)) return -1;  // (SL_OUT0 stages grad_signals, SL_OUT1 is the untaped block)
+  cplx* pre = (cplx*)bv;
+  cplx* pstore = pre + (size_t)B * S * Dm * Dm;
   GradArgs G = {};
   G.Ubar = Ubar;
   G.fr_phase = fr_phase;
@@ -814,19 +846,19 @@ int run_vjp_lind_smalld(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks
   G.D = Dm;
   G.ld = Dm | 1;
   G.S = S;
-  G.seg = (cplx*)sv;
+  G.seg = bf.seg;
   G.Mb = (cplx*)mv;
   G.pre = pre;
   G.general = 1;
   LAUNCH_TRY(c3p_launch_grad_scan_general(G, false, st));
   SmallGradArgs g = {};
-  g.tables = tabs;
-  g.tables_h = tabs + tdoubles;
-  g.tab_per_sample = a.tab_per_sample;
+  g.tables = bf.tabs;
+  g.tables_h = bf.tabs + tdoubles;
+  g.tab_per_sample = per_sample ? 1 : 0;
   g.signals = signals;
   g.Mb = G.Mb;
   g.pre = pre;
-  g.dUs = dUs;
+  g.dUs = bf.dus;
   g.pstore = pstore;
   g.grad = grad;
   g.B = B;
@@ -834,9 +866,23 @@ int run_vjp_lind_smalld(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks
   g.N = N;
   g.Dm = Dm;
   g.S = S;
-  g.Lmax = a.Lmax;
+  g.Lmax = (N + S - 1) / S;
   LAUNCH_TRY(c3p_launch_smalld_grad_general(g, st));
   return 0;
+}
+// Returns 1 when not applicable.
+int run_vjp_lind_smalld(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals, const cplx* clp,
+                        double dt, int B, int K, int N, int D, int Dm, const double* fr_phase, const cplx* Ubar, double* grad,
+                        hipStream_t st) {
+  const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
+  const int S = lind_small_segments(B, K, N, Dm, per_sample);
+  if (S < 0) return 1;
+  const LindSmallSizes z = lind_small_sizes(B, K, N, Dm, S, per_sample ? B : 1);
+  void* blk;
+  if (ws_get(w, SL_OUT1, z.total(), &blk)) return -1;
+  const LindSmallBufs bf = lind_small_carve(blk, z);
+  if (lind_small_forward(bf, h0, h0_bs, hks, hk_bs, signals, clp, dt, B, K, N, D, Dm, S, st)) return -1;
+  return lind_small_backward(w, bf, per_sample, signals, B, K, N, Dm, S, fr_phase, Ubar, grad, st) ? -1 : 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -2577,6 +2623,13 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
 
 // ---- open-system evaluation from ONE forward pass: a caller-owned tape between c3p_pwc_lindblad_taped and its vjp ----
 size_t c3p_pwc_lindblad_tape_bytes(int B, int K, int N, int D, int* segments_out) {
+  if (B > 0 && K >= 1 && K <= 8 && N > 0 && D >= 2 && D <= 3) {
+    // superoperators up to 9 x 9 on the small-D kernels: tables, segment products and the slice propagators (the generator is
+    // not anti-Hermitian: the backward sweep cannot recompute prefixes from the adjoint side); per-sample operators need S % 4 = 0
+    const int S = lind_small_segments(B, K, N, D * D, true);
+    if (segments_out) *segments_out = S > 0 ? S : 0;
+    return S > 0 ? lind_small_sizes(B, K, N, D * D, S, B).total() : 0;
+  }
   if (B <= 0 || K < 1 || N <= 0 || D <= 0 || !c3p_regr_supported(D, D * D) || K > 16) {
     if (segments_out) *segments_out = 0;
     return 0;
@@ -2592,10 +2645,37 @@ int c3p_pwc_lindblad_taped(const void* h0, int64_t h0_bstride, const void* hks, 
   if (flags != 0) return fail("c3p_pwc_lindblad_taped takes device pointers and no flags");
   if (B <= 0 || K < 1 || K > 16 || N <= 0 || D <= 0) return fail("bad sizes B=%d K=%d N=%d D=%d", B, K, N, D);
   const int Dm = D * D;
-  if (!c3p_regr_supported(D, Dm)) return fail("the taped Lindblad evaluation serves D = 7, 8, 9 (Hermitian-basis kernels), got D=%d", D);
   if (!h0 || !hks || !signals || !col_ops || C <= 0 || !U_out || !tape) return fail("NULL pointer argument");
   if (h0_bstride < 0 || hks_bstride < 0) return fail("negative batch stride");
   if (segments < 1 || segments > N) return fail("bad segment count %d", segments);
+  if (D <= 3) {
+    // small-D kernels: the forward half of run_vjp_lind_smalld writes into the tape, U = the ordered product of its segments
+    int seg_chk = 0;
+    const size_t need = c3p_pwc_lindblad_tape_bytes(B, K, N, D, &seg_chk);
+    if (need == 0 || seg_chk != segments) return fail("taped Lindblad evaluation: shape not served or segment count %d != %d (c3p_pwc_lindblad_tape_bytes)", segments, seg_chk);
+    if (tape_bytes < need) return fail("tape too small: %zu bytes, need %zu (c3p_pwc_lindblad_tape_bytes)", tape_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    WsLock lk(st);
+    DeviceWs* w = lk.w;
+    if (!w) return fail("no HIP device");
+    if (!lk.ok) return fail("hipStreamWaitEvent on the previous call's stream failed");
+    void* clp;
+    if (ws_get(w, SL_CLP, (size_t)Dm * Dm * sizeof(cplx), &clp)) return -1;
+    LAUNCH_TRY(c3p_launch_clp((const cplx*)col_ops, C, D, (cplx*)clp, st));
+    const LindSmallBufs bf = lind_small_carve(tape, lind_small_sizes(B, K, N, Dm, segments, B));
+    if (record_start(w, st)) return -1;
+    if (lind_small_forward(bf, (const cplx*)h0, h0_bstride, (const cplx*)hks, hks_bstride, signals, (const cplx*)clp, dt, B, K, N, D, Dm, segments, st))
+      return -1;
+    if (record_stop(w, st)) return -1;
+    g_last_kernel = C3P_KERNEL_SMALLD;
+    if (segments == 1) {
+      HIP_TRY(hipMemcpyAsync(U_out, bf.seg, (size_t)B * Dm * Dm * sizeof(cplx), hipMemcpyDeviceToDevice, st));
+      if (fr_phase) LAUNCH_TRY(c3p_launch_rowphase((cplx*)U_out, fr_phase, B, Dm, st));
+      return 0;
+    }
+    return combine_smalld(w, bf.seg, B, segments, Dm, 0, fr_phase, (cplx*)U_out, st) ? -1 : 0;
+  }
+  if (!c3p_regr_supported(D, Dm)) return fail("the taped Lindblad evaluation serves D = 2, 3 (small-D kernels) and D = 7, 8, 9 (Hermitian-basis kernels), got D=%d", D);
   const LindRegrSizes z = lind_regr_sizes(B, K, N, Dm, segments, B);
   if (tape_bytes < z.total()) return fail("tape too small: %zu bytes, need %zu (c3p_pwc_lindblad_tape_bytes)", tape_bytes, z.total());
   hipStream_t st = (hipStream_t)stream;
@@ -2650,9 +2730,26 @@ int c3p_pwc_lindblad_vjp_taped(const void* tape, size_t tape_bytes, int segments
   if (flags != 0) return fail("c3p_pwc_lindblad_vjp_taped takes device pointers and no flags");
   if (B <= 0 || K < 1 || K > 16 || N <= 0 || D <= 0) return fail("bad sizes B=%d K=%d N=%d D=%d", B, K, N, D);
   const int Dm = D * D;
-  if (!c3p_regr_supported(D, Dm)) return fail("the taped Lindblad evaluation serves D = 7, 8, 9, got D=%d", D);
   if (!tape || !signals || !U_bar || !grad_signals) return fail("NULL pointer argument");
   if (segments < 1 || segments > N) return fail("bad segment count %d", segments);
+  if (D <= 3) {
+    int seg_chk = 0;
+    const size_t need = c3p_pwc_lindblad_tape_bytes(B, K, N, D, &seg_chk);
+    if (need == 0 || seg_chk != segments) return fail("taped Lindblad evaluation: shape not served or segment count %d != %d", segments, seg_chk);
+    if (tape_bytes < need) return fail("tape too small: %zu bytes, need %zu", tape_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    WsLock lk(st);
+    DeviceWs* w = lk.w;
+    if (!w) return fail("no HIP device");
+    if (!lk.ok) return fail("hipStreamWaitEvent on the previous call's stream failed");
+    const LindSmallBufs bf = lind_small_carve(const_cast<void*>(tape), lind_small_sizes(B, K, N, Dm, segments, B));
+    if (record_start(w, st)) return -1;
+    if (lind_small_backward(w, bf, per_sample_operators != 0, signals, B, K, N, Dm, segments, fr_phase, (const cplx*)U_bar, grad_signals, st)) return -1;
+    if (record_stop(w, st)) return -1;
+    g_last_kernel = C3P_KERNEL_SMALLD;
+    return 0;
+  }
+  if (!c3p_regr_supported(D, Dm)) return fail("the taped Lindblad evaluation serves D = 2, 3 and D = 7, 8, 9, got D=%d", D);
   const LindRegrSizes z = lind_regr_sizes(B, K, N, Dm, segments, B);
   if (tape_bytes < z.total()) return fail("tape too small: %zu bytes, need %zu", tape_bytes, z.total());
   hipStream_t st = (hipStream_t)stream;

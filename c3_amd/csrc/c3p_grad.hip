@@ -546,6 +546,10 @@ __global__ void __launch_bounds__(256) grad_scan_general_kernel(GradArgs A) {
   int bU = 0, bV = msz;
   const int bS = 2 * msz;
   const cplx* segb = A.seg + (long)b * A.S * D * D;
+  // the two sweeps are independent chains of S - 1 products: with on-chip matrices they run as two workgroups per sample
+  // (gridDim.y = 2: y = 0 the prefixes, y = 1 the left adjoints; 212 -> 110 us for 64 samples of 64 segments at Dm = 9)
+  const bool do_pre = GLOBAL || gridDim.y == 1 || blockIdx.y == 0, do_adj = GLOBAL || gridDim.y == 1 || blockIdx.y == 1;
+  if (do_pre) {
   for (int e = tid; e < D * D; e += nt) M.st(bU + (e / D) * ld + (e % D), cmake((e / D) == (e % D) ? 1.0 : 0.0, 0.0));
   __syncthreads();
   cplx* pb = A.pre + (long)b * A.S * D * D;
@@ -559,6 +563,8 @@ __global__ void __launch_bounds__(256) grad_scan_general_kernel(GradArgs A) {
     bV = t;
   }
   __syncthreads();
+  }
+  if (!do_adj) return;
   const cplx* ub = A.Ubar + (long)b * D * D;
   for (int e = tid; e < D * D; e += nt) {  // FR^H Ubar: row i times e^{-i phi_i}
     const int i = e / D, j = e - i * D;
@@ -786,7 +792,7 @@ hipError_t c3p_launch_grad_scan_general(const GradArgs& A, bool global_scratch, 
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)A.B), dim3(c3p_grad_threads(A.D)), lds3, st, A);
+    hipLaunchKernelGGL(kern, dim3((unsigned)A.B, 2), dim3(c3p_grad_threads(A.D)), lds3, st, A);
     return hipGetLastError();
   }
   (void)global_scratch;

@@ -78,7 +78,7 @@ def goal_run_with_grad(
         B, K, N, D = int(sig.shape[0]), int(sig.shape[1]), int(sig.shape[2]), int(h0d.shape[-1])
         tape = None
         if fused is not False and propagation.lindblad_tape_supported(B, K, N, D):
-            # ONE forward pass: the superoperators and, on the tape, what their vector-Jacobian product reads (D = 7, 8, 9)
+            # ONE forward pass: the superoperators and, on the tape, what their vector-Jacobian product reads (D = 2, 3, 7, 8, 9)
             try:
                 r = propagation.propagate_batch_lindblad_taped(h0d, hkd, sig, dt, cold, fr_phase=ph)
                 U, tape = r["U"], r["tape"]

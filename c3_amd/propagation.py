@@ -393,7 +393,7 @@ def lindblad_tape_supported(B: int, K: int, N: int, D: int) -> bool:
 
 
 def propagate_batch_lindblad_taped(h0, hks, signals, dt: float, col_ops, *, fr_phase=None):
-    """`propagate_batch(..., lindbladian=True)` for device tensors that also records a `LindbladTape` (D = 7, 8, 9, Hermitian
+    """`propagate_batch(..., lindbladian=True)` for device tensors that also records a `LindbladTape` (D = 2, 3; D = 7, 8, 9 with Hermitian
     Hamiltonians; c3p_pwc_lindblad_taped): returns {"U": [B,D^2,D^2], "tape": LindbladTape}.  One forward pass serves the
     superoperators AND their vector-Jacobian product (`tape.vjp`), where `propagate_batch` + `propagate_batch_lindblad_vjp`
     compute the chain twice."""
@@ -423,7 +423,7 @@ def propagate_batch_lindblad_taped(h0, hks, signals, dt: float, col_ops, *, fr_p
     seg = ctypes.c_int(0)
     nbytes = int(lib.c3p_pwc_lindblad_tape_bytes(B, K, N, D, ctypes.byref(seg)))
     if nbytes <= 0:
-        raise C3PropError(f"C3:Error: the taped Lindblad evaluation serves D = 7, 8, 9 and up to 16 control lines, got D={D} K={K}")
+        raise C3PropError(f"C3:Error: the taped Lindblad evaluation serves D = 2, 3 (up to 8 control lines) and D = 7, 8, 9 (up to 16), got D={D} K={K}")
     buf = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=call.dev)
     U = call.empty((B, Dm, Dm))
     _lib.check(

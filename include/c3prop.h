@@ -241,7 +241,9 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
                          const double* signals, const void* col_ops, int C, double dt, int B, int K, int N, int D,
                          int flags, const double* fr_phase, const void* U_bar, double* grad_signals, void* stream);
 
-/* Open-system optimiser evaluation from ONE forward pass (D = 7, 8, 9: 49 x 49 .. 81 x 81 superoperators, Hermitian Hamiltonians).
+/* Open-system optimiser evaluation from ONE forward pass (D = 7, 8, 9: 49 x 49 .. 81 x 81 superoperators, Hermitian Hamiltonians;
+ * D = 2, 3: 4 x 4 / 9 x 9 superoperators on the small-D kernels, any Hamiltonian, up to 8 control lines -- there the tape holds
+ * the generator tables, the segment products and the slice propagators).
  * c3p_pwc_lindblad followed by c3p_pwc_lindblad_vjp computes the chain twice (the second time with the per-slice prefixes the
  * backward sweep reads).  Here the forward call records what the backward pass needs -- the generator tables in the Hermitian
  * basis, the real segment products, the transposed local prefix of every slice -- on a TAPE the caller owns (device memory, as
@@ -253,7 +255,7 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
  *   c3p_pwc_lindblad_taped: arguments and U_out as c3p_pwc_lindblad (device pointers, flags = 0, no dUs_out);
  *   c3p_pwc_lindblad_vjp_taped: U_bar, fr_phase, grad_signals as c3p_pwc_lindblad_vjp; signals = the ones the tape was recorded
  *     with; per_sample_operators = whether h0 / hks had a batch stride.
- * A non-Hermitian Hamiltonian is an error of the taped forward call (use the untaped pair). */
+ * At D = 7, 8, 9 a non-Hermitian Hamiltonian is an error of the taped forward call (use the untaped pair). */
 size_t c3p_pwc_lindblad_tape_bytes(int B, int K, int N, int D, int* segments_out);
 int c3p_pwc_lindblad_taped(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride, const double* signals,
                            const void* col_ops, int C, double dt, int B, int K, int N, int D, int flags, const double* fr_phase,

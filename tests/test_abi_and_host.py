@@ -230,8 +230,8 @@ def test_dpp_blocks_are_hazard_guarded():
 
 def test_lindblad_tape_layout_is_host_arithmetic(lib):
     """c3p_pwc_lindblad_tape_bytes needs no device: the tape of the open-system evaluation (include/c3prop.h) is sized from the
-    shape alone -- two table sets, their flags, B x S complex segment slots, B x N real D^2 x D^2 prefixes -- and shapes the
-    Hermitian-basis kernels do not serve report 0."""
+    shape alone -- two table sets, their flags, B x S complex segment slots, B x N real D^2 x D^2 prefixes -- and shapes neither the
+    Hermitian-basis kernels (D = 7, 8, 9) nor the small-D kernels (D = 2, 3) serve report 0."""
     import ctypes
 
     seg = ctypes.c_int(-1)
@@ -239,6 +239,13 @@ def test_lindblad_tape_layout_is_host_arithmetic(lib):
     assert seg.value == 4  # 64 samples x 4 segments = one round of 256 workgroups
     assert n >= 64 * 1000 * 81 * 81 * 8 + 64 * 4 * 81 * 81 * 16
     assert n < 1.02 * (64 * 1000 * 81 * 81 * 8 + 64 * 4 * 81 * 81 * 16) + (1 << 22)
-    for D in (2, 3, 6, 10):
+    for D in (4, 5, 6, 10):
         assert lib.c3p_pwc_lindblad_tape_bytes(4, 2, 100, D, ctypes.byref(seg)) == 0 and seg.value == 0
+    # D = 2, 3 (small-D kernels): tables + B x S segment products + B x N slice propagators, complex D^2 x D^2
+    for D in (2, 3):
+        n = lib.c3p_pwc_lindblad_tape_bytes(64, 1, 1000, D, ctypes.byref(seg))
+        S, m = seg.value, D**4 * 16
+        assert S >= 1 and S % 4 == 0 and 64 * S <= 4096
+        assert 64 * (1000 + S) * m <= n < 64 * (1000 + S) * m + (1 << 20)
+    assert lib.c3p_pwc_lindblad_tape_bytes(4, 9, 100, 3, None) == 0
     assert lib.c3p_pwc_lindblad_tape_bytes(4, 17, 100, 9, None) == 0  # more control lines than the kernels hold

@@ -266,10 +266,45 @@ def test_lindblad_taped_evaluation_matches_the_untaped_pair(prop):
         assert np.abs(g2 - 2.0 * g0).max() < 2e-11 * np.abs(g0).max()
         ref = o.propagate_batch(h0[0] if per_sample else h0, hks[0] if per_sample else hks, sig[:1], 0.2, col_ops=col, lindbladian=True)
         assert np.linalg.norm(U[0] - np.exp(1j * ph[0])[:, None] * ref[0]) < 1e-10
-    assert not prop.lindblad_tape_supported(4, 2, 10, 3)
+    assert prop.lindblad_tape_supported(4, 2, 10, 3) and not prop.lindblad_tape_supported(4, 2, 10, 5)
     hn = h0 - 0.05j * np.diag(np.arange(D))
     with pytest.raises(Exception, match="Hermitian"):
         prop.propagate_batch_lindblad_taped(t(hn), t(hks), t(sig), 0.2, t(col))
+
+
+def test_lindblad_taped_evaluation_small_superoperators(prop):
+    """The taped pair at D = 2, 3 (4 x 4 / 9 x 9 superoperators on the small-D kernels: the tape holds the tables, the segment
+    products and the slice propagators of the forward half of the general sweep), against the untaped pair and the oracle's
+    finite differences: per-sample operators, non-Hermitian Hamiltonians (no restriction here), one and many segments."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.as_tensor(a, device=dev)
+    for D, B, K, N, per_sample, lossy in ((3, 5, 2, 41, False, False), (3, 4, 1, 17, True, True), (2, 7, 3, 30, False, False), (3, 64, 1, 200, False, False)):
+        h0, hks, col, sig, Ubar, ph = _lind_case(D, B, K, N, 1, 900 + D + N, per_sample)
+        if lossy:
+            h0 = h0 - 0.05j * np.diag(np.arange(D))
+        r = prop.propagate_batch_lindblad_taped(t(h0), t(hks), t(sig), 0.2, t(col), fr_phase=t(ph))
+        assert _lib.last_kernel() == "smalld"
+        g = r["tape"].vjp(t(Ubar)).cpu().numpy()
+        g2 = r["tape"].vjp(t(-3.0 * Ubar)).cpu().numpy()
+        U = r["U"].cpu().numpy()
+        U0 = np.asarray(prop.propagate_batch(h0, hks, sig, 0.2, col_ops=col, lindbladian=True, fr_phase=ph)["U"])
+        g0 = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, 0.2, col, Ubar, fr_phase=ph))
+        assert np.abs(U - U0).max() < 1e-12
+        assert np.abs(g - g0).max() < 1e-12 * np.abs(g0).max()
+        assert np.abs(g2 + 3.0 * g0).max() < 4e-12 * np.abs(g0).max()
+    # finite differences of the oracle's forward pass on the last small case but one
+    D, B, K, N = 3, 2, 2, 12
+    h0, hks, col, sig, Ubar, ph = _lind_case(D, B, K, N, 1, 77, False)
+    r = prop.propagate_batch_lindblad_taped(t(h0), t(hks), t(sig), 0.2, t(col))
+    g = r["tape"].vjp(t(Ubar)).cpu().numpy()
+    f = lambda sg: float(np.real(np.sum(np.conj(Ubar) * o.propagate_batch(h0, hks, sg, 0.2, col_ops=col, lindbladian=True))))
+    for (b, k, n) in ((0, 0, 3), (1, 1, 11), (1, 0, 0)):
+        e = np.zeros_like(sig)
+        e[b, k, n] = 1e-6
+        fd = (f(sig + e) - f(sig - e)) / 2e-6
+        assert abs(fd - g[b, k, n]) < 1e-6 * max(1.0, abs(fd))
 
 
 def test_goal_run_with_grad_open_system_taped_equals_untaped(prop):
