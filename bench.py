@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--batch", type=int, default=None, help="weak: samples per GPU; strong: GLOBAL batch")
     ap.add_argument("--slices", type=int, default=None)
+    ap.add_argument("--overlap-gather", action="store_true",
+                    help="--exchange gather: issue the all-gather asynchronously and compute the next step(s) into a second bank of slabs meanwhile")
     ap.add_argument("--gather-every", type=int, default=1,
                     help="steps exchanged per all-gather (multi-GPU).  Default 1 = north_star's schedule: ONE all-gather of U per batch; "
                          "the amortised schedule (32) and the gather-free goal exchange are timed beside it and reported as extra keys")
@@ -194,16 +196,18 @@ def main():
             force_generic=args.generic,
         )
     # The only data-path collective is the all-gather of the U slabs (RCCL over xGMI), in stream order, G steps per
-    # collective.  (An asynchronous gather beside the chain kernel was measured SLOWER: the RCCL kernel takes CUs away
-    # from a grid sized to fill the chip exactly and creates a partial second round.)
+    # collective.  (An asynchronous gather beside the chain kernel -- SlabRing(overlap=True), --overlap-gather -- is SLOWER at
+    # one rank: the RCCL kernel takes CUs away from a grid sized to fill the chip exactly; it is timed beside the default as
+    # `all_gather_every_step_overlapped`, because on N > 1 ranks it is the schedule that hides the link latency.)
     if args.exchange == "goal" and wl.lindblad:
         raise SystemExit("--exchange goal: unitary configurations only")
     goal_state = {}
 
-    def make_schedule(exchange, gather_every):
+    def make_schedule(exchange, gather_every, overlap=False):
         """(ring, compute) of one exchange schedule: `gather` = all-gather of the U slabs of `gather_every` steps in one
-        collective; `goal` = fused fidelity per sample + ONE all-reduce of the goal per step, nothing gathered."""
-        ring = c3dist.SlabRing(B, b_pad, (Dm, Dm), gather_every, device=dev, use_dist=use_dist and exchange == "gather")
+        collective (overlap: issued asynchronously while the next steps compute into a second bank of slabs); `goal` = fused
+        fidelity per sample + ONE all-reduce of the goal per step, nothing gathered."""
+        ring = c3dist.SlabRing(B, b_pad, (Dm, Dm), gather_every, device=dev, use_dist=use_dist and exchange == "gather", overlap=overlap)
         if exchange == "goal":
             from c3_amd import fidelities
 
@@ -263,7 +267,7 @@ def main():
         return el, dev_ms
 
     goal_mode = args.exchange == "goal"
-    ring, compute = make_schedule(args.exchange, args.gather_every)
+    ring, compute = make_schedule(args.exchange, args.gather_every, args.overlap_gather)
     G = ring.G
     lib = _lib.load()
     torch.cuda.synchronize()
@@ -290,8 +294,14 @@ def main():
             todo.append(("all_gather_every_step", "gather", 1))
         if not wl.lindblad and args.exchange != "goal":
             todo.append(("goal_all_reduce_every_step", "goal", 1))
-        for name, ex, ge in todo:
-            r2, c2 = make_schedule(ex, ge)
+        todo = [(n_, e_, g_, False) for n_, e_, g_ in todo]
+        if not (args.exchange == "gather" and G == 1 and args.overlap_gather):
+            # the north_star schedule with the collective of step k under the kernel of step k + 1 (two banks of slabs,
+            # asynchronous all-gather): at one rank the RCCL kernel only takes CUs from a grid sized to the chip (measured slower),
+            # on N > 1 ranks it hides the xGMI latency -- timed beside the default so that the first real curve can tell
+            todo.append(("all_gather_every_step_overlapped", "gather", 1, True))
+        for name, ex, ge, ov in todo:
+            r2, c2 = make_schedule(ex, ge, ov)
             el2, dms2 = time_schedule(r2, c2, args.steps, args.warmup)
             alt[name] = {"value": B_glob * args.steps / el2, "ms_per_step": el2 / args.steps * 1e3, "device_ms_per_step": dms2}
             del r2, c2
@@ -389,7 +399,7 @@ def main():
                 "baseline_batch": f"{cfg['B']} on {cfg.get('gpus', 1)} GPU(s)",
                 "clock_ramp_ms": args.ramp_ms,
                 "throughput": f"sustained: after a {args.ramp_ms:g} ms untimed clock ramp and {args.warmup} warmup steps",
-                "parallelism": ((f"dp{world} ({args.scaling}: batch sharded; " + ("one RCCL all-gather of U per step" if G == 1 else f"one RCCL all-gather of U per {G} steps") + ")" if args.exchange == "gather" else f"dp{world} ({args.scaling}: batch sharded; fused fidelity, one RCCL all-reduce of the goal per step, no gather)") if use_dist else ("single GPU" if args.exchange == "gather" else "single GPU, fused fidelity per step")),
+                "parallelism": ((f"dp{world} ({args.scaling}: batch sharded; " + ("one RCCL all-gather of U per step" if G == 1 else f"one RCCL all-gather of U per {G} steps") + (", issued asynchronously under the next step" if args.overlap_gather else "") + ")" if args.exchange == "gather" else f"dp{world} ({args.scaling}: batch sharded; fused fidelity, one RCCL all-reduce of the goal per step, no gather)") if use_dist else ("single GPU" if args.exchange == "gather" else "single GPU, fused fidelity per step")),
                 "exchange": args.exchange,
                 "kernel": kernel_name,
             },

@@ -148,7 +148,7 @@ class SlabRing:
     Works on any backend / device (RCCL on the GPU box, gloo on CPU in tests/test_dist_gloo.py).
     """
 
-    def __init__(self, b_local: int, b_pad: int, tail: tuple, G: int, *, dtype=None, device=None, group=None, use_dist=None):
+    def __init__(self, b_local: int, b_pad: int, tail: tuple, G: int, *, dtype=None, device=None, group=None, use_dist=None, overlap=False):
         import torch
         import torch.distributed as dist
 
@@ -160,9 +160,18 @@ class SlabRing:
         if self.b_local > self.b_pad:
             raise ValueError("b_local exceeds the padded slab")
         dtype = torch.complex128 if dtype is None else dtype
-        self.buf = torch.zeros((self.G, self.b_pad) + tuple(tail), dtype=dtype, device=device)
+        # overlap: TWO banks of G slabs.  The collective of a full bank is issued asynchronously (RCCL's own stream, ordered
+        # after the kernels that filled the bank) and the next G steps compute into the other bank; a bank is waited for only
+        # when it is about to be overwritten (and at drain()).  Still one collective per G steps, every slab gathered.
+        self.overlap = bool(overlap) and self.use_dist
+        nb = 2 if self.overlap else 1
+        self._banks = [torch.zeros((self.G, self.b_pad) + tuple(tail), dtype=dtype, device=device) for _ in range(nb)]
+        self.buf = self._banks[0]
         self.slab = int(np.prod((self.b_pad,) + tuple(tail)))
-        self.gathered = torch.empty((self.world * self.G * self.slab,), dtype=dtype, device=device) if self.use_dist else None
+        self._gathered = [torch.empty((self.world * self.G * self.slab,), dtype=dtype, device=device) for _ in range(nb)] if self.use_dist else [None]
+        self.gathered = self._gathered[0]
+        self._work = [None] * nb
+        self._cur = 0
         self.counter = 0
         self.pending = 0
         self.last_flushed = 0  # slabs moved by the most recent collective
@@ -171,17 +180,32 @@ class SlabRing:
     def _real(self, t):
         return self.torch.view_as_real(t) if t.is_complex() else t
 
+    def _wait(self, bank):
+        w = self._work[bank]
+        if w is not None:
+            w.wait()  # RCCL: the CURRENT STREAM waits for the collective (no host block); gloo: the host does
+            self._work[bank] = None
+
     def flush(self):
         g = self.pending
         if self.use_dist and g > 0:
             n = g * self.slab
-            self.dist.all_gather_into_tensor(self._real(self.gathered[: self.world * n]), self._real(self.buf[:g].reshape(-1)), group=self.group)
+            bank = self._cur
+            dst = self._real(self._gathered[bank][: self.world * n])
+            src = self._real(self._banks[bank][:g].reshape(-1))
+            if self.overlap:
+                self._work[bank] = self.dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True)
+                self._cur = bank ^ 1
+                self._wait(self._cur)  # the bank the next steps compute into: its previous collective must have read it
+            else:
+                self.dist.all_gather_into_tensor(dst, src, group=self.group)
+            self.gathered = self._gathered[bank]
             self.collectives += 1
             self.last_flushed = g
         self.pending = 0
 
     def step(self, compute):
-        out = self.buf[self.counter % self.G]
+        out = self._banks[self._cur][self.pending if self.overlap else self.counter % self.G]
         self.counter += 1
         res = compute(out)
         self.pending += 1
@@ -191,6 +215,8 @@ class SlabRing:
 
     def drain(self):
         self.flush()
+        for bank in range(len(self._work)):
+            self._wait(bank)
         self.counter = 0
 
     def warm(self, sizes):

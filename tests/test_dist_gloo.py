@@ -90,7 +90,7 @@ def test_robust_goal_all_reduce(tmp_path, B):
 # --------------------------------------------------------------------------
 
 
-def _ring_worker(rank, world, port, B_glob, G, steps, out_dir):
+def _ring_worker(rank, world, port, B_glob, G, steps, out_dir, overlap=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -101,7 +101,7 @@ def _ring_worker(rank, world, port, B_glob, G, steps, out_dir):
         Bg, lo, hi, b_pad = bench.plan_batch(cfg, "strong", None, world, rank)
         assert (lo, hi) == c3dist.shard_bounds(B_glob, world, rank) and Bg == B_glob and b_pad == c3dist.max_shard(B_glob, world)
         B = hi - lo
-        ring = c3dist.SlabRing(B, b_pad, (2, 2), G, use_dist=True)
+        ring = c3dist.SlabRing(B, b_pad, (2, 2), G, use_dist=True, overlap=overlap)
         ring.warm({min(G, steps), steps % G})
         calls = [0]
 
@@ -125,11 +125,13 @@ def _ring_worker(rank, world, port, B_glob, G, steps, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B_glob,G,steps", [(5, 3, 7), (4, 2, 4)])
-def test_bench_slab_ring_two_ranks(tmp_path, B_glob, G, steps):
+@pytest.mark.parametrize("B_glob,G,steps,overlap", [(5, 3, 7, False), (4, 2, 4, False), (5, 1, 6, True), (5, 3, 7, True), (4, 2, 4, True)])
+def test_bench_slab_ring_two_ranks(tmp_path, B_glob, G, steps, overlap):
+    """(overlap: the collective of a full bank of slabs is asynchronous and the next steps compute into the second bank; every
+    slab still arrives, the last collective's slabs are readable after drain())"""
     world = 2
     port = _free_port()
-    mp.spawn(_ring_worker, args=(world, port, B_glob, G, steps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_ring_worker, args=(world, port, B_glob, G, steps, str(tmp_path), overlap), nprocs=world, join=True)
     g_last = steps % G or G
     first = steps - g_last  # step index of slab 0 of the last collective
     b_pad = c3dist.max_shard(B_glob, world)

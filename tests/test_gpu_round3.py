@@ -184,7 +184,7 @@ def test_rccl_one_rank_sharded_propagation(lib):
     assert "DIST_NCCL_OK world=1" in out.stdout
 
 
-@pytest.mark.parametrize("extra", [[], ["--gather-every", "32"], ["--exchange", "goal"], ["--scaling", "strong", "--batch", "64"]])
+@pytest.mark.parametrize("extra", [[], ["--gather-every", "32"], ["--exchange", "goal"], ["--scaling", "strong", "--batch", "64"], ["--overlap-gather", "--steps", "7"]])
 def test_bench_under_torchrun_one_rank(lib, extra):
     """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, RCCL), with --check.  The DEFAULT
     schedule is north_star's: ONE all-gather of U per step; the amortised schedule (one all-gather per 32 steps) and the
@@ -210,6 +210,9 @@ def test_bench_under_torchrun_one_rank(lib, extra):
         assert "per 32 steps" in d["config"]["parallelism"] and "all_gather_every_step" in alt
     else:
         assert "one RCCL all-gather of U per step" in d["config"]["parallelism"]
+        assert ("issued asynchronously" in d["config"]["parallelism"]) == ("--overlap-gather" in extra)
+        if "--overlap-gather" not in extra:  # (round 4) the same schedule with the collective under the next step, timed beside it
+            assert alt["all_gather_every_step_overlapped"]["value"] > 0
         assert "all_gather_every_32_steps" in alt and alt["all_gather_every_32_steps"]["value"] > 0
         if "--scaling" not in extra:
             assert alt["goal_all_reduce_every_step"]["value"] > 0
