@@ -249,3 +249,26 @@ def test_lindblad_tape_layout_is_host_arithmetic(lib):
         assert 64 * (1000 + S) * m <= n < 64 * (1000 + S) * m + (1 << 20)
     assert lib.c3p_pwc_lindblad_tape_bytes(4, 9, 100, 3, None) == 0
     assert lib.c3p_pwc_lindblad_tape_bytes(4, 17, 100, 9, None) == 0  # more control lines than the kernels hold
+
+
+def _build_abi_client(tmp_path):
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = os.path.join(str(tmp_path), "abi_client")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "checks", "abi_client.c"), "-o", exe, "-ldl", "-lm"], check=True)
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_client_binds_the_library(lib, tmp_path):
+    """include/c3prop.h compiles as strict C99 and a C program that only knows the header (dlopen + dlsym, what a foreign
+    FFI does) drives the option table, the tape arithmetic and the no-device error path of the in-tree libc3prop.so."""
+    import subprocess
+
+    exe = _build_abi_client(tmp_path)
+    out = subprocess.run([exe, _lib.LIB_PATH, "host"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "ABI_CLIENT_HOST_OK" in out.stdout

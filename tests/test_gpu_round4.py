@@ -494,3 +494,21 @@ def test_ode_rowq_five_to_eight_control_lines(prop, D, K, real):
         assert np.abs(got - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()), solver
         orc = o.ode_solver_arrays(h0, hks, sig[1], ts, psi[1], solver, "schrodinger")["states"]
         assert np.abs(got[1] - orc).max() < 1e-11 * max(1.0, np.abs(orc).max()), solver
+
+
+def test_c_client_of_the_abi_on_the_device(lib, tmp_path):
+    """tests/checks/abi_client.c (strict C99, dlopen of the in-tree library, no torch in the process): one batch through
+    c3p_pwc_unitary with host pointers; U is unitary and equals the ordered product of the slice propagators it returns."""
+    import os
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(str(tmp_path), "abi_client")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "checks", "abi_client.c"), "-o", exe, "-ldl", "-lm"], check=True)
+    out = subprocess.run([exe, _lib.LIB_PATH, "gpu"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ABI_CLIENT_GPU_OK" in out.stdout
