@@ -4,7 +4,8 @@
   (b) Hermitian-basis Lindblad sweep (D = 7, 8, 9) against the tiled sweep, random segments, K, N, per-sample operators, drive
       strength (Taylor degree / squarings), and the taped pair against the untaped one;
   (c) core + border form (D = 5, 9) against the padded tiles, random N, B, amplitude, MW on / off;
-  (d) ODE trajectories in time segments against the direct integration.
+  (d) ODE trajectories in time segments against the direct integration; every other time: five to eight control lines against
+      the workgroup kernel, and the taped Lindblad pair at D = 2, 3 against the untaped one.
     python tools/fuzz_r04.py --seconds 120 --seed 1"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -100,6 +101,40 @@ while time.time() < t_end:
                 y = np.asarray(prop.propagate_batch(h0, hks, sig, 1e-11, fr_phase=ph)["U"])
         e = np.abs(x - y).max()
         assert e < 1e-10, ("split", D, B, N, amp, e)
+    elif kind == "ode" and it % 8 == 0:
+        # more than four control lines (assembled Hamiltonians, lane rows / the eight-line instance at D >= 17) and the small taped
+        # Lindblad pair, against the workgroup kernel / the untaped pair
+        D = int(rng.choice([3, 5, 9, 14, 16, 18, 24, 27]))
+        B, K, N = int(rng.integers(1, 6)), int(rng.integers(5, 9)), int(rng.integers(8, 60))
+        h0, hks = herm(D, 0.3), np.stack([herm(D, 0.2, bool(rng.integers(0, 2))) for _ in range(K)])
+        sig = rng.uniform(-1, 1, size=(B, K, N))
+        psi = rng.normal(size=(B, D, 1)) + 1j * rng.normal(size=(B, D, 1))
+        solver = str(rng.choice(["rk4", "rk38", "rk5", "tsit5"]))
+        fin = bool(rng.integers(0, 2))
+        x = np.asarray(prop.ode_solve_batch(h0, hks, sig, 0.05, psi, solver, "schrodinger", final_only=fin))
+        with _lib.options(ode_wg=1):
+            y = np.asarray(prop.ode_solve_batch(h0, hks, sig, 0.05, psi, solver, "schrodinger", final_only=fin))
+        e = np.abs(x - y).max() / max(1.0, np.abs(y).max())
+        assert e < 1e-11, ("ode K>4", D, B, K, N, solver, fin, e)
+        Dl = int(rng.choice([2, 3]))
+        Bl, Kl, Nl = int(rng.integers(1, 9)), int(rng.integers(1, 4)), int(rng.integers(4, 90))
+        ps = bool(rng.integers(0, 2))
+        nb = Bl if ps else 1
+        h0l = np.stack([herm(Dl, 0.8) - (0.05j * np.diag(np.arange(Dl)) if rng.integers(0, 2) else 0) for _ in range(nb)])
+        hkl = np.stack([np.stack([herm(Dl, 0.5) for _ in range(Kl)]) for _ in range(nb)])
+        if not ps:
+            h0l, hkl = h0l[0], hkl[0]
+        col = np.stack([0.3 * (rng.normal(size=(Dl, Dl)) + 1j * rng.normal(size=(Dl, Dl)))])
+        sgl = rng.uniform(-1, 1, size=(Bl, Kl, Nl))
+        Ub = rng.normal(size=(Bl, Dl**2, Dl**2)) + 1j * rng.normal(size=(Bl, Dl**2, Dl**2))
+        phl = rng.uniform(0, 6, size=(Bl, Dl**2)) if rng.integers(0, 2) else None
+        r = prop.propagate_batch_lindblad_taped(t(h0l), t(hkl), t(sgl), 0.2, t(col), fr_phase=None if phl is None else t(phl))
+        g1 = r["tape"].vjp(t(Ub)).cpu().numpy()
+        g0 = np.asarray(prop.propagate_batch_lindblad_vjp(h0l, hkl, sgl, 0.2, col, Ub, fr_phase=phl))
+        U0 = np.asarray(prop.propagate_batch(h0l, hkl, sgl, 0.2, col_ops=col, lindbladian=True, fr_phase=phl)["U"])
+        e2 = max(np.abs(g1 - g0).max() / max(np.abs(g0).max(), 1e-300), np.abs(r["U"].cpu().numpy() - U0).max())
+        assert e2 < 1e-10, ("taped small", Dl, Bl, Kl, Nl, ps, e2)
+        e = max(e, e2)
     else:
         D = int(rng.choice([3, 6, 9, 12, 18, 27, 33, 40]))
         B, K, N = int(rng.integers(1, 6)), int(rng.integers(1, 4)), int(rng.integers(70, 260))
