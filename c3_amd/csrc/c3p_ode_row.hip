@@ -283,18 +283,21 @@ __global__ void __launch_bounds__(64) ode_vec_kernel(OdeArgs A) {
 // matrix state rho: von Neumann (C = 0) and Lindblad steps; lane i owns row i of rho
 // ---------------------------------------------------------------------------------------------------------------
 struct MatLds {
-  int sig_off, k_off, col_off;
+  int sig_off, k_off, col_off, x_off, xs_off;
   size_t bytes;
 };
+constexpr int MAT_KX_MAX = 12;  // control lines beyond the four whose operator rows sit in registers (their rows: LDS)
 // stage slots hold the LIVE lanes only (4 rows x D lanes): 7 stages at D = 9 are 36 KB instead of 64 KB per wavefront
 // (rk4: a[s][j] = 0 but for j = s - 1, the previous stage is still in registers: no slots at all)
-__host__ __device__ inline MatLds mat_lds(int D, int DP, int KT, int solver, int C) {
+__host__ __device__ inline MatLds mat_lds(int D, int DP, int KT, int solver, int C, int KX = 0) {
   const int stages = solver == 0 ? 0 : (solver == 1 ? 4 : 7);
   MatLds m;
   m.sig_off = 0;
   m.k_off = 4 * KT * 16 * 8;
   m.col_off = m.k_off + stages * DP * 4 * D * 16;
-  m.bytes = (size_t)m.col_off + (size_t)C * DP * DP * 16;
+  m.x_off = m.col_off + C * DP * DP * 16;   // [KX][DP][DP] complex: rows of the extra control operators
+  m.xs_off = m.x_off + KX * DP * DP * 16;   // [4 samples][KX][16] control amplitudes of the extra lines (current chunk)
+  m.bytes = (size_t)m.xs_off + (size_t)4 * KX * 16 * 8;
   return m;
 }
 
@@ -305,7 +308,10 @@ __global__ void __launch_bounds__(64, 1) ode_mat_kernel(OdeArgs A, OdeRowAux X) 
   const int S = T.stages;
   const int lane = threadIdx.x, r = lane >> 4, i = lane & 15;
   const int D = A.D, K = A.K, N = A.N, C = A.C, us = A.u_stride;
-  const MatLds L = mat_lds(D, DP, KT, A.solver, C);
+  const int KX = K > KT ? K - KT : 0;  // (KT = 4 only: control lines beyond the four register-resident ones)
+  const MatLds L = mat_lds(D, DP, KT, A.solver, C, KX);
+  cplx* hx = reinterpret_cast<cplx*>(c3p_ode_row_smem + L.x_off);
+  double* sigx = reinterpret_cast<double*>(c3p_ode_row_smem + L.xs_off);
   const bool subdiag = A.solver == 0;  // rk4
   double* sig = reinterpret_cast<double*>(c3p_ode_row_smem + L.sig_off);
   cplx* kst = reinterpret_cast<cplx*>(c3p_ode_row_smem + L.k_off);       // [stage][c][live lane]
@@ -335,6 +341,14 @@ __global__ void __launch_bounds__(64, 1) ode_mat_kernel(OdeArgs A, OdeRowAux X) 
       if constexpr (!REALH) hki[k][j] = zk.y;
       im0 = im0 && (zk.y == 0.0);
     }
+  }
+  // rows of the control operators beyond the register-resident ones -> LDS (shared by the four samples of the wavefront)
+  for (int e = lane; e < KX * DP * DP; e += 64) {
+    const int k = e / (DP * DP), ii = (e / DP) % DP, jj = e % DP;
+    cplx z = cmake(0, 0);
+    if (ii < D && jj < D) z = A.hks[((long)(KT + k) * D + ii) * D + jj];
+    hx[e] = z;
+    im0 = im0 && (z.y == 0.0);
   }
   // the real instance takes real Hamiltonians without collapse operators, the complex one everything else
   const bool real_case = (__all(im0) != 0) && C == 0;
@@ -380,6 +394,11 @@ __global__ void __launch_bounds__(64, 1) ode_mat_kernel(OdeArgs A, OdeRowAux X) 
     const int base = chunk_base(n0, us, N);
 #pragma unroll
     for (int k = 0; k < KT; ++k) sig[(r * KT + k) * 16 + i] = pre[k];
+    if (KX > 0) {  // (the extra lines are fetched for the chunk itself, not one ahead)
+      int idx = base + i;
+      if (idx > N - 1) idx = N - 1;
+      for (int k = 0; k < KX; ++k) sigx[(r * KX + k) * 16 + i] = sg[(long)(KT + k) * N + idx];
+    }
     {
       const int nb = chunk_base(n0 + SPC, us, N);
       int idx = nb + i;
@@ -408,15 +427,33 @@ __global__ void __launch_bounds__(64, 1) ode_mat_kernel(OdeArgs A, OdeRowAux X) 
             const double y0 = sp[k * 16], y1 = sp[k * 16 + 1];
             c[k] = fma(f, y1 - y0, y0);
           }
+          double hxr[DP], hxi[REALH ? 1 : DP];  // contribution of the control lines beyond KT (operator rows from LDS)
 #pragma unroll
           for (int j = 0; j < DP; ++j) {
-            double hr = h0r[j];
+            hxr[j] = 0.0;
+            if constexpr (!REALH) hxi[j] = 0.0;
+          }
+          for (int k = 0; k < KX; ++k) {
+            const double* spx = &sigx[(r * KX + k) * 16 + (lo - base)];
+            const double y0 = spx[0], y1 = spx[1];
+            const double cx = fma(f, y1 - y0, y0);
+            const cplx* hrow = hx + ((long)k * DP + (row ? i : DP - 1)) * DP;
+#pragma unroll
+            for (int j = 0; j < DP; ++j) {
+              const cplx z = hrow[j];
+              hxr[j] = fma(cx, z.x, hxr[j]);
+              if constexpr (!REALH) hxi[j] = fma(cx, z.y, hxi[j]);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < DP; ++j) {
+            double hr = h0r[j] + (row ? hxr[j] : 0.0);
 #pragma unroll
             for (int k = 0; k < KT; ++k) hr = fma(c[k], hkr[k][j], hr);
             if constexpr (REALH) {
               Lr[j] = hr;
             } else {
-              double hi = h0i[j];
+              double hi = h0i[j] + (row ? hxi[j] : 0.0);
 #pragma unroll
               for (int k = 0; k < KT; ++k) hi = fma(c[k], hki[k][j], hi);
               // -(i/2) (gr + i gi) = gi/2 - i gr/2
@@ -659,7 +696,7 @@ hipError_t launch_mat1(const OdeArgs& A, const OdeRowAux& X, dim3 grid, hipStrea
     if (A.C == 0) e = launch_mat3<DP, 2, true>(A, X, grid, lds, st);
     if (e == hipSuccess) e = launch_mat3<DP, 2, false>(A, X, grid, lds, st);
   } else {
-    const size_t lds = mat_lds(A.D, DP, 4, A.solver, A.C).bytes;
+    const size_t lds = mat_lds(A.D, DP, 4, A.solver, A.C, A.K > 4 ? A.K - 4 : 0).bytes;
     if (A.C == 0) e = launch_mat3<DP, 4, true>(A, X, grid, lds, st);
     if (e == hipSuccess) e = launch_mat3<DP, 4, false>(A, X, grid, lds, st);
   }
@@ -670,14 +707,16 @@ hipError_t launch_mat1(const OdeArgs& A, const OdeRowAux& X, dim3 grid, hipStrea
 
 bool c3p_ode_row_supported(const OdeArgs& A) {
   if (c3p_opt_on(C3P_OPT_ode_wg)) return false;  // A/B switch: the workgroup-per-sample kernel of c3p_ode.hip
-  if (A.D > 16 || (A.K > 4 && !A.hs) || A.N < 2) return false;  // (supplied Hamiltonians: no control lines in the kernel)
+  if (A.D > 16 || A.N < 2) return false;
   if (A.u_stride != 1 && A.u_stride != 2) return false;
-  if (A.step == C3P_STEP_SCHRODINGER_ID || A.step == C3P_STEP_PROPAGATOR_ID) return true;
-  // rho-valued steps (supplied Hamiltonians were measured there: the row reads per stage make the lane-row kernel as slow as
-  // the workgroup kernel, 8.6 against 8.6 ms at D = 9, B = 256 -- not instantiated)
-  if (A.hs || A.reset_each_step || A.transpose_out) return false;
+  const bool vec = A.step == C3P_STEP_SCHRODINGER_ID || A.step == C3P_STEP_PROPAGATOR_ID;
+  if (vec) return A.K <= 4 || A.hs;  // (supplied Hamiltonians: no control lines in the kernel)
+  // rho-valued steps: control lines beyond four keep their operator rows in LDS.  (Supplied Hamiltonians were measured there:
+  // the row reads from memory per stage make the lane-row kernel as slow as the workgroup kernel, 8.6 against 8.6 ms at D = 9,
+  // B = 256 -- not instantiated.)
+  if (A.hs || A.reset_each_step || A.transpose_out || A.K > 4 + MAT_KX_MAX) return false;
   const int DP = pad_dim(A.D);
-  return mat_lds(A.D, DP, A.K <= 2 ? 2 : 4, A.solver, A.C).bytes <= (size_t)(150 * 1024);
+  return mat_lds(A.D, DP, A.K <= 2 ? 2 : 4, A.solver, A.C, A.K > 4 ? A.K - 4 : 0).bytes <= (size_t)(150 * 1024);
 }
 
 hipError_t c3p_launch_ode_assemble_hs(const OdeArgs& A, cplx* out, hipStream_t st) {

@@ -417,8 +417,8 @@ def test_randomised_parity_sweep_of_the_round4_entry_points(lib):
 def test_ode_row_more_than_four_control_lines(prop, D, K):
     """propagation.py:687-752 with K > 4 at D <= 16: H(t_n) is assembled for every sample index and the lane-row kernels
     interpolate it between samples (the same linear interpolation as tf_utils.py:521-559, after the sum instead of before):
-    vector states; rho-valued states keep the workgroup kernel.  Trajectory and final state, against the workgroup kernel
-    (ode_wg) and the oracle."""
+    vector states; rho-valued states read the operator rows of the extra lines from LDS.  Trajectory and final state, against
+    the workgroup kernel (ode_wg) and the oracle."""
     from c3_amd import _lib
     import oracle.c3_oracle as o
 
@@ -436,8 +436,8 @@ def test_ode_row_more_than_four_control_lines(prop, D, K):
     for solver, step, init, c in cases:
         for fin in (False, True):
             got = np.asarray(prop.ode_solve_batch(h0, hks, sig, dt, init, solver, step, col_ops=c, final_only=fin))
-            # (rho-valued states with K > 4 stay on the workgroup kernel: reading H rows per stage is no faster there)
-            assert _lib.last_kernel() == ("ode_row" if step == "schrodinger" else "ode_wg"), (solver, step)
+            # (rho-valued states: the operator rows of the lines beyond four sit in LDS)
+            assert _lib.last_kernel() == "ode_row", (solver, step)
             with _lib.options(ode_wg=1):
                 ref = np.asarray(prop.ode_solve_batch(h0, hks, sig, dt, init, solver, step, col_ops=c, final_only=fin))
                 assert _lib.last_kernel() == "ode_wg"

@@ -15,9 +15,9 @@ t = lambda x: torch.as_tensor(x, device=dev)
 rng = np.random.default_rng(5)
 
 
-def herm(D, s):
-    m = rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))
-    return s * (m + m.conj().T) / 2
+def herm(D, s, real=False):
+    m = rng.normal(size=(D, D)) + (0 if real else 1j) * rng.normal(size=(D, D))
+    return (s * (m + m.conj().T) / 2).astype(complex)
 
 
 def timed(fn, reps=5):
@@ -34,13 +34,17 @@ def timed(fn, reps=5):
 
 rows = []
 for D, K, B, N, solver, step in [(9, 6, 256, 1000, "rk4", "schrodinger"), (9, 6, 2048, 1000, "rk4", "schrodinger"), (9, 6, 256, 1000, "tsit5", "schrodinger"),
-                                 (16, 8, 256, 1000, "rk4", "schrodinger"), (16, 8, 2048, 1000, "rk4", "schrodinger")]:
-    h0, hks = t(herm(D, 0.3)), t(np.stack([herm(D, 0.2) for _ in range(K)]))
+                                 (16, 8, 256, 1000, "rk4", "schrodinger"), (16, 8, 2048, 1000, "rk4", "schrodinger"),
+                                 (9, 6, 256, 1000, "rk4", "von_neumann"), (9, 6, 2048, 1000, "rk4", "von_neumann"), (9, 6, 2048, 1000, "tsit5", "von_neumann"), (9, 6, 16384, 200, "rk4", "von_neumann"), (9, 4, 2048, 1000, "rk4", "von_neumann"), (9, 4, 16384, 200, "rk4", "von_neumann"),
+                                 (9, 6, 256, 1000, "rk4", "von_neumann_real"), (9, 6, 2048, 1000, "rk4", "von_neumann_real"), (9, 4, 2048, 1000, "rk4", "von_neumann_real")]:
+    real = step.endswith("_real")
+    step = step.replace("_real", "")
+    h0, hks = t(herm(D, 0.3, real)), t(np.stack([herm(D, 0.2, real) for _ in range(K)]))
     sig = t(rng.uniform(-1, 1, size=(B, K, N)))
     psi = rng.normal(size=(B, D, 1)) + 1j * rng.normal(size=(B, D, 1))
     init = t(psi if step == "schrodinger" else np.einsum("bik,bjk->bij", psi, psi.conj()))
     f = lambda: prop.ode_solve_batch(h0, hks, sig, 0.05, init, solver, step, final_only=True)
-    row = {"case": f"{step} {solver} D={D} K={K}", "B": B, "N": N}
+    row = {"case": f"{step} {solver} D={D} K={K}" + (" real operators" if real else ""), "B": B, "N": N}
     row["lane_row_ms"] = timed(f)
     row["kernel"] = _lib.last_kernel()
     x = f().cpu().numpy()
