@@ -5,7 +5,7 @@
 // rk5 / tsit5 (:755-883), the step functions schrodinger / von_neumann / lindblad (:886-904), Model.Hs_of_t
 // (c3/model.py:641-697) with interpolate_signal (c3/utils/tf_utils.py:521-559) and the rk4_unitary family
 // (propagation.py:71-101,221-255) -- same arithmetic as the workgroup-per-sample kernel of c3p_ode.hip (which stays the
-// path for D > 48, more than four control lines and supplied per-sample Hamiltonians; 17 <= D <= 48 runs on
+// path for D > 48 and Lindblad steps above D = 32; 17 <= D <= 48 runs on
 // c3p_ode_rowq.hip / c3p_ode_rhoq.hip), mapped to the machine differently:
 //
 //  * ONE SAMPLE PER 16-LANE DPP ROW, four samples per wavefront: lane i of the row owns ROW i of the Hamiltonian
