@@ -33,7 +33,7 @@ except Exception:
 out["_comment"] = ("per-launch PMC figures of the dominant kernel of each bench configuration (tools/final_r04.sh pmc -> tools/profile_r03.sh on the "
                    "bench command WITH its clock ramp, tools/pmc_to_json.py); bench.py quotes an entry only when its kernel_sources_digest, batch "
                    "and slice count match the running build")
-for tag in ("cfg2", "cfg3", "cfg4", "cfg5", "cfg2_complex"):
+for tag in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg2_complex"):
     f = os.path.join(R, "gpurun_out", f"pmc_{tag}.json")
     try:
         ent = json.load(open(f))
