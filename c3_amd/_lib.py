@@ -17,6 +17,7 @@ HOST_PTRS = 0x1
 PER_SLICE_H = 0x2
 ORDER_RIGHT = 0x4
 FORCE_GENERIC = 0x8
+HERMITIAN_H = 0x10  # c3p_pwc_lindblad: the caller declares h0 / hks Hermitian (D = 2, 3: real arithmetic in the Hermitian basis)
 
 KERNEL_NAMES = {0: "none", 1: "generic_lds", 2: "generic_global", 3: "smalld", 4: "mfma", 5: "ode_wg", 6: "ode_row", 7: "ode_mfma"}
 

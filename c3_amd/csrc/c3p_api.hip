@@ -15,6 +15,7 @@
 #include "c3p_kernels.h"
 #include "c3p_ode.h"
 #include "c3p_smalld.h"
+#include "c3p_smallr.h"
 #include "c3p_midd.h"
 #include "c3p_bigd.h"
 #include "c3p_regd.h"
@@ -382,6 +383,55 @@ int pick_segments(int B, int N, int K, int Dm, bool need_mult4, long slots = 819
     if (S <= N && (N + S - 1) / S <= lmax_cap) best = S;
   }
   return (int)best;
+}
+
+// Lindblad chains of one qubit / qutrit whose Hamiltonians the caller declares Hermitian (C3P_HERMITIAN_H): real arithmetic
+// in the Hermitian basis on the small-D tile layout (c3p_smallr.hip).  Real generator tables -> segment products (turned back
+// into the reference's vectorisation by the chain that formed them) -> ordered product with the frame phases (the
+// supplied-matrix mode of the complex small-D chain kernel).  Returns 1 when not applicable.
+int run_pwc_smallr(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals, const cplx* clp, double dt,
+                   int B, int K, int N, int D, int Dm, const double* fr_phase, cplx* U_out, hipStream_t st) {
+  const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
+  int S = pick_segments(B, N, K, Dm, per_sample);
+  if (S < 0) return 1;
+  while (S < N && c3p_smallr_lds_bytes(Dm, K, (N + S - 1) / S) > (size_t)60 * 1024) S += per_sample ? 4 : 1;
+  if (c3p_smallr_lds_bytes(Dm, K, (N + S - 1) / S) > (size_t)60 * 1024) return 1;
+  const int nsamp = per_sample ? B : 1;
+  const size_t tdoubles = (size_t)nsamp * c3p_smallr_table_doubles(Dm, K);
+  const size_t fl_off = (tdoubles * sizeof(double) + 255) & ~(size_t)255;
+  void *tv, *sv;
+  if (ws_get(w, SL_TABLES, fl_off + (size_t)nsamp * (1 + K) * sizeof(int), &tv)) return -1;
+  if (ws_get(w, SL_SEG_A, (size_t)B * S * Dm * Dm * sizeof(cplx), &sv)) return -1;
+  double* tabs = (double*)tv;
+  int* flags = reinterpret_cast<int*>(static_cast<char*>(tv) + fl_off);
+  RegdPrepArgs p = {};
+  p.h0 = h0;
+  p.h0_bstride = h0_bs;
+  p.hks = hks;
+  p.hks_bstride = hk_bs;
+  p.clp = clp;
+  p.dt = dt;
+  p.K = K;
+  p.Dh = D;
+  p.Dm = Dm;
+  p.lindblad = 1;
+  LAUNCH_TRY(c3p_launch_smallr_prep(p, nsamp, tabs, flags, st));
+  SmallRArgs a = {};
+  a.tables = tabs;
+  a.tab_per_sample = per_sample ? 1 : 0;
+  a.signals = signals;
+  a.B = B;
+  a.K = K;
+  a.N = N;
+  a.Dm = Dm;
+  a.S = S;
+  a.Lmax = (N + S - 1) / S;
+  a.seg_out = (cplx*)sv;
+  g_last_kernel = C3P_KERNEL_SMALLD;
+  if (record_start(w, st)) return -1;
+  LAUNCH_TRY(c3p_launch_smallr_chain(a, st));
+  if (record_stop(w, st)) return -1;
+  return combine_smalld(w, (const cplx*)sv, B, S, Dm, 0, fr_phase, U_out, st) ? -1 : 0;
 }
 
 int run_pwc_smalld(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs,
@@ -1730,6 +1780,12 @@ int pwc_common(int lindblad, const void* h0, int64_t h0_bstride, const void* hks
     const int rc = (Dm <= kSmallDLimit && c3p_smalld_supported(Dm))
                        ? run_xg_smalld(w, (const cplx*)gv, gbs, dt, 0.0, B, N, Dm, a.fr_phase, (cplx*)d_U, a.dUs_out, st)
                        : run_xg_midd(w, (const cplx*)gv, gbs, dt, 0.0, B, N, Dm, a.fr_phase, (cplx*)d_U, a.dUs_out, st);
+    if (rc < 0) return -1;
+    done = (rc == 0);
+  }
+  if (!done && !(flags & C3P_FORCE_GENERIC) && !per_slice && lindblad && (flags & C3P_HERMITIAN_H) && !a.dUs_out &&
+      c3p_smallr_supported(D, Dm, K) && !c3p_opt_on(C3P_OPT_no_smallr)) {
+    const int rc = run_pwc_smallr(w, a.h0, a.h0_bstride, a.hks, a.hks_bstride, a.signals, a.clp, dt, B, K, N, D, Dm, a.fr_phase, (cplx*)d_U, st);
     if (rc < 0) return -1;
     done = (rc == 0);
   }

@@ -15,6 +15,7 @@
   X(regr_rolled)        /* c3p_regr.hip, -DC3P_REGR_VARIANTS builds only: rolled product loop */                                \
   X(no_tiled)           /* Dm >= 93: generic kernel instead of the tiled path */                                       \
   X(no_split81)         /* small D, real path at D = 5, 9: padded tiles instead of the core + border form */             \
+  X(no_smallr)          /* Lindblad D = 2, 3 with C3P_HERMITIAN_H: the complex small-D kernels, not the real ones */       \
   X(no_mw)              /* small D: one-wave workgroups + ticket instead of workgroup-per-sample */                    \
   X(mw_skew)            /* per mille of a pair's slices given to the older wave */                                     \
   X(no_fuse)            /* small D: separate combine launch */                                                         \

@@ -1,0 +1,374 @@
+// Lindblad chains of ONE qubit / qutrit (D = 2, 3: 4 x 4 / 9 x 9 superoperators) in REAL arithmetic in the Hermitian basis,
+// on the small-D tile layout (round 4).  tf_propagation_lind (c3/libraries/propagation.py:551-585) builds the generator
+// L = -i (H (x) 1 - 1 (x) H^T) + dissipator per slice and exponentiates it; for a HERMITIAN Hamiltonian that generator maps
+// Hermitian matrices to Hermitian matrices, so in the basis  E_ii, (E_ij + E_ji) / sqrt 2, i (E_ji - E_ij) / sqrt 2  it is a
+// REAL Dm x Dm matrix (c3p_regr.hip uses the same fact at D = 7, 8, 9; the change of basis is c3p_hb_row / c3p_hb_col of
+// c3p_regd.h).  A real general 9 x 9 product is 27 matrix instructions here against 75 of the complex half-image product of
+// c3p_smalld.hip, and everything element-wise is a quarter.
+//
+// The caller asserts Hermitian Hamiltonians (flag C3P_HERMITIAN_H of c3p_pwc_lindblad: the Python layer sets it after
+// checking); without the flag the complex kernels run as before.  Layout: one wavefront = four chains (block b of
+// v_mfma_f64_4x4x4_4b_f64 = chain b), every matrix as NB x NB register tiles (lane (r, c) of tile (I, J) holds
+// M[4 I + r][4 J + c]); the left operand of a product goes through a per-chain row-major LDS image (row stride 4 NB + 1)
+// and is read back in the A layout.  exp = T18 (Bader-Blanes-Casas, five products) + s squarings, as the complex loop.
+// Segment products are turned back into the reference's vectorisation (U = T^+ U' T) by the chain that formed them; the
+// supplied-matrix mode of the complex small-D chain kernel multiplies them in order and applies the frame phases.
+#include "c3p_common.h"
+#include "c3p_kernels.h"
+#include "c3p_midd.h"
+#include "c3p_regd.h"
+#include "c3p_smallr.h"
+
+extern __shared__ __attribute__((aligned(16))) double c3p_sr_lds[];
+
+namespace {
+
+template <int DM>
+struct RG {
+  static constexpr int NB = (DM + 3) / 4;
+  static constexpr int WR = 4 * NB + 1;          // image row stride (doubles)
+  static constexpr int RIMG = 4 * NB * WR;       // one chain's image
+  static constexpr int TILES = NB * NB * 16;     // table body: tile-major, 16 elements per tile in lane order r * 4 + c
+  static constexpr int TABD = TILES + 4;         // + {mu, ||G' - mu||_1, max |Im|, max |Re|}
+};
+
+__device__ __forceinline__ double sr_mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+typedef __attribute__((address_space(3))) const volatile double sr_lds_cvd;
+__device__ __forceinline__ double sr_ld(const double* p) { return *(sr_lds_cvd*)p; }
+__device__ __forceinline__ void sr_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---- tables: G' = Re(T G T^+), trace shifted, tile-major ------------------------------------------------------------------
+__global__ void __launch_bounds__(64) smallr_prep_kernel(RegdPrepArgs P, double* tables, int* tabflag) {
+  __shared__ double red0[64], red1[64];
+  __shared__ double mu_s;
+  const int tid = threadIdx.x;
+  const int ti = blockIdx.x % (1 + P.K);
+  const int sample = blockIdx.x / (1 + P.K);
+  const int D = P.Dm, Dh = P.Dh;
+  const int NB = (D + 3) / 4;
+  const cplx* h = (ti == 0) ? P.h0 + (long)sample * P.h0_bstride : P.hks + (long)sample * P.hks_bstride + (long)(ti - 1) * Dh * Dh;
+  // element (row, col) of L0 = dt (clp - i (H0 (x) I - I (x) H0^T)) / Lk = -i dt (Hk (x) I - I (x) Hk^T) (propagation.py:565-582)
+  auto gelem = [&](int row, int col) -> cplx {
+    const int i = row / Dh, j = row - i * Dh, k = col / Dh, l = col - k * Dh;
+    cplx v = (ti == 0) ? P.clp[(long)row * D + col] : cmake(0, 0);
+    if (j == l) {
+      const cplx x = h[i * Dh + k];
+      v.x += x.y;
+      v.y -= x.x;
+    }
+    if (i == k) {
+      const cplx x = h[l * Dh + j];
+      v.x -= x.y;
+      v.y += x.x;
+    }
+    return cscale(v, P.dt);
+  };
+  auto helem = [&](int a, int b) -> cplx {  // element (a, b) of T G T^+
+    int ia[2], ib[2];
+    cplx ta[2], tb[2];
+    const int na = c3p_hb_row(a, Dh, ia, ta), nb = c3p_hb_row(b, Dh, ib, tb);
+    cplx s = cmake(0.0, 0.0);
+    for (int x = 0; x < na; ++x)
+      for (int y = 0; y < nb; ++y) cfma(s, cmul(ta[x], cconj(tb[y])), gelem(ia[x], ib[y]));
+    return s;
+  };
+  // every element of T G T^+ by its own thread first (Dm^2 <= 81), norms and the table from the shared copy
+  __shared__ double hre[96], him[96];
+  for (int e = tid; e < D * D; e += 64) {
+    const cplx v = helem(e / D, e % D);
+    hre[e] = v.x;
+    him[e] = v.y;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0;
+    for (int i = 0; i < D; ++i) a += hre[i * D + i];  // the trace is invariant under the change of basis
+    mu_s = a / D;
+  }
+  __syncthreads();
+  const double mu = mu_s;
+  double cs = 0, mre = 0, mim = 0;
+  for (int j = tid; j < D; j += 64) {
+    double sm = 0;
+    for (int i = 0; i < D; ++i) {
+      const double vx = hre[i * D + j], vy = him[i * D + j];
+      mre = fmax(mre, fabs(vx));
+      mim = fmax(mim, fabs(vy));
+      sm += fabs(i == j ? vx - mu : vx);
+    }
+    cs = fmax(cs, sm);
+  }
+  red0[tid] = cs;
+  red1[tid] = mre;
+  __syncthreads();
+  double nrm = 0, gmax = 0;
+  if (tid == 0)
+    for (int i = 0; i < 64; ++i) {
+      nrm = fmax(nrm, red0[i]);
+      gmax = fmax(gmax, red1[i]);
+    }
+  __syncthreads();
+  red0[tid] = mim;
+  __syncthreads();
+  const int TILES = NB * NB * 16;
+  double* out = tables + ((long)sample * (1 + P.K) + ti) * (TILES + 4);
+  for (int e = tid; e < TILES; e += 64) {
+    const int tile = e >> 4, idx = e & 15;
+    const int I = tile / NB, J = tile - I * NB;
+    const int row = 4 * I + (idx >> 2), col = 4 * J + (idx & 3);
+    double g = 0.0;
+    if (row < D && col < D) {
+      g = hre[row * D + col];
+      if (row == col) g -= mu;
+    }
+    out[e] = g;
+  }
+  if (tid == 0) {
+    double gim = 0;
+    for (int i = 0; i < 64; ++i) gim = fmax(gim, red0[i]);
+    out[TILES + 0] = mu;
+    out[TILES + 1] = nrm;
+    out[TILES + 2] = gim;
+    out[TILES + 3] = gmax;
+    tabflag[sample * (1 + P.K) + ti] = (gim <= 1e-14 * gmax) ? 1 : 0;
+  }
+}
+
+// ---- the chain kernel --------------------------------------------------------------------------------------------------
+template <int DM>
+__global__ void __launch_bounds__(64) smallr_chain_kernel(SmallRArgs A) {
+  using G = RG<DM>;
+  constexpr int NB = G::NB, WR = G::WR, RIMG = G::RIMG, TABD = G::TABD, TILES = G::TILES;
+  typedef double RMat[NB][NB];
+  const int lane = threadIdx.x;
+  const int r = lane >> 4, b = (lane >> 2) & 3, c = lane & 3, idx16 = r * 4 + c;
+  const int K = A.K;
+  double* tab = c3p_sr_lds;                    // (1 + K) tables of this wavefront's sample
+  double* img = tab + (1 + K) * TABD;          // four chain images
+  double* sg = img + 4 * RIMG;                 // 4 chains x K x Lmax control amplitudes
+
+  const long chain = (long)blockIdx.x * 4 + b;
+  const long nchains = (long)A.B * A.S;
+  const bool valid = chain < nchains;
+  const long cc = valid ? chain : nchains - 1;
+  const int sample = (int)(cc / A.S);
+  const int seg = (int)(cc - (long)sample * A.S);
+  const int n0 = (int)(((long)seg * A.N) / A.S);
+  const int n1 = (int)(((long)(seg + 1) * A.N) / A.S);
+  const int len = n1 - n0;
+
+  // (tables per sample: S % 4 == 0 and the four chains of a wavefront share the sample; otherwise all samples share them)
+  const double* gt0 = A.tables + (long)(A.tab_per_sample ? sample : 0) * (1 + K) * TABD;
+  for (int e = lane; e < (1 + K) * TABD; e += 64) tab[e] = gt0[e];
+  __syncthreads();
+  double nrm = tab[TILES + 1];
+  for (int k = 0; k < K; ++k) {
+    const double* s = A.signals + ((long)sample * K + k) * A.N + n0;
+    double cmax = 0.0;
+    for (int t = idx16; t < A.Lmax; t += 16) {
+      const double v = (valid && t < len) ? s[t] : 0.0;
+      sg[(b * K + k) * A.Lmax + t] = v;
+      cmax = fmax(cmax, fabs(v));
+    }
+    cmax = fmax(cmax, __shfl_xor(cmax, 1));
+    cmax = fmax(cmax, __shfl_xor(cmax, 2));
+    cmax = fmax(cmax, __shfl_xor(cmax, 16));
+    cmax = fmax(cmax, __shfl_xor(cmax, 32));
+    nrm = fma(cmax, tab[(k + 1) * TABD + TILES + 1], nrm);
+  }
+  __syncthreads();
+  nrm = fmax(nrm, __shfl_xor(nrm, 4));
+  nrm = fmax(nrm, __shfl_xor(nrm, 8));
+  int ps = 0;
+  {
+    double pth = C3P_T18_THETA;
+    while (pth < nrm && ps < 40) {
+      pth *= 2.0;
+      ++ps;
+    }
+  }
+  ps = __builtin_amdgcn_readfirstlane(ps);
+  const double scale = ldexp(1.0, -ps);
+
+  const int woff = b * RIMG + r * WR + c;  // D-layout write: + (4 I) WR + 4 J
+  const int roff = b * RIMG + c * WR + r;  // A-layout read:  + (4 I) WR + 4 K
+  auto to_image = [&](const RMat& M) {
+    sr_sync();
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) img[woff + 4 * I * WR + 4 * J] = M[I][J];
+    sr_sync();
+  };
+  // acc += (image) Bm
+  auto mm = [&](const RMat& Bm, RMat& acc) {
+#pragma unroll
+    for (int Kk = 0; Kk < NB; ++Kk) {
+      double a[NB];
+#pragma unroll
+      for (int I = 0; I < NB; ++I) a[I] = sr_ld(img + roff + 4 * I * WR + 4 * Kk);
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) acc[I][J] = sr_mfma4(a[I], Bm[Kk][J], acc[I][J]);
+    }
+  };
+  // out = c0 I + cx X + c2 A2 + c3 A3 + c6 A6
+  auto comb = [&](RMat& out, double c0, double cx, double c2, double c3, double c6, const RMat& X, const RMat& A2, const RMat& A3, const RMat& A6) {
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) {
+        double v = cx * X[I][J];
+        v = fma(c2, A2[I][J], v);
+        v = fma(c3, A3[I][J], v);
+        v = fma(c6, A6[I][J], v);
+        if (I == J) v += (r == c && 4 * I + r < DM) ? c0 : 0.0;
+        out[I][J] = v;
+      }
+  };
+  auto zero = [&](RMat& M) {
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) M[I][J] = 0.0;
+  };
+
+  RMat U;
+  zero(U);
+  double mus = 0.0;
+  for (int t = 0; t < A.Lmax; ++t) {
+    const bool act = valid && t < len;
+    const double sc = act ? scale : 0.0;  // chains past their segment end take X = 0, E = 1
+    double mu = act ? tab[TILES + 0] : 0.0;
+    RMat X;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) X[I][J] = sc * tab[(I * NB + J) * 16 + idx16];
+    for (int k = 0; k < K; ++k) {
+      const double c0 = sg[(b * K + k) * A.Lmax + t];  // zero padded past the segment end
+      const double ck = sc * c0;
+      const double* tk = tab + (k + 1) * TABD;
+      mu = fma(c0, tk[TILES + 0], mu);
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) X[I][J] = fma(ck, tk[(I * NB + J) * 16 + idx16], X[I][J]);
+    }
+    // T18 (Bader-Blanes-Casas): A2 = X X, A3 = X A2, A6 = A3 A3, A9 = B1 B5 + B4, exp = B2 + (B3 + A9) A9
+    RMat A2, A3, A6, P, acc;
+    zero(A2), zero(A3), zero(A6);
+    to_image(X);
+    mm(X, A2);
+    mm(A2, A3);
+    to_image(A3);
+    mm(A3, A6);
+    {
+      RMat B1, B5;
+      comb(B1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0, X, A2, A3, A6);
+      to_image(B1);
+      comb(B5, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64, X, A2, A3, A6);
+      comb(acc, C3P_T18_B03, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63, X, A2, A3, A6);
+      mm(B5, acc);  // A9
+    }
+    {
+      RMat L;
+      comb(L, C3P_T18_B02, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62, X, A2, A3, A6);
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) L[I][J] += acc[I][J];
+      to_image(L);
+    }
+    comb(P, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61, X, A2, A3, A6);
+    mm(acc, P);
+    for (int it = 0; it < ps; ++it) {
+      to_image(P);
+      RMat Q;
+      zero(Q);
+      mm(P, Q);
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) P[I][J] = Q[I][J];
+    }
+    if (t == 0) {
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) U[I][J] = P[I][J];
+    } else {
+      to_image(P);
+      RMat V;
+      zero(V);
+      mm(U, V);
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) U[I][J] = act ? V[I][J] : U[I][J];
+    }
+    mus += mu;
+  }
+  // the REAL segment product U' -> the complex matrix T^+ U' T in the reference's vectorisation (c3p_hb_col: at most two
+  // non-zeros per column of T), through the chain's image: 16 lanes share the Dm^2 elements of their chain
+  to_image(U);
+  const double er = exp(mus);
+  cplx* dst = A.seg_out + cc * DM * DM;
+  constexpr int Dh = (DM == 4) ? 2 : 3;
+  for (int e = idx16; e < DM * DM; e += 16) {
+    const int al = e / DM, be = e - al * DM;
+    int ia[2], ib[2];
+    cplx ta[2], tb[2];
+    const int na = c3p_hb_col(al, Dh, ia, ta), nb = c3p_hb_col(be, Dh, ib, tb);
+    cplx z = cmake(0.0, 0.0);
+    for (int x = 0; x < na; ++x)
+      for (int y = 0; y < nb; ++y) {
+        const cplx cf = cmul(cconj(ta[x]), tb[y]);
+        const double v = img[b * RIMG + ia[x] * WR + ib[y]];
+        z.x = fma(cf.x, v, z.x);
+        z.y = fma(cf.y, v, z.y);
+      }
+    if (valid) dst[e] = cmake(er * z.x, er * z.y);
+  }
+}
+
+template <int DM>
+hipError_t launch_chain_t(const SmallRArgs& A, hipStream_t st) {
+  using G = RG<DM>;
+  const long nchains = (long)A.B * A.S;
+  const size_t lds = (size_t)((1 + A.K) * G::TABD + 4 * G::RIMG + 4 * A.K * A.Lmax) * sizeof(double);
+  if (lds > 60 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(smallr_chain_kernel<DM>, dim3((unsigned)((nchains + 3) / 4)), dim3(64), lds, st, A);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool c3p_smallr_supported(int Dh, int Dm, int K) { return (Dh == 2 || Dh == 3) && Dm == Dh * Dh && K >= 0 && K <= 8; }
+
+size_t c3p_smallr_table_doubles(int Dm, int K) {
+  const int NB = (Dm + 3) / 4;
+  return (size_t)(1 + K) * (NB * NB * 16 + 4);
+}
+
+size_t c3p_smallr_lds_bytes(int Dm, int K, int Lmax) {
+  const int NB = (Dm + 3) / 4;
+  return (size_t)((1 + K) * (NB * NB * 16 + 4) + 4 * 4 * NB * (4 * NB + 1) + 4 * K * Lmax) * sizeof(double);
+}
+
+hipError_t c3p_launch_smallr_prep(const RegdPrepArgs& P, int nsamp, double* tables, int* tabflag, hipStream_t st) {
+  hipLaunchKernelGGL(smallr_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K))), dim3(64), 0, st, P, tables, tabflag);
+  return hipGetLastError();
+}
+
+hipError_t c3p_launch_smallr_chain(const SmallRArgs& A, hipStream_t st) {
+  switch (A.Dm) {
+    case 4: return launch_chain_t<4>(A, st);
+    case 9: return launch_chain_t<9>(A, st);
+    default: return hipErrorInvalidValue;
+  }
+}

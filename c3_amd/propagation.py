@@ -189,6 +189,9 @@ def propagate_batch(
         if col_ops is None:
             raise C3PropError("C3:Error: lindbladian propagation needs collapse operators")
         col = call.c128(col_ops if _is_torch(col_ops) else np.asarray(col_ops))
+        if D in (2, 3) and not (flags & _lib.PER_SLICE_H) and not want_dUs and _is_hermitian(call, h0) and (K == 0 or _is_hermitian(call, hks)):
+            # one qubit / qutrit with Hermitian Hamiltonians: the generator is real in the Hermitian basis (c3p_smallr.hip)
+            flags |= _lib.HERMITIAN_H
         rc = lib.c3p_pwc_lindblad(
             _ptr(h0), h0_bs, _ptr(hks), hk_bs, _ptr(signals), _ptr(col), int(col.shape[0]), float(dt),
             B, K, N, D, flags, _ptr(fr_phase), _ptr(U), _ptr(dUs), call.stream,
@@ -205,7 +208,16 @@ def propagate_batch(
 _hermitian_ok = {}  # id(tensor) -> (weakref to the tensor, _version it passed at)
 
 
-def _require_hermitian(call, name, h):
+def _is_hermitian(call, h) -> bool:
+    """|h - h^+| <= 1e-14 |h| (device tensors: cached per tensor object and version, as _require_hermitian)."""
+    try:
+        _require_hermitian(call, "h", h, tol=1e-14)
+        return True
+    except C3PropError:
+        return False
+
+
+def _require_hermitian(call, name, h, tol=1e-12):
     """The adjoint sweep assumes unitary slices, i.e. Hermitian Hamiltonians; the library only checks host-pointer
     inputs, so device tensors are checked here (one reduction + a host sync per operator set)."""
     if call.device:
@@ -215,20 +227,20 @@ def _require_hermitian(call, name, h):
         import weakref
 
         ent = _hermitian_ok.get(id(h))
-        if ent is not None and ent[0]() is h and ent[1] == h._version:
+        if ent is not None and ent[0]() is h and ent[1] == h._version and ent[2] <= tol:
             return
         dev = float((h - h.conj().transpose(-1, -2)).abs().max().item())
         scale = float(h.abs().max().item())
-        if dev <= 1e-12 * max(scale, 1e-300):
+        if dev <= tol * max(scale, 1e-300):
             key = id(h)
             try:
-                _hermitian_ok[key] = (weakref.ref(h, lambda _r, k=key: _hermitian_ok.pop(k, None)), h._version)
+                _hermitian_ok[key] = (weakref.ref(h, lambda _r, k=key: _hermitian_ok.pop(k, None)), h._version, tol)
             except TypeError:
                 pass
     else:
         dev = float(np.abs(h - np.conj(np.swapaxes(h, -1, -2))).max())
         scale = float(np.abs(h).max())
-    if dev > 1e-12 * max(scale, 1e-300):
+    if dev > tol * max(scale, 1e-300):
         raise C3PropError(f"C3:Error: {name} must be Hermitian for the gradient (|h - h^+| = {dev:.3e})")
 
 

@@ -56,6 +56,12 @@ extern "C" {
                                  of pwc, use_control_fields=False (propagation.py:295-308) */
 #define C3P_ORDER_RIGHT 0x4   /* c3p_matmul_chain: elems[0]@...@elems[N-1] (tf_matmul_right) */
 #define C3P_FORCE_GENERIC 0x8 /* use the generic LDS kernel even where a specialised one exists */
+#define C3P_HERMITIAN_H 0x10  /* c3p_pwc_lindblad: the caller DECLARES h0 and every hk Hermitian (the library does not check
+                                 device memory).  The Lindblad generator is then real in a basis of Hermitian matrices and the
+                                 chain of one qubit / qutrit (D = 2, 3) runs in real arithmetic (c3p_smallr.hip); other shapes
+                                 ignore the flag (D = 7, 8, 9 detect the case on the device).  Declared wrongly: wrong results.
+                                 The reference makes no such distinction (propagation.py:551-585): c3_amd/propagation.py sets
+                                 the flag after checking the arrays. */
 
 /* kernels selected (returned by c3p_last_kernel, for tests/bench reporting) */
 #define C3P_KERNEL_NONE 0

@@ -512,3 +512,49 @@ def test_c_client_of_the_abi_on_the_device(lib, tmp_path):
     out = subprocess.run([exe, _lib.LIB_PATH, "gpu"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ABI_CLIENT_GPU_OK" in out.stdout
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Lindblad chains of one qubit / qutrit in real arithmetic in the Hermitian basis (c3p_smallr.hip, flag C3P_HERMITIAN_H)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,B,K,N,per_sample,amp", [(3, 5, 2, 41, False, 1.0), (3, 4, 1, 17, True, 1.0), (2, 7, 3, 30, False, 1.0), (3, 64, 1, 200, False, 1.0),
+                                                     (2, 1, 1, 1, False, 1.0), (3, 3, 2, 9, False, 25.0), (3, 9, 0, 12, False, 1.0), (3, 256, 2, 1000, False, 0.3)])
+def test_lindblad_small_real_path(prop, D, B, K, N, per_sample, amp):
+    """propagation.py:551-585 at D = 2, 3 with Hermitian Hamiltonians: the real kernels (propagate_batch sets C3P_HERMITIAN_H
+    after checking the arrays) against the complex small-D kernels (option no_smallr) and the oracle; per-sample operators,
+    frame phases, no control line, large generators (squarings), one slice; a non-Hermitian Hamiltonian keeps the complex path."""
+    h0, hks, col, sig, _, ph = _lind_case(D, B, max(K, 1), N, 2 if D == 3 else 1, 4000 + 10 * D + N, per_sample, hscale=0.8 * amp)
+    if K == 0:
+        hks, sig = hks[..., :0, :, :], sig[:, :0, :]
+    got = np.asarray(prop.propagate_batch(h0, hks, sig, 0.2, col_ops=col, lindbladian=True, fr_phase=ph)["U"])
+    assert _lib.last_kernel() == "smalld"
+    with _lib.options(no_smallr=1):
+        ref = np.asarray(prop.propagate_batch(h0, hks, sig, 0.2, col_ops=col, lindbladian=True, fr_phase=ph)["U"])
+    assert np.abs(got - ref).max() < 2e-12 * max(1.0, np.abs(ref).max())
+    for b in sorted({0, B - 1}):
+        orc = o.propagate_batch(h0[b] if per_sample else h0, hks[b] if per_sample else hks, sig[b : b + 1], 0.2, col_ops=col, lindbladian=True)[0]
+        assert np.linalg.norm(got[b] - np.exp(1j * ph[b])[:, None] * orc) < 1e-10 * max(1.0, np.linalg.norm(orc))
+    # trace preservation: vec(1)^T S = vec(1)^T (frame phases are row phases: take them out first)
+    vecI = np.eye(D).reshape(-1)
+    S = np.exp(-1j * ph)[:, :, None] * got
+    assert np.abs(np.einsum("i,bij->bj", vecI, S) - vecI).max() < 1e-10
+
+
+def test_lindblad_small_real_path_is_not_taken_for_lossy_hamiltonians(prop):
+    import torch
+
+    D, B, K, N = 3, 4, 2, 25
+    h0, hks, col, sig, _, ph = _lind_case(D, B, K, N, 1, 4242)
+    hn = h0 - 0.05j * np.diag(np.arange(D))
+    x = np.asarray(prop.propagate_batch(hn, hks, sig, 0.2, col_ops=col, lindbladian=True)["U"])
+    with _lib.options(no_smallr=1):
+        y = np.asarray(prop.propagate_batch(hn, hks, sig, 0.2, col_ops=col, lindbladian=True)["U"])
+    assert np.array_equal(x, y)  # the same kernels: the flag was not set
+    orc = o.propagate_batch(hn, hks, sig[:1], 0.2, col_ops=col, lindbladian=True)[0]
+    assert np.linalg.norm(x[0] - orc) < 1e-10
+    # device tensors: the Hermitian check is cached per tensor object
+    t = lambda a: torch.as_tensor(a, device="cuda:0")
+    h0d, hkd, sgd, cold = t(h0), t(hks), t(sig), t(col)
+    a = prop.propagate_batch(h0d, hkd, sgd, 0.2, col_ops=cold, lindbladian=True)["U"].cpu().numpy()
+    b = np.asarray(prop.propagate_batch(h0, hks, sig, 0.2, col_ops=col, lindbladian=True)["U"])
+    assert np.abs(a - b).max() < 1e-13
