@@ -841,8 +841,8 @@ int lind_small_segments(int B, int K, int N, int Dm, bool need_mult4) {
     return -1;
   return S;
 }
-int lind_small_forward(const LindSmallBufs& bf, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals, const cplx* clp,
-                       double dt, int B, int K, int N, int D, int Dm, int S, hipStream_t st) {
+int lind_small_forward(DeviceWs* w, const LindSmallBufs& bf, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals,
+                       const cplx* clp, double dt, int B, int K, int N, int D, int Dm, int S, bool hermitian, hipStream_t st) {
   const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
   const int nsamp = per_sample ? B : 1;
   const size_t tdoubles = (size_t)nsamp * c3p_smalld_table_doubles(Dm, K);
@@ -861,6 +861,41 @@ int lind_small_forward(const LindSmallBufs& bf, const cplx* h0, long h0_bs, cons
   p.conjT = 1;
   p.tables = bf.tabs + tdoubles;
   LAUNCH_TRY(c3p_launch_smalld_prep(p, Dm, nsamp, st));
+  if (hermitian && c3p_smallr_supported(D, Dm, K) && !c3p_opt_on(C3P_OPT_no_smallr) &&
+      c3p_smallr_lds_bytes(Dm, K, (N + S - 1) / S) <= (size_t)60 * 1024) {
+    // declared Hermitian Hamiltonians (C3P_HERMITIAN_H): segment products and slice propagators from the real kernels of
+    // c3p_smallr.hip (the backward sweep reads them in the complex vectorisation: the kernel converts what it stores)
+    const size_t rdoubles = (size_t)nsamp * c3p_smallr_table_doubles(Dm, K);
+    const size_t fl_off = (rdoubles * sizeof(double) + 255) & ~(size_t)255;
+    void* tv;
+    if (ws_get(w, SL_TABLES, fl_off + (size_t)nsamp * (1 + K) * sizeof(int), &tv)) return -1;
+    RegdPrepArgs rp = {};
+    rp.h0 = h0;
+    rp.h0_bstride = h0_bs;
+    rp.hks = hks;
+    rp.hks_bstride = hk_bs;
+    rp.clp = clp;
+    rp.dt = dt;
+    rp.K = K;
+    rp.Dh = D;
+    rp.Dm = Dm;
+    rp.lindblad = 1;
+    LAUNCH_TRY(c3p_launch_smallr_prep(rp, nsamp, (double*)tv, reinterpret_cast<int*>(static_cast<char*>(tv) + fl_off), st));
+    SmallRArgs ra = {};
+    ra.tables = (const double*)tv;
+    ra.tab_per_sample = per_sample ? 1 : 0;
+    ra.signals = signals;
+    ra.B = B;
+    ra.K = K;
+    ra.N = N;
+    ra.Dm = Dm;
+    ra.S = S;
+    ra.Lmax = (N + S - 1) / S;
+    ra.seg_out = bf.seg;
+    ra.dUs_out = bf.dus;
+    LAUNCH_TRY(c3p_launch_smallr_chain(ra, st));
+    return 0;
+  }
   SmallArgs a = {};
   a.tables = bf.tabs;
   a.tab_per_sample = per_sample ? 1 : 0;
@@ -923,7 +958,7 @@ int lind_small_backward(DeviceWs* w, const LindSmallBufs& bf, bool per_sample, c
 // Returns 1 when not applicable.
 int run_vjp_lind_smalld(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals, const cplx* clp,
                         double dt, int B, int K, int N, int D, int Dm, const double* fr_phase, const cplx* Ubar, double* grad,
-                        hipStream_t st) {
+                        bool hermitian, hipStream_t st) {
   const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
   const int S = lind_small_segments(B, K, N, Dm, per_sample);
   if (S < 0) return 1;
@@ -931,7 +966,7 @@ int run_vjp_lind_smalld(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks
   void* blk;
   if (ws_get(w, SL_OUT1, z.total(), &blk)) return -1;
   const LindSmallBufs bf = lind_small_carve(blk, z);
-  if (lind_small_forward(bf, h0, h0_bs, hks, hk_bs, signals, clp, dt, B, K, N, D, Dm, S, st)) return -1;
+  if (lind_small_forward(w, bf, h0, h0_bs, hks, hk_bs, signals, clp, dt, B, K, N, D, Dm, S, hermitian, st)) return -1;
   return lind_small_backward(w, bf, per_sample, signals, B, K, N, Dm, S, fr_phase, Ubar, grad, st) ? -1 : 0;
 }
 
@@ -2556,7 +2591,8 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
     if (record_start(w, st)) return -1;
     const int rc = in_chunks([&](long b0, int nb) {
       return run_vjp_lind_smalld(w, p_h0 + b0 * h0_bstride, h0_bstride, p_hk + b0 * hks_bstride, hks_bstride, p_sig + b0 * K * N,
-                                 (const cplx*)clp, dt, nb, K, N, D, Dm, phase_at(b0), p_ub + b0 * gsz, p_grad + b0 * K * N, st);
+                                 (const cplx*)clp, dt, nb, K, N, D, Dm, phase_at(b0), p_ub + b0 * gsz, p_grad + b0 * K * N,
+                                 (flags & C3P_HERMITIAN_H) != 0, st);
     });
     if (rc < 0) return -1;
     if (rc == 0) {
@@ -2698,7 +2734,7 @@ size_t c3p_pwc_lindblad_tape_bytes(int B, int K, int N, int D, int* segments_out
 int c3p_pwc_lindblad_taped(const void* h0, int64_t h0_bstride, const void* hks, int64_t hks_bstride, const double* signals,
                            const void* col_ops, int C, double dt, int B, int K, int N, int D, int flags, const double* fr_phase,
                            void* U_out, void* tape, size_t tape_bytes, int segments, void* stream) {
-  if (flags != 0) return fail("c3p_pwc_lindblad_taped takes device pointers and no flags");
+  if (flags & ~C3P_HERMITIAN_H) return fail("c3p_pwc_lindblad_taped takes device pointers and no flags but C3P_HERMITIAN_H");
   if (B <= 0 || K < 1 || K > 16 || N <= 0 || D <= 0) return fail("bad sizes B=%d K=%d N=%d D=%d", B, K, N, D);
   const int Dm = D * D;
   if (!h0 || !hks || !signals || !col_ops || C <= 0 || !U_out || !tape) return fail("NULL pointer argument");
@@ -2720,7 +2756,8 @@ int c3p_pwc_lindblad_taped(const void* h0, int64_t h0_bstride, const void* hks, 
     LAUNCH_TRY(c3p_launch_clp((const cplx*)col_ops, C, D, (cplx*)clp, st));
     const LindSmallBufs bf = lind_small_carve(tape, lind_small_sizes(B, K, N, Dm, segments, B));
     if (record_start(w, st)) return -1;
-    if (lind_small_forward(bf, (const cplx*)h0, h0_bstride, (const cplx*)hks, hks_bstride, signals, (const cplx*)clp, dt, B, K, N, D, Dm, segments, st))
+    if (lind_small_forward(w, bf, (const cplx*)h0, h0_bstride, (const cplx*)hks, hks_bstride, signals, (const cplx*)clp, dt, B, K, N, D, Dm, segments,
+                           (flags & C3P_HERMITIAN_H) != 0, st))
       return -1;
     if (record_stop(w, st)) return -1;
     g_last_kernel = C3P_KERNEL_SMALLD;

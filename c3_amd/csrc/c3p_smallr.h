@@ -13,6 +13,7 @@ struct SmallRArgs {
   int B, K, N, Dm;
   int S, Lmax;           // segments per sample, ceil(N / S)
   cplx* seg_out;         // [B,S,Dm,Dm] segment products, already in the reference's (complex) vectorisation
+  cplx* dUs_out;         // [B,N,Dm,Dm] slice propagators (complex vectorisation) or null
 };
 
 bool c3p_smallr_supported(int Dh, int Dm, int K);

@@ -3,7 +3,7 @@
 // L = -i (H (x) 1 - 1 (x) H^T) + dissipator per slice and exponentiates it; for a HERMITIAN Hamiltonian that generator maps
 // Hermitian matrices to Hermitian matrices, so in the basis  E_ii, (E_ij + E_ji) / sqrt 2, i (E_ji - E_ij) / sqrt 2  it is a
 // REAL Dm x Dm matrix (c3p_regr.hip uses the same fact at D = 7, 8, 9; the change of basis is c3p_hb_row / c3p_hb_col of
-// c3p_regd.h).  A real general 9 x 9 product is 27 matrix instructions here against 75 of the complex half-image product of
+// c3p_regd.h).  A real general 9 x 9 product is 18 matrix instructions + a rank-1 tail here against 75 of the complex half-image product of
 // c3p_smalld.hip, and everything element-wise is a quarter.
 //
 // The caller asserts Hermitian Hamiltonians (flag C3P_HERMITIAN_H of c3p_pwc_lindblad: the Python layer sets it after
@@ -203,10 +203,15 @@ __global__ void __launch_bounds__(64) smallr_chain_kernel(SmallRArgs A) {
       for (int J = 0; J < NB; ++J) img[woff + 4 * I * WR + 4 * J] = M[I][J];
     sr_sync();
   };
-  // acc += (image) Bm
+  // acc += (image) Bm.  Dm = 1 (mod 4): the K dimension is exact -- NB - 1 steps of four on the matrix cores and the last
+  // index as a rank-1 update (column Dm-1 of the left operand from the image, row Dm-1 of the right one from the lanes
+  // (0, c) of its last tile row): 18 + a 9-FMA tail instead of 27 matrix instructions at Dm = 9
+  constexpr bool TAIL = (DM % 4 == 1) && DM > 4;
+  constexpr int KM = TAIL ? NB - 1 : NB;
+  const int row0_lane = 4 * b + c;
   auto mm = [&](const RMat& Bm, RMat& acc) {
 #pragma unroll
-    for (int Kk = 0; Kk < NB; ++Kk) {
+    for (int Kk = 0; Kk < KM; ++Kk) {
       double a[NB];
 #pragma unroll
       for (int I = 0; I < NB; ++I) a[I] = sr_ld(img + roff + 4 * I * WR + 4 * Kk);
@@ -214,6 +219,17 @@ __global__ void __launch_bounds__(64) smallr_chain_kernel(SmallRArgs A) {
       for (int I = 0; I < NB; ++I)
 #pragma unroll
         for (int J = 0; J < NB; ++J) acc[I][J] = sr_mfma4(a[I], Bm[Kk][J], acc[I][J]);
+    }
+    if constexpr (TAIL) {
+      double a8[NB], b8[NB];
+#pragma unroll
+      for (int I = 0; I < NB; ++I) a8[I] = sr_ld(img + b * RIMG + (4 * I + r) * WR + (DM - 1));
+#pragma unroll
+      for (int J = 0; J < NB; ++J) b8[J] = __shfl(Bm[NB - 1][J], row0_lane);
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) acc[I][J] = fma(a8[I], b8[J], acc[I][J]);
     }
   };
   // out = c0 I + cx X + c2 A2 + c3 A3 + c6 A6
@@ -235,6 +251,27 @@ __global__ void __launch_bounds__(64) smallr_chain_kernel(SmallRArgs A) {
     for (int I = 0; I < NB; ++I)
 #pragma unroll
       for (int J = 0; J < NB; ++J) M[I][J] = 0.0;
+  };
+
+  // a REAL matrix M' (in the chain's image) -> f T^+ M' T, the complex matrix in the reference's vectorisation (c3p_hb_col: at
+  // most two non-zeros per column of T); the 16 lanes of a chain share its Dm^2 elements
+  constexpr int Dh = (DM == 4) ? 2 : 3;
+  auto image_to_complex = [&](cplx* dst, double f, bool store) {
+    for (int e = idx16; e < DM * DM; e += 16) {
+      const int al = e / DM, be = e - al * DM;
+      int ia[2], ib[2];
+      cplx ta[2], tb[2];
+      const int na = c3p_hb_col(al, Dh, ia, ta), nb = c3p_hb_col(be, Dh, ib, tb);
+      cplx z = cmake(0.0, 0.0);
+      for (int x = 0; x < na; ++x)
+        for (int y = 0; y < nb; ++y) {
+          const cplx cf = cmul(cconj(ta[x]), tb[y]);
+          const double v = img[b * RIMG + ia[x] * WR + ib[y]];
+          z.x = fma(cf.x, v, z.x);
+          z.y = fma(cf.y, v, z.y);
+        }
+      if (store) dst[e] = cmake(f * z.x, f * z.y);
+    }
   };
 
   RMat U;
@@ -296,13 +333,17 @@ __global__ void __launch_bounds__(64) smallr_chain_kernel(SmallRArgs A) {
 #pragma unroll
         for (int J = 0; J < NB; ++J) P[I][J] = Q[I][J];
     }
+    if (A.dUs_out) {  // the slice propagator e^{mu} exp(X - mu), for the backward sweep of the gradient entries
+      to_image(P);
+      image_to_complex(A.dUs_out + ((long)sample * A.N + n0 + (act ? t : 0)) * DM * DM, exp(mu), act);
+    }
     if (t == 0) {
 #pragma unroll
       for (int I = 0; I < NB; ++I)
 #pragma unroll
         for (int J = 0; J < NB; ++J) U[I][J] = P[I][J];
     } else {
-      to_image(P);
+      if (!A.dUs_out) to_image(P);
       RMat V;
       zero(V);
       mm(U, V);
@@ -313,27 +354,9 @@ __global__ void __launch_bounds__(64) smallr_chain_kernel(SmallRArgs A) {
     }
     mus += mu;
   }
-  // the REAL segment product U' -> the complex matrix T^+ U' T in the reference's vectorisation (c3p_hb_col: at most two
-  // non-zeros per column of T), through the chain's image: 16 lanes share the Dm^2 elements of their chain
+  // the REAL segment product U' -> the complex matrix e^{sum mu} T^+ U' T
   to_image(U);
-  const double er = exp(mus);
-  cplx* dst = A.seg_out + cc * DM * DM;
-  constexpr int Dh = (DM == 4) ? 2 : 3;
-  for (int e = idx16; e < DM * DM; e += 16) {
-    const int al = e / DM, be = e - al * DM;
-    int ia[2], ib[2];
-    cplx ta[2], tb[2];
-    const int na = c3p_hb_col(al, Dh, ia, ta), nb = c3p_hb_col(be, Dh, ib, tb);
-    cplx z = cmake(0.0, 0.0);
-    for (int x = 0; x < na; ++x)
-      for (int y = 0; y < nb; ++y) {
-        const cplx cf = cmul(cconj(ta[x]), tb[y]);
-        const double v = img[b * RIMG + ia[x] * WR + ib[y]];
-        z.x = fma(cf.x, v, z.x);
-        z.y = fma(cf.y, v, z.y);
-      }
-    if (valid) dst[e] = cmake(er * z.x, er * z.y);
-  }
+  image_to_complex(A.seg_out + cc * DM * DM, exp(mus), valid);
 }
 
 template <int DM>

@@ -440,7 +440,8 @@ def propagate_batch_lindblad_taped(h0, hks, signals, dt: float, col_ops, *, fr_p
     U = call.empty((B, Dm, Dm))
     _lib.check(
         lib.c3p_pwc_lindblad_taped(
-            _ptr(h0), h0_bs, _ptr(hks), hk_bs, _ptr(signals), _ptr(col), int(col.shape[0]), float(dt), B, K, N, D, 0, _ptr(fr_phase), _ptr(U),
+            _ptr(h0), h0_bs, _ptr(hks), hk_bs, _ptr(signals), _ptr(col), int(col.shape[0]), float(dt), B, K, N, D,
+            _lib.HERMITIAN_H if D in (2, 3) and _is_hermitian(call, h0) and _is_hermitian(call, hks) else 0, _ptr(fr_phase), _ptr(U),
             buf.data_ptr(), nbytes, int(seg.value), call.stream
         )
     )
@@ -516,7 +517,8 @@ def propagate_batch_lindblad_vjp(h0, hks, signals, dt: float, col_ops, U_bar, *,
         grad = np.empty((B, K, N), dtype=np.float64)
     _lib.check(
         _lib.load().c3p_pwc_lindblad_vjp(
-            _ptr(h0), h0_bs, _ptr(hks), hk_bs, _ptr(signals), _ptr(col), int(col.shape[0]), float(dt), B, K, N, D, call.flags,
+            _ptr(h0), h0_bs, _ptr(hks), hk_bs, _ptr(signals), _ptr(col), int(col.shape[0]), float(dt), B, K, N, D,
+            call.flags | (_lib.HERMITIAN_H if D in (2, 3) and _is_hermitian(call, h0) and _is_hermitian(call, hks) else 0),
             _ptr(fr_phase), _ptr(U_bar), _ptr(grad), call.stream
         )
     )

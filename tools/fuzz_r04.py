@@ -135,6 +135,18 @@ while time.time() < t_end:
         e2 = max(np.abs(g1 - g0).max() / max(np.abs(g0).max(), 1e-300), np.abs(r["U"].cpu().numpy() - U0).max())
         assert e2 < 1e-10, ("taped small", Dl, Bl, Kl, Nl, ps, e2)
         e = max(e, e2)
+        # the real Hermitian-basis forward kernels (Hermitian Hamiltonians: the flag is set) against the complex ones
+        h0h = np.stack([herm(Dl, float(rng.choice([0.3, 0.8, 6.0]))) for _ in range(nb)])
+        if not ps:
+            h0h = h0h[0]
+        Nr = int(rng.integers(1, 400))
+        sgr = rng.uniform(-1, 1, size=(Bl, Kl, Nr))
+        xr = np.asarray(prop.propagate_batch(h0h, hkl, sgr, 0.2, col_ops=col, lindbladian=True, fr_phase=phl)["U"])
+        with _lib.options(no_smallr=1):
+            yr = np.asarray(prop.propagate_batch(h0h, hkl, sgr, 0.2, col_ops=col, lindbladian=True, fr_phase=phl)["U"])
+        e3 = np.abs(xr - yr).max() / max(1.0, np.abs(yr).max())
+        assert e3 < 1e-11, ("small real", Dl, Bl, Kl, Nr, ps, e3)
+        e = max(e, e3)
     else:
         D = int(rng.choice([3, 6, 9, 12, 18, 27, 33, 40]))
         B, K, N = int(rng.integers(1, 6)), int(rng.integers(1, 4)), int(rng.integers(70, 260))
