@@ -955,6 +955,106 @@ int lind_small_backward(DeviceWs* w, const LindSmallBufs& bf, bool per_sample, c
   LAUNCH_TRY(c3p_launch_smalld_grad_general(g, st));
   return 0;
 }
+// The same two halves in REAL arithmetic in the Hermitian basis (declared Hermitian Hamiltonians, C3P_HERMITIAN_H; c3p_smallr.hip):
+// real tables of G' and G'^T, real segment products and slice propagators from the forward half; the cotangent in the basis
+// (hb_ubar), the real segment scan and the real pair-evaluation sweep in the backward half.  The block is laid out inside
+// the memory the complex halves would use (it is smaller in every part).
+struct LindSmallRSizes {
+  size_t tabs, seg, dus;
+  size_t total() const { return tabs + seg + dus; }
+};
+LindSmallRSizes lind_smallr_sizes(int B, int K, int N, int Dm, int S, int nsamp) {
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  LindSmallRSizes z;
+  z.tabs = up(2 * (size_t)nsamp * c3p_smallr_table_doubles(Dm, K) * sizeof(double)) + up((size_t)nsamp * (1 + K) * sizeof(int));
+  z.seg = up((size_t)B * S * Dm * Dm * sizeof(double));
+  z.dus = up((size_t)B * N * Dm * Dm * sizeof(double));
+  return z;
+}
+struct LindSmallRBufs {
+  double *tabs, *tabs_t;
+  int* flags;
+  double *seg, *dus;
+};
+LindSmallRBufs lind_smallr_carve(void* base, const LindSmallRSizes& z, int nsamp, int Dm, int K) {
+  char* p = static_cast<char*>(base);
+  const size_t td = (size_t)nsamp * c3p_smallr_table_doubles(Dm, K);
+  LindSmallRBufs b;
+  b.tabs = reinterpret_cast<double*>(p);
+  b.tabs_t = b.tabs + td;
+  b.flags = reinterpret_cast<int*>(p + ((2 * td * sizeof(double) + 255) & ~(size_t)255));
+  b.seg = reinterpret_cast<double*>(p + z.tabs);
+  b.dus = reinterpret_cast<double*>(p + z.tabs + z.seg);
+  return b;
+}
+bool lind_smallr_ok(bool hermitian, int D, int Dm, int K, int N, int S) {
+  return hermitian && c3p_smallr_supported(D, Dm, K) && !c3p_opt_on(C3P_OPT_no_smallr) &&
+         c3p_smallr_lds_bytes(Dm, K, (N + S - 1) / S) <= (size_t)60 * 1024 && c3p_smallr_grad_lds_bytes(Dm, K, (N + S - 1) / S) <= (size_t)60 * 1024;
+}
+// forward half; seg_complex (workspace, [B,S,Dm,Dm]) receives the segment products in the reference's vectorisation for U
+int lind_smallr_forward(const LindSmallRBufs& bf, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals, const cplx* clp,
+                        double dt, int B, int K, int N, int D, int Dm, int S, cplx* seg_complex, hipStream_t st) {
+  const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
+  const int nsamp = per_sample ? B : 1;
+  RegdPrepArgs rp = {};
+  rp.h0 = h0;
+  rp.h0_bstride = h0_bs;
+  rp.hks = hks;
+  rp.hks_bstride = hk_bs;
+  rp.clp = clp;
+  rp.dt = dt;
+  rp.K = K;
+  rp.Dh = D;
+  rp.Dm = Dm;
+  rp.lindblad = 1;
+  LAUNCH_TRY(c3p_launch_smallr_prep(rp, nsamp, bf.tabs, bf.flags, st, 0));
+  LAUNCH_TRY(c3p_launch_smallr_prep(rp, nsamp, bf.tabs_t, bf.flags, st, 1));
+  SmallRArgs ra = {};
+  ra.tables = bf.tabs;
+  ra.tab_per_sample = per_sample ? 1 : 0;
+  ra.signals = signals;
+  ra.B = B;
+  ra.K = K;
+  ra.N = N;
+  ra.Dm = Dm;
+  ra.S = S;
+  ra.Lmax = (N + S - 1) / S;
+  ra.seg_out = seg_complex;
+  ra.seg_real = bf.seg;
+  ra.dus_real = bf.dus;
+  LAUNCH_TRY(c3p_launch_smallr_chain(ra, st));
+  return 0;
+}
+int lind_smallr_backward(DeviceWs* w, const LindSmallRBufs& bf, bool per_sample, const double* signals, int B, int K, int N, int D, int Dm, int S,
+                         const double* fr_phase, const cplx* Ubar, double* grad, hipStream_t st) {
+  const size_t m8 = (size_t)Dm * Dm * sizeof(double);
+  void *uv, *pv, *sv, *qv;
+  if (ws_get(w, SL_SCRATCH, (size_t)B * m8, &uv)) return -1;
+  if (ws_get(w, SL_SEG_A, (size_t)B * S * m8, &pv)) return -1;
+  if (ws_get(w, SL_SEG_B, (size_t)B * S * m8, &sv)) return -1;
+  if (ws_get(w, SL_SEG_F, (size_t)B * N * m8, &qv)) return -1;
+  LAUNCH_TRY(c3p_launch_hb_ubar(Ubar, fr_phase, B, D, (double*)uv, st));
+  LAUNCH_TRY(c3p_launch_smallr_scan(bf.seg, (const double*)uv, B, S, Dm, (double*)pv, (double*)sv, st));
+  SmallRGradArgs g = {};
+  g.tables = bf.tabs;
+  g.tables_t = bf.tabs_t;
+  g.tab_per_sample = per_sample ? 1 : 0;
+  g.signals = signals;
+  g.pre = (const double*)pv;
+  g.suf = (const double*)sv;
+  g.dus = bf.dus;
+  g.pstore = (double*)qv;
+  g.grad = grad;
+  g.B = B;
+  g.K = K;
+  g.N = N;
+  g.Dm = Dm;
+  g.S = S;
+  g.Lmax = (N + S - 1) / S;
+  LAUNCH_TRY(c3p_launch_smallr_grad(g, st));
+  return 0;
+}
+
 // Returns 1 when not applicable.
 int run_vjp_lind_smalld(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals, const cplx* clp,
                         double dt, int B, int K, int N, int D, int Dm, const double* fr_phase, const cplx* Ubar, double* grad,
@@ -965,6 +1065,15 @@ int run_vjp_lind_smalld(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks
   const LindSmallSizes z = lind_small_sizes(B, K, N, Dm, S, per_sample ? B : 1);
   void* blk;
   if (ws_get(w, SL_OUT1, z.total(), &blk)) return -1;
+  if (lind_smallr_ok(hermitian, D, Dm, K, N, S)) {
+    const int nsamp = per_sample ? B : 1;
+    const LindSmallRSizes zr = lind_smallr_sizes(B, K, N, Dm, S, nsamp);
+    const LindSmallRBufs rb = lind_smallr_carve(blk, zr, nsamp, Dm, K);
+    void* sc;
+    if (ws_get(w, SL_OUT2, (size_t)B * S * Dm * Dm * sizeof(cplx), &sc)) return -1;  // (the complex segment products: not needed here)
+    if (lind_smallr_forward(rb, h0, h0_bs, hks, hk_bs, signals, clp, dt, B, K, N, D, Dm, S, (cplx*)sc, st)) return -1;
+    return lind_smallr_backward(w, rb, per_sample, signals, B, K, N, D, Dm, S, fr_phase, Ubar, grad, st) ? -1 : 0;
+  }
   const LindSmallBufs bf = lind_small_carve(blk, z);
   if (lind_small_forward(w, bf, h0, h0_bs, hks, hk_bs, signals, clp, dt, B, K, N, D, Dm, S, hermitian, st)) return -1;
   return lind_small_backward(w, bf, per_sample, signals, B, K, N, Dm, S, fr_phase, Ubar, grad, st) ? -1 : 0;
@@ -2754,6 +2863,22 @@ int c3p_pwc_lindblad_taped(const void* h0, int64_t h0_bstride, const void* hks, 
     void* clp;
     if (ws_get(w, SL_CLP, (size_t)Dm * Dm * sizeof(cplx), &clp)) return -1;
     LAUNCH_TRY(c3p_launch_clp((const cplx*)col_ops, C, D, (cplx*)clp, st));
+    if (lind_smallr_ok((flags & C3P_HERMITIAN_H) != 0, D, Dm, K, N, segments)) {
+      // declared Hermitian: the tape holds the REAL tables, segment products and slice propagators (c3p_pwc_lindblad_vjp_taped
+      // must be given the same flag); U from the complex copies of the segment products
+      const bool ps = (h0_bstride != 0) || (hks_bstride != 0);
+      const int nsamp = ps ? B : 1;
+      const LindSmallRBufs rb = lind_smallr_carve(tape, lind_smallr_sizes(B, K, N, Dm, segments, nsamp), nsamp, Dm, K);
+      void* sc;
+      if (ws_get(w, SL_OUT2, (size_t)B * segments * Dm * Dm * sizeof(cplx), &sc)) return -1;
+      if (record_start(w, st)) return -1;
+      if (lind_smallr_forward(rb, (const cplx*)h0, h0_bstride, (const cplx*)hks, hks_bstride, signals, (const cplx*)clp, dt, B, K, N, D, Dm, segments,
+                              (cplx*)sc, st))
+        return -1;
+      if (record_stop(w, st)) return -1;
+      g_last_kernel = C3P_KERNEL_SMALLD;
+      return combine_smalld(w, (const cplx*)sc, B, segments, Dm, 0, fr_phase, (cplx*)U_out, st) ? -1 : 0;
+    }
     const LindSmallBufs bf = lind_small_carve(tape, lind_small_sizes(B, K, N, Dm, segments, B));
     if (record_start(w, st)) return -1;
     if (lind_small_forward(w, bf, (const cplx*)h0, h0_bstride, (const cplx*)hks, hks_bstride, signals, (const cplx*)clp, dt, B, K, N, D, Dm, segments,
@@ -2820,7 +2945,7 @@ int c3p_pwc_lindblad_taped(const void* h0, int64_t h0_bstride, const void* hks, 
 int c3p_pwc_lindblad_vjp_taped(const void* tape, size_t tape_bytes, int segments, int per_sample_operators, const double* signals, int B,
                                int K, int N, int D, int flags, const double* fr_phase, const void* U_bar, double* grad_signals,
                                void* stream) {
-  if (flags != 0) return fail("c3p_pwc_lindblad_vjp_taped takes device pointers and no flags");
+  if (flags & ~C3P_HERMITIAN_H) return fail("c3p_pwc_lindblad_vjp_taped takes device pointers and no flags but C3P_HERMITIAN_H (as given to c3p_pwc_lindblad_taped)");
   if (B <= 0 || K < 1 || K > 16 || N <= 0 || D <= 0) return fail("bad sizes B=%d K=%d N=%d D=%d", B, K, N, D);
   const int Dm = D * D;
   if (!tape || !signals || !U_bar || !grad_signals) return fail("NULL pointer argument");
@@ -2835,6 +2960,16 @@ int c3p_pwc_lindblad_vjp_taped(const void* tape, size_t tape_bytes, int segments
     DeviceWs* w = lk.w;
     if (!w) return fail("no HIP device");
     if (!lk.ok) return fail("hipStreamWaitEvent on the previous call's stream failed");
+    if (lind_smallr_ok((flags & C3P_HERMITIAN_H) != 0, D, Dm, K, N, segments)) {
+      const int nsamp = per_sample_operators ? B : 1;
+      const LindSmallRBufs rb = lind_smallr_carve(const_cast<void*>(tape), lind_smallr_sizes(B, K, N, Dm, segments, nsamp), nsamp, Dm, K);
+      if (record_start(w, st)) return -1;
+      if (lind_smallr_backward(w, rb, per_sample_operators != 0, signals, B, K, N, D, Dm, segments, fr_phase, (const cplx*)U_bar, grad_signals, st))
+        return -1;
+      if (record_stop(w, st)) return -1;
+      g_last_kernel = C3P_KERNEL_SMALLD;
+      return 0;
+    }
     const LindSmallBufs bf = lind_small_carve(const_cast<void*>(tape), lind_small_sizes(B, K, N, Dm, segments, B));
     if (record_start(w, st)) return -1;
     if (lind_small_backward(w, bf, per_sample_operators != 0, signals, B, K, N, Dm, segments, fr_phase, (const cplx*)U_bar, grad_signals, st)) return -1;

@@ -14,11 +14,33 @@ struct SmallRArgs {
   int S, Lmax;           // segments per sample, ceil(N / S)
   cplx* seg_out;         // [B,S,Dm,Dm] segment products, already in the reference's (complex) vectorisation
   cplx* dUs_out;         // [B,N,Dm,Dm] slice propagators (complex vectorisation) or null
+  double* seg_real;      // [B,S,Dm,Dm] the same segment products, REAL (Hermitian basis), or null: input of the real backward sweep
+  double* dus_real;      // [B,N,Dm,Dm] the slice propagators, REAL (Hermitian basis), or null
+};
+
+// Backward sweep in the Hermitian basis (smallr_grad_kernel): the general-generator sweep of smalld_grad_general_kernel in real
+// arithmetic -- the prefix in front of every slice from the stored slice propagators, then one pair evaluation
+// (value + derivative of T18) per slice at X_n^T.
+struct SmallRGradArgs {
+  const double* tables;    // G' tables (inner products)
+  const double* tables_t;  // G'^T tables (the matrix that is exponentiated)
+  int tab_per_sample;
+  const double* signals;   // [B,K,N]
+  const double* pre;       // [B,S,Dm,Dm] real prefix in front of every segment
+  const double* suf;       // [B,S,Dm,Dm] real left adjoint behind every segment
+  const double* dus;       // [B,N,Dm,Dm] real slice propagators
+  double* pstore;          // [B,N,Dm,Dm] scratch: the prefix in front of every slice
+  double* grad;            // [B,K,N]
+  int B, K, N, Dm, S, Lmax;
 };
 
 bool c3p_smallr_supported(int Dh, int Dm, int K);
 size_t c3p_smallr_table_doubles(int Dm, int K);
 size_t c3p_smallr_lds_bytes(int Dm, int K, int Lmax);
 // arguments as c3p_launch_regr_prep (lindblad generators of h0 / hks / clp); tabflag [nsamp][1 + K]: 1 = real in the basis
-hipError_t c3p_launch_smallr_prep(const RegdPrepArgs& P, int nsamp, double* tables, int* tabflag, hipStream_t st);
+hipError_t c3p_launch_smallr_prep(const RegdPrepArgs& P, int nsamp, double* tables, int* tabflag, hipStream_t st, int transpose = 0);
+size_t c3p_smallr_grad_lds_bytes(int Dm, int K, int Lmax);
+hipError_t c3p_launch_smallr_grad(const SmallRGradArgs& A, hipStream_t st);
+// pre[j] = S_{j-1} ... S_0 (pre[0] = 1), suf[j] = S_{j+1}^T ... S_{S-1}^T U_bar' from the REAL segment products seg [B,S,Dm,Dm]
+hipError_t c3p_launch_smallr_scan(const double* seg, const double* ubar, int B, int S, int Dm, double* pre, double* suf, hipStream_t st);
 hipError_t c3p_launch_smallr_chain(const SmallRArgs& A, hipStream_t st);

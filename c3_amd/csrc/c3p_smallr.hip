@@ -41,7 +41,7 @@ __device__ __forceinline__ void sr_sync() {
 }
 
 // ---- tables: G' = Re(T G T^+), trace shifted, tile-major ------------------------------------------------------------------
-__global__ void __launch_bounds__(64) smallr_prep_kernel(RegdPrepArgs P, double* tables, int* tabflag) {
+__global__ void __launch_bounds__(64) smallr_prep_kernel(RegdPrepArgs P, double* tables, int* tabflag, int transpose) {
   __shared__ double red0[64], red1[64];
   __shared__ double mu_s;
   const int tid = threadIdx.x;
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(64) smallr_prep_kernel(RegdPrepArgs P, double*
   // every element of T G T^+ by its own thread first (Dm^2 <= 81), norms and the table from the shared copy
   __shared__ double hre[96], him[96];
   for (int e = tid; e < D * D; e += 64) {
-    const cplx v = helem(e / D, e % D);
+    const cplx v = transpose ? helem(e % D, e / D) : helem(e / D, e % D);  // (transpose: the tables of G'^T, for the backward sweep)
     hre[e] = v.x;
     him[e] = v.y;
   }
@@ -333,6 +333,17 @@ __global__ void __launch_bounds__(64) smallr_chain_kernel(SmallRArgs A) {
 #pragma unroll
         for (int J = 0; J < NB; ++J) P[I][J] = Q[I][J];
     }
+    if (A.dus_real && act) {  // the slice propagator, real: input of the real backward sweep
+      const double em = exp(mu);
+      double* dr = A.dus_real + ((long)sample * A.N + n0 + t) * DM * DM;
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) {
+          const int row = 4 * I + r, col = 4 * J + c;
+          if (row < DM && col < DM) dr[row * DM + col] = em * P[I][J];
+        }
+    }
     if (A.dUs_out) {  // the slice propagator e^{mu} exp(X - mu), for the backward sweep of the gradient entries
       to_image(P);
       image_to_complex(A.dUs_out + ((long)sample * A.N + n0 + (act ? t : 0)) * DM * DM, exp(mu), act);
@@ -354,9 +365,370 @@ __global__ void __launch_bounds__(64) smallr_chain_kernel(SmallRArgs A) {
     }
     mus += mu;
   }
+  if (A.seg_real && valid) {
+    const double em = exp(mus);
+    double* dr = A.seg_real + cc * DM * DM;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) {
+        const int row = 4 * I + r, col = 4 * J + c;
+        if (row < DM && col < DM) dr[row * DM + col] = em * U[I][J];
+      }
+  }
   // the REAL segment product U' -> the complex matrix e^{sum mu} T^+ U' T
   to_image(U);
   image_to_complex(A.seg_out + cc * DM * DM, exp(mus), valid);
+}
+
+// ---- segment scan, real: pre[j] = S_{j-1} ... S_0 (pre[0] = 1), suf[j] = S_{j+1}^T ... S_{S-1}^T U_bar' ------------------------
+// one wavefront per (sample, direction): the chains of S - 1 dependent Dm x Dm products run from LDS without workgroup barriers
+template <int DM>
+__global__ void __launch_bounds__(64) smallr_scan_kernel(const double* seg, const double* ubar, int S, double* pre, double* suf) {
+  constexpr int M2 = DM * DM;
+  __shared__ double cur[2][96], sg[96];
+  const int lane = threadIdx.x;
+  const long bidx = blockIdx.x;
+  const bool fwd = blockIdx.y == 0;
+  const double* sb = seg + bidx * S * M2;
+  double* out = (fwd ? pre : suf) + bidx * S * M2;
+  int w = 0;
+  for (int e = lane; e < M2; e += 64) cur[0][e] = fwd ? ((e / DM == e % DM) ? 1.0 : 0.0) : ubar[bidx * M2 + e];
+  sr_sync();
+  for (int step = 0; step < S; ++step) {
+    const int j = fwd ? step : S - 1 - step;
+    for (int e = lane; e < M2; e += 64) out[(long)j * M2 + e] = cur[w][e];
+    if (step == S - 1) break;
+    const double* sj = sb + (long)(fwd ? j : j) * M2;  // forward: S_j takes pre[j] to pre[j + 1]; backward: S_j^T takes suf[j] to suf[j - 1]
+    for (int e = lane; e < M2; e += 64) sg[e] = sj[e];
+    sr_sync();
+    for (int e = lane; e < M2; e += 64) {
+      const int i = e / DM, jx = e - i * DM;
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < DM; ++k) acc = fma(fwd ? sg[i * DM + k] : sg[k * DM + i], cur[w][k * DM + jx], acc);
+      cur[w ^ 1][e] = acc;
+    }
+    sr_sync();
+    w ^= 1;
+  }
+}
+
+// ---- backward sweep --------------------------------------------------------------------------------------------------------
+template <int DM>
+__global__ void __launch_bounds__(64, 1) smallr_grad_kernel(SmallRGradArgs A) {
+  using G = RG<DM>;
+  constexpr int NB = G::NB, WR = G::WR, RIMG = G::RIMG, TABD = G::TABD, TILES = G::TILES;
+  constexpr int M2 = DM * DM;
+  typedef double RMat[NB][NB];
+  const int lane = threadIdx.x;
+  const int r = lane >> 4, b = (lane >> 2) & 3, c = lane & 3, idx16 = r * 4 + c;
+  const int K = A.K;
+  double* tab = c3p_sr_lds;             // G' tables: inner products
+  double* tabt = tab + (1 + K) * TABD;  // G'^T tables: the matrix that is exponentiated
+  double* img0 = tabt + (1 + K) * TABD;
+  double* img1 = img0 + 4 * RIMG;
+  double* sg = img1 + 4 * RIMG;
+
+  const long chain = (long)blockIdx.x * 4 + b;
+  const long nchains = (long)A.B * A.S;
+  const bool valid = chain < nchains;
+  const long cc = valid ? chain : nchains - 1;
+  const int sample = (int)(cc / A.S);
+  const int seg = (int)(cc - (long)sample * A.S);
+  const int n0 = (int)(((long)seg * A.N) / A.S);
+  const int n1 = (int)(((long)(seg + 1) * A.N) / A.S);
+  const int len = n1 - n0;
+
+  const long tsz = (long)(1 + K) * TABD;
+  const double* gt0 = A.tables + (long)(A.tab_per_sample ? sample : 0) * tsz;
+  const double* gh0 = A.tables_t + (long)(A.tab_per_sample ? sample : 0) * tsz;
+  for (int e = lane; e < (int)tsz; e += 64) {
+    tab[e] = gt0[e];
+    tabt[e] = gh0[e];
+  }
+  __syncthreads();
+  double nrm = tabt[TILES + 1];
+  for (int k = 0; k < K; ++k) {
+    const double* s = A.signals + ((long)sample * K + k) * A.N + n0;
+    double cmax = 0.0;
+    for (int t = idx16; t < A.Lmax; t += 16) {
+      const double v = (valid && t < len) ? s[t] : 0.0;
+      sg[(b * K + k) * A.Lmax + t] = v;
+      cmax = fmax(cmax, fabs(v));
+    }
+    cmax = fmax(cmax, __shfl_xor(cmax, 1));
+    cmax = fmax(cmax, __shfl_xor(cmax, 2));
+    cmax = fmax(cmax, __shfl_xor(cmax, 16));
+    cmax = fmax(cmax, __shfl_xor(cmax, 32));
+    nrm = fma(cmax, tabt[(k + 1) * TABD + TILES + 1], nrm);
+  }
+  __syncthreads();
+  nrm = fmax(nrm, __shfl_xor(nrm, 4));
+  nrm = fmax(nrm, __shfl_xor(nrm, 8));
+  int ps = 0;
+  {
+    double pth = C3P_T18_THETA;
+    while (pth < nrm && ps < 40) {
+      pth *= 2.0;
+      ++ps;
+    }
+  }
+  ps = __builtin_amdgcn_readfirstlane(ps);
+  const double scale = ldexp(1.0, -ps);
+
+  const int woff = b * RIMG + r * WR + c;
+  const int roff = b * RIMG + c * WR + r;
+  constexpr bool TAIL = (DM % 4 == 1) && DM > 4;
+  constexpr int KM = TAIL ? NB - 1 : NB;
+  const int row0_lane = 4 * b + c;
+  auto to_image = [&](double* img, const RMat& M) {
+    sr_sync();
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) img[woff + 4 * I * WR + 4 * J] = M[I][J];
+    sr_sync();
+  };
+  auto mm = [&](const double* img, const RMat& Bm, RMat& acc) {  // acc += (image) Bm
+#pragma unroll
+    for (int Kk = 0; Kk < KM; ++Kk) {
+      double a[NB];
+#pragma unroll
+      for (int I = 0; I < NB; ++I) a[I] = sr_ld(img + roff + 4 * I * WR + 4 * Kk);
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) acc[I][J] = sr_mfma4(a[I], Bm[Kk][J], acc[I][J]);
+    }
+    if constexpr (TAIL) {
+      double a8[NB], b8[NB];
+#pragma unroll
+      for (int I = 0; I < NB; ++I) a8[I] = sr_ld(img + b * RIMG + (4 * I + r) * WR + (DM - 1));
+#pragma unroll
+      for (int J = 0; J < NB; ++J) b8[J] = __shfl(Bm[NB - 1][J], row0_lane);
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) acc[I][J] = fma(a8[I], b8[J], acc[I][J]);
+    }
+  };
+  auto comb = [&](RMat& out, double c0, double cx, double c2, double c3, double c6, const RMat& X, const RMat& A2, const RMat& A3, const RMat& A6) {
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) {
+        double v = cx * X[I][J];
+        v = fma(c2, A2[I][J], v);
+        v = fma(c3, A3[I][J], v);
+        v = fma(c6, A6[I][J], v);
+        if (I == J) v += (r == c && 4 * I + r < DM) ? c0 : 0.0;
+        out[I][J] = v;
+      }
+  };
+  auto zero = [&](RMat& M) {
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) M[I][J] = 0.0;
+  };
+  auto load_real = [&](RMat& M, const double* src, bool on, bool TR) {  // row-major Dm x Dm (TR: its transpose) -> tiles
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) {
+        const int row = 4 * I + r, col = 4 * J + c;
+        M[I][J] = (on && row < DM && col < DM) ? (TR ? src[col * DM + row] : src[row * DM + col]) : 0.0;
+      }
+  };
+  auto set_identity = [&](RMat& M) {
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) M[I][J] = (I == J && r == c && 4 * I + r < DM) ? 1.0 : 0.0;
+  };
+
+  // ---- forward: the prefix in front of every slice of the segment ----
+  double* pst = A.pstore + ((long)sample * A.N + n0) * M2;
+  {
+    RMat P;
+    load_real(P, A.pre + cc * M2, valid, false);
+    const double* du = A.dus + ((long)sample * A.N + n0) * M2;
+    for (int t = 0; t < A.Lmax; ++t) {
+      const bool act = valid && t < len;
+      if (act) {
+        double* dst = pst + (long)t * M2;
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+          for (int J = 0; J < NB; ++J) {
+            const int row = 4 * I + r, col = 4 * J + c;
+            if (row < DM && col < DM) dst[row * DM + col] = P[I][J];
+          }
+      }
+      if (t + 1 == A.Lmax) break;
+      RMat E, V;
+      load_real(E, du + (long)(act ? t : 0) * M2, act, false);
+      if (!act) set_identity(E);
+      to_image(img0, E);
+      zero(V);
+      mm(img0, P, V);
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) P[I][J] = V[I][J];
+    }
+  }
+  __threadfence_block();
+
+  // ---- backward ----
+  RMat Aa;  // left adjoint, without the trace shifts of the slices behind it: they accumulate in ams
+  load_real(Aa, A.suf + cc * M2, valid, false);
+  double ams = 0.0;
+  for (int t = A.Lmax - 1; t >= 0; --t) {
+    const bool act = valid && t < len;
+    const double sc = act ? scale : 0.0;
+    RMat X, dX;
+    {
+      RMat PH, Mn;
+      load_real(PH, pst + (long)(act ? t : 0) * M2, act, true);
+      to_image(img0, Aa);
+      zero(Mn);
+      mm(img0, PH, Mn);  // M_n = A P_n^T
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) dX[I][J] = scale * Mn[I][J];
+    }
+    double mu = act ? tabt[TILES + 0] : 0.0;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = 0; J < NB; ++J) X[I][J] = sc * tabt[(I * NB + J) * 16 + idx16];
+    for (int k = 0; k < K; ++k) {
+      const double c0 = sg[(b * K + k) * A.Lmax + t];  // zero for inactive slices
+      const double ck = sc * c0;
+      const double* tk = tabt + (k + 1) * TABD;
+      mu = fma(c0, tk[TILES + 0], mu);
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) X[I][J] = fma(ck, tk[(I * NB + J) * 16 + idx16], X[I][J]);
+    }
+    // pair evaluation of T18: value and derivative in the direction dX (as smalld_grad_general_kernel, real)
+    to_image(img0, X);
+    to_image(img1, dX);
+    RMat A2, dA2, A3, dA3, A6, dA6;
+    zero(A2), zero(dA2), zero(A3), zero(dA3), zero(A6), zero(dA6);
+    mm(img0, X, A2);
+    mm(img0, dX, dA2);
+    mm(img1, X, dA2);
+    mm(img0, A2, A3);
+    mm(img0, dA2, dA3);
+    mm(img1, A2, dA3);
+    to_image(img0, A3);
+    to_image(img1, dA3);
+    mm(img0, A3, A6);
+    mm(img0, dA3, dA6);
+    mm(img1, A3, dA6);
+    RMat A9, dA9;
+    {
+      RMat B1, dB1;
+      comb(B1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0, X, A2, A3, A6);
+      comb(dB1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0, dX, dA2, dA3, dA6);
+      to_image(img0, B1);
+      to_image(img1, dB1);
+    }
+    {
+      RMat B5, dB5;
+      comb(B5, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64, X, A2, A3, A6);
+      comb(dB5, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64, dX, dA2, dA3, dA6);
+      comb(A9, C3P_T18_B03, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63, X, A2, A3, A6);
+      comb(dA9, 0.0, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63, dX, dA2, dA3, dA6);
+      mm(img0, B5, A9);
+      mm(img0, dB5, dA9);
+      mm(img1, B5, dA9);
+    }
+    RMat T, dT;
+    {
+      RMat L, dL;
+      comb(L, C3P_T18_B02, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62, X, A2, A3, A6);
+      comb(dL, 0.0, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62, dX, dA2, dA3, dA6);
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) {
+          L[I][J] += A9[I][J];
+          dL[I][J] += dA9[I][J];
+        }
+      to_image(img0, L);
+      to_image(img1, dL);
+    }
+    comb(T, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61, X, A2, A3, A6);
+    comb(dT, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61, dX, dA2, dA3, dA6);
+    mm(img0, A9, T);
+    mm(img0, dA9, dT);
+    mm(img1, A9, dT);
+    for (int it = 0; it < ps; ++it) {
+      to_image(img0, T);
+      to_image(img1, dT);
+      RMat T2, dT2;
+      zero(T2), zero(dT2);
+      mm(img0, T, T2);
+      mm(img0, dT, dT2);
+      mm(img1, T, dT2);
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) {
+          T[I][J] = T2[I][J];
+          dT[I][J] = dT2[I][J];
+        }
+    }
+    // grad[k] = e^{ams + mu} <dT, G'_k> (the tables hold G'_k - mu_k 1: the trace part separately)
+    {
+      const double ef = exp(ams + mu);
+      double trz = 0.0;
+#pragma unroll
+      for (int I = 0; I < NB; ++I) trz += (r == c && 4 * I + r < DM) ? dT[I][I] : 0.0;
+      for (int k = 0; k < K; ++k) {
+        const double* tk = tab + (k + 1) * TABD;
+        double part = tk[TILES + 0] * trz;
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+          for (int J = 0; J < NB; ++J) part = fma(dT[I][J], tk[(I * NB + J) * 16 + idx16], part);
+        part *= ef;
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (act && idx16 == 0) A.grad[((long)sample * K + k) * A.N + n0 + t] = part;
+      }
+    }
+    // A <- dU_n^T A = e^{mu} T A
+    {
+      RMat V;
+      to_image(img0, T);
+      zero(V);
+      mm(img0, Aa, V);
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J < NB; ++J) Aa[I][J] = V[I][J];
+      ams += mu;
+    }
+  }
+}
+
+template <int DM>
+hipError_t launch_grad_t(const SmallRGradArgs& A, hipStream_t st) {
+  using G = RG<DM>;
+  const long nchains = (long)A.B * A.S;
+  const size_t lds = (size_t)(2 * (1 + A.K) * G::TABD + 8 * G::RIMG + 4 * A.K * A.Lmax) * sizeof(double);
+  if (lds > 60 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(smallr_grad_kernel<DM>, dim3((unsigned)((nchains + 3) / 4)), dim3(64), lds, st, A);
+  return hipGetLastError();
 }
 
 template <int DM>
@@ -383,8 +755,8 @@ size_t c3p_smallr_lds_bytes(int Dm, int K, int Lmax) {
   return (size_t)((1 + K) * (NB * NB * 16 + 4) + 4 * 4 * NB * (4 * NB + 1) + 4 * K * Lmax) * sizeof(double);
 }
 
-hipError_t c3p_launch_smallr_prep(const RegdPrepArgs& P, int nsamp, double* tables, int* tabflag, hipStream_t st) {
-  hipLaunchKernelGGL(smallr_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K))), dim3(64), 0, st, P, tables, tabflag);
+hipError_t c3p_launch_smallr_prep(const RegdPrepArgs& P, int nsamp, double* tables, int* tabflag, hipStream_t st, int transpose) {
+  hipLaunchKernelGGL(smallr_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K))), dim3(64), 0, st, P, tables, tabflag, transpose);
   return hipGetLastError();
 }
 
@@ -394,4 +766,27 @@ hipError_t c3p_launch_smallr_chain(const SmallRArgs& A, hipStream_t st) {
     case 9: return launch_chain_t<9>(A, st);
     default: return hipErrorInvalidValue;
   }
+}
+
+size_t c3p_smallr_grad_lds_bytes(int Dm, int K, int Lmax) {
+  const int NB = (Dm + 3) / 4;
+  return (size_t)(2 * (1 + K) * (NB * NB * 16 + 4) + 8 * 4 * NB * (4 * NB + 1) + 4 * K * Lmax) * sizeof(double);
+}
+
+hipError_t c3p_launch_smallr_grad(const SmallRGradArgs& A, hipStream_t st) {
+  switch (A.Dm) {
+    case 4: return launch_grad_t<4>(A, st);
+    case 9: return launch_grad_t<9>(A, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t c3p_launch_smallr_scan(const double* seg, const double* ubar, int B, int S, int Dm, double* pre, double* suf, hipStream_t st) {
+  if (Dm == 4)
+    hipLaunchKernelGGL(smallr_scan_kernel<4>, dim3((unsigned)B, 2), dim3(64), 0, st, seg, ubar, S, pre, suf);
+  else if (Dm == 9)
+    hipLaunchKernelGGL(smallr_scan_kernel<9>, dim3((unsigned)B, 2), dim3(64), 0, st, seg, ubar, S, pre, suf);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
 }

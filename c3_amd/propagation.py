@@ -375,9 +375,10 @@ class LindbladTape:
     reference's GradientTape keeps those of `tf_propagation_lind` (propagation.py:551-585 under optimizers/optimizer.py:206-216):
     `tape.vjp(U_bar)` returns d loss / d signals [B,K,N] without a second forward pass."""
 
-    def __init__(self, buf, nbytes, segments, per_sample, signals, B, K, N, D, fr_phase):
+    def __init__(self, buf, nbytes, segments, per_sample, signals, B, K, N, D, fr_phase, flags=0):
         self.buf, self.nbytes, self.segments, self.per_sample = buf, nbytes, segments, per_sample
         self.signals, self.B, self.K, self.N, self.D, self.fr_phase = signals, B, K, N, D, fr_phase
+        self.flags = flags  # C3P_HERMITIAN_H as given to the forward call: it selects the layout of the tape
 
     def vjp(self, U_bar):
         import torch
@@ -390,7 +391,7 @@ class LindbladTape:
         grad = torch.empty((self.B, self.K, self.N), dtype=torch.float64, device=dev)
         _lib.check(
             _lib.load().c3p_pwc_lindblad_vjp_taped(
-                self.buf.data_ptr(), self.nbytes, self.segments, 1 if self.per_sample else 0, self.signals.data_ptr(), self.B, self.K, self.N, self.D, 0,
+                self.buf.data_ptr(), self.nbytes, self.segments, 1 if self.per_sample else 0, self.signals.data_ptr(), self.B, self.K, self.N, self.D, self.flags,
                 _ptr(self.fr_phase), U_bar.data_ptr(), grad.data_ptr(), torch.cuda.current_stream(dev).cuda_stream
             )
         )
@@ -438,14 +439,15 @@ def propagate_batch_lindblad_taped(h0, hks, signals, dt: float, col_ops, *, fr_p
         raise C3PropError(f"C3:Error: the taped Lindblad evaluation serves D = 2, 3 (up to 8 control lines) and D = 7, 8, 9 (up to 16), got D={D} K={K}")
     buf = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=call.dev)
     U = call.empty((B, Dm, Dm))
+    tflags = _lib.HERMITIAN_H if D in (2, 3) and _is_hermitian(call, h0) and _is_hermitian(call, hks) else 0
     _lib.check(
         lib.c3p_pwc_lindblad_taped(
             _ptr(h0), h0_bs, _ptr(hks), hk_bs, _ptr(signals), _ptr(col), int(col.shape[0]), float(dt), B, K, N, D,
-            _lib.HERMITIAN_H if D in (2, 3) and _is_hermitian(call, h0) and _is_hermitian(call, hks) else 0, _ptr(fr_phase), _ptr(U),
+            tflags, _ptr(fr_phase), _ptr(U),
             buf.data_ptr(), nbytes, int(seg.value), call.stream
         )
     )
-    return {"U": U, "tape": LindbladTape(buf, nbytes, int(seg.value), bool(h0_bs or hk_bs), signals, B, K, N, D, fr_phase)}
+    return {"U": U, "tape": LindbladTape(buf, nbytes, int(seg.value), bool(h0_bs or hk_bs), signals, B, K, N, D, fr_phase, tflags)}
 
 
 def propagate_per_slice_vjp(hs, dt: float, U_bar, *, fr_phase=None):
