@@ -389,10 +389,36 @@ int pick_segments(int B, int N, int K, int Dm, bool need_mult4, long slots = 819
 // in the Hermitian basis on the small-D tile layout (c3p_smallr.hip).  Real generator tables -> segment products (turned back
 // into the reference's vectorisation by the chain that formed them) -> ordered product with the frame phases (the
 // supplied-matrix mode of the complex small-D chain kernel).  Returns 1 when not applicable.
+int combine_midd(DeviceWs* w, const cplx* cur, int B, int count, int Dm, int right_order, const double* fr_phase, cplx* U_out, hipStream_t st);
+// segments of the real Hermitian-basis kernels at Dm = 16 (two qubits; one wavefront = four chains, one wavefront per SIMD:
+// 4096 chain slots): the S that minimises rounds x segment length within the LDS of both kernels; -1 = none
+int pick_segments_r(int B, int N, int K, int Dm, bool need_mult4, bool with_grad) {
+  if (c3p_opt(C3P_OPT_smalld_segments) > 0) {
+    const long S = c3p_opt(C3P_OPT_smalld_segments);
+    if (S >= 1 && S <= N && (!need_mult4 || S % 4 == 0)) return (int)S;
+  }
+  long best = -1;
+  double best_cost = 1e300;
+  const long smax = N < 4096 ? N : 4096;
+  for (long S = 1; S <= smax; ++S) {
+    if (S > 1 && (S % 4) != 0 && S + 3 <= N) continue;
+    if (need_mult4 && (S % 4) != 0) continue;
+    const int Lmax = (int)((N + S - 1) / S);
+    if (c3p_smallr_lds_bytes(Dm, K, Lmax) > (size_t)60 * 1024) continue;
+    if (with_grad && c3p_smallr_grad_lds_bytes(Dm, K, Lmax) > (size_t)60 * 1024) continue;
+    const long rounds = ((long)B * S + 4095) / 4096;
+    const double cost = (double)rounds * (double)(Lmax + 8);
+    if (cost < best_cost * (1.0 - 1e-9)) {
+      best_cost = cost;
+      best = S;
+    }
+  }
+  return (int)best;
+}
 int run_pwc_smallr(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals, const cplx* clp, double dt,
                    int B, int K, int N, int D, int Dm, const double* fr_phase, cplx* U_out, hipStream_t st) {
   const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
-  int S = pick_segments(B, N, K, Dm, per_sample);
+  int S = Dm > 12 ? pick_segments_r(B, N, K, Dm, per_sample, false) : pick_segments(B, N, K, Dm, per_sample);
   if (S < 0) return 1;
   while (S < N && c3p_smallr_lds_bytes(Dm, K, (N + S - 1) / S) > (size_t)60 * 1024) S += per_sample ? 4 : 1;
   if (c3p_smallr_lds_bytes(Dm, K, (N + S - 1) / S) > (size_t)60 * 1024) return 1;
@@ -431,6 +457,13 @@ int run_pwc_smallr(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, lon
   if (record_start(w, st)) return -1;
   LAUNCH_TRY(c3p_launch_smallr_chain(a, st));
   if (record_stop(w, st)) return -1;
+  if (Dm > 12) {
+    g_last_kernel = C3P_KERNEL_MFMA;
+    const int keep = g_last_kernel;
+    const int rc = combine_midd(w, (const cplx*)sv, B, S, Dm, 0, fr_phase, U_out, st);
+    g_last_kernel = keep;
+    return rc ? -1 : 0;
+  }
   return combine_smalld(w, (const cplx*)sv, B, S, Dm, 0, fr_phase, U_out, st) ? -1 : 0;
 }
 
@@ -1053,6 +1086,22 @@ int lind_smallr_backward(DeviceWs* w, const LindSmallRBufs& bf, bool per_sample,
   g.Lmax = (N + S - 1) / S;
   LAUNCH_TRY(c3p_launch_smallr_grad(g, st));
   return 0;
+}
+
+// two qubits (16 x 16 superoperators), declared Hermitian: both halves on the real kernels; 1 = not applicable
+int run_vjp_lind_smallr16(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, long hk_bs, const double* signals, const cplx* clp,
+                          double dt, int B, int K, int N, int D, int Dm, const double* fr_phase, const cplx* Ubar, double* grad, hipStream_t st) {
+  const bool per_sample = (h0_bs != 0) || (hk_bs != 0);
+  const int S = pick_segments_r(B, N, K, Dm, per_sample, true);
+  if (S < 0 || !lind_smallr_ok(true, D, Dm, K, N, S)) return 1;
+  const int nsamp = per_sample ? B : 1;
+  const LindSmallRSizes zr = lind_smallr_sizes(B, K, N, Dm, S, nsamp);
+  void *blk, *sc;
+  if (ws_get(w, SL_OUT1, zr.total(), &blk)) return -1;
+  if (ws_get(w, SL_OUT2, (size_t)B * S * Dm * Dm * sizeof(cplx), &sc)) return -1;
+  const LindSmallRBufs rb = lind_smallr_carve(blk, zr, nsamp, Dm, K);
+  if (lind_smallr_forward(rb, h0, h0_bs, hks, hk_bs, signals, clp, dt, B, K, N, D, Dm, S, (cplx*)sc, st)) return -1;
+  return lind_smallr_backward(w, rb, per_sample, signals, B, K, N, D, Dm, S, fr_phase, Ubar, grad, st) ? -1 : 0;
 }
 
 // Returns 1 when not applicable.
@@ -2711,6 +2760,22 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
       return 0;
     }
   }
+  if (D == 4 && (flags & C3P_HERMITIAN_H) && K <= 8 && !(flags & C3P_FORCE_GENERIC) && !c3p_opt_on(C3P_OPT_no_smallr) &&
+      !c3p_opt_on(C3P_OPT_tiled_grad) && !c3p_opt_on(C3P_OPT_valu_grad)) {
+    // two qubits with declared Hermitian Hamiltonians: the real Hermitian-basis kernels of c3p_smallr.hip, both halves
+    if (record_start(w, st)) return -1;
+    const int rc = in_chunks([&](long b0, int nb) {
+      return run_vjp_lind_smallr16(w, p_h0 + b0 * h0_bstride, h0_bstride, p_hk + b0 * hks_bstride, hks_bstride, p_sig + b0 * K * N,
+                                   (const cplx*)clp, dt, nb, K, N, D, Dm, phase_at(b0), p_ub + b0 * gsz, p_grad + b0 * K * N, st);
+    });
+    if (rc < 0) return -1;
+    if (rc == 0) {
+      g_last_kernel = C3P_KERNEL_MFMA;
+      if (record_stop(w, st)) return -1;
+      if (flags & C3P_HOST_PTRS) return sg.finish();
+      return 0;
+    }
+  }
   // 49 x 49 .. 81 x 81 superoperators (D = 7, 8, 9; cfg4) and, zero padded in the 49 class, 36 x 36 (D = 6): on-chip backward sweep in
   // the Hermitian basis, real arithmetic; the transposed local prefix of every slice (N D^4 doubles per sample) is kept in HBM:
   // chunks of samples below the budget.  1 = a Hamiltonian is not Hermitian (the caller goes on to the complex sweeps).
@@ -2824,6 +2889,12 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
 
 // ---- open-system evaluation from ONE forward pass: a caller-owned tape between c3p_pwc_lindblad_taped and its vjp ----
 size_t c3p_pwc_lindblad_tape_bytes(int B, int K, int N, int D, int* segments_out) {
+  if (B > 0 && K >= 1 && K <= 8 && N > 0 && D == 4) {
+    // two qubits: the real Hermitian-basis kernels only (the taped calls then need C3P_HERMITIAN_H)
+    const int S = c3p_opt_on(C3P_OPT_no_smallr) ? -1 : pick_segments_r(B, N, K, 16, true, true);
+    if (segments_out) *segments_out = S > 0 ? S : 0;
+    return S > 0 ? lind_smallr_sizes(B, K, N, 16, S, B).total() : 0;
+  }
   if (B > 0 && K >= 1 && K <= 8 && N > 0 && D >= 2 && D <= 3) {
     // superoperators up to 9 x 9 on the small-D kernels: tables, segment products and the slice propagators (the generator is
     // not anti-Hermitian: the backward sweep cannot recompute prefixes from the adjoint side); per-sample operators need S % 4 = 0
@@ -2849,7 +2920,7 @@ int c3p_pwc_lindblad_taped(const void* h0, int64_t h0_bstride, const void* hks, 
   if (!h0 || !hks || !signals || !col_ops || C <= 0 || !U_out || !tape) return fail("NULL pointer argument");
   if (h0_bstride < 0 || hks_bstride < 0) return fail("negative batch stride");
   if (segments < 1 || segments > N) return fail("bad segment count %d", segments);
-  if (D <= 3) {
+  if (D <= 4) {
     // small-D kernels: the forward half of run_vjp_lind_smalld writes into the tape, U = the ordered product of its segments
     int seg_chk = 0;
     const size_t need = c3p_pwc_lindblad_tape_bytes(B, K, N, D, &seg_chk);
@@ -2876,9 +2947,14 @@ int c3p_pwc_lindblad_taped(const void* h0, int64_t h0_bstride, const void* hks, 
                               (cplx*)sc, st))
         return -1;
       if (record_stop(w, st)) return -1;
-      g_last_kernel = C3P_KERNEL_SMALLD;
-      return combine_smalld(w, (const cplx*)sc, B, segments, Dm, 0, fr_phase, (cplx*)U_out, st) ? -1 : 0;
+      g_last_kernel = Dm > 12 ? C3P_KERNEL_MFMA : C3P_KERNEL_SMALLD;
+      const int keep = g_last_kernel;
+      const int rc = Dm > 12 ? combine_midd(w, (const cplx*)sc, B, segments, Dm, 0, fr_phase, (cplx*)U_out, st)
+                             : combine_smalld(w, (const cplx*)sc, B, segments, Dm, 0, fr_phase, (cplx*)U_out, st);
+      g_last_kernel = keep;
+      return rc ? -1 : 0;
     }
+    if (D == 4) return fail("the taped Lindblad evaluation at D = 4 runs in the Hermitian basis: declare the Hamiltonians Hermitian (C3P_HERMITIAN_H) or use the untaped pair");
     const LindSmallBufs bf = lind_small_carve(tape, lind_small_sizes(B, K, N, Dm, segments, B));
     if (record_start(w, st)) return -1;
     if (lind_small_forward(w, bf, (const cplx*)h0, h0_bstride, (const cplx*)hks, hks_bstride, signals, (const cplx*)clp, dt, B, K, N, D, Dm, segments,
@@ -2893,7 +2969,7 @@ int c3p_pwc_lindblad_taped(const void* h0, int64_t h0_bstride, const void* hks, 
     }
     return combine_smalld(w, bf.seg, B, segments, Dm, 0, fr_phase, (cplx*)U_out, st) ? -1 : 0;
   }
-  if (!c3p_regr_supported(D, Dm)) return fail("the taped Lindblad evaluation serves D = 2, 3 (small-D kernels) and D = 7, 8, 9 (Hermitian-basis kernels), got D=%d", D);
+  if (!c3p_regr_supported(D, Dm)) return fail("the taped Lindblad evaluation serves D = 2, 3, 4 (small-D tile kernels) and D = 7, 8, 9 (Hermitian-basis kernels), got D=%d", D);
   const LindRegrSizes z = lind_regr_sizes(B, K, N, Dm, segments, B);
   if (tape_bytes < z.total()) return fail("tape too small: %zu bytes, need %zu (c3p_pwc_lindblad_tape_bytes)", tape_bytes, z.total());
   hipStream_t st = (hipStream_t)stream;
@@ -2950,7 +3026,7 @@ int c3p_pwc_lindblad_vjp_taped(const void* tape, size_t tape_bytes, int segments
   const int Dm = D * D;
   if (!tape || !signals || !U_bar || !grad_signals) return fail("NULL pointer argument");
   if (segments < 1 || segments > N) return fail("bad segment count %d", segments);
-  if (D <= 3) {
+  if (D <= 4) {
     int seg_chk = 0;
     const size_t need = c3p_pwc_lindblad_tape_bytes(B, K, N, D, &seg_chk);
     if (need == 0 || seg_chk != segments) return fail("taped Lindblad evaluation: shape not served or segment count %d != %d", segments, seg_chk);
@@ -2967,9 +3043,10 @@ int c3p_pwc_lindblad_vjp_taped(const void* tape, size_t tape_bytes, int segments
       if (lind_smallr_backward(w, rb, per_sample_operators != 0, signals, B, K, N, D, Dm, segments, fr_phase, (const cplx*)U_bar, grad_signals, st))
         return -1;
       if (record_stop(w, st)) return -1;
-      g_last_kernel = C3P_KERNEL_SMALLD;
+      g_last_kernel = Dm > 12 ? C3P_KERNEL_MFMA : C3P_KERNEL_SMALLD;
       return 0;
     }
+    if (D == 4) return fail("the taped Lindblad evaluation at D = 4 needs C3P_HERMITIAN_H, as given to c3p_pwc_lindblad_taped");
     const LindSmallBufs bf = lind_small_carve(const_cast<void*>(tape), lind_small_sizes(B, K, N, Dm, segments, B));
     if (record_start(w, st)) return -1;
     if (lind_small_backward(w, bf, per_sample_operators != 0, signals, B, K, N, Dm, segments, fr_phase, (const cplx*)U_bar, grad_signals, st)) return -1;

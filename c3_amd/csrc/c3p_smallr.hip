@@ -1,4 +1,4 @@
-// Lindblad chains of ONE qubit / qutrit (D = 2, 3: 4 x 4 / 9 x 9 superoperators) in REAL arithmetic in the Hermitian basis,
+// Lindblad chains of ONE qubit / qutrit and of two qubits (D = 2, 3, 4: 4 x 4 / 9 x 9 / 16 x 16 superoperators) in REAL arithmetic in the Hermitian basis,
 // on the small-D tile layout (round 4).  tf_propagation_lind (c3/libraries/propagation.py:551-585) builds the generator
 // L = -i (H (x) 1 - 1 (x) H^T) + dissipator per slice and exponentiates it; for a HERMITIAN Hamiltonian that generator maps
 // Hermitian matrices to Hermitian matrices, so in the basis  E_ii, (E_ij + E_ji) / sqrt 2, i (E_ji - E_ij) / sqrt 2  it is a
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(64) smallr_prep_kernel(RegdPrepArgs P, double*
     return s;
   };
   // every element of T G T^+ by its own thread first (Dm^2 <= 81), norms and the table from the shared copy
-  __shared__ double hre[96], him[96];
+  __shared__ double hre[256], him[256];
   for (int e = tid; e < D * D; e += 64) {
     const cplx v = transpose ? helem(e % D, e / D) : helem(e / D, e % D);  // (transpose: the tables of G'^T, for the backward sweep)
     hre[e] = v.x;
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(64) smallr_chain_kernel(SmallRArgs A) {
 
   // a REAL matrix M' (in the chain's image) -> f T^+ M' T, the complex matrix in the reference's vectorisation (c3p_hb_col: at
   // most two non-zeros per column of T); the 16 lanes of a chain share its Dm^2 elements
-  constexpr int Dh = (DM == 4) ? 2 : 3;
+  constexpr int Dh = (DM == 4) ? 2 : (DM == 9 ? 3 : 4);
   auto image_to_complex = [&](cplx* dst, double f, bool store) {
     for (int e = idx16; e < DM * DM; e += 16) {
       const int al = e / DM, be = e - al * DM;
@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(64) smallr_chain_kernel(SmallRArgs A) {
 template <int DM>
 __global__ void __launch_bounds__(64) smallr_scan_kernel(const double* seg, const double* ubar, int S, double* pre, double* suf) {
   constexpr int M2 = DM * DM;
-  __shared__ double cur[2][96], sg[96];
+  __shared__ double cur[2][DM * DM], sg[DM * DM];
   const int lane = threadIdx.x;
   const long bidx = blockIdx.x;
   const bool fwd = blockIdx.y == 0;
@@ -743,7 +743,7 @@ hipError_t launch_chain_t(const SmallRArgs& A, hipStream_t st) {
 
 }  // namespace
 
-bool c3p_smallr_supported(int Dh, int Dm, int K) { return (Dh == 2 || Dh == 3) && Dm == Dh * Dh && K >= 0 && K <= 8; }
+bool c3p_smallr_supported(int Dh, int Dm, int K) { return (Dh == 2 || Dh == 3 || Dh == 4) && Dm == Dh * Dh && K >= 0 && K <= 8; }
 
 size_t c3p_smallr_table_doubles(int Dm, int K) {
   const int NB = (Dm + 3) / 4;
@@ -764,6 +764,7 @@ hipError_t c3p_launch_smallr_chain(const SmallRArgs& A, hipStream_t st) {
   switch (A.Dm) {
     case 4: return launch_chain_t<4>(A, st);
     case 9: return launch_chain_t<9>(A, st);
+    case 16: return launch_chain_t<16>(A, st);
     default: return hipErrorInvalidValue;
   }
 }
@@ -777,6 +778,7 @@ hipError_t c3p_launch_smallr_grad(const SmallRGradArgs& A, hipStream_t st) {
   switch (A.Dm) {
     case 4: return launch_grad_t<4>(A, st);
     case 9: return launch_grad_t<9>(A, st);
+    case 16: return launch_grad_t<16>(A, st);
     default: return hipErrorInvalidValue;
   }
 }
@@ -786,6 +788,8 @@ hipError_t c3p_launch_smallr_scan(const double* seg, const double* ubar, int B, 
     hipLaunchKernelGGL(smallr_scan_kernel<4>, dim3((unsigned)B, 2), dim3(64), 0, st, seg, ubar, S, pre, suf);
   else if (Dm == 9)
     hipLaunchKernelGGL(smallr_scan_kernel<9>, dim3((unsigned)B, 2), dim3(64), 0, st, seg, ubar, S, pre, suf);
+  else if (Dm == 16)
+    hipLaunchKernelGGL(smallr_scan_kernel<16>, dim3((unsigned)B, 2), dim3(64), 0, st, seg, ubar, S, pre, suf);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();

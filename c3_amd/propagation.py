@@ -189,7 +189,7 @@ def propagate_batch(
         if col_ops is None:
             raise C3PropError("C3:Error: lindbladian propagation needs collapse operators")
         col = call.c128(col_ops if _is_torch(col_ops) else np.asarray(col_ops))
-        if D in (2, 3) and not (flags & _lib.PER_SLICE_H) and not want_dUs and _is_hermitian(call, h0) and (K == 0 or _is_hermitian(call, hks)):
+        if D in (2, 3, 4) and not (flags & _lib.PER_SLICE_H) and not want_dUs and _is_hermitian(call, h0) and (K == 0 or _is_hermitian(call, hks)):
             # one qubit / qutrit with Hermitian Hamiltonians: the generator is real in the Hermitian basis (c3p_smallr.hip)
             flags |= _lib.HERMITIAN_H
         rc = lib.c3p_pwc_lindblad(
@@ -436,10 +436,10 @@ def propagate_batch_lindblad_taped(h0, hks, signals, dt: float, col_ops, *, fr_p
     seg = ctypes.c_int(0)
     nbytes = int(lib.c3p_pwc_lindblad_tape_bytes(B, K, N, D, ctypes.byref(seg)))
     if nbytes <= 0:
-        raise C3PropError(f"C3:Error: the taped Lindblad evaluation serves D = 2, 3 (up to 8 control lines) and D = 7, 8, 9 (up to 16), got D={D} K={K}")
+        raise C3PropError(f"C3:Error: the taped Lindblad evaluation serves D = 2, 3, 4 (up to 8 control lines, at least four slices) and D = 7, 8, 9 (up to 16), got D={D} K={K} N={N}")
     buf = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=call.dev)
     U = call.empty((B, Dm, Dm))
-    tflags = _lib.HERMITIAN_H if D in (2, 3) and _is_hermitian(call, h0) and _is_hermitian(call, hks) else 0
+    tflags = _lib.HERMITIAN_H if D in (2, 3, 4) and _is_hermitian(call, h0) and _is_hermitian(call, hks) else 0
     _lib.check(
         lib.c3p_pwc_lindblad_taped(
             _ptr(h0), h0_bs, _ptr(hks), hk_bs, _ptr(signals), _ptr(col), int(col.shape[0]), float(dt), B, K, N, D,
@@ -520,7 +520,7 @@ def propagate_batch_lindblad_vjp(h0, hks, signals, dt: float, col_ops, U_bar, *,
     _lib.check(
         _lib.load().c3p_pwc_lindblad_vjp(
             _ptr(h0), h0_bs, _ptr(hks), hk_bs, _ptr(signals), _ptr(col), int(col.shape[0]), float(dt), B, K, N, D,
-            call.flags | (_lib.HERMITIAN_H if D in (2, 3) and _is_hermitian(call, h0) and _is_hermitian(call, hks) else 0),
+            call.flags | (_lib.HERMITIAN_H if D in (2, 3, 4) and _is_hermitian(call, h0) and _is_hermitian(call, hks) else 0),
             _ptr(fr_phase), _ptr(U_bar), _ptr(grad), call.stream
         )
     )

@@ -239,8 +239,11 @@ def test_lindblad_tape_layout_is_host_arithmetic(lib):
     assert seg.value == 4  # 64 samples x 4 segments = one round of 256 workgroups
     assert n >= 64 * 1000 * 81 * 81 * 8 + 64 * 4 * 81 * 81 * 16
     assert n < 1.02 * (64 * 1000 * 81 * 81 * 8 + 64 * 4 * 81 * 81 * 16) + (1 << 22)
-    for D in (4, 5, 6, 10):
+    for D in (5, 6, 10):
         assert lib.c3p_pwc_lindblad_tape_bytes(4, 2, 100, D, ctypes.byref(seg)) == 0 and seg.value == 0
+    # D = 4 (two qubits, real Hermitian-basis kernels): two real table sets, B x S real segment products, B x N real slice propagators
+    n = lib.c3p_pwc_lindblad_tape_bytes(64, 2, 1000, 4, ctypes.byref(seg))
+    assert seg.value >= 4 and seg.value % 4 == 0 and 64 * (1000 + seg.value) * 256 * 8 <= n < 64 * (1000 + seg.value) * 256 * 8 + (1 << 21)
     # D = 2, 3 (small-D kernels): tables + B x S segment products + B x N slice propagators, complex D^2 x D^2
     for D in (2, 3):
         n = lib.c3p_pwc_lindblad_tape_bytes(64, 1, 1000, D, ctypes.byref(seg))

@@ -561,3 +561,49 @@ def test_lindblad_small_real_path_is_not_taken_for_lossy_hamiltonians(prop):
     a = prop.propagate_batch(h0d, hkd, sgd, 0.2, col_ops=cold, lindbladian=True)["U"].cpu().numpy()
     b = np.asarray(prop.propagate_batch(h0, hks, sig, 0.2, col_ops=col, lindbladian=True)["U"])
     assert np.abs(a - b).max() < 1e-13
+
+
+@pytest.mark.parametrize("B,K,N,per_sample,amp", [(5, 2, 37, False, 1.0), (4, 1, 16, True, 1.0), (64, 2, 200, False, 0.5), (3, 2, 9, False, 12.0), (1, 1, 1, False, 1.0)])
+def test_lindblad_two_qubits_real_path(prop, B, K, N, per_sample, amp):
+    """Two qubits (D = 4, 16 x 16 superoperators: the size of the reference's own Lindblad golden test) with Hermitian
+    Hamiltonians on the real Hermitian-basis kernels: forward against the complex mid-D kernels (no_smallr) and the oracle,
+    trace preservation; the gradient (untaped and taped) against the complex sweep and finite differences of the oracle."""
+    import torch
+
+    D = 4
+    h0, hks, col, sig, Ubar, ph = _lind_case(D, B, K, N, 2, 5000 + N, per_sample, hscale=0.8 * amp)
+    got = np.asarray(prop.propagate_batch(h0, hks, sig, 0.2, col_ops=col, lindbladian=True, fr_phase=ph)["U"])
+    g = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, 0.2, col, Ubar, fr_phase=ph))
+    with _lib.options(no_smallr=1):
+        ref = np.asarray(prop.propagate_batch(h0, hks, sig, 0.2, col_ops=col, lindbladian=True, fr_phase=ph)["U"])
+        g0 = np.asarray(prop.propagate_batch_lindblad_vjp(h0, hks, sig, 0.2, col, Ubar, fr_phase=ph))
+    assert np.abs(got - ref).max() < 5e-12 * max(1.0, np.abs(ref).max())
+    assert np.abs(g - g0).max() < 1e-10 * np.abs(g0).max()
+    orc = o.propagate_batch(h0[0] if per_sample else h0, hks[0] if per_sample else hks, sig[:1], 0.2, col_ops=col, lindbladian=True)[0]
+    assert np.linalg.norm(got[0] - np.exp(1j * ph[0])[:, None] * orc) < 1e-10 * max(1.0, np.linalg.norm(orc))
+    vecI = np.eye(D).reshape(-1)
+    assert np.abs(np.einsum("i,bij->bj", vecI, np.exp(-1j * ph)[:, :, None] * got) - vecI).max() < 1e-10
+    # the taped pair
+    assert prop.lindblad_tape_supported(B, K, N, D) == (N >= 4)  # (the tape is laid out for a multiple of four segments)
+    t = lambda a: torch.as_tensor(a, device="cuda:0")
+    if N >= 4:
+        r = prop.propagate_batch_lindblad_taped(t(h0), t(hks), t(sig), 0.2, t(col), fr_phase=t(ph))
+        assert np.abs(r["U"].cpu().numpy() - ref).max() < 5e-12 * max(1.0, np.abs(ref).max())
+        gt = r["tape"].vjp(t(Ubar)).cpu().numpy()
+        assert np.abs(gt - g0).max() < 1e-10 * np.abs(g0).max()
+    if N <= 16 and not per_sample:
+        f = lambda sg: float(np.real(np.sum(np.conj(Ubar) * np.exp(1j * ph)[:, :, None] * o.propagate_batch(h0, hks, sg, 0.2, col_ops=col, lindbladian=True))))
+        for (b, k, n) in ((0, 0, 0), (B - 1, K - 1, N - 1)):
+            e = np.zeros_like(sig)
+            e[b, k, n] = 1e-6
+            fd = (f(sig + e) - f(sig - e)) / 2e-6
+            assert abs(fd - g[b, k, n]) < 2e-6 * max(1.0, abs(fd))
+    # a lossy Hamiltonian: the complex kernels, and the taped call says so
+    hn = h0 - 0.03j * np.diag(np.arange(D))
+    x = np.asarray(prop.propagate_batch(hn, hks, sig, 0.2, col_ops=col, lindbladian=True)["U"])
+    with _lib.options(no_smallr=1):
+        y = np.asarray(prop.propagate_batch(hn, hks, sig, 0.2, col_ops=col, lindbladian=True)["U"])
+    assert np.array_equal(x, y)
+    if N >= 4:
+        with pytest.raises(Exception, match="Hermitian"):
+            prop.propagate_batch_lindblad_taped(t(hn), t(hks), t(sig), 0.2, t(col))

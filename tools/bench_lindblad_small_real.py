@@ -27,12 +27,21 @@ def timed(fn, reps=20):
 
 
 rows = []
-for D, B, N in [(3, 64, 1000), (3, 256, 1000), (3, 1024, 1000), (2, 256, 1000), (2, 1024, 1000)]:
+for D, B, N in [(3, 64, 1000), (3, 256, 1000), (3, 1024, 1000), (2, 256, 1000), (2, 1024, 1000), (4, 64, 1000), (4, 256, 1000), (4, 1024, 1000)]:
     rng = np.random.default_rng(D * 100 + B)
     if D == 3:
         wl = workloads.make_workload(1, B=B, N=N)  # cfg1's qutrit
         h0, hks, sig, dt = wl.h0, wl.hks, wl.signals, wl.dt
         col = workloads.qubit_collapse_op(workloads.annihilator(3).astype(complex), 27e-6, 39e-6)[None]
+    elif D == 4:
+        # two coupled qubits, one drive each (lab frame), T1 on both
+        sz, sx, sm, id2 = np.diag([0.0, 1.0]), np.array([[0, 1], [1, 0]], dtype=float), np.array([[0, 1], [0, 0]], dtype=float), np.eye(2)
+        w1, w2, g = 5.0e9 * 2 * np.pi, 5.6e9 * 2 * np.pi, 20e6 * 2 * np.pi
+        h0 = (w1 * np.kron(sz, id2) + w2 * np.kron(id2, sz) + g * np.kron(sx, sx)).astype(complex)
+        hks = np.stack([np.kron(sx, id2), np.kron(id2, sx)]).astype(complex)
+        sig = rng.normal(size=(B, 2, N)) * 2e8
+        dt = 1e-11
+        col = np.stack([np.sqrt(1 / 27e-6) * np.kron(sm, id2), np.sqrt(1 / 23e-6) * np.kron(id2, sm)]).astype(complex)
     else:
         h0 = np.diag([0.0, 5e9 * 2 * np.pi]).astype(complex)
         hks = np.array([[[0, 1], [1, 0]]], dtype=complex)
@@ -51,6 +60,16 @@ for D, B, N in [(3, 64, 1000), (3, 256, 1000), (3, 1024, 1000), (2, 256, 1000), 
         y = f()["U"].cpu().numpy()
     row["speedup"] = row["complex_ms"] / row["real_ms"]
     row["max_dev"] = float(np.abs(x - y).max())
+    # the gradient (c3p_pwc_lindblad_vjp) the same way
+    Ub = t(rng.normal(size=(B, D * D, D * D)) + 1j * rng.normal(size=(B, D * D, D * D)))
+    gfn = lambda: prop.propagate_batch_lindblad_vjp(h0d, hkd, sgd, dt, cold, Ub, fr_phase=phd)
+    row["vjp_real_ms"] = timed(gfn, 5)
+    gx = gfn().cpu().numpy()
+    with _lib.options(no_smallr=1):
+        row["vjp_complex_ms"] = timed(gfn, 5)
+        gy = gfn().cpu().numpy()
+    row["vjp_speedup"] = row["vjp_complex_ms"] / row["vjp_real_ms"]
+    row["vjp_max_rel_dev"] = float(np.abs(gx - gy).max() / np.abs(gy).max())
     row["propagators_per_s"] = B / row["real_ms"] * 1e3
     rows.append(row)
     print(json.dumps(row), flush=True)
