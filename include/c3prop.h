@@ -58,7 +58,7 @@ extern "C" {
 #define C3P_FORCE_GENERIC 0x8 /* use the generic LDS kernel even where a specialised one exists */
 #define C3P_HERMITIAN_H 0x10  /* c3p_pwc_lindblad: the caller DECLARES h0 and every hk Hermitian (the library does not check
                                  device memory).  The Lindblad generator is then real in a basis of Hermitian matrices and the
-                                 chain of one qubit / qutrit (D = 2, 3) runs in real arithmetic (c3p_smallr.hip); other shapes
+                                 chain of one qubit / qutrit or two qubits (D = 2, 3, 4) runs in real arithmetic (c3p_smallr.hip); other shapes
                                  ignore the flag (D = 7, 8, 9 detect the case on the device).  Declared wrongly: wrong results.
                                  The reference makes no such distinction (propagation.py:551-585): c3_amd/propagation.py sets
                                  the flag after checking the arrays. */
@@ -249,7 +249,8 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
 
 /* Open-system optimiser evaluation from ONE forward pass (D = 7, 8, 9: 49 x 49 .. 81 x 81 superoperators, Hermitian Hamiltonians;
  * D = 2, 3: 4 x 4 / 9 x 9 superoperators on the small-D kernels, any Hamiltonian, up to 8 control lines -- there the tape holds
- * the generator tables, the segment products and the slice propagators).
+ * the generator tables, the segment products and the slice propagators; D = 4 (two qubits) with C3P_HERMITIAN_H in `flags` of
+ * BOTH calls: the real Hermitian-basis kernels -- the flag selects the layout of the tape at D = 2, 3 as well).
  * c3p_pwc_lindblad followed by c3p_pwc_lindblad_vjp computes the chain twice (the second time with the per-slice prefixes the
  * backward sweep reads).  Here the forward call records what the backward pass needs -- the generator tables in the Hermitian
  * basis, the real segment products, the transposed local prefix of every slice -- on a TAPE the caller owns (device memory, as

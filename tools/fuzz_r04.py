@@ -116,11 +116,12 @@ while time.time() < t_end:
             y = np.asarray(prop.ode_solve_batch(h0, hks, sig, 0.05, psi, solver, "schrodinger", final_only=fin))
         e = np.abs(x - y).max() / max(1.0, np.abs(y).max())
         assert e < 1e-11, ("ode K>4", D, B, K, N, solver, fin, e)
-        Dl = int(rng.choice([2, 3]))
+        Dl = int(rng.choice([2, 3, 4]))
         Bl, Kl, Nl = int(rng.integers(1, 9)), int(rng.integers(1, 4)), int(rng.integers(4, 90))
         ps = bool(rng.integers(0, 2))
         nb = Bl if ps else 1
-        h0l = np.stack([herm(Dl, 0.8) - (0.05j * np.diag(np.arange(Dl)) if rng.integers(0, 2) else 0) for _ in range(nb)])
+        # (lossy Hamiltonians: the complex kernels; at D = 4 the taped pair exists in the Hermitian basis only)
+        h0l = np.stack([herm(Dl, 0.8) - (0.05j * np.diag(np.arange(Dl)) if (Dl < 4 and rng.integers(0, 2)) else 0) for _ in range(nb)])
         hkl = np.stack([np.stack([herm(Dl, 0.5) for _ in range(Kl)]) for _ in range(nb)])
         if not ps:
             h0l, hkl = h0l[0], hkl[0]
