@@ -54,7 +54,7 @@ def graph_timed(fn, reps, torch, dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cases", default="1:256:200,2:256:1000,2:1024:1000,3:256:2000,5:64:5000,L3:64:1000,L9:16:1000,L9:64:1000")
+    ap.add_argument("--cases", default="1:256:200,2:256:1000,2:1024:1000,3:256:2000,5:64:5000,L3:64:1000,L4:64:1000,L4:256:1000,L9:16:1000,L9:64:1000")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     import torch
@@ -71,14 +71,26 @@ def main():
         B, N = int(B), int(N)
         lind = tag.startswith("L")
         if lind:
-            D1 = int(tag[1:])  # L3: one qutrit (cfg1's operators); L9: cfg4's two qutrits
+            D1 = int(tag[1:])  # L3: one qutrit (cfg1's operators); L4: two coupled qubits; L9: cfg4's two qutrits
             wl = workloads.make_workload(4 if D1 == 9 else 1, B=1, N=8)
             if D1 == 9:
                 col = wl.col_ops
+            elif D1 == 4:
+                sz, sx, sm, id2 = np.diag([0.0, 1.0]), np.array([[0, 1], [1, 0]], dtype=float), np.array([[0, 1], [0, 0]], dtype=float), np.eye(2)
+                w1, w2, g = 5.05e9 * TWO_PI, 5.65e9 * TWO_PI, 20e6 * TWO_PI
+
+                class _W:
+                    pass
+
+                wl = _W()
+                wl.D, wl.K = 4, 2
+                wl.h0 = (w1 * np.kron(sz, id2) + w2 * np.kron(id2, sz) + g * np.kron(sx, sx)).astype(complex)
+                wl.hks = np.stack([np.kron(sx, id2), np.kron(id2, sx)]).astype(complex)
+                col = np.stack([np.sqrt(1 / 27e-6) * np.kron(sm, id2), np.sqrt(1 / 23e-6) * np.kron(id2, sm)]).astype(complex)
             else:
                 a = workloads.annihilator(3).astype(complex)
                 col = workloads.qubit_collapse_op(a, 27e-6, 39e-6)[None]
-            dims = [3] if D1 == 3 else [3, 3]
+            dims = {3: [3], 4: [2, 2], 9: [3, 3]}[D1]
         else:
             wl = workloads.make_workload(int(tag), B=1, N=8)
             col = None
