@@ -904,7 +904,7 @@ class BatchPropagator:
     (valid once that stream is synchronised).
     """
 
-    def __init__(self, h0, hks, signals, dt, *, col_ops=None, fr_phase=None, want_dUs=False, force_generic=False):
+    def __init__(self, h0, hks, signals, dt, *, col_ops=None, fr_phase=None, want_dUs=False, force_generic=False, hermitian=None):
         import torch
 
         self.torch = torch
@@ -928,6 +928,14 @@ class BatchPropagator:
         self.U = torch.empty((self.B, self.Dm, self.Dm), dtype=c128, device=dev)
         self.dUs = torch.empty((self.B, self.N, self.Dm, self.Dm), dtype=c128, device=dev) if want_dUs else None
         self.flags = _lib.FORCE_GENERIC if force_generic else 0
+        # open systems of one qubit / qutrit / two qubits: Hermitian Hamiltonians run in real arithmetic (C3P_HERMITIAN_H).
+        # hermitian = None: checked here, once (the tensors are held by this object); True / False: the caller's word
+        if self.lind and self.D in (2, 3, 4) and not want_dUs:
+            if hermitian is None:
+                herm = lambda h: float((h - h.conj().transpose(-1, -2)).abs().max().item()) <= 1e-14 * max(float(h.abs().max().item()), 1e-300)
+                hermitian = herm(self.h0) and (self.K == 0 or herm(self.hks))
+            if hermitian:
+                self.flags |= _lib.HERMITIAN_H
 
     def run(self, out=None):
         """One C-ABI call on torch's current stream; `out` overrides the result tensor

@@ -561,6 +561,11 @@ def test_lindblad_small_real_path_is_not_taken_for_lossy_hamiltonians(prop):
     a = prop.propagate_batch(h0d, hkd, sgd, 0.2, col_ops=cold, lindbladian=True)["U"].cpu().numpy()
     b = np.asarray(prop.propagate_batch(h0, hks, sig, 0.2, col_ops=col, lindbladian=True)["U"])
     assert np.abs(a - b).max() < 1e-13
+    # the pre-bound call checks once and keeps the flag; a lossy Hamiltonian keeps the complex kernels
+    bp = prop.BatchPropagator(h0d, hkd, sgd, 0.2, col_ops=cold)
+    assert bp.flags & _lib.HERMITIAN_H
+    assert np.abs(bp.run().cpu().numpy() - b).max() < 1e-13
+    assert not (prop.BatchPropagator(t(hn), hkd, sgd, 0.2, col_ops=cold).flags & _lib.HERMITIAN_H)
 
 
 @pytest.mark.parametrize("B,K,N,per_sample,amp", [(5, 2, 37, False, 1.0), (4, 1, 16, True, 1.0), (64, 2, 200, False, 0.5), (3, 2, 9, False, 12.0), (1, 1, 1, False, 1.0)])
