@@ -26,8 +26,12 @@ namespace {
 template <int DM>
 struct RG {
   static constexpr int NB = (DM + 3) / 4;
-  static constexpr int WR = 4 * NB + 1;          // image row stride (doubles)
-  static constexpr int RIMG = 4 * NB * WR;       // one chain's image
+  // image row stride and chain stride (doubles).  64-bit LDS reads are served 32 lanes at a time on 64 dword banks: the A-layout
+  // reads of the four chains of a wavefront (address b RIMG + c WR + r) were 4-way conflicted at Dm = 16 with the natural
+  // 17 / 272 (68 % of the LDS cycles of both kernels, profiles/r04/smallr_pmc.json); 18 / 296 makes them conflict-free (writes
+  // two-way) -- brute force over strides with the bank rule.  Dm = 9: 13 / 156 (reads two-way, writes free); Dm = 4: 5 / 20.
+  static constexpr int WR = NB == 4 ? 18 : 4 * NB + 1;
+  static constexpr int RIMG = NB == 4 ? 296 : 4 * NB * WR;
   static constexpr int TILES = NB * NB * 16;     // table body: tile-major, 16 elements per tile in lane order r * 4 + c
   static constexpr int TABD = TILES + 4;         // + {mu, ||G' - mu||_1, max |Im|, max |Re|}
 };
@@ -750,9 +754,11 @@ size_t c3p_smallr_table_doubles(int Dm, int K) {
   return (size_t)(1 + K) * (NB * NB * 16 + 4);
 }
 
+static int sr_rimg(int NB) { return NB == 4 ? 296 : 4 * NB * (4 * NB + 1); }  // = RG<Dm>::RIMG
+
 size_t c3p_smallr_lds_bytes(int Dm, int K, int Lmax) {
   const int NB = (Dm + 3) / 4;
-  return (size_t)((1 + K) * (NB * NB * 16 + 4) + 4 * 4 * NB * (4 * NB + 1) + 4 * K * Lmax) * sizeof(double);
+  return (size_t)((1 + K) * (NB * NB * 16 + 4) + 4 * sr_rimg(NB) + 4 * K * Lmax) * sizeof(double);
 }
 
 hipError_t c3p_launch_smallr_prep(const RegdPrepArgs& P, int nsamp, double* tables, int* tabflag, hipStream_t st, int transpose) {
@@ -771,7 +777,7 @@ hipError_t c3p_launch_smallr_chain(const SmallRArgs& A, hipStream_t st) {
 
 size_t c3p_smallr_grad_lds_bytes(int Dm, int K, int Lmax) {
   const int NB = (Dm + 3) / 4;
-  return (size_t)(2 * (1 + K) * (NB * NB * 16 + 4) + 8 * 4 * NB * (4 * NB + 1) + 4 * K * Lmax) * sizeof(double);
+  return (size_t)(2 * (1 + K) * (NB * NB * 16 + 4) + 8 * sr_rimg(NB) + 4 * K * Lmax) * sizeof(double);
 }
 
 hipError_t c3p_launch_smallr_grad(const SmallRGradArgs& A, hipStream_t st) {
