@@ -1040,8 +1040,7 @@ int lind_smallr_forward(const LindSmallRBufs& bf, const cplx* h0, long h0_bs, co
   rp.Dh = D;
   rp.Dm = Dm;
   rp.lindblad = 1;
-  LAUNCH_TRY(c3p_launch_smallr_prep(rp, nsamp, bf.tabs, bf.flags, st, 0));
-  LAUNCH_TRY(c3p_launch_smallr_prep(rp, nsamp, bf.tabs_t, bf.flags, st, 1));
+  LAUNCH_TRY(c3p_launch_smallr_prep_pair(rp, nsamp, bf.tabs, bf.tabs_t, bf.flags, st));
   SmallRArgs ra = {};
   ra.tables = bf.tabs;
   ra.tab_per_sample = per_sample ? 1 : 0;

@@ -39,6 +39,8 @@ size_t c3p_smallr_table_doubles(int Dm, int K);
 size_t c3p_smallr_lds_bytes(int Dm, int K, int Lmax);
 // arguments as c3p_launch_regr_prep (lindblad generators of h0 / hks / clp); tabflag [nsamp][1 + K]: 1 = real in the basis
 hipError_t c3p_launch_smallr_prep(const RegdPrepArgs& P, int nsamp, double* tables, int* tabflag, hipStream_t st, int transpose = 0);
+// both table sets (G' and G'^T) from one launch
+hipError_t c3p_launch_smallr_prep_pair(const RegdPrepArgs& P, int nsamp, double* tables, double* tables_t, int* tabflag, hipStream_t st);
 size_t c3p_smallr_grad_lds_bytes(int Dm, int K, int Lmax);
 hipError_t c3p_launch_smallr_grad(const SmallRGradArgs& A, hipStream_t st);
 // pre[j] = S_{j-1} ... S_0 (pre[0] = 1), suf[j] = S_{j+1}^T ... S_{S-1}^T U_bar' from the REAL segment products seg [B,S,Dm,Dm]

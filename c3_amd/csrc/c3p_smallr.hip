@@ -45,7 +45,10 @@ __device__ __forceinline__ void sr_sync() {
 }
 
 // ---- tables: G' = Re(T G T^+), trace shifted, tile-major ------------------------------------------------------------------
-__global__ void __launch_bounds__(64) smallr_prep_kernel(RegdPrepArgs P, double* tables, int* tabflag, int transpose) {
+// (transpose = 2: blockIdx.y = 0 tabulates G' into tables, blockIdx.y = 1 its transpose into tables_t -- one launch for both)
+__global__ void __launch_bounds__(64) smallr_prep_kernel(RegdPrepArgs P, double* tables_in, double* tables_t, int* tabflag, int transpose_in) {
+  const int transpose = transpose_in == 2 ? (int)blockIdx.y : transpose_in;
+  double* tables = (transpose_in == 2 && blockIdx.y == 1) ? tables_t : tables_in;
   __shared__ double red0[64], red1[64];
   __shared__ double mu_s;
   const int tid = threadIdx.x;
@@ -762,7 +765,12 @@ size_t c3p_smallr_lds_bytes(int Dm, int K, int Lmax) {
 }
 
 hipError_t c3p_launch_smallr_prep(const RegdPrepArgs& P, int nsamp, double* tables, int* tabflag, hipStream_t st, int transpose) {
-  hipLaunchKernelGGL(smallr_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K))), dim3(64), 0, st, P, tables, tabflag, transpose);
+  hipLaunchKernelGGL(smallr_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K))), dim3(64), 0, st, P, tables, (double*)nullptr, tabflag, transpose);
+  return hipGetLastError();
+}
+
+hipError_t c3p_launch_smallr_prep_pair(const RegdPrepArgs& P, int nsamp, double* tables, double* tables_t, int* tabflag, hipStream_t st) {
+  hipLaunchKernelGGL(smallr_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K)), 2), dim3(64), 0, st, P, tables, tables_t, tabflag, 2);
   return hipGetLastError();
 }
 
