@@ -1060,11 +1060,10 @@ int lind_smallr_forward(const LindSmallRBufs& bf, const cplx* h0, long h0_bs, co
 int lind_smallr_backward(DeviceWs* w, const LindSmallRBufs& bf, bool per_sample, const double* signals, int B, int K, int N, int D, int Dm, int S,
                          const double* fr_phase, const cplx* Ubar, double* grad, hipStream_t st) {
   const size_t m8 = (size_t)Dm * Dm * sizeof(double);
-  void *uv, *pv, *sv, *qv;
+  void *uv, *pv, *sv;
   if (ws_get(w, SL_SCRATCH, (size_t)B * m8, &uv)) return -1;
   if (ws_get(w, SL_SEG_A, (size_t)B * S * m8, &pv)) return -1;
   if (ws_get(w, SL_SEG_B, (size_t)B * S * m8, &sv)) return -1;
-  if (ws_get(w, SL_SEG_F, (size_t)B * N * m8, &qv)) return -1;
   LAUNCH_TRY(c3p_launch_hb_ubar(Ubar, fr_phase, B, D, (double*)uv, st));
   LAUNCH_TRY(c3p_launch_smallr_scan(bf.seg, (const double*)uv, B, S, Dm, (double*)pv, (double*)sv, st));
   SmallRGradArgs g = {};
@@ -1075,7 +1074,6 @@ int lind_smallr_backward(DeviceWs* w, const LindSmallRBufs& bf, bool per_sample,
   g.pre = (const double*)pv;
   g.suf = (const double*)sv;
   g.dus = bf.dus;
-  g.pstore = (double*)qv;
   g.grad = grad;
   g.B = B;
   g.K = K;

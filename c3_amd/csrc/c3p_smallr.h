@@ -15,12 +15,12 @@ struct SmallRArgs {
   cplx* seg_out;         // [B,S,Dm,Dm] segment products, already in the reference's (complex) vectorisation
   cplx* dUs_out;         // [B,N,Dm,Dm] slice propagators (complex vectorisation) or null
   double* seg_real;      // [B,S,Dm,Dm] the same segment products, REAL (Hermitian basis), or null: input of the real backward sweep
-  double* dus_real;      // [B,N,Dm,Dm] the slice propagators, REAL (Hermitian basis), or null
+  double* dus_real;      // [B,N,Dm,Dm] the LOCAL prefix of every slice (product of the slices of its segment in front of it), REAL, or null
 };
 
 // Backward sweep in the Hermitian basis (smallr_grad_kernel): the general-generator sweep of smalld_grad_general_kernel in real
-// arithmetic -- the prefix in front of every slice from the stored slice propagators, then one pair evaluation
-// (value + derivative of T18) per slice at X_n^T.
+// arithmetic -- one pair evaluation (value + derivative of T18) per slice at X_n^T, its direction from the adjoint (with the
+// prefix at the segment start folded in) and the local prefix of the slice the forward kernel stored.
 struct SmallRGradArgs {
   const double* tables;    // G' tables (inner products)
   const double* tables_t;  // G'^T tables (the matrix that is exponentiated)
@@ -28,8 +28,7 @@ struct SmallRGradArgs {
   const double* signals;   // [B,K,N]
   const double* pre;       // [B,S,Dm,Dm] real prefix in front of every segment
   const double* suf;       // [B,S,Dm,Dm] real left adjoint behind every segment
-  const double* dus;       // [B,N,Dm,Dm] real slice propagators
-  double* pstore;          // [B,N,Dm,Dm] scratch: the prefix in front of every slice
+  const double* dus;       // [B,N,Dm,Dm] real local prefixes (SmallRArgs.dus_real)
   double* grad;            // [B,K,N]
   int B, K, N, Dm, S, Lmax;
 };

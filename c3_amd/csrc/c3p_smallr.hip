@@ -340,15 +340,18 @@ __global__ void __launch_bounds__(64) smallr_chain_kernel(SmallRArgs A) {
 #pragma unroll
         for (int J = 0; J < NB; ++J) P[I][J] = Q[I][J];
     }
-    if (A.dus_real && act) {  // the slice propagator, real: input of the real backward sweep
-      const double em = exp(mu);
+    if (A.dus_real && act) {
+      // the LOCAL prefix of slice t -- the product of the slices of this segment in front of it, with their trace shifts -- for
+      // the real backward sweep (M_n = A~_n Q_n^T with the prefix at the segment start folded into the adjoint: no slice
+      // propagators, no second forward walk there)
+      const double em = exp(mus);
       double* dr = A.dus_real + ((long)sample * A.N + n0 + t) * DM * DM;
 #pragma unroll
       for (int I = 0; I < NB; ++I)
 #pragma unroll
         for (int J = 0; J < NB; ++J) {
           const int row = 4 * I + r, col = 4 * J + c;
-          if (row < DM && col < DM) dr[row * DM + col] = em * P[I][J];
+          if (row < DM && col < DM) dr[row * DM + col] = (t == 0) ? ((row == col) ? 1.0 : 0.0) : em * U[I][J];
         }
     }
     if (A.dUs_out) {  // the slice propagator e^{mu} exp(X - mu), for the backward sweep of the gradient entries
@@ -555,42 +558,19 @@ __global__ void __launch_bounds__(64, 1) smallr_grad_kernel(SmallRGradArgs A) {
       for (int J = 0; J < NB; ++J) M[I][J] = (I == J && r == c && 4 * I + r < DM) ? 1.0 : 0.0;
   };
 
-  // ---- forward: the prefix in front of every slice of the segment ----
-  double* pst = A.pstore + ((long)sample * A.N + n0) * M2;
-  {
-    RMat P;
-    load_real(P, A.pre + cc * M2, valid, false);
-    const double* du = A.dus + ((long)sample * A.N + n0) * M2;
-    for (int t = 0; t < A.Lmax; ++t) {
-      const bool act = valid && t < len;
-      if (act) {
-        double* dst = pst + (long)t * M2;
-#pragma unroll
-        for (int I = 0; I < NB; ++I)
-#pragma unroll
-          for (int J = 0; J < NB; ++J) {
-            const int row = 4 * I + r, col = 4 * J + c;
-            if (row < DM && col < DM) dst[row * DM + col] = P[I][J];
-          }
-      }
-      if (t + 1 == A.Lmax) break;
-      RMat E, V;
-      load_real(E, du + (long)(act ? t : 0) * M2, act, false);
-      if (!act) set_identity(E);
-      to_image(img0, E);
-      zero(V);
-      mm(img0, P, V);
-#pragma unroll
-      for (int I = 0; I < NB; ++I)
-#pragma unroll
-        for (int J = 0; J < NB; ++J) P[I][J] = V[I][J];
-    }
-  }
-  __threadfence_block();
-
   // ---- backward ----
-  RMat Aa;  // left adjoint, without the trace shifts of the slices behind it: they accumulate in ams
-  load_real(Aa, A.suf + cc * M2, valid, false);
+  // left adjoint behind the segment with the prefix in front of the segment folded in, A~ = suf pre^T (then M_n = A~_n Q_n^T
+  // with the LOCAL prefix Q_n the forward kernel stored, and A~_{n-1} = E_n^T A~_n like the plain adjoint), without the trace
+  // shifts of the slices behind it: they accumulate in ams
+  RMat Aa;
+  {
+    RMat SF, PT;
+    load_real(SF, A.suf + cc * M2, valid, false);
+    load_real(PT, A.pre + cc * M2, valid, true);
+    to_image(img0, SF);
+    zero(Aa);
+    mm(img0, PT, Aa);
+  }
   double ams = 0.0;
   for (int t = A.Lmax - 1; t >= 0; --t) {
     const bool act = valid && t < len;
@@ -598,10 +578,10 @@ __global__ void __launch_bounds__(64, 1) smallr_grad_kernel(SmallRGradArgs A) {
     RMat X, dX;
     {
       RMat PH, Mn;
-      load_real(PH, pst + (long)(act ? t : 0) * M2, act, true);
+      load_real(PH, A.dus + ((long)sample * A.N + n0 + (act ? t : 0)) * M2, act, true);
       to_image(img0, Aa);
       zero(Mn);
-      mm(img0, PH, Mn);  // M_n = A P_n^T
+      mm(img0, PH, Mn);  // M_n = A~ Q_n^T
 #pragma unroll
       for (int I = 0; I < NB; ++I)
 #pragma unroll
