@@ -867,7 +867,12 @@ LindSmallBufs lind_small_carve(void* base, const LindSmallSizes& z) {
 // segments of the small-D Lindblad sweep, -1 when the shape is not served (tables + images beyond the LDS of the backward kernel)
 int lind_small_segments(int B, int K, int N, int Dm, bool need_mult4) {
   if (Dm > 12) return -1;
-  const int S = pick_segments(B, N, K, Dm, need_mult4, 4096);
+  // (8192 chain slots: the real sweep of c3p_smallr.hip runs two wavefronts per SIMD; for the complex one -- one per SIMD -- two
+  // rounds of half-length segments cost what one round did)
+  int S = pick_segments(B, N, K, Dm, need_mult4, 8192);
+  // (short segments cost more than the cost model of pick_segments knows here: the segment scan is sequential over S and every
+  // chain has a prologue -- below 16 slices per segment the 4096-slot choice is the faster one: B = 64, N = 1000)
+  if (S > 0 && N / S < 16) S = pick_segments(B, N, K, Dm, need_mult4, 4096);
   if (S < 0) return -1;
   // (the backward kernel keeps BOTH table sets in LDS)
   if ((2 * c3p_smalld_table_doubles(Dm, K) + 8 * (size_t)c3p_smalld_mat_doubles(Dm) + 4 * (size_t)K * ((N + S - 1) / S)) * sizeof(double) > 60 * 1024)

@@ -426,7 +426,9 @@ __global__ void __launch_bounds__(64) smallr_scan_kernel(const double* seg, cons
 
 // ---- backward sweep --------------------------------------------------------------------------------------------------------
 template <int DM>
-__global__ void __launch_bounds__(64, 1) smallr_grad_kernel(SmallRGradArgs A) {
+// (Dm <= 9: 256 registers, ~30 spilled, TWO wavefronts per SIMD -- the sweep is a chain of dependent products at 22 % matrix-pipe
+// occupancy with one; Dm = 16 keeps 512 registers: 326 would spill)
+__global__ void __launch_bounds__(64, (DM <= 9 ? 2 : 1)) smallr_grad_kernel(SmallRGradArgs A) {
   using G = RG<DM>;
   constexpr int NB = G::NB, WR = G::WR, RIMG = G::RIMG, TABD = G::TABD, TILES = G::TILES;
   constexpr int M2 = DM * DM;
