@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_l3 -o l3 -- python $R/tests/perf/bench_goal_run.py --cases L3:64:1000 > $R/gpurun_out/prof_l3.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_l3 -o l3 -- python $R/tests/perf/bench_goal_run.py --cases L3:64:1000,L4:256:1000 > $R/gpurun_out/prof_l3.log 2>&1
 tail -3 $R/gpurun_out/prof_l3.log | cut -c1-400
 python - <<'PY'
 import csv, glob, os
