@@ -441,6 +441,90 @@ __global__ void __launch_bounds__(64) smallr_scan_kernel(const double* seg, cons
   }
 }
 
+// The same scan in blocks (S >= 16): NBK wavefronts per (sample, direction), wavefront w scans its block of segments locally
+// (local prefixes / suffixes to the output, the product of the block to LDS), wavefront 0 chains the NBK block products, then
+// every wavefront multiplies its local results by the offset of its block: ~3 S / NBK dependent products instead of S - 1.
+template <int DM, int NBK>
+__global__ void __launch_bounds__(64 * NBK) smallr_scan_blocked_kernel(const double* seg, const double* ubar, int S, double* pre, double* suf) {
+  constexpr int M2 = DM * DM;
+  __shared__ double curs[NBK][2][M2], sgs[NBK][M2], blk[NBK][M2], off[NBK][M2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long bidx = blockIdx.x;
+  const bool fwd = blockIdx.y == 0;
+  const double* sb = seg + bidx * S * M2;
+  double* out = (fwd ? pre : suf) + bidx * S * M2;
+  const int Lb = (S + NBK - 1) / NBK;
+  const int j0 = wv * Lb, j1 = (j0 + Lb < S) ? j0 + Lb : S;  // this wavefront's segments [j0, j1)
+  const int nloc = j1 > j0 ? j1 - j0 : 0;
+  double(*cur)[M2] = curs[wv];
+  double* sg = sgs[wv];
+  // C = op(sg) cur[w] -> cur[w ^ 1]
+  auto step_mm = [&](int w) {
+    for (int e = lane; e < M2; e += 64) {
+      const int i = e / DM, jx = e - i * DM;
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < DM; ++k) acc = fma(fwd ? sg[i * DM + k] : sg[k * DM + i], cur[w][k * DM + jx], acc);
+      cur[w ^ 1][e] = acc;
+    }
+  };
+  // phase 1: local scan of the block, starting from the identity; the block product S_{j1-1} ... S_{j0} (its transpose chain
+  // S_{j0}^T ... S_{j1-1}^T for the suffix direction) ends in blk[wv]
+  int w = 0;
+  for (int e = lane; e < M2; e += 64) cur[0][e] = (e / DM == e % DM) ? 1.0 : 0.0;
+  sr_sync();
+  for (int step = 0; step < nloc; ++step) {
+    const int j = fwd ? j0 + step : j1 - 1 - step;
+    for (int e = lane; e < M2; e += 64) out[(long)j * M2 + e] = cur[w][e];  // local prefix in front of / suffix behind segment j
+    for (int e = lane; e < M2; e += 64) sg[e] = sb[(long)j * M2 + e];
+    sr_sync();
+    step_mm(w);
+    sr_sync();
+    w ^= 1;
+  }
+  for (int e = lane; e < M2; e += 64) blk[wv][e] = cur[w][e];
+  __threadfence_block();
+  __syncthreads();
+  // phase 2: offsets of the blocks (wavefront 0): forward off[0] = 1, off[b + 1] = blk[b] off[b]; suffix off[NBK - 1] = U_bar',
+  // off[b - 1] = blk[b] off[b]  (blk of the suffix direction is already the transposed chain)
+  if (wv == 0) {
+    for (int e = lane; e < M2; e += 64) cur[0][e] = fwd ? ((e / DM == e % DM) ? 1.0 : 0.0) : ubar[bidx * M2 + e];
+    sr_sync();
+    int ww = 0;
+    for (int step = 0; step < NBK; ++step) {
+      const int bq = fwd ? step : NBK - 1 - step;
+      for (int e = lane; e < M2; e += 64) off[bq][e] = cur[ww][e];
+      if (step == NBK - 1) break;
+      sr_sync();
+      for (int e = lane; e < M2; e += 64) {  // plain product: blk[bq] cur
+        const int i = e / DM, jx = e - i * DM;
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) acc = fma(blk[bq][i * DM + k], cur[ww][k * DM + jx], acc);
+        cur[ww ^ 1][e] = acc;
+      }
+      sr_sync();
+      ww ^= 1;
+    }
+  }
+  __syncthreads();
+  // phase 3: out[j] = local[j] off[block]
+  for (int step = 0; step < nloc; ++step) {
+    const int j = j0 + step;
+    double* o = out + (long)j * M2;
+    for (int e = lane; e < M2; e += 64) sg[e] = o[e];
+    sr_sync();
+    for (int e = lane; e < M2; e += 64) {
+      const int i = e / DM, jx = e - i * DM;
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < DM; ++k) acc = fma(sg[i * DM + k], off[wv][k * DM + jx], acc);
+      o[e] = acc;
+    }
+    sr_sync();
+  }
+}
+
 // ---- backward sweep --------------------------------------------------------------------------------------------------------
 template <int DM>
 // (Dm <= 9: 256 registers, ~30 spilled, TWO wavefronts per SIMD -- the sweep is a chain of dependent products at 22 % matrix-pipe
@@ -797,6 +881,17 @@ hipError_t c3p_launch_smallr_grad(const SmallRGradArgs& A, hipStream_t st) {
 }
 
 hipError_t c3p_launch_smallr_scan(const double* seg, const double* ubar, int B, int S, int Dm, double* pre, double* suf, hipStream_t st) {
+  if (S >= 16 && !c3p_opt_on(C3P_OPT_no_fuse)) {  // (no_fuse: the sequential scan, A/B)
+    if (Dm == 4)
+      hipLaunchKernelGGL((smallr_scan_blocked_kernel<4, 8>), dim3((unsigned)B, 2), dim3(512), 0, st, seg, ubar, S, pre, suf);
+    else if (Dm == 9)
+      hipLaunchKernelGGL((smallr_scan_blocked_kernel<9, 8>), dim3((unsigned)B, 2), dim3(512), 0, st, seg, ubar, S, pre, suf);
+    else if (Dm == 16)
+      hipLaunchKernelGGL((smallr_scan_blocked_kernel<16, 4>), dim3((unsigned)B, 2), dim3(256), 0, st, seg, ubar, S, pre, suf);
+    else
+      return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   if (Dm == 4)
     hipLaunchKernelGGL(smallr_scan_kernel<4>, dim3((unsigned)B, 2), dim3(64), 0, st, seg, ubar, S, pre, suf);
   else if (Dm == 9)
