@@ -871,8 +871,9 @@ int lind_small_segments(int B, int K, int N, int Dm, bool need_mult4) {
   // rounds of half-length segments cost what one round did)
   int S = pick_segments(B, N, K, Dm, need_mult4, 8192);
   // (short segments cost more than the cost model of pick_segments knows here: the segment scan is sequential over S and every
-  // chain has a prologue -- below 16 slices per segment the 4096-slot choice is the faster one: B = 64, N = 1000)
-  if (S > 0 && N / S < 16) S = pick_segments(B, N, K, Dm, need_mult4, 4096);
+  // chain has a prologue -- below 8 slices per segment the 4096-slot choice is the faster one (with the blocked scan of
+  // c3p_smallr.hip; 16 before it): B = 64, N = 1000 takes 128 segments of 8, 0.286 -> 0.259 ms per gradient call)
+  if (S > 0 && N / S < 8) S = pick_segments(B, N, K, Dm, need_mult4, 4096);
   if (S < 0) return -1;
   // (the backward kernel keeps BOTH table sets in LDS)
   if ((2 * c3p_smalld_table_doubles(Dm, K) + 8 * (size_t)c3p_smalld_mat_doubles(Dm) + 4 * (size_t)K * ((N + S - 1) / S)) * sizeof(double) > 60 * 1024)
