@@ -16,11 +16,21 @@ The only data-path collective is the all-gather of the U slabs over RCCL (c3_amd
 `--gather-every` consecutive steps travel in ONE collective).  Inputs are resident in HBM before the timed region.
 The value is SUSTAINED throughput: an untimed clock ramp (`--ramp-ms`, default 60 ms) precedes the W warmup steps.
 Rank 0 prints ONE JSON line.
+
+Launching N > 1:  `python bench.py --gpus N` starts the N ranks ITSELF (one child process per GPU, RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1, rank 0's JSON line passed through on stdout); under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (WORLD_SIZE already set) it is a rank.  At N > 1
+`--check` is on by default (`--no-check` turns it off).  When there are more ranks than visible devices (two ranks on a
+one-GPU box: RCCL refuses that with "Duplicate GPU detected") the ranks share devices and the exchange runs on gloo through
+host staging -- the line says so (`oversubscribed`, `backend`) and such a run measures nothing about scaling; it exists so
+that the N > 1 code path can be executed on one device.
 """
 import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -118,8 +128,7 @@ def _claim_stdout():
     return real
 
 
-def main():
-    real_stdout = _claim_stdout()
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -138,12 +147,76 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive side measurement")
     ap.add_argument("--generic", action="store_true", help="force the generic LDS kernel")
-    ap.add_argument("--check", action="store_true", help="verify samples against the oracle (and the gathered slabs)")
+    ap.add_argument("--check", action="store_true", default=None, help="verify samples against the oracle (and the gathered slabs); default at N > 1")
+    ap.add_argument("--no-check", action="store_false", dest="check")
+    ap.add_argument("--backend", choices=("auto", "nccl", "gloo"), default="auto",
+                    help="auto: nccl (= RCCL), or gloo with host staging when the ranks outnumber the visible devices")
     ap.add_argument("--complex", action="store_true", dest="complex_ops",
                     help="give the second control operator an imaginary (Hermitian) part: the general complex-Hamiltonian instances instead of the real fast path")
     ap.add_argument("--exchange", choices=("gather", "goal"), default="gather",
                     help="multi-GPU exchange: all-gather of the U slabs (default) or the gather-free optimiser loop: fused fidelity per sample + ONE all-reduce of the goal per step")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as child processes of this one (what
+    `torch.distributed.run --standalone --nproc-per-node N` would do, without its agent and log redirection), one per GPU,
+    rendezvous on 127.0.0.1 at a free port.  Every child inherits stdout / stderr: rank 0 alone writes the JSON line.  The first
+    rank that fails takes the others down (by their own process handles); the exit code is the first non-zero one."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), C3P_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (the host driver supports nothing else)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    live = list(procs)
+    try:
+        while live:
+            time.sleep(0.05)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"[bench] rank {procs.index(p)} exited with {code}: stopping the other ranks", file=sys.stderr, flush=True)
+                    for q in live:
+                        q.terminate()
+    finally:
+        for q in live:
+            q.kill()
+    return rc
+
+
+class _StandInPropagator:
+    """TEST SCAFFOLD (C3P_BENCH_STANDIN=1, tests/test_dist_gloo.py): takes the place of the HIP propagator so that the launcher,
+    the sharding, the exchange schedules and the multi-rank check of this file run on CPU ranks over gloo.  It computes nothing:
+    element (i, j) of global sample g is g + 1e-3 (i Dm + j) - 1e-6 i.  A stand-in line is labelled as such and is not a
+    measurement."""
+
+    def __init__(self, torch, lo, B, Dm):
+        g = torch.arange(lo, lo + B, dtype=torch.float64).reshape(B, 1, 1)
+        e = torch.arange(Dm * Dm, dtype=torch.float64).reshape(1, Dm, Dm)
+        self.U = torch.complex(g + 1e-3 * e, -1e-6 * e.expand(B, Dm, Dm))
+
+    def run(self, out=None):
+        if out is None:
+            return self.U.clone()
+        out.copy_(self.U)
+        return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    real_stdout = _claim_stdout()
 
     import numpy as np
     import torch
@@ -154,21 +227,46 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if args.gpus != world and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): running {world}", file=sys.stderr, flush=True)
+    if args.check is None:
+        args.check = world > 1
+    standin = os.environ.get("C3P_BENCH_STANDIN") == "1"  # test scaffold: CPU ranks over gloo, nothing computed (see _StandInPropagator)
     dist = None
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    ndev = 0 if standin else torch.cuda.device_count()
+    if not standin and ndev <= 0:
+        _lib.require_gpu()  # raises: the propagator path has no CPU fallback
+    oversubscribed = (not standin) and local_world > ndev
+    backend = args.backend
+    if backend == "auto":
+        # RCCL refuses two ranks on one device ("Duplicate GPU detected"): ranks that share a device exchange over gloo,
+        # staged through host memory -- an execution of the N > 1 path, not a measurement of it
+        backend = "gloo" if (standin or oversubscribed) else "nccl"
+    dev = torch.device("cpu") if standin else torch.device("cuda", local_rank % ndev)
+    if not standin:
+        torch.cuda.set_device(dev)
     if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         if rank == 0:
-            print(f"[bench] RCCL world size {dist.get_world_size()} (backend {dist.get_backend()})", file=sys.stderr, flush=True)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+            print(f"[bench] world size {dist.get_world_size()} (backend {dist.get_backend()}{', ranks share devices' if oversubscribed else ''})", file=sys.stderr, flush=True)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the scalar reductions of this file live
+    sync = (lambda: None) if standin else torch.cuda.synchronize
+
+    def reduce_scalar(x, op):
+        if not use_dist:
+            return float(x)
+        t = torch.tensor([float(x)], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=op)
+        return float(t.item())
 
     cfg = workloads.CONFIGS[args.config]
     B_glob, lo, hi, b_pad = plan_batch(cfg, args.scaling, args.batch, world, rank)
@@ -185,7 +283,9 @@ def main():
     if wl.lindblad:
         fr = np.stack([(p[:, None] - p[None, :]).ravel() for p in wl.fr_phase])
     bp = None
-    if B > 0:
+    if B > 0 and standin:
+        bp = _StandInPropagator(torch, lo, B, Dm)
+    elif B > 0:
         bp = propagation.BatchPropagator(
             torch.as_tensor(wl.h0, device=dev),
             torch.as_tensor(wl.hks, device=dev),
@@ -201,13 +301,16 @@ def main():
     # `all_gather_every_step_overlapped`, because on N > 1 ranks it is the schedule that hides the link latency.)
     if args.exchange == "goal" and wl.lindblad:
         raise SystemExit("--exchange goal: unitary configurations only")
+    if standin:
+        args.no_e2e = args.no_cpu_baseline = True
     goal_state = {}
 
     def make_schedule(exchange, gather_every, overlap=False):
         """(ring, compute) of one exchange schedule: `gather` = all-gather of the U slabs of `gather_every` steps in one
         collective (overlap: issued asynchronously while the next steps compute into a second bank of slabs); `goal` = fused
         fidelity per sample + ONE all-reduce of the goal per step, nothing gathered."""
-        ring = c3dist.SlabRing(B, b_pad, (Dm, Dm), gather_every, device=dev, use_dist=use_dist and exchange == "gather", overlap=overlap)
+        ring = c3dist.SlabRing(B, b_pad, (Dm, Dm), gather_every, device=dev, use_dist=use_dist and exchange == "gather", overlap=overlap,
+                                stage_host=(backend == "gloo" and dev.type == "cuda"))
         if exchange == "goal":
             from c3_amd import fidelities
 
@@ -226,7 +329,11 @@ def main():
                     g = fidelities.infid_sum(ideal, out[:B], comp_index, list(wl.dims), kind="unitary")["sum"]  # {sum, B}: one launch
                 else:
                     goal_buf.zero_()
-                if use_dist:
+                if use_dist and g.device != red_dev:  # ranks sharing a device (gloo): the two goal scalars travel through the host
+                    gh = g.to(red_dev)
+                    dist.all_reduce(gh, op=dist.ReduceOp.SUM)
+                    g = gh
+                elif use_dist:
                     dist.all_reduce(g, op=dist.ReduceOp.SUM)
                 goal_state["last"] = g
 
@@ -240,37 +347,40 @@ def main():
         for _ in range(warmup):
             ring.step(compute)
         ring.drain()
-        torch.cuda.synchronize()
+        sync()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sync()
+        ev0 = ev1 = None
+        if dev.type == "cuda":
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev0.record()  # HIP events on the stream the kernels are launched on (torch's current stream), over the timed region
+        if ev0 is not None:
+            ev0.record()  # HIP events on the stream the kernels are launched on (torch's current stream), over the timed region
         for _ in range(steps):
             ring.step(compute)
-        ev1.record()
+        if ev1 is not None:
+            ev1.record()
         ring.drain()
-        torch.cuda.synchronize()
+        sync()
         # The K steps end here on this rank (the last all-gather inside drain() has already waited for every rank's
         # slabs); the closing barrier follows and the MAX over ranks of the per-rank times is reported, so the
         # barrier's own latency is not booked as step time.
-        el = time.perf_counter() - t0
+        el_rank = time.perf_counter() - t0
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
-        dev_ms = ev0.elapsed_time(ev1) / max(1, steps)
-        if use_dist:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el, dev_ms
+        sync()
+        dev_ms = (ev0.elapsed_time(ev1) if ev0 is not None else el_rank * 1e3) / max(1, steps)
+        el = reduce_scalar(el_rank, dist.ReduceOp.MAX) if use_dist else el_rank
+        el_min = reduce_scalar(el_rank, dist.ReduceOp.MIN) if use_dist else el_rank
+        return el, dev_ms, el_min
 
     goal_mode = args.exchange == "goal"
     ring, compute = make_schedule(args.exchange, args.gather_every, args.overlap_gather)
     G = ring.G
-    lib = _lib.load()
-    torch.cuda.synchronize()
+    if not standin:
+        _lib.load()
+    sync()
     # Untimed clock ramp: the MI355X needs tens of milliseconds of sustained work to reach its steady clocks
     # (measured: 0.210 ms per cfg2 batch after 5 warmup batches, 0.194 ms after 300).  The metric is sustained
     # throughput, so the device is brought to steady state before the W warmup steps and the K timed steps.
@@ -279,8 +389,8 @@ def main():
         while (time.perf_counter() - t_r) * 1e3 < args.ramp_ms:
             for _ in range(16):
                 bp.run(out=ring.buf[0][:B])
-            torch.cuda.synchronize()
-    elapsed, device_ms_per_step = time_schedule(ring, compute, args.steps, args.warmup)
+            sync()
+    elapsed, device_ms_per_step, elapsed_min = time_schedule(ring, compute, args.steps, args.warmup)
     goal_last = [goal_state.get("last")]
     # The other exchange schedules, timed the same way right after the headline one and reported as extra keys of the
     # SAME line (multi-GPU runs only): the amortised all-gather (32 steps per collective) and the gather-free goal
@@ -292,7 +402,7 @@ def main():
             todo.append(("all_gather_every_32_steps", "gather", 32))
         if not (args.exchange == "gather" and G == 1):
             todo.append(("all_gather_every_step", "gather", 1))
-        if not wl.lindblad and args.exchange != "goal":
+        if not wl.lindblad and args.exchange != "goal" and not standin:
             todo.append(("goal_all_reduce_every_step", "goal", 1))
         todo = [(n_, e_, g_, False) for n_, e_, g_ in todo]
         if not (args.exchange == "gather" and G == 1 and args.overlap_gather):
@@ -302,44 +412,72 @@ def main():
             todo.append(("all_gather_every_step_overlapped", "gather", 1, True))
         for name, ex, ge, ov in todo:
             r2, c2 = make_schedule(ex, ge, ov)
-            el2, dms2 = time_schedule(r2, c2, args.steps, args.warmup)
-            alt[name] = {"value": B_glob * args.steps / el2, "ms_per_step": el2 / args.steps * 1e3, "device_ms_per_step": dms2}
+            el2, dms2, el2_min = time_schedule(r2, c2, args.steps, args.warmup)
+            alt[name] = {"value": B_glob * args.steps / el2, "ms_per_step": el2 / args.steps * 1e3, "ms_per_step_fastest_rank": el2_min / args.steps * 1e3,
+                         "device_ms_per_step": dms2, "collectives": r2.collectives}
             del r2, c2
-    kernel_name = _lib.last_kernel()
+    kernel_name = "TEST STAND-IN" if standin else _lib.last_kernel()
 
     err = None
     nchk = 0
+    gathered_checked = 0
     if args.check:
-        from oracle import c3_oracle
-
-        # a spread of samples of this rank's shard against the oracle (bounded by the oracle's cost); a rank with an
-        # empty shard (strong scaling of a batch smaller than the world) still takes part in every collective below
+        # (1) a spread of samples of this rank's shard against the oracle (bounded by the oracle's cost); a rank with an
+        # empty shard (strong scaling of a batch smaller than the world) still takes part in every collective below.
+        # (2) N > 1: after one more gathered step, this rank's slab as RECEIVED must equal what it computed, and one sample
+        # of every OTHER rank's received slab is checked against the oracle on that sample's inputs (the synthetic inputs are
+        # seeded per global sample index, so any rank can rebuild them).
         err = 0.0
+
+        def reference(w, idx):
+            from oracle import c3_oracle  # the CPU restatement: checker only, after the timed region
+
+            return c3_oracle.propagate_batch(w.h0, w.hks, w.signals[idx], w.dt, col_ops=w.col_ops, lindbladian=w.lindblad, fr_phase=w.fr_phase[idx])
+
+        if standin:
+            def reference(w, idx, lo_=lo):  # noqa: F811  (the stand-in's own formula: nothing is computed in that mode)
+                return _StandInPropagator(torch, lo_, len(w.signals), Dm).U.numpy()[idx]
+
         if bp is not None:
             cost = wl.N * (Dm / 9.0) ** 3
             nchk = int(min(B, max(2, min(32, 2.5e5 / cost))))
             idx = np.unique(np.linspace(0, B - 1, nchk).astype(int))
             U = bp.run()
-            torch.cuda.synchronize()
-            ref = c3_oracle.propagate_batch(wl.h0, wl.hks, wl.signals[idx], wl.dt, col_ops=wl.col_ops, lindbladian=wl.lindblad, fr_phase=wl.fr_phase[idx])
+            sync()
+            ref = reference(wl, idx)
             Uh = U[torch.as_tensor(idx, device=dev)].cpu().numpy()
             err = float(max(np.linalg.norm(Uh[i] - ref[i]) for i in range(len(idx))))
             nchk = len(idx)
         if use_dist:
             if args.exchange == "gather":
-                # the slab every rank received from this rank must equal this rank's own result
                 ring.step(compute)
                 ring.drain()
-                torch.cuda.synchronize()
+                sync()
                 if bp is not None:
                     mine = ring.gathered_slab(rank, 0)[:B]
                     assert torch.equal(mine, ring.buf[0][:B]), "all-gather mismatch"
-            e = torch.tensor([err], dtype=torch.float64, device=dev)
-            dist.all_reduce(e, op=dist.ReduceOp.MAX)
-            err = float(e.item())
-            n_ = torch.tensor([float(nchk)], dtype=torch.float64, device=dev)
-            dist.all_reduce(n_, op=dist.ReduceOp.SUM)
-            nchk = int(n_.item())
+                for q in range(world):
+                    if q == rank:
+                        continue
+                    _, lo_q, hi_q, _ = plan_batch(cfg, args.scaling, args.batch, world, q)
+                    if hi_q <= lo_q:
+                        continue
+                    j = (rank + 7 * q) % (hi_q - lo_q)  # a different sample of rank q's shard on every checking rank
+                    got = ring.gathered_slab(q, 0)[j].cpu().numpy()
+                    if standin:
+                        want = _StandInPropagator(torch, lo_q + j, 1, Dm).U.numpy()[0]
+                    else:
+                        wq = workloads.make_workload(args.config, B=1, N=args.slices, b_offset=lo_q + j)
+                        if args.complex_ops:
+                            wq.hks = wl.hks
+                        want = reference(wq, np.array([0]))[0]
+                    err = max(err, float(np.linalg.norm(got - want)))
+                    gathered_checked += 1
+            err = reduce_scalar(err, dist.ReduceOp.MAX)
+            nchk = int(reduce_scalar(nchk, dist.ReduceOp.SUM))
+            gathered_checked = int(reduce_scalar(gathered_checked, dist.ReduceOp.SUM))
+        if err > 1e-10:
+            print(f"[bench] CHECK FAILED: max |U - U_ref|_F = {err:.3e}", file=sys.stderr, flush=True)
 
     if rank == 0:
         total_props = B_glob * args.steps
@@ -380,6 +518,7 @@ def main():
             "value": value,
             "unit": "propagators/s",
             "n_gpus": world,
+            "n_devices_visible": ndev,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -427,6 +566,22 @@ def main():
                 "note": "fp64 compute-bound path. frac = USEFUL issued flops / device time per step (HIP events over the timed region, launch gaps included) / dense fp64 peak: flops the kernel really issues (PMC) with the zero padding of its MFMA tiles taken out; null unless the committed PMC profile is of exactly this kernel build, batch and slice count (pmc_exact_match). frac_algorithmic = SURVEY 8d's figure (the reference's complex Pade order per slice + product tree) over the same time: a method that needs fewer flops than the reference's (real cos / sin evaluation of real Hamiltonians; Lindblad chains in real arithmetic in the Hermitian basis) exceeds the hardware fraction there and can exceed 1; it is an algorithm credit, not a hardware one. traffic = HBM-side bytes per launch from the same PMC passes",
             },
         }
+        if use_dist:
+            out["launch"] = {
+                "launcher": "bench.py self-launch (one child process per rank)" if os.environ.get("C3P_BENCH_SELF_LAUNCHED") == "1" else "external (torch.distributed.run / RANK, WORLD_SIZE from the environment)",
+                "backend": dist.get_backend(),
+                "rccl_world_size" if backend == "nccl" else "gloo_world_size": dist.get_world_size(),
+                "oversubscribed": bool(oversubscribed),
+                "ms_per_step_slowest_rank": elapsed / args.steps * 1e3,
+                "ms_per_step_fastest_rank": elapsed_min / args.steps * 1e3,
+                "collectives_per_timed_region": -(-args.steps // G),
+            }
+            if oversubscribed:
+                out["launch"]["note"] = (f"{world} ranks on {ndev} visible device(s): RCCL refuses ranks that share a device (Duplicate GPU detected), so the slabs travel over gloo through host "
+                                         "memory and the ranks time-slice the device -- an execution of the N > 1 path (sharding, exchange schedules, gathered check), NOT a scaling measurement")
+        if standin:
+            out["metric"] = "TEST STAND-IN (nothing computed; launcher / exchange plumbing only)"
+            out["data"] = "stand-in"
         if alt:
             out["other_exchange_schedules"] = dict(alt, note="same steps / warmup, timed right after the headline schedule in the same process; value = whole-job propagators/s")
         if goal_mode and goal_last[0] is not None:
@@ -435,6 +590,7 @@ def main():
         if err is not None:
             out["max_fro_err_vs_oracle"] = err
             out["oracle_samples_checked"] = nchk
+            out["gathered_samples_of_other_ranks_checked"] = gathered_checked
         if world == 1 and not args.no_e2e and bp is not None:
             t_e = time.perf_counter()
             out["e2e"] = e2e_rates(wl, fr, propagation, torch, dev)
@@ -453,6 +609,8 @@ def main():
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
+    if err is not None and err > 1e-10:
+        sys.exit(3)
 
 
 def evaluation_rates(cfg, wl, fr, propagation, torch, dev, forward_ms, reps=5):

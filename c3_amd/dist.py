@@ -145,10 +145,12 @@ class SlabRing:
 
     `compute(out)` fills `out` [b_pad, ...] (rows past the rank's own `b_local` samples are padding so that uneven
     shards -- strong scaling of a batch that does not divide by the world size -- use one equal-size collective).
-    Works on any backend / device (RCCL on the GPU box, gloo on CPU in tests/test_dist_gloo.py).
+    Works on any backend / device (RCCL on the GPU box, gloo on CPU in tests/test_dist_gloo.py).  `stage_host`: device
+    slabs exchanged by a CPU-only backend (gloo between ranks that SHARE a device, which RCCL refuses): the bank is copied
+    to host memory, gathered there and copied back -- synchronous, for executing the N > 1 path on one device, not for speed.
     """
 
-    def __init__(self, b_local: int, b_pad: int, tail: tuple, G: int, *, dtype=None, device=None, group=None, use_dist=None, overlap=False):
+    def __init__(self, b_local: int, b_pad: int, tail: tuple, G: int, *, dtype=None, device=None, group=None, use_dist=None, overlap=False, stage_host=False):
         import torch
         import torch.distributed as dist
 
@@ -163,7 +165,8 @@ class SlabRing:
         # overlap: TWO banks of G slabs.  The collective of a full bank is issued asynchronously (RCCL's own stream, ordered
         # after the kernels that filled the bank) and the next G steps compute into the other bank; a bank is waited for only
         # when it is about to be overwritten (and at drain()).  Still one collective per G steps, every slab gathered.
-        self.overlap = bool(overlap) and self.use_dist
+        self.stage_host = bool(stage_host) and self.use_dist
+        self.overlap = bool(overlap) and self.use_dist and not self.stage_host
         nb = 2 if self.overlap else 1
         self._banks = [torch.zeros((self.G, self.b_pad) + tuple(tail), dtype=dtype, device=device) for _ in range(nb)]
         self.buf = self._banks[0]
@@ -193,13 +196,19 @@ class SlabRing:
             bank = self._cur
             dst = self._real(self._gathered[bank][: self.world * n])
             src = self._real(self._banks[bank][:g].reshape(-1))
-            if self.overlap:
+            if self.stage_host:
+                src_h = src.cpu()  # waits for the kernels that filled the bank
+                dst_h = self.torch.empty(dst.shape, dtype=dst.dtype)
+                self.dist.all_gather_into_tensor(dst_h, src_h, group=self.group)
+                dst.copy_(dst_h)
+            elif self.overlap:
                 self._work[bank] = self.dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True)
                 self._cur = bank ^ 1
                 self._wait(self._cur)  # the bank the next steps compute into: its previous collective must have read it
             else:
                 self.dist.all_gather_into_tensor(dst, src, group=self.group)
             self.gathered = self._gathered[bank]
+            self._gathered_bank = bank
             self.collectives += 1
             self.last_flushed = g
         self.pending = 0
@@ -228,7 +237,10 @@ class SlabRing:
             self.flush()
 
     def gathered_slab(self, r: int, i: int):
-        """Slab i (of the most recent collective) as sent by rank r: [b_pad, ...]."""
+        """Slab i (of the most recent collective) as sent by rank r: [b_pad, ...].  With `overlap` the collective may still be
+        in flight: it is waited for here (RCCL: the current stream is ordered after it; gloo: the host waits)."""
+        if self.use_dist:
+            self._wait(getattr(self, "_gathered_bank", 0))
         g = self.last_flushed
         flat = self.gathered[r * g * self.slab : (r + 1) * g * self.slab]
         return flat.reshape((g,) + tuple(self.buf.shape[1:]))[i]

@@ -45,6 +45,31 @@ def test_bench_json_line(lib):
     assert d["max_fro_err_vs_oracle"] < 1e-10
 
 
+@pytest.mark.gpu
+def test_bench_two_ranks_on_the_visible_devices(lib):
+    """`python bench.py --gpus 2` launches its own two ranks.  On a one-GPU box they share the device (RCCL refuses that, so the
+    slabs travel over gloo through host memory -- flagged `oversubscribed`); on a node with >= 2 GPUs the same command is the
+    RCCL run.  Either way: sharding, every exchange schedule and the gathered check (own slab + the other rank's) execute."""
+    import torch
+    from c3_amd import _lib
+
+    _lib.require_gpu()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "128"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, out.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 256 and d["config"]["batch_per_gpu"] == 128
+    la = d["launch"]
+    assert la["oversubscribed"] == (torch.cuda.device_count() < 2)
+    assert la.get("rccl_world_size", la.get("gloo_world_size")) == 2
+    assert d["max_fro_err_vs_oracle"] < 1e-10 and d["gathered_samples_of_other_ranks_checked"] == 2
+    assert set(d["other_exchange_schedules"]) >= {"all_gather_every_32_steps", "goal_all_reduce_every_step", "all_gather_every_step_overlapped"}
+    assert d["metric"] == "full-gate propagators/s"
+
+
 def test_design_tables_are_generated_from_the_committed_profiles():
     """DESIGN.md's measurement tables are the output of tools/design_tables.py over profiles/r04/*.json"""
     import subprocess

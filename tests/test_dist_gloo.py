@@ -157,3 +157,55 @@ def test_bench_plan_batch_defaults():
     assert bench.plan_batch(C[3], "strong", None, 8, 7) == (4096, 7 * 512, 4096, 512)
     assert bench.plan_batch(C[5], "strong", 10, 4, 3) == (10, 8, 10, 3)
     assert bench.plan_batch(C[2], "weak", 64, 4, 2) == (256, 128, 192, 64)
+
+
+# --------------------------------------------------------------------------
+# `python bench.py --gpus N` launches its own ranks.  C3P_BENCH_STANDIN=1 swaps the HIP propagator for a
+# labelled stand-in so that the launcher, plan_batch, every exchange schedule and the gathered check run here on gloo.
+# --------------------------------------------------------------------------
+
+
+def _run_bench(args, extra_env=None, launcher=None):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, C3P_BENCH_STANDIN="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    cmd = [sys.executable] + (launcher or []) + [os.path.join(root, "bench.py")] + args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    return out, (json.loads(out.stdout) if out.returncode == 0 and out.stdout.strip() else None)
+
+
+@pytest.mark.parametrize("scaling,batch", [("strong", 5), ("weak", 3)])
+def test_bench_self_launch_two_ranks(scaling, batch):
+    out, d = _run_bench(["--gpus", "2", "--steps", "5", "--warmup", "2", "--batch", str(batch), "--scaling", scaling, "--ramp-ms", "0"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert len(out.stdout.splitlines()) == 1  # ONE JSON line, from rank 0
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == scaling
+    assert d["config"]["global_batch"] == (5 if scaling == "strong" else 6)
+    la = d["launch"]
+    assert la["gloo_world_size"] == 2 and "self-launch" in la["launcher"] and la["oversubscribed"] is False
+    assert la["ms_per_step_fastest_rank"] <= la["ms_per_step_slowest_rank"] == d["ms_per_step"]
+    assert abs(d["value"] - d["config"]["global_batch"] * 5 / (d["ms_per_step"] * 5e-3)) < 1e-6 * d["value"]
+    # --check is the default at N > 1: own shard, own slab as received, one sample of the other rank's slab per rank
+    assert d["max_fro_err_vs_oracle"] == 0.0 and d["gathered_samples_of_other_ranks_checked"] == 2
+    assert set(d["other_exchange_schedules"]) >= {"all_gather_every_32_steps", "all_gather_every_step_overlapped"}
+    assert "STAND-IN" in d["metric"]  # a stand-in line can never pass for a measurement
+
+
+def test_bench_under_torchrun_two_ranks():
+    """the driver's launch form: python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2"""
+    launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port())]
+    out, d = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--ramp-ms", "0", "--no-alt-schedules"], launcher=launcher)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert d["n_gpus"] == 2 and d["launch"]["gloo_world_size"] == 2 and "external" in d["launch"]["launcher"]
+    assert d["max_fro_err_vs_oracle"] == 0.0
+
+
+def test_bench_self_launch_propagates_a_failing_rank():
+    out, d = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "0", "--config", "99"])
+    assert out.returncode != 0 and d is None
