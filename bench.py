@@ -257,7 +257,7 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         if rank == 0:
-            print(f"[bench] world size {dist.get_world_size()} (backend {dist.get_backend()}{', ranks share devices' if oversubscribed else ''})", file=sys.stderr, flush=True)
+            print(f"[bench] {'RCCL' if backend == 'nccl' else 'gloo'} world size {dist.get_world_size()} (backend {dist.get_backend()}{', ranks share devices' if oversubscribed else ''})", file=sys.stderr, flush=True)
     red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the scalar reductions of this file live
     sync = (lambda: None) if standin else torch.cuda.synchronize
 

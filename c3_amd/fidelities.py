@@ -17,6 +17,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 from . import _lib
+from ._cache import TensorMemo
 from .propagation import _Call, _ptr, C3PropError
 
 fidelities: Dict[str, object] = dict()
@@ -120,6 +121,17 @@ def average_infid(ideal, actual, index: List[int] = [0], dims=[2]):
     return 1 - (abs(s) ** 2 / L + 1) / (L + 1)
 
 
+def _mean_over_gates(vals):
+    """Mean over the gates of a set.  Device propagators give device infidelities: they are reduced on the device (np.asarray
+    of a CUDA tensor is a TypeError, and a .cpu() per gate a host synchronisation per gate)."""
+    if any(hasattr(v, "detach") for v in vals):
+        import torch
+
+        dev = next(v.device for v in vals if hasattr(v, "detach"))
+        return torch.stack([v if hasattr(v, "detach") else torch.as_tensor(np.asarray(v), device=dev) for v in vals]).mean(dim=0)
+    return np.mean([np.asarray(v) for v in vals], axis=0)
+
+
 def _ideal_of(instructions, gate, dims, index):
     g = instructions[gate]
     return g.get_ideal_gate(dims, index) if hasattr(g, "get_ideal_gate") else g
@@ -129,15 +141,13 @@ def _ideal_of(instructions, gate, dims, index):
 def unitary_infid_set(propagators: dict, instructions: dict, index, dims, n_eval=-1):
     """Mean over gates (fidelities.py:187-218).  `instructions[gate]` is a reference Instruction
     (`get_ideal_gate`) or directly the ideal matrix."""
-    vals = [np.asarray(unitary_infid(_ideal_of(instructions, g, dims, index), U, index, dims)) for g, U in propagators.items()]
-    return np.mean(vals, axis=0)
+    return _mean_over_gates([unitary_infid(_ideal_of(instructions, g, dims, index), U, index, dims) for g, U in propagators.items()])
 
 
 @fid_reg_deco
 def average_infid_set(propagators: dict, instructions: dict, index, dims, n_eval=-1):
     """Mean over gates (fidelities.py:316-347)."""
-    vals = [np.asarray(average_infid(_ideal_of(instructions, g, dims, index), U, index, dims)) for g, U in propagators.items()]
-    return np.mean(vals, axis=0)
+    return _mean_over_gates([average_infid(_ideal_of(instructions, g, dims, index), U, index, dims) for g, U in propagators.items()])
 
 
 def _cotangent(ideal, actual, index, dims, scale_of_L):
@@ -181,8 +191,9 @@ def average_infid_cotangent(ideal, actual, index: List[int] = [0], dims=[2]):
 # --------------------------------------------------------------------------
 
 
-_super_cache: Dict[tuple, tuple] = {}
-_super_emb: Dict[tuple, object] = {}
+# tf_super(ideal) images per ideal-gate tensor OBJECT (weak reference + version; dropped when the tensor dies): keyed by
+# (dims, index, device) under the tensor, value = (srows, Gs, rows_d, G, emb).  Never keyed by data_ptr().
+_super_memo = TensorMemo()
 
 
 def _super_overlap(ideal, actual, index, dims):
@@ -204,10 +215,11 @@ def _super_overlap(ideal, actual, index, dims):
     # synchronisation, and illegal inside a stream capture)
     key = None
     if call.device and hasattr(ideal, "data_ptr"):
-        key = (tuple(int(d) for d in dims), tuple(index) if index else None, str(call.dev), ideal.data_ptr(), getattr(ideal, "_version", 0), tuple(ideal.shape))
-    hit = _super_cache.get(key) if key is not None else None
+        key = (tuple(int(d) for d in dims), tuple(index) if index else None, str(call.dev), tuple(ideal.shape))
+    hit = _super_memo.get(ideal, key) if key is not None else None
+    emb = None
     if hit is not None:
-        srows, Gs, rows_d, G = hit
+        srows, Gs, rows_d, G, emb = hit
     else:
         srows = (rows[:, None].astype(np.int64) * D + rows[None, :]).reshape(-1).astype(np.int32)
         Gi = np.asarray(ideal.detach().cpu().numpy() if hasattr(ideal, "detach") else ideal, dtype=np.complex128)
@@ -218,20 +230,17 @@ def _super_overlap(ideal, actual, index, dims):
             rows_d = call.torch.as_tensor(srows, device=call.dev)
             G = call.torch.as_tensor(Gs, device=call.dev)
             if key is not None:
-                if len(_super_cache) > 32:
-                    _super_cache.clear()
                 emb = call.torch.zeros((Dm, Dm), dtype=call.torch.complex128, device=call.dev)
                 r = call.torch.as_tensor(srows.astype(np.int64), device=call.dev)
                 emb[r[:, None], r[None, :]] = G
-                _super_emb[key] = emb
-                _super_cache[key] = (srows, Gs, rows_d, G)
+                _super_memo.put(ideal, key, (srows, Gs, rows_d, G, emb))
         else:
             rows_d, G = srows, np.ascontiguousarray(Gs)
     if call.device:
         out = call.torch.empty((B,), dtype=call.torch.complex128, device=call.dev)
     else:
         out = np.empty((B,), dtype=np.complex128)
-    call.super_key = key
+    call.super_emb = emb
     _lib.check(_lib.load().c3p_gate_overlap(_ptr(S), B, Dm, _ptr(rows_d), L * L, _ptr(G), call.flags, _ptr(out), call.stream))
     return (out[0] if squeeze else out), L, srows, Gs, call, squeeze, B, Dm
 
@@ -246,12 +255,7 @@ def lindbladian_unitary_infid(ideal, actual, index: List[int] = [0], dims=[2]):
 @fid_reg_deco
 def lindbladian_unitary_infid_set(propagators: dict, instructions: dict, index, dims, n_eval=-1):
     """Mean over gates (fidelities.py:252-285)."""
-    vals = [lindbladian_unitary_infid(_ideal_of(instructions, g, dims, index), U, index, dims) for g, U in propagators.items()]
-    if any(hasattr(v, "detach") for v in vals):  # device propagators: reduce on the device
-        import torch
-
-        return torch.stack([v if hasattr(v, "detach") else torch.as_tensor(v) for v in vals]).mean(dim=0)
-    return np.mean([np.asarray(v) for v in vals], axis=0)
+    return _mean_over_gates([lindbladian_unitary_infid(_ideal_of(instructions, g, dims, index), U, index, dims) for g, U in propagators.items()])
 
 
 def lindbladian_unitary_infid_cotangent(ideal, actual, index: List[int] = [0], dims=[2]):
@@ -261,7 +265,7 @@ def lindbladian_unitary_infid_cotangent(ideal, actual, index: List[int] = [0], d
     tv = t.reshape(1) if squeeze else t
     if call.device:
         tt = call.torch
-        emb = _super_emb.get(getattr(call, "super_key", None)) if getattr(call, "super_key", None) is not None else None
+        emb = getattr(call, "super_emb", None)
         if emb is None:
             emb = tt.zeros((Dm, Dm), dtype=tt.complex128, device=call.dev)
             r = tt.as_tensor(srows.astype(np.int64), device=call.dev)

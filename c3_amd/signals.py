@@ -14,6 +14,7 @@ from typing import Dict, Optional, Sequence
 import numpy as np
 
 from . import _lib
+from ._cache import TensorMemo
 from ._lib import C3PropError
 from .propagation import _Call, _is_torch, _ptr
 
@@ -83,18 +84,21 @@ def pack_components(channels: Sequence[Sequence[Dict]], B: int = 1):
     return env, shapes
 
 
-_shapes_cache: Dict[tuple, object] = {}
+_shapes_memo = TensorMemo()  # device shape tables: per tensor object (weak reference + version), never per address
+_shapes_upload: Dict[tuple, object] = {}  # content-keyed uploads of host tables
 
 
 def _shapes(call, env_shapes, K: int, E: int):
     """(host int32 [K,E], the array the library call takes): validated once per distinct table; on the device path the upload
-    is cached per (table, device) -- an optimiser calls the synthesis and its vjp every iteration with the same shapes, and a
-    pageable host-to-device copy per call is a synchronisation (and illegal inside a stream capture)."""
-    if _is_torch(env_shapes) and env_shapes.is_cuda:
-        key = ("dev", env_shapes.data_ptr(), env_shapes._version, tuple(env_shapes.shape), str(env_shapes.dtype))
-        hit = _shapes_cache.get(key)
-        if hit is not None:
-            return hit
+    is cached -- an optimiser calls the synthesis and its vjp every iteration with the same shapes, and a pageable
+    host-to-device copy per call is a synchronisation (and illegal inside a stream capture).  A device table is remembered
+    per tensor OBJECT; the [K,E] check against the parameter rows runs on every call, hit or not."""
+    on_dev = _is_torch(env_shapes) and env_shapes.is_cuda
+    hit = _shapes_memo.get(env_shapes, str(env_shapes.dtype)) if on_dev else None
+    if hit is not None:
+        if hit[0].shape != (K, E):
+            raise C3PropError(f"C3:Error: env_shapes must be [{K},{E}], got {hit[0].shape}")
+        return hit
     shapes_np = np.ascontiguousarray(np.asarray(env_shapes.cpu() if _is_torch(env_shapes) else env_shapes, dtype=np.int32))
     if shapes_np.shape != (K, E):
         raise C3PropError(f"C3:Error: env_shapes must be [{K},{E}], got {shapes_np.shape}")
@@ -103,13 +107,13 @@ def _shapes(call, env_shapes, K: int, E: int):
     if not call.device:
         return shapes_np, shapes_np
     key2 = (shapes_np.tobytes(), shapes_np.shape, str(call.dev))
-    shp = _shapes_cache.get(key2)
+    shp = _shapes_upload.get(key2)
     if shp is None:
-        if len(_shapes_cache) > 64:
-            _shapes_cache.clear()
-        shp = _shapes_cache[key2] = call.torch.as_tensor(shapes_np, device=call.dev)
-    if _is_torch(env_shapes) and env_shapes.is_cuda:
-        _shapes_cache[key] = (shapes_np, shp)
+        if len(_shapes_upload) > 64:
+            _shapes_upload.clear()
+        shp = _shapes_upload[key2] = call.torch.as_tensor(shapes_np, device=call.dev)
+    if on_dev:
+        _shapes_memo.put(env_shapes, str(env_shapes.dtype), (shapes_np, shp))
     return shapes_np, shp
 
 
