@@ -662,8 +662,14 @@ def evaluation_rates(cfg, wl, fr, propagation, torch, dev, forward_ms, reps=5):
 
 
 def e2e_rates(wl, fr, propagation, torch, dev, reps=3):
-    """PCIe-inclusive rates (never the reported `value`): host numpy in / out through C3P_HOST_PTRS
-    (control samples in, U out, synchronous)."""
+    """PCIe-inclusive rates (never the reported `value`), two boundaries:
+      host samples    numpy arrays in host memory -> C ABI (C3P_HOST_PTRS: H2D of the control samples, kernel, D2H of U)
+      parameter rows  SURVEY 8f-2's boundary: envelope parameter rows + carriers in (a few KB), control samples synthesised ON
+                      THE DEVICE (c3p_synth_signals), chains, D2H of U -- what a caller that owns pulse parameters pays."""
+    import numpy as np
+
+    from c3_amd import signals as sg
+
     def host():
         propagation.propagate_batch(wl.h0, wl.hks, wl.signals, wl.dt, col_ops=wl.col_ops, lindbladian=wl.lindblad, fr_phase=fr)
 
@@ -673,13 +679,47 @@ def e2e_rates(wl, fr, propagation, torch, dev, reps=3):
         host()
     t = (time.perf_counter() - t0) / reps
     Dm = wl.D * wl.D if wl.lindblad else wl.D
-    return {
+    out = {
         "host_in_out_props_per_s": wl.B / t,
         "host_in_out_ms_per_batch": t * 1e3,
         "bytes_in": int(wl.signals.nbytes),
         "bytes_out": int(wl.B * Dm * Dm * 16),
-        "note": "numpy arrays in host memory -> C ABI (C3P_HOST_PTRS: H2D of the control samples, kernel, D2H of U, synchronous); parameter-row input (signals synthesised on the device): tools/bench_pcie.py",
+        "note": "host samples: numpy arrays in host memory -> C ABI (C3P_HOST_PTRS: H2D of the control samples, kernel, D2H of U, synchronous)",
     }
+    try:
+        T = wl.N * wl.dt
+        two_pi = 2.0 * np.pi
+        rng = np.random.default_rng(5)
+        chans = [[dict(shape="gaussian_nonorm", amp=rng.uniform(0.1, 0.6, wl.B), xy_angle=0.1 * k, freq_offset=-50e6 * two_pi, t_final=T, sigma=T / 4, use_t_before=True)]
+                 for k in range(wl.K)]
+        env, shapes = sg.pack_components(chans, B=wl.B)
+        car = np.tile(np.array([[(5.0e9 + 0.3e9 * k) * two_pi, 1e9 * two_pi] for k in range(wl.K)]), (wl.B, 1, 1))
+        t_ = lambda a: torch.as_tensor(a, device=dev)
+        h0, hks, ph = t_(wl.h0), t_(wl.hks), t_(fr)
+        col = t_(wl.col_ops) if wl.lindblad else None
+        sim_res = 1.0 / wl.dt
+
+        def rows():
+            sig = sg.synthesize_signals(t_(env), shapes, t_(car), 0.0, T, sim_res / 50.0, sim_res)
+            if tuple(sig.shape) != (wl.B, wl.K, wl.N):
+                raise RuntimeError(f"synthesised {tuple(sig.shape)}, wanted {(wl.B, wl.K, wl.N)}")
+            return propagation.propagate_batch(h0, hks, sig, wl.dt, col_ops=col, lindbladian=wl.lindblad, fr_phase=ph)["U"].cpu()
+
+        rows()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            rows()
+        tr = (time.perf_counter() - t0) / reps
+        out["parameter_rows"] = {
+            "props_per_s": wl.B / tr,
+            "ms_per_batch": tr * 1e3,
+            "bytes_in": int(env.nbytes + car.nbytes),
+            "bytes_out": int(wl.B * Dm * Dm * 16),
+            "note": "envelope parameter rows + carriers H2D, control samples synthesised on the device (c3p_synth_signals: gaussian envelopes, AWG sampling at 1/50 of the slice rate, IQ mixing), chain kernel, D2H of U, synchronous",
+        }
+    except Exception as e:  # noqa: BLE001  (a side measurement must not cost the headline line)
+        out["parameter_rows"] = {"error": str(e)[:200]}
+    return out
 
 
 def _oracle_run(wl, oracle, nb):
