@@ -137,8 +137,10 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--batch", type=int, default=None, help="weak: samples per GPU; strong: GLOBAL batch")
     ap.add_argument("--slices", type=int, default=None)
-    ap.add_argument("--overlap-gather", action="store_true",
-                    help="--exchange gather: issue the all-gather asynchronously and compute the next step(s) into a second bank of slabs meanwhile")
+    ap.add_argument("--overlap-gather", choices=("auto", "on", "off"), nargs="?", const="on", default="auto",
+                    help="--exchange gather: issue the all-gather asynchronously and compute the next step(s) into a second bank of slabs "
+                         "meanwhile.  auto (default): at N > 1 both forms of the one-gather-per-step schedule are calibrated untimed (same steps, "
+                         "MAX over ranks) and the faster one is the timed schedule; off at N = 1")
     ap.add_argument("--gather-every", type=int, default=1,
                     help="steps exchanged per all-gather (multi-GPU).  Default 1 = north_star's schedule: ONE all-gather of U per batch; "
                          "the amortised schedule (32) and the gather-free goal exchange are timed beside it and reported as extra keys")
@@ -376,20 +378,40 @@ def main():
         return el, dev_ms, el_min
 
     goal_mode = args.exchange == "goal"
+    sync()
+    # Untimed clock ramp: the MI355X needs tens of milliseconds of sustained work to reach its steady clocks
+    # (measured: 0.210 ms per cfg2 batch after 5 warmup batches, 0.194 ms after 300).  The metric is sustained
+    # throughput, so the device is brought to steady state before anything is calibrated or timed.
+    if args.ramp_ms > 0 and bp is not None:
+        scratch = torch.zeros((max(B, 1), Dm, Dm), dtype=torch.complex128, device=dev)
+        t_r = time.perf_counter()
+        while (time.perf_counter() - t_r) * 1e3 < args.ramp_ms:
+            for _ in range(16):
+                bp.run(out=scratch[:B])
+            sync()
+        del scratch
+    # Which form of "ONE all-gather of U per batch" is timed: in stream order behind the kernel, or asynchronous under the next
+    # batch's kernel (two banks of slabs).  Which one is faster depends on the node: under a chain kernel whose grid fills the
+    # chip exactly the RCCL kernel takes CUs away (one rank: 13 % slower), across N ranks it hides the link latency.  `auto`
+    # measures both untimed and takes the faster -- every rank takes the same decision (MAX over ranks of each time).
+    overlap_choice = {"mode": args.overlap_gather}
+    use_overlap = args.overlap_gather == "on"
+    if args.overlap_gather == "auto":
+        use_overlap = False
+        if use_dist and world > 1 and args.exchange == "gather" and (backend == "nccl" or standin):
+            cal = {}
+            for name_, ov_ in (("in_stream_order", False), ("overlapped", True)):
+                r_, c_ = make_schedule("gather", args.gather_every, ov_)
+                cal[name_] = time_schedule(r_, c_, max(8, args.warmup), 2)[0] / max(8, args.warmup) * 1e3
+                del r_, c_
+            use_overlap = cal["overlapped"] < cal["in_stream_order"]
+            overlap_choice.update(calibration_ms_per_step=cal, chosen="overlapped" if use_overlap else "in_stream_order")
+    args.overlap_gather = use_overlap
     ring, compute = make_schedule(args.exchange, args.gather_every, args.overlap_gather)
     G = ring.G
     if not standin:
         _lib.load()
     sync()
-    # Untimed clock ramp: the MI355X needs tens of milliseconds of sustained work to reach its steady clocks
-    # (measured: 0.210 ms per cfg2 batch after 5 warmup batches, 0.194 ms after 300).  The metric is sustained
-    # throughput, so the device is brought to steady state before the W warmup steps and the K timed steps.
-    if args.ramp_ms > 0 and bp is not None:
-        t_r = time.perf_counter()
-        while (time.perf_counter() - t_r) * 1e3 < args.ramp_ms:
-            for _ in range(16):
-                bp.run(out=ring.buf[0][:B])
-            sync()
     elapsed, device_ms_per_step, elapsed_min = time_schedule(ring, compute, args.steps, args.warmup)
     goal_last = [goal_state.get("last")]
     # The other exchange schedules, timed the same way right after the headline one and reported as extra keys of the
@@ -400,7 +422,7 @@ def main():
         todo = []
         if not (args.exchange == "gather" and G == 32):
             todo.append(("all_gather_every_32_steps", "gather", 32))
-        if not (args.exchange == "gather" and G == 1):
+        if not (args.exchange == "gather" and G == 1 and not args.overlap_gather):
             todo.append(("all_gather_every_step", "gather", 1))
         if not wl.lindblad and args.exchange != "goal" and not standin:
             todo.append(("goal_all_reduce_every_step", "goal", 1))
@@ -455,7 +477,7 @@ def main():
                 sync()
                 if bp is not None:
                     mine = ring.gathered_slab(rank, 0)[:B]
-                    assert torch.equal(mine, ring.buf[0][:B]), "all-gather mismatch"
+                    assert torch.equal(mine, ring.sent_slab(0)[:B]), "all-gather mismatch"
                 for q in range(world):
                     if q == rank:
                         continue
@@ -575,6 +597,7 @@ def main():
                 "ms_per_step_slowest_rank": elapsed / args.steps * 1e3,
                 "ms_per_step_fastest_rank": elapsed_min / args.steps * 1e3,
                 "collectives_per_timed_region": -(-args.steps // G),
+                "gather_overlap": overlap_choice,
             }
             if oversubscribed:
                 out["launch"]["note"] = (f"{world} ranks on {ndev} visible device(s): RCCL refuses ranks that share a device (Duplicate GPU detected), so the slabs travel over gloo through host "

@@ -2973,6 +2973,13 @@ int c3p_pwc_lindblad_taped(const void* h0, int64_t h0_bstride, const void* hks, 
     return combine_smalld(w, bf.seg, B, segments, Dm, 0, fr_phase, (cplx*)U_out, st) ? -1 : 0;
   }
   if (!c3p_regr_supported(D, Dm)) return fail("the taped Lindblad evaluation serves D = 2, 3, 4 (small-D tile kernels) and D = 7, 8, 9 (Hermitian-basis kernels), got D=%d", D);
+  {
+    // the segment count is the library's choice (c3p_pwc_lindblad_tape_bytes), as at D <= 4: the chain, scan and backward kernels
+    // are tuned and tested for that range only, and the tape layout follows from it
+    int seg_chk = 0;
+    if (c3p_pwc_lindblad_tape_bytes(B, K, N, D, &seg_chk) == 0 || seg_chk != segments)
+      return fail("taped Lindblad evaluation: shape not served or segment count %d != %d (c3p_pwc_lindblad_tape_bytes)", segments, seg_chk);
+  }
   const LindRegrSizes z = lind_regr_sizes(B, K, N, Dm, segments, B);
   if (tape_bytes < z.total()) return fail("tape too small: %zu bytes, need %zu (c3p_pwc_lindblad_tape_bytes)", tape_bytes, z.total());
   hipStream_t st = (hipStream_t)stream;
@@ -3057,7 +3064,14 @@ int c3p_pwc_lindblad_vjp_taped(const void* tape, size_t tape_bytes, int segments
     g_last_kernel = C3P_KERNEL_SMALLD;
     return 0;
   }
-  if (!c3p_regr_supported(D, Dm)) return fail("the taped Lindblad evaluation serves D = 2, 3 and D = 7, 8, 9, got D=%d", D);
+  if (!c3p_regr_supported(D, Dm)) return fail("the taped Lindblad evaluation serves D = 2, 3, 4 and D = 7, 8, 9, got D=%d", D);
+  {
+    // recomputed from the option table as it is NOW: an option that changes the segment count (or the kernel family) between
+    // the taped forward call and this one would reinterpret the tape -- refuse what can be detected
+    int seg_chk = 0;
+    if (c3p_pwc_lindblad_tape_bytes(B, K, N, D, &seg_chk) == 0 || seg_chk != segments)
+      return fail("taped Lindblad vjp: segment count %d != %d (c3p_pwc_lindblad_tape_bytes; were library options changed since the forward call?)", segments, seg_chk);
+  }
   const LindRegrSizes z = lind_regr_sizes(B, K, N, Dm, segments, B);
   if (tape_bytes < z.total()) return fail("tape too small: %zu bytes, need %zu", tape_bytes, z.total());
   hipStream_t st = (hipStream_t)stream;

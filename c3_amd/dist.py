@@ -236,6 +236,10 @@ class SlabRing:
             self.pending = g
             self.flush()
 
+    def sent_slab(self, i: int):
+        """This rank's own slab i of the most recent collective, as computed (the bank it was gathered from)."""
+        return self._banks[getattr(self, "_gathered_bank", 0)][i]
+
     def gathered_slab(self, r: int, i: int):
         """Slab i (of the most recent collective) as sent by rank r: [b_pad, ...].  With `overlap` the collective may still be
         in flight: it is waited for here (RCCL: the current stream is ordered after it; gloo: the host waits)."""

@@ -258,7 +258,9 @@ int c3p_pwc_lindblad_vjp(const void* h0, int64_t h0_bstride, const void* hks, in
  * c3/optimizers/optimizer.py:206-216), and the vector-Jacobian product runs from the tape: no second forward pass, nothing of
  * the evaluation lives in the library's shared workspace between the two calls.
  *   c3p_pwc_lindblad_tape_bytes: bytes of the tape for a shape (0: shape not served) and the segment count it is laid out for
- *     (pass it to both calls unchanged);
+ *     (pass it to both calls unchanged: both calls recompute it and fail on a mismatch, for every D.  The layout of the tape
+ *     also follows from the library's option table -- c3p_set_option must not be called between the taped forward call and
+ *     its vjp; a change that alters the segment count is refused by the vjp call);
  *   c3p_pwc_lindblad_taped: arguments and U_out as c3p_pwc_lindblad (device pointers, flags = 0, no dUs_out);
  *   c3p_pwc_lindblad_vjp_taped: U_bar, fr_phase, grad_signals as c3p_pwc_lindblad_vjp; signals = the ones the tape was recorded
  *     with; per_sample_operators = whether h0 / hks had a batch stride.

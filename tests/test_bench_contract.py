@@ -66,7 +66,8 @@ def test_bench_two_ranks_on_the_visible_devices(lib):
     assert la["oversubscribed"] == (torch.cuda.device_count() < 2)
     assert la.get("rccl_world_size", la.get("gloo_world_size")) == 2
     assert d["max_fro_err_vs_oracle"] < 1e-10 and d["gathered_samples_of_other_ranks_checked"] == 2
-    assert set(d["other_exchange_schedules"]) >= {"all_gather_every_32_steps", "goal_all_reduce_every_step", "all_gather_every_step_overlapped"}
+    assert set(d["other_exchange_schedules"]) >= {"all_gather_every_32_steps", "goal_all_reduce_every_step"}
+    assert {"all_gather_every_step", "all_gather_every_step_overlapped"} & set(d["other_exchange_schedules"])
     assert d["metric"] == "full-gate propagators/s"
 
 

@@ -193,7 +193,11 @@ def test_bench_self_launch_two_ranks(scaling, batch):
     assert abs(d["value"] - d["config"]["global_batch"] * 5 / (d["ms_per_step"] * 5e-3)) < 1e-6 * d["value"]
     # --check is the default at N > 1: own shard, own slab as received, one sample of the other rank's slab per rank
     assert d["max_fro_err_vs_oracle"] == 0.0 and d["gathered_samples_of_other_ranks_checked"] == 2
-    assert set(d["other_exchange_schedules"]) >= {"all_gather_every_32_steps", "all_gather_every_step_overlapped"}
+    # both forms of the one-gather-per-step schedule were calibrated; the one not chosen is timed beside the headline
+    cal = la["gather_overlap"]
+    assert cal["mode"] == "auto" and set(cal["calibration_ms_per_step"]) == {"in_stream_order", "overlapped"}
+    other = "all_gather_every_step" if cal["chosen"] == "overlapped" else "all_gather_every_step_overlapped"
+    assert set(d["other_exchange_schedules"]) >= {"all_gather_every_32_steps", other}
     assert "STAND-IN" in d["metric"]  # a stand-in line can never pass for a measurement
 
 
