@@ -2477,7 +2477,27 @@ int c3p_ode_solve(const void* h0, const void* hks, const double* signals, const 
       // chain kernel and the product is applied to the initial state -- D x the arithmetic on nseg x D x the lanes
       if (ode_segmented(w, a, nseg, (const cplx*)d_init, init_bstride, nullptr, (cplx*)d_states, st)) return -1;
     } else {
+      // rho-valued states, more than four control lines, no collapse operators, a batch that leaves SIMDs idle on the lane rows
+      // (one wave = four samples; measured crossover between 2048 and 16 384 samples, profiles/r04/ode_fallbacks.json): COMPLEX
+      // operators run 1.1 - 1.3x faster on the workgroup kernel there, real ones 1.4 - 1.7x faster on the lane rows.  The device
+      // decides (both kernels look at the operators and one of them leaves at once), as regr_prep_kernel does for the PWC path.
+      const bool split = step == C3P_STEP_VON_NEUMANN && K > 4 && C == 0 && B <= 4096 && !c3p_opt_on(C3P_OPT_ode_no_split);
+      a.complex_to_wg = split ? 1 : 0;
       LAUNCH_TRY(c3p_launch_ode_row(a, aux, st));
+      if (split) {
+        OdeArgs g = a;
+        g.complex_to_wg = 0;
+        g.wg_if_complex = 1;
+        const size_t elems = c3p_ode_elems(D, M, C);
+        const bool global = elems * cs > (size_t)(150 * 1024);
+        if (global) {
+          void* v;
+          if (ws_get(w, SL_SCRATCH, (size_t)B * elems * cs, &v)) return -1;
+          g.scratch = (cplx*)v;
+          g.scratch_stride = (long)elems;
+        }
+        LAUNCH_TRY(c3p_launch_ode(g, global, st));
+      }
     }
     if (record_stop(w, st)) return -1;
     if (flags & C3P_HOST_PTRS) return sg.finish();

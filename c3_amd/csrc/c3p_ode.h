@@ -36,6 +36,11 @@ struct OdeArgs {
   // init[(b * seg_count + seg) * init_bstride], integrates its own step range and writes states[b, n] of that range
   int seg_traj;
   int rho_general;  // matrix-core rho kernel: do not use the Hermitian shortcut (set by its launcher from C3P_ODE_RHO_GENERAL)
+  // Dispatch by what the DEVICE sees (the host cannot look into device operators): rho-valued states with more than four control
+  // lines and COMPLEX operators run faster on the workgroup kernel while the batch leaves SIMDs idle on the lane rows.  Both
+  // kernels are launched; complex_to_wg = 1 makes the lane-row kernel's complex instance leave at once when the operators are
+  // complex (the real instance keeps real ones), wg_if_complex = 1 makes the workgroup kernel leave at once when they are real.
+  int complex_to_wg, wg_if_complex;
 };
 
 // padded copies of the collapse operators for the lane-row rho kernel (c3p_ode_row.hip), written by its prep kernel

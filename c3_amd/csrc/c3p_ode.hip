@@ -91,6 +91,12 @@ __global__ void __launch_bounds__(256) ode_kernel(OdeArgs A) {
   const double* sig = A.signals + (long)b * K * N;
   const double dt = A.dt;
 
+  if (A.wg_if_complex) {
+    // launched beside the lane-row kernel (c3p_api.hip): only complex operators are this kernel's (same test as ode_mat_kernel)
+    int cx = 0;
+    for (int e = tid; e < (1 + K) * hsz; e += nt) cx |= ((e < hsz ? A.h0[e] : A.hks[e - hsz]).y != 0.0) ? 1 : 0;
+    if (!__syncthreads_or(cx)) return;
+  }
   const cplx* init = A.init + (long)b * A.init_bstride;
   for (int e = tid; e < ssz; e += nt) M.st(oS + e, init[e]);
   if (A.step == C3P_STEP_LINDBLAD_ID) {

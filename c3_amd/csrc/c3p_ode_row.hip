@@ -353,6 +353,9 @@ __global__ void __launch_bounds__(64, 1) ode_mat_kernel(OdeArgs A, OdeRowAux X) 
   // the real instance takes real Hamiltonians without collapse operators, the complex one everything else
   const bool real_case = (__all(im0) != 0) && C == 0;
   if (real_case != REALH) return;
+  if constexpr (!REALH) {
+    if (A.complex_to_wg && C == 0) return;  // complex operators of this call: the workgroup kernel launched beside takes them
+  }
 
   // G = sum_m C_m^+ C_m (row i, from the padded copy the prep kernel wrote), own rows of the collapse operators -> LDS
   double Gr[REALH ? 1 : DP], Gi[REALH ? 1 : DP];

@@ -34,6 +34,16 @@
 
 extern __shared__ __attribute__((aligned(16))) double c3p_rr_lds[];
 
+// Round 5: the running product U of the segment is parked in LDS between chain products (one tile set, 51 KB at Dm = 81;
+// every lane reads back its own elements: no barrier) instead of staying in registers for the whole slice.  Five tile sets
+// (R, accumulators, X / B2, X^2 / B3, U = 250 registers) + operands did not fit the 256 VALU-addressable registers: the
+// compiler kept part of them in the accumulation registers and 23 doubles per lane in SCRATCH, and the s_memtime probes
+// (-DC3P_REGR_TIMING) showed the phases between products -- a few hundred instructions each -- taking 9 - 17 k cycles: scratch
+// round trips.  -DC3P_REGR_ULDS=0 builds the round-4 form.
+#ifndef C3P_REGR_ULDS
+#define C3P_REGR_ULDS 1
+#endif
+
 namespace {
 
 // The chain loop of one wave.  NW = 4: one wave per SIMD, wave w owns the 4 NRG columns of column group w (NJ = NRG column
@@ -52,6 +62,8 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
   constexpr int DM = G::DM, LD = G::LD, BS = G::BS, DMP = G::DMP;
   constexpr int TSET = G::TSET;
   constexpr int RR_THREADS = 64 * NW;
+  constexpr bool ULDS = (C3P_REGR_ULDS != 0) && !LEAN && NW == 4;  // U parked in LDS (see the top of the file)
+  constexpr bool UOUT = LEAN || ULDS;                              // U does not live in registers
   const bool second = jj0 != 0;                         // the second wave of a pair
   const bool col_owner = (NW == 4) || second;           // column DM-1 of a product: the lighter wave of the pair
   const bool corner_owner = (cg == 0) && !second;
@@ -64,6 +76,7 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
   double* rpart = cpart + 4 * DMP;
   double* sg = rpart + 4 * DMP;
   double* red = sg + RR_KMAX * RR_CH;
+  double* ulds = red + 2 * RR_MAXWAVES;  // ULDS: element (tile, thread) of U at tile * 256 + tid (conflict free)
   const int col0 = 4 * NRG * cg + 4 * jj0;  // first column of this wave
   int rowC = 4 * b + q;                     // row of a C/D-layout element inside its row group
   int rowA = 4 * b + p;                     // row of an A-fragment element inside its row group
@@ -96,7 +109,7 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
   double acc[NRG][NJ];  // accumulators = the product
   double Xs[LEAN ? 1 : NRG][LEAN ? 1 : NJ];  // X, later B2 (LEAN: re-assembled / parked in the arena)
   double A2s[NRG][NJ];  // X^2, later B3
-  double Us[LEAN ? 1 : NRG][LEAN ? 1 : NJ];  // running product of the segment (LEAN: in the arena)
+  double Us[UOUT ? 1 : NRG][UOUT ? 1 : NJ];  // running product of the segment (LEAN: in the arena, ULDS: in LDS)
   double* arena = arena_base + (long)blockIdx.x * 2 * TSET;  // LEAN: sets {B2, U} of this workgroup
   auto park = [&](int set, const double (&v)[NRG][NJ]) {
     double* dst = rr_ubase(arena + set * TSET);
@@ -111,6 +124,19 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
     for (int Ig = 0; Ig < NRG; ++Ig)
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) v[Ig][jj] = src[(Ig * NJ + jj) * RR_THREADS + tid];
+  };
+
+  auto park_u = [&](const double (&v)[NRG][NJ]) {
+#pragma unroll
+    for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) ulds[(Ig * NJ + jj) * RR_THREADS + tid] = v[Ig][jj];
+  };
+  auto unpark_u = [&](double (&v)[NRG][NJ]) {
+#pragma unroll
+    for (int Ig = 0; Ig < NRG; ++Ig)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) v[Ig][jj] = ulds[(Ig * NJ + jj) * RR_THREADS + tid];
   };
 
   auto mfma = [](double a, double bb, double c) -> double { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, bb, c, 0, 0, 0); };
@@ -533,6 +559,8 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
           if (first) {
             if constexpr (LEAN) {
               park(1, acc);
+            } else if constexpr (ULDS) {
+              if (len > 1) park_u(acc);
             } else {
 #pragma unroll
               for (int Ig = 0; Ig < NRG; ++Ig)
@@ -550,6 +578,8 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
             if (tid < BS) border_to_image(brd[sd * BS + tid]);
             if constexpr (LEAN) {
               unpark(1, Rm);
+            } else if constexpr (ULDS) {
+              unpark_u(Rm);
             } else {
 #pragma unroll
               for (int Ig = 0; Ig < NRG; ++Ig)
@@ -564,6 +594,8 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
       } else {  // OP_CH: C = the running product
         if constexpr (LEAN) {
           if (t + 1 < len) park(1, acc);  // (the last one is written out from the accumulators)
+        } else if constexpr (ULDS) {
+          if (t + 1 < len) park_u(acc);
         } else {
 #pragma unroll
           for (int Ig = 0; Ig < NRG; ++Ig)
@@ -595,7 +627,7 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
 #endif
     // segment product (basis change and frame-rotation row phases are separate epilogues); the last product sits in
     // Us = acc and its border in slot ucur
-    if constexpr (!LEAN) {
+    if constexpr (!UOUT) {
 #pragma unroll
       for (int Ig = 0; Ig < NRG; ++Ig)
 #pragma unroll
@@ -759,7 +791,7 @@ __global__ void __launch_bounds__(256) hb_to_complex_kernel(cplx* mats, int mats
 
 template <int NRG, int NW, bool LEAN>
 hipError_t launch_rr(const MidArgs& A, void* arena, hipStream_t st) {
-  const size_t lds = (size_t)RR<NRG>::LDS_D * sizeof(double);
+  const size_t lds = ((size_t)RR<NRG>::LDS_D + ((C3P_REGR_ULDS != 0) && !LEAN && NW == 4 ? (size_t)RR<NRG>::TSET : 0)) * sizeof(double);
   const long nchains = (long)A.B * A.S;
   const long maxg = LEAN ? 2 * C3P_REGD_MAX_WGS : C3P_REGD_MAX_WGS;
   const unsigned grid = (unsigned)(nchains < maxg ? nchains : maxg);
