@@ -49,6 +49,23 @@
 #else
 #define C3P_MDR_ROWSPLIT 0
 #endif
+// Pinwheel deal of the 32-row real class with 7 column blocks (D = 25..28, cfg3): the 7 x 7 grid of 4 x 4 output blocks is
+// cut into four 3 x 4 / 4 x 3 rectangles around the centre block, one rectangle per wave, every block on
+// v_mfma_f64_4x4x4_4b (see Sched::PW).  -DC3P_MDR_NO_PINWHEEL builds the four padded 16 x 16 units for A/B.
+#ifndef C3P_PW_PFP
+#define C3P_PW_PFP 1  // K-step PAIRS the operand fetch of the pinwheel products runs ahead
+#endif
+#ifndef C3P_PW_TIMING
+#define C3P_PW_TIMING 0  // 1: timing-only build (WRONG results): one 4-column fragment per K-step instead of three
+#endif
+#ifndef C3P_PW_WGS
+#define C3P_PW_WGS 3  // workgroups per CU of the pinwheel class (forward kernel)
+#endif
+#if !defined(C3P_MDR_NO_PINWHEEL)
+#define C3P_MDR_PINWHEEL 1
+#else
+#define C3P_MDR_PINWHEEL 0
+#endif
 extern __shared__ __attribute__((aligned(16))) double c3p_md_lds[];
 
 namespace {
@@ -96,9 +113,18 @@ struct Sched {
   // cycles and their 16 x 4 stores are 8-way bank-conflicted; the kernel shares the LDS pipe of a CU between three
   // workgroups and was as LDS-bound (63 % busy) as MFMA-bound (62 %).  cfg3 +9 %; with 6 column blocks (D = 21..24) the
   // padding costs more matrix-pipe time than it saves LDS time (-4 %).
-  static constexpr bool PAD = NIG == 2 && NJ == 7;
-  static constexpr int NB16 = PAD ? 2 : NJ / 4;
-  static constexpr int JR = PAD ? 0 : NJ % 4;
+  // Round 5, the same class (PW): the padded deal multiplies 32 x 32 x 28 for a 27 x 27 x 27 product (tile utilisation 0.686).
+  // Pinwheel: the 28 x 28 output is 7 x 7 blocks of 4 x 4; wave 0 owns block rows 0..3 x block columns 0..2 (three "tall"
+  // 16 x 4 units), wave 1 block rows 0..2 x block columns 3..6 (three "wide" 4 x 16 units at column 12) plus the centre
+  // block (3, 3), wave 2 block rows 3..6 x block columns 4..6 (tall units at row 12), wave 3 block rows 4..6 x block
+  // columns 0..3 (wide units).  Every unit is ONE v_mfma_f64_4x4x4_4b per K-step: 3 x 16 matrix-pipe cycles per wave and
+  // K-step instead of 64; the centre block is K-packed (the four blocks of an instruction are four K-steps of the SAME
+  // output block, summed across the lane quads afterwards): 2 instructions per product instead of 7.  Per product
+  // 21 (+ 2) instructions of 16 cycles against 7 of 64; tile utilisation 27^3 / (4 * 21 + 2) / 256 = 0.894.
+  static constexpr bool PW = C3P_MDR_PINWHEEL != 0 && NIG == 2 && NJ == 7;
+  static constexpr bool PAD = !PW && NIG == 2 && NJ == 7;
+  static constexpr int NB16 = PAD ? 2 : (PW ? 0 : NJ / 4);
+  static constexpr int JR = (PAD || PW) ? 0 : NJ % 4;
   // The 48-row real class with 9 column blocks (D = 33..36, cfg5; real instance only): six 16 x 16 units and three 16 x 4
   // ones deal out as 128 / 128 / 96 / 80 matrix-pipe cycles per K-step; with the last NSPLIT = 2 big units dealt as four
   // small ones each it is 112 / 112 / 112 / 96.  (Splitting wherever it lowers the maximum was measured: +2 - 3 % here,
@@ -162,9 +188,32 @@ struct Sched {
 template <int NIG, int NJ, int W, int WV>
 struct WaveTiles {
   using S = Sched<NIG, NJ>;
-  static constexpr int NBW = S::nbig(WV);
-  static constexpr int NSW = S::nsmall(WV);
+  static constexpr int NBW = S::PW ? 0 : S::nbig(WV);
+  static constexpr int NSW = S::PW ? (WV == 1 ? 4 : 3) : S::nsmall(WV);
   static constexpr int NE = 4 * NBW + NSW;  // doubles per matrix held by each lane of this wave
+  // pinwheel deal (S::PW): element e < 3 is a tall unit (waves 0 / 2: rows R0 + 4b + r, column C0 + c) or a wide unit
+  // (waves 1 / 3: row R0 + r, columns C0 + 4b + c); element 3 of wave 1 is the centre block (rows 12 + r, columns 12 + c),
+  // valid in the lanes of quad b = 0 -- the other quads hold copies that are parked at never-read positions of the zero
+  // rows 28..31 (columns 4 (b - 1) + c), outside the matrix for every mask.  The units at row / column 12 (waves 2 / 1)
+  // put quad b on block (b + 1) & 3 of their 16 rows / columns (see md_pw_off).
+  static constexpr bool pw_tall = (WV & 1) == 0;
+  static constexpr int pw_r0(int e) { return WV == 0 ? 0 : WV == 2 ? 12 : WV == 1 ? 4 * e : 16 + 4 * e; }
+  static constexpr int pw_c0(int e) { return WV == 0 ? 4 * e : WV == 2 ? 16 + 4 * e : WV == 1 ? 12 : 0; }
+  // row / column of element e in lane (r, b, c)
+  static __device__ __forceinline__ int lrow(int e, int r, int b, int c) {
+    if (S::PW) {
+      if (e == 3) return b == 0 ? 12 + r : 28 + r;
+      return pw_r0(e) + (pw_tall ? 4 * (WV == 2 ? (b + 1) & 3 : b) + r : r);
+    }
+    return row0(e) + (is_big(e) ? r : 4 * b + r);
+  }
+  static __device__ __forceinline__ int lcol(int e, int r, int b, int c) {
+    if (S::PW) {
+      if (e == 3) return b == 0 ? 12 + c : 4 * (b - 1) + c;
+      return pw_c0(e) + (pw_tall ? c : 4 * (WV == 1 ? (b + 1) & 3 : b) + c);
+    }
+    return col0(e) + (is_big(e) ? 4 * b + c : c);
+  }
   // big unit i: ub = WV + 4 i -> (Jg, Ig)
   // (RS deal: wave 0 (0,0); wave 1 (1,0); wave 2 (0,1) + wide (2,0); wave 3 (1,1) + wide (2,1))
   static constexpr int bIg(int i) {
@@ -233,6 +282,7 @@ struct MidCommon {
   // real images: lane offsets of a 16x16 unit element / a 16x4 unit element / a 4x4 B block; index 0 for columns
   // 0..15, 1 for columns 16..31 (they differ only in the swizzled layout)
   int rbig[2], rsm[2], rblk[2];
+  int rb12, rctr;  // pinwheel deal: 16 columns from column 12 of row r; the centre block's K-packed fragments (row 4b + r, column 12 + c)
   unsigned negmask;
   int pr, ps, t18;
   double scale;
@@ -367,6 +417,130 @@ __device__ __forceinline__ void md_stage_signals(const MidArgs& A, const MidComm
 // (5 + s + 1) complex = 24 + 4 s real-equivalent ones.  Products that share an operand are issued
 // together (MODE 1: shared left operand, MODE 2: shared right operand) and share its LDS reads.
 // ---------------------------------------------------------------------------------------------
+// v rotated by N lanes inside each row of 16 lanes (DPP row_ror)
+template <int N>
+__device__ __forceinline__ double md_row_ror(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + N, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Image layout of the pinwheel class (Sched::PW): 32 x 32 doubles, rows paired so that ONE ds_read_b128 fetches a
+// fragment of two K-steps.  Element (row, col) lives in "pair row" p = 4 (row >> 3) + (row & 3), half h = (row >> 2) & 1
+// (K-steps 2P and 2P + 1 = row blocks 2P, 2P + 1 share the pair rows 4P..4P + 3), 16-byte chunk col ^ X(p) with
+// X(p) = 12 (p & 1) ^ 4 ((p >> 2) & 3):  double index (32 p + (col ^ X(p))) 2 + h.
+//  * 12 (p & 1): a 128-bit read is served in lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... -- quads 0 / 3 of pair row
+//    4P + r and quads 1 / 2 of 4P + r + 1; chunk c and c + 16 share banks.  16-column fragments put chunk block b (mod 4) in quad
+//    b, so the XOR (which swaps blocks 1 <-> 2, 0 <-> 3) keeps them apart; 4-column fragments (all quads one block) need it.
+//  * 4 ((p >> 2) & 3) = 4 (P & 3): spreads the four row blocks of a tall unit's 64-bit stores over the banks.
+__device__ __forceinline__ int md_pw_off(int row, int col) {
+  const int p = 4 * (row >> 3) + (row & 3), h = (row >> 2) & 1;
+  return (32 * p + (col ^ (12 * (p & 1)) ^ (4 * ((p >> 2) & 3)))) * 2 + h;
+}
+
+// mm_real for the pinwheel deal (Sched::PW; 7 K-steps = 4 K-step pairs).  Per PAIR a wave reads ONE 16-column fragment
+// (pair row 4P + r, columns X + 4 q(b) + c: the left operand's rows for a tall wave, the right operand's columns for a wide
+// one) and THREE 4-column fragments (column X' + c, the same in all four lane quads: the right operand's column blocks of a
+// tall wave, the left operand's row blocks of a wide one), 128 bits each, and issues 2 x 3 v_mfma_f64_4x4x4_4b (the second
+// K-step of the last pair is the zero rows 28..31: skipped).  Left operands are symmetric (or stored transposed), read as
+// M[k][i] like everywhere on this path.
+template <int WV, int MODE, int IA1, int IA2, int IB1, int IB2, typename Regs>
+__device__ __forceinline__ void mm_real_pw(const MidCommon& cm, Regs& acc1, Regs& acc2) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  constexpr int NJ = 7, NP = 4, IMGR = 16 * 2 * 32;
+  constexpr bool TWOA = MODE == 2, TWOB = MODE == 1;
+  constexpr bool TALL = (WV & 1) == 0;
+  constexpr int PFP = C3P_PW_PFP, NSP = PFP + 1;
+  // 16-column fragment: waves 0 / 3 columns 4b + c; waves 1 / 2 the unit at 12 with quad b on columns 12 + 4 ((b + 1) & 3) + c
+  // (chunk block b mod 4 in quad b); one lane base per P & 3
+  const int cf = (WV == 0 || WV == 3) ? 4 * cm.b + cm.c : 12 + 4 * ((cm.b + 1) & 3) + cm.c;
+  const int xr = 12 * (cm.r & 1);
+  const double* qfm[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) qfm[m] = c3p_md_lds + (32 * cm.r + (cf ^ xr ^ (4 * m))) * 2;
+  // 4-column fragments: column block j of the aligned group X4 (compile-time j = block ^ P): one lane base per block
+  constexpr int X4 = WV < 2 ? 0 : 16;
+  const double* q4j[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) q4j[j] = c3p_md_lds + (32 * cm.r + ((X4 + 4 * j + cm.c) ^ xr)) * 2;
+  constexpr int IF1 = TALL ? IA1 : IB1, IF2 = TALL ? IA2 : IB2;  // images of the 16-column fragments
+  constexpr int I41 = TALL ? IB1 : IA1, I42 = TALL ? IB2 : IA2;  // images of the 4-column fragments
+  constexpr bool TWOF = TALL ? TWOA : TWOB, TWO4 = TALL ? TWOB : TWOA;
+  d2 f1[NSP], f2[NSP], s1[NSP][3], s2[NSP][3];
+  // centre block (wave 1): quad b of instruction h multiplies K-step 4h + b (K-step 7 = the zero rows 28..31); fetched when the
+  // ring of the main loop no longer refills (the registers of its drained stages are free)
+  double ca1[2], ca2[2], cb1[2], cb2[2];
+  auto load_centre = [&]() {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const double* qc = c3p_md_lds + md_pw_off(16 * h + 4 * cm.b + cm.r, 12 + cm.c);
+      ca1[h] = qc[IA1 * IMGR];
+      cb1[h] = qc[IB1 * IMGR];
+      if constexpr (TWOA) ca2[h] = qc[IA2 * IMGR];
+      if constexpr (TWOB) cb2[h] = qc[IB2 * IMGR];
+    }
+  };
+#define C3P_MMP_LOAD(P)                                                                                    \
+  {                                                                                                        \
+    constexpr int st_ = (P) % NSP;                                                                         \
+    f1[st_] = *reinterpret_cast<const d2*>(qfm[(P) & 3] + IF1 * IMGR + (P) * 256);                         \
+    if constexpr (TWOF) f2[st_] = *reinterpret_cast<const d2*>(qfm[(P) & 3] + IF2 * IMGR + (P) * 256);     \
+    _Pragma("unroll") for (int e = 0; e < 3; ++e) {                                                        \
+      const int j_ = (C3P_PW_TIMING ? 0 : e) ^ ((P) & 3);                                                  \
+      s1[st_][e] = *reinterpret_cast<const d2*>(q4j[j_] + I41 * IMGR + (P) * 256);                         \
+      if constexpr (TWO4) s2[st_][e] = *reinterpret_cast<const d2*>(q4j[j_] + I42 * IMGR + (P) * 256);     \
+    }                                                                                                      \
+  }
+#define C3P_MMP_FMAS(P, H)                                                                                 \
+  {                                                                                                        \
+    constexpr int st_ = (P) % NSP;                                                                         \
+    _Pragma("unroll") for (int e = 0; e < 3; ++e) {                                                        \
+      if constexpr (TALL) {                                                                                \
+        acc1.sm[e] = md_mfma4(f1[st_][H], s1[st_][e][H], acc1.sm[e]);                                      \
+        if constexpr (TWOB) acc2.sm[e] = md_mfma4(f1[st_][H], s2[st_][e][H], acc2.sm[e]);                  \
+        if constexpr (TWOA) acc2.sm[e] = md_mfma4(f2[st_][H], s1[st_][e][H], acc2.sm[e]);                  \
+      } else {                                                                                             \
+        acc1.sm[e] = md_mfma4(s1[st_][e][H], f1[st_][H], acc1.sm[e]);                                      \
+        if constexpr (TWOB) acc2.sm[e] = md_mfma4(s1[st_][e][H], f2[st_][H], acc2.sm[e]);                  \
+        if constexpr (TWOA) acc2.sm[e] = md_mfma4(s2[st_][e][H], f1[st_][H], acc2.sm[e]);                  \
+      }                                                                                                    \
+    }                                                                                                      \
+  }
+  md_unroll<0, PFP>([&](auto Pc) { constexpr int P = decltype(Pc)::value; C3P_MMP_LOAD(P) });
+  md_unroll<0, NP>([&](auto Pc) {
+    constexpr int P = decltype(Pc)::value;
+    if constexpr (P + PFP < NP) C3P_MMP_LOAD(P + PFP)
+    if constexpr (WV == 1 && P + PFP == NP) load_centre();
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA group
+    C3P_MMP_FMAS(P, 0)
+    if constexpr (2 * P + 1 < NJ) C3P_MMP_FMAS(P, 1)
+    __builtin_amdgcn_sched_barrier(0);
+  });
+#undef C3P_MMP_LOAD
+#undef C3P_MMP_FMAS
+  if constexpr (WV == 1) {
+    // the incoming value counts once (quad 0); afterwards every quad holds the sum over the four K-slices
+    double c1 = cm.b == 0 ? acc1.sm[3] : 0.0;
+    c1 = md_mfma4(ca1[0], cb1[0], c1);
+    c1 = md_mfma4(ca1[1], cb1[1], c1);
+    double c2 = 0.0;
+    if constexpr (TWOA || TWOB) {
+      c2 = cm.b == 0 ? acc2.sm[3] : 0.0;
+      c2 = md_mfma4(TWOA ? ca2[0] : ca1[0], TWOB ? cb2[0] : cb1[0], c2);
+      c2 = md_mfma4(TWOA ? ca2[1] : ca1[1], TWOB ? cb2[1] : cb1[1], c2);
+    }
+    c1 += md_row_ror<4>(c1);
+    c1 += md_row_ror<8>(c1);
+    acc1.sm[3] = c1;
+    if constexpr (TWOA || TWOB) {
+      c2 += md_row_ror<4>(c2);
+      c2 += md_row_ror<8>(c2);
+      acc2.sm[3] = c2;
+    }
+  }
+}
+
 template <int NIGR, int NJ, int W, int WV, int MODE, int IA1, int IA2, int IB1, int IB2>
 __device__ __forceinline__ void mm_real(const MidCommon& cm,
                                         TileRegs<WaveTiles<NIGR, NJ, W, WV>::NBW, WaveTiles<NIGR, NJ, W, WV>::NSW>& acc1,
@@ -375,6 +549,10 @@ __device__ __forceinline__ void mm_real(const MidCommon& cm,
   constexpr int WI = SWZ ? 32 : W;
   using T = WaveTiles<NIGR, NJ, WI, WV>;
   using S = Sched<NIGR, NJ>;
+  if constexpr (S::PW) {
+    mm_real_pw<WV, MODE, IA1, IA2, IB1, IB2>(cm, acc1, acc2);
+    return;
+  }
   constexpr int NB16 = S::NB16 > 0 ? S::NB16 : 1;
   constexpr int JR = NJ;  // small B blocks by column block J
   constexpr bool TWOA = MODE == 2, TWOB = MODE == 1;
@@ -486,13 +664,22 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
   double* const qbig1 = c3p_md_lds + cm.rbig[1];
   double* const qsm0 = c3p_md_lds + cm.rsm[0];
   double* const qsm1 = c3p_md_lds + cm.rsm[1];
-  auto erow = [&](int e) -> int { return T::row0(e) + (T::is_big(e) ? rbig : rsmall); };
-  auto ecol = [&](int e) -> int { return T::col0(e) + (T::is_big(e) ? cbig : csmall); };
+  auto erow = [&](int e) -> int { return T::lrow(e, cm.r, cm.b, cm.c); };
+  auto ecol = [&](int e) -> int { return T::lcol(e, cm.r, cm.b, cm.c); };
+  // pinwheel deal: one lane offset per element (swizzled position of its row / column)
+  constexpr bool PW = Sched<NIGR, NJ>::PW;
+  int pwoff[NE > 0 ? NE : 1];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) pwoff[e] = PW ? md_pw_off(erow(e), ecol(e)) : 0;
   auto store_tiles = [&](auto img, const Regs& v) {
     constexpr int I = decltype(img)::value;
 #pragma unroll
-    for (int e = 0; e < NE; ++e)
-      (T::is_big(e) ? (T::col0(e) < 16 ? qbig0 : qbig1) : (T::col0(e) < 16 ? qsm0 : qsm1))[I * IMGR + T::off0(e)] = v.get(e);
+    for (int e = 0; e < NE; ++e) {
+      if constexpr (PW)
+        c3p_md_lds[I * IMGR + pwoff[e]] = v.get(e);
+      else
+        (T::is_big(e) ? (T::col0(e) < 16 ? qbig0 : qbig1) : (T::col0(e) < 16 ? qsm0 : qsm1))[I * IMGR + T::off0(e)] = v.get(e);
+    }
   };
   auto zero = [&](Regs& v) {
 #pragma unroll
@@ -536,29 +723,34 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
   constexpr bool DEG16 = VAR == 16, DEG20 = VAR == 20;
   for (int t = 0; t < cm.len; ++t) {
     if ((t & (SGC - 1)) == 0) md_stage_signals<WV>(A, cm, t);
-    double mu_r = tmu_r[0], mu_i = tmu_i[0];
-    Regs Y = Tab[0];
+    double mu_r = 0.0, mu_i = 0.0;
+    auto form_Y = [&](Regs& Yo) {
+      mu_r = tmu_r[0], mu_i = tmu_i[0];
+      Yo = Tab[0];
 #pragma unroll
-    for (int k = 0; k < KP; ++k) {
-      const double c0 = k < K ? cm.sg[k * SGC + (t & (SGC - 1))] : 0.0;  // Tab[k + 1] = 0 beyond K
-      mu_r = fma(c0, tmu_r[k + 1], mu_r);
-      mu_i = fma(c0, tmu_i[k + 1], mu_i);
+      for (int k = 0; k < KP; ++k) {
+        const double c0 = k < K ? cm.sg[k * SGC + (t & (SGC - 1))] : 0.0;  // Tab[k + 1] = 0 beyond K
+        mu_r = fma(c0, tmu_r[k + 1], mu_r);
+        mu_i = fma(c0, tmu_i[k + 1], mu_i);
 #pragma unroll
-      for (int e = 0; e < NE; ++e) Y.set(e, fma(c0, Tab[k + 1].get(e), Y.get(e)));
-    }
-    for (int k = KP; k < K; ++k) {  // control lines beyond the register budget: their tables come from L2 every slice
-      const double c0 = cm.sg[k * SGC + (t & (SGC - 1))];
-      const double* tk = tabs + (long)(k + 1) * (IMG + 4);
-      mu_r = fma(c0, md_rfl(tk[IMG + 0]), mu_r);
-      mu_i = fma(c0, md_rfl(tk[IMG + 1]), mu_i);
-      const double f = -cm.scale * c0;
-#pragma unroll
-      for (int e = 0; e < NE; ++e) {
-        const int row = erow(e), col = ecol(e);
-        const bool in = row < D && col < D;
-        Y.set(e, fma(f, in ? tk[(2 * row + 1) * W + col] : 0.0, Y.get(e)));
+        for (int e = 0; e < NE; ++e) Yo.set(e, fma(c0, Tab[k + 1].get(e), Yo.get(e)));
       }
-    }
+      for (int k = KP; k < K; ++k) {  // control lines beyond the register budget: their tables come from L2 every slice
+        const double c0 = cm.sg[k * SGC + (t & (SGC - 1))];
+        const double* tk = tabs + (long)(k + 1) * (IMG + 4);
+        mu_r = fma(c0, md_rfl(tk[IMG + 0]), mu_r);
+        mu_i = fma(c0, md_rfl(tk[IMG + 1]), mu_i);
+        const double f = -cm.scale * c0;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const int row = erow(e), col = ecol(e);
+          const bool in = row < D && col < D;
+          Yo.set(e, fma(f, in ? tk[(2 * row + 1) * W + col] : 0.0, Yo.get(e)));
+        }
+      }
+    };
+    Regs Y;
+    form_Y(Y);
     store_tiles(IC<0>{}, Y);
     md_bar();
     Regs W1, W2, W3, Cm, Sp, acc, acs;
@@ -591,32 +783,39 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       zero(W5);
       mm_real<NIGR, NJ, W, WV, 2, 1, 2, 2, 2>(cm, W3, W4);
       store_tiles(IC<3>{}, W3);
-      md_bar();
-      mm_real<NIGR, NJ, W, WV, 0, 2, 2, 3, 3>(cm, W5, dummy);
-#pragma unroll
-      for (int e = 0; e < NE; ++e) {
-        double a = -c3p_inv_fact[10] * dmask(e), s = -c3p_inv_fact[11] * dmask(e);
-        a = fma(c3p_inv_fact[12], W1.get(e), a), s = fma(c3p_inv_fact[13], W1.get(e), s);
-        a = fma(-c3p_inv_fact[14], W2.get(e), a), s = fma(-c3p_inv_fact[15], W2.get(e), s);
-        a = fma(c3p_inv_fact[16], W3.get(e), a), s = fma(c3p_inv_fact[17], W3.get(e), s);
-        a = fma(-c3p_inv_fact[18], W4.get(e), a), s = fma(-c3p_inv_fact[19], W4.get(e), s);
-        acc.set(e, fma(c3p_inv_fact[20], W5.get(e), a));
-        acs.set(e, fma(c3p_inv_fact[21], W5.get(e), s));
-      }
-      store_tiles(IC<0>{}, W5);
-      store_tiles(IC<1>{}, acc);
-      store_tiles(IC<4>{}, acs);
-      md_bar();
+      // everything W .. W^4 feed is formed BEFORE the W^5 product, whose operands come from the images: the four power
+      // tile sets are dead while it runs and afterwards (16 -> 12 live tile sets at the peak; the slice loop is register-bound)
       rc(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], -c3p_inv_fact[6]);
       rc(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7]);
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
         Cm.set(e, fma(c3p_inv_fact[8], W4.get(e), Cm.get(e)));
         Sp.set(e, fma(c3p_inv_fact[9], W4.get(e), Sp.get(e)));
+        double a = -c3p_inv_fact[10] * dmask(e), s = -c3p_inv_fact[11] * dmask(e);
+        a = fma(c3p_inv_fact[12], W1.get(e), a), s = fma(c3p_inv_fact[13], W1.get(e), s);
+        a = fma(-c3p_inv_fact[14], W2.get(e), a), s = fma(-c3p_inv_fact[15], W2.get(e), s);
+        a = fma(c3p_inv_fact[16], W3.get(e), a), s = fma(c3p_inv_fact[17], W3.get(e), s);
+        acc.set(e, fma(-c3p_inv_fact[18], W4.get(e), a));
+        acs.set(e, fma(-c3p_inv_fact[19], W4.get(e), s));
       }
+      md_bar();
+      mm_real<NIGR, NJ, W, WV, 0, 2, 2, 3, 3>(cm, W5, dummy);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        acc.set(e, fma(c3p_inv_fact[20], W5.get(e), acc.get(e)));
+        acs.set(e, fma(c3p_inv_fact[21], W5.get(e), acs.get(e)));
+      }
+      store_tiles(IC<0>{}, W5);
+      store_tiles(IC<1>{}, acc);
+      store_tiles(IC<4>{}, acs);
+      md_bar();
       mm_real<NIGR, NJ, W, WV, 1, 0, 0, 1, 4>(cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
       store_tiles(IC<2>{}, Sp);
-      store_tiles(IC<3>{}, Y);
+      {
+        Regs Y2;  // Y again from the tables (three multiply-adds per element; cheaper than a tile set held across five products)
+        form_Y(Y2);
+        store_tiles(IC<3>{}, Y2);
+      }
       md_bar();
       mm_real<NIGR, NJ, W, WV, 0, 3, 3, 2, 2>(cm, Sn, dummy);  // sin Y
     } else if constexpr (DEG16) {
@@ -639,7 +838,11 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       rc(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7]);
       mm_real<NIGR, NJ, W, WV, 1, 3, 3, 0, 4>(cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
       store_tiles(IC<1>{}, Sp);
-      store_tiles(IC<2>{}, Y);
+      {
+        Regs Y2;
+        form_Y(Y2);
+        store_tiles(IC<2>{}, Y2);
+      }
       md_bar();
       mm_real<NIGR, NJ, W, WV, 0, 2, 2, 1, 1>(cm, Sn, dummy);  // sin Y
     } else {
@@ -661,7 +864,11 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       rc(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], 0.0);
       mm_real<NIGR, NJ, W, WV, 1, 3, 3, 1, 2>(cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
       store_tiles(IC<0>{}, Sp);
-      store_tiles(IC<4>{}, Y);
+      {
+        Regs Y2;
+        form_Y(Y2);
+        store_tiles(IC<4>{}, Y2);
+      }
       md_bar();
       mm_real<NIGR, NJ, W, WV, 0, 4, 4, 0, 0>(cm, Sn, dummy);  // sin Y
     }
@@ -1022,7 +1229,8 @@ struct MidOcc {
 // REAL = true: the real-Hamiltonian kernel (own LDS layout, register budget and occupancy).  For unitary-mode
 // calls both kernels are launched; a workgroup whose sample is (not) real leaves the (real) complex one at once.
 template <int NIG, int NJ, int W, bool GIVEN, bool DUS, bool XG = false, bool REAL = false>
-__global__ void __launch_bounds__(256, (REAL ? MDR<NIG, W>::WGS : MidOcc<NIG, W>::WGS)) midd_chain_kernel(MidArgs A) {
+__global__ void __launch_bounds__(256, (REAL ? (Sched<MDR<NIG, W>::NIGR, NJ>::PW ? (C3P_PW_WGS) : MDR<NIG, W>::WGS) : MidOcc<NIG, W>::WGS))
+    midd_chain_kernel(MidArgs A) {
   using C = MD<NIG, NJ>;
   constexpr int IMG = C::ROWS * W;
   const int tid = threadIdx.x;
@@ -1080,6 +1288,8 @@ __global__ void __launch_bounds__(256, (REAL ? MDR<NIG, W>::WGS : MidOcc<NIG, W>
     cm.rsm[1] = (4 * cm.b + cm.r) * WI + cm.c - sw;
     cm.rblk[0] = cm.r * WI + cm.c + sw;
     cm.rblk[1] = cm.r * WI + cm.c - sw;
+    cm.rb12 = cm.r * WI + ((12 + 4 * cm.b + cm.c) ^ sw);
+    cm.rctr = (4 * cm.b + cm.r) * WI + ((12 + cm.c) ^ sw ^ (4 * cm.b));
   }
 
   // zero all images once (padding rows/columns must stay zero)
@@ -2056,13 +2266,21 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
   double* const qbig1 = c3p_md_lds + cm.rbig[1];
   double* const qsm0 = c3p_md_lds + cm.rsm[0];
   double* const qsm1 = c3p_md_lds + cm.rsm[1];
-  auto erow = [&](int e) -> int { return T::row0(e) + (T::is_big(e) ? rbig : rsmall); };
-  auto ecol = [&](int e) -> int { return T::col0(e) + (T::is_big(e) ? cbig : csmall); };
+  auto erow = [&](int e) -> int { return T::lrow(e, cm.r, cm.b, cm.c); };
+  auto ecol = [&](int e) -> int { return T::lcol(e, cm.r, cm.b, cm.c); };
+  constexpr bool PW = Sched<NIGR, NJ>::PW;  // pinwheel deal: one lane offset per element
+  int pwoff[NE > 0 ? NE : 1];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) pwoff[e] = PW ? md_pw_off(erow(e), ecol(e)) : 0;
   auto st = [&](auto img, const Regs& v) {
     constexpr int I = decltype(img)::value;
 #pragma unroll
-    for (int e = 0; e < NE; ++e)
-      (T::is_big(e) ? (T::col0(e) < 16 ? qbig0 : qbig1) : (T::col0(e) < 16 ? qsm0 : qsm1))[I * IMGR + T::off0(e)] = v.get(e);
+    for (int e = 0; e < NE; ++e) {
+      if constexpr (PW)
+        c3p_md_lds[I * IMGR + pwoff[e]] = v.get(e);
+      else
+        (T::is_big(e) ? (T::col0(e) < 16 ? qbig0 : qbig1) : (T::col0(e) < 16 ? qsm0 : qsm1))[I * IMGR + T::off0(e)] = v.get(e);
+    }
   };
   // the mirror position of every element of the lane: offset of (col, row) in an image, 0 / 1 mask (inside the matrix)
   int toff[NE > 0 ? NE : 1], soff[NE > 0 ? NE : 1];
@@ -2543,6 +2761,8 @@ __global__ void __launch_bounds__(256, (MDR<NIG, W>::SWZ ? 2 : 1)) midd_grad_rea
     cm.rsm[1] = (4 * cm.b + cm.r) * WI + cm.c - sw;
     cm.rblk[0] = cm.r * WI + cm.c + sw;
     cm.rblk[1] = cm.r * WI + cm.c - sw;
+    cm.rb12 = cm.r * WI + ((12 + 4 * cm.b + cm.c) ^ sw);
+    cm.rctr = (4 * cm.b + cm.r) * WI + ((12 + cm.c) ^ sw ^ (4 * cm.b));
   }
   double nrm = cm.tabs[IMG + 2];
   for (int k = 0; k < K; ++k) {
