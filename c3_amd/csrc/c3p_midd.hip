@@ -55,6 +55,13 @@
 #ifndef C3P_PW_PFP
 #define C3P_PW_PFP 1  // K-step PAIRS the operand fetch of the pinwheel products runs ahead
 #endif
+#ifndef C3P_PW_ILV
+#define C3P_PW_ILV 1  // operand reads of the next K-step pair interleaved with the matrix instructions of this one
+#endif
+#ifndef C3P_PW_CPL
+#define C3P_PW_CPL 1  // K-step pair whose matrix instructions the centre block's operand reads go out with
+#define C3P_PW_CPF 2  // ... and the pair its two K-packed instructions follow
+#endif
 #ifndef C3P_PW_TIMING
 #define C3P_PW_TIMING 0  // 1: timing-only build (WRONG results): one 4-column fragment per K-step instead of three
 #endif
@@ -487,9 +494,15 @@ __device__ __forceinline__ void mm_real_pw(const MidCommon& cm, Regs& acc1, Regs
     f1[st_] = *reinterpret_cast<const d2*>(qfm[(P) & 3] + IF1 * IMGR + (P) * 256);                         \
     if constexpr (TWOF) f2[st_] = *reinterpret_cast<const d2*>(qfm[(P) & 3] + IF2 * IMGR + (P) * 256);     \
     _Pragma("unroll") for (int e = 0; e < 3; ++e) {                                                        \
-      const int j_ = (C3P_PW_TIMING ? 0 : e) ^ ((P) & 3);                                                  \
+      const int j_ = (C3P_PW_TIMING ? 0 : e) ^ ((P) & 3);  /* timing builds: one fragment, read once */                                                  \
       s1[st_][e] = *reinterpret_cast<const d2*>(q4j[j_] + I41 * IMGR + (P) * 256);                         \
       if constexpr (TWO4) s2[st_][e] = *reinterpret_cast<const d2*>(q4j[j_] + I42 * IMGR + (P) * 256);     \
+      if constexpr (C3P_PW_TIMING == 2 && true) {  /* same registers as the real build, one LDS read */   \
+        if (e > 0) {                                                                                       \
+          asm volatile("" : "+v"(s1[st_][e]));                                                             \
+          if constexpr (TWO4) asm volatile("" : "+v"(s2[st_][e]));                                         \
+        }                                                                                                  \
+      }                                                                                                    \
     }                                                                                                      \
   }
 #define C3P_MMP_FMAS(P, H)                                                                                 \
@@ -507,29 +520,48 @@ __device__ __forceinline__ void mm_real_pw(const MidCommon& cm, Regs& acc1, Regs
       }                                                                                                    \
     }                                                                                                      \
   }
+  // centre block (wave 1): operands fetched with pair 1's, its two K-packed instructions (+ two of the paired product) go
+  // out behind pair 2's, the quad sums after the last pair -- nothing of it is left for the end of the product, where the other
+  // three waves would wait at the barrier
+  constexpr int CP_LOAD = C3P_PW_CPL, CP_FMA = C3P_PW_CPF;
+  double c1 = 0.0, c2 = 0.0;
   md_unroll<0, PFP>([&](auto Pc) { constexpr int P = decltype(Pc)::value; C3P_MMP_LOAD(P) });
   md_unroll<0, NP>([&](auto Pc) {
     constexpr int P = decltype(Pc)::value;
     if constexpr (P + PFP < NP) C3P_MMP_LOAD(P + PFP)
-    if constexpr (WV == 1 && P + PFP == NP) load_centre();
-    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA group
+    if constexpr (WV == 1 && P == CP_LOAD) load_centre();
+    if constexpr (C3P_PW_ILV == 0) __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA group
     C3P_MMP_FMAS(P, 0)
     if constexpr (2 * P + 1 < NJ) C3P_MMP_FMAS(P, 1)
+    if constexpr (WV == 1 && P == CP_FMA) {
+      // the incoming value counts once (quad 0); after the quad sums every quad holds the sum over the four K-slices
+      c1 = cm.b == 0 ? acc1.sm[3] : 0.0;
+      c1 = md_mfma4(ca1[0], cb1[0], c1);
+      if constexpr (TWOA || TWOB) {
+        c2 = cm.b == 0 ? acc2.sm[3] : 0.0;
+        c2 = md_mfma4(TWOA ? ca2[0] : ca1[0], TWOB ? cb2[0] : cb1[0], c2);
+      }
+      c1 = md_mfma4(ca1[1], cb1[1], c1);
+      if constexpr (TWOA || TWOB) c2 = md_mfma4(TWOA ? ca2[1] : ca1[1], TWOB ? cb2[1] : cb1[1], c2);
+    }
+    if constexpr (C3P_PW_ILV != 0) {
+      // the reads of the next pair go out BETWEEN this pair's matrix instructions: a read that waits for the LDS queue then
+      // holds up one instruction that has its predecessor still in the pipe, not the whole group
+      constexpr int NC = (MODE == 0 ? 4 : 6);  // centre: reads / (half of that) matrix instructions
+      constexpr int NM = (MODE == 0 ? 3 : 6) * (2 * P + 1 < NJ ? 2 : 1) + ((WV == 1 && P == CP_FMA) ? NC / 2 : 0);
+      constexpr int NR = ((P + PFP < NP) ? (MODE == 0 ? 4 : (TWOF ? 5 : 7)) : 0) + ((WV == 1 && P == CP_LOAD) ? NC : 0);
+      constexpr int STEP = NM / (NR > 0 ? NR : 1) > 0 ? NM / (NR > 0 ? NR : 1) : 1;
+      md_unroll<0, NR>([&](auto) {
+        __builtin_amdgcn_sched_group_barrier(0x008, STEP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      });
+      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
   });
 #undef C3P_MMP_LOAD
 #undef C3P_MMP_FMAS
   if constexpr (WV == 1) {
-    // the incoming value counts once (quad 0); afterwards every quad holds the sum over the four K-slices
-    double c1 = cm.b == 0 ? acc1.sm[3] : 0.0;
-    c1 = md_mfma4(ca1[0], cb1[0], c1);
-    c1 = md_mfma4(ca1[1], cb1[1], c1);
-    double c2 = 0.0;
-    if constexpr (TWOA || TWOB) {
-      c2 = cm.b == 0 ? acc2.sm[3] : 0.0;
-      c2 = md_mfma4(TWOA ? ca2[0] : ca1[0], TWOB ? cb2[0] : cb1[0], c2);
-      c2 = md_mfma4(TWOA ? ca2[1] : ca1[1], TWOB ? cb2[1] : cb1[1], c2);
-    }
     c1 += md_row_ror<4>(c1);
     c1 += md_row_ror<8>(c1);
     acc1.sm[3] = c1;
@@ -701,18 +733,36 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
   // half-image tables hold -Y;
   // positions outside the matrix are clamped and masked.
   constexpr int KP = MDR<NIG, W>::KP;
+  // Pinwheel class (TABL): the slice loop is register-bound (three workgroups per CU: 168 registers), so the table elements
+  // are NOT kept across the slice -- they are read again (L2) while the chain products of the previous slice run and are dead
+  // after Y is formed: 8 NE registers less at the peak of the polynomial stage.
+  constexpr bool TABL = false && PW;
   Regs Tab[KP + 1];
   double tmu_r[KP + 1], tmu_i[KP + 1];
+  int tix[NE > 0 ? NE : 1];
+  unsigned inb = 0;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int row = erow(e), col = ecol(e);
+    const bool in = row < D && col < D;
+    tix[e] = in ? (2 * row + 1) * W + col : W;
+    inb |= in ? (1u << e) : 0u;
+  }
+  auto load_tabs = [&]() {
+    const double* tb = tabs;
+    if constexpr (TABL) asm volatile("" : "+s"(tb));  // opaque per call: the (loop-invariant) loads must not be hoisted
+#pragma unroll
+    for (int k = 0; k <= KP; ++k) {
+      const double* tk = tb + (long)(k <= K ? k : 0) * (IMG + 4);
+      const double on = k <= K ? -cm.scale : 0.0;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) Tab[k].set(e, (inb >> e) & 1u ? on * tk[tix[e]] : 0.0);
+    }
+  };
+  load_tabs();
 #pragma unroll
   for (int k = 0; k <= KP; ++k) {
     const double* tk = tabs + (long)(k <= K ? k : 0) * (IMG + 4);
-    const double on = k <= K ? -cm.scale : 0.0;
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      const int row = erow(e), col = ecol(e);
-      const bool in = row < D && col < D;
-      Tab[k].set(e, in ? on * tk[(2 * row + 1) * W + col] : 0.0);
-    }
     tmu_r[k] = md_rfl(k <= K ? tk[IMG + 0] : 0.0);
     tmu_i[k] = md_rfl(k <= K ? tk[IMG + 1] : 0.0);
   }
@@ -811,11 +861,7 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       md_bar();
       mm_real<NIGR, NJ, W, WV, 1, 0, 0, 1, 4>(cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
       store_tiles(IC<2>{}, Sp);
-      {
-        Regs Y2;  // Y again from the tables (three multiply-adds per element; cheaper than a tile set held across five products)
-        form_Y(Y2);
-        store_tiles(IC<3>{}, Y2);
-      }
+      store_tiles(IC<3>{}, Y);
       md_bar();
       mm_real<NIGR, NJ, W, WV, 0, 3, 3, 2, 2>(cm, Sn, dummy);  // sin Y
     } else if constexpr (DEG16) {
@@ -838,11 +884,7 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       rc(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7]);
       mm_real<NIGR, NJ, W, WV, 1, 3, 3, 0, 4>(cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
       store_tiles(IC<1>{}, Sp);
-      {
-        Regs Y2;
-        form_Y(Y2);
-        store_tiles(IC<2>{}, Y2);
-      }
+      store_tiles(IC<2>{}, Y);
       md_bar();
       mm_real<NIGR, NJ, W, WV, 0, 2, 2, 1, 1>(cm, Sn, dummy);  // sin Y
     } else {
@@ -864,11 +906,7 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       rc(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], 0.0);
       mm_real<NIGR, NJ, W, WV, 1, 3, 3, 1, 2>(cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
       store_tiles(IC<0>{}, Sp);
-      {
-        Regs Y2;
-        form_Y(Y2);
-        store_tiles(IC<4>{}, Y2);
-      }
+      store_tiles(IC<4>{}, Y);
       md_bar();
       mm_real<NIGR, NJ, W, WV, 0, 4, 4, 0, 0>(cm, Sn, dummy);  // sin Y
     }
@@ -914,6 +952,7 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       }
     }
     // ---- chain in real blocks: Ur' = C Ur + S Ui,  Ui' = C Ui - S Ur ----
+    if constexpr (TABL) load_tabs();  // for the next slice, in flight behind the chain products
     if (t == 0) {
 #pragma unroll
       for (int e = 0; e < NE; ++e) {

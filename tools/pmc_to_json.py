@@ -14,7 +14,7 @@ def tile_utilisation(Dm, kernel):
     of the kernel class that ran:
       smalld (Dm <= 12): 4 x 4 blocks, rows and columns padded to 4 ceil(Dm / 4); the K dimension is exact when
                          Dm = 1 (mod 4) (rank-1 tail on the vector unit), otherwise padded as well;
-      midd (13..40):     16-row units and 4-column blocks, K in steps of 4 (real instance, Dm = 25..28: columns padded to 32);
+      midd (13..40):     16-row units and 4-column blocks, K in steps of 4 (real instance, Dm = 25..28: pinwheel deal, 28^3);
       regd (49/65/81):   the 16 n x 16 n core tiles exactly, the border runs on the vector unit: 1.0;
       others:            1.0 (not corrected)."""
     if Dm in (5, 9) and not os.environ.get("C3P_PMC_COMPLEX") and "smalld_chain_kernel" in kernel and kernel.split("smalld_chain_kernel")[-1].split(">")[0].rstrip().endswith("true"):
@@ -35,11 +35,13 @@ def tile_utilisation(Dm, kernel):
         rv = (Dm - 32) / 4.0
         useful = (Dm / 36.0) * (256.0 + 32.0 * rv + 32.0 * rv + 16.0 * ((Dm - 32) / 16.0) * rv)
         return useful / 336.0, f"mid-D real instance, 32 + 4 row split: exact rows in the wide units, column block 8 and its last unit carry {Dm - 32} of 4 / 16"
+    if 25 <= Dm <= 28 and "midd_chain_kernel" in kernel and "true" in kernel.split("midd_chain_kernel")[-1][:40]:
+        # real instance, pinwheel deal (round 5): per product 4 x 21 v_mfma_f64_4x4x4_4b of the four 3 x 4 / 4 x 3 block
+        # rectangles and 2 K-packed ones of the centre block, 256 multiply-adds each
+        return Dm**3 / (86 * 256.0), f"mid-D real instance, pinwheel deal: {Dm}^3 of 86 x 256 multiply-adds per product (28 x 28 x 28 tiles + the K-packed centre block)"
     if Dm <= 40:
         rows = 16 * ((Dm + 15) // 16)
         cols = 4 * ((Dm + 3) // 4)
-        if "true" in kernel.split("midd_chain_kernel")[-1][:40] and 25 <= Dm <= 28:
-            cols = 32
         kp = 4 * ((Dm + 3) // 4)
         return (Dm / rows) * (Dm / cols) * (Dm / kp), f"mid-D kernel: {Dm}/{rows} rows x {Dm}/{cols} columns x {Dm}/{kp} in K"
     return 1.0, "no padded MFMA work (register-resident core / not corrected)"
