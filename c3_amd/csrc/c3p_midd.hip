@@ -55,6 +55,18 @@
 #ifndef C3P_PW_PFP
 #define C3P_PW_PFP 1  // K-step PAIRS the operand fetch of the pinwheel products runs ahead
 #endif
+#ifndef C3P_MMR_ILV
+#define C3P_MMR_ILV 2  // mm_real of the 48-row real classes: reads per matrix instruction in the interleaved issue order (0 = grouped)
+#endif
+#ifndef C3P_MMR_PRIO
+#define C3P_MMR_PRIO 0  // s_setprio inside the K loops of mm_real (the classes other than the pinwheel one)
+#endif
+#ifndef C3P_PW_ROT
+#define C3P_PW_ROT 0  // wave roles of the pinwheel class rotated by blockIdx % this (0 = off)
+#endif
+#ifndef C3P_PW_PRIO
+#define C3P_PW_PRIO 2  // s_setprio inside the K loops of the pinwheel products
+#endif
 #ifndef C3P_PW_ILV
 #define C3P_PW_ILV 1  // operand reads of the next K-step pair interleaved with the matrix instructions of this one
 #endif
@@ -82,6 +94,10 @@ constexpr int SGC = 64;  // slices of control amplitudes staged in LDS at a time
 
 __device__ __forceinline__ double md_mfma4(double a, double b, double c) {
   return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+// c - a b (the A operand negated by the instruction's neg modifier: blgp bit 0 on the f64 forms)
+__device__ __forceinline__ double md_mfma4n(double a, double b, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 1);
 }
 __device__ __forceinline__ double md_flip(double v, unsigned mask_hi) {
   unsigned long long u = __double_as_longlong(v);
@@ -456,7 +472,13 @@ template <int WV, int MODE, int IA1, int IA2, int IB1, int IB2, typename Regs>
 __device__ __forceinline__ void mm_real_pw(const MidCommon& cm, Regs& acc1, Regs& acc2) {
   typedef double d2 __attribute__((ext_vector_type(2)));
   constexpr int NJ = 7, NP = 4, IMGR = 16 * 2 * 32;
-  constexpr bool TWOA = MODE == 2, TWOB = MODE == 1;
+  // MODE 3 / 4: the four products of a complex-by-complex step in real blocks, one pass over the operands (two left, two
+  // right fragments sets per K-step pair instead of two passes with one + two):
+  //   3:  acc1 += A1 B1 + A2 B2,  acc2 += A1 B2 - A2 B1     (Ur' = C Ur + S Ui, Ui' = C Ui - S Ur)
+  //   4:  acc1 += A1 B1 - A2 B2,  acc2 += A1 B2 + A2 B1     (Nr' = Rr C - Ri S, Ni' = Rr S + Ri C)
+  // (the minus sign is the neg modifier of the matrix instruction)
+  constexpr bool QUAD = MODE == 3 || MODE == 4;
+  constexpr bool TWOA = MODE == 2 || QUAD, TWOB = MODE == 1 || QUAD;
   constexpr bool TALL = (WV & 1) == 0;
   constexpr int PFP = C3P_PW_PFP, NSP = PFP + 1;
   // 16-column fragment: waves 0 / 3 columns 4b + c; waves 1 / 2 the unit at 12 with quad b on columns 12 + 4 ((b + 1) & 3) + c
@@ -508,6 +530,21 @@ __device__ __forceinline__ void mm_real_pw(const MidCommon& cm, Regs& acc1, Regs
 #define C3P_MMP_FMAS(P, H)                                                                                 \
   {                                                                                                        \
     constexpr int st_ = (P) % NSP;                                                                         \
+    if constexpr (QUAD) {                                                                                  \
+      /* tall: f = left (A1, A2), s = right (B1, B2); wide: s = left, f = right */                          \
+      _Pragma("unroll") for (int e = 0; e < 3; ++e)                                                        \
+        acc1.sm[e] = TALL ? md_mfma4(f1[st_][H], s1[st_][e][H], acc1.sm[e]) : md_mfma4(s1[st_][e][H], f1[st_][H], acc1.sm[e]); \
+      _Pragma("unroll") for (int e = 0; e < 3; ++e)                                                        \
+        acc2.sm[e] = TALL ? md_mfma4(f1[st_][H], s2[st_][e][H], acc2.sm[e]) : md_mfma4(s1[st_][e][H], f2[st_][H], acc2.sm[e]); \
+      _Pragma("unroll") for (int e = 0; e < 3; ++e) {                                                      \
+        const double a_ = TALL ? f2[st_][H] : s2[st_][e][H], b_ = TALL ? s2[st_][e][H] : f2[st_][H];       \
+        acc1.sm[e] = MODE == 3 ? md_mfma4(a_, b_, acc1.sm[e]) : md_mfma4n(a_, b_, acc1.sm[e]);             \
+      }                                                                                                    \
+      _Pragma("unroll") for (int e = 0; e < 3; ++e) {                                                      \
+        const double a_ = TALL ? f2[st_][H] : s2[st_][e][H], b_ = TALL ? s1[st_][e][H] : f1[st_][H];       \
+        acc2.sm[e] = MODE == 3 ? md_mfma4n(a_, b_, acc2.sm[e]) : md_mfma4(a_, b_, acc2.sm[e]);             \
+      }                                                                                                    \
+    } else {                                                                                               \
     _Pragma("unroll") for (int e = 0; e < 3; ++e) {                                                        \
       if constexpr (TALL) {                                                                                \
         acc1.sm[e] = md_mfma4(f1[st_][H], s1[st_][e][H], acc1.sm[e]);                                      \
@@ -519,6 +556,7 @@ __device__ __forceinline__ void mm_real_pw(const MidCommon& cm, Regs& acc1, Regs
         if constexpr (TWOA) acc2.sm[e] = md_mfma4(s2[st_][e][H], f1[st_][H], acc2.sm[e]);                  \
       }                                                                                                    \
     }                                                                                                      \
+    }                                                                                                      \
   }
   // centre block (wave 1): operands fetched with pair 1's, its two K-packed instructions (+ two of the paired product) go
   // out behind pair 2's, the quad sums after the last pair -- nothing of it is left for the end of the product, where the other
@@ -526,6 +564,7 @@ __device__ __forceinline__ void mm_real_pw(const MidCommon& cm, Regs& acc1, Regs
   constexpr int CP_LOAD = C3P_PW_CPL, CP_FMA = C3P_PW_CPF;
   double c1 = 0.0, c2 = 0.0;
   md_unroll<0, PFP>([&](auto Pc) { constexpr int P = decltype(Pc)::value; C3P_MMP_LOAD(P) });
+  if constexpr (C3P_PW_PRIO != 0) __builtin_amdgcn_s_setprio(C3P_PW_PRIO);
   md_unroll<0, NP>([&](auto Pc) {
     constexpr int P = decltype(Pc)::value;
     if constexpr (P + PFP < NP) C3P_MMP_LOAD(P + PFP)
@@ -536,20 +575,28 @@ __device__ __forceinline__ void mm_real_pw(const MidCommon& cm, Regs& acc1, Regs
     if constexpr (WV == 1 && P == CP_FMA) {
       // the incoming value counts once (quad 0); after the quad sums every quad holds the sum over the four K-slices
       c1 = cm.b == 0 ? acc1.sm[3] : 0.0;
-      c1 = md_mfma4(ca1[0], cb1[0], c1);
-      if constexpr (TWOA || TWOB) {
-        c2 = cm.b == 0 ? acc2.sm[3] : 0.0;
-        c2 = md_mfma4(TWOA ? ca2[0] : ca1[0], TWOB ? cb2[0] : cb1[0], c2);
+      if constexpr (TWOA || TWOB) c2 = cm.b == 0 ? acc2.sm[3] : 0.0;
+      if constexpr (QUAD) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          c1 = md_mfma4(ca1[h], cb1[h], c1);
+          c2 = md_mfma4(ca1[h], cb2[h], c2);
+          c1 = MODE == 3 ? md_mfma4(ca2[h], cb2[h], c1) : md_mfma4n(ca2[h], cb2[h], c1);
+          c2 = MODE == 3 ? md_mfma4n(ca2[h], cb1[h], c2) : md_mfma4(ca2[h], cb1[h], c2);
+        }
+      } else {
+        c1 = md_mfma4(ca1[0], cb1[0], c1);
+        if constexpr (TWOA || TWOB) c2 = md_mfma4(TWOA ? ca2[0] : ca1[0], TWOB ? cb2[0] : cb1[0], c2);
+        c1 = md_mfma4(ca1[1], cb1[1], c1);
+        if constexpr (TWOA || TWOB) c2 = md_mfma4(TWOA ? ca2[1] : ca1[1], TWOB ? cb2[1] : cb1[1], c2);
       }
-      c1 = md_mfma4(ca1[1], cb1[1], c1);
-      if constexpr (TWOA || TWOB) c2 = md_mfma4(TWOA ? ca2[1] : ca1[1], TWOB ? cb2[1] : cb1[1], c2);
     }
     if constexpr (C3P_PW_ILV != 0) {
       // the reads of the next pair go out BETWEEN this pair's matrix instructions: a read that waits for the LDS queue then
       // holds up one instruction that has its predecessor still in the pipe, not the whole group
-      constexpr int NC = (MODE == 0 ? 4 : 6);  // centre: reads / (half of that) matrix instructions
-      constexpr int NM = (MODE == 0 ? 3 : 6) * (2 * P + 1 < NJ ? 2 : 1) + ((WV == 1 && P == CP_FMA) ? NC / 2 : 0);
-      constexpr int NR = ((P + PFP < NP) ? (MODE == 0 ? 4 : (TWOF ? 5 : 7)) : 0) + ((WV == 1 && P == CP_LOAD) ? NC : 0);
+      constexpr int NCR = QUAD ? 8 : (MODE == 0 ? 4 : 6), NCM = QUAD ? 8 : (MODE == 0 ? 2 : 4);  // centre: reads, matrix instructions
+      constexpr int NM = (QUAD ? 12 : (MODE == 0 ? 3 : 6)) * (2 * P + 1 < NJ ? 2 : 1) + ((WV == 1 && P == CP_FMA) ? NCM : 0);
+      constexpr int NR = ((P + PFP < NP) ? (QUAD ? 8 : (MODE == 0 ? 4 : (TWOF ? 5 : 7))) : 0) + ((WV == 1 && P == CP_LOAD) ? NCR : 0);
       constexpr int STEP = NM / (NR > 0 ? NR : 1) > 0 ? NM / (NR > 0 ? NR : 1) : 1;
       md_unroll<0, NR>([&](auto) {
         __builtin_amdgcn_sched_group_barrier(0x008, STEP, 0);
@@ -561,6 +608,7 @@ __device__ __forceinline__ void mm_real_pw(const MidCommon& cm, Regs& acc1, Regs
   });
 #undef C3P_MMP_LOAD
 #undef C3P_MMP_FMAS
+  if constexpr (C3P_PW_PRIO != 0) __builtin_amdgcn_s_setprio(0);
   if constexpr (WV == 1) {
     c1 += md_row_ror<4>(c1);
     c1 += md_row_ror<8>(c1);
@@ -652,15 +700,27 @@ __device__ __forceinline__ void mm_real(const MidCommon& cm,
     }                                                                                                            \
   }
   md_unroll<0, PF>([&](auto Kc) { constexpr int K = decltype(Kc)::value; C3P_MMR_LOAD(K) });
+  if constexpr (C3P_MMR_PRIO != 0) __builtin_amdgcn_s_setprio(C3P_MMR_PRIO);
   md_unroll<0, NJ>([&](auto Kc) {
     constexpr int K = decltype(Kc)::value;
     if constexpr (K + PF < NJ) C3P_MMR_LOAD(K + PF)
-    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA group
+    // 48-row classes (D = 33..40): the reads of a later K-step go out BETWEEN this step's matrix instructions, as in
+    // mm_real_pw (cfg5 +1.9 %, its gradient +3.8 %; D = 40 +1.5 %); the 16- / 32-row classes keep the grouped order (D = 24 lost 11 % with it)
+    constexpr int ILV = NIGR >= 3 ? (C3P_MMR_ILV) : 0;
+    if constexpr (ILV == 0) __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA group
     C3P_MMR_FMAS(K)
+    if constexpr (ILV != 0) {
+      md_unroll<0, 12>([&](auto) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, ILV, 0);
+      });
+      __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
   });
 #undef C3P_MMR_LOAD
 #undef C3P_MMR_FMAS
+  if constexpr (C3P_MMR_PRIO != 0) __builtin_amdgcn_s_setprio(0);
 }
 
 template <int NIG, int W>
@@ -972,10 +1032,14 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       Regs Vr, Vi;
       zero(Vr);
       zero(Vi);
-      mm_real<NIGR, NJ, W, WV, 1, 2, 2, 4, 3>(cm, Vr, Vi);  // S Ui, S Ur
+      if constexpr (PW) {
+        mm_real<NIGR, NJ, W, WV, 3, 1, 2, 3, 4>(cm, Vr, Vi);  // all four products in one pass over the operands
+      } else {
+        mm_real<NIGR, NJ, W, WV, 1, 2, 2, 4, 3>(cm, Vr, Vi);  // S Ui, S Ur
 #pragma unroll
-      for (int e = 0; e < NE; ++e) Vi.set(e, -Vi.get(e));
-      mm_real<NIGR, NJ, W, WV, 1, 1, 1, 3, 4>(cm, Vr, Vi);  // + C Ur, + C Ui
+        for (int e = 0; e < NE; ++e) Vi.set(e, -Vi.get(e));
+        mm_real<NIGR, NJ, W, WV, 1, 1, 1, 3, 4>(cm, Vr, Vi);  // + C Ur, + C Ui
+      }
       Ur = Vr;
       Ui = Vi;
       mus_r += mu_r;
@@ -1402,7 +1466,10 @@ __global__ void __launch_bounds__(256, (REAL ? (Sched<MDR<NIG, W>::NIGR, NJ>::PW
     __syncthreads();
   }
   if constexpr (REAL) {
-    switch (wave) {
+    // (pinwheel class: the role that also carries the centre block moves with the workgroup, so that the workgroups of a CU
+    // do not put it on one SIMD)
+    const int role = (Sched<MDR<NIG, W>::NIGR, NJ>::PW && C3P_PW_ROT) ? ((wave + (int)(blockIdx.x % (C3P_PW_ROT ? C3P_PW_ROT : 1))) & 3) : wave;
+    switch (role) {
       case 0: midd_real_body<NIG, NJ, W, DUS, 0>(A, cm, chain); break;
       case 1: midd_real_body<NIG, NJ, W, DUS, 1>(A, cm, chain); break;
       case 2: midd_real_body<NIG, NJ, W, DUS, 2>(A, cm, chain); break;
@@ -2524,10 +2591,14 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
     Regs Rr, Ri;
     zero(Rr);
     zero(Ri);
-    mm_real<NIGR, NJ, W, WV, 1, 1, 1, 3, 2>(cm, Rr, Ri);  // S Ni, S Nr
+    if constexpr (PW) {
+      mm_real<NIGR, NJ, W, WV, 3, 0, 1, 2, 3>(cm, Rr, Ri);  // all four products in one pass over the operands
+    } else {
+      mm_real<NIGR, NJ, W, WV, 1, 1, 1, 3, 2>(cm, Rr, Ri);  // S Ni, S Nr
 #pragma unroll
-    for (int e = 0; e < NE; ++e) Ri.set(e, -Ri.get(e));
-    mm_real<NIGR, NJ, W, WV, 1, 0, 0, 2, 3>(cm, Rr, Ri);  // + C Nr, + C Ni
+      for (int e = 0; e < NE; ++e) Ri.set(e, -Ri.get(e));
+      mm_real<NIGR, NJ, W, WV, 1, 0, 0, 2, 3>(cm, Rr, Ri);  // + C Nr, + C Ni
+    }
     // tr N (= tr M), this wave's share
     double trr = 0.0, tri = 0.0;
 #pragma unroll
@@ -2753,10 +2824,14 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
     if (t > 0) {
       zero(Nr);
       zero(Ni);
-      mm_real<NIGR, NJ, W, WV, 2, 7, 6, 1, 1>(cm, Nr, Ni);  // Ri S, Rr S
+      if constexpr (PW) {
+        mm_real<NIGR, NJ, W, WV, 4, 6, 7, 0, 1>(cm, Nr, Ni);  // Rr C - Ri S, Rr S + Ri C in one pass
+      } else {
+        mm_real<NIGR, NJ, W, WV, 2, 7, 6, 1, 1>(cm, Nr, Ni);  // Ri S, Rr S
 #pragma unroll
-      for (int e = 0; e < NE; ++e) Nr.set(e, -Nr.get(e));
-      mm_real<NIGR, NJ, W, WV, 2, 6, 7, 0, 0>(cm, Nr, Ni);  // + Rr C, + Ri C
+        for (int e = 0; e < NE; ++e) Nr.set(e, -Nr.get(e));
+        mm_real<NIGR, NJ, W, WV, 2, 6, 7, 0, 0>(cm, Nr, Ni);  // + Rr C, + Ri C
+      }
     }
   }
 }

@@ -46,6 +46,16 @@ int main() {
       {"b128 consecutive", [](int l) { return 2 * l; }, 1},
       {"b128 broadcast 16 addresses", [=](int l) { return 2 * (4 * R(l) + C(l)); }, 1},
       {"b128 32 addresses (2 x F4)", [=](int l) { return 2 * (8 * R(l) + 4 * (Bq(l) & 1) + C(l)); }, 1},
+      {"W=37 B big read: 37 r + 4b + c", [=](int l) { return 37 * R(l) + 4 * Bq(l) + C(l); }, 0},
+      {"W=37 A slab read: 37 (4b + c) + r", [=](int l) { return 37 * (4 * Bq(l) + C(l)) + R(l); }, 0},
+      {"W=37 small B block: 37 r + c", [=](int l) { return 37 * R(l) + C(l); }, 0},
+      {"W=37 wide A (rows 32..35): 37 c + r", [=](int l) { return 37 * C(l) + R(l); }, 0},
+      {"W=40 rotated B big read: 40 r + (4b + c + 8 (r&1))", [=](int l) { int r = R(l); return 40 * r + (4 * Bq(l) + C(l) + 8 * (r & 1)); }, 0},
+      {"W=40 rotated small B block", [=](int l) { int r = R(l); return 40 * r + (C(l) + 8 * (r & 1)); }, 0},
+      {"w64 W=37 big element: 37 r + 4b + c", [=](int l) { return 37 * R(l) + 4 * Bq(l) + C(l); }, 2},
+      {"w64 W=37 small element: 37 (4b + r) + c", [=](int l) { return 37 * (4 * Bq(l) + R(l)) + C(l); }, 2},
+      {"w64 W=40 rotated big element", [=](int l) { int r = R(l); return 40 * r + 4 * Bq(l) + C(l) + 8 * (r & 1); }, 2},
+      {"w64 W=40 rotated small element: 40 (4b + r) + c + 8 (r & 1)", [=](int l) { int r = R(l); return 40 * (4 * Bq(l) + r) + C(l) + 8 * (r & 1); }, 2},
       {"w64 consecutive", [](int l) { return l; }, 2},
       {"w64 wide element (row r, 16 columns swizzled)", [=](int l) { int r = R(l); return 32 * r + ((4 * Bq(l) + C(l)) ^ (16 * (r & 1))); }, 2},
       {"w64 tall element (row 4b + r, column c)", [=](int l) { int r = R(l); return 32 * (4 * Bq(l) + r) + (C(l) ^ (16 * (r & 1))); }, 2},
