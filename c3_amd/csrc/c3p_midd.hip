@@ -61,6 +61,9 @@
 #ifndef C3P_MMR_PRIO
 #define C3P_MMR_PRIO 0  // s_setprio inside the K loops of mm_real (the classes other than the pinwheel one)
 #endif
+#ifndef C3P_PW_SPLITK
+#define C3P_PW_SPLITK 0  // single pinwheel products: odd K-steps in a second accumulator set (measured: -1.4 %)
+#endif
 #ifndef C3P_PW_ROT
 #define C3P_PW_ROT 0  // wave roles of the pinwheel class rotated by blockIdx % this (0 = off)
 #endif
@@ -544,6 +547,9 @@ __device__ __forceinline__ void mm_real_pw(const MidCommon& cm, Regs& acc1, Regs
         const double a_ = TALL ? f2[st_][H] : s2[st_][e][H], b_ = TALL ? s1[st_][e][H] : f1[st_][H];       \
         acc2.sm[e] = MODE == 3 ? md_mfma4n(a_, b_, acc2.sm[e]) : md_mfma4(a_, b_, acc2.sm[e]);             \
       }                                                                                                    \
+    } else if constexpr (MODE == 0 && C3P_PW_SPLITK != 0 && (H) == 1) {                                    \
+      _Pragma("unroll") for (int e = 0; e < 3; ++e)                                                        \
+        odd[e] = TALL ? md_mfma4(f1[st_][H], s1[st_][e][H], odd[e]) : md_mfma4(s1[st_][e][H], f1[st_][H], odd[e]); \
     } else {                                                                                               \
     _Pragma("unroll") for (int e = 0; e < 3; ++e) {                                                        \
       if constexpr (TALL) {                                                                                \
@@ -563,6 +569,9 @@ __device__ __forceinline__ void mm_real_pw(const MidCommon& cm, Regs& acc1, Regs
   // three waves would wait at the barrier
   constexpr int CP_LOAD = C3P_PW_CPL, CP_FMA = C3P_PW_CPF;
   double c1 = 0.0, c2 = 0.0;
+  // single products: the odd K-steps accumulate in a second register set (three dependent chains of a 4 x 4 x 4 instruction
+  // leave no slack: 45 cycles of latency against 3 x 16 of issue)
+  double odd[3] = {0.0, 0.0, 0.0};
   md_unroll<0, PFP>([&](auto Pc) { constexpr int P = decltype(Pc)::value; C3P_MMP_LOAD(P) });
   if constexpr (C3P_PW_PRIO != 0) __builtin_amdgcn_s_setprio(C3P_PW_PRIO);
   md_unroll<0, NP>([&](auto Pc) {
@@ -609,6 +618,10 @@ __device__ __forceinline__ void mm_real_pw(const MidCommon& cm, Regs& acc1, Regs
 #undef C3P_MMP_LOAD
 #undef C3P_MMP_FMAS
   if constexpr (C3P_PW_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+  if constexpr (MODE == 0 && C3P_PW_SPLITK != 0) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) acc1.sm[e] += odd[e];
+  }
   if constexpr (WV == 1) {
     c1 += md_row_ror<4>(c1);
     c1 += md_row_ror<8>(c1);
@@ -738,6 +751,12 @@ struct MDR {
   static constexpr int WGS = (AREA * 8 + 6144) * 3 <= 160 * 1024 ? 3 : (C3P_MDR_BIG_WGS);
 };
 
+// doubles of the real image area: the pinwheel class runs its unsquared degree-20 slices on SIX images (see PLAN6 below)
+template <int NIG, int NJ, int W>
+constexpr int mdr_area() {
+  return MDR<NIG, W>::AREA + (Sched<MDR<NIG, W>::NIGR, NJ>::PW ? 16 * MDR<NIG, W>::NIGR * MDR<NIG, W>::WI : 0);
+}
+
 template <int NIG, int NJ, int W, bool DUS, int WV>
 __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon& cm, long chain) {
   constexpr int NIGR = MDR<NIG, W>::NIGR;
@@ -828,9 +847,14 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
   }
   // instantiated per polynomial variant with the branch outside the loop (as in the small-D kernel): below
   // theta_16 = 0.816 the degree-16 / 17 polynomials are exact to roundoff and W^3, W^4 are one paired product
-  auto real_loop = [&](auto var_tag) {
+  auto real_loop = [&](auto var_tag, auto plan_tag) {
   constexpr int VAR = decltype(var_tag)::value;  // Taylor degree of cos: 16, 18 or 20
   constexpr bool DEG16 = VAR == 16, DEG20 = VAR == 20;
+  // Pinwheel class, degree 20 without squarings (cfg3): six images.  Y keeps image 0 for the whole slice (W^5 goes to image 5),
+  // so sin Y = Y (sin Y / Y) reads it there -- no second store of Y -- and the operands of the chain step (C, S, Ur, Ui ->
+  // images 1, 3, 4, 5) are none of the two that product reads: the barrier in front of their stores goes (7 instead of 8
+  // per slice, 12 tile-set stores instead of 13).
+  constexpr bool PLAN6 = decltype(plan_tag)::value != 0;
   for (int t = 0; t < cm.len; ++t) {
     if ((t & (SGC - 1)) == 0) md_stage_signals<WV>(A, cm, t);
     double mu_r = 0.0, mu_i = 0.0;
@@ -915,15 +939,26 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
         acc.set(e, fma(c3p_inv_fact[20], W5.get(e), acc.get(e)));
         acs.set(e, fma(c3p_inv_fact[21], W5.get(e), acs.get(e)));
       }
-      store_tiles(IC<0>{}, W5);
-      store_tiles(IC<1>{}, acc);
-      store_tiles(IC<4>{}, acs);
-      md_bar();
-      mm_real<NIGR, NJ, W, WV, 1, 0, 0, 1, 4>(cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
-      store_tiles(IC<2>{}, Sp);
-      store_tiles(IC<3>{}, Y);
-      md_bar();
-      mm_real<NIGR, NJ, W, WV, 0, 3, 3, 2, 2>(cm, Sn, dummy);  // sin Y
+      if constexpr (PLAN6) {
+        store_tiles(IC<5>{}, W5);
+        store_tiles(IC<1>{}, acc);
+        store_tiles(IC<4>{}, acs);
+        md_bar();
+        mm_real<NIGR, NJ, W, WV, 1, 5, 5, 1, 4>(cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
+        store_tiles(IC<2>{}, Sp);
+        md_bar();
+        mm_real<NIGR, NJ, W, WV, 0, 0, 0, 2, 2>(cm, Sn, dummy);  // sin Y
+      } else {
+        store_tiles(IC<0>{}, W5);
+        store_tiles(IC<1>{}, acc);
+        store_tiles(IC<4>{}, acs);
+        md_bar();
+        mm_real<NIGR, NJ, W, WV, 1, 0, 0, 1, 4>(cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
+        store_tiles(IC<2>{}, Sp);
+        store_tiles(IC<3>{}, Y);
+        md_bar();
+        mm_real<NIGR, NJ, W, WV, 0, 3, 3, 2, 2>(cm, Sn, dummy);  // sin Y
+      }
     } else if constexpr (DEG16) {
       // q = 4: {W^3, W^4} = {W, W^2} W^2 as one paired product, then ONE paired Horner step in W^4
       Regs W4;
@@ -1023,17 +1058,19 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       mus_i = c3p_phase_add(0.0, mu_i);
       md_bar();  // image 0 is rewritten by the next slice
     } else {
-      md_bar();  // the last product's operands are no longer read
+      if constexpr (!PLAN6) md_bar();  // the last product's operands are no longer read
       store_tiles(IC<1>{}, Cm);
-      store_tiles(IC<2>{}, Sn);
-      store_tiles(IC<3>{}, Ur);
-      store_tiles(IC<4>{}, Ui);
+      store_tiles(IC<PLAN6 ? 3 : 2>{}, Sn);
+      store_tiles(IC<PLAN6 ? 4 : 3>{}, Ur);
+      store_tiles(IC<PLAN6 ? 5 : 4>{}, Ui);
       md_bar();
       Regs Vr, Vi;
       zero(Vr);
       zero(Vi);
-      if constexpr (PW) {
-        mm_real<NIGR, NJ, W, WV, 3, 1, 2, 3, 4>(cm, Vr, Vi);  // all four products in one pass over the operands
+      if constexpr (PLAN6) {
+        mm_real<NIGR, NJ, W, WV, 3, 1, 3, 4, 5>(cm, Vr, Vi);  // all four products in one pass over the operands
+      } else if constexpr (PW) {
+        mm_real<NIGR, NJ, W, WV, 3, 1, 2, 3, 4>(cm, Vr, Vi);
       } else {
         mm_real<NIGR, NJ, W, WV, 1, 2, 2, 4, 3>(cm, Vr, Vi);  // S Ui, S Ur
 #pragma unroll
@@ -1047,12 +1084,16 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
     }
   }
   };
-  if (cm.t18 == 2)  // (reused as the variant flag on the real path: 1 = degree 16, 0 = degree 18, 2 = degree 20)
-    real_loop(IC<20>{});
-  else if (cm.t18 == 1)
-    real_loop(IC<16>{});
-  else
-    real_loop(IC<18>{});
+  if (cm.t18 == 2) {  // (reused as the variant flag on the real path: 1 = degree 16, 0 = degree 18, 2 = degree 20)
+    if (PW && cm.ps == 0)
+      real_loop(IC<20>{}, IC<PW ? 1 : 0>{});
+    else
+      real_loop(IC<20>{}, IC<0>{});
+  } else if (cm.t18 == 1) {
+    real_loop(IC<16>{}, IC<0>{});
+  } else {
+    real_loop(IC<18>{}, IC<0>{});
+  }
   // ---- segment result: e^{sum mu} (Ur + i Ui), optional row phases ----
   double sn, cs;
   sincos(mus_i, &sn, &cs);
@@ -1348,7 +1389,7 @@ __global__ void __launch_bounds__(256, (REAL ? (Sched<MDR<NIG, W>::NIGR, NJ>::PW
   cm.nbkR = (cm.D + 3) / 4;
   cm.K = A.K;
   const int K = A.K;
-  constexpr int AREA = REAL ? MDR<NIG, W>::AREA : 3 * IMG;  // image area: 3 complex images or the real pipeline's
+  constexpr int AREA = REAL ? mdr_area<NIG, NJ, W>() : 3 * IMG;  // image area: 3 complex images or the real pipeline's
 
   cm.buf0 = c3p_md_lds;
   cm.buf1 = cm.buf0 + IMG;
@@ -1636,7 +1677,7 @@ hipError_t launch_t(const MidArgs& A, hipStream_t st) {
 #if C3P_MIDD_HAS(2)
 template <int NIG, int NJ, int W>
 hipError_t launch_real_t(const MidArgs& A, hipStream_t st) {
-  const size_t ldsr = (size_t)(MDR<NIG, W>::AREA + A.K * SGC) * sizeof(double);
+  const size_t ldsr = (size_t)(mdr_area<NIG, NJ, W>() + A.K * SGC) * sizeof(double);
   return A.dUs_out ? md_go(midd_chain_kernel<NIG, NJ, W, false, true, false, true>, A, ldsr, st)
                    : md_go(midd_chain_kernel<NIG, NJ, W, false, false, false, true>, A, ldsr, st);
 }

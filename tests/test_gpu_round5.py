@@ -178,3 +178,99 @@ def test_three_call_gradient_form_is_capturable(prop):
     torch.cuda.synchronize()
     assert torch.allclose(out["goal"], eager["goal"], rtol=0, atol=1e-13)
     assert torch.allclose(out["grad_env"], eager["grad_env"], rtol=1e-12, atol=1e-12 * float(eager["grad_env"].abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Pinwheel deal of the D = 25..28 real class (c3p_midd.hip, Sched::PW): every matrix instruction is a 4 x 4 x 4 one, the
+# centre block is K-packed, the images are in the pair-row layout, the chain step is one four-product pass.  Reference:
+# propagation.py:426-440 (tf_propagation_vectorized) at the tunable coupler's D = 27 (test/test_tunable_coupler.py:393-403).
+# ---------------------------------------------------------------------------------------------------------------------
+def _sym(rng, D, s=1.0):
+    a = rng.normal(size=(D, D))
+    return (s * (a + a.T) / 2).astype(complex)
+
+
+@pytest.mark.parametrize("D", [25, 26, 27, 28])
+@pytest.mark.parametrize("amp,K", [(0.3, 2), (1.0, 3), (1.4, 2), (3.0, 4), (9.0, 5)])
+def test_pinwheel_class_forward_matches_oracle(prop, D, amp, K):
+    """All three polynomial variants, 0..3 squarings, the six-image plan (degree 20, no squaring), control lines beyond the
+    three whose tables stay in registers, slice propagators, frame-rotation row phases; N = 37 slices in 1..3 segments."""
+    rng = np.random.default_rng(100 * D + K)
+    h0 = _sym(rng, D, amp * 1e10)
+    hks = np.stack([_sym(rng, D) for _ in range(K)])
+    sig = rng.normal(size=(3, K, 37)) * amp * 4e9 / np.sqrt(K / 2)
+    ph = rng.uniform(0, 6, size=(3, D))
+    ref = o.propagate_batch(h0, hks, sig, 1e-11, fr_phase=ph)
+    scale = max(1.0, amp) ** 2
+    for S in (0, 1, 3):
+        with _lib.options(segments=S):
+            r = prop.propagate_batch(h0, hks, sig, 1e-11, fr_phase=ph, want_dUs=(S == 0))
+        U = np.asarray(r["U"])
+        assert _lib.last_kernel() == "mfma"
+        assert max(np.linalg.norm(U[b] - ref[b]) for b in range(3)) < 2e-12 * scale, (D, amp, K, S)
+        if S == 0:
+            refd = np.stack([o.pwc_arrays(h0, hks, sig[b], 1e-11)["dUs"] for b in range(3)])
+            assert np.abs(np.asarray(r["dUs"]) - refd).max() < 2e-13 * scale
+
+
+@pytest.mark.parametrize("D", [25, 27, 28])
+def test_pinwheel_class_propagators_are_unitary_at_full_length(prop, D):
+    """Size-independent property at the BASELINE slice count (cfg3: N = 2000): U U^+ = 1, and the product of two half
+    pulses equals the propagator of the whole pulse (chain order)."""
+    import torch
+
+    rng = np.random.default_rng(D)
+    dev = torch.device("cuda:0")
+    h0 = _sym(rng, D, 1.2e10)
+    hks = np.stack([_sym(rng, D) for _ in range(3)])
+    sig = rng.normal(size=(4, 3, 2000)) * 3e9
+    t = lambda a: torch.as_tensor(a, device=dev)
+    U = prop.propagate_batch(t(h0), t(hks), t(sig), 1e-11)["U"]
+    eye = torch.eye(D, dtype=U.dtype, device=dev)
+    assert float((U @ U.conj().transpose(1, 2) - eye).abs().max()) < 5e-12
+    Ua = prop.propagate_batch(t(h0), t(hks), t(sig[:, :, :1000].copy()), 1e-11)["U"]
+    Ub = prop.propagate_batch(t(h0), t(hks), t(sig[:, :, 1000:].copy()), 1e-11)["U"]
+    assert float((Ub @ Ua - U).abs().max()) < 5e-12
+
+
+@pytest.mark.parametrize("D,amp", [(25, 0.25), (27, 0.3), (28, 0.2), (27, 0.6)])
+def test_pinwheel_class_gradient_real_sweep(prop, D, amp):
+    """The real backward sweep of the class (same deal, quad passes MODE 3 / 4) against the general sweep and against a
+    finite difference of the oracle's forward."""
+    rng = np.random.default_rng(7 * D)
+    h0 = _sym(rng, D, amp * 1e10)
+    hks = np.stack([_sym(rng, D) for _ in range(2)])
+    sig = rng.normal(size=(2, 2, 23)) * amp * 4e9
+    ph = rng.uniform(0, 6, size=(2, D))
+    Ubar = rng.normal(size=(2, D, D)) + 1j * rng.normal(size=(2, D, D))
+    g = np.asarray(prop.propagate_batch_vjp(h0, hks, sig, 1e-11, Ubar, fr_phase=ph))
+    with _lib.options(no_real_grad=1):
+        g2 = np.asarray(prop.propagate_batch_vjp(h0, hks, sig, 1e-11, Ubar, fr_phase=ph))
+    assert np.abs(g - g2).max() < 1e-12 * np.abs(g2).max()
+    # finite difference of Re <Ubar, U> in one control sample of each line
+    for k, n in ((0, 3), (1, 17)):
+        eps = 1e5
+        sp, sm = sig.copy(), sig.copy()
+        sp[0, k, n] += eps
+        sm[0, k, n] -= eps
+        fp = np.real(np.vdot(Ubar[0], o.propagate_batch(h0, hks, sp[:1], 1e-11, fr_phase=ph[:1])[0]))
+        fm = np.real(np.vdot(Ubar[0], o.propagate_batch(h0, hks, sm[:1], 1e-11, fr_phase=ph[:1])[0]))
+        fd = (fp - fm) / (2 * eps)
+        assert abs(fd - g[0, k, n]) < 2e-6 * max(abs(fd), np.abs(g).max() * 1e-3), (fd, g[0, k, n])
+
+
+def test_pinwheel_class_mixes_with_complex_samples(prop):
+    """Per-sample operators: samples whose operators are real symmetric take the pinwheel instance, the others the complex
+    one, in the same call (both kernels are launched; a workgroup leaves the instance that is not its own)."""
+    rng = np.random.default_rng(5)
+    D, B = 27, 4
+    h0 = np.stack([_sym(rng, D, 5e9) for _ in range(B)])
+    hks = np.stack([np.stack([_sym(rng, D) for _ in range(2)]) for _ in range(B)])
+    a = rng.normal(size=(D, D))
+    hks[1, 0] = hks[1, 0] + 1j * (a - a.T) / 2  # Hermitian, not real
+    hks[3, 1] = hks[3, 1] + 0.3j * (a - a.T)
+    sig = rng.normal(size=(B, 2, 19)) * 2e9
+    U = np.asarray(prop.propagate_batch(h0, hks, sig, 1e-11)["U"])
+    for b in range(B):
+        ref = o.pwc_arrays(h0[b], hks[b], sig[b], 1e-11)["U"]
+        assert np.linalg.norm(U[b] - ref) < 2e-12, b
