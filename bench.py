@@ -38,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP64_TFLOPS = 78.6  # MI355X dense fp64 (vector = matrix; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 # thresholds of the reference's expm (tf.linalg.expm, Higham 2005 Pade 3/5/7/9/13 chosen from ||A||_1)
 _PADE_THETA = (1.495585217958292e-2, 2.539398330063230e-1, 9.504178996162932e-1, 2.097847961257068, 5.371920351148152)
