@@ -104,7 +104,16 @@ def main():
         util, why = tile_utilisation(Dm, dom)
         out["mfma_tile_utilisation"] = util
         out["mfma_tile_utilisation_note"] = why
-        out["useful_flop_per_launch"] = mfma_flop * util + valu_flop
+        # Active lanes of the vector instructions: SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU), both from
+        # the same kind of pass (SQ_ACTIVE_INST_VALU is averaged over passes 1 and 6), is the average
+        # fraction of the 64 lanes that execute over ALL vector instructions, matrix instructions included (those run with
+        # all lanes) -- so it bounds the fraction for the fp64 vector arithmetic from ABOVE only when the exec-masked
+        # instructions are the arithmetic ones; it is applied to the vector flops as measured, no finer split exists in the counters.
+        lane_util = None
+        if avg.get("SQ_THREAD_CYCLES_VALU") and avg.get("SQ_ACTIVE_INST_VALU"):
+            lane_util = min(1.0, avg["SQ_THREAD_CYCLES_VALU"] / (64.0 * avg["SQ_ACTIVE_INST_VALU"]))
+            out["valu_active_lane_fraction"] = lane_util
+        out["useful_flop_per_launch"] = mfma_flop * util + valu_flop * (lane_util if lane_util is not None else 1.0)
     if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "SQ_BUSY_CYCLES" in avg:
         out["mfma_busy_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch cycles); launch cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs: it reproduces launch time x 2.4 GHz)"
         if avg.get("GRBM_GUI_ACTIVE"):
