@@ -274,3 +274,13 @@ def test_pinwheel_class_mixes_with_complex_samples(prop):
     for b in range(B):
         ref = o.pwc_arrays(h0[b], hks[b], sig[b], 1e-11)["U"]
         assert np.linalg.norm(U[b] - ref) < 2e-12, b
+
+
+def test_pinwheel_class_fuzz_short_run():
+    """tools/fuzz_r05.py for a few seconds (the 4-minute run of the round: 118 k forward, 30 k oracle and 18 k gradient cases,
+    `profiles/r05/fuzz_r05.txt`)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_r05.py"), "--seconds", "6", "--seed", "11"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
