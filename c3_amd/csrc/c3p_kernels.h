@@ -41,7 +41,8 @@
   X(ode_prop_rows)      /* rk4_unitary at 17 <= D <= 48 on the lane-row column kernel */                               \
   X(ode_rho_general)    /* matrix-core ODE kernel: two products per commutator for every input */                      \
   X(ode_no_seg)         /* ODE: no time segments for small final-state batches */                                     \
-  X(ode_no_split)       /* ODE: rho-valued states with K > 4: lane-row kernel whatever the operators are (no device-side split) */
+  X(ode_no_split)       /* ODE: rho-valued states with K > 4: lane-row kernel whatever the operators are (no device-side split) */ \
+  X(ode_lind_wg)        /* ODE: Lindblad steps at 33 <= D <= 48 on the workgroup kernel of round 1 (A/B: not the matrix-core one) */
 
 enum C3pOption {
 #define C3P_OPT_ENUM(n) C3P_OPT_##n,

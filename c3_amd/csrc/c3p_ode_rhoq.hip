@@ -20,7 +20,8 @@
 //  * Lindblad: with G = sum_m C_m^+ C_m the anticommutator is folded into L = H - (i/2) G, R = H + (i/2) G:
 //    -i (L Y - Y R) = -i [H, Y] - {G, Y} / 2 (the same commutator loop on complex planes), and every jump term is two more
 //    products, T = C_m Y (written back to an LDS plane by the owning waves, one barrier) and T C_m^+ (the B fragment of C^+
-//    is the conjugated A-pattern read of C).  The C_m sit in LDS planes for the whole integration; D <= 32 only (LDS).
+//    is the conjugated A-pattern read of C).  The C_m sit in LDS planes for the whole integration at D <= 32; at 33 <= D <= 48
+//    they stay in memory and their fragments are fetched one product ahead (CGLOB, round 5).
 //  * Hermitian shortcut (the usual case: Hermitian operators, rho(0) a density matrix): every stage argument is Hermitian,
 //    so Y H = (H Y)^+ -- ONE product per commutator (half the MFMAs), written to a plane, and the other half is the
 //    conjugate of the mirrored element read back behind one more barrier.  Symmetry is checked per sample in the prologue;
@@ -61,9 +62,11 @@ __device__ __forceinline__ void rstatic_for(F&& f) {
 }
 
 // MODE 0: von Neumann, real operators; 1: von Neumann, complex operators; 2: Lindblad (complex planes)
-__host__ __device__ constexpr int rho_planes(int mode, int C) { return mode == 0 ? 5 : (mode == 1 ? 6 : 8 + 2 * C); }
+// (Lindblad at D > 32, NT = 3: the collapse operators do not get LDS planes -- 8 + 2 C planes of 19 KB do not fit -- their
+// fragments are read from memory (L2) for every jump term, see CGLOB in the kernel)
+__host__ __device__ constexpr int rho_planes(int NT, int mode, int C) { return mode == 0 ? 5 : (mode == 1 ? 6 : (NT >= 3 ? 8 : 8 + 2 * C)); }
 __host__ __device__ constexpr size_t rho_lds_bytes(int NT, int mode, int C) {
-  return (size_t)rho_planes(mode, C) * (16 * NT) * (16 * NT + 2) * sizeof(double);
+  return (size_t)rho_planes(NT, mode, C) * (16 * NT) * (16 * NT + 2) * sizeof(double);
 }
 
 // workgroup barrier that waits for this wave's LDS traffic only (`__syncthreads` also drains the vector-memory counter, i.e.
@@ -84,6 +87,12 @@ template <int NT, int SOLVER, int MODE, bool HERM>
 __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) ode_rhoq_kernel(OdeArgs A) {
   constexpr bool CPX = MODE != 0;
   constexpr bool LIND = MODE == 2;
+  // Lindblad at 33 <= D <= 48 (round 5): the collapse operators stay in memory.  A jump term needs two fragment sets of C_m per
+  // wave -- rows of tile row I (T = C_m Y) and rows of tile row J (T C_m^+) --, ceil(D / 4) complex values per lane each:
+  // fetched as 16-byte loads one product AHEAD of their use (the set of the second product while the first one runs, the
+  // first set of the next term while the second runs), L2 resident (C D^2 16 bytes, shared by every sample).
+  constexpr bool CGLOB = LIND && NT >= 3;
+  constexpr int KSMAX = 4 * NT;  // K-steps of a product at most
   constexpr int S = rtab_of(SOLVER).stages;
   constexpr int DP = 16 * NT, LD = DP + 2, PL = DP * LD;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -204,28 +213,41 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
   // Lindblad: collapse operators -> LDS planes, G = sum_m C_m^+ C_m -> (1/2) G in registers
   double g2r[LIND ? 4 : 1], g2i[LIND ? 4 : 1];
   if constexpr (LIND) {
-    for (int m = 0; m < A.C; ++m) {
+    if constexpr (!CGLOB) {
+      for (int m = 0; m < A.C; ++m) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int row = 16 * I + 4 * v + lr;
-        cplx z = cmake(0, 0);
-        if (valid[v]) z = A.col_ops[((long)m * D + row) * D + col];
-        Cp[(2 * m) * PL + eoff[v]] = z.x;
-        Cp[(2 * m + 1) * PL + eoff[v]] = z.y;
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * I + 4 * v + lr;
+          cplx z = cmake(0, 0);
+          if (valid[v]) z = A.col_ops[((long)m * D + row) * D + col];
+          Cp[(2 * m) * PL + eoff[v]] = z.x;
+          Cp[(2 * m + 1) * PL + eoff[v]] = z.y;
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int row = 16 * I + 4 * v + lr;
       double sr = 0.0, si = 0.0;
       for (int m = 0; m < A.C; ++m) {
-        const double* cr = Cp + (2 * m) * PL;
-        const double* ci = cr + PL;
-        for (int k = 0; k < D; ++k) {  // conj(C[k][row]) C[k][col]
-          const double ar = cr[k * LD + row], ai = ci[k * LD + row], br = cr[k * LD + col], bi = ci[k * LD + col];
-          sr += ar * br + ai * bi;
-          si += ar * bi - ai * br;
+        if constexpr (CGLOB) {
+          if (valid[v]) {
+            const cplx* cm_ = A.col_ops + (long)m * D * D;
+            for (int k = 0; k < D; ++k) {  // conj(C[k][row]) C[k][col]
+              const cplx a = cm_[(long)k * D + row], bb = cm_[(long)k * D + col];
+              sr += a.x * bb.x + a.y * bb.y;
+              si += a.x * bb.y - a.y * bb.x;
+            }
+          }
+        } else {
+          const double* cr = Cp + (2 * m) * PL;
+          const double* ci = cr + PL;
+          for (int k = 0; k < D; ++k) {  // conj(C[k][row]) C[k][col]
+            const double ar = cr[k * LD + row], ai = ci[k * LD + row], br = cr[k * LD + col], bi = ci[k * LD + col];
+            sr += ar * br + ai * bi;
+            si += ar * bi - ai * br;
+          }
         }
       }
       g2r[v] = 0.5 * sr;
@@ -452,7 +474,55 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
       [[maybe_unused]] const long long t4 = t3;
       // k_s = -i dt acc (+ dt sum_m C_m Y C_m^+)
       d4 jR = {0.0, 0.0, 0.0, 0.0}, jI = {0.0, 0.0, 0.0, 0.0};
-      if constexpr (LIND) {
+      if constexpr (CGLOB) {
+        // fragment (row 16 T + lc, k = 4 kk + lr) of C_m, zero outside the matrix
+        cplx fa[KSMAX], fb[KSMAX];
+        auto fetch = [&](cplx (&f)[KSMAX], int m, int T) {
+          const int row = 16 * T + lc;
+          const cplx* src = A.col_ops + ((long)m * D + (row < D ? row : 0)) * D;
+#pragma unroll
+          for (int kk = 0; kk < KSMAX; ++kk) {
+            const int k = 4 * kk + lr;
+            f[kk] = (kk < ksteps && row < D && k < D) ? src[k] : cmake(0, 0);
+          }
+        };
+        if (A.C > 0) fetch(fa, 0, I);
+        for (int m = 0; m < A.C; ++m) {
+          d4 tR = {0.0, 0.0, 0.0, 0.0}, tI = {0.0, 0.0, 0.0, 0.0};
+          fetch(fb, m, J);  // in flight behind the first product
+#pragma unroll
+          for (int kk = 0; kk < KSMAX; ++kk) {
+            if (kk < ksteps) {
+              const int bo = boff + 4 * kk * LD;
+              const double ar = fa[kk].x, ai = fa[kk].y, br = Yr[bo], bi = Yi[bo];
+              tR = mfma(ar, br, tR);
+              tI = mfma(ar, bi, tI);
+              tR = mfma(-ai, bi, tR);
+              tI = mfma(ai, br, tI);
+            }
+          }
+          if (m > 0) lds_barrier();  // the previous jump term's readers of T are done
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            Tr[eoff[v]] = tR[v];
+            Ti[eoff[v]] = tI[v];
+          }
+          lds_barrier();
+          p_pending = false;
+          if (m + 1 < A.C) fetch(fa, m + 1, I);  // in flight behind the second product
+#pragma unroll
+          for (int kk = 0; kk < KSMAX; ++kk) {
+            if (kk < ksteps) {
+              const int ao = aoff + 4 * kk;
+              const double ar = Tr[ao], ai = Ti[ao], br = fb[kk].x, bi = fb[kk].y;  // B = C^+: (br, -bi)
+              jR = mfma(ar, br, jR);
+              jI = mfma(ai, br, jI);
+              jR = mfma(ai, bi, jR);
+              jI = mfma(-ar, bi, jI);
+            }
+          }
+        }
+      } else if constexpr (LIND) {
         for (int m = 0; m < A.C; ++m) {
           const double* cr = Cp + (2 * m) * PL;
           const double* ci = cr + PL;
@@ -576,8 +646,7 @@ hipError_t launch_rho3(const OdeArgs& A, hipStream_t st) {
 template <int NT, int SOLVER>
 hipError_t launch_rho2(const OdeArgs& A, hipStream_t st) {
   if (A.step == C3P_STEP_LINDBLAD_ID) {
-    if constexpr (NT == 2) return launch_rho3<NT, SOLVER, 2>(A, st);
-    return hipErrorInvalidValue;
+    return launch_rho3<NT, SOLVER, 2>(A, st);
   }
   hipError_t e = launch_rho3<NT, SOLVER, 0>(A, st);
   if (e != hipSuccess) return e;
@@ -606,7 +675,8 @@ bool c3p_ode_rhoq_supported(const OdeArgs& A) {
   if (A.seg_count > 0) return false;  // (A/B switch: the lane-row column kernel)
   if (A.reset_each_step || A.transpose_out) return false;
   if (A.step == C3P_STEP_VON_NEUMANN_ID) return true;
-  if (A.step != C3P_STEP_LINDBLAD_ID || A.D > 32) return false;
+  if (A.step != C3P_STEP_LINDBLAD_ID) return false;
+  if (A.D > 32) return !c3p_opt_on(C3P_OPT_ode_lind_wg);  // collapse operators from memory: 8 planes whatever C is
   return rho_lds_bytes(2, 2, A.C) <= (size_t)(150 * 1024);
 }
 

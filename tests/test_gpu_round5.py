@@ -284,3 +284,61 @@ def test_pinwheel_class_fuzz_short_run():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_r05.py"), "--seconds", "6", "--seed", "11"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ODE: Lindblad steps at 33 <= D <= 48 on the matrix-core kernel (collapse operators read from memory, c3p_ode_rhoq.hip CGLOB)
+# reference: propagation.py:886-894 (lindblad step) under ode_solver :687-752
+# ---------------------------------------------------------------------------------------------------------------------
+def _ode_problem5(D, K, B, N, real, seed):
+    rng = np.random.default_rng(seed)
+
+    def herm(s):
+        a = rng.normal(size=(D, D)) + (0 if real else 1j) * rng.normal(size=(D, D))
+        return (s * (a + a.conj().T) / 2).astype(complex)
+
+    h0, hks = herm(1.0), np.stack([herm(0.4) for _ in range(K)])
+    sig = rng.normal(size=(B, K, N))
+    ts = np.linspace(0.0, 0.02 * (N - 1), N)
+    return h0, hks, sig, ts
+
+
+@pytest.mark.parametrize("solver", ["rk4", "rk38", "rk5", "tsit5"])
+@pytest.mark.parametrize("D,K,C,real", [(33, 2, 1, True), (36, 3, 2, False), (40, 1, 3, False), (45, 2, 2, True), (48, 4, 1, False)])
+def test_ode_lindblad_above_32_on_the_matrix_core_kernel(prop, solver, D, K, C, real):
+    B, N = 2, 9
+    h0, hks, sig, ts = _ode_problem5(D, K, B, N, real, 13 * D + C)
+    rng = np.random.default_rng(D + C)
+    a = rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))
+    rho = a @ a.conj().T
+    rho /= np.trace(rho)
+    col = np.stack([0.2 * (rng.normal(size=(D, D)) + (0 if real else 1j) * rng.normal(size=(D, D))) for _ in range(C)])
+    out = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], rho, solver, "lindblad", col_ops=col))
+    assert _lib.last_kernel() == "ode_mfma"
+    fin = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], rho, solver, "lindblad", col_ops=col, final_only=True))
+    with _lib.options(ode_lind_wg=1):
+        old = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], rho, solver, "lindblad", col_ops=col, final_only=True))
+        assert _lib.last_kernel() == "ode_wg"
+    for b in range(B):
+        ref = o.ode_solver_arrays(h0, hks, sig[b], ts, rho, solver, "lindblad", col=col)["states"]
+        assert np.abs(out[b] - ref).max() < 1e-11
+        assert np.abs(fin[b] - ref[-1]).max() < 1e-11
+        assert np.abs(old[b] - ref[-1]).max() < 1e-11
+        assert abs(np.trace(fin[b]) - 1.0) < 1e-12
+
+
+def test_ode_lindblad_above_32_non_hermitian_inputs(prop):
+    """A non-Hermitian state and a non-Hermitian control operator go to the general two-product instance of the same kernel."""
+    D, K, C, B, N = 36, 2, 2, 3, 7
+    h0, hks, sig, ts = _ode_problem5(D, K, B, N, False, 77)
+    rng = np.random.default_rng(9)
+    hks[1] = hks[1] + 0.2 * rng.normal(size=(D, D))
+    a = rng.normal(size=(B, D, D)) + 1j * rng.normal(size=(B, D, D))
+    rho = a @ a.conj().transpose(0, 2, 1)
+    rho[1] = a[1]
+    col = np.stack([0.15 * (rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))) for _ in range(C)])
+    out = np.asarray(prop.ode_solve_batch(h0, hks, sig, ts[1] - ts[0], rho, "rk4", "lindblad", col_ops=col, final_only=True))
+    assert _lib.last_kernel() == "ode_mfma"
+    for b in range(B):
+        ref = o.ode_solver_arrays(h0, hks, sig[b], ts, rho[b], "rk4", "lindblad", col=col, final_only=True)["states"]
+        assert np.abs(out[b] - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())

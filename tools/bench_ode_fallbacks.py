@@ -56,6 +56,28 @@ for D, K, B, N, solver, step in [(9, 6, 256, 1000, "rk4", "schrodinger"), (9, 6,
     row["rk_steps_per_s"] = B * N / row["lane_row_ms"] * 1e3
     rows.append(row)
     print(json.dumps(row), flush=True)
+# Lindblad steps at 33 <= D <= 48 (round 5): matrix-core kernel with the collapse operators read from memory against the
+# workgroup kernel these shapes ran on until then (option ode_lind_wg)
+for D, C, B, N, solver in [(36, 2, 16, 400, "rk4"), (36, 2, 256, 400, "rk4"), (36, 2, 256, 400, "tsit5"), (48, 1, 256, 400, "rk4"), (33, 3, 256, 400, "rk4")]:
+    h0, hks = t(herm(D, 0.3)), t(np.stack([herm(D, 0.2) for _ in range(2)]))
+    col = t(np.stack([0.05 * (rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))) for _ in range(C)]))
+    sig = t(rng.uniform(-1, 1, size=(B, 2, N)))
+    a_ = rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))
+    rho = a_ @ a_.conj().T
+    init = t(rho / np.trace(rho))
+    f = lambda: prop.ode_solve_batch(h0, hks, sig, 0.02, init, solver, "lindblad", col_ops=col, final_only=True)
+    row = {"case": f"lindblad {solver} D={D} K=2 C={C}", "B": B, "N": N}
+    row["lane_row_ms"] = timed(f)
+    row["kernel"] = _lib.last_kernel()
+    x = f().cpu().numpy()
+    with _lib.options(ode_lind_wg=1):
+        row["workgroup_ms"] = timed(f, 3)
+        y = f().cpu().numpy()
+    row["speedup"] = row["workgroup_ms"] / row["lane_row_ms"]
+    row["max_dev"] = float(np.abs(x - y).max())
+    row["rk_steps_per_s"] = B * N / row["lane_row_ms"] * 1e3
+    rows.append(row)
+    print(json.dumps(row), flush=True)
 for D, Ns in [(9, 2001), (16, 2001)]:
     Hs = rng.normal(size=(Ns, D, D)) + 1j * rng.normal(size=(Ns, D, D))
     Hs = t(0.2 * (Hs + Hs.conj().transpose(0, 2, 1)))
