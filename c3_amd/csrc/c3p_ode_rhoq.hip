@@ -39,6 +39,9 @@
 #include "c3p_ode.h"
 #include "c3p_ode_tab.h"
 
+#ifndef C3P_RHOQ_CG_LATE
+#define C3P_RHOQ_CG_LATE 1  // 1: one collapse-operator fragment set live at a time (fetched behind the product that used the other: 2 - 7 % faster than both in flight, which spills)
+#endif
 extern __shared__ __attribute__((aligned(16))) unsigned char c3p_ode_rhoq_smem[];
 
 namespace {
@@ -489,7 +492,9 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
         if (A.C > 0) fetch(fa, 0, I);
         for (int m = 0; m < A.C; ++m) {
           d4 tR = {0.0, 0.0, 0.0, 0.0}, tI = {0.0, 0.0, 0.0, 0.0};
+#if !C3P_RHOQ_CG_LATE
           fetch(fb, m, J);  // in flight behind the first product
+#endif
 #pragma unroll
           for (int kk = 0; kk < KSMAX; ++kk) {
             if (kk < ksteps) {
@@ -501,6 +506,9 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
               tI = mfma(ai, br, tI);
             }
           }
+#if C3P_RHOQ_CG_LATE
+          fetch(fb, m, J);  // behind the first product's instructions: the first set's registers are free again
+#endif
           if (m > 0) lds_barrier();  // the previous jump term's readers of T are done
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
@@ -509,7 +517,9 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
           }
           lds_barrier();
           p_pending = false;
+#if !C3P_RHOQ_CG_LATE
           if (m + 1 < A.C) fetch(fa, m + 1, I);  // in flight behind the second product
+#endif
 #pragma unroll
           for (int kk = 0; kk < KSMAX; ++kk) {
             if (kk < ksteps) {
@@ -521,6 +531,9 @@ __global__ void __launch_bounds__(64 * NT * NT, rho_min_wgs(NT, SOLVER, MODE)) o
               jI = mfma(-ar, bi, jI);
             }
           }
+#if C3P_RHOQ_CG_LATE
+          if (m + 1 < A.C) fetch(fa, m + 1, I);
+#endif
         }
       } else if constexpr (LIND) {
         for (int m = 0; m < A.C; ++m) {

@@ -2,7 +2,9 @@
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
-from c3_amd import _lib, propagation as prop
+from c3_amd import _lib
+if len(sys.argv) > 1: _lib.LIB_PATH = os.path.abspath(sys.argv[1])
+from c3_amd import propagation as prop
 rng = np.random.default_rng(1)
 t = lambda a: torch.as_tensor(a, device="cuda:0")
 for D, C in ((36, 2), (48, 1), (33, 3)):
