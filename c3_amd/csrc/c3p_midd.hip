@@ -119,6 +119,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ d4 md_mfma16(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ d4 md_mfma16n(double a, double b, d4 c) {  // c - a b (neg modifier on A)
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 1);
+}
 
 template <int NIG, int NJ>
 struct MD {
@@ -606,7 +609,7 @@ __device__ __forceinline__ void mm_real_pw(const MidCommon& cm, Regs& acc1, Regs
       constexpr int NCR = QUAD ? 8 : (MODE == 0 ? 4 : 6), NCM = QUAD ? 8 : (MODE == 0 ? 2 : 4);  // centre: reads, matrix instructions
       constexpr int NM = (QUAD ? 12 : (MODE == 0 ? 3 : 6)) * (2 * P + 1 < NJ ? 2 : 1) + ((WV == 1 && P == CP_FMA) ? NCM : 0);
       constexpr int NR = ((P + PFP < NP) ? (QUAD ? 8 : (MODE == 0 ? 4 : (TWOF ? 5 : 7))) : 0) + ((WV == 1 && P == CP_LOAD) ? NCR : 0);
-      constexpr int STEP = NM / (NR > 0 ? NR : 1) > 0 ? NM / (NR > 0 ? NR : 1) : 1;
+      constexpr int STEP = 1;  // (one matrix instruction per read from the start of the group: +0.5 % over an even spread)
       md_unroll<0, NR>([&](auto) {
         __builtin_amdgcn_sched_group_barrier(0x008, STEP, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -648,7 +651,8 @@ __device__ __forceinline__ void mm_real(const MidCommon& cm,
   }
   constexpr int NB16 = S::NB16 > 0 ? S::NB16 : 1;
   constexpr int JR = NJ;  // small B blocks by column block J
-  constexpr bool TWOA = MODE == 2, TWOB = MODE == 1;
+  constexpr bool QUAD = MODE == 3 || MODE == 4;  // four products in one pass over the operands, as in mm_real_pw
+  constexpr bool TWOA = MODE == 2 || QUAD, TWOB = MODE == 1 || QUAD;
   // D is in (4 NJ - 4, 4 NJ]: a real product has exactly NJ K-steps.  The loop is fully unrolled with the operands
   // fetched PF steps ahead in a ring of PF + 1 register stages: the LDS round trip (~150 cycles) is more than two
   // K-steps of a single 16x16x4 instruction, and a one-step prefetch left the matrix pipe waiting on every step.
@@ -693,6 +697,28 @@ __device__ __forceinline__ void mm_real(const MidCommon& cm,
     }                                                                                                            \
   }
 #define C3P_MMR_FMAS(K)                                                                                          \
+  if constexpr (QUAD) {                                                                                          \
+    constexpr int st_ = (K) % NS;                                                                                \
+    _Pragma("unroll") for (int i = 0; i < T::NBW; ++i) {                                                         \
+      if (T::is_wide(i)) {                                                                                       \
+        acc1.big[i][0] = md_mfma4(aw[st_], g[st_][T::bJg(i)], acc1.big[i][0]);                                   \
+        acc2.big[i][0] = md_mfma4(aw[st_], h[st_][T::bJg(i)], acc2.big[i][0]);                                   \
+        acc1.big[i][0] = MODE == 3 ? md_mfma4(xw[st_], h[st_][T::bJg(i)], acc1.big[i][0]) : md_mfma4n(xw[st_], h[st_][T::bJg(i)], acc1.big[i][0]); \
+        acc2.big[i][0] = MODE == 3 ? md_mfma4n(xw[st_], g[st_][T::bJg(i)], acc2.big[i][0]) : md_mfma4(xw[st_], g[st_][T::bJg(i)], acc2.big[i][0]); \
+        continue;                                                                                                \
+      }                                                                                                          \
+      acc1.big[i] = md_mfma16(a[st_][T::bIg(i)], g[st_][T::bJg(i)], acc1.big[i]);                                \
+      acc2.big[i] = md_mfma16(a[st_][T::bIg(i)], h[st_][T::bJg(i)], acc2.big[i]);                                \
+      acc1.big[i] = MODE == 3 ? md_mfma16(x[st_][T::bIg(i)], h[st_][T::bJg(i)], acc1.big[i]) : md_mfma16n(x[st_][T::bIg(i)], h[st_][T::bJg(i)], acc1.big[i]); \
+      acc2.big[i] = MODE == 3 ? md_mfma16n(x[st_][T::bIg(i)], g[st_][T::bJg(i)], acc2.big[i]) : md_mfma16(x[st_][T::bIg(i)], g[st_][T::bJg(i)], acc2.big[i]); \
+    }                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < T::NSW; ++i) {                                                         \
+      acc1.sm[i] = md_mfma4(a[st_][T::sIg(i)], sb[st_][T::sJ(i)], acc1.sm[i]);                                   \
+      acc2.sm[i] = md_mfma4(a[st_][T::sIg(i)], ub[st_][T::sJ(i)], acc2.sm[i]);                                   \
+      acc1.sm[i] = MODE == 3 ? md_mfma4(x[st_][T::sIg(i)], ub[st_][T::sJ(i)], acc1.sm[i]) : md_mfma4n(x[st_][T::sIg(i)], ub[st_][T::sJ(i)], acc1.sm[i]); \
+      acc2.sm[i] = MODE == 3 ? md_mfma4n(x[st_][T::sIg(i)], sb[st_][T::sJ(i)], acc2.sm[i]) : md_mfma4(x[st_][T::sIg(i)], sb[st_][T::sJ(i)], acc2.sm[i]); \
+    }                                                                                                            \
+  } else                                                                                                         \
   {                                                                                                              \
     constexpr int st_ = (K) % NS;                                                                                \
     _Pragma("unroll") for (int i = 0; i < T::NBW; ++i) {                                                         \
@@ -1067,9 +1093,12 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       Regs Vr, Vi;
       zero(Vr);
       zero(Vi);
+      // (the 48-row classes take the four-product pass of the pinwheel class too: cfg5 +0.6 %, D = 36 / 40 at 256 samples +1.5 - 2 %;
+      // no gain on the 16- / 32-row classes)
+      constexpr bool QUADC = PW || NIGR >= 3;
       if constexpr (PLAN6) {
         mm_real<NIGR, NJ, W, WV, 3, 1, 3, 4, 5>(cm, Vr, Vi);  // all four products in one pass over the operands
-      } else if constexpr (PW) {
+      } else if constexpr (QUADC) {
         mm_real<NIGR, NJ, W, WV, 3, 1, 2, 3, 4>(cm, Vr, Vi);
       } else {
         mm_real<NIGR, NJ, W, WV, 1, 2, 2, 4, 3>(cm, Vr, Vi);  // S Ui, S Ur
