@@ -222,8 +222,12 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
           for (int Ig = 0; Ig < NRG; ++Ig) aC[Ig] = aN[Ig];
 #pragma unroll
           for (int jj = 0; jj < NJ; ++jj) br[jj] = brN[jj];
-          // a basic-block boundary per K-step (an opaque, never taken scalar branch)
+          // (-DC3P_REGR_BB: a basic-block boundary per K-step -- an opaque scalar branch that jumps over an s_sleep -- as in rounds 2 - 4,
+          // when it kept the scheduler from merging K-steps; with the per-instruction sched_barrier above it only costs its taken
+          // branch: 108.9 -> 106.1 ms per 512-sample cfg4 batch without it)
+#ifdef C3P_REGR_BB
           if (rr_opq(0) != 0) asm volatile("s_sleep 1");
+#endif
         });
         // row DM-1 (and, on one wave, the corner): partial sums over the k of each MFMA block
         {

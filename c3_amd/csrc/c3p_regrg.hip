@@ -196,7 +196,9 @@ __global__ void __launch_bounds__(256, 1) regr_grad_kernel(RegrGradArgs A) {
           for (int Ig = 0; Ig < NRG; ++Ig) aC[Ig] = aN[Ig];
 #pragma unroll
           for (int jj = 0; jj < NJ; ++jj) br[jj] = brN[jj];
-          if (rr_opq(0) != 0) asm volatile("s_sleep 1");  // a basic-block boundary per K-step
+#ifdef C3P_REGR_BB
+          if (rr_opq(0) != 0) asm volatile("s_sleep 1");  // a basic-block boundary per K-step (rounds 2 - 4; see c3p_regr.hip)
+#endif
         });
         {
           const double va = pr[OFF];
