@@ -262,6 +262,12 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
     // the k of block (b - g) mod 4 of every row group: over the four groups every block meets every k -- four partial
     // sums, one per group.  Its own short loop (A fragments one row group ahead): inside the main loop, as "the K-step
     // s == g", the branch was if-converted into four times the MFMAs on the two-waves-per-SIMD instance.
+    // operands of the rank-1 update (k = DM-1) further down: fetched here, so that their LDS round trip runs under the column loop
+    double a80[NRG], b80[NJ];
+#pragma unroll
+    for (int Ig = 0; Ig < NRG; ++Ig) a80[Ig] = img[(16 * Ig + rowC) * LD + DM - 1];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) b80[jj] = rb[col0 + 4 * jj + p];
     if (col_owner) {
       const int kb = 4 * ((b - cg) & 3) + q;
       const double* pa = img + rowA * LD + kb;
@@ -295,11 +301,6 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
     cornerR = rb[BS - 1];
     // k = DM-1: rank-1 update of the core
     {
-      double a80[NRG], b80[NJ];
-#pragma unroll
-      for (int Ig = 0; Ig < NRG; ++Ig) a80[Ig] = img[(16 * Ig + rowC) * LD + DM - 1];
-#pragma unroll
-      for (int jj = 0; jj < NJ; ++jj) b80[jj] = rb[col0 + 4 * jj + p];
 #pragma unroll
       for (int Ig = 0; Ig < NRG; ++Ig)
 #pragma unroll
@@ -437,13 +438,29 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
     // X = 2^-s (G0 + sum_k c_k G_k) for slice tt of the staged chunk (tables: L2 resident, shared by all workgroups):
     // tiles -> Xs, Rm and the image, borders -> slot M0 and the image; trace shift of the slice -> mu
     auto assemble = [&](int tt) {
-      mu = meta(0)[0];
       double bv = 0.0;
-      if (tid < BS) bv = scale * tabs[TSET + tid];
-      for (int k = 0; k < K; ++k) {
-        const double c = sg[k * RR_CH + tt];
-        mu = fma(c, meta(k + 1)[0], mu);
-        if (tid < BS) bv = fma(scale * c, tabs[(long)(k + 1) * G::TAB_D + TSET + tid], bv);
+      if (K <= 2) {
+        // (cfg4: K = 2) the trace shifts and border elements of all three tables in ONE round trip to L2 -- the rolled loop below
+        // waited for a load per control line, three dependent round trips in the phase after the chain product
+        const int btid = tid < BS ? tid : 0;
+        double mk[3], bk[3];
+#pragma unroll
+        for (int k1 = 0; k1 < 3; ++k1) {
+          const int ks = k1 <= K ? k1 : 0;
+          mk[k1] = meta(ks)[0];
+          bk[k1] = tabs[(long)ks * G::TAB_D + TSET + btid];
+        }
+        const double c1 = K >= 1 ? sg[0 * RR_CH + tt] : 0.0, c2 = K >= 2 ? sg[1 * RR_CH + tt] : 0.0;
+        mu = fma(c2, mk[2], fma(c1, mk[1], mk[0]));
+        bv = scale * fma(c2, bk[2], fma(c1, bk[1], bk[0]));
+      } else {
+        mu = meta(0)[0];
+        if (tid < BS) bv = scale * tabs[TSET + tid];
+        for (int k = 0; k < K; ++k) {
+          const double c = sg[k * RR_CH + tt];
+          mu = fma(c, meta(k + 1)[0], mu);
+          if (tid < BS) bv = fma(scale * c, tabs[(long)(k + 1) * G::TAB_D + TSET + tid], bv);
+        }
       }
       if (tid < BS) {
         brd[S_M0 * BS + tid] = bv;
@@ -511,7 +528,8 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
           for (int jj = 0; jj < NJ; ++jj) {
             const double dg = (16 * Ig + rowC == col0 + 4 * jj + p) ? 1.0 : 0.0;
             const double x = LEAN ? Rm[Ig][jj] : Xs[Ig][jj], a2 = A2s[Ig][jj], a6 = acc[Ig][jj];
-            const double a3 = img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p];  // the left operand of A6 = A3 A3
+            // A3: the right operand of A6 = A3 A3 still sits in Rm (the lean form re-assembled X there: it reads the image)
+            const double a3 = LEAN ? img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p] : Rm[Ig][jj];
             // B1 -> image (left operand of A9 = B1 B5 + B4)
             img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p] = fma(C3P_T18_A31, a3, fma(C3P_T18_A21, a2, C3P_T18_A11 * x));
             // B2, B3 stay in registers (in the places of X and A2)
