@@ -342,3 +342,13 @@ def test_ode_lindblad_above_32_non_hermitian_inputs(prop):
     for b in range(B):
         ref = o.ode_solver_arrays(h0, hks, sig[b], ts, rho[b], "rk4", "lindblad", col=col, final_only=True)["states"]
         assert np.abs(out[b] - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+
+
+def test_pinwheel_class_edge_sizes():
+    """One to seven slices, one or two samples, segments requested beyond the slice count, zero drift / zero controls
+    (U = 1 exactly): tools/chk_pinwheel_edges.py (forward against the oracle, real sweep against the general one)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "chk_pinwheel_edges.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "edge cases OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
