@@ -355,13 +355,29 @@ __global__ void __launch_bounds__(256, 1) regr_grad_kernel(RegrGradArgs A) {
     };
     // border of A -> slot B_A; trace shift of the slice -> mu
     auto assemble_border = [&](int tt) __attribute__((always_inline)) {
-      mu = meta_t(0)[0];
       double bv = 0.0;
-      if (tid < BS) bv = scale * tabs_t[TSET + tid];
-      for (int k = 0; k < K; ++k) {
-        const double c = sg[k * RR_CH + tt];
-        mu = fma(c, meta_t(k + 1)[0], mu);
-        if (tid < BS) bv = fma(scale * c, tabs_t[(long)(k + 1) * G::TAB_D + TSET + tid], bv);
+      if (K <= 2) {
+        // (K <= 2, cfg4) trace shifts and border elements of the three tables in ONE round trip to L2 instead of one per line,
+        // as in the forward kernel (c3p_regr.hip)
+        const int btid = tid < BS ? tid : 0;
+        double mk[3], bk[3];
+#pragma unroll
+        for (int k1 = 0; k1 < 3; ++k1) {
+          const int ks = k1 <= K ? k1 : 0;
+          mk[k1] = meta_t(ks)[0];
+          bk[k1] = tabs_t[(long)ks * G::TAB_D + TSET + btid];
+        }
+        const double c1 = K >= 1 ? sg[0 * RR_CH + tt] : 0.0, c2 = K >= 2 ? sg[1 * RR_CH + tt] : 0.0;
+        mu = fma(c2, mk[2], fma(c1, mk[1], mk[0]));
+        bv = scale * fma(c2, bk[2], fma(c1, bk[1], bk[0]));
+      } else {
+        mu = meta_t(0)[0];
+        if (tid < BS) bv = scale * tabs_t[TSET + tid];
+        for (int k = 0; k < K; ++k) {
+          const double c = sg[k * RR_CH + tt];
+          mu = fma(c, meta_t(k + 1)[0], mu);
+          if (tid < BS) bv = fma(scale * c, tabs_t[(long)(k + 1) * G::TAB_D + TSET + tid], bv);
+        }
       }
       if (tid < BS) brd[B_A * BS + tid] = bv;
     };
