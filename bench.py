@@ -165,6 +165,14 @@ def self_launch(n, argv):
     `torch.distributed.run --standalone --nproc-per-node N` would do, without its agent and log redirection), one per GPU,
     rendezvous on 127.0.0.1 at a free port.  Every child inherits stdout / stderr: rank 0 alone writes the JSON line.  The first
     rank that fails takes the others down (by their own process handles); the exit code is the first non-zero one."""
+    import signal
+    import tempfile
+
+    # Rendezvous through a FILE store created here (rank 0 never has to win a race for a TCP port that a probe socket found
+    # free a moment ago -- ADVICE r5); MASTER_ADDR / MASTER_PORT are still exported for libraries that read them.
+    fd, store = tempfile.mkstemp(prefix="c3p_bench_rdzv_")
+    os.close(fd)
+    os.unlink(store)  # the FileStore creates it; a stale file would carry a previous run's keys
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -172,11 +180,18 @@ def self_launch(n, argv):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), C3P_BENCH_SELF_LAUNCHED="1")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), C3P_BENCH_SELF_LAUNCHED="1", C3P_BENCH_RDZV_FILE=store)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (the host driver supports nothing else)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
     rc = 0
     live = list(procs)
+
+    def on_term(signum, _frame):  # the parent is told to stop: the ranks must not outlive it
+        for q in live:
+            q.terminate()
+        raise SystemExit(128 + signum)
+
+    old_term = signal.signal(signal.SIGTERM, on_term)
     try:
         while live:
             time.sleep(0.05)
@@ -191,8 +206,13 @@ def self_launch(n, argv):
                     for q in live:
                         q.terminate()
     finally:
+        signal.signal(signal.SIGTERM, old_term)
         for q in live:
             q.kill()
+        try:
+            os.unlink(store)
+        except OSError:
+            pass
     return rc
 
 
@@ -233,7 +253,9 @@ def main():
     if args.gpus != world and rank == 0:
         print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): running {world}", file=sys.stderr, flush=True)
     if args.check is None:
-        args.check = world > 1
+        # default ON at every N: the line the driver records carries max_fro_err_vs_oracle next to the rate (BASELINE.json's
+        # metric is "propagators/s ...; |U - U_ref|_F").  The check runs AFTER the timed region on a bounded spread of samples.
+        args.check = True
     standin = os.environ.get("C3P_BENCH_STANDIN") == "1"  # test scaffold: CPU ranks over gloo, nothing computed (see _StandInPropagator)
     dist = None
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
@@ -254,10 +276,12 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        rdzv = os.environ.get("C3P_BENCH_RDZV_FILE")  # self-launched ranks: file store, no port race (see self_launch)
+        kw = {"init_method": f"file://{rdzv}"} if rdzv else {}
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, **kw)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, **kw)
         if rank == 0:
             print(f"[bench] {'RCCL' if backend == 'nccl' else 'gloo'} world size {dist.get_world_size()} (backend {dist.get_backend()}{', ranks share devices' if oversubscribed else ''})", file=sys.stderr, flush=True)
     red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the scalar reductions of this file live
@@ -462,6 +486,7 @@ def main():
 
         if bp is not None:
             cost = wl.N * (Dm / 9.0) ** 3
+            # cfg2: 32 spread samples (~0.15 s of oracle); the large configurations 2 - 4 (full-size parity: tests/test_gpu_*.py)
             nchk = int(min(B, max(2, min(32, 2.5e5 / cost))))
             idx = np.unique(np.linspace(0, B - 1, nchk).astype(int))
             U = bp.run()
@@ -561,7 +586,9 @@ def main():
                 "clock_ramp_ms": args.ramp_ms,
                 "throughput": f"sustained: after a {args.ramp_ms:g} ms untimed clock ramp and {args.warmup} warmup steps",
                 "parallelism": ((f"dp{world} ({args.scaling}: batch sharded; " + ("one RCCL all-gather of U per step" if G == 1 else f"one RCCL all-gather of U per {G} steps") + (", issued asynchronously under the next step" if args.overlap_gather else "") + ")" if args.exchange == "gather" else f"dp{world} ({args.scaling}: batch sharded; fused fidelity, one RCCL all-reduce of the goal per step, no gather)") if use_dist else ("single GPU" if args.exchange == "gather" else "single GPU, fused fidelity per step")),
-                "exchange": args.exchange,
+                # (N > 1 with --overlap-gather auto: the timed schedule is the faster of two forms of the one-gather-per-step
+                # exchange, picked by an untimed calibration -- named HERE, not only under launch.gather_overlap)
+                "exchange": args.exchange if not (use_dist and args.exchange == "gather") else f"gather ({'overlapped' if args.overlap_gather else 'in_stream_order'}{', picked by calibration' if overlap_choice.get('chosen') else ''})",
                 "kernel": kernel_name,
             },
             "roofline": {

@@ -19,7 +19,7 @@ ORDER_RIGHT = 0x4
 FORCE_GENERIC = 0x8
 HERMITIAN_H = 0x10  # c3p_pwc_lindblad: the caller declares h0 / hks Hermitian (D = 2, 3: real arithmetic in the Hermitian basis)
 
-KERNEL_NAMES = {0: "none", 1: "generic_lds", 2: "generic_global", 3: "smalld", 4: "mfma", 5: "ode_wg", 6: "ode_row", 7: "ode_mfma"}
+KERNEL_NAMES = {0: "none", 1: "generic_lds", 2: "generic_global", 3: "smalld", 4: "mfma", 5: "ode_wg", 6: "ode_row", 7: "ode_mfma", 8: "ode_row_or_wg"}
 
 SOLVERS = {"rk4": 0, "rk38": 1, "rk5": 2, "tsit5": 3}
 STEPS = {"schrodinger": 0, "von_neumann": 1, "lindblad": 2}

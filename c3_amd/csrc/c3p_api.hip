@@ -2483,6 +2483,10 @@ int c3p_ode_solve(const void* h0, const void* hks, const double* signals, const 
       // decides (both kernels look at the operators and one of them leaves at once), as regr_prep_kernel does for the PWC path.
       const bool split = step == C3P_STEP_VON_NEUMANN && K > 4 && C == 0 && B <= 4096 && !c3p_opt_on(C3P_OPT_ode_no_split);
       a.complex_to_wg = split ? 1 : 0;
+      // (the host cannot know which of the two did the work: a distinct id, so that profiles do not book a workgroup-kernel
+      // run on the lane rows; the second launch -- B workgroups of 256 threads that leave at once for real operators -- is paid
+      // on every such call)
+      if (split) g_last_kernel = C3P_KERNEL_ODE_ROW_OR_WG;
       LAUNCH_TRY(c3p_launch_ode_row(a, aux, st));
       if (split) {
         OdeArgs g = a;

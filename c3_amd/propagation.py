@@ -144,6 +144,7 @@ def propagate_batch(
     fr_phase=None,
     want_dUs: bool = False,
     force_generic: bool = False,
+    recheck_operators: bool = False,
 ) -> Dict:
     """U[b] for B independent parameter samples in one library call.
 
@@ -153,7 +154,12 @@ def propagate_batch(
     signals  [B,K,N] real | None
     fr_phase [B,Dm] real or None; U <- diag(exp(i phase)) U   (experiment.py:482-509)
     Returns {"U": [B,Dm,Dm], "dUs": [B,N,Dm,Dm] or None}, Dm = D (unitary) or D*D (Lindblad).
+
+    `recheck_operators`: measure the hermiticity of device operator tensors again instead of trusting the per-tensor verdict
+    (`forget_operators`; needed after a write through a raw pointer / DLPack view, which does not bump `_version`).
     """
+    if recheck_operators:
+        forget_operators(h0, hks)
     call = _Call(h0, hks, signals, col_ops, fr_phase)
     lib = _lib.load()
     flags = call.flags | (_lib.FORCE_GENERIC if force_generic else 0)
@@ -209,6 +215,17 @@ def propagate_batch(
 _hermitian_memo = TensorMemo()  # per operator tensor OBJECT: the measured relative deviation |h - h^+| / |h| (both verdicts)
 
 
+def forget_operators(*tensors) -> None:
+    """Drop the cached hermiticity verdict of these operator tensors.  The verdict is kept per tensor object and
+    `_version`; in-place writes that torch does not see -- a libc3prop output pointer, a DLPack / cupy view, another library's
+    kernel -- leave `_version` unchanged, and a stale 'Hermitian' verdict would send a non-Hermitian operator down the real
+    Hermitian-basis Lindblad kernels (D = 2..4) or past the gradient's hermiticity guard.  Call this (or pass
+    `recheck_operators=True`) after such a write."""
+    for t in tensors:
+        if t is not None:
+            _hermitian_memo.forget(t)
+
+
 def _hermitian_deviation(call, h) -> float:
     """|h - h^+|_max / |h|_max.  Device tensors: measured ONCE per tensor object and `_version` (an optimiser calls with the same
     operator tensors every iteration; the measurement is two host synchronisations, which also break stream capture) -- the
@@ -243,7 +260,7 @@ def _require_hermitian(call, name, h, tol=1e-12):
         raise C3PropError(f"C3:Error: {name} must be Hermitian for the gradient (|h - h^+| / |h| = {dev:.3e})")
 
 
-def propagate_batch_vjp(h0, hks, signals, dt: float, U_bar, *, fr_phase=None, force_generic: bool = False, want_model_grads: bool = False, check_hermitian: bool = True):
+def propagate_batch_vjp(h0, hks, signals, dt: float, U_bar, *, fr_phase=None, force_generic: bool = False, want_model_grads: bool = False, check_hermitian: bool = True, recheck_operators: bool = False):
     """Vector-Jacobian product of `propagate_batch` (unitary, branch A) w.r.t. the control samples.
 
     The reference tapes the goal function (optimizers/optimizer.py:206-216) and lets TensorFlow
@@ -255,6 +272,8 @@ def propagate_batch_vjp(h0, hks, signals, dt: float, U_bar, *, fr_phase=None, fo
     Hamiltonians themselves (d loss = Re sum conj(grad_h) dh), contracted from the per-slice generator
     cotangents Z[b,n] -- what a model-parameter fit differentiates (optimizers/modellearning.py:300-341).
     """
+    if recheck_operators:
+        forget_operators(h0, hks)
     call = _Call(h0, hks, signals, U_bar, fr_phase)
     h0 = call.c128(h0)
     hks = call.c128(hks)
@@ -308,7 +327,7 @@ def goal_vjp_is_fused(B: int, D: int) -> bool:
     return D <= 40 or (D <= 64 and B < 384 and _lib.get_option("tiled_grad") <= 0)
 
 
-def propagate_batch_goal_vjp(h0, hks, signals, dt: float, ideal, index, dims, *, kind: str = "unitary", fr_phase=None, want_U: bool = True, check_hermitian: bool = True):
+def propagate_batch_goal_vjp(h0, hks, signals, dt: float, ideal, index, dims, *, kind: str = "unitary", fr_phase=None, want_U: bool = True, check_hermitian: bool = True, recheck_operators: bool = False):
     """Goal and gradient of one optimiser evaluation from ONE pass over the chains (c3p_pwc_unitary_goal_vjp).
 
     The reference evaluates `goal_run = fid_func(compute_propagators())` (optimizers/optimalcontrol.py:200-228) under a
@@ -317,6 +336,8 @@ def propagate_batch_goal_vjp(h0, hks, signals, dt: float, ideal, index, dims, *,
     fidelities.py:154-184) or average_infid ("average", :290-313) of every sample and grad = d goal[b] / d signals[b]."""
     from .fidelities import computational_rows
 
+    if recheck_operators:
+        forget_operators(h0, hks)
     call = _Call(h0, hks, signals, fr_phase, ideal)
     h0 = call.c128(h0)
     hks = call.c128(hks)
@@ -404,7 +425,7 @@ def lindblad_tape_supported(B: int, K: int, N: int, D: int) -> bool:
     return int(_lib.load().c3p_pwc_lindblad_tape_bytes(B, K, N, D, ctypes.byref(seg))) > 0
 
 
-def propagate_batch_lindblad_taped(h0, hks, signals, dt: float, col_ops, *, fr_phase=None):
+def propagate_batch_lindblad_taped(h0, hks, signals, dt: float, col_ops, *, fr_phase=None, recheck_operators: bool = False):
     """`propagate_batch(..., lindbladian=True)` for device tensors that also records a `LindbladTape` (D = 2, 3; D = 7, 8, 9 with Hermitian
     Hamiltonians; c3p_pwc_lindblad_taped): returns {"U": [B,D^2,D^2], "tape": LindbladTape}.  One forward pass serves the
     superoperators AND their vector-Jacobian product (`tape.vjp`), where `propagate_batch` + `propagate_batch_lindblad_vjp`
@@ -413,6 +434,8 @@ def propagate_batch_lindblad_taped(h0, hks, signals, dt: float, col_ops, *, fr_p
 
     import torch
 
+    if recheck_operators:
+        forget_operators(h0, hks)
     call = _Call(h0, hks, signals, col_ops, fr_phase)
     if not call.device:
         raise C3PropError("C3:Error: the taped Lindblad evaluation takes device tensors")
@@ -485,10 +508,12 @@ def propagate_per_slice_vjp(hs, dt: float, U_bar, *, fr_phase=None):
     return (1j * dt) * Z
 
 
-def propagate_batch_lindblad_vjp(h0, hks, signals, dt: float, col_ops, U_bar, *, fr_phase=None):
+def propagate_batch_lindblad_vjp(h0, hks, signals, dt: float, col_ops, U_bar, *, fr_phase=None, recheck_operators: bool = False):
     """Vector-Jacobian product of `propagate_batch(..., lindbladian=True)` w.r.t. the control samples: the reference
     tapes tf_propagation_lind (propagation.py:551-585) under the same GradientTape (optimizers/optimizer.py:206-216).
     `U_bar` [B,D^2,D^2] is the cotangent of the superoperators (d loss = Re sum conj(U_bar) dU); returns f64 [B,K,N]."""
+    if recheck_operators:
+        forget_operators(h0, hks)
     call = _Call(h0, hks, signals, U_bar, fr_phase, col_ops)
     h0 = call.c128(h0)
     hks = call.c128(hks)

@@ -94,7 +94,8 @@ def _shapes(call, env_shapes, K: int, E: int):
     host-to-device copy per call is a synchronisation (and illegal inside a stream capture).  A device table is remembered
     per tensor OBJECT; the [K,E] check against the parameter rows runs on every call, hit or not."""
     on_dev = _is_torch(env_shapes) and env_shapes.is_cuda
-    hit = _shapes_memo.get(env_shapes, str(env_shapes.dtype)) if on_dev else None
+    mkey = (str(env_shapes.dtype), str(call.dev)) if on_dev else None  # the upload lives on call.dev (ADVICE r5)
+    hit = _shapes_memo.get(env_shapes, mkey) if on_dev else None
     if hit is not None:
         if hit[0].shape != (K, E):
             raise C3PropError(f"C3:Error: env_shapes must be [{K},{E}], got {hit[0].shape}")
@@ -113,7 +114,7 @@ def _shapes(call, env_shapes, K: int, E: int):
             _shapes_upload.clear()
         shp = _shapes_upload[key2] = call.torch.as_tensor(shapes_np, device=call.dev)
     if on_dev:
-        _shapes_memo.put(env_shapes, str(env_shapes.dtype), (shapes_np, shp))
+        _shapes_memo.put(env_shapes, mkey, (shapes_np, shp))
     return shapes_np, shp
 
 

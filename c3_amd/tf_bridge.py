@@ -45,7 +45,8 @@ from .propagation import unitary_deco
 
 _tf_module = None
 
-# module-level switches (a provider's signature is fixed by experiment.py:472-478)
+# module-level switches (a provider's signature is fixed by experiment.py:472-478).  They are read when `pwc_tf` RUNS, i.e.
+# at TRACE time under `@tf.function`: a function traced once keeps the values it was traced with (re-trace to change them).
 options = {
     "want_dUs": True,  # False: skip the [N,Dm,Dm] partial propagators (result["dUs"] is None)
     "model_grads": True,  # closed systems: also return h0_bar / hks_bar (costs one [N,D,D] cotangent stack)
@@ -185,6 +186,44 @@ def hip_propagate(h0, hks, signals, dt, col_ops=None, lindbladian: bool = False,
     return finish(*op(h0, hks, signals))
 
 
+def _guard(tf, cond_value, bound, message: str):
+    """`cond_value < bound` everywhere, as the reference's `if not np.all(... < ...): raise` (propagation.py:301-308).
+    Eager: evaluated now, raises the reference's Exception.  While a `@tf.function` is traced the operands are symbolic and
+    `np.all` cannot run: a `tf.debugging.assert_less` op is returned instead (InvalidArgumentError at run time) and the
+    caller puts the result under `tf.control_dependencies`.  Returns the list of assert ops (empty when eager)."""
+    eager = getattr(tf, "executing_eagerly", lambda: True)()
+    if eager:
+        if not np.all(_np(cond_value) < _np(bound)):
+            raise Exception(message)
+        return []
+    return [tf.debugging.assert_less(cond_value, bound, message=message)]
+
+
+def _real_signal(tf, values, guards: list):
+    """The reference casts the control samples to complex128 (propagation.py:293) and a complex sample would enter the
+    Hamiltonian as a complex coefficient; the library takes REAL samples (devices.py:936: i1 i2 + q1 q2 is real).  A sample
+    with an imaginary part is therefore refused instead of silently projected."""
+    dt = getattr(values, "dtype", None)
+    is_cplx = dt is not None and ("complex" in str(dt))
+    if is_cplx:
+        im = tf.math.reduce_max(tf.math.abs(tf.math.imag(values)))
+        guards += _guard(tf, im, 1e-300, "C3:Error: pwc_tf takes real control samples (the signal has an imaginary part)")
+    return tf.cast(tf.math.real(values), tf.float64)
+
+
+class _deps:
+    """`tf.control_dependencies(ops)` when there are ops to depend on, a no-op otherwise (eager / stand-in)."""
+
+    def __init__(self, tf, ops):
+        self._cm = tf.control_dependencies(ops) if ops else None
+
+    def __enter__(self):
+        return self._cm.__enter__() if self._cm is not None else None
+
+    def __exit__(self, *a):
+        return self._cm.__exit__(*a) if self._cm is not None else False
+
+
 @unitary_deco
 def pwc_tf(model, gen, instr, folding_stack: list, batch_size=None) -> Dict:
     """The reference's `pwc` (propagation.py:258-341) with the propagation on the MI355X and a registered gradient: usable as
@@ -195,6 +234,7 @@ def pwc_tf(model, gen, instr, folding_stack: list, batch_size=None) -> Dict:
     signal = gen.generate_signals(instr)
     lind = bool(model.lindbladian)
     col_ops = None
+    guards: list = []  # graph-mode assert ops (empty when eager: the checks have raised already)
     if lind:
         col_ops = list(model.get_Lindbladians())
         if model.max_excitations:
@@ -205,15 +245,25 @@ def pwc_tf(model, gen, instr, folding_stack: list, batch_size=None) -> Dict:
         h0, hctrls = model.get_Hamiltonians()
         sigs, hks, ts = [], [], None
         for key in signal:
-            sigs.append(tf.cast(tf.math.real(signal[key]["values"]), tf.float64))
+            sigs.append(_real_signal(tf, signal[key]["values"], guards))
             ts = signal[key]["ts"]
             hks.append(tf.cast(hctrls[key], tf.complex128))
-        U, dUs = hip_propagate(h0, tf.stack(hks), tf.stack(sigs), ts[1] - ts[0], col_ops=col_ops, lindbladian=lind,
-                               want_dUs=options["want_dUs"], model_grads=options["model_grads"])
+        if not sigs:
+            # (the reference fails here too: `ts` stays [] and `ts[1] - ts[0]` raises IndexError, propagation.py:284-310)
+            raise C3PropError("C3:Error: pwc_tf: the instruction drives no line, so there is no time grid to propagate on")
+        with _deps(tf, guards):
+            U, dUs = hip_propagate(h0, tf.stack(hks), tf.stack(sigs), ts[1] - ts[0], col_ops=col_ops, lindbladian=lind,
+                                   want_dUs=options["want_dUs"], model_grads=options["model_grads"])
     else:
         hs = model.get_Hamiltonian(signal)
-        ts = tf.math.reduce_mean(tf.stack([sig["ts"][1:] for sig in signal.values()]), axis=0)
-        U, dUs = hip_propagate(hs, None, None, ts[1] - ts[0], col_ops=col_ops, lindbladian=lind, want_dUs=options["want_dUs"])
+        ts_list = tf.stack([sig["ts"][1:] for sig in signal.values()])
+        ts = tf.math.reduce_mean(ts_list, axis=0)
+        # the reference's two sanity checks of the time grid (propagation.py:301-308), same message
+        tol = 1e-5 * (ts[1] - ts[0])
+        guards += _guard(tf, tf.math.reduce_variance(ts_list, axis=0), tol, "C3Error:Something with the times happend.")
+        guards += _guard(tf, tf.math.reduce_variance(ts[1:] - ts[:-1]), tol, "C3Error:Something with the times happend.")
+        with _deps(tf, guards):
+            U, dUs = hip_propagate(hs, None, None, ts[1] - ts[0], col_ops=col_ops, lindbladian=lind, want_dUs=options["want_dUs"])
     if model.max_excitations:
         if lind:
             raise C3PropError("C3:Error: blow-up of a cut Lindblad superoperator is undefined in the reference")

@@ -72,6 +72,7 @@ extern "C" {
 #define C3P_KERNEL_ODE_WG 5  /* workgroup-per-sample ODE kernel (c3p_ode.hip)            */
 #define C3P_KERNEL_ODE_ROW 6 /* lane-row ODE kernels (c3p_ode_row.hip, c3p_ode_rowq.hip)  */
 #define C3P_KERNEL_ODE_MFMA 7 /* matrix-core rho-valued ODE kernel, 17 <= D <= 48 (c3p_ode_rhoq.hip) */
+#define C3P_KERNEL_ODE_ROW_OR_WG 8 /* both launched; the DEVICE picks: real operators -> lane rows, complex -> workgroup kernel */
 
 /* ODE solver / step ids (propagation.py:27-32 solver_slicing; :886-904 steps) */
 #define C3P_SOLVER_RK4 0

@@ -440,7 +440,8 @@ def test_ode_row_more_than_four_control_lines(prop, D, K):
         for fin in (False, True):
             got = np.asarray(prop.ode_solve_batch(h0, hks, sig, dt, init, solver, step, col_ops=c, final_only=fin))
             # (rho-valued states: the operator rows of the lines beyond four sit in LDS)
-            assert _lib.last_kernel() == "ode_row", (solver, step)
+            # (von Neumann without collapse operators at this batch: lane rows AND workgroup kernel are launched, the device picks)
+            assert _lib.last_kernel() == ("ode_row_or_wg" if (step == "von_neumann" and c is None) else "ode_row"), (solver, step)
             with _lib.options(ode_wg=1):
                 ref = np.asarray(prop.ode_solve_batch(h0, hks, sig, dt, init, solver, step, col_ops=c, final_only=fin))
                 assert _lib.last_kernel() == "ode_wg"

@@ -38,8 +38,10 @@ def test_ode_rho_many_control_lines_dispatch_by_device_flag(prop, D, K, solver, 
     dt = ts[1] - ts[0]
     for final_only in (True, False):
         got = np.asarray(prop.ode_solve_batch(h0, hks, sig, dt, rho, solver, "von_neumann", final_only=final_only))
+        assert _lib.last_kernel() == "ode_row_or_wg"  # a distinct id: the host does not know which of the two did the work
         with _lib.options(ode_no_split=1):
             rows = np.asarray(prop.ode_solve_batch(h0, hks, sig, dt, rho, solver, "von_neumann", final_only=final_only))
+            assert _lib.last_kernel() == "ode_row"
         with _lib.options(ode_wg=1):
             wg = np.asarray(prop.ode_solve_batch(h0, hks, sig, dt, rho, solver, "von_neumann", final_only=final_only))
         scale = max(1.0, np.abs(wg).max())

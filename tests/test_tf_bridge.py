@@ -158,6 +158,39 @@ def test_bridge_options_and_signals_only_gradient(monkeypatch):
         b.use_tf_module(None)
 
 
+def test_bridge_keeps_the_reference_guards(monkeypatch):
+    """what the reference's pwc refuses, pwc_tf refuses too: a non-uniform time grid on the per-slice branch
+    (propagation.py:301-308, same message), control samples with an imaginary part (the reference would use them as complex
+    coefficients, the library takes real samples), and an instruction without drive lines (IndexError in the reference)."""
+    from c3_amd._lib import C3PropError
+
+    _oracle_backed(monkeypatch)
+    tf = StandIn()
+    b = _bridge(tf)
+    try:
+        m, gen, instr = setup(N=12)
+        m.controllability = False
+        sig = gen.generate_signals(instr)
+        bad = {k: dict(v) for k, v in sig.items()}
+        first = next(iter(bad))
+        bad[first]["ts"] = np.array(bad[first]["ts"], copy=True)
+        bad[first]["ts"][5] += 1e-7  # (the reference compares a VARIANCE in s^2 with 1e-5 dt in s: only a gross error trips it)
+        with pytest.raises(Exception, match="Something with the times happend"):
+            b.pwc_tf(m, workloads.SignalSource({"g": bad}), instr, [], None)
+        m.controllability = True
+        cplx = {k: dict(v) for k, v in sig.items()}
+        cplx[first]["values"] = np.asarray(cplx[first]["values"]) + 1e-3j
+        with pytest.raises(Exception, match="real control samples"):
+            b.pwc_tf(m, workloads.SignalSource({"g": cplx}), instr, [], None)
+        real_as_complex = {k: dict(v, values=np.asarray(v["values"]).astype(complex)) for k, v in sig.items()}
+        got = b.pwc_tf(m, workloads.SignalSource({"g": real_as_complex}), instr, [], None)  # zero imaginary part: accepted
+        assert np.linalg.norm(np.asarray(got["U"]) - o.pwc(m, gen, instr, None, None)["U"]) < 1e-10
+        with pytest.raises(C3PropError, match="drives no line"):
+            b.pwc_tf(m, workloads.SignalSource({"g": {}}), instr, [], None)
+    finally:
+        b.use_tf_module(None)
+
+
 def test_bridge_without_tensorflow_fails_loudly():
     from c3_amd import tf_bridge
     from c3_amd._lib import C3PropError

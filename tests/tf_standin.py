@@ -22,6 +22,22 @@ class _Math:
     def reduce_mean(x, axis=None):
         return _t(np.mean(np.asarray(x), axis=axis))
 
+    @staticmethod
+    def reduce_variance(x, axis=None):
+        return _t(np.var(np.asarray(x), axis=axis))
+
+    @staticmethod
+    def reduce_max(x, axis=None):
+        return _t(np.max(np.asarray(x), axis=axis))
+
+    @staticmethod
+    def imag(x):
+        return _t(np.imag(np.asarray(x)))
+
+    @staticmethod
+    def abs(x):
+        return _t(np.abs(np.asarray(x)))
+
 
 class StandIn:
     complex128 = np.complex128
@@ -31,6 +47,10 @@ class StandIn:
     def __init__(self):
         self.grad_fns = []  # one per custom_gradient op executed, in order
         self.py_function_calls = 0
+
+    @staticmethod
+    def executing_eagerly():
+        return True
 
     def cast(self, x, dtype):
         a = np.asarray(x)
