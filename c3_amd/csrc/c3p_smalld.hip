@@ -424,6 +424,9 @@ __device__ __forceinline__ double dpp_f64(double v) {
 }
 // sum over the four lanes of a quad (the column index c), result in all four
 __device__ __forceinline__ double quad_sum(double v) {
+#if defined(C3P_SD_ABL) && (C3P_SD_ABL & 16)
+  return v * 4.0;  // TIMING-ONLY (wrong results): no quad reductions
+#endif
   v += dpp_f64<0xB1>(v);  // quad_perm [1,0,3,2]
   v += dpp_f64<0x4E>(v);  // quad_perm [2,3,0,1]
   return v;
@@ -440,6 +443,79 @@ __device__ __forceinline__ void s8_zero(SMat<NC>& a) {
   a.s = 0.0;
 }
 
+// Border sums on the matrix cores (round 6).  On gfx950 a wave's vector instructions and the fp64 matrix instructions of its
+// SIMD do not overlap (tools/ubench_coissue.hip: 8 MFMAs + 32 v_mov_dpp take the SUM of their issue times), a quad reduction of a
+// double costs four v_mov_b32_dpp + two v_add_f64 = ~29 cycles, one v_mfma_f64_4x4x4_4b 16.7 -- and the instruction contracts over
+// the lane's r index for free.  So the partial products of a border are formed with the sum index ON r (for a symmetric left
+// operand: its transposed tile, the register the lane holds anyway, times the r form of the vector) and reduced by ONE matrix
+// instruction against a tile of ones: A = partials, B = 1 -> D[i][j] = sum_r t(r, c = i), i.e. the r form of the result in every lane,
+// with the rest of the border update (a.vr b.s + c.vr) riding in as the accumulator.  -DC3P_SD_QUADSUM builds the DPP reductions.
+#ifndef C3P_SD_QUADSUM
+// C += A B for symmetric commuting A, B (upper core tiles, vr, s of C; s8_finish completes the operand form of C)
+template <int NC>
+__device__ __forceinline__ void mm_s8(const SMat<NC>& a, const SMat<NC>& b, SMat<NC>& c) {
+#pragma unroll
+  for (int K = 0; K < NC; ++K)
+#pragma unroll
+    for (int I = 0; I < NC; ++I)
+#pragma unroll
+      for (int J = I; J < NC; ++J) c.m[I][J] = mfma4(a.m[K][I], b.m[K][J], c.m[I][J]);
+  double t[NC], cs = 0.0;
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+    t[I] = 0.0;
+#pragma unroll
+    for (int K = 0; K < NC; ++K) t[I] = fma(a.m[K][I], b.vr[K], t[I]);  // lane (r, c): A[4I+c][4K+r] b[4K+r]
+    cs = fma(a.vr[I], b.vr[I], cs);
+  }
+#pragma unroll
+  for (int I = 0; I < NC; ++I) c.vr[I] = mfma4(t[I], 1.0, fma(a.vr[I], b.s, c.vr[I]));
+  c.s = mfma4(cs, 1.0, fma(a.s, b.s, c.s));
+#pragma unroll
+  for (int I = 0; I < NC; ++I)
+#pragma unroll
+    for (int J = I; J < NC; ++J) c.m[I][J] = fma(a.vr[I], b.vc[J], c.m[I][J]);
+}
+// two products with one left operand, interleaved (C1 += A B1, C2 += A B2)
+template <int NC>
+__device__ __forceinline__ void mm_s8x2(const SMat<NC>& a, const SMat<NC>& b1, SMat<NC>& c1, const SMat<NC>& b2, SMat<NC>& c2) {
+#pragma unroll
+  for (int K = 0; K < NC; ++K)
+#pragma unroll
+    for (int I = 0; I < NC; ++I)
+#pragma unroll
+      for (int J = I; J < NC; ++J) {
+        c1.m[I][J] = mfma4(a.m[K][I], b1.m[K][J], c1.m[I][J]);
+        c2.m[I][J] = mfma4(a.m[K][I], b2.m[K][J], c2.m[I][J]);
+      }
+  double t1[NC], t2[NC], cs1 = 0.0, cs2 = 0.0;
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+    t1[I] = t2[I] = 0.0;
+#pragma unroll
+    for (int K = 0; K < NC; ++K) {
+      t1[I] = fma(a.m[K][I], b1.vr[K], t1[I]);
+      t2[I] = fma(a.m[K][I], b2.vr[K], t2[I]);
+    }
+    cs1 = fma(a.vr[I], b1.vr[I], cs1);
+    cs2 = fma(a.vr[I], b2.vr[I], cs2);
+  }
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+    c1.vr[I] = mfma4(t1[I], 1.0, fma(a.vr[I], b1.s, c1.vr[I]));
+    c2.vr[I] = mfma4(t2[I], 1.0, fma(a.vr[I], b2.s, c2.vr[I]));
+  }
+  c1.s = mfma4(cs1, 1.0, fma(a.s, b1.s, c1.s));
+  c2.s = mfma4(cs2, 1.0, fma(a.s, b2.s, c2.s));
+#pragma unroll
+  for (int I = 0; I < NC; ++I)
+#pragma unroll
+    for (int J = I; J < NC; ++J) {
+      c1.m[I][J] = fma(a.vr[I], b1.vc[J], c1.m[I][J]);
+      c2.m[I][J] = fma(a.vr[I], b2.vc[J], c2.m[I][J]);
+    }
+}
+#else
 // C += A B for symmetric commuting A, B (upper core tiles, vr, s of C; s8_finish completes the operand form of C)
 template <int NC>
 __device__ __forceinline__ void mm_s8(const SMat<NC>& a, const SMat<NC>& b, SMat<NC>& c) {
@@ -504,9 +580,20 @@ __device__ __forceinline__ void mm_s8x2(const SMat<NC>& a, const SMat<NC>& b1, S
       c2.m[I][J] = fma(a.vr[I], b2.vc[J], c2.m[I][J]);
     }
 }
+#endif
 // operand form of a product: lower core tiles by the in-chain lane swap, the c form of the border column
 template <int NC>
 __device__ __forceinline__ void s8_finish(SMat<NC>& a, int swap_lane, int tail_lane) {
+#if defined(C3P_SD_ABL) && (C3P_SD_ABL & 1)
+  // TIMING-ONLY (wrong results): no lane swaps in the symmetric stage
+#pragma unroll
+  for (int I = 1; I < NC; ++I)
+#pragma unroll
+    for (int J = 0; J < I; ++J) a.m[I][J] = a.m[J][I];
+#pragma unroll
+  for (int J = 0; J < NC; ++J) a.vc[J] = a.vr[J];
+  return;
+#endif
 #pragma unroll
   for (int I = 1; I < NC; ++I)
 #pragma unroll
@@ -514,6 +601,61 @@ __device__ __forceinline__ void s8_finish(SMat<NC>& a, int swap_lane, int tail_l
 #pragma unroll
   for (int J = 0; J < NC; ++J) a.vc[J] = __shfl(a.vr[J], tail_lane);
 }
+// LEFT-operand form of a product (core tiles complete, vr, s): the lower core tiles alone -- a symmetric left operand is read
+// through its tiles, its r-form border and its corner only (mm_s8, chain_step8), the c form is a right operand's business
+template <int NC>
+__device__ __forceinline__ void s8_finish_lower(SMat<NC>& a, int swap_lane) {
+#pragma unroll
+  for (int I = 1; I < NC; ++I)
+#pragma unroll
+    for (int J = 0; J < I; ++J) a.m[I][J] = __shfl(a.m[J][I], swap_lane);
+}
+template <int NC>
+__device__ __forceinline__ void s8_finish_vc(SMat<NC>& a, int tail_lane) {
+#pragma unroll
+  for (int J = 0; J < NC; ++J) a.vc[J] = __shfl(a.vr[J], tail_lane);
+}
+#ifndef C3P_SD_QUADSUM
+// two products with one RIGHT operand, interleaved (C1 += A1 B, C2 += A2 B): A1, A2 in left-operand form
+template <int NC>
+__device__ __forceinline__ void mm_s8x2r(const SMat<NC>& a1, const SMat<NC>& a2, const SMat<NC>& b, SMat<NC>& c1, SMat<NC>& c2) {
+#pragma unroll
+  for (int K = 0; K < NC; ++K)
+#pragma unroll
+    for (int I = 0; I < NC; ++I)
+#pragma unroll
+      for (int J = I; J < NC; ++J) {
+        c1.m[I][J] = mfma4(a1.m[K][I], b.m[K][J], c1.m[I][J]);
+        c2.m[I][J] = mfma4(a2.m[K][I], b.m[K][J], c2.m[I][J]);
+      }
+  double t1[NC], t2[NC], cs1 = 0.0, cs2 = 0.0;
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+    t1[I] = t2[I] = 0.0;
+#pragma unroll
+    for (int K = 0; K < NC; ++K) {
+      t1[I] = fma(a1.m[K][I], b.vr[K], t1[I]);
+      t2[I] = fma(a2.m[K][I], b.vr[K], t2[I]);
+    }
+    cs1 = fma(a1.vr[I], b.vr[I], cs1);
+    cs2 = fma(a2.vr[I], b.vr[I], cs2);
+  }
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+    c1.vr[I] = mfma4(t1[I], 1.0, fma(a1.vr[I], b.s, c1.vr[I]));
+    c2.vr[I] = mfma4(t2[I], 1.0, fma(a2.vr[I], b.s, c2.vr[I]));
+  }
+  c1.s = mfma4(cs1, 1.0, fma(a1.s, b.s, c1.s));
+  c2.s = mfma4(cs2, 1.0, fma(a2.s, b.s, c2.s));
+#pragma unroll
+  for (int I = 0; I < NC; ++I)
+#pragma unroll
+    for (int J = I; J < NC; ++J) {
+      c1.m[I][J] = fma(a1.vr[I], b.vc[J], c1.m[I][J]);
+      c2.m[I][J] = fma(a2.vr[I], b.vc[J], c2.m[I][J]);
+    }
+}
+#endif
 // out = c0 I + c1 W1 + c2 W2 (+ c3 W3), every part (operands are complete: the combination is too); ACCUM: only what a
 // product accumulates into (upper core tiles, vr, s) -- the initial value of an accumulation that s8_finish completes later
 template <int NC, bool WITH3, bool ACCUM = false>
@@ -542,8 +684,104 @@ __device__ __forceinline__ void s8_comb(SMat<NC>& out, double c0, double c1, dou
 
 // chain step in real blocks for the core + border form: (Ur + i Ui) <- (C - i S)(Ur + i Ui) with three real products
 // (T1 = C Ur, T2 = S Ui, T3 = (C - S)(Ur + Ui): Re = T1 + T2, Im = T3 - T1 + T2), C and S symmetric (complete operand form).
-// The three products are combined BEFORE the quad reductions and lane swaps of the borders (six reductions, eight swaps per
-// step instead of nine and twelve).
+// Round 6: no lane swaps and no DPP reductions.  The column border and the corner are reduced over r by a matrix instruction
+// against ones (see mm_s8; the partial products use the TRANSPOSED tile of the symmetric left operand and the r form `cr` of the
+// state's column border, so the c form `cc` is not carried any more); the row border comes out of its matrix instructions already
+// replicated over r, because the A tile holds the border row of the left operand in EVERY row instead of row 0 alone.
+#ifndef C3P_SD_QUADSUM
+template <int NC>
+__device__ __forceinline__ void chain_step8(const SMat<NC>& Cc, const SMat<NC>& Sc, GMat<NC>& Ur, GMat<NC>& Ui, const LanePos& lp,
+                                            int tail_lane, int row0_lane) {
+  (void)lp, (void)tail_lane, (void)row0_lane;
+  SMat<NC> Dm;
+  GMat<NC> Us;
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+#pragma unroll
+    for (int J = 0; J < NC; ++J) {
+      Dm.m[I][J] = Cc.m[I][J] - Sc.m[I][J];
+      Us.m[I][J] = Ur.m[I][J] + Ui.m[I][J];
+    }
+    Dm.vr[I] = Cc.vr[I] - Sc.vr[I];
+    Us.cr[I] = Ur.cr[I] + Ui.cr[I];
+    Us.rc[I] = Ur.rc[I] + Ui.rc[I];
+  }
+  Dm.s = Cc.s - Sc.s;
+  Us.s = Ur.s + Ui.s;
+  double T1[NC][NC], T2[NC][NC], T3[NC][NC], R1[NC], R2[NC], R3[NC];
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+#pragma unroll
+    for (int J = 0; J < NC; ++J) T1[I][J] = T2[I][J] = T3[I][J] = 0.0;
+    R1[I] = R2[I] = R3[I] = 0.0;
+  }
+#pragma unroll
+  for (int K = 0; K < NC; ++K) {
+#pragma unroll
+    for (int I = 0; I < NC; ++I)
+#pragma unroll
+      for (int J = 0; J < NC; ++J) {
+        T1[I][J] = mfma4(Cc.m[K][I], Ur.m[K][J], T1[I][J]);
+        T2[I][J] = mfma4(Sc.m[K][I], Ui.m[K][J], T2[I][J]);
+        T3[I][J] = mfma4(Dm.m[K][I], Us.m[K][J], T3[I][J]);
+      }
+    // row border: A tile = the border row of the left operand in every row (vr[K]: lane (r, c) holds M[4K+r][D-1] = M[D-1][4K+r])
+#pragma unroll
+    for (int J = 0; J < NC; ++J) {
+      R1[J] = mfma4(Cc.vr[K], Ur.m[K][J], R1[J]);
+      R2[J] = mfma4(Sc.vr[K], Ui.m[K][J], R2[J]);
+      R3[J] = mfma4(Dm.vr[K], Us.m[K][J], R3[J]);
+    }
+  }
+  // column border and corner: partial products with the sum index on r, the three products combined before the reduction
+  double pr[NC], pi[NC], cr_ = 0.0, ci_ = 0.0;
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+    double p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+    for (int K = 0; K < NC; ++K) {
+      p1 = fma(Cc.m[K][I], Ur.cr[K], p1);
+      p2 = fma(Sc.m[K][I], Ui.cr[K], p2);
+      p3 = fma(Dm.m[K][I], Us.cr[K], p3);
+    }
+    pr[I] = p1 + p2;
+    pi[I] = (p3 - p1) + p2;
+    const double c1 = Cc.vr[I] * Ur.cr[I], c2 = Sc.vr[I] * Ui.cr[I], c3 = Dm.vr[I] * Us.cr[I];
+    cr_ += c1 + c2;
+    ci_ += (c3 - c1) + c2;
+  }
+  const double e1 = Cc.s * Ur.s, e2 = Sc.s * Ui.s, e3 = Dm.s * Us.s;
+  const double sr = mfma4(cr_, 1.0, e1 + e2), si = mfma4(ci_, 1.0, (e3 - e1) + e2);
+  double colr[NC], coli[NC], rowr[NC], rowi[NC];
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+    const double q1 = Cc.vr[I] * Ur.s, q2 = Sc.vr[I] * Ui.s, q3 = Dm.vr[I] * Us.s;
+    colr[I] = mfma4(pr[I], 1.0, q1 + q2);
+    coli[I] = mfma4(pi[I], 1.0, (q3 - q1) + q2);
+    // row border: the k = D-1 term on top of the matrix-core sums (every lane holds the row)
+    const double r1 = fma(Cc.s, Ur.rc[I], R1[I]), r2 = fma(Sc.s, Ui.rc[I], R2[I]), r3 = fma(Dm.s, Us.rc[I], R3[I]);
+    rowr[I] = r1 + r2;
+    rowi[I] = (r3 - r1) + r2;
+  }
+#pragma unroll
+  for (int I = 0; I < NC; ++I)
+#pragma unroll
+    for (int J = 0; J < NC; ++J) {
+      const double t1 = fma(Cc.vr[I], Ur.rc[J], T1[I][J]), t2 = fma(Sc.vr[I], Ui.rc[J], T2[I][J]), t3 = fma(Dm.vr[I], Us.rc[J], T3[I][J]);
+      Ur.m[I][J] = t1 + t2;
+      Ui.m[I][J] = (t3 - t1) + t2;
+    }
+#pragma unroll
+  for (int I = 0; I < NC; ++I) {
+    Ur.cr[I] = colr[I];
+    Ui.cr[I] = coli[I];
+    Ur.rc[I] = rowr[I];
+    Ui.rc[I] = rowi[I];
+  }
+  Ur.s = sr;
+  Ui.s = si;
+}
+#else
 template <int NC>
 __device__ __forceinline__ void chain_step8(const SMat<NC>& Cc, const SMat<NC>& Sc, GMat<NC>& Ur, GMat<NC>& Ui, const LanePos& lp,
                                             int tail_lane, int row0_lane) {
@@ -634,14 +872,20 @@ __device__ __forceinline__ void chain_step8(const SMat<NC>& Cc, const SMat<NC>& 
   for (int I = 0; I < NC; ++I) {
     Ur.cr[I] = colr[I];
     Ui.cr[I] = coli[I];
+#if defined(C3P_SD_ABL) && (C3P_SD_ABL & 8)
+    Ur.cc[I] = colr[I], Ui.cc[I] = coli[I], Ur.rc[I] = rowr[I], Ui.rc[I] = rowi[I];  // TIMING-ONLY: no lane swaps in the chain step
+#else
     Ur.cc[I] = __shfl(colr[I], tail_lane);
     Ui.cc[I] = __shfl(coli[I], tail_lane);
     Ur.rc[I] = __shfl(rowr[I], row0_lane);
     Ui.rc[I] = __shfl(rowi[I], row0_lane);
+#endif
   }
   Ur.s = sr;
   Ui.s = si;
 }
+
+#endif
 
 // q = 4 plan: degree 4r, s squarings, from a bound on ||X||_1
 __device__ __forceinline__ void plan_q4(double nrm, int& r, int& s) {
@@ -1077,6 +1321,7 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
               s8_zero(W4);
               mm_s8(W1, W2, W3);
               mm_s8(W2, W2, W4);
+#ifdef C3P_SD_QUADSUM
               s8_finish(W3, swap_lane, tail_lane);
               s8_finish(W4, swap_lane, tail_lane);
               s8_comb<NC, true>(acc, c3p_inv_fact[8], -c3p_inv_fact[10], c3p_inv_fact[12], -c3p_inv_fact[14], W1, W2, W3, lp);
@@ -1098,6 +1343,32 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
               s8_comb<NC, true, true>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], -c3p_inv_fact[6], W1, W2, W3, lp);
               s8_comb<NC, true, true>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7], W1, W2, W3, lp);
               mm_s8x2(W4, acc, Cm, acs, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
+#else
+              // (round 6) the Horner factors B1 = c8 - c10 W + c12 W^2 - c14 W^3 + c16 W^4 are the LEFT operands of the paired
+              // product (everything commutes): they are combined on the 6 registers a product accumulates into (upper core
+              // tiles, r-form border, corner) and completed by ONE lane swap each; W^3 is never a product operand, so it is not
+              // completed at all; W^4 is the shared right operand
+              s8_finish(W4, swap_lane, tail_lane);
+              s8_comb<NC, true, true>(acc, c3p_inv_fact[8], -c3p_inv_fact[10], c3p_inv_fact[12], -c3p_inv_fact[14], W1, W2, W3, lp);
+              s8_comb<NC, true, true>(acs, c3p_inv_fact[9], -c3p_inv_fact[11], c3p_inv_fact[13], -c3p_inv_fact[15], W1, W2, W3, lp);
+#pragma unroll
+              for (int I = 0; I < NC; ++I) {
+#pragma unroll
+                for (int J = I; J < NC; ++J) {
+                  acc.m[I][J] = fma(c3p_inv_fact[16], W4.m[I][J], acc.m[I][J]);
+                  acs.m[I][J] = fma(c3p_inv_fact[17], W4.m[I][J], acs.m[I][J]);
+                }
+                acc.vr[I] = fma(c3p_inv_fact[16], W4.vr[I], acc.vr[I]);
+                acs.vr[I] = fma(c3p_inv_fact[17], W4.vr[I], acs.vr[I]);
+              }
+              acc.s = fma(c3p_inv_fact[16], W4.s, acc.s);
+              acs.s = fma(c3p_inv_fact[17], W4.s, acs.s);
+              s8_finish_lower(acc, swap_lane);
+              s8_finish_lower(acs, swap_lane);
+              s8_comb<NC, true, true>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], -c3p_inv_fact[6], W1, W2, W3, lp);
+              s8_comb<NC, true, true>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7], W1, W2, W3, lp);
+              mm_s8x2r(acc, acs, W4, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
+#endif
             } else {
               mm_s8(W1, W2, W3);  // W^3
               s8_finish(W3, swap_lane, tail_lane);
@@ -1112,11 +1383,25 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
               s8_comb<NC, false, true>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], 0.0, W1, W2, W3, lp);
               mm_s8x2(W3, acc, Cm, acs, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
             }
+#ifdef C3P_SD_QUADSUM
             s8_finish(Cm, swap_lane, tail_lane);
             s8_finish(Sp, swap_lane, tail_lane);
             s8_zero(acc);
             mm_s8(Y, Sp, acc);  // acc = sin Y
             s8_finish(acc, swap_lane, tail_lane);
+#else
+            // cos Y, sin Y / Y and sin Y are LEFT operands from here on (sin Y = (sin Y / Y) Y, the chain step): lower tiles only;
+            // their c-form borders are only fetched for the squarings and the first slice of a segment
+            s8_finish_lower(Cm, swap_lane);
+            s8_finish_lower(Sp, swap_lane);
+            s8_zero(acc);
+            mm_s8(Sp, Y, acc);  // acc = sin Y
+            s8_finish_lower(acc, swap_lane);
+            if (ps18 > 0 || t == 0) {
+              s8_finish_vc(Cm, tail_lane);
+              s8_finish_vc(acc, tail_lane);
+            }
+#endif
             // squarings: cos 2Y = (C - S)(C + S), sin 2Y = 2 S C
             for (int it = 0; it < ps18; ++it) {
               SM Dm, Sm, C2, SC;
@@ -1168,7 +1453,19 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
               mus_r = mu_r;
               mus_i = c3p_phase_add(0.0, mu_i);
             } else {
+#if defined(C3P_SD_ABL) && (C3P_SD_ABL & 2)
+              // TIMING-ONLY (wrong results): no chain product
+#pragma unroll
+              for (int I = 0; I < NC; ++I) {
+#pragma unroll
+                for (int J = 0; J < NC; ++J) Gr.m[I][J] += Cm.m[I][J], Gi.m[I][J] -= acc.m[I][J];
+                Gr.cr[I] += Cm.vr[I], Gr.cc[I] += Cm.vc[I], Gr.rc[I] += Cm.vc[I];
+                Gi.cr[I] -= acc.vr[I], Gi.cc[I] -= acc.vc[I], Gi.rc[I] -= acc.vc[I];
+              }
+              Gr.s += Cm.s, Gi.s -= acc.s;
+#else
               chain_step8(Cm, acc, Gr, Gi, lp, tail_lane, row0_lane);
+#endif
               mus_r += mu_r;
               mus_i = c3p_phase_add(mus_i, mu_i);
             }
@@ -1835,8 +2132,9 @@ hipError_t launch_chain_t(const SmallArgs& A, hipStream_t st) {
       // a pair's slices in per mille, default 640; 500 = equal segments).
       SmallArgs A2 = A;
       if (nW == 8 && A.N >= 4 * A.S) {
-        // (measured optimum 640 with the padded tiles, 660 with the core + border form of D = 5, 9: tools/sweep_split81.py)
-        int skew = ((D == 9 || D == 5) && !c3p_opt_on(C3P_OPT_no_split81)) ? 660 : 640;
+        // (measured optimum 640 with the padded tiles, 660 with the core + border form of D = 5, 9, 680 with its border sums on the
+        // matrix cores -- round 6: tools/sweep_split81.py, gpurun_out/r06/sweep_skew_ones.txt)
+        int skew = ((D == 9 || D == 5) && !c3p_opt_on(C3P_OPT_no_split81)) ? 680 : 640;
         if (c3p_opt(C3P_OPT_mw_skew) >= 0) skew = (int)c3p_opt(C3P_OPT_mw_skew);
         if (skew > 500 && skew < 900) {
           const int h = A.S / 2;
