@@ -10,7 +10,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libc3prop.so")
+# (C3P_LIB: an alternative build of the library -- A/B timing of kernel variants, tools/ab_build*.sh; never set in production)
+LIB_PATH = os.path.abspath(os.environ["C3P_LIB"]) if os.environ.get("C3P_LIB") else os.path.join(_HERE, "libc3prop.so")
 
 # flags (mirror include/c3prop.h)
 HOST_PTRS = 0x1

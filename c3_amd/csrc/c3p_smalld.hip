@@ -454,6 +454,12 @@ __device__ __forceinline__ void s8_zero(SMat<NC>& a) {
 // C += A B for symmetric commuting A, B (upper core tiles, vr, s of C; s8_finish completes the operand form of C)
 template <int NC>
 __device__ __forceinline__ void mm_s8(const SMat<NC>& a, const SMat<NC>& b, SMat<NC>& c) {
+  // (the rank-1 term of the border goes into the accumulators BEFORE the matrix instructions: a vector instruction that reads a
+  // matrix result waits for the whole instruction, ~45 cycles; the other way round costs two wait states)
+#pragma unroll
+  for (int I = 0; I < NC; ++I)
+#pragma unroll
+    for (int J = I; J < NC; ++J) c.m[I][J] = fma(a.vr[I], b.vc[J], c.m[I][J]);
 #pragma unroll
   for (int K = 0; K < NC; ++K)
 #pragma unroll
@@ -471,14 +477,17 @@ __device__ __forceinline__ void mm_s8(const SMat<NC>& a, const SMat<NC>& b, SMat
 #pragma unroll
   for (int I = 0; I < NC; ++I) c.vr[I] = mfma4(t[I], 1.0, fma(a.vr[I], b.s, c.vr[I]));
   c.s = mfma4(cs, 1.0, fma(a.s, b.s, c.s));
-#pragma unroll
-  for (int I = 0; I < NC; ++I)
-#pragma unroll
-    for (int J = I; J < NC; ++J) c.m[I][J] = fma(a.vr[I], b.vc[J], c.m[I][J]);
 }
 // two products with one left operand, interleaved (C1 += A B1, C2 += A B2)
 template <int NC>
 __device__ __forceinline__ void mm_s8x2(const SMat<NC>& a, const SMat<NC>& b1, SMat<NC>& c1, const SMat<NC>& b2, SMat<NC>& c2) {
+#pragma unroll
+  for (int I = 0; I < NC; ++I)
+#pragma unroll
+    for (int J = I; J < NC; ++J) {
+      c1.m[I][J] = fma(a.vr[I], b1.vc[J], c1.m[I][J]);
+      c2.m[I][J] = fma(a.vr[I], b2.vc[J], c2.m[I][J]);
+    }
 #pragma unroll
   for (int K = 0; K < NC; ++K)
 #pragma unroll
@@ -507,13 +516,6 @@ __device__ __forceinline__ void mm_s8x2(const SMat<NC>& a, const SMat<NC>& b1, S
   }
   c1.s = mfma4(cs1, 1.0, fma(a.s, b1.s, c1.s));
   c2.s = mfma4(cs2, 1.0, fma(a.s, b2.s, c2.s));
-#pragma unroll
-  for (int I = 0; I < NC; ++I)
-#pragma unroll
-    for (int J = I; J < NC; ++J) {
-      c1.m[I][J] = fma(a.vr[I], b1.vc[J], c1.m[I][J]);
-      c2.m[I][J] = fma(a.vr[I], b2.vc[J], c2.m[I][J]);
-    }
 }
 #else
 // C += A B for symmetric commuting A, B (upper core tiles, vr, s of C; s8_finish completes the operand form of C)
@@ -620,6 +622,13 @@ __device__ __forceinline__ void s8_finish_vc(SMat<NC>& a, int tail_lane) {
 template <int NC>
 __device__ __forceinline__ void mm_s8x2r(const SMat<NC>& a1, const SMat<NC>& a2, const SMat<NC>& b, SMat<NC>& c1, SMat<NC>& c2) {
 #pragma unroll
+  for (int I = 0; I < NC; ++I)
+#pragma unroll
+    for (int J = I; J < NC; ++J) {
+      c1.m[I][J] = fma(a1.vr[I], b.vc[J], c1.m[I][J]);
+      c2.m[I][J] = fma(a2.vr[I], b.vc[J], c2.m[I][J]);
+    }
+#pragma unroll
   for (int K = 0; K < NC; ++K)
 #pragma unroll
     for (int I = 0; I < NC; ++I)
@@ -647,13 +656,6 @@ __device__ __forceinline__ void mm_s8x2r(const SMat<NC>& a1, const SMat<NC>& a2,
   }
   c1.s = mfma4(cs1, 1.0, fma(a1.s, b.s, c1.s));
   c2.s = mfma4(cs2, 1.0, fma(a2.s, b.s, c2.s));
-#pragma unroll
-  for (int I = 0; I < NC; ++I)
-#pragma unroll
-    for (int J = I; J < NC; ++J) {
-      c1.m[I][J] = fma(a1.vr[I], b.vc[J], c1.m[I][J]);
-      c2.m[I][J] = fma(a2.vr[I], b.vc[J], c2.m[I][J]);
-    }
 }
 #endif
 // out = c0 I + c1 W1 + c2 W2 (+ c3 W3), every part (operands are complete: the combination is too); ACCUM: only what a
@@ -661,24 +663,22 @@ __device__ __forceinline__ void mm_s8x2r(const SMat<NC>& a1, const SMat<NC>& a2,
 template <int NC, bool WITH3, bool ACCUM = false>
 __device__ __forceinline__ void s8_comb(SMat<NC>& out, double c0, double c1, double c2, double c3, const SMat<NC>& W1, const SMat<NC>& W2,
                                         const SMat<NC>& W3, const LanePos& lp) {
-  auto lc = [&](double x1, double x2, double x3) {
-    double v = c1 * x1;
+  // (the c0 I term rides in as the addend of the first multiply-add: no separate add on the diagonal tiles and the corner)
+  auto lc = [&](double x1, double x2, double x3, double add) {
+    double v = fma(c1, x1, add);
     v = fma(c2, x2, v);
     if constexpr (WITH3) v = fma(c3, x3, v);
     return v;
   };
+  const double dg = (lp.r == lp.c) ? c0 : 0.0;
 #pragma unroll
   for (int I = 0; I < NC; ++I) {
 #pragma unroll
-    for (int J = ACCUM ? I : 0; J < NC; ++J) {
-      double v = lc(W1.m[I][J], W2.m[I][J], W3.m[I][J]);
-      if (I == J) v += (lp.r == lp.c) ? c0 : 0.0;
-      out.m[I][J] = v;
-    }
-    out.vr[I] = lc(W1.vr[I], W2.vr[I], W3.vr[I]);
-    if constexpr (!ACCUM) out.vc[I] = lc(W1.vc[I], W2.vc[I], W3.vc[I]);
+    for (int J = ACCUM ? I : 0; J < NC; ++J) out.m[I][J] = lc(W1.m[I][J], W2.m[I][J], W3.m[I][J], I == J ? dg : 0.0);
+    out.vr[I] = lc(W1.vr[I], W2.vr[I], W3.vr[I], 0.0);
+    if constexpr (!ACCUM) out.vc[I] = lc(W1.vc[I], W2.vc[I], W3.vc[I], 0.0);
   }
-  out.s = lc(W1.s, W2.s, W3.s) + c0;
+  out.s = lc(W1.s, W2.s, W3.s, c0);
 }
 
 
@@ -1022,10 +1022,18 @@ __device__ __forceinline__ void build_tables(const SmallArgs& A, int sample, dou
         remax = fmax(remax, fabs(gr[q]));
       }
     }
+    // column sums of |G| (the 1-norm).  Round 6: plain sqrt(a^2 + b^2) on unrolled, independent LDS reads instead of D
+    // dependent hypot() calls (the elements are dt x Hamiltonian entries: no overflow to guard) -- this function sits on the
+    // critical path of every workgroup's prologue
     wave_sync();
     double cs = 0.0;
-    if (lane < D)
-      for (int i = 0; i < D; ++i) cs += hypot(out[(2 * i) * W + lane], out[(2 * i + 1) * W + lane]);
+    if (lane < D) {
+      double ar[D], ai[D];
+#pragma unroll
+      for (int i = 0; i < D; ++i) ar[i] = out[(2 * i) * W + lane], ai[i] = out[(2 * i + 1) * W + lane];
+#pragma unroll
+      for (int i = 0; i < D; ++i) cs += sqrt(fma(ar[i], ar[i], ai[i] * ai[i]));
+    }
     const double nrm = wave_max64(cs);
     // the real fast path also needs Y = -Im G symmetric (Hermitian input).  Dressed operators V^T H V are
     // symmetric only to rounding (measured 5e-16 relative), so asymmetry below 1e-14 ||G|| counts as none;
