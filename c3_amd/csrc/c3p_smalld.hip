@@ -1882,6 +1882,9 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
   }
   // ---- segment result ----
   SD_TICK(tk2);
+#ifdef C3P_SD_TIMING
+  if (MW && blockIdx.x == 7 && lane == 0) printf("sd wave %d: loop ends at %lld (100 MHz ticks after the wave's start), prologue %lld, slices %d\n", wv, tk2 - tk0, tk1 - tk0, tmax);
+#endif
   if constexpr (!GIVEN) {
     if (A.fuse) {
       // (1) fold the wave's four consecutive segments: W = U3 U2 U1 U0 (later segment on the left)
@@ -2140,9 +2143,10 @@ hipError_t launch_chain_t(const SmallArgs& A, hipStream_t st) {
       // a pair's slices in per mille, default 640; 500 = equal segments).
       SmallArgs A2 = A;
       if (nW == 8 && A.N >= 4 * A.S) {
-        // (measured optimum 640 with the padded tiles, 660 with the core + border form of D = 5, 9, 680 with its border sums on the
-        // matrix cores -- round 6: tools/sweep_split81.py, gpurun_out/r06/sweep_skew_ones.txt)
-        int skew = ((D == 9 || D == 5) && !c3p_opt_on(C3P_OPT_no_split81)) ? 680 : 640;
+        // (measured optimum 640 with the padded tiles, 660 with the core + border form of D = 5, 9, 700 with its border sums on the
+        // matrix cores -- round 6: tools/sweep_split81.py, profiles/r06/sweep_skew.txt; one slice of the long segments moves the
+        // two waves of a SIMD by 7 us against each other, so the optimum is sharp)
+        int skew = ((D == 9 || D == 5) && !c3p_opt_on(C3P_OPT_no_split81)) ? 700 : 640;
         if (c3p_opt(C3P_OPT_mw_skew) >= 0) skew = (int)c3p_opt(C3P_OPT_mw_skew);
         if (skew > 500 && skew < 900) {
           const int h = A.S / 2;

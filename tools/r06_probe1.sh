@@ -15,7 +15,7 @@ for _ in range(30): x @ x
 torch.cuda.synchronize()
 w = make_workload(2, B=256)
 h0, hks, sig, ph = t(w.h0), t(w.hks), t(w.signals), t(w.fr_phase)
-for _ in range(12):
+for _ in range(6):
     prop.propagate_batch(h0, hks, sig, w.dt, fr_phase=ph)
 torch.cuda.synchronize()
 PY
