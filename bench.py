@@ -38,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP64_TFLOPS = 78.6  # MI355X dense fp64 (vector = matrix; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 # thresholds of the reference's expm (tf.linalg.expm, Higham 2005 Pade 3/5/7/9/13 chosen from ||A||_1)
 _PADE_THETA = (1.495585217958292e-2, 2.539398330063230e-1, 9.504178996162932e-1, 2.097847961257068, 5.371920351148152)
@@ -610,6 +610,8 @@ def main():
                 "pmc_profile": f"profiles/{PROFILE_ROUND}/pmc.json" if pmc_exact else None,
                 "pmc_exact_match": pmc_exact,
                 "pmc_avg_launch_us": ent.get("avg_launch_us") if pmc_exact else None,
+                "pmc_median_launch_us": ent.get("median_launch_us") if pmc_exact else None,
+                "issue_busy_model": ent.get("issue_busy_model") if pmc_exact else None,
                 "kernel": f"chain kernel ({kernel_name})",
                 "device_ms_per_step": device_ms_per_step,
                 "note": "fp64 compute-bound path. frac = USEFUL issued flops / device time per step (HIP events over the timed region, launch gaps included) / dense fp64 peak: flops the kernel really issues (PMC) with the zero padding of its MFMA tiles taken out; null unless the committed PMC profile is of exactly this kernel build, batch and slice count (pmc_exact_match). frac_algorithmic = SURVEY 8d's figure (the reference's complex Pade order per slice + product tree) over the same time: a method that needs fewer flops than the reference's (real cos / sin evaluation of real Hamiltonians; Lindblad chains in real arithmetic in the Hermitian basis) exceeds the hardware fraction there and can exceed 1; it is an algorithm credit, not a hardware one. traffic = HBM-side bytes per launch from the same PMC passes",

@@ -36,6 +36,7 @@ SIGNATURES = {
     "c3p_device_count": (_i, []),
     "c3p_last_error": (C.c_char_p, []),
     "c3p_last_kernel": (_i, []),
+    "c3p_last_kernel_detail": (_i, [C.c_char_p, _i]),
     "c3p_set_profiling": (_i, [_i]),
     "c3p_set_option": (_i, [C.c_char_p, C.c_char_p]),
     "c3p_get_option": (C.c_long, [C.c_char_p]),
@@ -108,6 +109,15 @@ def require_gpu() -> None:
 
 def last_kernel() -> str:
     return KERNEL_NAMES.get(load().c3p_last_kernel(), "?")
+
+
+def last_kernel_detail() -> str:
+    """"file: kernel<...> xN; ..." -- every kernel the last compute call of this thread launched (c3p_last_kernel_detail)."""
+    lib = load()
+    n = lib.c3p_last_kernel_detail(None, 0)
+    buf = C.create_string_buffer(n + 1)
+    lib.c3p_last_kernel_detail(buf, n + 1)
+    return buf.value.decode()
 
 
 def set_option(name: str, value) -> None:

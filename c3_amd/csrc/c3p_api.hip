@@ -17,6 +17,9 @@
 #include "c3p_smalld.h"
 #include "c3p_smallr.h"
 #include "c3p_midd.h"
+#include <cxxabi.h>
+#include <cstring>
+
 #include "c3p_bigd.h"
 #include "c3p_regd.h"
 #include <atomic>
@@ -28,6 +31,14 @@ namespace {
 
 thread_local std::string g_err;
 thread_local int g_last_kernel = C3P_KERNEL_NONE;
+// launch log of the current API call (c3p_note_launch / c3p_last_kernel_detail)
+struct LaunchNote {
+  const void* fn;
+  const char* file;
+  int count;
+};
+thread_local LaunchNote g_notes[48];
+thread_local int g_nnotes = 0;
 thread_local hipStream_t g_call_stream = nullptr;  // stream of the call in flight (capture check on workspace growth)
 thread_local bool g_dry = false;  // c3p_reserve: run the planning and size the workspace, launch nothing
 
@@ -127,6 +138,7 @@ struct WsLock {
     w->mu.lock();
     locked = true;
     g_call_stream = stream;
+    if (order) g_nnotes = 0;  // a compute call starts a new launch log (c3p_last_kernel_ms looks with order = false)
     // a capturing stream takes no dependency on work outside its graph: the caller orders other streams before the capture
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) order = false;
@@ -2028,6 +2040,15 @@ long c3p_opt(C3pOption o) {
   return g_opt_val[o].load(std::memory_order_relaxed);
 }
 
+void c3p_note_launch(const void* host_fn, const char* file) {
+  for (int i = 0; i < g_nnotes; ++i)
+    if (g_notes[i].fn == host_fn) {
+      ++g_notes[i].count;
+      return;
+    }
+  if (g_nnotes < (int)(sizeof(g_notes) / sizeof(g_notes[0]))) g_notes[g_nnotes++] = LaunchNote{host_fn, file, 1};
+}
+
 extern "C" {
 
 int c3p_version(void) { return 1; }
@@ -2043,6 +2064,45 @@ int c3p_device_count(void) {
 
 const char* c3p_last_error(void) { return g_err.c_str(); }
 int c3p_last_kernel(void) { return g_last_kernel; }
+
+int c3p_last_kernel_detail(char* buf, int cap) {
+  std::string out;
+  for (int i = 0; i < g_nnotes; ++i) {
+    const LaunchNote& n = g_notes[i];
+    const char* raw = hipKernelNameRefByPtr(n.fn, nullptr);
+    (void)hipGetLastError();
+    std::string name = raw ? raw : "?";
+    int status = 1;
+    char* dm = abi::__cxa_demangle(name.c_str(), nullptr, nullptr, &status);
+    if (status == 0 && dm) name = dm;
+    free(dm);
+    // "void (anonymous namespace)::kernel<...>(Args)" -> "kernel<...>"
+    size_t p0 = name.rfind(')');
+    if (p0 != std::string::npos) {  // drop the parameter list: the matching '(' of the LAST ')'
+      int depth = 0;
+      for (size_t q = p0 + 1; q-- > 0;) {
+        if (name[q] == ')') ++depth;
+        else if (name[q] == '(' && --depth == 0) {
+          name.erase(q);
+          break;
+        }
+      }
+    }
+    const std::string anon = "(anonymous namespace)::";
+    for (size_t q; (q = name.find(anon)) != std::string::npos;) name.erase(q, anon.size());
+    if (name.rfind("void ", 0) == 0) name.erase(0, 5);
+    const char* base = strrchr(n.file, '/');
+    if (!out.empty()) out += "; ";
+    out += std::string(base ? base + 1 : n.file) + ": " + name;
+    if (n.count > 1) out += " x" + std::to_string(n.count);
+  }
+  if (buf && cap > 0) {
+    const size_t m = std::min(out.size(), (size_t)cap - 1);
+    memcpy(buf, out.data(), m);
+    buf[m] = 0;
+  }
+  return (int)out.size();
+}
 
 int c3p_set_option(const char* name, const char* value) {
   if (!name) return fail("c3p_set_option: null name");

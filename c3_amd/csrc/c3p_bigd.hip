@@ -497,7 +497,7 @@ hipError_t launch_b(const MidArgs& A, double* arena, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(BW * 64), lds, st, A, arena);
+    C3P_LAUNCH(kern, dim3(grid), dim3(BW * 64), lds, st, A, arena);
     return hipGetLastError();
   };
   if (A.dUs_out) return go(bigd_chain_kernel<NIG, NJ, W, true>);
@@ -535,7 +535,7 @@ size_t c3p_bigd_lds_bytes(int Dm, int K, int Lmax) {
 
 hipError_t c3p_launch_rowphase(cplx* U, const double* phase, int B, int Dm, hipStream_t st) {
   const long total = (long)B * Dm * Dm;
-  hipLaunchKernelGGL(rowphase_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, U, phase, Dm, total);
+  C3P_LAUNCH(rowphase_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, U, phase, Dm, total);
   return hipGetLastError();
 }
 

@@ -199,3 +199,15 @@ __constant__ double c3p_inv_fact[22] = {
     1.0 / 2432902008176640000.0,
     1.0 / 51090942171709440000.0,
 };
+
+// Launch log of the current API call of this thread (c3p_last_kernel_detail; INTEGRATION.md's dispatch table is generated from
+// it by tools/dispatch_table.py): every kernel launch of the library goes through C3P_LAUNCH, which notes the kernel's host
+// function and the source file before handing over to hipLaunchKernelGGL.  A pointer store per launch; names are resolved
+// (hipKernelNameRefByPtr + demangling) only when the log is read.
+void c3p_note_launch(const void* host_fn, const char* file);
+#define C3P_LAUNCH(kern, ...)                                                   \
+  do {                                                                          \
+    c3p_note_launch(reinterpret_cast<const void*>(&*(kern)), __FILE__);         \
+    hipLaunchKernelGGL(kern, __VA_ARGS__);                                      \
+  } while (0)
+

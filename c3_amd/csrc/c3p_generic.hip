@@ -546,21 +546,21 @@ hipError_t c3p_launch_chain_generic(const ChainArgs& A, bool global_scratch, hip
   const int threads = c3p_generic_threads(A.Dm);
   const dim3 grid((unsigned)((long)A.B * A.S));
   if (global_scratch) {
-    hipLaunchKernelGGL(chain_kernel<true>, grid, dim3(threads), 0, st, A);
+    C3P_LAUNCH(chain_kernel<true>, grid, dim3(threads), 0, st, A);
   } else {
     const size_t lds = c3p_generic_lds_bytes(A.Dm);
     // per launch: the attribute is per DEVICE, and one process may drive several GPUs
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(chain_kernel<false>, grid, dim3(threads), lds, st, A);
+    C3P_LAUNCH(chain_kernel<false>, grid, dim3(threads), lds, st, A);
   }
   return hipGetLastError();
 }
 
 hipError_t c3p_launch_clp(const cplx* col, int C, int D, cplx* clp, hipStream_t st) {
   const long total = (long)D * D * D * D;
-  hipLaunchKernelGGL(clp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, col, C, D,
+  C3P_LAUNCH(clp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, col, C, D,
                      clp);
   return hipGetLastError();
 }
@@ -570,7 +570,7 @@ hipError_t c3p_launch_kron(const cplx* A, const cplx* Bm, int n, int Da, int Db,
   const long Dm = (long)Da * Db;
   const long total = (long)n * Dm * Dm;
   if (total == 0) return hipSuccess;
-  hipLaunchKernelGGL(kron_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, A, Bm, Da,
+  C3P_LAUNCH(kron_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, A, Bm, Da,
                      Db, which, total, out);
   return hipGetLastError();
 }
@@ -582,15 +582,15 @@ int c3p_infid_blocks(int B) {
 hipError_t c3p_launch_infid(const cplx* U, int B, int D, const int* rows, int L, const cplx* ideal, int kind, double* infid,
                             double* partial, double* sum_out, hipStream_t st) {
   const int nb = c3p_infid_blocks(B);
-  hipLaunchKernelGGL(infid_kernel, dim3((unsigned)nb), dim3(256), 0, st, U, B, D, rows, L, ideal, kind, infid, partial);
-  if (sum_out) hipLaunchKernelGGL(infid_sum_kernel, dim3(1), dim3(64), 0, st, partial, nb, B, sum_out);
+  C3P_LAUNCH(infid_kernel, dim3((unsigned)nb), dim3(256), 0, st, U, B, D, rows, L, ideal, kind, infid, partial);
+  if (sum_out) C3P_LAUNCH(infid_sum_kernel, dim3(1), dim3(64), 0, st, partial, nb, B, sum_out);
   return hipGetLastError();
 }
 
 hipError_t c3p_launch_overlap(const cplx* U, int B, int D, const int* rows, int L, const cplx* ideal,
                               cplx* out, hipStream_t st) {
   if (B == 0) return hipSuccess;
-  hipLaunchKernelGGL(overlap_kernel, dim3((unsigned)B), dim3(64), 0, st, U, D, rows, L, ideal, out);
+  C3P_LAUNCH(overlap_kernel, dim3((unsigned)B), dim3(64), 0, st, U, D, rows, L, ideal, out);
   return hipGetLastError();
 }
 
@@ -598,10 +598,10 @@ hipError_t c3p_launch_hmeta(const cplx* hs, long bstride, long nmat, int N, int 
                             hipStream_t st) {
   if (nmat == 0) return hipSuccess;
   if (D <= 16) {
-    hipLaunchKernelGGL(hmeta_small_kernel, dim3((unsigned)((nmat + 3) / 4)), dim3(256), 0, st, hs, bstride, N, D, cr, ci, meta,
+    C3P_LAUNCH(hmeta_small_kernel, dim3((unsigned)((nmat + 3) / 4)), dim3(256), 0, st, hs, bstride, N, D, cr, ci, meta,
                        nmat);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(hmeta_kernel, dim3((unsigned)nmat), dim3(64), 0, st, hs, bstride, N, D, cr, ci, meta);
+  C3P_LAUNCH(hmeta_kernel, dim3((unsigned)nmat), dim3(64), 0, st, hs, bstride, N, D, cr, ci, meta);
   return hipGetLastError();
 }

@@ -736,7 +736,7 @@ hipError_t launch_one(KT kern, unsigned grid, const GradArgs& A, bool global_scr
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), lds, st, A);
+  C3P_LAUNCH(kern, dim3(grid), dim3(nt), lds, st, A);
   return hipGetLastError();
 }
 }  // namespace
@@ -778,7 +778,7 @@ hipError_t launch_general(KT kern, unsigned grid, const GradArgs& A, bool global
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), lds, st, A);
+  C3P_LAUNCH(kern, dim3(grid), dim3(nt), lds, st, A);
   return hipGetLastError();
 }
 }  // namespace
@@ -792,7 +792,7 @@ hipError_t c3p_launch_grad_scan_general(const GradArgs& A, bool global_scratch, 
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)A.B, 2), dim3(c3p_grad_threads(A.D)), lds3, st, A);
+    C3P_LAUNCH(kern, dim3((unsigned)A.B, 2), dim3(c3p_grad_threads(A.D)), lds3, st, A);
     return hipGetLastError();
   }
   (void)global_scratch;
@@ -805,14 +805,14 @@ hipError_t c3p_launch_grad_bwd_general(const GradArgs& A, bool global_scratch, h
 hipError_t c3p_launch_lind_generators(const cplx* h0, long h0_bstride, const cplx* hks, long hks_bstride, const cplx* clp, int nb,
                                       int K, int D, cplx* out, hipStream_t st) {
   const long nel = (long)D * D * D * D;
-  hipLaunchKernelGGL(lind_gen_kernel, dim3((unsigned)((nel + 255) / 256), (unsigned)nb, (unsigned)(K + 1)), dim3(256), 0, st, h0, h0_bstride,
+  C3P_LAUNCH(lind_gen_kernel, dim3((unsigned)((nel + 255) / 256), (unsigned)nb, (unsigned)(K + 1)), dim3(256), 0, st, h0, h0_bstride,
                      hks, hks_bstride, clp, K, D, out);
   return hipGetLastError();
 }
 
 hipError_t c3p_launch_lind_slice_generators(const cplx* hs, long hs_bstride, const cplx* clp, int B, int N, int D, cplx* out, hipStream_t st) {
   const long nel = (long)D * D * D * D;
-  hipLaunchKernelGGL(lind_slice_gen_kernel, dim3((unsigned)((long)B * N), (unsigned)((nel + 255) / 256)), dim3(256), 0, st, hs, hs_bstride, clp, N,
+  C3P_LAUNCH(lind_slice_gen_kernel, dim3((unsigned)((long)B * N), (unsigned)((nel + 255) / 256)), dim3(256), 0, st, hs, hs_bstride, clp, N,
                      D, out);
   return hipGetLastError();
 }

@@ -1680,7 +1680,7 @@ hipError_t md_go(Kern kern, const MidArgs& A, size_t bytes, hipStream_t st) {
                                        (int)bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)((long)A.B * A.S)), dim3(256), bytes, st, A);
+  C3P_LAUNCH(kern, dim3((unsigned)((long)A.B * A.S)), dim3(256), bytes, st, A);
   return hipGetLastError();
 }
 
@@ -3003,7 +3003,7 @@ hipError_t launch_grad_t(const MidGradArgs& A, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)((long)A.B * A.S)), dim3(256), lds, st, A);
+  C3P_LAUNCH(kern, dim3((unsigned)((long)A.B * A.S)), dim3(256), lds, st, A);
   return hipGetLastError();
 }
 
@@ -3017,7 +3017,7 @@ hipError_t launch_grad_general_x(const MidGradArgs& A, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)((long)A.B * A.S)), dim3(256), lds, st, A);
+  C3P_LAUNCH(kern, dim3((unsigned)((long)A.B * A.S)), dim3(256), lds, st, A);
   return hipGetLastError();
 }
 template <int NIG, int NJ, int W>
@@ -3038,7 +3038,7 @@ hipError_t launch_grad_real_t(const MidGradArgs& A, hipStream_t st, bool* launch
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)((long)A.B * A.S)), dim3(256), lds, st, A);
+  C3P_LAUNCH(kern, dim3((unsigned)((long)A.B * A.S)), dim3(256), lds, st, A);
   *launched = true;
   return hipGetLastError();
 }
@@ -3101,7 +3101,7 @@ hipError_t c3p_launch_midd_chain(const MidArgs& A, hipStream_t st) {
 }
 
 hipError_t c3p_launch_midd_prep(const MidPrepArgs& P, int nsamp, hipStream_t st) {
-  hipLaunchKernelGGL(midd_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K))), dim3(256), 0, st, P);
+  C3P_LAUNCH(midd_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K))), dim3(256), 0, st, P);
   return hipGetLastError();
 }
 #endif

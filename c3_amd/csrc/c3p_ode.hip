@@ -210,14 +210,14 @@ hipError_t c3p_launch_ode(const OdeArgs& A, bool global_scratch, hipStream_t st)
   if (threads > 256) threads = 256;
   if (threads < 64) threads = 64;
   if (global_scratch) {
-    hipLaunchKernelGGL(ode_kernel<true>, dim3(A.B), dim3(threads), 0, st, A);
+    C3P_LAUNCH(ode_kernel<true>, dim3(A.B), dim3(threads), 0, st, A);
   } else {
     const size_t lds = c3p_ode_elems(A.D, A.M, A.C) * sizeof(cplx);
     // per launch: the attribute is per DEVICE, and one process may drive several GPUs
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ode_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ode_kernel<false>, dim3(A.B), dim3(threads), lds, st, A);
+    C3P_LAUNCH(ode_kernel<false>, dim3(A.B), dim3(threads), lds, st, A);
   }
   return hipGetLastError();
 }

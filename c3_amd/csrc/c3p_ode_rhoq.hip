@@ -638,7 +638,7 @@ hipError_t launch_rho4(const OdeArgs& A, hipStream_t st) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((ode_rhoq_kernel<NT, SOLVER, MODE, HERM>), dim3((unsigned)(A.B * (A.seg_count > 0 ? A.seg_count : 1))), dim3(64 * NT * NT), lds,
+  C3P_LAUNCH((ode_rhoq_kernel<NT, SOLVER, MODE, HERM>), dim3((unsigned)(A.B * (A.seg_count > 0 ? A.seg_count : 1))), dim3(64 * NT * NT), lds,
                      st, A);
   return hipGetLastError();
 }

@@ -656,8 +656,8 @@ int pad_dim(int D) {
 
 template <int DP, int KT, int SOLVER>
 hipError_t launch_vec3(const OdeArgs& A, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL((ode_vec_kernel<DP, KT, SOLVER, true>), grid, dim3(64), 0, st, A);
-  hipLaunchKernelGGL((ode_vec_kernel<DP, KT, SOLVER, false>), grid, dim3(64), 0, st, A);
+  C3P_LAUNCH((ode_vec_kernel<DP, KT, SOLVER, true>), grid, dim3(64), 0, st, A);
+  C3P_LAUNCH((ode_vec_kernel<DP, KT, SOLVER, false>), grid, dim3(64), 0, st, A);
   return hipGetLastError();
 }
 template <int DP, int KT>
@@ -673,10 +673,10 @@ template <int DP>
 hipError_t launch_vec1(const OdeArgs& A, dim3 grid, hipStream_t st) {
   if (A.hs) {  // supplied Hamiltonians: one (complex) instance per solver
     switch (A.solver) {
-      case 0: hipLaunchKernelGGL((ode_vec_kernel<DP, 2, 0, false, true>), grid, dim3(64), 0, st, A); break;
-      case 1: hipLaunchKernelGGL((ode_vec_kernel<DP, 2, 1, false, true>), grid, dim3(64), 0, st, A); break;
-      case 2: hipLaunchKernelGGL((ode_vec_kernel<DP, 2, 2, false, true>), grid, dim3(64), 0, st, A); break;
-      default: hipLaunchKernelGGL((ode_vec_kernel<DP, 2, 3, false, true>), grid, dim3(64), 0, st, A); break;
+      case 0: C3P_LAUNCH((ode_vec_kernel<DP, 2, 0, false, true>), grid, dim3(64), 0, st, A); break;
+      case 1: C3P_LAUNCH((ode_vec_kernel<DP, 2, 1, false, true>), grid, dim3(64), 0, st, A); break;
+      case 2: C3P_LAUNCH((ode_vec_kernel<DP, 2, 2, false, true>), grid, dim3(64), 0, st, A); break;
+      default: C3P_LAUNCH((ode_vec_kernel<DP, 2, 3, false, true>), grid, dim3(64), 0, st, A); break;
     }
     return hipGetLastError();
   }
@@ -688,7 +688,7 @@ hipError_t launch_mat3(const OdeArgs& A, const OdeRowAux& X, dim3 grid, size_t l
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ode_mat_kernel<DP, KT, REALH>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((ode_mat_kernel<DP, KT, REALH>), grid, dim3(64), lds, st, A, X);
+  C3P_LAUNCH((ode_mat_kernel<DP, KT, REALH>), grid, dim3(64), lds, st, A, X);
   return hipGetLastError();
 }
 template <int DP>
@@ -723,7 +723,7 @@ bool c3p_ode_row_supported(const OdeArgs& A) {
 }
 
 hipError_t c3p_launch_ode_assemble_hs(const OdeArgs& A, cplx* out, hipStream_t st) {
-  hipLaunchKernelGGL(ode_assemble_hs_kernel, dim3((unsigned)((long)A.N * A.B)), dim3(A.D * A.D >= 256 ? 256 : 64), 0, st, A.h0, A.hks,
+  C3P_LAUNCH(ode_assemble_hs_kernel, dim3((unsigned)((long)A.N * A.B)), dim3(A.D * A.D >= 256 ? 256 : 64), 0, st, A.h0, A.hks,
                      A.signals, A.K, A.N, A.D, out);
   return hipGetLastError();
 }
@@ -756,7 +756,7 @@ hipError_t c3p_launch_ode_row(const OdeArgs& A, void* aux, hipStream_t st) {
     cplx* colpad = base;
     cplx* coladj = base + (size_t)A.C * one;
     cplx* gpad = base + (size_t)2 * A.C * one;
-    hipLaunchKernelGGL(ode_colprep_kernel, dim3(1), dim3(256), 0, st, A.col_ops, A.C, A.D, DP, colpad, coladj, gpad);
+    C3P_LAUNCH(ode_colprep_kernel, dim3(1), dim3(256), 0, st, A.col_ops, A.C, A.D, DP, colpad, coladj, gpad);
     X.colpad = colpad;
     X.coladj = coladj;
     X.gpad = gpad;
@@ -842,16 +842,16 @@ __global__ void __launch_bounds__(64) ode_starts_kernel(const cplx* maps, const 
 }  // namespace
 
 hipError_t c3p_launch_ode_starts(const cplx* maps, const cplx* init, long init_bstride, cplx* starts, int B, int S, int D, hipStream_t st) {
-  hipLaunchKernelGGL(ode_starts_kernel, dim3((unsigned)B), dim3(64), 0, st, maps, init, init_bstride, starts, S, D);
+  C3P_LAUNCH(ode_starts_kernel, dim3((unsigned)B), dim3(64), 0, st, maps, init, init_bstride, starts, S, D);
   return hipGetLastError();
 }
 
 hipError_t c3p_launch_ode_identity(cplx* out, int D, hipStream_t st) {
-  hipLaunchKernelGGL(ode_identity_kernel, dim3(1), dim3(256), 0, st, out, D);
+  C3P_LAUNCH(ode_identity_kernel, dim3(1), dim3(256), 0, st, out, D);
   return hipGetLastError();
 }
 
 hipError_t c3p_launch_ode_apply(const cplx* U, const cplx* init, long init_bstride, cplx* out, int B, int D, hipStream_t st) {
-  hipLaunchKernelGGL(ode_apply_kernel, dim3((unsigned)B), dim3(64), 0, st, U, init, init_bstride, out, D);
+  C3P_LAUNCH(ode_apply_kernel, dim3((unsigned)B), dim3(64), 0, st, U, init, init_bstride, out, D);
   return hipGetLastError();
 }

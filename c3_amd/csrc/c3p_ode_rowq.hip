@@ -322,7 +322,7 @@ hipError_t launch_q2(const OdeArgs& A, hipStream_t st) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ode_vecq_kernel<NQ, CL, true, NW, QK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ode_vecq_kernel<NQ, CL, true, NW, QK>), grid, dim3(64 * NW), L.bytes, st, A);
+    C3P_LAUNCH((ode_vecq_kernel<NQ, CL, true, NW, QK>), grid, dim3(64 * NW), L.bytes, st, A);
   }
   {
     constexpr int NW = 4;
@@ -331,7 +331,7 @@ hipError_t launch_q2(const OdeArgs& A, hipStream_t st) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ode_vecq_kernel<NQ, CL, false, NW, QK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ode_vecq_kernel<NQ, CL, false, NW, QK>), grid, dim3(64 * NW), L.bytes, st, A);
+    C3P_LAUNCH((ode_vecq_kernel<NQ, CL, false, NW, QK>), grid, dim3(64 * NW), L.bytes, st, A);
   }
   return hipGetLastError();
 }

@@ -856,7 +856,7 @@ hipError_t launch_r(const MidArgs& A, void* arena, hipStream_t st) {
     if (!dbg_dev) (void)hipMalloc(&dbg_dev, 12 * sizeof(long long));
     dbg = dbg_dev;
 #endif
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(RG_THREADS), lds, st, A, reinterpret_cast<cplx*>(arena), dbg);
+    C3P_LAUNCH(kern, dim3(grid), dim3(RG_THREADS), lds, st, A, reinterpret_cast<cplx*>(arena), dbg);
 #ifdef C3P_REGD_TIMING
     {
       long long h[12];
@@ -901,7 +901,7 @@ size_t c3p_regd_arena_bytes(int Dm) {
 
 hipError_t c3p_launch_regd_prep(const RegdPrepArgs& P, int nsamp, hipStream_t st) {
   if (!c3p_regd_supported(P.Dm)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(regd_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K))), dim3(256), 0, st, P);
+  C3P_LAUNCH(regd_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K))), dim3(256), 0, st, P);
   return hipGetLastError();
 }
 

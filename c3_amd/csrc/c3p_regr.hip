@@ -826,7 +826,7 @@ hipError_t launch_rr(const MidArgs& A, void* arena, hipStream_t st) {
     if (!dbg_dev) (void)hipMalloc(&dbg_dev, 12 * sizeof(long long));
     dbg = dbg_dev;
 #endif
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, A, reinterpret_cast<double*>(arena), dbg);
+    C3P_LAUNCH(kern, dim3(grid), dim3(64 * NW), lds, st, A, reinterpret_cast<double*>(arena), dbg);
 #ifdef C3P_REGR_TIMING
     {
       long long h[12];
@@ -864,7 +864,7 @@ size_t c3p_regr_table_doubles(int Dm, int K) {
 }
 
 hipError_t c3p_launch_regr_prep_t(const RegdPrepArgs& P, int nsamp, double* tables, int* tabflag, int transpose, hipStream_t st) {
-  hipLaunchKernelGGL(regr_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K))), dim3(256), 0, st, P, tables, tabflag, transpose);
+  C3P_LAUNCH(regr_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K))), dim3(256), 0, st, P, tables, tabflag, transpose);
   return hipGetLastError();
 }
 hipError_t c3p_launch_regr_prep(const RegdPrepArgs& P, int nsamp, double* tables, int* tabflag, hipStream_t st) {
@@ -906,6 +906,6 @@ hipError_t c3p_launch_hb_to_complex(cplx* mats, long nmat, int mats_per_sample, 
   const size_t lds = (size_t)Dh * Dh * Dh * Dh * sizeof(double);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hb_to_complex_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(hb_to_complex_kernel, dim3((unsigned)nmat), dim3(256), lds, st, mats, mats_per_sample, tabflag, tab_per_sample, K, Dh);
+  C3P_LAUNCH(hb_to_complex_kernel, dim3((unsigned)nmat), dim3(256), lds, st, mats, mats_per_sample, tabflag, tab_per_sample, K, Dh);
   return hipGetLastError();
 }

@@ -692,7 +692,7 @@ hipError_t launch_rg(const RegrGradArgs& A, hipStream_t st) {
   const unsigned grid = (unsigned)(nchains < C3P_REGD_MAX_WGS ? nchains : C3P_REGD_MAX_WGS);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(regr_grad_kernel<NRG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(regr_grad_kernel<NRG>, dim3(grid), dim3(256), lds, st, A);
+  C3P_LAUNCH(regr_grad_kernel<NRG>, dim3(grid), dim3(256), lds, st, A);
   return hipGetLastError();
 }
 
@@ -714,7 +714,7 @@ hipError_t c3p_launch_regr_grad(const RegrGradArgs& A, hipStream_t st) {
 }
 
 hipError_t c3p_launch_hb_ubar(const cplx* Ubar, const double* fr_phase, int B, int Dh, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(hb_ubar_kernel, dim3((unsigned)B), dim3(256), 0, st, Ubar, fr_phase, Dh, out);
+  C3P_LAUNCH(hb_ubar_kernel, dim3((unsigned)B), dim3(256), 0, st, Ubar, fr_phase, Dh, out);
   return hipGetLastError();
 }
 
@@ -725,7 +725,7 @@ hipError_t c3p_launch_regr_scan(const cplx* seg_slots, const double* ubar, int B
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(regr_scan_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(regr_scan_seq_kernel, dim3((unsigned)B), dim3(256), lds, st, seg_slots, ubar, S, Dm, pre, suf, tau);
-  hipLaunchKernelGGL(regr_scan_fold_kernel, dim3((unsigned)(B * S)), dim3(256), lds, st, pre, suf, S, Dm, lam);
+  C3P_LAUNCH(regr_scan_seq_kernel, dim3((unsigned)B), dim3(256), lds, st, seg_slots, ubar, S, Dm, pre, suf, tau);
+  C3P_LAUNCH(regr_scan_fold_kernel, dim3((unsigned)(B * S)), dim3(256), lds, st, pre, suf, S, Dm, lam);
   return hipGetLastError();
 }

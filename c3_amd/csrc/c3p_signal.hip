@@ -8,6 +8,7 @@
 // 8 B written per sample, nothing re-read from HBM: the I/Q rows stay in L2).
 #include <hip/hip_runtime.h>
 
+#include "c3p_common.h"
 #include "c3p_signal.h"
 
 namespace {
@@ -324,9 +325,9 @@ hipError_t c3p_launch_synth_vjp(const SynthArgs& A, const double* gsig, double* 
                                 double* gcar, hipStream_t st) {
   const long ta = (long)A.B * A.K * A.Na;
   if (ta == 0) return hipSuccess;
-  hipLaunchKernelGGL(awg_iq_kernel, dim3((unsigned)((ta + 127) / 128)), dim3(128), 0, st, A);
-  hipLaunchKernelGGL(mix_bwd_kernel, dim3((unsigned)ta), dim3(64), 0, st, A, gsig, giq, gcar_part);
-  hipLaunchKernelGGL(awg_bwd_kernel, dim3((unsigned)(A.B * A.K)), dim3(64), 0, st, A, (const double*)giq,
+  C3P_LAUNCH(awg_iq_kernel, dim3((unsigned)((ta + 127) / 128)), dim3(128), 0, st, A);
+  C3P_LAUNCH(mix_bwd_kernel, dim3((unsigned)ta), dim3(64), 0, st, A, gsig, giq, gcar_part);
+  C3P_LAUNCH(awg_bwd_kernel, dim3((unsigned)(A.B * A.K)), dim3(64), 0, st, A, (const double*)giq,
                      (const double*)gcar_part, genv, gcar);
   return hipGetLastError();
 }
@@ -334,9 +335,9 @@ hipError_t c3p_launch_synth_vjp(const SynthArgs& A, const double* gsig, double* 
 hipError_t c3p_launch_synth(const SynthArgs& A, hipStream_t st) {
   const long ta = (long)A.B * A.K * A.Na, ts = (long)A.B * A.K * A.N;
   if (ta == 0 || ts == 0) return hipSuccess;
-  hipLaunchKernelGGL(awg_iq_kernel, dim3((unsigned)((ta + 127) / 128)), dim3(128), 0, st, A);
+  C3P_LAUNCH(awg_iq_kernel, dim3((unsigned)((ta + 127) / 128)), dim3(128), 0, st, A);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(mix_kernel, dim3((unsigned)((ts + 255) / 256)), dim3(256), 0, st, A);
+  C3P_LAUNCH(mix_kernel, dim3((unsigned)((ts + 255) / 256)), dim3(256), 0, st, A);
   return hipGetLastError();
 }

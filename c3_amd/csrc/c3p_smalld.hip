@@ -2121,13 +2121,13 @@ hipError_t launch_chain_t(const SmallArgs& A, hipStream_t st) {
   if (lds > 60 * 1024) return hipErrorInvalidValue;
   if (A.mode == C3P_MODE_EXPM) {
     if (A.dUs_out)
-      hipLaunchKernelGGL((smalld_chain_kernel<D, false, true, true>), dim3(grid), dim3(64), lds, st, A);
+      C3P_LAUNCH((smalld_chain_kernel<D, false, true, true>), dim3(grid), dim3(64), lds, st, A);
     else
-      hipLaunchKernelGGL((smalld_chain_kernel<D, false, false, true>), dim3(grid), dim3(64), lds, st, A);
+      C3P_LAUNCH((smalld_chain_kernel<D, false, false, true>), dim3(grid), dim3(64), lds, st, A);
   } else if (A.mode == C3P_MODE_GIVEN)
-    hipLaunchKernelGGL((smalld_chain_kernel<D, true, false>), dim3(grid), dim3(64), lds, st, A);
+    C3P_LAUNCH((smalld_chain_kernel<D, true, false>), dim3(grid), dim3(64), lds, st, A);
   else if (A.dUs_out)
-    hipLaunchKernelGGL((smalld_chain_kernel<D, false, true>), dim3(grid), dim3(64), lds, st, A);
+    C3P_LAUNCH((smalld_chain_kernel<D, false, true>), dim3(grid), dim3(64), lds, st, A);
   else {
     // one workgroup per sample (MW) when the S / 4 waves of a sample fit a CU together with enough other samples for all
     // B workgroups to be resident at once (8 waves per CU at two per SIMD): B = 256, S = 32 -> 256 workgroups of 8 waves
@@ -2172,13 +2172,13 @@ hipError_t launch_chain_t(const SmallArgs& A, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_use);
         if (e != hipSuccess) return e;
       }
-      hipLaunchKernelGGL(kern, dim3((unsigned)A.B), dim3(64 * nW), lds_use, st, A2);
+      C3P_LAUNCH(kern, dim3((unsigned)A.B), dim3(64 * nW), lds_use, st, A2);
     } else {
       auto kern1 = smalld_chain_kernel<D, false, false>;
       if constexpr (D == 9 || D == 5) {
         if (!c3p_opt_on(C3P_OPT_no_split81)) kern1 = smalld_chain_kernel<D, false, false, false, false, true>;
       }
-      hipLaunchKernelGGL(kern1, dim3(grid), dim3(64), lds, st, A);
+      C3P_LAUNCH(kern1, dim3(grid), dim3(64), lds, st, A);
     }
   }
   return hipGetLastError();
@@ -3186,7 +3186,7 @@ hipError_t launch_grad_real_t(const SmallGradArgs& A, hipStream_t st) {
   const unsigned grid = (unsigned)((nchains + 3) / 4);
   const size_t lds = (size_t)((1 + A.K) * (C::MAT + 4) + 8 * RIMG + 4 * A.K * A.Lmax) * sizeof(double);
   if (lds > 60 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(smalld_grad_real_kernel<D>, dim3(grid), dim3(64), lds, st, A);
+  C3P_LAUNCH(smalld_grad_real_kernel<D>, dim3(grid), dim3(64), lds, st, A);
   return hipGetLastError();
 }
 
@@ -3197,7 +3197,7 @@ hipError_t launch_grad_t(const SmallGradArgs& A, hipStream_t st) {
   const unsigned grid = (unsigned)((nchains + 3) / 4);
   const size_t lds = (size_t)((1 + A.K) * (C::MAT + 4) + 8 * C::MAT + 4 * A.K * A.Lmax) * sizeof(double);
   if (lds > 60 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(smalld_grad_kernel<D>, dim3(grid), dim3(64), lds, st, A);
+  C3P_LAUNCH(smalld_grad_kernel<D>, dim3(grid), dim3(64), lds, st, A);
   return hipGetLastError();
 }
 
@@ -3209,15 +3209,15 @@ hipError_t launch_grad_general_t(const SmallGradArgs& A, hipStream_t st) {
   const size_t lds = (size_t)(2 * (1 + A.K) * (C::MAT + 4) + 8 * C::MAT + 4 * A.K * A.Lmax) * sizeof(double);
   if (lds > 60 * 1024) return hipErrorInvalidValue;
   if (A.hs != nullptr)
-    hipLaunchKernelGGL((smalld_grad_general_kernel<D, true>), dim3(grid), dim3(64), lds, st, A);
+    C3P_LAUNCH((smalld_grad_general_kernel<D, true>), dim3(grid), dim3(64), lds, st, A);
   else
-    hipLaunchKernelGGL((smalld_grad_general_kernel<D, false>), dim3(grid), dim3(64), lds, st, A);
+    C3P_LAUNCH((smalld_grad_general_kernel<D, false>), dim3(grid), dim3(64), lds, st, A);
   return hipGetLastError();
 }
 
 template <int D>
 hipError_t launch_prep_t(const PrepArgs& P, int nsamp, hipStream_t st) {
-  hipLaunchKernelGGL(smalld_prep_kernel<D>, dim3((unsigned)(nsamp * (1 + P.K))), dim3(64), 0, st, P);
+  C3P_LAUNCH(smalld_prep_kernel<D>, dim3((unsigned)(nsamp * (1 + P.K))), dim3(64), 0, st, P);
   return hipGetLastError();
 }
 

@@ -817,7 +817,7 @@ hipError_t launch_grad_t(const SmallRGradArgs& A, hipStream_t st) {
   const long nchains = (long)A.B * A.S;
   const size_t lds = (size_t)(2 * (1 + A.K) * G::TABD + 8 * G::RIMG + 4 * A.K * A.Lmax) * sizeof(double);
   if (lds > 60 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(smallr_grad_kernel<DM>, dim3((unsigned)((nchains + 3) / 4)), dim3(64), lds, st, A);
+  C3P_LAUNCH(smallr_grad_kernel<DM>, dim3((unsigned)((nchains + 3) / 4)), dim3(64), lds, st, A);
   return hipGetLastError();
 }
 
@@ -827,7 +827,7 @@ hipError_t launch_chain_t(const SmallRArgs& A, hipStream_t st) {
   const long nchains = (long)A.B * A.S;
   const size_t lds = (size_t)((1 + A.K) * G::TABD + 4 * G::RIMG + 4 * A.K * A.Lmax) * sizeof(double);
   if (lds > 60 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(smallr_chain_kernel<DM>, dim3((unsigned)((nchains + 3) / 4)), dim3(64), lds, st, A);
+  C3P_LAUNCH(smallr_chain_kernel<DM>, dim3((unsigned)((nchains + 3) / 4)), dim3(64), lds, st, A);
   return hipGetLastError();
 }
 
@@ -848,12 +848,12 @@ size_t c3p_smallr_lds_bytes(int Dm, int K, int Lmax) {
 }
 
 hipError_t c3p_launch_smallr_prep(const RegdPrepArgs& P, int nsamp, double* tables, int* tabflag, hipStream_t st, int transpose) {
-  hipLaunchKernelGGL(smallr_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K))), dim3(64), 0, st, P, tables, (double*)nullptr, tabflag, transpose);
+  C3P_LAUNCH(smallr_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K))), dim3(64), 0, st, P, tables, (double*)nullptr, tabflag, transpose);
   return hipGetLastError();
 }
 
 hipError_t c3p_launch_smallr_prep_pair(const RegdPrepArgs& P, int nsamp, double* tables, double* tables_t, int* tabflag, hipStream_t st) {
-  hipLaunchKernelGGL(smallr_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K)), 2), dim3(64), 0, st, P, tables, tables_t, tabflag, 2);
+  C3P_LAUNCH(smallr_prep_kernel, dim3((unsigned)(nsamp * (1 + P.K)), 2), dim3(64), 0, st, P, tables, tables_t, tabflag, 2);
   return hipGetLastError();
 }
 
@@ -883,21 +883,21 @@ hipError_t c3p_launch_smallr_grad(const SmallRGradArgs& A, hipStream_t st) {
 hipError_t c3p_launch_smallr_scan(const double* seg, const double* ubar, int B, int S, int Dm, double* pre, double* suf, hipStream_t st) {
   if (S >= 16 && !c3p_opt_on(C3P_OPT_no_fuse)) {  // (no_fuse: the sequential scan, A/B)
     if (Dm == 4)
-      hipLaunchKernelGGL((smallr_scan_blocked_kernel<4, 8>), dim3((unsigned)B, 2), dim3(512), 0, st, seg, ubar, S, pre, suf);
+      C3P_LAUNCH((smallr_scan_blocked_kernel<4, 8>), dim3((unsigned)B, 2), dim3(512), 0, st, seg, ubar, S, pre, suf);
     else if (Dm == 9)
-      hipLaunchKernelGGL((smallr_scan_blocked_kernel<9, 8>), dim3((unsigned)B, 2), dim3(512), 0, st, seg, ubar, S, pre, suf);
+      C3P_LAUNCH((smallr_scan_blocked_kernel<9, 8>), dim3((unsigned)B, 2), dim3(512), 0, st, seg, ubar, S, pre, suf);
     else if (Dm == 16)
-      hipLaunchKernelGGL((smallr_scan_blocked_kernel<16, 4>), dim3((unsigned)B, 2), dim3(256), 0, st, seg, ubar, S, pre, suf);
+      C3P_LAUNCH((smallr_scan_blocked_kernel<16, 4>), dim3((unsigned)B, 2), dim3(256), 0, st, seg, ubar, S, pre, suf);
     else
       return hipErrorInvalidValue;
     return hipGetLastError();
   }
   if (Dm == 4)
-    hipLaunchKernelGGL(smallr_scan_kernel<4>, dim3((unsigned)B, 2), dim3(64), 0, st, seg, ubar, S, pre, suf);
+    C3P_LAUNCH(smallr_scan_kernel<4>, dim3((unsigned)B, 2), dim3(64), 0, st, seg, ubar, S, pre, suf);
   else if (Dm == 9)
-    hipLaunchKernelGGL(smallr_scan_kernel<9>, dim3((unsigned)B, 2), dim3(64), 0, st, seg, ubar, S, pre, suf);
+    C3P_LAUNCH(smallr_scan_kernel<9>, dim3((unsigned)B, 2), dim3(64), 0, st, seg, ubar, S, pre, suf);
   else if (Dm == 16)
-    hipLaunchKernelGGL(smallr_scan_kernel<16>, dim3((unsigned)B, 2), dim3(64), 0, st, seg, ubar, S, pre, suf);
+    C3P_LAUNCH(smallr_scan_kernel<16>, dim3((unsigned)B, 2), dim3(64), 0, st, seg, ubar, S, pre, suf);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();

@@ -847,11 +847,11 @@ int c3p_tiled_run(const TiledArgs& A, void* ws, int Bc, hipStream_t st, std::str
       T.tables = tables;
       T.meta = meta;
       if (b0 == 0 || per_sample) {
-        hipLaunchKernelGGL(tg_meta_kernel, dim3(1 + K, nts), dim3(256), 0, st, T);
-        hipLaunchKernelGGL(tg_table_kernel, dim3(ebl, 1 + K, nts), dim3(256), 0, st, T, g.DPR, g.DPC);
+        C3P_LAUNCH(tg_meta_kernel, dim3(1 + K, nts), dim3(256), 0, st, T);
+        C3P_LAUNCH(tg_table_kernel, dim3(ebl, 1 + K, nts), dim3(256), 0, st, T, g.DPR, g.DPC);
       }
       if (K > 0)
-        hipLaunchKernelGGL(tg_sigmax_kernel, dim3(K), dim3(256), 0, st, A.signals + (long)b0 * K * A.N, nb, K, A.N, red);
+        C3P_LAUNCH(tg_sigmax_kernel, dim3(K), dim3(256), 0, st, A.signals + (long)b0 * K * A.N, nb, K, A.N, red);
       TG_TRY(hipGetLastError());
       std::vector<double> hm((size_t)nts * (1 + K) * 4);
       std::vector<unsigned long long> hr(64);
@@ -867,9 +867,9 @@ int c3p_tiled_run(const TiledArgs& A, void* ws, int Bc, hipStream_t st, std::str
       }
     } else {
       const long nmat = (long)nb * A.N;
-      hipLaunchKernelGGL(tg_hnorm_kernel, dim3((unsigned)nmat), dim3(64), 0, st, A.h0 + (long)b0 * A.h0_bstride, A.h0_bstride, A.N,
+      C3P_LAUNCH(tg_hnorm_kernel, dim3((unsigned)nmat), dim3(64), 0, st, A.h0 + (long)b0 * A.h0_bstride, A.h0_bstride, A.N,
                          A.D, red);
-      if (A.lindblad) hipLaunchKernelGGL(tg_hnorm_kernel, dim3(1), dim3(64), 0, st, A.clp, 0L, 1, A.Dm, red + 2);
+      if (A.lindblad) C3P_LAUNCH(tg_hnorm_kernel, dim3(1), dim3(64), 0, st, A.clp, 0L, 1, A.Dm, red + 2);
       TG_TRY(hipGetLastError());
       std::vector<unsigned long long> hr(64);
       TG_TRY(hipMemcpyAsync(hr.data(), red, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -894,7 +894,7 @@ int c3p_tiled_run(const TiledArgs& A, void* ws, int Bc, hipStream_t st, std::str
     gg.z = (unsigned)nb;
     auto M = [&](int slot) -> double* { return mats + (long)slot * MS; };
     auto gemm = [&](int a, int b, int add, int c) {
-      hipLaunchKernelGGL(tg_gemm_kernel, gg, dim3(256), 0, st, M(a), M(b), add >= 0 ? M(add) : nullptr, M(c), 2 * g.DPR, g.DPC,
+      C3P_LAUNCH(tg_gemm_kernel, gg, dim3(256), 0, st, M(a), M(b), add >= 0 ? M(add) : nullptr, M(c), 2 * g.DPR, g.DPC,
                          (long)M_COUNT * MS, (long)M_COUNT * MS, (long)M_COUNT * MS);
     };
     int ucur = M_U0;
@@ -921,13 +921,13 @@ int c3p_tiled_run(const TiledArgs& A, void* ws, int Bc, hipStream_t st, std::str
       P.X = mats;
       P.mus = mus;
       P.mun = mun;
-      hipLaunchKernelGGL(tg_assemble_kernel, eg, dim3(256), 0, st, P, g.DPR, g.DPC);
+      C3P_LAUNCH(tg_assemble_kernel, eg, dim3(256), 0, st, P, g.DPR, g.DPC);
       gemm(M_X, M_X, -1, M_A2);
       gemm(M_X, M_A2, -1, M_A3);
       gemm(M_A3, M_A3, -1, M_A6);
-      hipLaunchKernelGGL(tg_combo_kernel, eg, dim3(256), 0, st, mats, A.Dm, g.DPR, g.DPC);
+      C3P_LAUNCH(tg_combo_kernel, eg, dim3(256), 0, st, mats, A.Dm, g.DPR, g.DPC);
       gemm(M_T1, M_T2, M_T3, M_A2);                                                   // A9 = B1 B5 + B4
-      hipLaunchKernelGGL(tg_add_kernel, eg, dim3(256), 0, st, mats, M_T4, M_A2, M_A3, MS);  // B3 + A9
+      C3P_LAUNCH(tg_add_kernel, eg, dim3(256), 0, st, mats, M_T4, M_A2, M_A3, MS);  // B3 + A9
       gemm(M_A3, M_A2, M_X, M_A6);                                                    // T18 = (B3 + A9) A9 + B2
       int e = M_A6, o = M_T1;
       for (int it = 0; it < s18; ++it) {
@@ -935,7 +935,7 @@ int c3p_tiled_run(const TiledArgs& A, void* ws, int Bc, hipStream_t st, std::str
         std::swap(e, o);
       }
       if (A.dUs_out)
-        hipLaunchKernelGGL(tg_out_kernel, dim3((unsigned)(((long)A.Dm * A.Dm + 255) / 256), (unsigned)nb), dim3(256), 0, st, mats, e,
+        C3P_LAUNCH(tg_out_kernel, dim3((unsigned)(((long)A.Dm * A.Dm + 255) / 256), (unsigned)nb), dim3(256), 0, st, mats, e,
                            mun, (const double*)nullptr, A.dUs_out + ((long)b0 * A.N + n) * A.Dm * A.Dm, (long)A.N * A.Dm * A.Dm, A.Dm,
                            g.DPR, g.DPC);
       if (n == 0) {
@@ -950,7 +950,7 @@ int c3p_tiled_run(const TiledArgs& A, void* ws, int Bc, hipStream_t st, std::str
       }
       TG_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(tg_out_kernel, dim3((unsigned)(((long)A.Dm * A.Dm + 255) / 256), (unsigned)nb), dim3(256), 0, st, mats, ucur, mus,
+    C3P_LAUNCH(tg_out_kernel, dim3((unsigned)(((long)A.Dm * A.Dm + 255) / 256), (unsigned)nb), dim3(256), 0, st, mats, ucur, mus,
                        A.fr_phase ? A.fr_phase + (long)b0 * A.Dm : nullptr, A.U_out + (long)b0 * A.Dm * A.Dm, (long)A.Dm * A.Dm, A.Dm,
                        g.DPR, g.DPC);
     TG_TRY(hipGetLastError());
@@ -1058,12 +1058,12 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
       T.tables = tables;
       T.meta = meta;
       if (b0 == 0 || per_sample) {
-        hipLaunchKernelGGL(tg_meta_kernel, dim3(1 + K, nts), dim3(256), 0, st, T);
-        hipLaunchKernelGGL(tg_table_kernel, dim3(ebl, 1 + K, nts), dim3(256), 0, st, T, g.DPR, g.DPC);
-        hipLaunchKernelGGL(tg_adjoint_kernel, dim3(ebl, (unsigned)(nts * (1 + K))), dim3(256), 0, st, tables, MS, tables_adj, MS, A.Dm,
+        C3P_LAUNCH(tg_meta_kernel, dim3(1 + K, nts), dim3(256), 0, st, T);
+        C3P_LAUNCH(tg_table_kernel, dim3(ebl, 1 + K, nts), dim3(256), 0, st, T, g.DPR, g.DPC);
+        C3P_LAUNCH(tg_adjoint_kernel, dim3(ebl, (unsigned)(nts * (1 + K))), dim3(256), 0, st, tables, MS, tables_adj, MS, A.Dm,
                            g.DPR, g.DPC, (const int*)nullptr, 0);
       }
-      hipLaunchKernelGGL(tg_sigmax_kernel, dim3(K), dim3(256), 0, st, A.signals + (long)b0 * K * N, nb, K, N, red);
+      C3P_LAUNCH(tg_sigmax_kernel, dim3(K), dim3(256), 0, st, A.signals + (long)b0 * K * N, nb, K, N, red);
       TG_TRY(hipGetLastError());
       std::vector<double> hm((size_t)nts * (1 + K) * 4);
       std::vector<unsigned long long> hr(64);
@@ -1080,8 +1080,8 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
       TG_TRY(hipMemcpyAsync(meta_adj, meta, nt * (1 + K) * 4 * sizeof(double), hipMemcpyDeviceToDevice, st));
     } else {
       const long nmat = (long)nb * N;
-      hipLaunchKernelGGL(tg_hnorm_kernel, dim3((unsigned)nmat), dim3(64), 0, st, A.h0 + (long)b0 * A.h0_bstride, A.h0_bstride, N, A.D, red);
-      if (A.lindblad) hipLaunchKernelGGL(tg_hnorm_kernel, dim3(1), dim3(64), 0, st, A.clp, 0L, 1, A.Dm, red + 2);
+      C3P_LAUNCH(tg_hnorm_kernel, dim3((unsigned)nmat), dim3(64), 0, st, A.h0 + (long)b0 * A.h0_bstride, A.h0_bstride, N, A.D, red);
+      if (A.lindblad) C3P_LAUNCH(tg_hnorm_kernel, dim3(1), dim3(64), 0, st, A.clp, 0L, 1, A.Dm, red + 2);
       TG_TRY(hipGetLastError());
       std::vector<unsigned long long> hr(64);
       TG_TRY(hipMemcpyAsync(hr.data(), red, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -1110,7 +1110,7 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
     const bool tile32 = t32e >= 0 ? t32e != 0 : ((long)ggrid.x * ggrid.y * nb * 2 < 1024);
     auto M = [&](int slot) -> double* { return mats + (long)slot * MS; };
     auto gemm = [&](int a, int b, int add, int c) {
-      hipLaunchKernelGGL(tg_gemm_kernel, gg, dim3(256), 0, st, M(a), M(b), add >= 0 ? M(add) : nullptr, M(c), 2 * g.DPR, g.DPC, VS, VS,
+      C3P_LAUNCH(tg_gemm_kernel, gg, dim3(256), 0, st, M(a), M(b), add >= 0 ? M(add) : nullptr, M(c), 2 * g.DPR, g.DPC, VS, VS,
                          VS, (const int*)nullptr, 0, 0L);
     };
     // X (or X^H) of slice *nctr + off into slot V_Y
@@ -1139,7 +1139,7 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
         P.hs_bstride = A.h0_bstride;
         P.adjoint = (tabs == tables_adj) ? 1 : 0;
       }
-      hipLaunchKernelGGL(tg_assemble_slots_kernel, eg, dim3(256), 0, st, P, V_COUNT, g.DPR, g.DPC);
+      C3P_LAUNCH(tg_assemble_slots_kernel, eg, dim3(256), 0, st, P, V_COUNT, g.DPR, g.DPC);
     };
     auto copy_slot = [&](int src, int dst) -> int {
       for (int b = 0; b < nb; ++b)
@@ -1152,10 +1152,10 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
       gemm(V_Y, V_Y, -1, V_A2);
       gemm(V_Y, V_A2, -1, V_A3);
       gemm(V_A3, V_A3, -1, V_A6);
-      hipLaunchKernelGGL(tg_combo_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_Y, V_A2, V_A3, V_A6, V_T1, V_T2, V_T3, V_T4, 1,
+      C3P_LAUNCH(tg_combo_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_Y, V_A2, V_A3, V_A6, V_T1, V_T2, V_T3, V_T4, 1,
                          A.Dm, g.DPR, g.DPC);
       gemm(V_T1, V_T2, V_T3, V_A2);
-      hipLaunchKernelGGL(tg_add_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_T4, V_A2, V_A3, MS);
+      C3P_LAUNCH(tg_add_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_T4, V_A2, V_A3, MS);
       gemm(V_A3, V_A2, V_Y, V_A6);
       int e = V_A6, o = V_T1;
       for (int it = 0; it < s18; ++it) {
@@ -1170,7 +1170,7 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
       assemble(tables, meta, off, mus, mun);
       const int e = t18_value();
       gemm(e, pin, -1, pout);
-      hipLaunchKernelGGL(tg_adjoint_kernel, eg, dim3(256), 0, st, M(pout), VS, store + MS, SS, A.Dm, g.DPR, g.DPC, (const int*)nctr, off);
+      C3P_LAUNCH(tg_adjoint_kernel, eg, dim3(256), 0, st, M(pout), VS, store + MS, SS, A.Dm, g.DPR, g.DPC, (const int*)nctr, off);
     };
     int pcur = V_P0;
     {
@@ -1179,8 +1179,8 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
       const int e = t18_value();
       if (copy_slot(e, pcur)) return -1;
       if (N > 1)
-        hipLaunchKernelGGL(tg_adjoint_kernel, eg, dim3(256), 0, st, M(pcur), VS, store + MS, SS, A.Dm, g.DPR, g.DPC, (const int*)nctr, 0);
-      hipLaunchKernelGGL(tg_count_kernel, dim3(1), dim3(1), 0, st, nctr, 1);
+        C3P_LAUNCH(tg_adjoint_kernel, eg, dim3(256), 0, st, M(pcur), VS, store + MS, SS, A.Dm, g.DPR, g.DPC, (const int*)nctr, 0);
+      C3P_LAUNCH(tg_count_kernel, dim3(1), dim3(1), 0, st, nctr, 1);
       TG_TRY(hipGetLastError());
     }
     {
@@ -1188,7 +1188,7 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
       if (rem > 0 && (rem & 1)) {
         const int pn = pcur == V_P0 ? V_P1 : V_P0;
         fwd_slice(0, pcur, pn);
-        hipLaunchKernelGGL(tg_count_kernel, dim3(1), dim3(1), 0, st, nctr, 1);
+        C3P_LAUNCH(tg_count_kernel, dim3(1), dim3(1), 0, st, nctr, 1);
         pcur = pn;
         --rem;
       }
@@ -1196,21 +1196,21 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
       if (tg_replay(st, use_graph, rem / 2, [&]() {
             fwd_slice(0, pa, pb);
             fwd_slice(1, pb, pa);
-            hipLaunchKernelGGL(tg_count_kernel, dim3(1), dim3(1), 0, st, nctr, 2);
+            C3P_LAUNCH(tg_count_kernel, dim3(1), dim3(1), 0, st, nctr, 2);
           }, err))
         return -1;
     }
     // (the counter is now N; the adjoint of P_{N-1} went to store slot N, which is one past the end: the store is sized N + 1)
     // ---- cotangent of the trace-shifted product and the trace-shift term ----
     int lcur = V_L0;
-    hipLaunchKernelGGL(tg_ubar_kernel, dim3((unsigned)nb), dim3(256), 0, st, U_bar + (long)b0 * A.Dm * A.Dm, mus,
+    C3P_LAUNCH(tg_ubar_kernel, dim3((unsigned)nb), dim3(256), 0, st, U_bar + (long)b0 * A.Dm * A.Dm, mus,
                        A.fr_phase ? A.fr_phase + (long)b0 * A.Dm : nullptr, M(pcur), VS, M(lcur), VS, tau, A.Dm, g.DPR, g.DPC);
-    hipLaunchKernelGGL(tg_count_kernel, dim3(1), dim3(1), 0, st, nctr, -1);  // counter = N - 1
+    C3P_LAUNCH(tg_count_kernel, dim3(1), dim3(1), 0, st, nctr, -1);  // counter = N - 1
     // ---- backward: Ebar_n = Lambda_n B_n^H, Xbar_n = L(X_n^H)[Ebar_n] by the pair evaluation of T18, Lambda_{n-1} = E_n^H Lambda_n ----
     // one backward slice at n = counter + off >= 1
     auto bwd_slice = [&](int off, int lin, int lout, bool first_slice_zero) {
       if (!first_slice_zero)
-        hipLaunchKernelGGL(tg_gemm_kernel, gg, dim3(256), 0, st, M(lin), store, (const double*)nullptr, M(V_V), 2 * g.DPR, g.DPC, VS, SS,
+        C3P_LAUNCH(tg_gemm_kernel, gg, dim3(256), 0, st, M(lin), store, (const double*)nullptr, M(V_V), 2 * g.DPR, g.DPC, VS, SS,
                            VS, (const int*)nctr, off, MS);
       assemble(tables_adj, meta_adj, off, junk, junk + 2 * (size_t)Bc);  // Y = X_n^H (scaled)
       // two results per dependency level (value, derivative), every derivative the sum of two products: one launch per level
@@ -1231,29 +1231,29 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
         if (tile32) {
           g2.x *= 2;
           g2.y *= 2;
-          hipLaunchKernelGGL(tg_gemm_tasks32_kernel, g2, dim3(256), 0, st, mats, VS, MS, T, nb, 2 * g.DPR, g.DPC);
+          C3P_LAUNCH(tg_gemm_tasks32_kernel, g2, dim3(256), 0, st, mats, VS, MS, T, nb, 2 * g.DPR, g.DPC);
         } else {
-          hipLaunchKernelGGL(tg_gemm_tasks_kernel, g2, dim3(256), 0, st, mats, VS, MS, T, nb, 2 * g.DPR, g.DPC);
+          C3P_LAUNCH(tg_gemm_tasks_kernel, g2, dim3(256), 0, st, mats, VS, MS, T, nb, 2 * g.DPR, g.DPC);
         }
       };
       level(V_Y, V_Y, -1, V_A2, V_V, V_Y, V_Y, V_V, -1, V_DA2);
       level(V_Y, V_A2, -1, V_A3, V_V, V_A2, V_Y, V_DA2, -1, V_DA3);
       level(V_A3, V_A3, -1, V_A6, V_DA3, V_A3, V_A3, V_DA3, -1, V_DA6);
       if (no_batch) {
-        hipLaunchKernelGGL(tg_combo_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_Y, V_A2, V_A3, V_A6, V_T1, V_T2, V_T3, V_T4, 1,
+        C3P_LAUNCH(tg_combo_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_Y, V_A2, V_A3, V_A6, V_T1, V_T2, V_T3, V_T4, 1,
                            A.Dm, g.DPR, g.DPC);
-        hipLaunchKernelGGL(tg_combo_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_V, V_DA2, V_DA3, V_DA6, V_DT1, V_DT2, V_DT3,
+        C3P_LAUNCH(tg_combo_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_V, V_DA2, V_DA3, V_DA6, V_DT1, V_DT2, V_DT3,
                            V_DT4, 0, A.Dm, g.DPR, g.DPC);
       } else {
-        hipLaunchKernelGGL(tg_combo2_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_Y, V_A2, V_A3, V_A6, V_T1, V_T2, V_T3, V_T4,
+        C3P_LAUNCH(tg_combo2_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_Y, V_A2, V_A3, V_A6, V_T1, V_T2, V_T3, V_T4,
                            V_V, V_DA2, V_DA3, V_DA6, V_DT1, V_DT2, V_DT3, V_DT4, A.Dm, g.DPR, g.DPC);
       }
       level(V_T1, V_T2, V_T3, V_A2, V_DT1, V_T2, V_T1, V_DT2, V_DT3, V_DA2);  // A9 = B1 B5 + B4; dA9 = dB1 B5 + B1 dB5 + dB4
       if (no_batch) {
-        hipLaunchKernelGGL(tg_add_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_T4, V_A2, V_A3, MS);     // L = B3 + A9
-        hipLaunchKernelGGL(tg_add_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_DT4, V_DA2, V_DA3, MS);  // dL
+        C3P_LAUNCH(tg_add_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_T4, V_A2, V_A3, MS);     // L = B3 + A9
+        C3P_LAUNCH(tg_add_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_DT4, V_DA2, V_DA3, MS);  // dL
       } else {
-        hipLaunchKernelGGL(tg_add2_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_T4, V_A2, V_A3, V_DT4, V_DA2, V_DA3, MS);
+        C3P_LAUNCH(tg_add2_slots_kernel, eg, dim3(256), 0, st, mats, V_COUNT, V_T4, V_A2, V_A3, V_DT4, V_DA2, V_DA3, MS);
       }
       level(V_A3, V_A2, V_Y, V_A6, V_DA3, V_A2, V_A3, V_DA2, V_V, V_DA6);  // F = L A9 + B2; dF = dL A9 + L dA9 + dB2
       int e = V_A6, o = V_T1, de = V_DA6, dq = V_DT1;
@@ -1263,10 +1263,10 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
         std::swap(de, dq);
       }
       if (per_slice)
-        hipLaunchKernelGGL(tg_genbar_kernel, dim3((unsigned)(((long)A.Dm * A.Dm + 255) / 256), (unsigned)nb), dim3(256), 0, st, mats, V_COUNT,
+        C3P_LAUNCH(tg_genbar_kernel, dim3((unsigned)(((long)A.Dm * A.Dm + 255) / 256), (unsigned)nb), dim3(256), 0, st, mats, V_COUNT,
                            de, scale, zout + (long)b0 * N * A.Dm * A.Dm, (long)N * A.Dm * A.Dm, (const int*)nctr, off, A.Dm, g.DPR, g.DPC);
       else
-        hipLaunchKernelGGL(tg_graddot_kernel, dim3((unsigned)K, (unsigned)nb), dim3(256), 0, st, mats, V_COUNT, de, tables, meta,
+        C3P_LAUNCH(tg_graddot_kernel, dim3((unsigned)K, (unsigned)nb), dim3(256), 0, st, mats, V_COUNT, de, tables, meta,
                            per_sample ? 1 : 0, K, tau, scale, grad, b0, (const int*)nctr, off, N, MS);
       if (lout >= 0) gemm(e, lin, -1, lout);  // Lambda_{n-1} = E_n^H Lambda_n
     };
@@ -1275,7 +1275,7 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
       if (rem > 0 && (rem & 1)) {
         const int ln = lcur == V_L0 ? V_L1 : V_L0;
         bwd_slice(0, lcur, ln, false);
-        hipLaunchKernelGGL(tg_count_kernel, dim3(1), dim3(1), 0, st, nctr, -1);
+        C3P_LAUNCH(tg_count_kernel, dim3(1), dim3(1), 0, st, nctr, -1);
         lcur = ln;
         --rem;
       }
@@ -1283,7 +1283,7 @@ int c3p_tiled_vjp_run(const TiledArgs& A, const cplx* U_bar, double* grad, cplx*
       if (tg_replay(st, use_graph, rem / 2, [&]() {
             bwd_slice(0, la, lb, false);
             bwd_slice(-1, lb, la, false);
-            hipLaunchKernelGGL(tg_count_kernel, dim3(1), dim3(1), 0, st, nctr, -2);
+            C3P_LAUNCH(tg_count_kernel, dim3(1), dim3(1), 0, st, nctr, -2);
           }, err))
         return -1;
       // slice 0: B_0 = I, Ebar_0 = Lambda_0 (the counter is 0)

@@ -97,6 +97,11 @@ int c3p_version(void);
 int c3p_device_count(void);
 const char* c3p_last_error(void);
 int c3p_last_kernel(void);
+/* The kernels the most recent compute call of this thread launched, as "file: kernel<template arguments> xCOUNT; ..." in
+ * launch order (names resolved from the host function pointers: what ran, not what was planned).  Writes at most cap - 1
+ * characters + NUL into buf (may be NULL) and returns the full length.  Diagnostic: INTEGRATION.md's dispatch table is
+ * generated from it (tools/dispatch_table.py).  No reference counterpart. */
+int c3p_last_kernel_detail(char* buf, int cap);
 /* Device time (ms) of the most recent c3p_pwc_* call's main kernel, measured
  * with hipEvents on the stream it was launched on; valid after that stream has
  * been synchronised.  Only recorded when profiling was enabled with

@@ -27,6 +27,22 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.c3p_version() >= 1
 
 
+def test_dispatch_table_in_integration_md_is_the_committed_measurement():
+    """INTEGRATION.md section 8 is the rendering of profiles/r06/dispatch_table.json (launch logs measured on the GPU box,
+    VERDICT r5 item 9); tests/test_gpu_round6.py re-measures sample rows."""
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dispatch_table.py"), "--check", os.path.join(ROOT, "profiles", "r06", "dispatch_table.json")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_launch_log_is_empty_before_any_compute_call(lib):
+    buf = __import__("ctypes").create_string_buffer(16)
+    assert lib.c3p_last_kernel_detail(buf, 16) >= 0  # callable without a device; no compute call on this thread yet or a short log
+
+
 def test_no_gpu_fails_loudly(lib):
     """The product path has no CPU fallback: without a device every entry point raises."""
     if lib.c3p_device_count() > 0:

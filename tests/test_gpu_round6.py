@@ -1,0 +1,81 @@
+"""Round 6: the launch log behind INTEGRATION.md's dispatch table, and the round's kernel changes on the headline path."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def prop():
+    from c3_amd import _lib, propagation
+
+    _lib.require_gpu()
+    return propagation
+
+
+def test_dispatch_table_rows_reproduce_on_this_box(prop):
+    """a spread of rows of profiles/r06/dispatch_table.json, re-measured: the same kernels (template arguments included) run"""
+    import dispatch_table as dt
+
+    rows = json.load(open(os.path.join(ROOT, "profiles", "r06", "dispatch_table.json")))["rows"]
+    grid = {(e, lab): dict(fixed) for e, lab, fixed, _ in dt.GRID}
+    picked = [r for i, r in enumerate(rows) if i % 9 == 0 and r["D"] <= 64]
+    assert len(picked) >= 12
+    for r in picked:
+        kw = dict(grid[(r["entry"], r["regime"])])
+        flags, real = kw.pop("flags", ""), kw.pop("real", True)
+        fam, det = dt.probe(r["entry"], r["D"], real=real, flags=flags, **kw)
+        assert fam == r["family"] and det == r["kernels"], (r, fam, det)
+
+
+def test_launch_log_names_the_headline_kernel(prop):
+    import torch
+
+    from c3_amd import _lib
+    from c3_amd.workloads import make_workload
+    from oracle import c3_oracle
+
+    w = make_workload(2, B=256, N=1000)
+    t = lambda a: torch.as_tensor(a, device="cuda:0")
+    U = prop.propagate_batch(t(w.h0), t(w.hks), t(w.signals), w.dt, fr_phase=t(w.fr_phase))["U"]
+    torch.cuda.synchronize()
+    # one launch per batch: workgroup per sample (MW), core + border form (SPLIT)
+    assert _lib.last_kernel_detail() == "c3p_smalld.hip: smalld_chain_kernel<9, false, false, false, true, true>"
+    idx = np.array([0, 37, 128, 255])
+    ref = c3_oracle.propagate_batch(w.h0, w.hks, w.signals[idx], w.dt, fr_phase=w.fr_phase[idx])
+    got = U[torch.as_tensor(idx, device="cuda:0")].cpu().numpy()
+    assert max(np.linalg.norm(got[i] - ref[i]) for i in range(len(idx))) < 1e-11
+
+
+@pytest.mark.parametrize("D", [5, 9])
+@pytest.mark.parametrize("squarings", [0, 1, 3])
+def test_border_sums_on_the_matrix_cores_all_variants(prop, D, squarings):
+    """round 6's form of the core + border loop (reductions against a tile of ones, chain step without lane swaps, Horner factors as
+    left operands) against the oracle: both polynomial variants (norm below / above theta_16), squarings (the c-form borders are
+    only fetched there and on the first slice), workgroup-per-sample and one-wave workgroups, frame-rotation phases."""
+    import torch
+
+    from c3_amd import _lib
+    from oracle import c3_oracle
+
+    rng = np.random.default_rng(600 + D + squarings)
+    herm = lambda s: (lambda m: s * (m + m.T) / 2)(rng.normal(size=(D, D))).astype(np.complex128)
+    K, N = 2, 96
+    for B, scale in ((64, 0.25), (3, 0.25), (64, 0.42)):  # MW / one-wave workgroups; degree-16 and degree-18 variants
+        h0 = np.diag(rng.uniform(0, 1, D)).astype(np.complex128) + herm(0.02)
+        hks = np.stack([herm(0.3) for _ in range(K)])
+        sig = rng.uniform(-1, 1, size=(B, K, N))
+        dt = scale * 2.0**squarings
+        ph = rng.uniform(0, 6.28, size=(B, D))
+        t = lambda a: torch.as_tensor(a, device="cuda:0")
+        U = prop.propagate_batch(t(h0), t(hks), t(sig), dt, fr_phase=t(ph))["U"].cpu().numpy()
+        assert "true>" in _lib.last_kernel_detail()  # SPLIT instance
+        ref = c3_oracle.propagate_batch(h0, hks, sig, dt, fr_phase=ph)
+        err = max(np.linalg.norm(U[b] - ref[b]) for b in range(B))
+        assert err < 2e-12 * max(1.0, 2.0**squarings), (B, scale, squarings, err)

@@ -21,10 +21,16 @@ def tile_utilisation(Dm, kernel):
         # core + border form of the real path (round 4): the (Dm-1)^2 core tiles exactly; of the matrix instructions of a slice
         # (degree-16 variant: 7 symmetric products of NC^2 (NC+1)/2, the chain step's 3 NC^3 core and 3 NC^2 row-border ones)
         # only the row-border instructions of the chain step carry padding (one of four A rows)
+        # round 6: the border sums run on the matrix cores as well -- per slice (degree-16 variant) 7 symmetric products of
+        # NC^2 (NC+1)/2 exact core instructions + (NC + 1) reductions against a tile of ones each, the chain step's 3 NC^3 core,
+        # 3 NC^2 row-border (the border row in all four rows of the A tile: 1/4 useful) and 2 (NC + 1) reduction instructions.
+        # A reduction instruction adds 4 x 4 partial products to 4 sums per block: 12 useful additions of its 128 flops.
         nc = (Dm - 1) // 4
         sym, core, row = 7 * nc * nc * (nc + 1) // 2, 3 * nc**3, 3 * nc * nc
-        return (sym + core + 0.25 * row) / (sym + core + row), (f"small-D kernel, core + border form: {sym} + {core} exact core MFMAs and {row} row-border "
-                                                                f"MFMAs at 1/4 per slice (degree-16 variant); the borders run on the vector unit")
+        red = 7 * (nc + 1) + 2 * (nc + 1)
+        return (sym + core + 0.25 * row + (12.0 / 128.0) * red) / (sym + core + row + red), (
+            f"small-D kernel, core + border form: {sym} + {core} exact core MFMAs, {row} row-border MFMAs at 1/4 and {red} "
+            f"reduction MFMAs at 12/128 per slice (degree-16 variant)")
     if Dm <= 12:
         p = 4 * ((Dm + 3) // 4)
         kk = 1.0 if Dm % 4 == 1 else Dm / p
@@ -82,6 +88,9 @@ def main():
         "kernel": dom[:160],
         "launches_in_trace": len(dur[dom]),
         "avg_launch_us": sum(dur[dom]) / len(dur[dom]) / 1e3,
+        # (the mean takes in the launches of the clock ramp; the median is the steady launch)
+        "median_launch_us": sorted(dur[dom])[len(dur[dom]) // 2] / 1e3,
+        "min_launch_us": min(dur[dom]) / 1e3,
         "batch": hi - lo,
         "slices": c["N"],
         "kernel_sources_digest": bench.kernel_sources_digest(cfg),
@@ -121,6 +130,26 @@ def main():
             out["launch_cycles"] = cyc
             out["mfma_busy_frac"] = avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0)
             out["issued_frac_of_fp64_peak"] = out.get("issued_flop_per_launch", 0.0) / (cyc * 1024.0 * 32.0)
+            # VERDICT r5 item 1 asked for a shared-pipe busy figure.  No counter gives vector-unit busy CYCLES on gfx950
+            # (SQ_ACTIVE_INST_VALU counts instructions: it equals SQ_INSTS_VALU, which INCLUDES the matrix instructions --
+            # checked on tools/ubench_coissue.hip), so the figure is instruction counts x MEASURED issue costs
+            # (profiles/r06/ubench_coissue.txt, ubench_valu64.txt: a SIMD issues matrix and vector instructions one after the
+            # other, nothing overlaps; v_mfma_f64_4x4x4_4b 16.7 cycles, 16x16x4 65.1; an fp64 vector instruction 5.8 with two waves
+            # per SIMD (4.8 - 6.4 by operand form; 8.2 with ONE wave, 5.3 with four); other vector instructions 2.6 - 4.5, priced 3.5)
+            n_mfma = avg.get("SQ_INSTS_MFMA", 0.0)
+            n_f64 = avg.get("SQ_INSTS_VALU_FMA_F64", 0.0) + avg.get("SQ_INSTS_VALU_ADD_F64", 0.0) + avg.get("SQ_INSTS_VALU_MUL_F64", 0.0)
+            n_other = max(0.0, avg.get("SQ_INSTS_VALU", 0.0) - n_mfma - n_f64)
+            waves_per_simd = max(1.0, meta.get("workgroup", 64) / 64.0 / 4.0) if meta else 2.0
+            mops = avg.get("SQ_INSTS_VALU_MFMA_MOPS_F64") or n_mfma
+            c_mfma = 16.7 * (mops / n_mfma) if n_mfma else 16.7  # (a 16x16x4 instruction is four 512-flop units: 65 cycles)
+            c_f64 = 8.2 if waves_per_simd < 1.5 and meta.get("vgpr", 0) + meta.get("agpr", 0) > 256 else 5.8
+            busy = n_mfma * c_mfma + n_f64 * c_f64 + n_other * 3.5
+            out["issue_busy_model"] = {
+                "mfma": n_mfma * c_mfma / (cyc * 1024.0), "valu_f64": n_f64 * c_f64 / (cyc * 1024.0), "valu_other": n_other * 3.5 / (cyc * 1024.0),
+                "total": busy / (cyc * 1024.0), "cycles_per_mfma": c_mfma, "cycles_per_f64_valu": c_f64, "cycles_per_other_valu": 3.5,
+                "instructions_per_launch": {"mfma": n_mfma, "valu_f64": n_f64, "valu_other": n_other},
+                "note": "fraction of the SIMD cycles of the launch taken by the serialised issue of matrix + vector instructions (counts x measured costs)",
+            }
     print(json.dumps(out, indent=1))
 
 
