@@ -72,10 +72,10 @@ def test_bench_two_ranks_on_the_visible_devices(lib):
 
 
 def test_design_tables_are_generated_from_the_committed_profiles():
-    """DESIGN.md's measurement tables are the output of tools/design_tables.py over profiles/r05/*.json"""
+    """DESIGN.md's measurement tables are the output of tools/design_tables.py over profiles/r06/*.json"""
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "design_tables.py"), "r05", "--check"], capture_output=True, text=True)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "design_tables.py"), "r06", "--check"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr

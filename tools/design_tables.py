@@ -27,9 +27,16 @@ def f3(x, nd=3):
     return f"{x:.{nd}g}"
 
 
+def busy(r):
+    m = r.get("issue_busy_model")
+    if not m:
+        return ""
+    return f"{m['total']:.2f} = {m['mfma']:.2f} + {m['valu_f64']:.2f} + {m['valu_other']:.2f}"
+
+
 def bench_table(rnd):
-    out = ["| config | batch / GPU | kernel | propagators/s | ms / step | frac (useful issued) | issued / peak | tile utilisation | frac_algorithmic | HBM-side bytes / launch | max_b err vs oracle |",
-           "|---|---|---|---|---|---|---|---|---|---|---|"]
+    out = ["| config | batch / GPU | kernel | propagators/s | ms / step | frac (useful issued) | issued / peak | tile utilisation | issue busy (model: MFMA + fp64 VALU + other) | frac_algorithmic | HBM-side bytes / launch | max_b err vs oracle |",
+           "|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for tag, fn in (("cfg1", "bench_cfg1.json"), ("**cfg2 (headline)**", "bench_cfg2.json"), ("cfg2, complex control operator", "bench_cfg2_complex.json"),
                     ("cfg3", "bench_cfg3.json"), ("cfg4", "bench_cfg4.json"), ("cfg5", "bench_cfg5.json")):
         d = load(rnd, fn)
@@ -39,7 +46,7 @@ def bench_table(rnd):
         tr = r.get("traffic")
         trs = "" if tr is None else (f"{tr / 1e6:.1f} MB" if tr < 1e9 else f"{tr / 1e9:.2f} GB")
         out.append(f"| {tag}: {d['config']['workload']} | {d['config']['batch_per_gpu']} | {d['config'].get('kernel', '')} | {f3(d['value'], 4)} | {f3(d['ms_per_step'], 4)} | "
-                   f"{f3(r.get('frac'))} | {f3(r.get('issued_frac'))} | {f3(r.get('mfma_tile_utilisation'), 4)} | {f3(r.get('frac_algorithmic'))} | {trs} | "
+                   f"{f3(r.get('frac'))} | {f3(r.get('issued_frac'))} | {f3(r.get('mfma_tile_utilisation'), 4)} | {busy(r)} | {f3(r.get('frac_algorithmic'))} | {trs} | "
                    f"{f3(d.get('max_fro_err_vs_oracle'), 2)} |")
     return "\n".join(out)
 
