@@ -200,6 +200,20 @@ __constant__ double c3p_inv_fact[22] = {
     1.0 / 51090942171709440000.0,
 };
 
+// Economised cos / sin polynomials of the real path (round 6; tools/gen_minimax_cossin.py, exact rational arithmetic): for a real
+// symmetric Y with ||Y|| <= theta the spectrum of W = Y^2 lies in [0, theta^2] and ||p(W) - f(W)||_2 is the scalar error on that
+// interval (Y is normal), so cos(sqrt w) and sin(sqrt w) / sqrt w are replaced by the Chebyshev-economised degree-6 / degree-7
+// polynomials on [0, theta^2]: the same accuracy as the degree-8 Taylor polynomials at theta_16 = 0.816 with ONE PRODUCT LESS
+// (degree 6: powers to W^3), and theta = 1.30 instead of 1.13 for the degree-7 pair (powers to W^4, no W^4 term in the factor).
+// degree 6, ||Y|| <= 0.83: error bound (dropped Chebyshev mass) cos 1.02e-16, sin / Y 6.81e-18
+#define C3P_MM6_THETA 0.83
+__constant__ double c3p_mm6_cos[7] = {0x1.fffffffffffffp-1, -0x1.ffffffffffefbp-2, 0x1.5555555549783p-5, -0x1.6c16c15f2ae1ep-10, 0x1.a019f4383856bp-16, -0x1.27ddd6f90d4c9p-22, 0x1.1b266723fe85ap-29};
+__constant__ double c3p_mm6_sinc[7] = {0x1.0000000000000p+0, -0x1.5555555555532p-3, 0x1.111111110de63p-7, -0x1.a01a019933c31p-13, 0x1.71de332d191bcp-19, -0x1.ae5cb6388e6d3p-26, 0x1.5d1c004547c53p-33};
+// degree 7, ||Y|| <= 1.3: error bound (dropped Chebyshev mass) cos 9.48e-17, sin / Y 5.59e-18
+#define C3P_MM7_THETA 1.3
+__constant__ double c3p_mm7_cos[8] = {0x1.fffffffffffffp-1, -0x1.fffffffffff7fp-2, 0x1.5555555552310p-5, -0x1.6c16c16a3a84dp-10, 0x1.a01a008b1794dp-16, -0x1.27e4a3ee8ce57p-22, 0x1.1ecee25c752dfp-29, -0x1.885f3ce855c89p-37};
+__constant__ double c3p_mm7_sinc[8] = {0x1.0000000000000p+0, -0x1.5555555555546p-3, 0x1.1111111110536p-7, -0x1.a01a019f395fdp-13, 0x1.71de39d2c6922p-19, -0x1.ae6403f077f9dp-26, 0x1.610774ce48dc0p-33, -0x1.a3ec628c31277p-41};
+
 // Launch log of the current API call of this thread (c3p_last_kernel_detail; INTEGRATION.md's dispatch table is generated from
 // it by tools/dispatch_table.py): every kernel launch of the library goes through C3P_LAUNCH, which notes the kernel's host
 // function and the source file before handing over to hipLaunchKernelGGL.  A pointer store per launch; names are resolved

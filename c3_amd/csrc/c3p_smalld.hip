@@ -1284,11 +1284,32 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
           sco[I] = (2 * (4 * I + lp.c) + 1) * W + (D - 1);
         }
         constexpr int sso = (2 * (D - 1) + 1) * W + (D - 1);
+#ifndef C3P_SD_QUADSUM
+        // Round 6: the ECONOMISED polynomials of c3p_common.h (Y is real symmetric, so the polynomial error on [0, theta^2] IS the
+        // matrix error).  Scaling against theta_7 = 1.30; a scaled norm below theta_6 = 0.83 (cfg2: 0.81) takes the degree-6 pair:
+        // W, W^2, W^3, ONE paired Horner step in W^3, sin = (sin Y / Y) Y -- 6 products at dependency depth 5 (the degree-8 Taylor
+        // pair needed W^4: 7); above it the degree-7 pair with W^4 (7 products where the degree-9 / 8 Taylor pair took 8).
+        int ps_s = 0;
+        {
+          double p = C3P_MM7_THETA;
+          while (p < nrm && ps_s < 40) {
+            p *= 2.0;
+            ++ps_s;
+          }
+        }
+        ps_s = __builtin_amdgcn_readfirstlane(ps_s);
+        const double rscale_s = ldexp(1.0, -ps_s);
+        const bool small_var = __builtin_amdgcn_readfirstlane((int)(nrm * rscale_s <= C3P_MM6_THETA)) != 0;
+#else
+        const int ps_s = ps18;
+        const double rscale_s = rscale;
+        const bool small_var = deg16;
+#endif
         auto split_loop = [&](auto deg16_tag) {
-          constexpr bool DEG16 = decltype(deg16_tag)::value;
+          constexpr bool DEG16 = decltype(deg16_tag)::value;  // (round-6 build: true = the degree-6 pair, false = the degree-7 pair)
           for (int t = 0; t < tmax; ++t) {
             const bool act = valid && t < len;
-            const double sc = act ? rscale : 0.0;
+            const double sc = act ? rscale_s : 0.0;
             const double muw = act ? 1.0 : 0.0;
             double mu_r = muw * tab[MAT + 0], mu_i = muw * tab[MAT + 1];
             SM Y;
@@ -1324,12 +1345,12 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
             s8_finish(W1, swap_lane, tail_lane);
             mm_s8(W1, W1, W2);  // W^2
             s8_finish(W2, swap_lane, tail_lane);
+#ifdef C3P_SD_QUADSUM
             if constexpr (DEG16) {
               SM W4;
               s8_zero(W4);
               mm_s8(W1, W2, W3);
               mm_s8(W2, W2, W4);
-#ifdef C3P_SD_QUADSUM
               s8_finish(W3, swap_lane, tail_lane);
               s8_finish(W4, swap_lane, tail_lane);
               s8_comb<NC, true>(acc, c3p_inv_fact[8], -c3p_inv_fact[10], c3p_inv_fact[12], -c3p_inv_fact[14], W1, W2, W3, lp);
@@ -1351,32 +1372,6 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
               s8_comb<NC, true, true>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], -c3p_inv_fact[6], W1, W2, W3, lp);
               s8_comb<NC, true, true>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7], W1, W2, W3, lp);
               mm_s8x2(W4, acc, Cm, acs, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
-#else
-              // (round 6) the Horner factors B1 = c8 - c10 W + c12 W^2 - c14 W^3 + c16 W^4 are the LEFT operands of the paired
-              // product (everything commutes): they are combined on the 6 registers a product accumulates into (upper core
-              // tiles, r-form border, corner) and completed by ONE lane swap each; W^3 is never a product operand, so it is not
-              // completed at all; W^4 is the shared right operand
-              s8_finish(W4, swap_lane, tail_lane);
-              s8_comb<NC, true, true>(acc, c3p_inv_fact[8], -c3p_inv_fact[10], c3p_inv_fact[12], -c3p_inv_fact[14], W1, W2, W3, lp);
-              s8_comb<NC, true, true>(acs, c3p_inv_fact[9], -c3p_inv_fact[11], c3p_inv_fact[13], -c3p_inv_fact[15], W1, W2, W3, lp);
-#pragma unroll
-              for (int I = 0; I < NC; ++I) {
-#pragma unroll
-                for (int J = I; J < NC; ++J) {
-                  acc.m[I][J] = fma(c3p_inv_fact[16], W4.m[I][J], acc.m[I][J]);
-                  acs.m[I][J] = fma(c3p_inv_fact[17], W4.m[I][J], acs.m[I][J]);
-                }
-                acc.vr[I] = fma(c3p_inv_fact[16], W4.vr[I], acc.vr[I]);
-                acs.vr[I] = fma(c3p_inv_fact[17], W4.vr[I], acs.vr[I]);
-              }
-              acc.s = fma(c3p_inv_fact[16], W4.s, acc.s);
-              acs.s = fma(c3p_inv_fact[17], W4.s, acs.s);
-              s8_finish_lower(acc, swap_lane);
-              s8_finish_lower(acs, swap_lane);
-              s8_comb<NC, true, true>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], -c3p_inv_fact[6], W1, W2, W3, lp);
-              s8_comb<NC, true, true>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7], W1, W2, W3, lp);
-              mm_s8x2r(acc, acs, W4, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
-#endif
             } else {
               mm_s8(W1, W2, W3);  // W^3
               s8_finish(W3, swap_lane, tail_lane);
@@ -1391,6 +1386,37 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
               s8_comb<NC, false, true>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], 0.0, W1, W2, W3, lp);
               mm_s8x2(W3, acc, Cm, acs, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
             }
+#else
+            // The Horner factors are the LEFT operands of the paired product (everything commutes): they are combined on the 6
+            // registers a product accumulates into (upper core tiles, r-form border, corner) and completed by ONE lane swap each;
+            // the shared right operand (W^3 / W^4) is completed in full; a power that is never a product operand is not completed.
+            if constexpr (DEG16) {
+              // degree 6: cos = (c0 + c1 W + c2 W^2) + W^3 (c3 + c4 W + c5 W^2 + c6 W^3)
+              mm_s8(W1, W2, W3);
+              s8_finish(W3, swap_lane, tail_lane);
+              s8_comb<NC, true, true>(acc, c3p_mm6_cos[3], c3p_mm6_cos[4], c3p_mm6_cos[5], c3p_mm6_cos[6], W1, W2, W3, lp);
+              s8_comb<NC, true, true>(acs, c3p_mm6_sinc[3], c3p_mm6_sinc[4], c3p_mm6_sinc[5], c3p_mm6_sinc[6], W1, W2, W3, lp);
+              s8_finish_lower(acc, swap_lane);
+              s8_finish_lower(acs, swap_lane);
+              s8_comb<NC, false, true>(Cm, c3p_mm6_cos[0], c3p_mm6_cos[1], c3p_mm6_cos[2], 0.0, W1, W2, W3, lp);
+              s8_comb<NC, false, true>(Sp, c3p_mm6_sinc[0], c3p_mm6_sinc[1], c3p_mm6_sinc[2], 0.0, W1, W2, W3, lp);
+              mm_s8x2r(acc, acs, W3, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
+            } else {
+              // degree 7: cos = (c0 + c1 W + c2 W^2 + c3 W^3) + W^4 (c4 + c5 W + c6 W^2 + c7 W^3); W^3 is not a product operand
+              SM W4;
+              s8_zero(W4);
+              mm_s8(W1, W2, W3);
+              mm_s8(W2, W2, W4);
+              s8_finish(W4, swap_lane, tail_lane);
+              s8_comb<NC, true, true>(acc, c3p_mm7_cos[4], c3p_mm7_cos[5], c3p_mm7_cos[6], c3p_mm7_cos[7], W1, W2, W3, lp);
+              s8_comb<NC, true, true>(acs, c3p_mm7_sinc[4], c3p_mm7_sinc[5], c3p_mm7_sinc[6], c3p_mm7_sinc[7], W1, W2, W3, lp);
+              s8_finish_lower(acc, swap_lane);
+              s8_finish_lower(acs, swap_lane);
+              s8_comb<NC, true, true>(Cm, c3p_mm7_cos[0], c3p_mm7_cos[1], c3p_mm7_cos[2], c3p_mm7_cos[3], W1, W2, W3, lp);
+              s8_comb<NC, true, true>(Sp, c3p_mm7_sinc[0], c3p_mm7_sinc[1], c3p_mm7_sinc[2], c3p_mm7_sinc[3], W1, W2, W3, lp);
+              mm_s8x2r(acc, acs, W4, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
+            }
+#endif
 #ifdef C3P_SD_QUADSUM
             s8_finish(Cm, swap_lane, tail_lane);
             s8_finish(Sp, swap_lane, tail_lane);
@@ -1405,13 +1431,13 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
             s8_zero(acc);
             mm_s8(Sp, Y, acc);  // acc = sin Y
             s8_finish_lower(acc, swap_lane);
-            if (ps18 > 0 || t == 0) {
+            if (ps_s > 0 || t == 0) {
               s8_finish_vc(Cm, tail_lane);
               s8_finish_vc(acc, tail_lane);
             }
 #endif
             // squarings: cos 2Y = (C - S)(C + S), sin 2Y = 2 S C
-            for (int it = 0; it < ps18; ++it) {
+            for (int it = 0; it < ps_s; ++it) {
               SM Dm, Sm, C2, SC;
 #pragma unroll
               for (int I = 0; I < NC; ++I) {
@@ -1479,7 +1505,7 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
             }
           }
         };
-        if (deg16)
+        if (small_var)
           split_loop(std::true_type{});
         else
           split_loop(std::false_type{});
