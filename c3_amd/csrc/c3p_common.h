@@ -213,6 +213,11 @@ __constant__ double c3p_mm6_sinc[7] = {0x1.0000000000000p+0, -0x1.5555555555532p
 #define C3P_MM7_THETA 1.3
 __constant__ double c3p_mm7_cos[8] = {0x1.fffffffffffffp-1, -0x1.fffffffffff7fp-2, 0x1.5555555552310p-5, -0x1.6c16c16a3a84dp-10, 0x1.a01a008b1794dp-16, -0x1.27e4a3ee8ce57p-22, 0x1.1ecee25c752dfp-29, -0x1.885f3ce855c89p-37};
 __constant__ double c3p_mm7_sinc[8] = {0x1.0000000000000p+0, -0x1.5555555555546p-3, 0x1.1111111110536p-7, -0x1.a01a019f395fdp-13, 0x1.71de39d2c6922p-19, -0x1.ae6403f077f9dp-26, 0x1.610774ce48dc0p-33, -0x1.a3ec628c31277p-41};
+// degree 8, ||Y|| <= 1.85: error bound cos 7.36e-17, sin / Y 3.89e-18 -- the product structure of the degree-8 Taylor pair (powers to W^4,
+// theta_16 = 0.816) at more than twice its radius: cfg3 (1.32) and cfg5 (1.47) need no squaring with it
+#define C3P_MM8_THETA 1.85
+__constant__ double c3p_mm8_cos[9] = {0x1.fffffffffffffp-1, -0x1.fffffffffffc1p-2, 0x1.555555555460bp-5, -0x1.6c16c16bbaf0ap-10, 0x1.a01a017d9204bp-16, -0x1.27e4f42b216adp-22, 0x1.1eebbeaf2fd74p-29, -0x1.931094adecb53p-37, 0x1.99564aa7ce940p-45};
+__constant__ double c3p_mm8_sinc[9] = {0x1.0000000000000p+0, -0x1.555555555554fp-3, 0x1.1111111110dd6p-7, -0x1.a01a019ff3325p-13, 0x1.71de3a46d43f1p-19, -0x1.ae6450543683bp-26, 0x1.6122d8e56c0d7p-33, -0x1.ae0d75ffe9679p-41, 0x1.83508886d45cep-49};
 
 // Launch log of the current API call of this thread (c3p_last_kernel_detail; INTEGRATION.md's dispatch table is generated from
 // it by tools/dispatch_table.py): every kernel launch of the library goes through C3P_LAUNCH, which notes the kernel's host

@@ -990,19 +990,20 @@ __device__ __forceinline__ void midd_real_body(const MidArgs& A, const MidCommon
       Regs W4;
       zero(W4);
       mm_real<NIGR, NJ, W, WV, 2, 1, 2, 2, 2>(cm, W3, W4);
-      rc(acc, c3p_inv_fact[8], -c3p_inv_fact[10], c3p_inv_fact[12], -c3p_inv_fact[14]);
-      rc(acs, c3p_inv_fact[9], -c3p_inv_fact[11], c3p_inv_fact[13], -c3p_inv_fact[15]);
+      // (round 6: the ECONOMISED degree-8 pair of c3p_common.h -- same products, valid to ||Y|| = 1.85 instead of 0.816)
+      rc(acc, c3p_mm8_cos[4], c3p_mm8_cos[5], c3p_mm8_cos[6], c3p_mm8_cos[7]);
+      rc(acs, c3p_mm8_sinc[4], c3p_mm8_sinc[5], c3p_mm8_sinc[6], c3p_mm8_sinc[7]);
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
-        acc.set(e, fma(c3p_inv_fact[16], W4.get(e), acc.get(e)));
-        acs.set(e, fma(c3p_inv_fact[17], W4.get(e), acs.get(e)));
+        acc.set(e, fma(c3p_mm8_cos[8], W4.get(e), acc.get(e)));
+        acs.set(e, fma(c3p_mm8_sinc[8], W4.get(e), acs.get(e)));
       }
       store_tiles(IC<3>{}, W4);
       store_tiles(IC<0>{}, acc);
       store_tiles(IC<4>{}, acs);
       md_bar();
-      rc(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], -c3p_inv_fact[6]);
-      rc(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7]);
+      rc(Cm, c3p_mm8_cos[0], c3p_mm8_cos[1], c3p_mm8_cos[2], c3p_mm8_cos[3]);
+      rc(Sp, c3p_mm8_sinc[0], c3p_mm8_sinc[1], c3p_mm8_sinc[2], c3p_mm8_sinc[3]);
       mm_real<NIGR, NJ, W, WV, 1, 3, 3, 0, 4>(cm, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
       store_tiles(IC<1>{}, Sp);
       store_tiles(IC<2>{}, Y);
@@ -1523,7 +1524,9 @@ __global__ void __launch_bounds__(256, (REAL ? (Sched<MDR<NIG, W>::NIGR, NJ>::PW
         }
         return s;
       };
-      const int s16 = squarings(8.16e-1), s18 = squarings(C3P_T18_THETA), s20 = squarings(1.49);
+      // Round 6: the 7-product variant evaluates the Chebyshev-economised degree-8 polynomials (theta = 1.85: Y is real symmetric,
+      // so the scalar error on [0, theta^2] is the matrix error) -- it dominates the degree-18 / 20 Taylor variants below
+      const int s16 = squarings(C3P_MM8_THETA), s18 = squarings(C3P_T18_THETA), s20 = squarings(1.49);
       int var = 1, s = s16, cost = 7 + 2 * s16;
       if (8 + 2 * s18 < cost) var = 0, s = s18, cost = 8 + 2 * s18;
       // (degree 20 only in the 16- and 32-row classes: at D >= 33 its extra dependent product and two more live tile sets

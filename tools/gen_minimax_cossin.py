@@ -4,17 +4,17 @@
 For a real symmetric Y with ||Y|| <= theta the spectrum of W = Y^2 lies in [0, L], L = theta^2, and for ANY polynomial p
     || p(W) - f(W) ||_2 = max over the spectrum | p(w) - f(w) |        (Y is normal),
 so f(w) = cos(sqrt w) and g(w) = sin(sqrt w) / sqrt w may be replaced by their best polynomials on [0, L] instead of Taylor
-polynomials.  Chebyshev economisation of the degree-14 Taylor polynomials (remainder < 1e-25 for theta <= 1.4): expand in shifted
+polynomials.  Chebyshev economisation of the degree-20 Taylor polynomials (remainder < 1e-25 for theta <= 2): expand in shifted
 Chebyshev polynomials on [0, L], drop everything above degree d; the error is bounded by the sum of the dropped coefficients'
 moduli (printed).  Degree 6 reaches 1e-16 at theta = 0.83 (the degree-8 Taylor polynomials need theta_16 = 0.816 and ONE MORE
-product: W^4), degree 7 at theta = 1.33 (the degree-9/8 Taylor pair, theta = 1.13, needs 8 products).
+product: W^4), degree 7 at theta = 1.30 (the degree-9/8 Taylor pair, theta = 1.13, needs 8 products), degree 8 at theta = 1.85.
 
     python tools/gen_minimax_cossin.py            # prints the C tables pasted into c3_amd/csrc/c3p_common.h
 """
 from fractions import Fraction as F
 from math import comb, factorial
 
-M = 14
+M = 20
 
 
 def cheb_T(n):
@@ -61,7 +61,7 @@ def tables(theta, deg):
 
 
 if __name__ == "__main__":
-    for name, theta, deg in (("C3P_MM6", F(83, 100), 6), ("C3P_MM7", F(133, 100), 7)):
+    for name, theta, deg in (("C3P_MM6", F(83, 100), 6), ("C3P_MM7", F(130, 100), 7), ("C3P_MM8", F(185, 100), 8)):
         pc, ps, dc, ds = tables(theta, deg)
         print(f"// degree {deg} in W = Y^2 on ||Y|| <= {float(theta)}: dropped Chebyshev mass cos {dc:.2e}, sin/Y {ds:.2e}")
         print(f"#define {name}_THETA {float(theta)!r}")
@@ -69,7 +69,7 @@ if __name__ == "__main__":
         print(f"__device__ __constant__ const double c3p_{name[4:].lower()}_sinc[{deg + 1}] = {{" + ", ".join(float(x).hex() for x in ps) + "};")
         print("//   cos :", ", ".join(f"{float(x):.17e}" for x in pc))
         print("//   sinc:", ", ".join(f"{float(x):.17e}" for x in ps))
-    for th in (0.83, 0.85, 1.2, 1.3, 1.33, 1.35, 1.4):
-        for deg in (6, 7):
+    for th in (0.83, 0.85, 1.2, 1.3, 1.33, 1.8, 1.85, 1.9):
+        for deg in (6, 7, 8):
             _, _, dc, ds = tables(F(th).limit_denominator(1000), deg)
             print(f"// theta {th}: degree {deg}: cos {dc:.2e} sinc {ds:.2e}")

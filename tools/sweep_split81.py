@@ -14,7 +14,7 @@ def run(reps=300):
     for _ in range(reps): bp.run()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-for skew in (660, 680, 700, 710, 720, 740):
+for skew in (640, 660, 680, 700, 720, 740):
     _lib.set_option("mw_skew", skew)
     print("skew", skew, "ms", round(min(run(), run()), 5), flush=True)
 _lib.set_option("mw_skew", None)
