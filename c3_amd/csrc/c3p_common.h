@@ -205,18 +205,19 @@ __constant__ double c3p_inv_fact[22] = {
 // interval (Y is normal), so cos(sqrt w) and sin(sqrt w) / sqrt w are replaced by the Chebyshev-economised degree-6 / degree-7
 // polynomials on [0, theta^2]: the same accuracy as the degree-8 Taylor polynomials at theta_16 = 0.816 with ONE PRODUCT LESS
 // (degree 6: powers to W^3), and theta = 1.30 instead of 1.13 for the degree-7 pair (powers to W^4, no W^4 term in the factor).
-// degree 6, ||Y|| <= 0.83: error bound (dropped Chebyshev mass) cos 1.02e-16, sin / Y 6.81e-18
+// (constant terms set to 1 exactly, so that exp(0) = I: idle slices, zero Hamiltonians; the bounds include that shift)
+// degree 6, ||Y|| <= 0.83: error bound cos 2.0e-16, sin / Y 1.4e-17
 #define C3P_MM6_THETA 0.83
-__constant__ double c3p_mm6_cos[7] = {0x1.fffffffffffffp-1, -0x1.ffffffffffefbp-2, 0x1.5555555549783p-5, -0x1.6c16c15f2ae1ep-10, 0x1.a019f4383856bp-16, -0x1.27ddd6f90d4c9p-22, 0x1.1b266723fe85ap-29};
+__constant__ double c3p_mm6_cos[7] = {0x1.0000000000000p+0, -0x1.ffffffffffefbp-2, 0x1.5555555549783p-5, -0x1.6c16c15f2ae1ep-10, 0x1.a019f4383856bp-16, -0x1.27ddd6f90d4c9p-22, 0x1.1b266723fe85ap-29};
 __constant__ double c3p_mm6_sinc[7] = {0x1.0000000000000p+0, -0x1.5555555555532p-3, 0x1.111111110de63p-7, -0x1.a01a019933c31p-13, 0x1.71de332d191bcp-19, -0x1.ae5cb6388e6d3p-26, 0x1.5d1c004547c53p-33};
-// degree 7, ||Y|| <= 1.3: error bound (dropped Chebyshev mass) cos 9.48e-17, sin / Y 5.59e-18
+// degree 7, ||Y|| <= 1.3: error bound cos 1.9e-16, sin / Y 1.1e-17
 #define C3P_MM7_THETA 1.3
-__constant__ double c3p_mm7_cos[8] = {0x1.fffffffffffffp-1, -0x1.fffffffffff7fp-2, 0x1.5555555552310p-5, -0x1.6c16c16a3a84dp-10, 0x1.a01a008b1794dp-16, -0x1.27e4a3ee8ce57p-22, 0x1.1ecee25c752dfp-29, -0x1.885f3ce855c89p-37};
+__constant__ double c3p_mm7_cos[8] = {0x1.0000000000000p+0, -0x1.fffffffffff7fp-2, 0x1.5555555552310p-5, -0x1.6c16c16a3a84dp-10, 0x1.a01a008b1794dp-16, -0x1.27e4a3ee8ce57p-22, 0x1.1ecee25c752dfp-29, -0x1.885f3ce855c89p-37};
 __constant__ double c3p_mm7_sinc[8] = {0x1.0000000000000p+0, -0x1.5555555555546p-3, 0x1.1111111110536p-7, -0x1.a01a019f395fdp-13, 0x1.71de39d2c6922p-19, -0x1.ae6403f077f9dp-26, 0x1.610774ce48dc0p-33, -0x1.a3ec628c31277p-41};
-// degree 8, ||Y|| <= 1.85: error bound cos 7.36e-17, sin / Y 3.89e-18 -- the product structure of the degree-8 Taylor pair (powers to W^4,
+// degree 8, ||Y|| <= 1.85: error bound cos 1.5e-16, sin / Y 7.8e-18 -- the product structure of the degree-8 Taylor pair (powers to W^4,
 // theta_16 = 0.816) at more than twice its radius: cfg3 (1.32) and cfg5 (1.47) need no squaring with it
 #define C3P_MM8_THETA 1.85
-__constant__ double c3p_mm8_cos[9] = {0x1.fffffffffffffp-1, -0x1.fffffffffffc1p-2, 0x1.555555555460bp-5, -0x1.6c16c16bbaf0ap-10, 0x1.a01a017d9204bp-16, -0x1.27e4f42b216adp-22, 0x1.1eebbeaf2fd74p-29, -0x1.931094adecb53p-37, 0x1.99564aa7ce940p-45};
+__constant__ double c3p_mm8_cos[9] = {0x1.0000000000000p+0, -0x1.fffffffffffc1p-2, 0x1.555555555460bp-5, -0x1.6c16c16bbaf0ap-10, 0x1.a01a017d9204bp-16, -0x1.27e4f42b216adp-22, 0x1.1eebbeaf2fd74p-29, -0x1.931094adecb53p-37, 0x1.99564aa7ce940p-45};
 __constant__ double c3p_mm8_sinc[9] = {0x1.0000000000000p+0, -0x1.555555555554fp-3, 0x1.1111111110dd6p-7, -0x1.a01a019ff3325p-13, 0x1.71de3a46d43f1p-19, -0x1.ae6450543683bp-26, 0x1.6122d8e56c0d7p-33, -0x1.ae0d75ffe9679p-41, 0x1.83508886d45cep-49};
 
 // Launch log of the current API call of this thread (c3p_last_kernel_detail; INTEGRATION.md's dispatch table is generated from

@@ -1939,7 +1939,7 @@ struct MGR {
 
 __device__ __forceinline__ int mgr_squarings(double nrm) {
   int ps = 0;
-  double p = 8.16e-1;
+  double p = C3P_MM8_THETA;  // round 6: the economised degree-8 pair (c3p_common.h) instead of theta_16 = 0.816
   while (p < nrm && ps < 40) {
     p *= 2.0;
     ++ps;
@@ -2585,6 +2585,10 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
         out.set(e, fma(c0, dmask(e), v));
       }
     };
+    // coefficients of W^j in cos Y / (sin Y / Y): Taylor for the degree-20 variant, the economised degree-8 pair (theta = 1.85,
+    // c3p_common.h) otherwise -- forward evaluation and its adjoint below use the same table
+    auto ca = [&](int j) { return DEG20 ? ((j & 1) ? -c3p_inv_fact[2 * j] : c3p_inv_fact[2 * j]) : c3p_mm8_cos[j]; };
+    auto sa = [&](int j) { return DEG20 ? ((j & 1) ? -c3p_inv_fact[2 * j + 1] : c3p_inv_fact[2 * j + 1]) : c3p_mm8_sinc[j]; };
     // the power the Horner step runs in: W^4 (degree 16), W^5 = W^2 W^3 (degree 20, theta_20 = 1.49: one squaring less)
     Regs H;
     if constexpr (DEG20) {
@@ -2605,20 +2609,20 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
       st(IC<7>{}, H);
     } else {
       H = W4;
-      rc(acc, c3p_inv_fact[8], -c3p_inv_fact[10], c3p_inv_fact[12], -c3p_inv_fact[14]);
-      rc(acs, c3p_inv_fact[9], -c3p_inv_fact[11], c3p_inv_fact[13], -c3p_inv_fact[15]);
+      rc(acc, ca(4), ca(5), ca(6), ca(7));
+      rc(acs, sa(4), sa(5), sa(6), sa(7));
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
-        acc.set(e, fma(c3p_inv_fact[16], W4.get(e), acc.get(e)));
-        acs.set(e, fma(c3p_inv_fact[17], W4.get(e), acs.get(e)));
+        acc.set(e, fma(ca(8), W4.get(e), acc.get(e)));
+        acs.set(e, fma(sa(8), W4.get(e), acs.get(e)));
       }
       st(IC<7>{}, H);
     }
     st(IC<4>{}, acc);
     st(IC<5>{}, acs);
     md_bar();
-    rc(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], -c3p_inv_fact[6]);
-    rc(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7]);
+    rc(Cm, ca(0), ca(1), ca(2), ca(3));
+    rc(Sp, sa(0), sa(1), sa(2), sa(3));
     if constexpr (DEG20) {
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
@@ -2814,10 +2818,10 @@ __device__ __forceinline__ void midd_grad_real_body(const MidGradArgs& A, const 
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
         const double ab = accb.get(e), sb = acsb.get(e), cb = Cb.get(e), pb = Spb.get(e);
-        W1b.set(e, -(c3p_inv_fact[2] * cb + c3p_inv_fact[3] * pb + c3p_inv_fact[10] * ab + c3p_inv_fact[11] * sb));
-        W2b.set(e, c3p_inv_fact[4] * cb + c3p_inv_fact[5] * pb + c3p_inv_fact[12] * ab + c3p_inv_fact[13] * sb);
-        W3b.set(e, -(c3p_inv_fact[6] * cb + c3p_inv_fact[7] * pb + c3p_inv_fact[14] * ab + c3p_inv_fact[15] * sb));
-        W4b.set(e, 0.5 * W4b2.get(e) + c3p_inv_fact[16] * ab + c3p_inv_fact[17] * sb);
+        W1b.set(e, ca(1) * cb + sa(1) * pb + ca(5) * ab + sa(5) * sb);
+        W2b.set(e, ca(2) * cb + sa(2) * pb + ca(6) * ab + sa(6) * sb);
+        W3b.set(e, ca(3) * cb + sa(3) * pb + ca(7) * ab + sa(7) * sb);
+        W4b.set(e, 0.5 * W4b2.get(e) + ca(8) * ab + sa(8) * sb);
       }
     }
     // ---- W4 = W2^2, W3 = W W2:  W2_bar += {W4_bar, W2} + sym(W3_bar W),  W_bar += sym(W3_bar W2) ----

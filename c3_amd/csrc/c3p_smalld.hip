@@ -1244,9 +1244,20 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
     if (realH) {
       constexpr int NB = RD<D>::NB;
       typedef double RMat[NB][NB];
+      // Round 6: the 7-product variant of the padded-tile loop below evaluates the economised degree-8 pair (theta = 1.85,
+      // c3p_common.h) and serves every norm; -DC3P_SD_QUADSUM keeps round 5's Taylor variants (theta_16 = 0.816 / 1.13)
+#ifndef C3P_SD_QUADSUM
+#define C3P_SD_CA(j) c3p_mm8_cos[j]
+#define C3P_SD_SA(j) c3p_mm8_sinc[j]
+      constexpr double theta_real = C3P_MM8_THETA, theta_deg16 = C3P_MM8_THETA;
+#else
+#define C3P_SD_CA(j) (((j) & 1) ? -c3p_inv_fact[2 * (j)] : c3p_inv_fact[2 * (j)])
+#define C3P_SD_SA(j) (((j) & 1) ? -c3p_inv_fact[2 * (j) + 1] : c3p_inv_fact[2 * (j) + 1])
+      constexpr double theta_real = C3P_T18_THETA, theta_deg16 = 8.16e-1;
+#endif
       int ps18 = 0;
       {
-        double p = C3P_T18_THETA;
+        double p = theta_real;
         while (p < nrm && ps18 < 40) {
           p *= 2.0;
           ++ps18;
@@ -1269,7 +1280,7 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
       // theta_16 (unit roundoff 2^-52) = 0.816: below it the degree-16 / 17 polynomials are exact to roundoff and the
       // shallower 7-product evaluation is used.  The variant is chosen per segment OUTSIDE the slice loop (the loop is
       // instantiated twice) so that neither variant's registers burden the other's schedule.
-      const bool deg16 = __builtin_amdgcn_readfirstlane((int)(nrm * rscale <= 8.16e-1)) != 0;
+      const bool deg16 = __builtin_amdgcn_readfirstlane((int)(nrm * rscale <= theta_deg16)) != 0;
       if constexpr (SPLIT) {
         // ---- core + border form (D = 4 NC + 1; see SMat / GMat above): the same polynomial evaluation and chain step ----
         static_assert(!SPLIT || (D % 4 == 1 && D > 4 && !DUS), "core + border form: D = 5, 9 without slice output");
@@ -1595,17 +1606,17 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
           mm_sym<D>(W2, W2, W4, tail_lane);
           sym_fill<D>(W3, swap_lane);
           sym_fill<D>(W4, swap_lane);
-          rcomb<D, true>(acc, c3p_inv_fact[8], -c3p_inv_fact[10], c3p_inv_fact[12], -c3p_inv_fact[14], W1, W2, W3, lp);
-          rcomb<D, true>(acs, c3p_inv_fact[9], -c3p_inv_fact[11], c3p_inv_fact[13], -c3p_inv_fact[15], W1, W2, W3, lp);
+          rcomb<D, true>(acc, C3P_SD_CA(4), C3P_SD_CA(5), C3P_SD_CA(6), C3P_SD_CA(7), W1, W2, W3, lp);
+          rcomb<D, true>(acs, C3P_SD_SA(4), C3P_SD_SA(5), C3P_SD_SA(6), C3P_SD_SA(7), W1, W2, W3, lp);
 #pragma unroll
           for (int I = 0; I < NB; ++I)
 #pragma unroll
             for (int J = sym_j0<D>(I); J < NB; ++J) {
-              acc[I][J] = fma(c3p_inv_fact[16], W4[I][J], acc[I][J]);
-              acs[I][J] = fma(c3p_inv_fact[17], W4[I][J], acs[I][J]);
+              acc[I][J] = fma(C3P_SD_CA(8), W4[I][J], acc[I][J]);
+              acs[I][J] = fma(C3P_SD_SA(8), W4[I][J], acs[I][J]);
             }
-          rcomb<D, true, true>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], -c3p_inv_fact[6], W1, W2, W3, lp);
-          rcomb<D, true, true>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7], W1, W2, W3, lp);
+          rcomb<D, true, true>(Cm, C3P_SD_CA(0), C3P_SD_CA(1), C3P_SD_CA(2), C3P_SD_CA(3), W1, W2, W3, lp);
+          rcomb<D, true, true>(Sp, C3P_SD_SA(0), C3P_SD_SA(1), C3P_SD_SA(2), C3P_SD_SA(3), W1, W2, W3, lp);
           mm_sym2<D>(W4, acc, Cm, acs, Sp, tail_lane);  // Cm = cos Y, Sp = sin(Y) / Y
         } else {
         mm_sym<D>(W1, W2, W3, tail_lane);  // W^3
@@ -2242,13 +2253,14 @@ __device__ __forceinline__ void mat_zero(double (&m)[SD<D>::NBI][SD<D>::NJ]) {
     for (int J = 0; J < SD<D>::NJ; ++J) m[I][J] = 0.0;
 }
 
-// squarings of the real-Hamiltonian backward sweep (smalld_grad_real_kernel below): degree 16 / 17, theta_16 = 0.816
+// squarings of the real-Hamiltonian backward sweep (smalld_grad_real_kernel below): the economised degree-8 cos / sin pair of
+// c3p_common.h (round 6: theta = 1.85 on the product structure of the degree-8 Taylor pair, theta_16 = 0.816)
 constexpr int SDG_MAXS = 3;
 
 template <int D>
 __device__ __forceinline__ int sdg_real_squarings(double nrm) {
   int ps = 0;
-  double p = 8.16e-1;
+  double p = C3P_MM8_THETA;
   while (p < nrm && ps < 40) {
     p *= 2.0;
     ++ps;
@@ -2957,17 +2969,17 @@ __global__ void __launch_bounds__(64, 1) smalld_grad_real_kernel(SmallGradArgs A
     mm_sym<D>(W2, W2, W4, tail_lane);
     sym_fill<D>(W3, swap_lane);
     sym_fill<D>(W4, swap_lane);
-    rcomb<D, true>(acc, c3p_inv_fact[8], -c3p_inv_fact[10], c3p_inv_fact[12], -c3p_inv_fact[14], W1, W2, W3, lp);
-    rcomb<D, true>(acs, c3p_inv_fact[9], -c3p_inv_fact[11], c3p_inv_fact[13], -c3p_inv_fact[15], W1, W2, W3, lp);
+    rcomb<D, true>(acc, c3p_mm8_cos[4], c3p_mm8_cos[5], c3p_mm8_cos[6], c3p_mm8_cos[7], W1, W2, W3, lp);
+    rcomb<D, true>(acs, c3p_mm8_sinc[4], c3p_mm8_sinc[5], c3p_mm8_sinc[6], c3p_mm8_sinc[7], W1, W2, W3, lp);
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
       for (int J = sym_j0<D>(I); J < NB; ++J) {
-        acc[I][J] = fma(c3p_inv_fact[16], W4[I][J], acc[I][J]);
-        acs[I][J] = fma(c3p_inv_fact[17], W4[I][J], acs[I][J]);
+        acc[I][J] = fma(c3p_mm8_cos[8], W4[I][J], acc[I][J]);
+        acs[I][J] = fma(c3p_mm8_sinc[8], W4[I][J], acs[I][J]);
       }
-    rcomb<D, true, true>(Cm, 1.0, -c3p_inv_fact[2], c3p_inv_fact[4], -c3p_inv_fact[6], W1, W2, W3, lp);
-    rcomb<D, true, true>(Sp, 1.0, -c3p_inv_fact[3], c3p_inv_fact[5], -c3p_inv_fact[7], W1, W2, W3, lp);
+    rcomb<D, true, true>(Cm, c3p_mm8_cos[0], c3p_mm8_cos[1], c3p_mm8_cos[2], c3p_mm8_cos[3], W1, W2, W3, lp);
+    rcomb<D, true, true>(Sp, c3p_mm8_sinc[0], c3p_mm8_sinc[1], c3p_mm8_sinc[2], c3p_mm8_sinc[3], W1, W2, W3, lp);
     mm_sym2<D>(W4, acc, Cm, acs, Sp, tail_lane);
     sym_fill<D>(Cm, swap_lane);
     sym_fill<D>(Sp, swap_lane);
@@ -3102,10 +3114,10 @@ __global__ void __launch_bounds__(64, 1) smalld_grad_real_kernel(SmallGradArgs A
 #pragma unroll
       for (int J = sym_j0<D>(I); J < NB; ++J) {
         const double ab = accb[I][J], sb = acsb[I][J], cb = Cb[I][J], pb = Spb[I][J];
-        W1b[I][J] = -(c3p_inv_fact[2] * cb + c3p_inv_fact[3] * pb + c3p_inv_fact[10] * ab + c3p_inv_fact[11] * sb);
-        W2b[I][J] = c3p_inv_fact[4] * cb + c3p_inv_fact[5] * pb + c3p_inv_fact[12] * ab + c3p_inv_fact[13] * sb;
-        W3b[I][J] = -(c3p_inv_fact[6] * cb + c3p_inv_fact[7] * pb + c3p_inv_fact[14] * ab + c3p_inv_fact[15] * sb);
-        W4b[I][J] = W4b[I][J] + c3p_inv_fact[16] * ab + c3p_inv_fact[17] * sb;
+        W1b[I][J] = c3p_mm8_cos[1] * cb + c3p_mm8_sinc[1] * pb + c3p_mm8_cos[5] * ab + c3p_mm8_sinc[5] * sb;
+        W2b[I][J] = c3p_mm8_cos[2] * cb + c3p_mm8_sinc[2] * pb + c3p_mm8_cos[6] * ab + c3p_mm8_sinc[6] * sb;
+        W3b[I][J] = c3p_mm8_cos[3] * cb + c3p_mm8_sinc[3] * pb + c3p_mm8_cos[7] * ab + c3p_mm8_sinc[7] * sb;
+        W4b[I][J] = W4b[I][J] + c3p_mm8_cos[8] * ab + c3p_mm8_sinc[8] * sb;
       }
     {
       // W4 = W2^2, W3 = W W2:  W2_bar += {W4_bar, W2} + sym(W3_bar W),  W_bar += sym(W3_bar W2)

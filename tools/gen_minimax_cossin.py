@@ -57,6 +57,12 @@ def tables(theta, deg):
     gs = [F((-1) ** j, factorial(2 * j + 1)) for j in range(M + 1)]
     pc, dc = economise(fc, L, deg)
     ps, ds = economise(gs, L, deg)
+    # exp(0) = I exactly (idle slices of a chain, a zero Hamiltonian): the constant terms are set to 1; the economised constant of
+    # the cosine is 1 - 1.1e-16, so its error bound grows by that much (the error curve moves from [-d, d] to [0, 2 d])
+    dc += abs(1 - pc[0])
+    ds += abs(1 - ps[0])
+    pc[0] = F(1)
+    ps[0] = F(1)
     return pc, ps, float(dc), float(ds)
 
 
