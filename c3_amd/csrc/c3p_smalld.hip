@@ -2938,10 +2938,16 @@ __global__ void __launch_bounds__(64, 1) smalld_grad_real_kernel(SmallGradArgs A
       }
   }
 
+  // Two instances of the slice loop, the branch outside (as in the forward kernel): MM6 = the economised degree-6 pair (scaled norm
+  // <= 0.83: cfg2) -- Horner step in W^3, no W^4: one forward product and one adjoint product less per slice; otherwise the
+  // degree-8 pair with W^4 (theta = 1.85).
+  const bool small_var = __builtin_amdgcn_readfirstlane((int)(nrm * scale <= C3P_MM6_THETA)) != 0;
+  auto sweep = [&](auto mm6_tag) {
+  constexpr bool MM6 = decltype(mm6_tag)::value;
   for (int t = A.Lmax - 1; t >= 0; --t) {
     const bool act = valid && t < len;
     const double sc = act ? scale : 0.0;
-    // ---- forward: Y, W = Y^2, ..., cos Y, sin Y (as in smalld_chain_kernel, degree 16 / 17) ----
+    // ---- forward: Y, W = Y^2, ..., cos Y, sin Y (as in smalld_chain_kernel) ----
     RMat Y;
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
@@ -2966,21 +2972,30 @@ __global__ void __launch_bounds__(64, 1) smalld_grad_real_kernel(SmallGradArgs A
     mm_sym<D>(W1, W1, W2, tail_lane);
     sym_fill<D>(W2, swap_lane);
     mm_sym<D>(W1, W2, W3, tail_lane);
-    mm_sym<D>(W2, W2, W4, tail_lane);
+    if constexpr (!MM6) mm_sym<D>(W2, W2, W4, tail_lane);
     sym_fill<D>(W3, swap_lane);
-    sym_fill<D>(W4, swap_lane);
-    rcomb<D, true>(acc, c3p_mm8_cos[4], c3p_mm8_cos[5], c3p_mm8_cos[6], c3p_mm8_cos[7], W1, W2, W3, lp);
-    rcomb<D, true>(acs, c3p_mm8_sinc[4], c3p_mm8_sinc[5], c3p_mm8_sinc[6], c3p_mm8_sinc[7], W1, W2, W3, lp);
+    if constexpr (MM6) {
+      // cos = (c0 + c1 W + c2 W^2) + W^3 (c3 + c4 W + c5 W^2 + c6 W^3)
+      rcomb<D, true>(acc, c3p_mm6_cos[3], c3p_mm6_cos[4], c3p_mm6_cos[5], c3p_mm6_cos[6], W1, W2, W3, lp);
+      rcomb<D, true>(acs, c3p_mm6_sinc[3], c3p_mm6_sinc[4], c3p_mm6_sinc[5], c3p_mm6_sinc[6], W1, W2, W3, lp);
+      rcomb<D, false, true>(Cm, c3p_mm6_cos[0], c3p_mm6_cos[1], c3p_mm6_cos[2], 0.0, W1, W2, W3, lp);
+      rcomb<D, false, true>(Sp, c3p_mm6_sinc[0], c3p_mm6_sinc[1], c3p_mm6_sinc[2], 0.0, W1, W2, W3, lp);
+      mm_sym2<D>(W3, acc, Cm, acs, Sp, tail_lane);
+    } else {
+      sym_fill<D>(W4, swap_lane);
+      rcomb<D, true>(acc, c3p_mm8_cos[4], c3p_mm8_cos[5], c3p_mm8_cos[6], c3p_mm8_cos[7], W1, W2, W3, lp);
+      rcomb<D, true>(acs, c3p_mm8_sinc[4], c3p_mm8_sinc[5], c3p_mm8_sinc[6], c3p_mm8_sinc[7], W1, W2, W3, lp);
 #pragma unroll
-    for (int I = 0; I < NB; ++I)
+      for (int I = 0; I < NB; ++I)
 #pragma unroll
-      for (int J = sym_j0<D>(I); J < NB; ++J) {
-        acc[I][J] = fma(c3p_mm8_cos[8], W4[I][J], acc[I][J]);
-        acs[I][J] = fma(c3p_mm8_sinc[8], W4[I][J], acs[I][J]);
-      }
-    rcomb<D, true, true>(Cm, c3p_mm8_cos[0], c3p_mm8_cos[1], c3p_mm8_cos[2], c3p_mm8_cos[3], W1, W2, W3, lp);
-    rcomb<D, true, true>(Sp, c3p_mm8_sinc[0], c3p_mm8_sinc[1], c3p_mm8_sinc[2], c3p_mm8_sinc[3], W1, W2, W3, lp);
-    mm_sym2<D>(W4, acc, Cm, acs, Sp, tail_lane);
+        for (int J = sym_j0<D>(I); J < NB; ++J) {
+          acc[I][J] = fma(c3p_mm8_cos[8], W4[I][J], acc[I][J]);
+          acs[I][J] = fma(c3p_mm8_sinc[8], W4[I][J], acs[I][J]);
+        }
+      rcomb<D, true, true>(Cm, c3p_mm8_cos[0], c3p_mm8_cos[1], c3p_mm8_cos[2], c3p_mm8_cos[3], W1, W2, W3, lp);
+      rcomb<D, true, true>(Sp, c3p_mm8_sinc[0], c3p_mm8_sinc[1], c3p_mm8_sinc[2], c3p_mm8_sinc[3], W1, W2, W3, lp);
+      mm_sym2<D>(W4, acc, Cm, acs, Sp, tail_lane);
+    }
     sym_fill<D>(Cm, swap_lane);
     sym_fill<D>(Sp, swap_lane);
     mm_sym<D>(Y, Sp, S0, tail_lane);
@@ -3102,9 +3117,9 @@ __global__ void __launch_bounds__(64, 1) smalld_grad_real_kernel(SmallGradArgs A
       zero(Pw), zero(Pd), zero(Pf);
       prod(Cb, acc, Pw);
       prod(Spb, acs, Pw);
-      prod(Cb, W4, Pd);
-      prod(Spb, W4, Pf);
-      mirror(Pw, 0.5, W4b);   // sym(C_bar acc) + sym(Sp_bar acs)
+      prod(Cb, MM6 ? W3 : W4, Pd);
+      prod(Spb, MM6 ? W3 : W4, Pf);
+      mirror(Pw, 0.5, W4b);   // sym(C_bar acc) + sym(Sp_bar acs): the cotangent of the Horner power (W^3 in the degree-6 variant)
       mirror(Pd, 0.5, accb);  // sym(W4 C_bar)
       mirror(Pf, 0.5, acsb);  // sym(W4 Sp_bar)
     }
@@ -3114,16 +3129,22 @@ __global__ void __launch_bounds__(64, 1) smalld_grad_real_kernel(SmallGradArgs A
 #pragma unroll
       for (int J = sym_j0<D>(I); J < NB; ++J) {
         const double ab = accb[I][J], sb = acsb[I][J], cb = Cb[I][J], pb = Spb[I][J];
-        W1b[I][J] = c3p_mm8_cos[1] * cb + c3p_mm8_sinc[1] * pb + c3p_mm8_cos[5] * ab + c3p_mm8_sinc[5] * sb;
-        W2b[I][J] = c3p_mm8_cos[2] * cb + c3p_mm8_sinc[2] * pb + c3p_mm8_cos[6] * ab + c3p_mm8_sinc[6] * sb;
-        W3b[I][J] = c3p_mm8_cos[3] * cb + c3p_mm8_sinc[3] * pb + c3p_mm8_cos[7] * ab + c3p_mm8_sinc[7] * sb;
-        W4b[I][J] = W4b[I][J] + c3p_mm8_cos[8] * ab + c3p_mm8_sinc[8] * sb;
+        if constexpr (MM6) {
+          W1b[I][J] = c3p_mm6_cos[1] * cb + c3p_mm6_sinc[1] * pb + c3p_mm6_cos[4] * ab + c3p_mm6_sinc[4] * sb;
+          W2b[I][J] = c3p_mm6_cos[2] * cb + c3p_mm6_sinc[2] * pb + c3p_mm6_cos[5] * ab + c3p_mm6_sinc[5] * sb;
+          W3b[I][J] = W4b[I][J] + c3p_mm6_cos[6] * ab + c3p_mm6_sinc[6] * sb;  // (W4b holds the Horner power's cotangent)
+        } else {
+          W1b[I][J] = c3p_mm8_cos[1] * cb + c3p_mm8_sinc[1] * pb + c3p_mm8_cos[5] * ab + c3p_mm8_sinc[5] * sb;
+          W2b[I][J] = c3p_mm8_cos[2] * cb + c3p_mm8_sinc[2] * pb + c3p_mm8_cos[6] * ab + c3p_mm8_sinc[6] * sb;
+          W3b[I][J] = c3p_mm8_cos[3] * cb + c3p_mm8_sinc[3] * pb + c3p_mm8_cos[7] * ab + c3p_mm8_sinc[7] * sb;
+          W4b[I][J] = W4b[I][J] + c3p_mm8_cos[8] * ab + c3p_mm8_sinc[8] * sb;
+        }
       }
     {
-      // W4 = W2^2, W3 = W W2:  W2_bar += {W4_bar, W2} + sym(W3_bar W),  W_bar += sym(W3_bar W2)
+      // W4 = W2^2, W3 = W W2:  W2_bar += {W4_bar, W2} + sym(W3_bar W),  W_bar += sym(W3_bar W2)   (degree 6: no W4)
       RMat Pi, Pg, Ph, q, h;
       zero(Pi), zero(Pg), zero(Ph);
-      prod(W4b, W2, Pi);
+      if constexpr (!MM6) prod(W4b, W2, Pi);
       prod(W3b, W1, Pg);
       prod(W3b, W2, Ph);
 #pragma unroll
@@ -3214,6 +3235,11 @@ __global__ void __launch_bounds__(64, 1) smalld_grad_real_kernel(SmallGradArgs A
         }
     }
   }
+  };
+  if (small_var)
+    sweep(std::true_type{});
+  else
+    sweep(std::false_type{});
 }
 
 template <int D>

@@ -11,7 +11,7 @@ for _ in range(30): x @ x
 torch.cuda.synchronize()
 w = make_workload(2, B=256)
 h0, hks, sig, ph = t(w.h0), t(w.hks), t(w.signals), t(w.fr_phase)
-for skew in (None, 700, 720, 740):
+for skew in (None,):
     _lib.set_option("mw_skew", skew)
     print("skew", skew, flush=True)
     for _ in range(4):
