@@ -291,3 +291,35 @@ def test_header_is_plain_c_and_a_c_client_binds_the_library(lib, tmp_path):
     out = subprocess.run([exe, _lib.LIB_PATH, "host"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert "ABI_CLIENT_HOST_OK" in out.stdout
+
+
+def test_economised_cos_sin_tables_are_the_generator_output_and_accurate():
+    """c3p_common.h's c3p_mm{6,7,8}_{cos,sinc} (round 6): (1) equal to what tools/gen_minimax_cossin.py derives in exact rational
+    arithmetic, (2) accurate on their whole interval: |p(w) - cos(sqrt w)| and |p(w) - sin(sqrt w)/sqrt w| on [0, theta^2] in
+    exact arithmetic against long Taylor sums, below 2.4e-16 / 4e-17 (economisation + rounding of the coefficients to double) -- for a real symmetric Y that scalar error IS the matrix error."""
+    import importlib.util
+    from fractions import Fraction as F
+    from math import factorial
+
+    spec = importlib.util.spec_from_file_location("gen_mm", os.path.join(ROOT, "tools", "gen_minimax_cossin.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    text = open(os.path.join(ROOT, "c3_amd", "csrc", "c3p_common.h")).read()
+    for name, theta, deg in (("mm6", F(83, 100), 6), ("mm7", F(130, 100), 7), ("mm8", F(185, 100), 8)):
+        assert f"#define C3P_{name.upper()}_THETA {float(theta)!r}" in text
+        pc, ps, dc, ds = g.tables(theta, deg)
+        for kind, tab, bound in (("cos", pc, 2.4e-16), ("sinc", ps, 4.0e-17)):
+            m = re.search(r"c3p_%s_%s\[%d\] = \{([^}]*)\}" % (name, kind, deg + 1), text)
+            vals = [float.fromhex(x.strip()) for x in m.group(1).split(",")]
+            assert vals == [float(x) for x in tab], (name, kind)
+            assert vals[0] == 1.0  # exp(0) = I exactly
+            # exact evaluation of the DOUBLE coefficients against a degree-30 Taylor sum at 400 points of [0, theta^2]
+            worst = F(0)
+            L = theta * theta
+            for i in range(401):
+                w = L * i / 400
+                p = sum(F(v) * w**j for j, v in enumerate(vals))
+                f = sum(F((-1) ** j, factorial(2 * j + (0 if kind == "cos" else 1))) * w**j for j in range(31))
+                worst = max(worst, abs(p - f))
+            assert float(worst) < bound, (name, kind, float(worst))
+        assert dc < 2.2e-16 and ds < 2e-17

@@ -79,3 +79,42 @@ def test_border_sums_on_the_matrix_cores_all_variants(prop, D, squarings):
         ref = c3_oracle.propagate_batch(h0, hks, sig, dt, fr_phase=ph)
         err = max(np.linalg.norm(U[b] - ref[b]) for b in range(B))
         assert err < 2e-12 * max(1.0, 2.0**squarings), (B, scale, squarings, err)
+
+
+def _sym_problem(D, K, B, N, rng, target_norm):
+    """real symmetric operators scaled so that the kernels' norm bound ||G0||_1 + sum_k max|c_k| ||G_k||_1 (trace-shifted, dt = 1)
+    hits `target_norm`"""
+    herm = lambda s: (lambda m: s * (m + m.T) / 2)(rng.normal(size=(D, D))).astype(np.complex128)
+    h0 = np.diag(rng.uniform(0, 1, D)).astype(np.complex128) + herm(0.05)
+    hks = np.stack([herm(0.4) for _ in range(K)])
+    sig = rng.uniform(-1, 1, size=(B, K, N))
+    one = lambda h: np.abs(h - np.trace(h) / D * np.eye(D)).sum(axis=0).max()
+    bound = one(h0) + sum(np.abs(sig[:, k, :]).max() * one(hks[k]) for k in range(K))
+    return h0, hks, sig, target_norm / bound
+
+
+@pytest.mark.parametrize("D", [3, 5, 9, 12, 14, 20, 27, 33, 36])
+def test_economised_polynomials_at_their_thresholds(prop, D):
+    """the real path on both sides of theta_6 = 0.83 (degree-6 pair, core + border loop), theta_7 = 1.30, theta_8 = 1.85 (the
+    7-product variants; one squaring just above) and deep in the squaring regime -- forward against the oracle, and the
+    real backward sweeps (same tables) against the general ones."""
+    import torch
+
+    from c3_amd import _lib
+    from oracle import c3_oracle
+
+    rng = np.random.default_rng(900 + D)
+    K, B, N = 2, 5, 40
+    t = lambda a: torch.as_tensor(a, device="cuda:0")
+    for target in (0.80, 0.829, 0.831, 1.29, 1.31, 1.84, 1.86, 3.6, 7.5):
+        h0, hks, sig, dt = _sym_problem(D, K, B, N, rng, target)
+        U = prop.propagate_batch(t(h0), t(hks), t(sig), dt)["U"].cpu().numpy()
+        ref = c3_oracle.propagate_batch(h0, hks, sig, dt)
+        err = max(np.linalg.norm(U[b] - ref[b]) for b in range(B))
+        assert err < 3e-13 * max(1.0, target) * np.sqrt(D), (D, target, err)
+        if D <= 40 and target <= 7.5:
+            Ub = rng.normal(size=(B, D, D)) + 1j * rng.normal(size=(B, D, D))
+            g = np.asarray(prop.propagate_batch_vjp(t(h0), t(hks), t(sig), dt, t(Ub)).cpu())
+            with _lib.options(no_real_grad=1):
+                gg = np.asarray(prop.propagate_batch_vjp(t(h0), t(hks), t(sig), dt, t(Ub)).cpu())
+            assert np.abs(g - gg).max() < 1e-10 * max(1.0, np.abs(gg).max()), (D, target)
