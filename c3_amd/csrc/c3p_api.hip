@@ -311,7 +311,20 @@ int run_chain_generic(DeviceWs* w, ChainArgs base, cplx* U_out, hipStream_t st, 
 // ---------------------------------------------------------------------------
 // Small-D MFMA path (Dm <= C3P_SMALLD_LIMIT): tables -> segment chains -> ordered combine
 // ---------------------------------------------------------------------------
-const int kSmallDLimit = 12;  // D = 11, 12 spill ~100 registers but still beat the generic kernel
+const int kSmallDLimit = 12;
+
+// Unitary gradients at 41 <= D <= 64: the VALU sweep (c3p_grad.hip, ~D^3 B) against the tiled sweep (c3p_tiled.hip: matrix cores,
+// padded to 64-multiples, so D = 48 and D = 64 cost the same there, and ~35 launches per slice whatever B is).  Measured on one
+// MI355X, N = 1000 (tools/bench_grad_41_64.py, profiles/r06/grad_41_64.txt; ms VALU / tiled): D = 48: B = 64 112 / 220,
+// B = 256 426 / 505; D = 64: B = 64 254 / 224, B = 256 983 / 519.  Rule: tiled when 1.66 B (D / 48)^3 ms (the VALU estimate)
+// exceeds max(220, 1.97 B) ms (the tiled one).
+static inline bool tiled_unitary_grad(int D, int B) {
+  if (D > 64) return true;
+  if (D <= 40) return false;
+  if (c3p_opt_on(C3P_OPT_tiled_grad)) return true;
+  const double r = (double)D / 48.0, valu = 1.66 * B * r * r * r, tiled = std::max(220.0, 1.97 * B);
+  return valu > tiled;
+}  // D = 11, 12 spill ~100 registers but still beat the generic kernel
 
 int record_start(DeviceWs* w, hipStream_t st) {
   if (!w->profiling || g_dry) return 0;
@@ -3454,7 +3467,8 @@ static int unitary_vjp_branch_a(const void* h0, int64_t h0_bstride, const void* 
   // beyond the on-chip sweeps: forward partials in HBM, one pair evaluation of T18 per slice on the tiled MFMA GEMM.  ~35
   // launches per slice: below a few hundred samples the launches, not the GEMMs, set the time, and the VALU sweep (which
   // stops at D = 64) is faster for 41 <= D <= 64 (profiles/r03/grad_tiled.json: D = 48, B = 64: 151 ms against 545 ms)
-  const bool tiled_grad = D > 64 || (D > 40 && (B >= 384 || c3p_opt_on(C3P_OPT_tiled_grad)));
+  // (the fused goal entry has no tiled form: it stays on the VALU sweep in its whole domain)
+  const bool tiled_grad = goal ? false : tiled_unitary_grad(D, B);
   if (!done && !(flags & C3P_FORCE_GENERIC) && tiled_grad && !gen_bar_out) {
     if (run_vjp_tiled(w, 0, A.h0, h0_bstride, A.hks, hks_bstride, A.signals, nullptr, dt, B, K, N, D, D, A.fr_phase, A.Ubar, A.grad, st))
       return -1;
