@@ -713,6 +713,7 @@ int run_xg_midd(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, dou
   a.mode = C3P_MODE_EXPM;
   a.dUs_out = dUs_out;
   a.no_t18 = c3p_opt_on(C3P_OPT_no_t18) ? 1 : 0;
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
   a.no_real = c3p_opt_on(C3P_OPT_no_real) ? 1 : 0;
   if (S == 1) {
     a.seg_out = U_out;
@@ -1236,6 +1237,7 @@ int run_pwc_midd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   a.mode = lindblad ? C3P_MODE_LINDBLAD : C3P_MODE_UNITARY;
   a.dUs_out = dUs_out;
   a.no_t18 = c3p_opt_on(C3P_OPT_no_t18) ? 1 : 0;
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
   a.no_real = c3p_opt_on(C3P_OPT_no_real) ? 1 : 0;
   if (S == 1) {
     a.seg_out = U_out;
@@ -1314,6 +1316,7 @@ int run_vjp_lind_midd(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, 
   a.seg_out = (cplx*)sv;
   a.dUs_out = dUs;
   a.no_t18 = c3p_opt_on(C3P_OPT_no_t18) ? 1 : 0;
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
   a.no_real = 1;
   LAUNCH_TRY(c3p_launch_midd_chain(a, st));
   GradArgs G = {};
@@ -1413,6 +1416,7 @@ int run_vjp_xg_general(DeviceWs* w, const cplx* hs, long hs_bstride, double coef
     a.seg_out = (cplx*)sv;
     a.dUs_out = dUs;
     a.no_t18 = c3p_opt_on(C3P_OPT_no_t18) ? 1 : 0;
+    a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
     a.no_real = 1;
     LAUNCH_TRY(c3p_launch_midd_chain(a, st));
   }
@@ -1604,6 +1608,7 @@ int run_pwc_regd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
     a.hb_tables = rtables;
     a.hb_tabflag = tabflag;
   }
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
   cplx* seg = U_out;
   if (S > 1) {
     void* sv;
@@ -1788,6 +1793,7 @@ int lind_regr_forward(DeviceWs* w, const LindRegrBufs& bf, const cplx* h0, long 
   a.hb_tables = bf.tab_f;
   a.hb_tabflag = bf.flag_f;
   a.hb_qT = bf.qT;
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
   a.seg_out = bf.seg;
   LAUNCH_TRY(c3p_launch_regr_chain(a, av, st));
   return 0;

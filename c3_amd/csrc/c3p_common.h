@@ -144,6 +144,22 @@ __host__ __device__ __forceinline__ TaylorPlan c3p_pick_plan_q4(double nrm) {
 #define C3P_T18_B34 (-0.01693649390020817171)
 #define C3P_T18_B64 (-0.00001400867981820361)
 
+// T18 for NORMAL generators with an imaginary spectrum (round 6; tools/gen_t18_normal.py: the 20 parameters re-solved in 60-digit
+// arithmetic for the Chebyshev-economised degree-18 polynomial of e^z on [-i theta, i theta]).  For X = -i dt (H - tr H / D) with H
+// Hermitian, and for a Lindblad generator with Hermitian H up to a small dissipator, ||p(X) - exp(X)||_2 is the scalar error on the
+// spectrum, so the radius is 2.0 instead of the 1.13 of the Taylor parameters (any matrix): cfg4 (1.6) needs no squaring.  Error
+// bound of the economisation: even part 1.6e-18, odd part 6.3e-17; with the parameters rounded to double 3.4e-16 on the interval;
+// measured against scipy's expm the no-squaring evaluation is as accurate as Taylor-T18 + one squaring also with a dissipator of
+// norm 0.1 next to a skew part of norm 1.6 (tests/test_abi_and_host.py::test_t18_for_normal_generators).
+// Row 0 = the published Taylor parameters, row 1 = the economised ones; order: a11, a21, a31, b11, b21, b31, b61, b02, b12, b22, b32, b62, b03, b13, b23, b33, b63, b24, b34, b64.
+#define C3P_T18N_THETA 2.0
+#define C3P_T18N_MAX_NONNORMAL 0.25  /* 1-norm of the symmetric (non-skew) part of a real generator the economised table accepts */
+enum { C3P_I_A11, C3P_I_A21, C3P_I_A31, C3P_I_B11, C3P_I_B21, C3P_I_B31, C3P_I_B61, C3P_I_B02, C3P_I_B12, C3P_I_B22, C3P_I_B32, C3P_I_B62, C3P_I_B03, C3P_I_B13, C3P_I_B23, C3P_I_B33, C3P_I_B63, C3P_I_B24, C3P_I_B34, C3P_I_B64 };
+__constant__ double c3p_t18_tab[2][20] = {
+    {C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61, C3P_T18_B02, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62, C3P_T18_B03, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64},
+    {-0x1.eb38ce5c91740p-4, -0x1.25636bcf4b5b5p-7, -0x1.04c9aedbe699cp-10, 0x1.6a80b11b0bcabp-3, 0x1.1dc21d43eb4cfp+0, 0x1.420dbe5746422p-2, -0x1.289454f80f910p-11, -0x1.3deb71e2be061p+2, 0x1.b130d3faac326p+0, 0x1.21f0bba48bb5dp-4, -0x1.f3a48235292fdp-9, 0x1.1ada67e7564b6p-15, -0x1.8ccda6e1cc3c0p-3, -0x1.b823d05f2b313p-3, 0x1.b4116a8ca5541p-5, 0x1.83665c777fc72p-6, -0x1.5ac92f9e0ac99p-17, -0x1.d79745bcca89dp-4, -0x1.7f4469c9ea034p-7, -0x1.9a9222987bdffp-17},
+};
+
 // Plan for the MFMA kernels: either the q = 4 Paterson-Stockmeyer polynomial (degree 4r,
 // 3 + (r-1) products) or T18 (5 products), plus s squarings; fewest products wins, ties go
 // to Paterson-Stockmeyer (less element-wise work).

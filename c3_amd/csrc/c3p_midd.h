@@ -17,6 +17,7 @@ struct MidArgs {
   int S, Lmax;
   int mode, right_order;
   int no_t18;  // debug/tuning: force the Paterson-Stockmeyer plan
+  int no_t18n;  // debug/tuning: Taylor T18 parameters also for (nearly) normal generators (c3p_common.h: c3p_t18_tab)
   int no_real;  // debug/tuning: keep real Hamiltonians on the complex path
   cplx* seg_out;
   cplx* dUs_out;

@@ -387,6 +387,7 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
     __syncthreads();  // the previous chain is done with the LDS
     // plan: squarings from ||G0||_1 + sum_k max_t |c_k(t)| ||G_k||_1 over the segment
     double nrm = meta(0)[1];
+    double kmaxv[RR_KMAX];
     for (int k = 0; k < K; ++k) {
       const double* s = A.signals + ((long)sample * K + k) * A.N + n0;
       double cmax = 0.0;
@@ -398,11 +399,18 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
       for (int w = 0; w < NW; ++w) cmax = fmax(cmax, red[w]);
       __syncthreads();
       nrm = fma(cmax, meta(k + 1)[1], nrm);
+      kmaxv[k] = cmax;
     }
     nrm = rr_rfl(nrm);
+    // Round 6: the generator is real in the Hermitian basis, skew-symmetric up to the dissipator (H is Hermitian on this path): when the
+    // symmetric part is small the economised T18 parameters apply (radius 2.0 instead of 1.13: cfg4 needs no squaring)
+    double nsym = meta(0)[3];
+    for (int k = 0; k < K; ++k) nsym = fma(kmaxv[k], meta(k + 1)[3], nsym);
+    const int econ = __builtin_amdgcn_readfirstlane((int)(rr_rfl(nsym) <= C3P_T18N_MAX_NONNORMAL && !A.no_t18n));
+    const double* tc = c3p_t18_tab[econ];
     int s18 = 0;
     {
-      double pth = C3P_T18_THETA;
+      double pth = econ ? C3P_T18N_THETA : C3P_T18_THETA;
       while (pth < nrm && s18 < 40) {
         pth *= 2.0;
         ++s18;
@@ -531,24 +539,24 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
             // A3: the right operand of A6 = A3 A3 still sits in Rm (the lean form re-assembled X there: it reads the image)
             const double a3 = LEAN ? img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p] : Rm[Ig][jj];
             // B1 -> image (left operand of A9 = B1 B5 + B4)
-            img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p] = fma(C3P_T18_A31, a3, fma(C3P_T18_A21, a2, C3P_T18_A11 * x));
+            img[(16 * Ig + rowC) * LD + col0 + 4 * jj + p] = fma(tc[C3P_I_A31], a3, fma(tc[C3P_I_A21], a2, tc[C3P_I_A11] * x));
             // B2, B3 stay in registers (in the places of X and A2)
-            const double b2 = fma(C3P_T18_B61, a6, fma(C3P_T18_B31, a3, fma(C3P_T18_B21, a2, C3P_T18_B11 * x)));
+            const double b2 = fma(tc[C3P_I_B61], a6, fma(tc[C3P_I_B31], a3, fma(tc[C3P_I_B21], a2, tc[C3P_I_B11] * x)));
             if constexpr (LEAN) rr_ubase(arena)[(Ig * NJ + jj) * RR_THREADS + tid] = b2;
             else Xs[Ig][jj] = b2;
-            A2s[Ig][jj] = fma(C3P_T18_B62, a6, fma(C3P_T18_B32, a3, fma(C3P_T18_B22, a2, fma(C3P_T18_B12, x, C3P_T18_B02 * dg))));
+            A2s[Ig][jj] = fma(tc[C3P_I_B62], a6, fma(tc[C3P_I_B32], a3, fma(tc[C3P_I_B22], a2, fma(tc[C3P_I_B12], x, tc[C3P_I_B02] * dg))));
             // B5 -> right operand, B4 -> initial value of the accumulators
-            Rm[Ig][jj] = fma(C3P_T18_B64, a6, fma(C3P_T18_B34, a3, C3P_T18_B24 * a2));
-            acc[Ig][jj] = fma(C3P_T18_B63, a6, fma(C3P_T18_B33, a3, fma(C3P_T18_B23, a2, fma(C3P_T18_B13, x, C3P_T18_B03 * dg))));
+            Rm[Ig][jj] = fma(tc[C3P_I_B64], a6, fma(tc[C3P_I_B34], a3, tc[C3P_I_B24] * a2));
+            acc[Ig][jj] = fma(tc[C3P_I_B63], a6, fma(tc[C3P_I_B33], a3, fma(tc[C3P_I_B23], a2, fma(tc[C3P_I_B13], x, tc[C3P_I_B03] * dg))));
           }
         if (tid < BS) {
           const double dg = (tid == DM - 1 || tid == BS - 1) ? 1.0 : 0.0;
           const double x = brd[S_M0 * BS + tid], a2 = brd[S_M1 * BS + tid], a3 = brd[S_M2 * BS + tid], a6 = brd[S_M3 * BS + tid];
-          border_to_image(fma(C3P_T18_A31, a3, fma(C3P_T18_A21, a2, C3P_T18_A11 * x)));
-          brd[S_M3 * BS + tid] = fma(C3P_T18_B61, a6, fma(C3P_T18_B31, a3, fma(C3P_T18_B21, a2, C3P_T18_B11 * x)));                            // B2
-          brd[S_M0 * BS + tid] = fma(C3P_T18_B62, a6, fma(C3P_T18_B32, a3, fma(C3P_T18_B22, a2, fma(C3P_T18_B12, x, C3P_T18_B02 * dg))));       // B3
-          brd[S_M1 * BS + tid] = fma(C3P_T18_B64, a6, fma(C3P_T18_B34, a3, C3P_T18_B24 * a2));                                                  // B5
-          brd[S_M2 * BS + tid] = fma(C3P_T18_B63, a6, fma(C3P_T18_B33, a3, fma(C3P_T18_B23, a2, fma(C3P_T18_B13, x, C3P_T18_B03 * dg))));       // B4
+          border_to_image(fma(tc[C3P_I_A31], a3, fma(tc[C3P_I_A21], a2, tc[C3P_I_A11] * x)));
+          brd[S_M3 * BS + tid] = fma(tc[C3P_I_B61], a6, fma(tc[C3P_I_B31], a3, fma(tc[C3P_I_B21], a2, tc[C3P_I_B11] * x)));                            // B2
+          brd[S_M0 * BS + tid] = fma(tc[C3P_I_B62], a6, fma(tc[C3P_I_B32], a3, fma(tc[C3P_I_B22], a2, fma(tc[C3P_I_B12], x, tc[C3P_I_B02] * dg))));       // B3
+          brd[S_M1 * BS + tid] = fma(tc[C3P_I_B64], a6, fma(tc[C3P_I_B34], a3, tc[C3P_I_B24] * a2));                                                  // B5
+          brd[S_M2 * BS + tid] = fma(tc[C3P_I_B63], a6, fma(tc[C3P_I_B33], a3, fma(tc[C3P_I_B23], a2, fma(tc[C3P_I_B13], x, tc[C3P_I_B03] * dg))));       // B4
         }
         op = OP_P4, sr = S_M1, si = S_M2, sd = S_R0;
       } else if (op == OP_P4) {  // C = A9: left operand B3 + A9, right operand A9, initial value B2
@@ -722,16 +730,20 @@ __global__ void __launch_bounds__(256) regr_prep_kernel(RegdPrepArgs P, double* 
   }
   __syncthreads();
   const double mu = mu_s;
-  double cs = 0, mre = 0, mim = 0;
+  double cs = 0, mre = 0, mim = 0, csym = 0;
   for (int j = tid; j < D; j += 256) {
-    double s = 0;
+    double s = 0, ssym = 0;
     for (int i = 0; i < D; ++i) {
       const cplx v = helem(i, j);
       mre = fmax(mre, fabs(v.x));
       mim = fmax(mim, fabs(v.y));
       s += fabs(i == j ? v.x - mu : v.x);
+      // symmetric (non-skew) part of the real generator: what keeps it from being normal with an imaginary spectrum (round 6:
+      // the economised T18 parameters are used while its 1-norm over the segment stays below C3P_T18N_MAX_NONNORMAL)
+      ssym += fabs(0.5 * (v.x + helem(j, i).x) - (i == j ? mu : 0.0));
     }
     cs = fmax(cs, s);
+    csym = fmax(csym, ssym);
   }
   __syncthreads();
   red0[tid] = cs;
@@ -745,6 +757,7 @@ __global__ void __launch_bounds__(256) regr_prep_kernel(RegdPrepArgs P, double* 
     }
   __syncthreads();
   red0[tid] = mim;
+  red1[tid] = csym;
   __syncthreads();
   const int TSET = NRG * NJ * 256, BS = 2 * DP;
   const long TAB_D = (long)TSET + BS + 4;
@@ -770,13 +783,13 @@ __global__ void __launch_bounds__(256) regr_prep_kernel(RegdPrepArgs P, double* 
     out[e] = g;
   }
   if (tid == 0) {
-    double gim = 0;
-    for (int i = 0; i < 256; ++i) gim = fmax(gim, red0[i]);
+    double gim = 0, nsym = 0;
+    for (int i = 0; i < 256; ++i) gim = fmax(gim, red0[i]), nsym = fmax(nsym, red1[i]);
     double* m = out + (TSET + BS);
     m[0] = mu;
     m[1] = nrm;
     m[2] = gim;
-    m[3] = gmax;
+    m[3] = nsym;  // 1-norm of the symmetric part (trace-shifted)
     tabflag[sample * (1 + P.K) + ti] = (gim <= 1e-14 * gmax) ? 1 : 0;
   }
 }

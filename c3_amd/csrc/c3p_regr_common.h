@@ -24,7 +24,7 @@ struct RR {
   static constexpr int DMP = DM + 1;
   static constexpr int IMG_D = DM * LD;
   static constexpr int TSET = NT * 256;  // elements of a tile set: element (tile, column group, lane) at tile * 256 + group * 64 + lane
-  static constexpr int TAB_D = TSET + BS + 4;   // doubles per generator table: tile set, border slot, {mu, norm1, 0, 0}
+  static constexpr int TAB_D = TSET + BS + 4;   // doubles per generator table: tile set, border slot, {mu, norm1, max |Im|, 1-norm of the symmetric part}
   static constexpr int LDS_D = IMG_D + S_NSLOT * BS + 8 * DMP + RR_KMAX * RR_CH + 2 * RR_MAXWAVES;
 };
 
