@@ -468,6 +468,7 @@ int run_pwc_smallr(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, lon
   p.lindblad = 1;
   LAUNCH_TRY(c3p_launch_smallr_prep(p, nsamp, tabs, flags, st));
   SmallRArgs a = {};
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
   a.tables = tabs;
   a.tab_per_sample = per_sample ? 1 : 0;
   a.signals = signals;
@@ -947,6 +948,8 @@ int lind_small_forward(DeviceWs* w, const LindSmallBufs& bf, const cplx* h0, lon
     rp.lindblad = 1;
     LAUNCH_TRY(c3p_launch_smallr_prep(rp, nsamp, (double*)tv, reinterpret_cast<int*>(static_cast<char*>(tv) + fl_off), st));
     SmallRArgs ra = {};
+    ra.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
+  ra.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
     ra.tables = (const double*)tv;
     ra.tab_per_sample = per_sample ? 1 : 0;
     ra.signals = signals;
@@ -1074,6 +1077,7 @@ int lind_smallr_forward(const LindSmallRBufs& bf, const cplx* h0, long h0_bs, co
   rp.lindblad = 1;
   LAUNCH_TRY(c3p_launch_smallr_prep_pair(rp, nsamp, bf.tabs, bf.tabs_t, bf.flags, st));
   SmallRArgs ra = {};
+  ra.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
   ra.tables = bf.tabs;
   ra.tab_per_sample = per_sample ? 1 : 0;
   ra.signals = signals;
@@ -1099,6 +1103,7 @@ int lind_smallr_backward(DeviceWs* w, const LindSmallRBufs& bf, bool per_sample,
   LAUNCH_TRY(c3p_launch_hb_ubar(Ubar, fr_phase, B, D, (double*)uv, st));
   LAUNCH_TRY(c3p_launch_smallr_scan(bf.seg, (const double*)uv, B, S, Dm, (double*)pv, (double*)sv, st));
   SmallRGradArgs g = {};
+  g.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
   g.tables = bf.tabs;
   g.tables_t = bf.tabs_t;
   g.tab_per_sample = per_sample ? 1 : 0;

@@ -16,6 +16,7 @@ struct SmallRArgs {
   cplx* dUs_out;         // [B,N,Dm,Dm] slice propagators (complex vectorisation) or null
   double* seg_real;      // [B,S,Dm,Dm] the same segment products, REAL (Hermitian basis), or null: input of the real backward sweep
   double* dus_real;      // [B,N,Dm,Dm] the LOCAL prefix of every slice (product of the slices of its segment in front of it), REAL, or null
+  int no_t18n;           // debug/tuning: Taylor T18 parameters also for nearly skew-symmetric generators (c3p_common.h: c3p_t18_tab)
 };
 
 // Backward sweep in the Hermitian basis (smallr_grad_kernel): the general-generator sweep of smalld_grad_general_kernel in real
@@ -31,6 +32,7 @@ struct SmallRGradArgs {
   const double* dus;       // [B,N,Dm,Dm] real local prefixes (SmallRArgs.dus_real)
   double* grad;            // [B,K,N]
   int B, K, N, Dm, S, Lmax;
+  int no_t18n;
 };
 
 bool c3p_smallr_supported(int Dh, int Dm, int K);

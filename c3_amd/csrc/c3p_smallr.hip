@@ -97,16 +97,18 @@ __global__ void __launch_bounds__(64) smallr_prep_kernel(RegdPrepArgs P, double*
   }
   __syncthreads();
   const double mu = mu_s;
-  double cs = 0, mre = 0, mim = 0;
+  double cs = 0, mre = 0, mim = 0, csym = 0;
   for (int j = tid; j < D; j += 64) {
-    double sm = 0;
+    double sm = 0, ssym = 0;
     for (int i = 0; i < D; ++i) {
       const double vx = hre[i * D + j], vy = him[i * D + j];
       mre = fmax(mre, fabs(vx));
       mim = fmax(mim, fabs(vy));
       sm += fabs(i == j ? vx - mu : vx);
+      ssym += fabs(0.5 * (vx + hre[j * D + i]) - (i == j ? mu : 0.0));  // symmetric (non-skew) part: see c3p_t18_tab
     }
     cs = fmax(cs, sm);
+    csym = fmax(csym, ssym);
   }
   red0[tid] = cs;
   red1[tid] = mre;
@@ -119,6 +121,7 @@ __global__ void __launch_bounds__(64) smallr_prep_kernel(RegdPrepArgs P, double*
     }
   __syncthreads();
   red0[tid] = mim;
+  red1[tid] = csym;
   __syncthreads();
   const int TILES = NB * NB * 16;
   double* out = tables + ((long)sample * (1 + P.K) + ti) * (TILES + 4);
@@ -134,12 +137,12 @@ __global__ void __launch_bounds__(64) smallr_prep_kernel(RegdPrepArgs P, double*
     out[e] = g;
   }
   if (tid == 0) {
-    double gim = 0;
-    for (int i = 0; i < 64; ++i) gim = fmax(gim, red0[i]);
+    double gim = 0, nsym = 0;
+    for (int i = 0; i < 64; ++i) gim = fmax(gim, red0[i]), nsym = fmax(nsym, red1[i]);
     out[TILES + 0] = mu;
     out[TILES + 1] = nrm;
     out[TILES + 2] = gim;
-    out[TILES + 3] = gmax;
+    out[TILES + 3] = nsym;  // 1-norm of the symmetric part of the (trace-shifted) real generator
     tabflag[sample * (1 + P.K) + ti] = (gim <= 1e-14 * gmax) ? 1 : 0;
   }
 }
@@ -171,7 +174,7 @@ __global__ void __launch_bounds__(64) smallr_chain_kernel(SmallRArgs A) {
   const double* gt0 = A.tables + (long)(A.tab_per_sample ? sample : 0) * (1 + K) * TABD;
   for (int e = lane; e < (1 + K) * TABD; e += 64) tab[e] = gt0[e];
   __syncthreads();
-  double nrm = tab[TILES + 1];
+  double nrm = tab[TILES + 1], nsym = tab[TILES + 3];
   for (int k = 0; k < K; ++k) {
     const double* s = A.signals + ((long)sample * K + k) * A.N + n0;
     double cmax = 0.0;
@@ -185,13 +188,19 @@ __global__ void __launch_bounds__(64) smallr_chain_kernel(SmallRArgs A) {
     cmax = fmax(cmax, __shfl_xor(cmax, 16));
     cmax = fmax(cmax, __shfl_xor(cmax, 32));
     nrm = fma(cmax, tab[(k + 1) * TABD + TILES + 1], nrm);
+    nsym = fma(cmax, tab[(k + 1) * TABD + TILES + 3], nsym);
   }
   __syncthreads();
   nrm = fmax(nrm, __shfl_xor(nrm, 4));
   nrm = fmax(nrm, __shfl_xor(nrm, 8));
+  nsym = fmax(nsym, __shfl_xor(nsym, 4));
+  nsym = fmax(nsym, __shfl_xor(nsym, 8));
+  // round 6: economised T18 parameters (radius 2.0) while the generator is skew-symmetric up to a small symmetric part
+  const int econ = __builtin_amdgcn_readfirstlane((int)(nsym <= C3P_T18N_MAX_NONNORMAL && !A.no_t18n));
+  const double* tc = c3p_t18_tab[econ];
   int ps = 0;
   {
-    double pth = C3P_T18_THETA;
+    double pth = econ ? C3P_T18N_THETA : C3P_T18_THETA;
     while (pth < nrm && ps < 40) {
       pth *= 2.0;
       ++ps;
@@ -313,22 +322,22 @@ __global__ void __launch_bounds__(64) smallr_chain_kernel(SmallRArgs A) {
     mm(A3, A6);
     {
       RMat B1, B5;
-      comb(B1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0, X, A2, A3, A6);
+      comb(B1, 0.0, tc[C3P_I_A11], tc[C3P_I_A21], tc[C3P_I_A31], 0.0, X, A2, A3, A6);
       to_image(B1);
-      comb(B5, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64, X, A2, A3, A6);
-      comb(acc, C3P_T18_B03, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63, X, A2, A3, A6);
+      comb(B5, 0.0, 0.0, tc[C3P_I_B24], tc[C3P_I_B34], tc[C3P_I_B64], X, A2, A3, A6);
+      comb(acc, tc[C3P_I_B03], tc[C3P_I_B13], tc[C3P_I_B23], tc[C3P_I_B33], tc[C3P_I_B63], X, A2, A3, A6);
       mm(B5, acc);  // A9
     }
     {
       RMat L;
-      comb(L, C3P_T18_B02, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62, X, A2, A3, A6);
+      comb(L, tc[C3P_I_B02], tc[C3P_I_B12], tc[C3P_I_B22], tc[C3P_I_B32], tc[C3P_I_B62], X, A2, A3, A6);
 #pragma unroll
       for (int I = 0; I < NB; ++I)
 #pragma unroll
         for (int J = 0; J < NB; ++J) L[I][J] += acc[I][J];
       to_image(L);
     }
-    comb(P, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61, X, A2, A3, A6);
+    comb(P, 0.0, tc[C3P_I_B11], tc[C3P_I_B21], tc[C3P_I_B31], tc[C3P_I_B61], X, A2, A3, A6);
     mm(acc, P);
     for (int it = 0; it < ps; ++it) {
       to_image(P);
@@ -561,7 +570,7 @@ __global__ void __launch_bounds__(64, (DM <= 9 ? 2 : 1)) smallr_grad_kernel(Smal
     tabt[e] = gh0[e];
   }
   __syncthreads();
-  double nrm = tabt[TILES + 1];
+  double nrm = tabt[TILES + 1], nsym = tabt[TILES + 3];
   for (int k = 0; k < K; ++k) {
     const double* s = A.signals + ((long)sample * K + k) * A.N + n0;
     double cmax = 0.0;
@@ -575,13 +584,18 @@ __global__ void __launch_bounds__(64, (DM <= 9 ? 2 : 1)) smallr_grad_kernel(Smal
     cmax = fmax(cmax, __shfl_xor(cmax, 16));
     cmax = fmax(cmax, __shfl_xor(cmax, 32));
     nrm = fma(cmax, tabt[(k + 1) * TABD + TILES + 1], nrm);
+    nsym = fma(cmax, tabt[(k + 1) * TABD + TILES + 3], nsym);
   }
   __syncthreads();
   nrm = fmax(nrm, __shfl_xor(nrm, 4));
   nrm = fmax(nrm, __shfl_xor(nrm, 8));
+  nsym = fmax(nsym, __shfl_xor(nsym, 4));
+  nsym = fmax(nsym, __shfl_xor(nsym, 8));
+  const int econ = __builtin_amdgcn_readfirstlane((int)(nsym <= C3P_T18N_MAX_NONNORMAL && !A.no_t18n));  // as in the forward kernel
+  const double* tc = c3p_t18_tab[econ];
   int ps = 0;
   {
-    double pth = C3P_T18_THETA;
+    double pth = econ ? C3P_T18N_THETA : C3P_T18_THETA;
     while (pth < nrm && ps < 40) {
       pth *= 2.0;
       ++ps;
@@ -724,17 +738,17 @@ __global__ void __launch_bounds__(64, (DM <= 9 ? 2 : 1)) smallr_grad_kernel(Smal
     RMat A9, dA9;
     {
       RMat B1, dB1;
-      comb(B1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0, X, A2, A3, A6);
-      comb(dB1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0, dX, dA2, dA3, dA6);
+      comb(B1, 0.0, tc[C3P_I_A11], tc[C3P_I_A21], tc[C3P_I_A31], 0.0, X, A2, A3, A6);
+      comb(dB1, 0.0, tc[C3P_I_A11], tc[C3P_I_A21], tc[C3P_I_A31], 0.0, dX, dA2, dA3, dA6);
       to_image(img0, B1);
       to_image(img1, dB1);
     }
     {
       RMat B5, dB5;
-      comb(B5, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64, X, A2, A3, A6);
-      comb(dB5, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64, dX, dA2, dA3, dA6);
-      comb(A9, C3P_T18_B03, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63, X, A2, A3, A6);
-      comb(dA9, 0.0, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63, dX, dA2, dA3, dA6);
+      comb(B5, 0.0, 0.0, tc[C3P_I_B24], tc[C3P_I_B34], tc[C3P_I_B64], X, A2, A3, A6);
+      comb(dB5, 0.0, 0.0, tc[C3P_I_B24], tc[C3P_I_B34], tc[C3P_I_B64], dX, dA2, dA3, dA6);
+      comb(A9, tc[C3P_I_B03], tc[C3P_I_B13], tc[C3P_I_B23], tc[C3P_I_B33], tc[C3P_I_B63], X, A2, A3, A6);
+      comb(dA9, 0.0, tc[C3P_I_B13], tc[C3P_I_B23], tc[C3P_I_B33], tc[C3P_I_B63], dX, dA2, dA3, dA6);
       mm(img0, B5, A9);
       mm(img0, dB5, dA9);
       mm(img1, B5, dA9);
@@ -742,8 +756,8 @@ __global__ void __launch_bounds__(64, (DM <= 9 ? 2 : 1)) smallr_grad_kernel(Smal
     RMat T, dT;
     {
       RMat L, dL;
-      comb(L, C3P_T18_B02, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62, X, A2, A3, A6);
-      comb(dL, 0.0, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62, dX, dA2, dA3, dA6);
+      comb(L, tc[C3P_I_B02], tc[C3P_I_B12], tc[C3P_I_B22], tc[C3P_I_B32], tc[C3P_I_B62], X, A2, A3, A6);
+      comb(dL, 0.0, tc[C3P_I_B12], tc[C3P_I_B22], tc[C3P_I_B32], tc[C3P_I_B62], dX, dA2, dA3, dA6);
 #pragma unroll
       for (int I = 0; I < NB; ++I)
 #pragma unroll
@@ -754,8 +768,8 @@ __global__ void __launch_bounds__(64, (DM <= 9 ? 2 : 1)) smallr_grad_kernel(Smal
       to_image(img0, L);
       to_image(img1, dL);
     }
-    comb(T, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61, X, A2, A3, A6);
-    comb(dT, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61, dX, dA2, dA3, dA6);
+    comb(T, 0.0, tc[C3P_I_B11], tc[C3P_I_B21], tc[C3P_I_B31], tc[C3P_I_B61], X, A2, A3, A6);
+    comb(dT, 0.0, tc[C3P_I_B11], tc[C3P_I_B21], tc[C3P_I_B31], tc[C3P_I_B61], dX, dA2, dA3, dA6);
     mm(img0, A9, T);
     mm(img0, dA9, dT);
     mm(img1, A9, dT);

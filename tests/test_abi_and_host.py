@@ -323,3 +323,69 @@ def test_economised_cos_sin_tables_are_the_generator_output_and_accurate():
                 worst = max(worst, abs(p - f))
             assert float(worst) < bound, (name, kind, float(worst))
         assert dc < 2.2e-16 and ds < 2e-17
+
+
+def test_t18_for_normal_generators():
+    """c3p_common.h's c3p_t18_tab row 1 (round 6): (1) the values tools/gen_t18_normal.py solves for, (2) the scheme with those
+    DOUBLE parameters reproduces e^{iy} on [-2, 2] to 5e-16 (exact expansion of the 5-product scheme), (3) on matrices: skew-Hermitian
+    generators and real skew-symmetric ones with a dissipator-like symmetric part up to the accepted 0.25, without squaring, are as
+    close to scipy's expm as the published Taylor parameters after one squaring."""
+    import importlib.util
+    import math
+    from decimal import Decimal as Dc
+    from fractions import Fraction as F
+
+    import scipy.linalg as sl
+
+    spec = importlib.util.spec_from_file_location("gen_t18n", os.path.join(ROOT, "tools", "gen_t18_normal.py"))
+    t = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(t)
+    text = open(os.path.join(ROOT, "c3_amd", "csrc", "c3p_common.h")).read()
+    assert "#define C3P_T18N_THETA 2.0" in text
+    rows = re.search(r"c3p_t18_tab\[2\]\[20\] = \{\s*\{([^}]*)\},\s*\{([^}]*)\},", text)
+    econ = [float.fromhex(x.strip()) for x in rows.group(2).split(",")]
+    v, resid, dc, ds = t.solve(F(2))
+    assert float(resid) < 1e-40 and dc < 1e-16 and ds < 1e-16
+    assert econ == [float(x) for x in v]
+    # the enum order of the header is the generator's parameter order
+    assert re.search(r"enum \{ " + ", ".join("C3P_I_" + n.upper() for n in t.NAMES) + r" \};", text)
+    coeff = t.t18_coeffs([Dc(x) for x in econ])
+    worst = 0.0
+    for i in range(-100, 101):
+        y = Dc(2) * i / 100
+        re_, im_, yk = Dc(0), Dc(0), Dc(1)
+        for k in range(19):
+            term = coeff[k] * yk
+            if k % 4 == 0: re_ += term
+            elif k % 4 == 1: im_ += term
+            elif k % 4 == 2: re_ -= term
+            else: im_ -= term
+            yk *= y
+        worst = max(worst, abs(complex(float(re_) - math.cos(float(y)), float(im_) - math.sin(float(y)))))
+    assert worst < 5e-16, worst
+    taylor = {k: float(x) for k, x in t.TAYLOR.items()}
+    pe = dict(zip(t.NAMES, econ))
+
+    def T18(A, p):
+        I = np.eye(A.shape[0]); A2 = A @ A; A3 = A2 @ A; A6 = A3 @ A3
+        B1 = p["a11"] * A + p["a21"] * A2 + p["a31"] * A3; B5 = p["b24"] * A2 + p["b34"] * A3 + p["b64"] * A6
+        B4 = p["b03"] * I + p["b13"] * A + p["b23"] * A2 + p["b33"] * A3 + p["b63"] * A6; A9 = B1 @ B5 + B4
+        B3 = p["b02"] * I + p["b12"] * A + p["b22"] * A2 + p["b32"] * A3 + p["b62"] * A6
+        B2 = p["b11"] * A + p["b21"] * A2 + p["b31"] * A3 + p["b61"] * A6
+        return B2 + (B3 + A9) @ A9
+
+    rng = np.random.default_rng(5)
+    for n, s in ((9, 2.0), (27, 1.6), (81, 2.0)):
+        M = rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n))
+        H = (M + M.conj().T) / 2
+        X = -1j * H * (s / np.linalg.norm(H, 2))
+        ref = sl.expm(X)
+        half = T18(X / 2, taylor)
+        assert np.linalg.norm(T18(X, pe) - ref, 2) < 1.5 * np.linalg.norm(half @ half - ref, 2) + 1e-15
+    for eps in (1e-6, 1e-2, 0.25):
+        A = rng.normal(size=(81, 81)); A = (A - A.T) / 2; A *= 1.7 / np.linalg.norm(A, 2)
+        E = rng.normal(size=(81, 81)); E = -(E @ E.T); E *= eps / np.abs(E).sum(axis=0).max()
+        X = A + E
+        ref = sl.expm(X)
+        half = T18(X / 2, taylor)
+        assert np.linalg.norm(T18(X, pe) - ref, 2) < 1.5 * np.linalg.norm(half @ half - ref, 2) + 1e-15, eps
