@@ -1297,12 +1297,12 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
         constexpr int sso = (2 * (D - 1) + 1) * W + (D - 1);
 #ifndef C3P_SD_QUADSUM
         // Round 6: the ECONOMISED polynomials of c3p_common.h (Y is real symmetric, so the polynomial error on [0, theta^2] IS the
-        // matrix error).  Scaling against theta_7 = 1.30; a scaled norm below theta_6 = 0.83 (cfg2: 0.81) takes the degree-6 pair:
+        // matrix error).  Scaling against theta_8 = 1.85; a scaled norm below theta_6 = 0.83 (cfg2: 0.81) takes the degree-6 pair:
         // W, W^2, W^3, ONE paired Horner step in W^3, sin = (sin Y / Y) Y -- 6 products at dependency depth 5 (the degree-8 Taylor
-        // pair needed W^4: 7); above it the degree-7 pair with W^4 (7 products where the degree-9 / 8 Taylor pair took 8).
+        // pair needed W^4: 7); above it the degree-8 pair with W^4 (7 products where the degree-9 / 8 Taylor pair, theta 1.13, took 8).
         int ps_s = 0;
         {
-          double p = C3P_MM7_THETA;
+          double p = C3P_MM8_THETA;
           while (p < nrm && ps_s < 40) {
             p *= 2.0;
             ++ps_s;
@@ -1317,7 +1317,7 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
         const bool small_var = deg16;
 #endif
         auto split_loop = [&](auto deg16_tag) {
-          constexpr bool DEG16 = decltype(deg16_tag)::value;  // (round-6 build: true = the degree-6 pair, false = the degree-7 pair)
+          constexpr bool DEG16 = decltype(deg16_tag)::value;  // (round-6 build: true = the degree-6 pair, false = the degree-8 pair)
           for (int t = 0; t < tmax; ++t) {
             const bool act = valid && t < len;
             const double sc = act ? rscale_s : 0.0;
@@ -1413,18 +1413,30 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
               s8_comb<NC, false, true>(Sp, c3p_mm6_sinc[0], c3p_mm6_sinc[1], c3p_mm6_sinc[2], 0.0, W1, W2, W3, lp);
               mm_s8x2r(acc, acs, W3, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
             } else {
-              // degree 7: cos = (c0 + c1 W + c2 W^2 + c3 W^3) + W^4 (c4 + c5 W + c6 W^2 + c7 W^3); W^3 is not a product operand
+              // degree 8: cos = (c0 + c1 W + c2 W^2 + c3 W^3) + W^4 (c4 + c5 W + c6 W^2 + c7 W^3 + c8 W^4); W^3 is not a product operand
               SM W4;
               s8_zero(W4);
               mm_s8(W1, W2, W3);
               mm_s8(W2, W2, W4);
               s8_finish(W4, swap_lane, tail_lane);
-              s8_comb<NC, true, true>(acc, c3p_mm7_cos[4], c3p_mm7_cos[5], c3p_mm7_cos[6], c3p_mm7_cos[7], W1, W2, W3, lp);
-              s8_comb<NC, true, true>(acs, c3p_mm7_sinc[4], c3p_mm7_sinc[5], c3p_mm7_sinc[6], c3p_mm7_sinc[7], W1, W2, W3, lp);
+              s8_comb<NC, true, true>(acc, c3p_mm8_cos[4], c3p_mm8_cos[5], c3p_mm8_cos[6], c3p_mm8_cos[7], W1, W2, W3, lp);
+              s8_comb<NC, true, true>(acs, c3p_mm8_sinc[4], c3p_mm8_sinc[5], c3p_mm8_sinc[6], c3p_mm8_sinc[7], W1, W2, W3, lp);
+#pragma unroll
+              for (int I = 0; I < NC; ++I) {
+#pragma unroll
+                for (int J = I; J < NC; ++J) {
+                  acc.m[I][J] = fma(c3p_mm8_cos[8], W4.m[I][J], acc.m[I][J]);
+                  acs.m[I][J] = fma(c3p_mm8_sinc[8], W4.m[I][J], acs.m[I][J]);
+                }
+                acc.vr[I] = fma(c3p_mm8_cos[8], W4.vr[I], acc.vr[I]);
+                acs.vr[I] = fma(c3p_mm8_sinc[8], W4.vr[I], acs.vr[I]);
+              }
+              acc.s = fma(c3p_mm8_cos[8], W4.s, acc.s);
+              acs.s = fma(c3p_mm8_sinc[8], W4.s, acs.s);
               s8_finish_lower(acc, swap_lane);
               s8_finish_lower(acs, swap_lane);
-              s8_comb<NC, true, true>(Cm, c3p_mm7_cos[0], c3p_mm7_cos[1], c3p_mm7_cos[2], c3p_mm7_cos[3], W1, W2, W3, lp);
-              s8_comb<NC, true, true>(Sp, c3p_mm7_sinc[0], c3p_mm7_sinc[1], c3p_mm7_sinc[2], c3p_mm7_sinc[3], W1, W2, W3, lp);
+              s8_comb<NC, true, true>(Cm, c3p_mm8_cos[0], c3p_mm8_cos[1], c3p_mm8_cos[2], c3p_mm8_cos[3], W1, W2, W3, lp);
+              s8_comb<NC, true, true>(Sp, c3p_mm8_sinc[0], c3p_mm8_sinc[1], c3p_mm8_sinc[2], c3p_mm8_sinc[3], W1, W2, W3, lp);
               mm_s8x2r(acc, acs, W4, Cm, Sp);  // Cm = cos Y, Sp = sin(Y) / Y
             }
 #endif
