@@ -168,10 +168,12 @@ struct MfmaPlan {
   int r;    // q = 4 degree 4r (when !t18)
   int s;    // squarings
 };
-__host__ __device__ __forceinline__ MfmaPlan c3p_pick_plan_mfma(double nrm) {
+// (theta18: C3P_T18_THETA for any matrix, C3P_T18N_THETA when the generator is known to be normal with an imaginary spectrum
+// and the economised parameters of c3p_t18_tab row 1 are used)
+__host__ __device__ __forceinline__ MfmaPlan c3p_pick_plan_mfma(double nrm, double theta18 = C3P_T18_THETA) {
   const TaylorPlan q = c3p_pick_plan_q4(nrm);
   int s18 = 0;
-  double p = C3P_T18_THETA;
+  double p = theta18;
   while (p < nrm && s18 < 40) {
     p *= 2.0;
     ++s18;

@@ -314,6 +314,7 @@ struct MidCommon {
   int rb12, rctr;  // pinwheel deal: 16 columns from column 12 of row r; the centre block's K-packed fragments (row 4b + r, column 12 + c)
   unsigned negmask;
   int pr, ps, t18;
+  int t18n;  // T18 with the economised parameters for normal generators (c3p_t18_tab row 1)
   double scale;
   const double* tabs;
   double *buf0, *buf1, *buf2, *sg;
@@ -1284,19 +1285,20 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
             out.set(e, v);
           }
         };
+        const double* tc = c3p_t18_tab[cm.t18n];
         Regs T1, T2;
-        comb(T1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0);  // B1
-        comb(T2, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64);  // B5
+        comb(T1, 0.0, tc[C3P_I_A11], tc[C3P_I_A21], tc[C3P_I_A31], 0.0);  // B1
+        comb(T2, 0.0, 0.0, tc[C3P_I_B24], tc[C3P_I_B34], tc[C3P_I_B64]);  // B5
         __syncthreads();  // buf0 (X) no longer read
         store_tiles(cm.buf0, T1);
         store_tiles(cm.buf2, T2);
-        comb(T1, C3P_T18_B03, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63);  // B4
+        comb(T1, tc[C3P_I_B03], tc[C3P_I_B13], tc[C3P_I_B23], tc[C3P_I_B33], tc[C3P_I_B63]);  // B4
         __syncthreads();
         product(cm.buf0, cm.buf2, T1);  // T1 = A9
-        comb(T2, C3P_T18_B02, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62);  // B3
+        comb(T2, tc[C3P_I_B02], tc[C3P_I_B12], tc[C3P_I_B22], tc[C3P_I_B32], tc[C3P_I_B62]);  // B3
 #pragma unroll
         for (int e = 0; e < NE; ++e) T2.set(e, T2.get(e) + T1.get(e));
-        comb(P, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61);  // B2
+        comb(P, 0.0, tc[C3P_I_B11], tc[C3P_I_B21], tc[C3P_I_B31], tc[C3P_I_B61]);  // B2
         __syncthreads();  // buf0 / buf2 no longer read
         store_tiles(cm.buf0, T2);
         store_tiles(cm.buf2, T1);
@@ -1473,6 +1475,7 @@ __global__ void __launch_bounds__(256, (REAL ? (Sched<MDR<NIG, W>::NIGR, NJ>::PW
   cm.pr = 1;
   cm.ps = 0;
   cm.t18 = 0;
+  cm.t18n = 0;
   cm.scale = 1.0;
   if constexpr (!GIVEN) {
     // segment-wide plan from ||G0|| + sum_k max_t |c_k(t)| ||G_k||  (XG: max of the per-slice norms)
@@ -1503,7 +1506,13 @@ __global__ void __launch_bounds__(256, (REAL ? (Sched<MDR<NIG, W>::NIGR, NJ>::PW
       nrm = fma(cmax, cm.tabs[(long)(k + 1) * (IMG + 4) + IMG + 2], nrm);
     }
     nrm = md_rfl(nrm);
-    const MfmaPlan p = c3p_pick_plan_mfma(nrm);
+    // round 6: Hermitian Hamiltonians (every table flagged skew-Hermitian by the prep kernel) -> T18 with the economised
+    // parameters, radius 2.0 instead of 1.13
+    bool normalG = !GIVEN && !XG && (A.mode == C3P_MODE_UNITARY) && !A.no_t18n;
+    if constexpr (!GIVEN && !XG)
+      for (int k = 0; k <= K; ++k) normalG = normalG && (cm.tabs[(long)k * (IMG + 4) + IMG + 3] < 0.0);
+    cm.t18n = __builtin_amdgcn_readfirstlane((int)normalG);
+    const MfmaPlan p = c3p_pick_plan_mfma(nrm, cm.t18n ? C3P_T18N_THETA : C3P_T18_THETA);
     cm.pr = __builtin_amdgcn_readfirstlane(p.r);
     cm.ps = __builtin_amdgcn_readfirstlane(p.s);
     cm.t18 = __builtin_amdgcn_readfirstlane(p.t18);
@@ -1613,7 +1622,7 @@ __global__ void __launch_bounds__(256) midd_prep_kernel(MidPrepArgs P) {
     mu[1] = bq / D;
   }
   __syncthreads();
-  double cs = 0, remax = 0, asym = 0;
+  double cs = 0, remax = 0, asym = 0, rsk = 0;
   for (int j = tid; j < D; j += 256) {
     double s = 0;
     for (int i = 0; i < D; ++i) {
@@ -1624,13 +1633,21 @@ __global__ void __launch_bounds__(256) midd_prep_kernel(MidPrepArgs P) {
       }
       s += hypot(v.x, v.y);
       remax = fmax(remax, fabs(v.x));
-      if (i < j) asym = fmax(asym, fabs(v.y - gelem(j, i).y));
+      if (i < j) {
+        const cplx w = gelem(j, i);
+        asym = fmax(asym, fabs(v.y - w.y));
+        rsk = fmax(rsk, fabs(v.x + w.x));  // G + G^H: Re part antisymmetric, Im part symmetric <=> the Hamiltonian is Hermitian
+      } else if (i == j) {
+        rsk = fmax(rsk, fabs(v.x));
+      }
     }
     cs = fmax(cs, s);
   }
   redr[tid] = cs;
   redi[tid] = remax;
   reda[tid] = asym;
+  __shared__ double redk[256];
+  redk[tid] = rsk;
   __syncthreads();
   const int IMG = P.tile_nig ? P.tile_nig * P.tile_nj * 64 : P.rows * P.W;
   double* out = P.tables + ((long)sample * (1 + P.K) + ti) * (IMG + 4);
@@ -1669,10 +1686,14 @@ __global__ void __launch_bounds__(256) midd_prep_kernel(MidPrepArgs P) {
     double as = 0;
     for (int i = 0; i < 256; ++i) as = fmax(as, reda[i]);
     if (as > 1e-14 * nrm) re = fmax(re, as);
+    double sk = as;
+    for (int i = 0; i < 256; ++i) sk = fmax(sk, redk[i]);
     out[IMG + 0] = mu[0];
     out[IMG + 1] = mu[1];
     out[IMG + 2] = nrm;
-    out[IMG + 3] = P.lindblad ? 1.0 : re;  // 0: G purely imaginary (real Hamiltonian) -> real path of the mid-D kernel
+    // 0: G purely imaginary (real symmetric Hamiltonian) -> real path of the mid-D kernel; NEGATIVE: complex but skew-Hermitian to
+    // rounding (Hermitian Hamiltonian: a normal generator, the economised T18 parameters apply); positive: anything else
+    out[IMG + 3] = P.lindblad ? 1.0 : ((re > 0.0 && sk <= 1e-14 * nrm && !P.conjT) ? -re : re);
   }
 }
 

@@ -21,16 +21,17 @@ def tile_utilisation(Dm, kernel):
         # core + border form of the real path (round 4): the (Dm-1)^2 core tiles exactly; of the matrix instructions of a slice
         # (degree-16 variant: 7 symmetric products of NC^2 (NC+1)/2, the chain step's 3 NC^3 core and 3 NC^2 row-border ones)
         # only the row-border instructions of the chain step carry padding (one of four A rows)
-        # round 6: the border sums run on the matrix cores as well -- per slice (degree-16 variant) 7 symmetric products of
-        # NC^2 (NC+1)/2 exact core instructions + (NC + 1) reductions against a tile of ones each, the chain step's 3 NC^3 core,
-        # 3 NC^2 row-border (the border row in all four rows of the A tile: 1/4 useful) and 2 (NC + 1) reduction instructions.
-        # A reduction instruction adds 4 x 4 partial products to 4 sums per block: 12 useful additions of its 128 flops.
+        # round 6: the border sums run on the matrix cores as well, and the degree-6 economised pair needs 6 symmetric products
+        # (cfg1 / cfg2 scale below theta_6 = 0.83): per slice 6 products of NC^2 (NC+1)/2 exact core instructions + (NC + 1)
+        # reductions against a tile of ones each, the chain step's 3 NC^3 core, 3 NC^2 row-border (the border row in all four
+        # rows of the A tile: 1/4 useful) and 2 (NC + 1) reduction instructions.  A reduction instruction adds 4 x 4 partial
+        # products to 4 sums per block: 12 useful additions of its 128 flops.
         nc = (Dm - 1) // 4
-        sym, core, row = 7 * nc * nc * (nc + 1) // 2, 3 * nc**3, 3 * nc * nc
-        red = 7 * (nc + 1) + 2 * (nc + 1)
+        sym, core, row = 6 * nc * nc * (nc + 1) // 2, 3 * nc**3, 3 * nc * nc
+        red = 6 * (nc + 1) + 2 * (nc + 1)
         return (sym + core + 0.25 * row + (12.0 / 128.0) * red) / (sym + core + row + red), (
             f"small-D kernel, core + border form: {sym} + {core} exact core MFMAs, {row} row-border MFMAs at 1/4 and {red} "
-            f"reduction MFMAs at 12/128 per slice (degree-16 variant)")
+            f"reduction MFMAs at 12/128 per slice (degree-6 economised variant)")
     if Dm <= 12:
         p = 4 * ((Dm + 3) // 4)
         kk = 1.0 if Dm % 4 == 1 else Dm / p
