@@ -509,6 +509,7 @@ int run_pwc_smalld(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const 
     counters = (int*)cv;
   }
   SmallArgs a = {};
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
   if (inline_tables) {
     // unitary mode: the chain kernel builds its tables itself (no dependent launch in front of it)
     a.inline_tables = 1;
@@ -742,6 +743,7 @@ int run_xg_smalld(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, d
   if (ws_get(w, SL_TABLES, (size_t)B * N * 4 * sizeof(double), &mv)) return -1;
   LAUNCH_TRY(c3p_launch_hmeta(hs, hs_bstride, (long)B * N, N, D, coef_r, coef_i, (double*)mv, st));
   SmallArgs a = {};
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
   a.hs = hs;
   a.hs_bstride = hs_bstride;
   a.meta = (const double*)mv;
@@ -814,6 +816,7 @@ int run_vjp_smalld(DeviceWs* w, GradArgs& G, hipStream_t st) {
     if (ws_get(w, SL_SEG_F, 2 * segb, &fv)) return -1;
   }
   SmallArgs a = {};
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
   a.tables = p.tables;
   a.tab_per_sample = per_sample ? 1 : 0;
   a.signals = G.signals;
@@ -965,6 +968,7 @@ int lind_small_forward(DeviceWs* w, const LindSmallBufs& bf, const cplx* h0, lon
     return 0;
   }
   SmallArgs a = {};
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
   a.tables = bf.tabs;
   a.tab_per_sample = per_sample ? 1 : 0;
   a.signals = signals;
@@ -1391,6 +1395,7 @@ int run_vjp_xg_general(DeviceWs* w, const cplx* hs, long hs_bstride, double coef
   const int Lmax = (int)((N + S - 1) / S);
   if (small) {
     SmallArgs a = {};
+    a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
     a.hs = hs;
     a.hs_bstride = hs_bstride;
     a.meta = (const double*)mv;

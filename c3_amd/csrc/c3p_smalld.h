@@ -32,6 +32,7 @@ struct SmallArgs {
   // Fused ordered combine (table modes, S % 4 == 0): every wave folds its four consecutive
   // segments in registers, publishes one partial product, and the last wave to arrive for a
   // sample (per-sample counter, agent-scope release/acquire) folds the S/4 partials into U.
+  int no_t18n;  // debug/tuning: Taylor T18 parameters also for Hermitian Hamiltonians (c3p_common.h: c3p_t18_tab)
   int fuse;
   // MW mode with two waves per SIMD: slices of the segments of the first half of a sample's chains (the OLDER waves of
   // their SIMDs, which the arbiter serves first); 0 = equal segments.  Set by the launcher.

@@ -1038,18 +1038,22 @@ __device__ __forceinline__ void build_tables(const SmallArgs& A, int sample, dou
     // the real fast path also needs Y = -Im G symmetric (Hermitian input).  Dressed operators V^T H V are
     // symmetric only to rounding (measured 5e-16 relative), so asymmetry below 1e-14 ||G|| counts as none;
     // anything larger is folded into the flag and sends the sample to the complex path.
-    double asym = 0.0;
+    double asym = 0.0, rsk = 0.0;
 #pragma unroll
     for (int q = 0; q < NE; ++q) {
       const int e = lane + 64 * q;
       if (e < D * D) {
         const int i = e / D, j = e - i * D;
         asym = fmax(asym, fabs(gi[q] - out[(2 * j + 1) * W + i]));
+        rsk = fmax(rsk, fabs(gr[q] + out[(2 * j) * W + i]));  // G + G^H = 0 <=> Hermitian Hamiltonian (diagonal: 2 Re G_ii)
       }
     }
     asym = wave_max64(asym);
+    rsk = wave_max64(rsk);
     if (asym > 1e-14 * nrm) remax = fmax(remax, asym);
     remax = wave_max64(remax);
+    // (round 6) NEGATIVE: complex but skew-Hermitian to rounding -- a normal generator: T18 with the economised parameters
+    if (remax > 0.0 && fmax(asym, rsk) <= 1e-14 * nrm) remax = -remax;
     if (lane == 0) {
       out[MAT + 0] = mur;
       out[MAT + 1] = mui;
@@ -1228,7 +1232,12 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
     nrm = fmax(nrm, __shfl_xor(nrm, 4));
     nrm = fmax(nrm, __shfl_xor(nrm, 8));
     nrm = readfirstlane_f64(nrm);
-    const MfmaPlan plan = c3p_pick_plan_mfma(nrm);
+    // (round 6) Hermitian Hamiltonians -- every table flagged skew-Hermitian -- take T18 with the economised parameters (radius 2.0)
+    bool normalG = !XG && (A.mode == C3P_MODE_UNITARY) && !A.no_t18n;
+    if constexpr (!XG)
+      for (int k = 0; k <= K; ++k) normalG = normalG && (tab[k * (MAT + 4) + MAT + 3] < 0.0);
+    const int t18n = __builtin_amdgcn_readfirstlane((int)normalG);
+    const MfmaPlan plan = c3p_pick_plan_mfma(nrm, t18n ? C3P_T18N_THETA : C3P_T18_THETA);
     const int pr = __builtin_amdgcn_readfirstlane(plan.r);
     const int ps = __builtin_amdgcn_readfirstlane(plan.s);
     const int t18 = __builtin_amdgcn_readfirstlane(plan.t18);
@@ -1762,6 +1771,28 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
       }  // !SPLIT
     } else {
     // the slice loop is instantiated per plan (T18 / Paterson-Stockmeyer) with the branch outside, as on the real path
+    // (the 20 parameters as wave-uniform values loaded ONCE: read through the table inside the slice loop they were re-fetched per slice)
+    const double* tc = c3p_t18_tab[t18n];
+    const double t18_a11 = tc[C3P_I_A11];
+    const double t18_a21 = tc[C3P_I_A21];
+    const double t18_a31 = tc[C3P_I_A31];
+    const double t18_b02 = tc[C3P_I_B02];
+    const double t18_b03 = tc[C3P_I_B03];
+    const double t18_b11 = tc[C3P_I_B11];
+    const double t18_b12 = tc[C3P_I_B12];
+    const double t18_b13 = tc[C3P_I_B13];
+    const double t18_b21 = tc[C3P_I_B21];
+    const double t18_b22 = tc[C3P_I_B22];
+    const double t18_b23 = tc[C3P_I_B23];
+    const double t18_b24 = tc[C3P_I_B24];
+    const double t18_b31 = tc[C3P_I_B31];
+    const double t18_b32 = tc[C3P_I_B32];
+    const double t18_b33 = tc[C3P_I_B33];
+    const double t18_b34 = tc[C3P_I_B34];
+    const double t18_b61 = tc[C3P_I_B61];
+    const double t18_b62 = tc[C3P_I_B62];
+    const double t18_b63 = tc[C3P_I_B63];
+    const double t18_b64 = tc[C3P_I_B64];
     auto complex_loop = [&](auto t18_tag) {
     constexpr bool T18 = decltype(t18_tag)::value;
     for (int t = 0; t < tmax; ++t) {
@@ -1829,22 +1860,22 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
         double acc[NBI][NJ];
         {
           double B1[NBI][NJ], B5[NBI][NJ];
-          lincomb6<D>(B1, 0.0, C3P_T18_A11, C3P_T18_A21, C3P_T18_A31, 0.0, X, A2, A3, A6, ddelta, rhalf);
+          lincomb6<D>(B1, 0.0, t18_a11, t18_a21, t18_a31, 0.0, X, A2, A3, A6, ddelta, rhalf);
           write_image<D>(B1, img, woff);
-          lincomb6<D>(B5, 0.0, 0.0, C3P_T18_B24, C3P_T18_B34, C3P_T18_B64, X, A2, A3, A6, ddelta, rhalf);
-          lincomb6<D>(acc, C3P_T18_B03, C3P_T18_B13, C3P_T18_B23, C3P_T18_B33, C3P_T18_B63, X, A2, A3, A6, ddelta, rhalf);
+          lincomb6<D>(B5, 0.0, 0.0, t18_b24, t18_b34, t18_b64, X, A2, A3, A6, ddelta, rhalf);
+          lincomb6<D>(acc, t18_b03, t18_b13, t18_b23, t18_b33, t18_b63, X, A2, A3, A6, ddelta, rhalf);
           mm_img<D>(img, roff, negmask, B5, acc);  // acc = A9 = B1 B5 + B4
         }
         {
           double L[NBI][NJ];
-          lincomb6<D>(L, C3P_T18_B02, C3P_T18_B12, C3P_T18_B22, C3P_T18_B32, C3P_T18_B62, X, A2, A3, A6, ddelta, rhalf);
+          lincomb6<D>(L, t18_b02, t18_b12, t18_b22, t18_b32, t18_b62, X, A2, A3, A6, ddelta, rhalf);
 #pragma unroll
           for (int I = 0; I < NBI; ++I)
 #pragma unroll
             for (int J = 0; J < NJ; ++J) L[I][J] += acc[I][J];
           write_image<D>(L, img, woff);
         }
-        lincomb6<D>(P, 0.0, C3P_T18_B11, C3P_T18_B21, C3P_T18_B31, C3P_T18_B61, X, A2, A3, A6, ddelta, rhalf);
+        lincomb6<D>(P, 0.0, t18_b11, t18_b21, t18_b31, t18_b61, X, A2, A3, A6, ddelta, rhalf);
         mm_img<D>(img, roff, negmask, acc, P);  // P = B2 + (B3 + A9) A9
       } else {
         {
@@ -2146,13 +2177,15 @@ __global__ void __launch_bounds__(64) smalld_prep_kernel(PrepArgs P) {
     out[MAT + 1] = mu[1];
     out[MAT + 2] = nrm;
     // 0 exactly when the Hamiltonian is real (the generator is purely imaginary): selects the real fast path
-    double remax = 0, asym = 0;  // real AND symmetric (to rounding: see build_tables)
+    double remax = 0, asym = 0, rsk = 0;  // real AND symmetric (to rounding: see build_tables)
     for (int e = 0; e < D * D; ++e) {
       const int i = e / D, j = e - i * D;
       remax = fmax(remax, fabs(g[2 * e]));
       asym = fmax(asym, fabs(g[2 * e + 1] - g[2 * (j * D + i) + 1]));
+      rsk = fmax(rsk, fabs(g[2 * e] + g[2 * (j * D + i)]));
     }
     if (asym > 1e-14 * nrm) remax = fmax(remax, asym);
+    if (remax > 0.0 && fmax(asym, rsk) <= 1e-14 * nrm) remax = -remax;  // skew-Hermitian: see build_tables
     out[MAT + 3] = P.lindblad ? 1.0 : remax;
   }
 }

@@ -5,7 +5,7 @@ from c3_amd import propagation as prop, _lib
 from oracle import c3_oracle
 rng = np.random.default_rng(3)
 t = lambda a: torch.as_tensor(a, device="cuda:0")
-for D in (13, 20, 27, 36):
+for D in (tuple(int(x) for x in sys.argv[1:]) or (13, 20, 27, 36)):
     herm = lambda s: (lambda m: s * (m + m.conj().T) / 2)(rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))
     h0 = np.diag(rng.uniform(0, 1, D)).astype(complex) + herm(0.05); hks = np.stack([herm(0.3) for _ in range(2)])
     B, N = 64, 200
