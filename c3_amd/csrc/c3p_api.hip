@@ -468,7 +468,7 @@ int run_pwc_smallr(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, lon
   p.lindblad = 1;
   LAUNCH_TRY(c3p_launch_smallr_prep(p, nsamp, tabs, flags, st));
   SmallRArgs a = {};
-  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? (int)c3p_opt(C3P_OPT_no_t18n) : 0;
   a.tables = tabs;
   a.tab_per_sample = per_sample ? 1 : 0;
   a.signals = signals;
@@ -509,7 +509,7 @@ int run_pwc_smalld(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const 
     counters = (int*)cv;
   }
   SmallArgs a = {};
-  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? (int)c3p_opt(C3P_OPT_no_t18n) : 0;
   if (inline_tables) {
     // unitary mode: the chain kernel builds its tables itself (no dependent launch in front of it)
     a.inline_tables = 1;
@@ -715,7 +715,7 @@ int run_xg_midd(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, dou
   a.mode = C3P_MODE_EXPM;
   a.dUs_out = dUs_out;
   a.no_t18 = c3p_opt_on(C3P_OPT_no_t18) ? 1 : 0;
-  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? (int)c3p_opt(C3P_OPT_no_t18n) : 0;
   a.no_real = c3p_opt_on(C3P_OPT_no_real) ? 1 : 0;
   if (S == 1) {
     a.seg_out = U_out;
@@ -743,7 +743,7 @@ int run_xg_smalld(DeviceWs* w, const cplx* hs, long hs_bstride, double coef_r, d
   if (ws_get(w, SL_TABLES, (size_t)B * N * 4 * sizeof(double), &mv)) return -1;
   LAUNCH_TRY(c3p_launch_hmeta(hs, hs_bstride, (long)B * N, N, D, coef_r, coef_i, (double*)mv, st));
   SmallArgs a = {};
-  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? (int)c3p_opt(C3P_OPT_no_t18n) : 0;
   a.hs = hs;
   a.hs_bstride = hs_bstride;
   a.meta = (const double*)mv;
@@ -816,7 +816,7 @@ int run_vjp_smalld(DeviceWs* w, GradArgs& G, hipStream_t st) {
     if (ws_get(w, SL_SEG_F, 2 * segb, &fv)) return -1;
   }
   SmallArgs a = {};
-  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? (int)c3p_opt(C3P_OPT_no_t18n) : 0;
   a.tables = p.tables;
   a.tab_per_sample = per_sample ? 1 : 0;
   a.signals = G.signals;
@@ -951,8 +951,8 @@ int lind_small_forward(DeviceWs* w, const LindSmallBufs& bf, const cplx* h0, lon
     rp.lindblad = 1;
     LAUNCH_TRY(c3p_launch_smallr_prep(rp, nsamp, (double*)tv, reinterpret_cast<int*>(static_cast<char*>(tv) + fl_off), st));
     SmallRArgs ra = {};
-    ra.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
-  ra.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
+    ra.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? (int)c3p_opt(C3P_OPT_no_t18n) : 0;
+  ra.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? (int)c3p_opt(C3P_OPT_no_t18n) : 0;
     ra.tables = (const double*)tv;
     ra.tab_per_sample = per_sample ? 1 : 0;
     ra.signals = signals;
@@ -968,7 +968,7 @@ int lind_small_forward(DeviceWs* w, const LindSmallBufs& bf, const cplx* h0, lon
     return 0;
   }
   SmallArgs a = {};
-  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? (int)c3p_opt(C3P_OPT_no_t18n) : 0;
   a.tables = bf.tabs;
   a.tab_per_sample = per_sample ? 1 : 0;
   a.signals = signals;
@@ -1081,7 +1081,7 @@ int lind_smallr_forward(const LindSmallRBufs& bf, const cplx* h0, long h0_bs, co
   rp.lindblad = 1;
   LAUNCH_TRY(c3p_launch_smallr_prep_pair(rp, nsamp, bf.tabs, bf.tabs_t, bf.flags, st));
   SmallRArgs ra = {};
-  ra.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
+  ra.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? (int)c3p_opt(C3P_OPT_no_t18n) : 0;
   ra.tables = bf.tabs;
   ra.tab_per_sample = per_sample ? 1 : 0;
   ra.signals = signals;
@@ -1107,7 +1107,7 @@ int lind_smallr_backward(DeviceWs* w, const LindSmallRBufs& bf, bool per_sample,
   LAUNCH_TRY(c3p_launch_hb_ubar(Ubar, fr_phase, B, D, (double*)uv, st));
   LAUNCH_TRY(c3p_launch_smallr_scan(bf.seg, (const double*)uv, B, S, Dm, (double*)pv, (double*)sv, st));
   SmallRGradArgs g = {};
-  g.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
+  g.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? (int)c3p_opt(C3P_OPT_no_t18n) : 0;
   g.tables = bf.tabs;
   g.tables_t = bf.tabs_t;
   g.tab_per_sample = per_sample ? 1 : 0;
@@ -1246,7 +1246,7 @@ int run_pwc_midd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
   a.mode = lindblad ? C3P_MODE_LINDBLAD : C3P_MODE_UNITARY;
   a.dUs_out = dUs_out;
   a.no_t18 = c3p_opt_on(C3P_OPT_no_t18) ? 1 : 0;
-  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? (int)c3p_opt(C3P_OPT_no_t18n) : 0;
   a.no_real = c3p_opt_on(C3P_OPT_no_real) ? 1 : 0;
   if (S == 1) {
     a.seg_out = U_out;
@@ -1325,7 +1325,7 @@ int run_vjp_lind_midd(DeviceWs* w, const cplx* h0, long h0_bs, const cplx* hks, 
   a.seg_out = (cplx*)sv;
   a.dUs_out = dUs;
   a.no_t18 = c3p_opt_on(C3P_OPT_no_t18) ? 1 : 0;
-  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? (int)c3p_opt(C3P_OPT_no_t18n) : 0;
   a.no_real = 1;
   LAUNCH_TRY(c3p_launch_midd_chain(a, st));
   GradArgs G = {};
@@ -1395,7 +1395,7 @@ int run_vjp_xg_general(DeviceWs* w, const cplx* hs, long hs_bstride, double coef
   const int Lmax = (int)((N + S - 1) / S);
   if (small) {
     SmallArgs a = {};
-    a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
+    a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? (int)c3p_opt(C3P_OPT_no_t18n) : 0;
     a.hs = hs;
     a.hs_bstride = hs_bstride;
     a.meta = (const double*)mv;
@@ -1426,7 +1426,7 @@ int run_vjp_xg_general(DeviceWs* w, const cplx* hs, long hs_bstride, double coef
     a.seg_out = (cplx*)sv;
     a.dUs_out = dUs;
     a.no_t18 = c3p_opt_on(C3P_OPT_no_t18) ? 1 : 0;
-    a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
+    a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? (int)c3p_opt(C3P_OPT_no_t18n) : 0;
     a.no_real = 1;
     LAUNCH_TRY(c3p_launch_midd_chain(a, st));
   }
@@ -1618,7 +1618,7 @@ int run_pwc_regd(DeviceWs* w, int lindblad, const cplx* h0, long h0_bs, const cp
     a.hb_tables = rtables;
     a.hb_tabflag = tabflag;
   }
-  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? (int)c3p_opt(C3P_OPT_no_t18n) : 0;
   cplx* seg = U_out;
   if (S > 1) {
     void* sv;
@@ -1803,7 +1803,7 @@ int lind_regr_forward(DeviceWs* w, const LindRegrBufs& bf, const cplx* h0, long 
   a.hb_tables = bf.tab_f;
   a.hb_tabflag = bf.flag_f;
   a.hb_qT = bf.qT;
-  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? 1 : 0;
+  a.no_t18n = c3p_opt_on(C3P_OPT_no_t18n) ? (int)c3p_opt(C3P_OPT_no_t18n) : 0;
   a.seg_out = bf.seg;
   LAUNCH_TRY(c3p_launch_regr_chain(a, av, st));
   return 0;

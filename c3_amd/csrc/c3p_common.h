@@ -160,17 +160,32 @@ __constant__ double c3p_t18_tab[2][20] = {
     {-0x1.eb38ce5c91740p-4, -0x1.25636bcf4b5b5p-7, -0x1.04c9aedbe699cp-10, 0x1.6a80b11b0bcabp-3, 0x1.1dc21d43eb4cfp+0, 0x1.420dbe5746422p-2, -0x1.289454f80f910p-11, -0x1.3deb71e2be061p+2, 0x1.b130d3faac326p+0, 0x1.21f0bba48bb5dp-4, -0x1.f3a48235292fdp-9, 0x1.1ada67e7564b6p-15, -0x1.8ccda6e1cc3c0p-3, -0x1.b823d05f2b313p-3, 0x1.b4116a8ca5541p-5, 0x1.83665c777fc72p-6, -0x1.5ac92f9e0ac99p-17, -0x1.d79745bcca89dp-4, -0x1.7f4469c9ea034p-7, -0x1.9a9222987bdffp-17},
 };
 
+// FOUR-product evaluation of exp for normal generators with an imaginary spectrum (round 6; tools/gen_t16n4.py): the 16-parameter
+// degree-16 scheme
+//     A2 = A^2,   y0 = A2 (e0 A2 + e1 A),   y1 = (y0 + e2 A2 + e3 A)(y0 + e4 A2) + e5 y0 + e6 A2,
+//     exp ~ y2 = (y1 + e7 A2 + e8 A)(y1 + e9 y0 + e10 A) + e11 y1 + e12 y0 + e13 A2 + e14 A + e15 I
+// with its parameters solved (70-digit Gauss-Newton) for the Chebyshev-economised target on [-1.35 i, 1.35 i]: error bound 7.9e-17
+// (even part) / 1.4e-17 (odd part), + 1.1e-16 for the unit constant term; with the parameters in double 6e-16 on the interval, and in
+// double-precision matrix tests MORE accurate than the published T18 (5 products, radius 1.13) at every norm <= 1.35, also next to a
+// dissipator of norm 0.25 (tests/test_abi_and_host.py::test_four_product_scheme_for_normal_generators).  Used where T18N is: Hermitian
+// Hamiltonians on the complex small-D / mid-D loops, nearly skew-symmetric real Lindblad generators.
+#define C3P_E4N_THETA 1.35
+// (compile-time constants: the kernels index them with literals, so they are instruction operands, not loads)
+constexpr double c3p_e4n[16] = {-0x1.a2dcd9f317fb5p-12, -0x1.7eb9c3a1416fep-9, 0x1.001119dfac460p-7, -0x1.9f18356154345p-2, -0x1.0a6d848c42c9ep-5, 0x1.ca82628a0fca7p-5, 0x1.0a698401e0e35p-2, -0x1.e6fe451dff289p-3, -0x1.9f4a7dec6c165p-6, -0x1.70af6b378b1a2p+2, 0x1.17d3c4bc46d68p+1, 0x1.44da69372b3bap+3, 0x1.579d596d5062bp+1, -0x1.0af90f8857611p+1, 0x1.0000000000000p+0, 0x1.0000000000000p+0};
+
 // Plan for the MFMA kernels: either the q = 4 Paterson-Stockmeyer polynomial (degree 4r,
 // 3 + (r-1) products) or T18 (5 products), plus s squarings; fewest products wins, ties go
 // to Paterson-Stockmeyer (less element-wise work).
 struct MfmaPlan {
-  int t18;  // 1: use T18
+  int t18;  // 1: use T18; 2: the four-product scheme c3p_e4n (normal generators only)
   int r;    // q = 4 degree 4r (when !t18)
   int s;    // squarings
 };
 // (theta18: C3P_T18_THETA for any matrix, C3P_T18N_THETA when the generator is known to be normal with an imaginary spectrum
 // and the economised parameters of c3p_t18_tab row 1 are used)
-__host__ __device__ __forceinline__ MfmaPlan c3p_pick_plan_mfma(double nrm, double theta18 = C3P_T18_THETA) {
+// (normal: also consider the four-product scheme, 4 + s products; it wins whenever T18N would need a squaring that it does not, and
+// ties with 5 + (s - 1) go to T18N's smaller truncation error)
+__host__ __device__ __forceinline__ MfmaPlan c3p_pick_plan_mfma(double nrm, double theta18 = C3P_T18_THETA, bool normal = false) {
   const TaylorPlan q = c3p_pick_plan_q4(nrm);
   int s18 = 0;
   double p = theta18;
@@ -188,6 +203,20 @@ __host__ __device__ __forceinline__ MfmaPlan c3p_pick_plan_mfma(double nrm, doub
     m.t18 = 0;
     m.r = q.r;
     m.s = q.s;
+  }
+  if (normal) {
+    int s4 = 0;
+    double p4 = C3P_E4N_THETA;
+    while (p4 < nrm && s4 < 40) {
+      p4 *= 2.0;
+      ++s4;
+    }
+    const int cost = m.t18 ? 5 + m.s : 3 + (m.r - 1) + m.s;
+    if (4 + s4 < cost) {
+      m.t18 = 2;
+      m.r = 0;
+      m.s = s4;
+    }
   }
   return m;
 }

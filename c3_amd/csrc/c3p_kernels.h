@@ -24,7 +24,7 @@
   X(segments)           /* segments per sample, mid D */                                                               \
   X(no_many_rounds)     /* mid D: round-1 segment rule */                                                              \
   X(no_t18)             /* Paterson-Stockmeyer plan only */                                                            \
-  X(no_t18n)            /* keep the Taylor T18 parameters (radius 1.13) where the economised ones for normal generators apply */ \
+  X(no_t18n)            /* 1: keep the Taylor T18 parameters (radius 1.13) where the schemes for normal generators apply; 2: keep T18N, drop only the four-product scheme */ \
   X(no_real)            /* real Hamiltonians on the complex instances */                                               \
   X(no_real_grad)       /* real Hamiltonians on the general backward sweeps */                                         \
   X(grad_target)        /* chains per launch of the VALU backward sweep */                                             \

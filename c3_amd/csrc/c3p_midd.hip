@@ -1207,7 +1207,8 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
   // the slice loop is instantiated per plan (T18 / Paterson-Stockmeyer), branch outside: inside the loop the two
   // variants' live ranges merge
   auto slice_loop = [&](auto t18_tag) {
-  constexpr bool T18 = decltype(t18_tag)::value;
+  constexpr int VARIANT = decltype(t18_tag)::value;  // 0 Paterson-Stockmeyer, 1 T18, 2 the four-product scheme (c3p_e4n, normal generators)
+  constexpr bool T18 = VARIANT == 1;
   for (int t = 0; t < cm.len; ++t) {
     if constexpr (!GIVEN && !XG)
       if ((t & (SGC - 1)) == 0) md_stage_signals<WV>(A, cm, t);
@@ -1265,6 +1266,46 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
       product(cm.buf0, cm.buf0, A2);
       store_tiles(cm.buf1, A2);
       __syncthreads();
+      if constexpr (VARIANT == 2) {
+        // ---- four products (c3p_common.h): y0 = A2 (e0 A2 + e1 X); y1 = (y0 + e2 A2 + e3 X)(y0 + e4 A2) + e5 y0 + e6 A2;
+        //      P = (y1 + e7 A2 + e8 X)(y1 + e9 y0 + e10 X) + e11 y1 + e12 y0 + e13 A2 + e14 X + e15 I.  A3 holds y0, acc y1 ----
+        constexpr const double (&ec)[16] = c3p_e4n;
+        zero(A3);
+        zero(acc);
+        auto comb = [&](Regs& out, double c0, double cx, double c2, double c3, double c6) {
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            double v = cx * X.get(e);
+            v = fma(c2, A2.get(e), v);
+            v = fma(c3, A3.get(e), v);
+            v = fma(c6, acc.get(e), v);
+            v += (c0 != 0.0 && is_diag(e)) ? c0 : 0.0;
+            out.set(e, v);
+          }
+        };
+        Regs T1, T2;
+        comb(T1, 0.0, ec[1], ec[0], 0.0, 0.0);
+        store_tiles(cm.buf2, T1);
+        __syncthreads();
+        product(cm.buf1, cm.buf2, A3);  // y0
+        comb(T1, 0.0, ec[3], ec[2], 1.0, 0.0);
+        comb(T2, 0.0, 0.0, ec[4], 1.0, 0.0);
+        __syncthreads();  // buf0 (X), buf2 no longer read
+        store_tiles(cm.buf0, T1);
+        store_tiles(cm.buf2, T2);
+        comb(T1, 0.0, 0.0, ec[6], ec[5], 0.0);
+        __syncthreads();
+        product(cm.buf0, cm.buf2, T1);
+        acc = T1;  // y1
+        comb(T1, 0.0, ec[8], ec[7], 0.0, 1.0);
+        comb(T2, 0.0, ec[10], 0.0, ec[9], 1.0);
+        comb(P, ec[15], ec[14], ec[13], ec[12], ec[11]);
+        __syncthreads();
+        store_tiles(cm.buf0, T1);
+        store_tiles(cm.buf2, T2);
+        __syncthreads();
+        product(cm.buf0, cm.buf2, P);
+      } else {
       zero(A3);
       product(cm.buf0, cm.buf1, A3);
       __syncthreads();  // all waves done reading A2 from buf1
@@ -1340,6 +1381,7 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
           P = acc;
         }
       }
+      }  // VARIANT != 2
       // ---- squarings ----
       for (int it = 0; it < cm.ps; ++it) {
         __syncthreads();
@@ -1383,10 +1425,12 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
     }
   }
   };
-  if (cm.t18)
-    slice_loop(std::true_type{});
+  if (cm.t18 == 2)
+    slice_loop(std::integral_constant<int, 2>{});
+  else if (cm.t18)
+    slice_loop(std::integral_constant<int, 1>{});
   else
-    slice_loop(std::false_type{});
+    slice_loop(std::integral_constant<int, 0>{});
   // ---- segment result: scalar e^{sum mu}, optional row phases ----
   double sn, cs;
   sincos(mus_i, &sn, &cs);
@@ -1508,11 +1552,11 @@ __global__ void __launch_bounds__(256, (REAL ? (Sched<MDR<NIG, W>::NIGR, NJ>::PW
     nrm = md_rfl(nrm);
     // round 6: Hermitian Hamiltonians (every table flagged skew-Hermitian by the prep kernel) -> T18 with the economised
     // parameters, radius 2.0 instead of 1.13
-    bool normalG = !GIVEN && !XG && (A.mode == C3P_MODE_UNITARY) && !A.no_t18n;
+    bool normalG = !GIVEN && !XG && (A.mode == C3P_MODE_UNITARY) && !(A.no_t18n & 1);
     if constexpr (!GIVEN && !XG)
-      for (int k = 0; k <= K; ++k) normalG = normalG && (cm.tabs[(long)k * (IMG + 4) + IMG + 3] < 0.0);
+      for (int k = 0; k <= K; ++k) normalG = normalG && (cm.tabs[(long)k * (IMG + 4) + IMG + 3] <= 0.0);  // negative: complex skew-Hermitian; zero: real symmetric Hamiltonian
     cm.t18n = __builtin_amdgcn_readfirstlane((int)normalG);
-    const MfmaPlan p = c3p_pick_plan_mfma(nrm, cm.t18n ? C3P_T18N_THETA : C3P_T18_THETA);
+    const MfmaPlan p = c3p_pick_plan_mfma(nrm, cm.t18n ? C3P_T18N_THETA : C3P_T18_THETA, cm.t18n != 0 && !(A.no_t18n & 2));
     cm.pr = __builtin_amdgcn_readfirstlane(p.r);
     cm.ps = __builtin_amdgcn_readfirstlane(p.s);
     cm.t18 = __builtin_amdgcn_readfirstlane(p.t18);

@@ -406,7 +406,7 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
     // symmetric part is small the economised T18 parameters apply (radius 2.0 instead of 1.13: cfg4 needs no squaring)
     double nsym = meta(0)[3];
     for (int k = 0; k < K; ++k) nsym = fma(kmaxv[k], meta(k + 1)[3], nsym);
-    const int econ = __builtin_amdgcn_readfirstlane((int)(rr_rfl(nsym) <= C3P_T18N_MAX_NONNORMAL && !A.no_t18n));
+    const int econ = __builtin_amdgcn_readfirstlane((int)(rr_rfl(nsym) <= C3P_T18N_MAX_NONNORMAL && !(A.no_t18n & 1)));
     const double* tc = c3p_t18_tab[econ];
     int s18 = 0;
     {

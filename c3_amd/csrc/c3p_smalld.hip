@@ -1233,11 +1233,11 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
     nrm = fmax(nrm, __shfl_xor(nrm, 8));
     nrm = readfirstlane_f64(nrm);
     // (round 6) Hermitian Hamiltonians -- every table flagged skew-Hermitian -- take T18 with the economised parameters (radius 2.0)
-    bool normalG = !XG && (A.mode == C3P_MODE_UNITARY) && !A.no_t18n;
+    bool normalG = !XG && (A.mode == C3P_MODE_UNITARY) && !(A.no_t18n & 1);
     if constexpr (!XG)
-      for (int k = 0; k <= K; ++k) normalG = normalG && (tab[k * (MAT + 4) + MAT + 3] < 0.0);
+      for (int k = 0; k <= K; ++k) normalG = normalG && (tab[k * (MAT + 4) + MAT + 3] <= 0.0);  // negative: complex skew-Hermitian; zero: real symmetric Hamiltonian
     const int t18n = __builtin_amdgcn_readfirstlane((int)normalG);
-    const MfmaPlan plan = c3p_pick_plan_mfma(nrm, t18n ? C3P_T18N_THETA : C3P_T18_THETA);
+    const MfmaPlan plan = c3p_pick_plan_mfma(nrm, t18n ? C3P_T18N_THETA : C3P_T18_THETA, t18n != 0 && !(A.no_t18n & 2));
     const int pr = __builtin_amdgcn_readfirstlane(plan.r);
     const int ps = __builtin_amdgcn_readfirstlane(plan.s);
     const int t18 = __builtin_amdgcn_readfirstlane(plan.t18);
@@ -1794,7 +1794,8 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
     const double t18_b63 = tc[C3P_I_B63];
     const double t18_b64 = tc[C3P_I_B64];
     auto complex_loop = [&](auto t18_tag) {
-    constexpr bool T18 = decltype(t18_tag)::value;
+    constexpr int VARIANT = decltype(t18_tag)::value;  // 0 Paterson-Stockmeyer, 1 T18, 2 the four-product scheme (normal generators)
+    constexpr bool T18 = VARIANT == 1;
     for (int t = 0; t < tmax; ++t) {
       const bool act = valid && t < len;
       // ---- X = scale (G0 + sum_k c_k G_k) in D-layout; trace shift mu ----
@@ -1847,6 +1848,36 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
 #pragma unroll
         for (int J = 0; J < NJ; ++J) A2[I][J] = A3[I][J] = 0.0;
       mm_img<D>(img, roff, negmask, X, A2);
+      if constexpr (VARIANT == 2) {
+        // ---- four products (c3p_common.h, c3p_e4n): A2 above; y0 = A2 (e0 A2 + e1 X);
+        //      y1 = (y0 + e2 A2 + e3 X)(y0 + e4 A2) + e5 y0 + e6 A2;
+        //      P = (y1 + e7 A2 + e8 X)(y1 + e9 y0 + e10 X) + e11 y1 + e12 y0 + e13 A2 + e14 X + e15 I ----
+        // (lincomb6(out, c0, cx, c2, c3, c6, X, A2, M3, M6) = c0 I + cx X + c2 A2 + c3 M3 + c6 M6, here with M3 = y0, M6 = y1;
+        //  A3 holds y0)
+        double y1[NBI][NJ];
+        {
+          double R[NBI][NJ];
+          lincomb6<D>(R, 0.0, c3p_e4n[1], c3p_e4n[0], 0.0, 0.0, X, A2, A2, A2, ddelta, rhalf);
+          write_image<D>(A2, img, woff);
+          mm_img<D>(img, roff, negmask, R, A3);
+        }
+        {
+          double L[NBI][NJ], R[NBI][NJ];
+          lincomb6<D>(L, 0.0, c3p_e4n[3], c3p_e4n[2], 1.0, 0.0, X, A2, A3, A3, ddelta, rhalf);
+          write_image<D>(L, img, woff);
+          lincomb6<D>(R, 0.0, 0.0, c3p_e4n[4], 1.0, 0.0, X, A2, A3, A3, ddelta, rhalf);
+          lincomb6<D>(y1, 0.0, 0.0, c3p_e4n[6], c3p_e4n[5], 0.0, X, A2, A3, A3, ddelta, rhalf);
+          mm_img<D>(img, roff, negmask, R, y1);
+        }
+        {
+          double L[NBI][NJ], R[NBI][NJ];
+          lincomb6<D>(L, 0.0, c3p_e4n[8], c3p_e4n[7], 0.0, 1.0, X, A2, A3, y1, ddelta, rhalf);
+          write_image<D>(L, img, woff);
+          lincomb6<D>(R, 0.0, c3p_e4n[10], 0.0, c3p_e4n[9], 1.0, X, A2, A3, y1, ddelta, rhalf);
+          lincomb6<D>(P, c3p_e4n[15], c3p_e4n[14], c3p_e4n[13], c3p_e4n[12], c3p_e4n[11], X, A2, A3, y1, ddelta, rhalf);
+          mm_img<D>(img, roff, negmask, R, P);
+        }
+      } else {
       mm_img<D>(img, roff, negmask, A2, A3);
       if constexpr (T18) {
         // ---- T18 (Bader-Blanes-Casas): 5 products in total ----
@@ -1907,6 +1938,7 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
             for (int J = 0; J < NJ; ++J) P[I][J] = acc[I][J];
         }
       }
+      }  // VARIANT != 2
       // ---- squarings ----
       for (int it = 0; it < ps; ++it) {
         write_image<D>(P, img, woff);
@@ -1954,10 +1986,12 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
       }
     }
     };
-    if (t18)
-      complex_loop(std::true_type{});
+    if (t18 == 2)
+      complex_loop(std::integral_constant<int, 2>{});
+    else if (t18)
+      complex_loop(std::integral_constant<int, 1>{});
     else
-      complex_loop(std::false_type{});
+      complex_loop(std::integral_constant<int, 0>{});
     }  // complex path
   }
   // ---- segment result ----

@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(64) smallr_chain_kernel(SmallRArgs A) {
   nsym = fmax(nsym, __shfl_xor(nsym, 4));
   nsym = fmax(nsym, __shfl_xor(nsym, 8));
   // round 6: economised T18 parameters (radius 2.0) while the generator is skew-symmetric up to a small symmetric part
-  const int econ = __builtin_amdgcn_readfirstlane((int)(nsym <= C3P_T18N_MAX_NONNORMAL && !A.no_t18n));
+  const int econ = __builtin_amdgcn_readfirstlane((int)(nsym <= C3P_T18N_MAX_NONNORMAL && !(A.no_t18n & 1)));
   const double* tc = c3p_t18_tab[econ];
   int ps = 0;
   {
@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(64, (DM <= 9 ? 2 : 1)) smallr_grad_kernel(Smal
   nrm = fmax(nrm, __shfl_xor(nrm, 8));
   nsym = fmax(nsym, __shfl_xor(nsym, 4));
   nsym = fmax(nsym, __shfl_xor(nsym, 8));
-  const int econ = __builtin_amdgcn_readfirstlane((int)(nsym <= C3P_T18N_MAX_NONNORMAL && !A.no_t18n));  // as in the forward kernel
+  const int econ = __builtin_amdgcn_readfirstlane((int)(nsym <= C3P_T18N_MAX_NONNORMAL && !(A.no_t18n & 1)));  // as in the forward kernel
   const double* tc = c3p_t18_tab[econ];
   int ps = 0;
   {

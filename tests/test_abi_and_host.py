@@ -325,6 +325,95 @@ def test_economised_cos_sin_tables_are_the_generator_output_and_accurate():
         assert dc < 2.2e-16 and ds < 2e-17
 
 
+
+def test_four_product_scheme_for_normal_generators():
+    """c3p_common.h's c3p_e4n (round 6): (1) the values tools/gen_t16n4.py solves for (unit constant term forced), (2) the scheme with
+    those DOUBLE parameters reproduces e^{iy} on [-1.35, 1.35] to 8e-16 (exact expansion of the 4-product scheme), (3) on matrices:
+    skew-Hermitian generators, and real skew-symmetric ones with a dissipator-like symmetric part up to the accepted 0.25, at norms up to
+    the radius are as close to scipy's expm as the published 5-product T18 (whose radius 1.13 they exceed: T18 takes one squaring there),
+    (4) the plan rule: the four products are taken exactly when they save a product over T18N / Paterson-Stockmeyer."""
+    import importlib.util
+    import math
+    from decimal import Decimal as Dc
+    from fractions import Fraction as F
+
+    import scipy.linalg as sl
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    g, t18 = load("gen_t16n4"), load("gen_t18_normal")
+    text = open(os.path.join(ROOT, "c3_amd", "csrc", "c3p_common.h")).read()
+    assert "#define C3P_E4N_THETA 1.35" in text
+    e = [float.fromhex(x.strip()) for x in re.search(r"c3p_e4n\[16\] = \{([^}]*)\};", text).group(1).split(",")]
+    u, resid, dc, ds, r0, r1 = g.solve(F(135, 100))
+    assert float(resid) < 1e-40 and dc < 1e-16 and ds < 2e-17
+    want = [float(x) for x in u]
+    assert abs(want[15] - 1.0) < 2.3e-16
+    want[15] = 1.0
+    assert e == want
+    coeff = g.scheme([Dc(x) for x in e])
+    worst = 0.0
+    for i in range(-100, 101):
+        y = Dc("1.35") * i / 100
+        re_, im_, yk = Dc(0), Dc(0), Dc(1)
+        for k in range(17):
+            term = coeff[k] * yk
+            if k % 4 == 0: re_ += term
+            elif k % 4 == 1: im_ += term
+            elif k % 4 == 2: re_ -= term
+            else: im_ -= term
+            yk *= y
+        worst = max(worst, abs(complex(float(re_) - math.cos(float(y)), float(im_) - math.sin(float(y)))))
+    assert worst < 8e-16, worst
+
+    def E4(A):
+        I = np.eye(A.shape[0]); A2 = A @ A
+        y0 = A2 @ (e[0] * A2 + e[1] * A)
+        y1 = (y0 + e[2] * A2 + e[3] * A) @ (y0 + e[4] * A2) + e[5] * y0 + e[6] * A2
+        return (y1 + e[7] * A2 + e[8] * A) @ (y1 + e[9] * y0 + e[10] * A) + e[11] * y1 + e[12] * y0 + e[13] * A2 + e[14] * A + e[15] * I
+
+    taylor = {k: float(x) for k, x in t18.TAYLOR.items()}
+
+    def T18(A, p=taylor):
+        I = np.eye(A.shape[0]); A2 = A @ A; A3 = A2 @ A; A6 = A3 @ A3
+        B1 = p["a11"] * A + p["a21"] * A2 + p["a31"] * A3; B5 = p["b24"] * A2 + p["b34"] * A3 + p["b64"] * A6
+        B4 = p["b03"] * I + p["b13"] * A + p["b23"] * A2 + p["b33"] * A3 + p["b63"] * A6; A9 = B1 @ B5 + B4
+        B3 = p["b02"] * I + p["b12"] * A + p["b22"] * A2 + p["b32"] * A3 + p["b62"] * A6
+        B2 = p["b11"] * A + p["b21"] * A2 + p["b31"] * A3 + p["b61"] * A6
+        return B2 + (B3 + A9) @ A9
+
+    rng = np.random.default_rng(6)
+    for n, s in ((9, 1.35), (9, 0.8), (27, 1.3), (36, 1.0)):
+        M = rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n))
+        H = (M + M.conj().T) / 2
+        X = -1j * H * (s / np.linalg.norm(H, 2))
+        ref = sl.expm(X)
+        half = T18(X / 2)
+        other = half @ half if s > 1.13 else T18(X)
+        assert np.linalg.norm(E4(X) - ref, 2) < 1.5 * np.linalg.norm(other - ref, 2) + 1e-15, (n, s)
+    for eps in (1e-6, 1e-2, 0.25):
+        A = rng.normal(size=(81, 81)); A = (A - A.T) / 2; A *= 1.1 / np.linalg.norm(A, 2)
+        E = rng.normal(size=(81, 81)); E = -(E @ E.T); E *= eps / np.abs(E).sum(axis=0).max()
+        X = A + E
+        ref = sl.expm(X)
+        assert np.linalg.norm(E4(X) - ref, 2) < 1.5 * np.linalg.norm(T18(X) - ref, 2) + 1e-15, eps
+    assert np.array_equal(E4(np.zeros((5, 5))), np.eye(5))
+
+    # (4) the plan rule of c3p_pick_plan_mfma(nrm, 2.0, normal = true), restated: products of each candidate
+    def squarings(theta, nrm):
+        s = 0
+        while theta * 2.0**s < nrm:
+            s += 1
+        return s
+
+    for nrm, four in ((0.5, True), (1.35, True), (1.36, False), (2.0, False), (2.1, True), (2.7, True), (2.71, False), (4.0, False), (5.0, True)):
+        assert (4 + squarings(1.35, nrm) < 5 + squarings(2.0, nrm)) == four, nrm
+
+
 def test_t18_for_normal_generators():
     """c3p_common.h's c3p_t18_tab row 1 (round 6): (1) the values tools/gen_t18_normal.py solves for, (2) the scheme with those
     DOUBLE parameters reproduces e^{iy} on [-2, 2] to 5e-16 (exact expansion of the 5-product scheme), (3) on matrices: skew-Hermitian

@@ -120,11 +120,12 @@ def test_economised_polynomials_at_their_thresholds(prop, D):
             assert np.abs(g - gg).max() < 1e-10 * max(1.0, np.abs(gg).max()), (D, target)
 
 
-@pytest.mark.parametrize("D", [13, 20, 27, 36])
-def test_t18_for_normal_generators_on_the_mid_d_complex_instance(prop, D):
-    """complex HERMITIAN Hamiltonians at 13 <= D <= 40: the prep kernel flags skew-Hermitian generator tables and the chain kernel
-    evaluates T18 with the economised parameters (radius 2.0: no squaring up to there); a NON-Hermitian Hamiltonian keeps the
-    Taylor parameters.  Both against the oracle, and against each other through the no_t18n switch."""
+@pytest.mark.parametrize("D", [5, 9, 12, 13, 20, 27, 36])
+def test_normal_generator_schemes_on_the_complex_instances(prop, D):
+    """complex HERMITIAN Hamiltonians at D <= 40 (small-D and mid-D complex loops): the prep kernel flags skew-Hermitian generator
+    tables and the chain kernel evaluates the four-product scheme (radius 1.35) or T18 with the economised parameters (radius 2.0),
+    whichever needs fewer products -- targets on both sides of 1.35, 2.0, 2.7 (= 1.35 with one squaring) and 4.0; a NON-Hermitian
+    Hamiltonian keeps the Taylor parameters.  Both against the oracle, and against each other through the no_t18n switch."""
     import torch
 
     from c3_amd import _lib
@@ -139,7 +140,7 @@ def test_t18_for_normal_generators_on_the_mid_d_complex_instance(prop, D):
     sig = rng.uniform(-1, 1, size=(B, 2, N))
     one = lambda h: np.abs(h - np.trace(h) / D * np.eye(D)).sum(axis=0).max()
     bound = one(h0) + sum(np.abs(sig[:, k, :]).max() * one(hks[k]) for k in range(2))
-    for target in (0.9, 1.5, 1.99, 2.01, 4.5):
+    for target in (0.9, 1.34, 1.36, 1.99, 2.01, 2.69, 2.72, 4.5, 5.2):
         dt = target / bound
         U = prop.propagate_batch(t(h0), t(hks), t(sig), dt)["U"].cpu().numpy()
         with _lib.options(no_t18n=1):
@@ -147,6 +148,19 @@ def test_t18_for_normal_generators_on_the_mid_d_complex_instance(prop, D):
         ref = c3_oracle.propagate_batch(h0, hks, sig, dt)
         assert max(np.linalg.norm(U[b] - ref[b]) for b in range(B)) < 2e-12, (D, target)
         assert max(np.linalg.norm(U[b] - V[b]) for b in range(B)) < 2e-12, (D, target)
+    # REAL symmetric drift and first control operator next to one complex Hermitian operator (bench.py --complex): tables with a zero
+    # real part count as normal too
+    h0r, hkm = h0.real.astype(complex), np.stack([hks[0].real.astype(complex), hks[1]])
+    hkm[0] = (hkm[0] + hkm[0].T) / 2
+    for target in (1.2, 2.5):
+        dt = target / bound
+        U = prop.propagate_batch(t(h0r), t(hkm), t(sig), dt)["U"].cpu().numpy()
+        name = _lib.last_kernel_detail()
+        with _lib.options(no_t18n=1):
+            V = prop.propagate_batch(t(h0r), t(hkm), t(sig), dt)["U"].cpu().numpy()
+        ref = c3_oracle.propagate_batch(h0r, hkm, sig, dt)
+        assert max(np.linalg.norm(U[b] - ref[b]) for b in range(B)) < 2e-12, (D, target, name)
+        assert 1e-17 < max(np.linalg.norm(U[b] - V[b]) for b in range(B)) < 2e-12, (D, target)  # not the same scheme
     # not Hermitian: the flag must not be set (the economised polynomial is only valid on an imaginary spectrum)
     h0n = h0 + 0.05 * (rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))
     dt = 1.6 / bound
