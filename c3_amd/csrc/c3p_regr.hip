@@ -418,6 +418,9 @@ __device__ __forceinline__ void regr_chain_body(const MidArgs& A, long long* dbg
     }
     const int ps = __builtin_amdgcn_readfirstlane(s18);
     const double scale = ldexp(1.0, -ps);
+#ifdef C3P_REGR_PLAN_PRINT
+    if (blockIdx.x < 4 && tid == 0) printf("regr chain %d: norm bound %.4f, symmetric part %.4f, economised %d, squarings %d\n", (int)blockIdx.x, nrm, nsym, econ, ps);
+#endif
 
     double mu = 0.0, mus = 0.0;
     auto stage_signals = [&](int t) {  // slices [t, t + RR_CH) of the segment

@@ -206,6 +206,18 @@ __global__ void __launch_bounds__(64) smallr_chain_kernel(SmallRArgs A) {
       ++ps;
     }
   }
+  // ... or the four-product scheme for normal generators (c3p_common.h: c3p_e4n, radius 1.35) where it saves a product
+  int e4 = 0;
+  if (econ && !(A.no_t18n & 2)) {
+    int s4 = 0;
+    double pth = C3P_E4N_THETA;
+    while (pth < nrm && s4 < 40) {
+      pth *= 2.0;
+      ++s4;
+    }
+    if (4 + s4 < 5 + ps) e4 = 1, ps = s4;
+  }
+  e4 = __builtin_amdgcn_readfirstlane(e4);
   ps = __builtin_amdgcn_readfirstlane(ps);
   const double scale = ldexp(1.0, -ps);
 
@@ -312,11 +324,41 @@ __global__ void __launch_bounds__(64) smallr_chain_kernel(SmallRArgs A) {
 #pragma unroll
         for (int J = 0; J < NB; ++J) X[I][J] = fma(ck, tk[(I * NB + J) * 16 + idx16], X[I][J]);
     }
-    // T18 (Bader-Blanes-Casas): A2 = X X, A3 = X A2, A6 = A3 A3, A9 = B1 B5 + B4, exp = B2 + (B3 + A9) A9
     RMat A2, A3, A6, P, acc;
     zero(A2), zero(A3), zero(A6);
     to_image(X);
     mm(X, A2);
+    if (e4) {
+      // four products: y0 = A2 (e0 A2 + e1 X); y1 = (y0 + e2 A2 + e3 X)(y0 + e4 A2) + e5 y0 + e6 A2;
+      // exp = (y1 + e7 A2 + e8 X)(y1 + e9 y0 + e10 X) + e11 y1 + e12 y0 + e13 A2 + e14 X + e15 I   (A3 holds y0, A6 y1)
+      {
+        RMat R;
+        comb(R, 0.0, c3p_e4n[1], c3p_e4n[0], 0.0, 0.0, X, A2, A3, A6);
+        to_image(A2);
+        mm(R, A3);
+      }
+      {
+        RMat L, R;
+        comb(L, 0.0, c3p_e4n[3], c3p_e4n[2], 1.0, 0.0, X, A2, A3, A6);
+        to_image(L);
+        comb(R, 0.0, 0.0, c3p_e4n[4], 1.0, 0.0, X, A2, A3, A6);
+        comb(L, 0.0, 0.0, c3p_e4n[6], c3p_e4n[5], 0.0, X, A2, A3, A6);
+        mm(R, L);
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+          for (int J = 0; J < NB; ++J) A6[I][J] = L[I][J];
+      }
+      {
+        RMat L, R;
+        comb(L, 0.0, c3p_e4n[8], c3p_e4n[7], 0.0, 1.0, X, A2, A3, A6);
+        to_image(L);
+        comb(R, 0.0, c3p_e4n[10], 0.0, c3p_e4n[9], 1.0, X, A2, A3, A6);
+        comb(P, c3p_e4n[15], c3p_e4n[14], c3p_e4n[13], c3p_e4n[12], c3p_e4n[11], X, A2, A3, A6);
+        mm(R, P);
+      }
+    } else {
+    // T18 (Bader-Blanes-Casas): A2 = X X, A3 = X A2, A6 = A3 A3, A9 = B1 B5 + B4, exp = B2 + (B3 + A9) A9
     mm(A2, A3);
     to_image(A3);
     mm(A3, A6);
@@ -339,6 +381,7 @@ __global__ void __launch_bounds__(64) smallr_chain_kernel(SmallRArgs A) {
     }
     comb(P, 0.0, tc[C3P_I_B11], tc[C3P_I_B21], tc[C3P_I_B31], tc[C3P_I_B61], X, A2, A3, A6);
     mm(acc, P);
+    }
     for (int it = 0; it < ps; ++it) {
       to_image(P);
       RMat Q;

@@ -167,3 +167,35 @@ def test_normal_generator_schemes_on_the_complex_instances(prop, D):
     U = prop.propagate_batch(t(h0n), t(hks), t(sig), dt)["U"].cpu().numpy()
     ref = c3_oracle.propagate_batch(h0n, hks, sig, dt)
     assert max(np.linalg.norm(U[b] - ref[b]) for b in range(B)) < 1e-11 * max(1.0, max(np.linalg.norm(ref[b]) for b in range(B)))
+
+
+@pytest.mark.parametrize("D", [2, 3, 4])
+def test_normal_generator_schemes_on_the_small_real_lindblad_kernel(prop, D):
+    """Lindblad chains of D = 2, 3, 4 in the Hermitian basis (c3p_smallr.hip): weak dissipators (symmetric part of the real
+    generator <= 0.25) take the four-product scheme or T18 with the economised parameters; generator norms from 0.3 to 12 walk
+    through every plan.  Against the oracle, and the three schemes against each other (no_t18n = 2: T18N only, 1: published T18)."""
+    from c3_amd import _lib
+    from oracle import c3_oracle
+
+    rng = np.random.default_rng(640 + D)
+    herm = lambda s: (lambda a: s * (a + a.conj().T) / 2)(rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))
+    B, K, N = 6, 2, 60
+    h0, hks = herm(0.8), np.stack([herm(0.5) for _ in range(K)])
+    col = np.stack([0.05 * (rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))])
+    sig = rng.uniform(-1, 1, size=(B, K, N))
+    differ = 0
+    for dt in (0.05, 0.12, 0.2, 0.3, 0.45, 0.7, 1.1, 2.0):
+        got = np.asarray(prop.propagate_batch(h0, hks, sig, dt, col_ops=col, lindbladian=True)["U"])
+        assert "smallr_chain_kernel" in _lib.last_kernel_detail()
+        with _lib.options(no_t18n=2):
+            mid = np.asarray(prop.propagate_batch(h0, hks, sig, dt, col_ops=col, lindbladian=True)["U"])
+        with _lib.options(no_t18n=1):
+            old = np.asarray(prop.propagate_batch(h0, hks, sig, dt, col_ops=col, lindbladian=True)["U"])
+        ref = c3_oracle.propagate_batch(h0, hks, sig[:2], dt, col_ops=col, lindbladian=True)
+        for b in range(2):
+            # (the oracle follows TF's Pade-13 rule, itself ~1e-11 at generator norms above 5: DESIGN 8 -- the bar here, the schemes
+            #  against each other two orders tighter)
+            assert np.linalg.norm(got[b] - ref[b]) < (2e-12 if dt < 1.0 else 1e-10) * max(1.0, np.linalg.norm(ref[b])), (D, dt)
+        assert np.abs(got - mid).max() < 2e-12 and np.abs(got - old).max() < 2e-12, (D, dt)
+        differ += int(np.abs(got - mid).max() > 0)
+    assert differ >= 2  # the four-product scheme was taken at several of the norms
