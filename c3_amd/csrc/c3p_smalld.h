@@ -37,6 +37,7 @@ struct SmallArgs {
   // MW mode with two waves per SIMD: slices of the segments of the first half of a sample's chains (the OLDER waves of
   // their SIMDs, which the arbiter serves first); 0 = equal segments.  Set by the launcher.
   int seg_long;
+  int seg_long_c;  // the same for samples that take the COMPLEX loop (its optimum differs: 640 against 700 per mille at D = 9); 0 = seg_long
   int* counters;   // [B], zeroed by the prep kernel of the same call
   cplx* final_out;  // [B,Dm,Dm]
 };

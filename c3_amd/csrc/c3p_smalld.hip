@@ -1111,23 +1111,26 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
   const int seg = (int)(cc - (long)sample * A.S);
   int n0 = (int)(((long)seg * A.N) / A.S);
   int n1 = (int)(((long)(seg + 1) * A.N) / A.S);
-  if (MW && A.seg_long > 0) {
-    // uneven segments: the first S / 2 chains (waves 0 .. 3, the older wave of each SIMD) take seg_long slices each, the
-    // others share the rest
-    const int h = A.S >> 1;
-    const long rest = (long)A.N - (long)h * A.seg_long;
-    n0 = seg < h ? seg * A.seg_long : h * A.seg_long + (int)(((long)(seg - h) * rest) / h);
-    n1 = seg + 1 <= h ? (seg + 1) * A.seg_long : h * A.seg_long + (int)(((long)(seg + 1 - h) * rest) / h);
-  }
-  const int len = n1 - n0;
-  // slices the wave iterates over: the longest of its four chains (MW with uneven segments), else the common maximum
-  int tmax = A.Lmax;
-  if (MW && A.seg_long > 0) {
-    int m = len;
-    m = max(m, __shfl_xor(m, 4));
-    m = max(m, __shfl_xor(m, 8));
-    tmax = __builtin_amdgcn_readfirstlane(m);
-  }
+  int len, tmax;
+  // uneven segments (MW): the first S / 2 chains (waves 0 .. 3, the older wave of each SIMD) take `seg_long` slices each, the
+  // others share the rest; the wave iterates over the longest of its four chains
+  auto split_segments = [&](int seg_long) {
+    if (MW && seg_long > 0) {
+      const int h = A.S >> 1;
+      const long rest = (long)A.N - (long)h * seg_long;
+      n0 = seg < h ? seg * seg_long : h * seg_long + (int)(((long)(seg - h) * rest) / h);
+      n1 = seg + 1 <= h ? (seg + 1) * seg_long : h * seg_long + (int)(((long)(seg + 1 - h) * rest) / h);
+    }
+    len = n1 - n0;
+    tmax = A.Lmax;
+    if (MW && seg_long > 0) {
+      int m = len;
+      m = max(m, __shfl_xor(m, 4));
+      m = max(m, __shfl_xor(m, 8));
+      tmax = __builtin_amdgcn_readfirstlane(m);
+    }
+  };
+  split_segments(A.seg_long);
 
   // per-lane LDS offsets (doubles)
   const int woff = lp.b * IMG + lp.r * W + lp.c;
@@ -1225,6 +1228,18 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
       for (int k = 0; k < K; ++k) (void)seg_max(k, false);
       SD_TICK(tk9);
       __syncthreads();  // the tables of wave 0 are in place
+      // a sample on the COMPLEX loop has its own split (the two waves of a SIMD finish together at a different ratio there): the
+      // table flags are known only now, so its waves fetch their amplitudes a second time (~1 us of a 285 us kernel)
+      if (A.seg_long_c > 0 && A.seg_long_c != A.seg_long) {
+        bool re = (A.mode == C3P_MODE_UNITARY);
+        for (int k = 0; k <= K; ++k) re = re && (tab[k * (MAT + 4) + MAT + 3] == 0.0);
+        if (__builtin_amdgcn_readfirstlane((int)re) == 0) {
+          wave_sync();
+          split_segments(A.seg_long_c);
+          for (int k = 0; k < K; ++k) (void)seg_max(k, false);
+          wave_sync();
+        }
+      }
     }
     nrm = tab[MAT + 2];
     for (int k = 0; k < K; ++k) nrm = fma(seg_max(k, MW), tab[(k + 1) * (MAT + 4) + MAT + 2], nrm);
@@ -2262,17 +2277,24 @@ hipError_t launch_chain_t(const SmallArgs& A, hipStream_t st) {
         // (measured optimum 640 with the padded tiles, 660 with the core + border form of D = 5, 9, 700 with its border sums on the
         // matrix cores -- round 6: tools/sweep_split81.py, profiles/r06/sweep_skew.txt; one slice of the long segments moves the
         // two waves of a SIMD by 7 us against each other, so the optimum is sharp)
-        int skew = ((D == 9 || D == 5) && !c3p_opt_on(C3P_OPT_no_split81)) ? 700 : 640;
-        if (c3p_opt(C3P_OPT_mw_skew) >= 0) skew = (int)c3p_opt(C3P_OPT_mw_skew);
+        // (the complex loop of the same kernel keeps 640: profiles/r06/sweep_skew_complex.txt -- its samples re-split on the device)
+        int skew = ((D == 9 || D == 5) && !c3p_opt_on(C3P_OPT_no_split81)) ? 700 : 640, skew_c = 640;
+        if (c3p_opt(C3P_OPT_mw_skew) >= 0) skew = skew_c = (int)c3p_opt(C3P_OPT_mw_skew);
         if (skew > 500 && skew < 900) {
           const int h = A.S / 2;
-          int La = (int)(((long)A.N * skew) / (500L * A.S));  // = skew / 1000 of the 2 N / S slices of a pair of chains
-          if (La < 1) La = 1;
-          if ((long)h * La > A.N - h) La = (A.N - h) / h;  // at least one slice for every short chain
-          const long rest = (long)A.N - (long)h * La;
-          const int Lb = (int)((rest + h - 1) / h);
-          A2.seg_long = La;
-          A2.Lmax = La > Lb ? La : Lb;
+          int lmax = 0;
+          auto split = [&](int per_mille) {
+            int La = (int)(((long)A.N * per_mille) / (500L * A.S));  // = per_mille / 1000 of the 2 N / S slices of a pair of chains
+            if (La < 1) La = 1;
+            if ((long)h * La > A.N - h) La = (A.N - h) / h;  // at least one slice for every short chain
+            const long rest = (long)A.N - (long)h * La;
+            const int Lb = (int)((rest + h - 1) / h);
+            lmax = std::max(lmax, std::max(La, Lb));
+            return La;
+          };
+          A2.seg_long = split(skew);
+          A2.seg_long_c = (skew_c > 500 && skew_c < 900 && skew_c != skew) ? split(skew_c) : 0;
+          A2.Lmax = lmax;
         }
       }
       const size_t wstride2 = (size_t)(4 * C::IMG + 4 * ((A2.K * A2.Lmax) | 1));
