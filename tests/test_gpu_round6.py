@@ -199,3 +199,34 @@ def test_normal_generator_schemes_on_the_small_real_lindblad_kernel(prop, D):
         assert np.abs(got - mid).max() < 2e-12 and np.abs(got - old).max() < 2e-12, (D, dt)
         differ += int(np.abs(got - mid).max() > 0)
     assert differ >= 2  # the four-product scheme was taken at several of the norms
+
+
+@pytest.mark.parametrize("D,N,B", [(9, 1000, 256), (5, 640, 256), (9, 333, 64), (12, 1000, 256)])
+def test_mixed_batch_real_hermitian_and_lossy_samples_in_the_workgroup_per_sample_mode(prop, D, N, B):
+    """per-sample drift Hamiltonians of three kinds in ONE batch -- real symmetric (real loop, 700 per mille split), complex Hermitian
+    (complex loop with the normal-generator schemes and its own 640 per mille split: the sample re-splits on the device) and lossy
+    (non-Hermitian: published parameters) -- at the workgroup-per-sample shapes of cfg2: every kind against the oracle."""
+    import torch
+
+    from c3_amd import _lib
+    from oracle import c3_oracle
+
+    rng = np.random.default_rng(77 + D + N)
+    K = 2
+    sym = lambda s: (lambda m: s * (m + m.T) / 2)(rng.normal(size=(D, D)))
+    herm = lambda s: (lambda m: s * (m + m.conj().T) / 2)(rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))
+    base = np.diag(rng.uniform(0, 1, D)) + sym(0.05)
+    h0 = np.empty((B, D, D), dtype=complex)
+    for b in range(B):
+        kind = b % 3
+        h0[b] = base + (0 if kind == 0 else (herm(0.05) if kind == 1 else herm(0.05) - 0.02j * np.diag(np.arange(D))))
+    hks = np.stack([sym(0.3).astype(complex) for _ in range(K)])
+    sig = rng.uniform(-1, 1, size=(B, K, N))
+    dt = 0.9 / (np.abs(base).sum(axis=0).max() + 0.35 * D)
+    t = lambda a: torch.as_tensor(a, device="cuda:0")
+    U = prop.propagate_batch(t(h0), t(hks), t(sig), dt)["U"].cpu().numpy()
+    detail = _lib.last_kernel_detail()
+    assert "smalld_chain_kernel" in detail, detail
+    for b in (0, 1, 2, 3, 4, 5, B - 3, B - 2, B - 1):
+        ref = c3_oracle.propagate_batch(h0[b], hks, sig[b : b + 1], dt)[0]
+        assert np.linalg.norm(U[b] - ref) < 2e-11 * max(1.0, np.linalg.norm(ref)), (D, N, b, b % 3)
