@@ -1195,6 +1195,21 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
       nrm = fmax(nrm, __shfl_xor(nrm, 32));
     } else {
     // (MW: table k is built by wave k mod nwv; the barrier comes after the waves have fetched their control amplitudes)
+    // The waves that build a table issue the loads of their control amplitudes FIRST (K <= 2, segments up to 48 slices: six
+    // registers) -- both are the kernel's first, cold, global accesses and were serialised (4.0 + 1.0 us on wave 0 at cfg2)
+    constexpr int PF_K = 2, PF_T = 3;
+    const bool prefetch = MW && A.inline_tables && K <= PF_K && A.Lmax <= 16 * PF_T;
+    double pre[PF_K][PF_T];
+    if (prefetch) {
+#pragma unroll
+      for (int k = 0; k < PF_K; ++k)
+#pragma unroll
+        for (int i = 0; i < PF_T; ++i) {
+          const int t = lp.idx16 + 16 * i;
+          const double* sk = A.signals + ((long)sample * K + (k < K ? k : 0)) * A.N + n0;
+          pre[k][i] = (k < K && valid && t < len) ? sk[t] : 0.0;
+        }
+    }
     if (A.inline_tables) {
       build_tables<D>(A, __builtin_amdgcn_readfirstlane(sample), tab, lane, wv, nwv);
     } else {
@@ -1225,7 +1240,17 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
     };
     SD_TICK(tk8);
     if constexpr (MW) {
-      for (int k = 0; k < K; ++k) (void)seg_max(k, false);
+      if (prefetch) {
+#pragma unroll
+        for (int k = 0; k < PF_K; ++k)
+#pragma unroll
+          for (int i = 0; i < PF_T; ++i) {
+            const int t = lp.idx16 + 16 * i;
+            if (k < K && t < A.Lmax) sg[lp.b * SG + k * A.Lmax + t] = pre[k][i];
+          }
+      } else {
+        for (int k = 0; k < K; ++k) (void)seg_max(k, false);
+      }
       SD_TICK(tk9);
       __syncthreads();  // the tables of wave 0 are in place
       // a sample on the COMPLEX loop has its own split (the two waves of a SIMD finish together at a different ratio there): the
@@ -1247,12 +1272,22 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
     nrm = fmax(nrm, __shfl_xor(nrm, 4));
     nrm = fmax(nrm, __shfl_xor(nrm, 8));
     nrm = readfirstlane_f64(nrm);
-    // (round 6) Hermitian Hamiltonians -- every table flagged skew-Hermitian -- take T18 with the economised parameters (radius 2.0)
-    bool normalG = !XG && (A.mode == C3P_MODE_UNITARY) && !(A.no_t18n & 1);
+    // every table of this sample purely imaginary (real Hamiltonians) -> real fast path
+    bool realH = !XG && (A.mode == C3P_MODE_UNITARY);
     if constexpr (!XG)
-      for (int k = 0; k <= K; ++k) normalG = normalG && (tab[k * (MAT + 4) + MAT + 3] <= 0.0);  // negative: complex skew-Hermitian; zero: real symmetric Hamiltonian
-    const int t18n = __builtin_amdgcn_readfirstlane((int)normalG);
-    const MfmaPlan plan = c3p_pick_plan_mfma(nrm, t18n ? C3P_T18N_THETA : C3P_T18_THETA, t18n != 0 && !(A.no_t18n & 2));
+      for (int k = 0; k <= K; ++k) realH = realH && (tab[k * (MAT + 4) + MAT + 3] == 0.0);
+    realH = __builtin_amdgcn_readfirstlane((int)realH) != 0;
+    // plan of the complex loop (not evaluated on the real path: its threshold loops cost ~0.5 us of a workgroup's prologue).
+    // (round 6) Hermitian Hamiltonians -- every table flagged skew-Hermitian -- take the schemes for normal generators
+    MfmaPlan plan = {0, 0, 0};
+    int t18n = 0;
+    if (!realH) {
+      bool normalG = !XG && (A.mode == C3P_MODE_UNITARY) && !(A.no_t18n & 1);
+      if constexpr (!XG)
+        for (int k = 0; k <= K; ++k) normalG = normalG && (tab[k * (MAT + 4) + MAT + 3] <= 0.0);  // negative: complex skew-Hermitian; zero: real symmetric Hamiltonian
+      t18n = __builtin_amdgcn_readfirstlane((int)normalG);
+      plan = c3p_pick_plan_mfma(nrm, t18n ? C3P_T18N_THETA : C3P_T18_THETA, t18n != 0 && !(A.no_t18n & 2));
+    }
     const int pr = __builtin_amdgcn_readfirstlane(plan.r);
     const int ps = __builtin_amdgcn_readfirstlane(plan.s);
     const int t18 = __builtin_amdgcn_readfirstlane(plan.t18);
@@ -1260,11 +1295,6 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
     __syncthreads();
     SD_TICK(tk1);
 
-    // every table of this sample purely imaginary (real Hamiltonians) -> real fast path
-    bool realH = !XG && (A.mode == C3P_MODE_UNITARY);
-    if constexpr (!XG)
-      for (int k = 0; k <= K; ++k) realH = realH && (tab[k * (MAT + 4) + MAT + 3] == 0.0);
-    realH = __builtin_amdgcn_readfirstlane((int)realH) != 0;
     if (realH) {
       constexpr int NB = RD<D>::NB;
       typedef double RMat[NB][NB];
@@ -2038,7 +2068,9 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
       const int wq = seg >> 2;
       double sn, cs;
       sincos(ti, &sn, &cs);
-      const double er = exp(tr);
+      // (Hermitian Hamiltonians: the trace shifts are imaginary, tr = 0 exactly -- skip the double-precision exp of the fold)
+      double er = 1.0;
+      if (__ballot(tr != 0.0) != 0) er = exp(tr);
       const double* ph = A.fr_phase ? A.fr_phase + (long)sample * D : nullptr;
       if (nW == 1) {
         double* dst = reinterpret_cast<double*>(A.final_out) + (long)sample * D * D * 2;
