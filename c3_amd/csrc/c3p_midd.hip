@@ -1271,35 +1271,34 @@ __device__ __forceinline__ void midd_body(const MidArgs& A, const MidCommon& cm,
         //      P = (y1 + e7 A2 + e8 X)(y1 + e9 y0 + e10 X) + e11 y1 + e12 y0 + e13 A2 + e14 X + e15 I.  A3 holds y0, acc y1 ----
         constexpr const double (&ec)[16] = c3p_e4n;
         zero(A3);
-        zero(acc);
-        auto comb = [&](Regs& out, double c0, double cx, double c2, double c3, double c6) {
-#pragma unroll
-          for (int e = 0; e < NE; ++e) {
-            double v = cx * X.get(e);
-            v = fma(c2, A2.get(e), v);
-            v = fma(c3, A3.get(e), v);
-            v = fma(c6, acc.get(e), v);
-            v += (c0 != 0.0 && is_diag(e)) ? c0 : 0.0;
-            out.set(e, v);
-          }
-        };
         Regs T1, T2;
-        comb(T1, 0.0, ec[1], ec[0], 0.0, 0.0);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) T1.set(e, fma(ec[0], A2.get(e), ec[1] * X.get(e)));
         store_tiles(cm.buf2, T1);
         __syncthreads();
         product(cm.buf1, cm.buf2, A3);  // y0
-        comb(T1, 0.0, ec[3], ec[2], 1.0, 0.0);
-        comb(T2, 0.0, 0.0, ec[4], 1.0, 0.0);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          T1.set(e, fma(ec[2], A2.get(e), fma(ec[3], X.get(e), A3.get(e))));
+          T2.set(e, fma(ec[4], A2.get(e), A3.get(e)));
+        }
         __syncthreads();  // buf0 (X), buf2 no longer read
         store_tiles(cm.buf0, T1);
         store_tiles(cm.buf2, T2);
-        comb(T1, 0.0, 0.0, ec[6], ec[5], 0.0);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) acc.set(e, fma(ec[5], A3.get(e), ec[6] * A2.get(e)));
         __syncthreads();
-        product(cm.buf0, cm.buf2, T1);
-        acc = T1;  // y1
-        comb(T1, 0.0, ec[8], ec[7], 0.0, 1.0);
-        comb(T2, 0.0, ec[10], 0.0, ec[9], 1.0);
-        comb(P, ec[15], ec[14], ec[13], ec[12], ec[11]);
+        product(cm.buf0, cm.buf2, acc);  // y1
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          T1.set(e, fma(ec[7], A2.get(e), fma(ec[8], X.get(e), acc.get(e))));
+          T2.set(e, fma(ec[9], A3.get(e), fma(ec[10], X.get(e), acc.get(e))));
+          double v = fma(ec[11], acc.get(e), ec[12] * A3.get(e));
+          v = fma(ec[13], A2.get(e), v);
+          v = fma(ec[14], X.get(e), v);
+          v += is_diag(e) ? ec[15] : 0.0;
+          P.set(e, v);
+        }
         __syncthreads();
         store_tiles(cm.buf0, T1);
         store_tiles(cm.buf2, T2);

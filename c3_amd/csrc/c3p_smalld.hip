@@ -1897,29 +1897,55 @@ __global__ void __launch_bounds__((MW ? 512 : 64), 2) smalld_chain_kernel(SmallA
         // ---- four products (c3p_common.h, c3p_e4n): A2 above; y0 = A2 (e0 A2 + e1 X);
         //      y1 = (y0 + e2 A2 + e3 X)(y0 + e4 A2) + e5 y0 + e6 A2;
         //      P = (y1 + e7 A2 + e8 X)(y1 + e9 y0 + e10 X) + e11 y1 + e12 y0 + e13 A2 + e14 X + e15 I ----
-        // (lincomb6(out, c0, cx, c2, c3, c6, X, A2, M3, M6) = c0 I + cx X + c2 A2 + c3 M3 + c6 M6, here with M3 = y0, M6 = y1;
-        //  A3 holds y0)
+        // (A3 holds y0)
+        // (element loops with exactly the terms of each combination: 15 vector operations per element and slice)
         double y1[NBI][NJ];
         {
           double R[NBI][NJ];
-          lincomb6<D>(R, 0.0, c3p_e4n[1], c3p_e4n[0], 0.0, 0.0, X, A2, A2, A2, ddelta, rhalf);
+#pragma unroll
+          for (int I = 0; I < NBI; ++I)
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) R[I][J] = fma(c3p_e4n[0], A2[I][J], c3p_e4n[1] * X[I][J]);
           write_image<D>(A2, img, woff);
           mm_img<D>(img, roff, negmask, R, A3);
         }
         {
           double L[NBI][NJ], R[NBI][NJ];
-          lincomb6<D>(L, 0.0, c3p_e4n[3], c3p_e4n[2], 1.0, 0.0, X, A2, A3, A3, ddelta, rhalf);
+#pragma unroll
+          for (int I = 0; I < NBI; ++I)
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) L[I][J] = fma(c3p_e4n[2], A2[I][J], fma(c3p_e4n[3], X[I][J], A3[I][J]));
           write_image<D>(L, img, woff);
-          lincomb6<D>(R, 0.0, 0.0, c3p_e4n[4], 1.0, 0.0, X, A2, A3, A3, ddelta, rhalf);
-          lincomb6<D>(y1, 0.0, 0.0, c3p_e4n[6], c3p_e4n[5], 0.0, X, A2, A3, A3, ddelta, rhalf);
+#pragma unroll
+          for (int I = 0; I < NBI; ++I)
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) {
+              R[I][J] = fma(c3p_e4n[4], A2[I][J], A3[I][J]);
+              y1[I][J] = fma(c3p_e4n[5], A3[I][J], c3p_e4n[6] * A2[I][J]);
+            }
           mm_img<D>(img, roff, negmask, R, y1);
         }
         {
           double L[NBI][NJ], R[NBI][NJ];
-          lincomb6<D>(L, 0.0, c3p_e4n[8], c3p_e4n[7], 0.0, 1.0, X, A2, A3, y1, ddelta, rhalf);
+#pragma unroll
+          for (int I = 0; I < NBI; ++I)
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) L[I][J] = fma(c3p_e4n[7], A2[I][J], fma(c3p_e4n[8], X[I][J], y1[I][J]));
           write_image<D>(L, img, woff);
-          lincomb6<D>(R, 0.0, c3p_e4n[10], 0.0, c3p_e4n[9], 1.0, X, A2, A3, y1, ddelta, rhalf);
-          lincomb6<D>(P, c3p_e4n[15], c3p_e4n[14], c3p_e4n[13], c3p_e4n[12], c3p_e4n[11], X, A2, A3, y1, ddelta, rhalf);
+#pragma unroll
+          for (int I = 0; I < NBI; ++I)
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) {
+              R[I][J] = fma(c3p_e4n[9], A3[I][J], fma(c3p_e4n[10], X[I][J], y1[I][J]));
+              double v = fma(c3p_e4n[11], y1[I][J], c3p_e4n[12] * A3[I][J]);
+              v = fma(c3p_e4n[13], A2[I][J], v);
+              v = fma(c3p_e4n[14], X[I][J], v);
+              if (2 * I - 4 * J >= -1 && 2 * I - 4 * J <= 3) {  // the real diagonal of the half image: + e15 I  (as lincomb6)
+                const bool on = (ddelta == 4 * J - 2 * I) && (2 * I + rhalf < D);
+                v += on ? c3p_e4n[15] : 0.0;
+              }
+              P[I][J] = v;
+            }
           mm_img<D>(img, roff, negmask, R, P);
         }
       } else {

@@ -333,28 +333,47 @@ __global__ void __launch_bounds__(64) smallr_chain_kernel(SmallRArgs A) {
       // exp = (y1 + e7 A2 + e8 X)(y1 + e9 y0 + e10 X) + e11 y1 + e12 y0 + e13 A2 + e14 X + e15 I   (A3 holds y0, A6 y1)
       {
         RMat R;
-        comb(R, 0.0, c3p_e4n[1], c3p_e4n[0], 0.0, 0.0, X, A2, A3, A6);
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+          for (int J = 0; J < NB; ++J) R[I][J] = fma(c3p_e4n[0], A2[I][J], c3p_e4n[1] * X[I][J]);
         to_image(A2);
         mm(R, A3);
       }
       {
         RMat L, R;
-        comb(L, 0.0, c3p_e4n[3], c3p_e4n[2], 1.0, 0.0, X, A2, A3, A6);
-        to_image(L);
-        comb(R, 0.0, 0.0, c3p_e4n[4], 1.0, 0.0, X, A2, A3, A6);
-        comb(L, 0.0, 0.0, c3p_e4n[6], c3p_e4n[5], 0.0, X, A2, A3, A6);
-        mm(R, L);
 #pragma unroll
         for (int I = 0; I < NB; ++I)
 #pragma unroll
-          for (int J = 0; J < NB; ++J) A6[I][J] = L[I][J];
+          for (int J = 0; J < NB; ++J) L[I][J] = fma(c3p_e4n[2], A2[I][J], fma(c3p_e4n[3], X[I][J], A3[I][J]));
+        to_image(L);
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+          for (int J = 0; J < NB; ++J) {
+            R[I][J] = fma(c3p_e4n[4], A2[I][J], A3[I][J]);
+            A6[I][J] = fma(c3p_e4n[5], A3[I][J], c3p_e4n[6] * A2[I][J]);
+          }
+        mm(R, A6);
       }
       {
         RMat L, R;
-        comb(L, 0.0, c3p_e4n[8], c3p_e4n[7], 0.0, 1.0, X, A2, A3, A6);
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+          for (int J = 0; J < NB; ++J) L[I][J] = fma(c3p_e4n[7], A2[I][J], fma(c3p_e4n[8], X[I][J], A6[I][J]));
         to_image(L);
-        comb(R, 0.0, c3p_e4n[10], 0.0, c3p_e4n[9], 1.0, X, A2, A3, A6);
-        comb(P, c3p_e4n[15], c3p_e4n[14], c3p_e4n[13], c3p_e4n[12], c3p_e4n[11], X, A2, A3, A6);
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+          for (int J = 0; J < NB; ++J) {
+            R[I][J] = fma(c3p_e4n[9], A3[I][J], fma(c3p_e4n[10], X[I][J], A6[I][J]));
+            double v = fma(c3p_e4n[11], A6[I][J], c3p_e4n[12] * A3[I][J]);
+            v = fma(c3p_e4n[13], A2[I][J], v);
+            v = fma(c3p_e4n[14], X[I][J], v);
+            if (I == J) v += (r == c && 4 * I + r < DM) ? c3p_e4n[15] : 0.0;
+            P[I][J] = v;
+          }
         mm(R, P);
       }
     } else {
