@@ -230,3 +230,14 @@ def test_mixed_batch_real_hermitian_and_lossy_samples_in_the_workgroup_per_sampl
     for b in (0, 1, 2, 3, 4, 5, B - 3, B - 2, B - 1):
         ref = c3_oracle.propagate_batch(h0[b], hks, sig[b : b + 1], dt)[0]
         assert np.linalg.norm(U[b] - ref) < 2e-11 * max(1.0, np.linalg.norm(ref)), (D, N, b, b % 3)
+
+
+def test_evaluation_schemes_fuzz_short_run():
+    """tools/fuzz_r06.py for a few seconds (the 200-second run of the round: 61 k unitary and 15 k Lindblad cases, 19 k of them against
+    scipy / the oracle, worst 1.6e-12 between the schemes: profiles/r06/fuzz_r06.txt)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_r06.py"), "--seconds", "8", "--seed", "11"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
