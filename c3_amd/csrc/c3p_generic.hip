@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256) chain_kernel(ChainArgs A) {
           tr += d.x;
           ti += d.y;
         }
-        red_mu = make_double2(tr / Dm, ti / Dm);
+        red_mu = make_double2(0.0, ti / Dm);  // imaginary shift only (c3p_smalld.hip: build_tables)
       }
       __syncthreads();
       const cplx mu = red_mu;
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(64) hmeta_kernel(const cplx* hs, long bstride,
       a += rr[i];
       c += ri[i];
     }
-    mu[0] = a / D;
+    mu[0] = 0.0;  // imaginary shift only (c3p_smalld.hip: build_tables)
     mu[1] = c / D;
   }
   __syncthreads();
@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(256) hmeta_small_kernel(const cplx* hs, long b
     tr += __shfl_xor(tr, o);
     ti += __shfl_xor(ti, o);
   }
-  const double mur = tr / D, mui = ti / D;
+  const double mur = 0.0, mui = ti / D;  // imaginary shift only (c3p_smalld.hip: build_tables)
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   double cs = 0.0;

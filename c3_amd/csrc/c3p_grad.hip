@@ -267,7 +267,7 @@ __device__ void assemble(const GMem<GLOBAL>& M, const GradArgs& A, Shared& sh, i
       tr += v.x;
       ti += v.y;
     }
-    sh.mu[0] = tr / D;
+    sh.mu[0] = 0.0;  // imaginary shift only (c3p_smalld.hip: build_tables)
     sh.mu[1] = ti / D;
   }
   __syncthreads();

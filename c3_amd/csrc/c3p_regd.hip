@@ -784,7 +784,7 @@ __global__ void __launch_bounds__(256) regd_prep_kernel(RegdPrepArgs P) {
       a += redr[i];
       bq += redi[i];
     }
-    mu[0] = a / D;
+    mu[0] = 0.0;  // imaginary shift only: a real one overflows the shifted product of long, strongly damped segments (c3p_smalld.hip: build_tables)
     mu[1] = bq / D;
   }
   __syncthreads();

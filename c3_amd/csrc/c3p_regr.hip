@@ -729,7 +729,9 @@ __global__ void __launch_bounds__(256) regr_prep_kernel(RegdPrepArgs P, double* 
   if (tid == 0) {
     double a = 0;
     for (int i = 0; i < 256; ++i) a += red0[i];
-    mu_s = a / D;
+    // (round 6) NO shift in the real kernels: the trace of the real generator is the dissipator's, and shifting by it makes the
+    // shifted chain product grow like e^{|mu| n} while e^{sum mu} underflows (c3p_smalld.hip: build_tables)
+    mu_s = 0.0 * a;
   }
   __syncthreads();
   const double mu = mu_s;

@@ -1005,7 +1005,9 @@ __device__ __forceinline__ void build_tables(const SmallArgs& A, int sample, dou
         }
       }
     }
-    const double mur = wave_sum64(tr) / D, mui = wave_sum64(tim) / D;
+    // (round 6) the shift is IMAGINARY only: a real shift (lossy Hamiltonians) makes the shifted chain product grow like
+    // e^{|Re mu| n} while e^{sum mu} underflows -- inf * 0 over a long segment (tools/fuzz_r06.py found it on the Lindblad tables)
+    const double mur = 0.0 * wave_sum64(tr), mui = wave_sum64(tim) / D;
     wave_sync();
     double remax = 0.0;
 #pragma unroll
@@ -2256,7 +2258,7 @@ __global__ void __launch_bounds__(64) smalld_prep_kernel(PrepArgs P) {
       tr += g[2 * (i * D + i)];
       ti2 += g[2 * (i * D + i) + 1];
     }
-    mu[0] = tr / D;
+    mu[0] = 0.0;  // imaginary shift only (see build_tables)
     mu[1] = ti2 / D;
   }
   __syncthreads();

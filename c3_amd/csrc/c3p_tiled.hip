@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(256) tg_meta_kernel(TabArgs P) {
     }
     __syncthreads();
   }
-  const double mur = r1[0] / P.Dm, mui = r2[0] / P.Dm;
+  const double mur = 0.0, mui = r2[0] / P.Dm;  // imaginary shift only (c3p_smalld.hip: build_tables)
   __syncthreads();
   double cs = 0.0;
   for (int j = tid; j < P.Dm; j += 256) {
