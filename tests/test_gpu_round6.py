@@ -269,3 +269,14 @@ def test_long_strongly_damped_segments_stay_finite(prop, D, forced):
         ref = c3_oracle.propagate_batch(h0, hks, sig[:1], dt, col_ops=col, lindbladian=True)[0]
         # (the oracle's own accuracy at these generator norms is ~1e-9: DESIGN 8)
         assert np.linalg.norm(U[0] - ref) < 1e-8 * max(1.0, np.linalg.norm(ref))
+
+
+def test_backward_sweeps_fuzz_short_run():
+    """tools/fuzz_r06_grad.py for a few seconds (the 100-second run of the round: 120 k cases, every gradient through two different
+    kernels <= 8.4e-12 relative, 45 k finite-difference entries <= 1.7e-8: profiles/r06/fuzz_r06.txt)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_r06_grad.py"), "--seconds", "8", "--seed", "13"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
