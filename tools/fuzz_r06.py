@@ -5,7 +5,8 @@ slice or against the oracle.
 Dimensions 2..40 (small-D and mid-D kernels), drift / control operators real symmetric, complex Hermitian, mixed or lossy
 (non-Hermitian), shared or per sample, 1..4 control lines, generator norms from 0.05 to 12 (every plan, 0..3 squarings), batch
 and slice counts on both sides of the workgroup-per-sample mode, frame phases; Lindblad chains at D = 2..4 with weak and strong
-dissipators (the symmetric-part guard of the real Hermitian-basis kernels).
+dissipators (the symmetric-part guard of the real Hermitian-basis kernels).  Every third case also asks for the partial propagators
+(equal between the schemes; their ordered product is U), every sixth repeats the chain from per-slice Hamiltonians (branch B of pwc).
     python tools/fuzz_r06.py --seconds 120 --seed 1"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -64,9 +65,31 @@ while time.time() < t_end:
         kw = dict(col_ops=np.stack([cs * (rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D)))]), lindbladian=True)
     if ph is not None:
         kw["fr_phase"] = ph
-    got = np.asarray(prop.propagate_batch(h0, hks, sig, dt, **kw)["U"])
+    want_dus = (it % 3 == 1) and B * N * (D ** (4 if lind else 2)) <= 2e6 and not (lind and D <= 4 and str(kinds) != "lossy")
+    r0 = prop.propagate_batch(h0, hks, sig, dt, want_dUs=want_dus, **kw)
+    got = np.asarray(r0["U"])
     with _lib.options(no_t18n=1):
-        ref = np.asarray(prop.propagate_batch(h0, hks, sig, dt, **kw)["U"])
+        r1 = prop.propagate_batch(h0, hks, sig, dt, want_dUs=want_dus, **kw)
+        ref = np.asarray(r1["U"])
+    if want_dus:
+        # the partial propagators: equal between the schemes, and their ordered product (later slice on the left) is U
+        d0, d1 = np.asarray(r0["dUs"]), np.asarray(r1["dUs"])
+        assert np.abs(d0 - d1).max() < 2e-12 * max(1.0, np.abs(d1).max()), ("dUs disagree", D, K, B, N, str(kinds), target, lind)
+        for b in range(min(B, 3)):
+            P = np.eye(d0.shape[-1], dtype=complex)
+            for t in range(N):
+                P = d0[b, t] @ P
+            if ph is not None:
+                P = np.exp(1j * ph[b])[:, None] * P
+            assert np.abs(P - got[b]).max() < 3e-12 * max(1.0, np.abs(got[b]).max()) * max(1.0, np.sqrt(N / 100.0)), ("prod dUs != U", D, K, B, N, str(kinds), target, lind)
+        n["dUs"] = n.get("dUs", 0) + 1
+    if it % 6 == 2 and not per_sample and B * N * D * D <= 2e6 and (not lind or D <= 6):
+        # branch B of pwc: the per-slice Hamiltonians assembled on the host, same chain
+        hs = h0[None, None] + np.einsum("bkn,kij->bnij", sig, hks)
+        kb = {k: v for k, v in kw.items()}
+        rb = np.asarray(prop.propagate_batch(hs, None, None, dt, **kb)["U"])
+        assert np.abs(rb - got).max() < 3e-12 * max(1.0, np.abs(got).max()) * max(1.0, np.sqrt(N / 100.0)), ("per-slice H != tables", D, K, B, N, str(kinds), target, lind)
+        n["per_slice"] = n.get("per_slice", 0) + 1
     scale = max(1.0, np.abs(ref).max())
     d = np.abs(got - ref).max() / scale
     worst["ab"] = max(worst["ab"], d)
