@@ -722,17 +722,9 @@ __global__ void __launch_bounds__(256) regr_prep_kernel(RegdPrepArgs P, double* 
       for (int y = 0; y < nb; ++y) cfma(s, cmul(ta[x], cconj(tb[y])), gelem(ia[x], ib[y]));
     return s;
   };
-  double tr = 0;
-  for (int i = tid; i < D; i += 256) tr += gelem(i, i).x;  // the trace is invariant
-  red0[tid] = tr;
-  __syncthreads();
-  if (tid == 0) {
-    double a = 0;
-    for (int i = 0; i < 256; ++i) a += red0[i];
-    // (round 6) NO shift in the real kernels: the trace of the real generator is the dissipator's, and shifting by it makes the
-    // shifted chain product grow like e^{|mu| n} while e^{sum mu} underflows (c3p_smalld.hip: build_tables)
-    mu_s = 0.0 * a;
-  }
+  // (round 6) NO trace shift in the real kernels: the trace of the real generator is the dissipator's, and shifting by it makes the
+  // shifted chain product grow like e^{|mu| n} while e^{sum mu} underflows (c3p_smalld.hip: build_tables).  The table slot stays.
+  if (tid == 0) mu_s = 0.0;
   __syncthreads();
   const double mu = mu_s;
   double cs = 0, mre = 0, mim = 0, csym = 0;

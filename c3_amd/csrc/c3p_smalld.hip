@@ -990,7 +990,7 @@ __device__ __forceinline__ void build_tables(const SmallArgs& A, int sample, dou
                               : A.hks + (long)sample * A.hks_bstride + (long)(ti - 1) * D * D;
     for (int e = lane; e < MAT; e += 64) out[e] = 0.0;
     double gr[NE], gi[NE];
-    double tr = 0.0, tim = 0.0;
+    double tim = 0.0;
 #pragma unroll
     for (int q = 0; q < NE; ++q) {
       const int e = lane + 64 * q;
@@ -999,15 +999,12 @@ __device__ __forceinline__ void build_tables(const SmallArgs& A, int sample, dou
         const cplx x = h[e];
         gr[q] = x.y * A.dt;  // -i dt h
         gi[q] = -x.x * A.dt;
-        if (e / D == e % D) {
-          tr += gr[q];
-          tim += gi[q];
-        }
+        if (e / D == e % D) tim += gi[q];
       }
     }
     // (round 6) the shift is IMAGINARY only: a real shift (lossy Hamiltonians) makes the shifted chain product grow like
     // e^{|Re mu| n} while e^{sum mu} underflows -- inf * 0 over a long segment (tools/fuzz_r06.py found it on the Lindblad tables)
-    const double mur = 0.0 * wave_sum64(tr), mui = wave_sum64(tim) / D;
+    const double mur = 0.0, mui = wave_sum64(tim) / D;
     wave_sync();
     double remax = 0.0;
 #pragma unroll
