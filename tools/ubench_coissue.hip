@@ -2,6 +2,7 @@
 // NM x v_mfma_f64_4x4x4_4b + NO x "other" instruction per iteration, 2 waves per SIMD (8 per CU), independent chains.
 // other = 0: v_fma_f64, 1: v_mov_b32 dpp (quad_perm), 2: v_xor_b32 (integer), 3: v_add_f64, 4: ds_bpermute_b32, 5: v_cndmask/v_mov pair (v_mov_b32)
 // Printed: cycles per iteration per SIMD at 2.4 GHz next to the serial sum NM*16 + NO*4 (x2 waves) and the max of the two.
+// build + run:  hipcc --offload-arch=gfx950 -O3 tools/ubench_coissue.hip -o tools/probe/ubench_coissue && tools/probe/ubench_coissue
 #include <hip/hip_runtime.h>
 #include <cstdio>
 

@@ -1,5 +1,6 @@
 // Micro-benchmark (round 6): issue cost of the fp64 vector instructions the small-D kernels use, 2 waves per SIMD, 32 independent chains per wave
 // (cycles per wave instruction on one SIMD at 2.4 GHz; v_mfma_f64_4x4x4_4b measured the same way for the clock reference)
+// build + run:  hipcc --offload-arch=gfx950 -O3 tools/ubench_valu64.hip -o tools/probe/ubench_valu64 && tools/probe/ubench_valu64
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
