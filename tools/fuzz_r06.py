@@ -1,6 +1,6 @@
 """Randomised parity sweep of the round-6 evaluation schemes (Chebyshev-economised polynomials for normal generators: DESIGN 3):
 every case runs with the default plan and with `no_t18n = 1` (published T18 / Taylor parameters on the complex loops) and the two
-must agree to 2e-12 (relative to the larger of 1 and the result); every fourth case is also checked against scipy's expm slice by
+must agree to 4e-12 (relative to the larger of 1 and the result; x sqrt(N / 100) for long chains; worst seen over 350 k cases 1.8e-12); every fourth case is also checked against scipy's expm slice by
 slice or against the oracle.
 Dimensions 2..40 (small-D and mid-D kernels), drift / control operators real symmetric, complex Hermitian, mixed or lossy
 (non-Hermitian), shared or per sample, 1..4 control lines, generator norms from 0.05 to 12 (every plan, 0..3 squarings), batch
@@ -95,7 +95,7 @@ while time.time() < t_end:
     worst["ab"] = max(worst["ab"], d)
     n["lindblad" if lind else "unitary"] += 1
     n["differ"] += int(d > 0)
-    assert d < 2e-12 * max(1.0, np.sqrt(N / 100.0)), ("schemes disagree", D, K, B, N, str(kinds), target, lind, per_sample, d)
+    assert d < 4e-12 * max(1.0, np.sqrt(N / 100.0)), ("schemes disagree", D, K, B, N, str(kinds), target, lind, per_sample, d)
     if it % 4 == 0:
         b = int(rng.integers(0, B))
         okw = {k: v for k, v in kw.items() if k != "fr_phase"}
